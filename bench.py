@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec for forward + BPTT + update of one LstmProjectedStreams layer
+(40 -> cell 800 / proj 512), BASELINE.json's metric.
+
+A "step" is one BPTT minibatch: Reset (at utterance starts) -> Propagate -> Backpropagate ->
+Update over T=20 frames x S streams (bd-nnet-train-lstm-streams.cc:209-228), on synthetic
+1000-frame utterances that are already resident in HBM.  N=1 runs BASELINE.json configs[1]
+(NumStream=4).  N>1 shards independent streams over ranks (S per GPU fixed -> weak scaling) with
+ONE all-reduce of the gradient blob per minibatch (torch.distributed nccl = RCCL).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+I_DIM, C_DIM, R_DIM, T_BPTT, UTT_LEN = 40, 800, 512, 20, 1000
+LR, MOMENTUM, PARAM_SCALE = 1e-5, 0.9, 0.01          # train_lstm_streams.sh:3-4, nnet.proto:3
+FLOPS_PER_FRAME = 6 * (4 * C_DIM * I_DIM + 4 * C_DIM * R_DIM + R_DIM * C_DIM)   # 13 056 000
+PEAK_F32_MFMA_TF = 157.3                              # MI355X_MICROARCH.md: f32-input MFMA
+
+
+def make_inputs(S, seed, device):
+    """One 1000-frame utterance per stream, N(0,1) features, laid out as 50 time-major
+    minibatches [T*S, I]; out_diff ~ N(0, 1e-2) stands in for the (absent) output layers."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    nchunk = UTT_LEN // T_BPTT
+    feats = torch.randn(nchunk, T_BPTT * S, I_DIM, generator=g)
+    odiff = 0.1 * torch.randn(nchunk, T_BPTT * S, R_DIM, generator=g)
+    return feats.to(device), odiff.to(device)
+
+
+def kernel_flops(name, S):
+    return {"k_gates_step": 2.0 * S * 4 * C_DIM * R_DIM, "k_proj_step": 2.0 * S * R_DIM * C_DIM,
+            "k_dr_step": 2.0 * S * 4 * C_DIM * R_DIM, "k_dm_step": 2.0 * S * R_DIM * C_DIM}[name]
+
+
+def cpu_baseline(S, budget_s):
+    """The oracle (reference op sequence, un-fused, 1 thread) timed on this host on a bounded
+    sample of the same workload."""
+    from oracle.oracle import Oracle, make_params
+    o = Oracle(I_DIM, C_DIM, R_DIM, S, np.float32, threads=1)
+    o.set_params(make_params(I_DIM, C_DIM, R_DIM, scale=PARAM_SCALE, seed=7))
+    rng = np.random.RandomState(0)
+    x = rng.randn(T_BPTT * S, I_DIM).astype(np.float32)
+    od = (0.1 * rng.randn(T_BPTT * S, R_DIM)).astype(np.float32)
+    o.propagate(x); o.backpropagate(x, od, MOMENTUM); o.update(LR)      # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.propagate(x); o.backpropagate(x, od, MOMENTUM); o.update(LR)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s and n >= 3:
+            break
+    return {"value": n * T_BPTT * S / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} minibatches of {T_BPTT}x{S} frames ({dt:.1f} s), oracle/lstmp_oracle.c fp32, "
+                      f"1 thread of {os.cpu_count()} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--streams-per-gpu", type=int, default=4)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import kaldi_lstm_amd as k
+    from oracle.oracle import make_params          # host-side parameter init only (never timed)
+    S = args.streams_per_gpu
+    stream = torch.cuda.Stream()
+    eng = k.Engine(I_DIM, C_DIM, R_DIM, S, device=local_rank, stream=stream)
+    eng.set_params(make_params(I_DIM, C_DIM, R_DIM, scale=PARAM_SCALE, seed=7))   # identical on all ranks
+    feats, odiff = make_inputs(S, 1234 + rank, "cuda")
+    nchunk = feats.shape[0]
+    out = torch.empty(T_BPTT * S, R_DIM, device="cuda")
+    in_diff = torch.empty(T_BPTT * S, I_DIM, device="cuda")
+    ones = np.ones(S, np.int32)
+    gblob = eng.grad_blob_tensor() if world > 1 else None
+    torch.cuda.synchronize()
+
+    def step(i):
+        c = i % nchunk
+        if c == 0:
+            eng.reset(ones)                         # new utterances on every stream (lock-step)
+        eng.propagate(feats[c], out)
+        if world > 1:
+            eng.backpropagate(feats[c], odiff[c], in_diff, MOMENTUM, k.DEFER_MOMENTUM)
+            dist.all_reduce(gblob)                  # sum, fp32, one contiguous 8.73 MB blob
+            eng.apply_momentum(MOMENTUM)
+        else:
+            eng.backpropagate(feats[c], odiff[c], in_diff, MOMENTUM)
+        eng.update(LR)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for i in range(args.warmup):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):
+            step(i)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+
+        # ---- roofline leg: per-kernel device time from HIP start/stop events on the engine stream
+        eng.set_option("profile", 1)
+        for i in range(3):
+            step(args.warmup + args.steps + i)
+        kern = {}
+        for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_gemm_xproj", "k_gemm_indiff",
+                     "k_gemm_dwx", "k_gemm_dwr", "k_gemm_dwm", "k_vec_grads", "k_update", "k_transpose",
+                     "k_begin", "k_end", "k_apply_momentum"):
+            tot, n = eng.profile_query(name)
+            if n:
+                kern[name] = {"avg_us": tot / n, "launches_per_step": n / 3.0, "us_per_step": tot / 3.0}
+        eng.set_option("profile", 0)
+
+    frames = args.steps * T_BPTT * S * world
+    value = frames / dt
+    res = None
+    if rank == 0:
+        dom = max((n for n in kern if n in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step")),
+                  key=lambda n: kern[n]["us_per_step"])
+        ach = kernel_flops(dom, S) / (kern[dom]["avg_us"] * 1e-6) / 1e12
+        res = {
+            "metric": "frames/sec fwd+BPTT, 40in/800cell/512proj LSTM at 1/2/4/8 MI355X",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "google/ LstmProjectedStreams 40->cell800/proj512, NumStream=%d per GPU, "
+                                   "T_bptt=20, 1000-frame synthetic utterances, fwd+BPTT+update "
+                                   "(BASELINE.json configs[1])" % S,
+                       "streams_per_gpu": S, "total_streams": S * world, "bptt": T_BPTT,
+                       "frames_per_step": T_BPTT * S * world,
+                       "parallelism": "dp%d over streams, 1 all-reduce/minibatch" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_F32_MFMA_TF, "traffic": None,
+                         "avg_us": kern[dom]["avg_us"], "flops_per_launch": kernel_flops(dom, S)},
+            "whole_path_tflops": value * FLOPS_PER_FRAME / 1e12 / world,
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(S, args.cpu_seconds)
+        print(json.dumps(res))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/*
+ * include/klstm.h -- C-ABI of the MI355X-native LstmProjectedStreams engine.
+ *
+ * This is the drop-in boundary for ONE path of dophist/kaldi-lstm: the multi-stream LSTMP
+ * forward + truncated BPTT + SGD update of
+ *     google/nnet/bd-nnet-lstm-projected-streams.h   (class LstmProjectedStreams)
+ * It replaces, for that component only, the google/cudamatrix (CuMatrix + cuBLAS +
+ * bd-cu-kernels.cu) layer the reference component calls into.  A Kaldi Component that
+ * forwards its virtuals to these entry points is shown in INTEGRATION.md; the C++ mirror of
+ * the reference class lives in include/klstm_component.hpp.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no exceptions cross this boundary.  Every call
+ *     returns a klstm_status; klstm_last_error() gives the message of the calling thread's
+ *     last failure (the adapter maps non-zero to KALDI_ERR, i.e. std::runtime_error, which is
+ *     how the reference reports CU_SAFE_CALL failures, cu-matrix.cc:813).
+ *   - all matrices are fp32 (Kaldi BaseFloat), row-major with an explicit row stride in
+ *     ELEMENTS (CuMatrixBase::Stride(), cu-matrix.h:479-489: rows are pitched, always honour
+ *     the stride).  Minibatch matrices are time-major: row = t*num_stream + s
+ *     (bd-nnet-train-lstm-streams.cc:191-199; ...streams.h:263-272).
+ *   - `in`, `out`, `out_diff`, `in_diff` are DEVICE pointers owned and pre-sized by the caller
+ *     (Nnet owns them in Kaldi); the engine owns parameters, gradient/momentum buffers, the
+ *     carried stream state and the activation slabs (...streams.h:577-620).
+ *   - one engine = one GPU = one HIP stream; calls on one handle must be host-serialised
+ *     (the reference is single-threaded, bd-nnet-train-lstm-streams.cc:93).  All calls are
+ *     asynchronous on the engine's stream except the *_host copies and klstm_synchronize.
+ *   - the flat parameter/gradient blob order is GetParams order (...streams.h:162-189):
+ *       w_gifo_x [4C x I] | w_gifo_r [4C x R] | bias [4C] | peephole_i_c [C] |
+ *       peephole_f_c [C] | peephole_o_c [C] | w_r_m [R x C]      (4C rows ordered g,i,f,o)
+ */
+#ifndef KLSTM_H_
+#define KLSTM_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct klstm_engine klstm_engine;
+
+typedef enum {
+  KLSTM_OK = 0,
+  KLSTM_ERR_ARG = 1,    /* bad argument (null pointer, negative size)                     */
+  KLSTM_ERR_SHAPE = 2,  /* KALDI_ASSERT-class violation: rows % num_stream != 0 (:225),
+                           reset flag count != num_stream (:214), bwd rows != fwd rows     */
+  KLSTM_ERR_STATE = 3,  /* call order violated (backpropagate without propagate)           */
+  KLSTM_ERR_HIP = 4,    /* a HIP runtime call failed                                       */
+  KLSTM_ERR_NOGPU = 5   /* no usable gfx950 device: there is NO CPU fallback               */
+} klstm_status;
+
+/* flags for klstm_backpropagate */
+#define KLSTM_BPTT_DEFAULT        0
+/* data-parallel mode: leave the pure local gradient (beta = 0) in the gradient blob and do
+ * NOT touch the momentum buffers; the caller all-reduces klstm_grad_blob() and then calls
+ * klstm_apply_momentum().  (The reference folds momentum into the gradient GEMM's beta,
+ * ...streams.h:465-487, which would multiply momentum by the number of ranks.) */
+#define KLSTM_BPTT_DEFER_MOMENTUM 1
+
+/* Message of the calling thread's most recent failing call ("" if none). */
+const char *klstm_last_error(void);
+/* Library / kernel-arch identification string, e.g. "klstm 0.1 gfx950". */
+const char *klstm_version(void);
+
+/* Replaces: LstmProjectedStreams(input_dim, output_dim) + <CellDim>/<NumStream> of
+ * InitData/ReadData (...streams.h:27-33, :55-99, :101-131).  recur_dim == output_dim.
+ * Parameters start at zero, momentum buffers and stream state at zero (kSetZero, :76-97).
+ * device: HIP device ordinal.  hip_stream: a hipStream_t to run on (e.g. the caller
+ * framework's current stream) or NULL to let the engine create its own. */
+klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_stream,
+                          int device, void *hip_stream, klstm_engine **out);
+void klstm_destroy(klstm_engine *e);
+
+/* dims / NumParams (...streams.h:152-160) */
+int klstm_input_dim(const klstm_engine *e);
+int klstm_cell_dim(const klstm_engine *e);
+int klstm_recur_dim(const klstm_engine *e);
+int klstm_num_stream(const klstm_engine *e);
+long klstm_num_params(const klstm_engine *e);
+
+/* Parameter / momentum / gradient blobs, flat GetParams order.  *_host variants take host
+ * pointers and synchronise; the device variants are stream-ordered.
+ * Replaces ReadData's tensor loads (:109-117), GetParams (:162-189) and the *_corr_ members
+ * that InfoGradient inspects (:201-210). */
+klstm_status klstm_set_params_host(klstm_engine *e, const float *flat);
+klstm_status klstm_get_params_host(klstm_engine *e, float *flat);
+klstm_status klstm_set_params_device(klstm_engine *e, const float *flat_dev);
+klstm_status klstm_get_corr_host(klstm_engine *e, float *flat);   /* momentum buffers *_corr_ */
+klstm_status klstm_set_corr_host(klstm_engine *e, const float *flat);
+klstm_status klstm_get_grads_host(klstm_engine *e, float *flat);  /* pure gradient (DP mode) */
+/* Device address of the contiguous gradient blob (num_params floats) for an in-place
+ * all-reduce (RCCL ncclAllReduce / torch.distributed.all_reduce) in DP mode. */
+float *klstm_grad_blob(klstm_engine *e);
+float *klstm_param_blob(klstm_engine *e);
+
+/* Reset (...streams.h:212-220): for every s with flags[s] == 1 zero stream s's carried
+ * state.  n must equal num_stream (KALDI_ASSERT :214 -> KLSTM_ERR_SHAPE). */
+klstm_status klstm_reset(klstm_engine *e, const int *flags, int n);
+/* Carried state of prev_nnet_state_ that is ever consumed: c [S x C] and r [S x R]
+ * (only these column groups are read back, :275,:278,:281,:294). Host pointers. */
+klstm_status klstm_get_state_host(klstm_engine *e, float *c, float *r);
+klstm_status klstm_set_state_host(klstm_engine *e, const float *c, const float *r);
+
+/* PropagateFnc (...streams.h:222-332).  in [rows x I], out [rows x R], device pointers,
+ * strides in elements.  rows % num_stream must be 0 (:225).  Carries state in and out
+ * (:231, :331). */
+klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_stride,
+                             float *out, int out_stride);
+
+/* BackpropagateFnc (...streams.h:334-499) for the minibatch of the immediately preceding
+ * klstm_propagate (it reuses that call's activation slab, :342-349; rows must match).
+ * in_diff may be NULL (the reference always computes it, :457; NULL skips that GEMM).
+ * momentum = opts_.momentum (:465).  flags: KLSTM_BPTT_*.
+ * Default mode leaves  corr = momentum*corr + grad  in the momentum buffers (:468-487). */
+klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride,
+                                 const float *out_diff, int out_diff_stride,
+                                 float *in_diff, int in_diff_stride, int rows,
+                                 float momentum, int flags);
+
+/* DP mode only, after the all-reduce of klstm_grad_blob():  corr = momentum*corr + grad. */
+klstm_status klstm_apply_momentum(klstm_engine *e, float momentum);
+
+/* Update (...streams.h:501-512):  theta -= learn_rate * theta_corr  for all seven tensors.
+ * clip_grad > 0 first clips every corr element to +-clip_grad IN PLACE, which is the
+ * standard/ LstmProjected::Update behaviour (standard/nnet/nnet-lstm-projected.h:480-493,
+ * max_grad = 50); pass 0 for the google/ component. */
+klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad);
+
+/* Block until everything queued on the engine's stream has finished. */
+klstm_status klstm_synchronize(klstm_engine *e);
+
+/* Test / diagnostics hook (the reference's DEBUG dumps, :314-324, :443-453): copy the
+ * activation slab of the last propagate (which = 0) or backpropagate (which = 1) to host in
+ * the REFERENCE layout [(T+2)*S rows] x [G|I|F|O|C|H|M|R], T = rows/S of that call.
+ * Row-blocks the engine never materialises (the slab's dummy blocks) read as zero. */
+klstm_status klstm_get_activations_host(klstm_engine *e, int which, float *dst);
+
+/* Engine knobs (not part of the reference interface).  Keys:
+ *   "graph"   0/1  replay the per-minibatch launch sequence from a hipGraph (default 1)
+ *   "profile" 0/1  run every kernel eagerly between its own start/stop HIP events on the
+ *                  engine's stream (hipExtLaunchKernelGGL); setting the key clears the
+ *                  statistics.  Used by bench.py for the roofline line. */
+klstm_status klstm_set_option(klstm_engine *e, const char *key, int value);
+
+/* With "profile" on: device time (microseconds, summed) and launch count of `kernel`
+ * ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_gemm_xproj", "k_gemm_dwr", ...)
+ * over everything executed since the option was set.  Synchronises the stream. */
+klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *total_us,
+                                 long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KLSTM_H_ */

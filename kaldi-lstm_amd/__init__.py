@@ -1,0 +1,9 @@
+"""kaldi-lstm_amd: MI355X-native LstmProjectedStreams forward/BPTT/update engine.
+
+The product is the C-ABI shared library `libklstm.so` (include/klstm.h, hand-written gfx950
+HIP kernels) plus the C++ mirror of the reference component (include/klstm_component.hpp).
+This Python package is plumbing over that ABI for tests, bench.py and torch.distributed
+launch; it contains no arithmetic and NO CPU fallback: if the library or a GPU is missing,
+calls raise.
+"""
+from .binding import Engine, KlstmError, lib_path, load_library, DEFER_MOMENTUM  # noqa: F401

@@ -1,0 +1,199 @@
+"""ctypes binding of include/klstm.h.  Mirrors the reference component's method names
+(google/nnet/bd-nnet-lstm-projected-streams.h): Reset / PropagateFnc / BackpropagateFnc /
+Update / NumParams / GetParams, with torch CUDA tensors standing in for CuMatrixBase
+(data pointer + row stride are passed through untouched)."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFER_MOMENTUM = 1
+_LIB = None
+
+
+class KlstmError(RuntimeError):
+    """Non-zero klstm_status (the adapter's KALDI_ERR equivalent)."""
+
+    def __init__(self, status, msg):
+        super().__init__(f"klstm status {status}: {msg}")
+        self.status = status
+
+
+def lib_path():
+    return os.path.join(_HERE, "libklstm.so")
+
+
+def load_library():
+    """dlopen libklstm.so (never builds, never falls back)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise KlstmError(-1, f"{path} not built: run `python kaldi-lstm_amd/build.py` (hipcc, gfx950)")
+    lib = ctypes.CDLL(path)
+    P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    lib.klstm_last_error.restype = ctypes.c_char_p
+    lib.klstm_version.restype = ctypes.c_char_p
+    lib.klstm_create.argtypes = [I, I, I, I, I, P, ctypes.POINTER(P)]
+    lib.klstm_destroy.argtypes = [P]
+    lib.klstm_destroy.restype = None
+    for n in ("input_dim", "cell_dim", "recur_dim", "num_stream"):
+        getattr(lib, f"klstm_{n}").argtypes = [P]
+    lib.klstm_num_params.argtypes = [P]
+    lib.klstm_num_params.restype = ctypes.c_long
+    for n in ("set_params_host", "get_params_host", "set_params_device", "get_corr_host",
+              "set_corr_host", "get_grads_host"):
+        getattr(lib, f"klstm_{n}").argtypes = [P, P]
+    lib.klstm_grad_blob.argtypes = [P]
+    lib.klstm_grad_blob.restype = P
+    lib.klstm_param_blob.argtypes = [P]
+    lib.klstm_param_blob.restype = P
+    lib.klstm_reset.argtypes = [P, P, I]
+    lib.klstm_get_state_host.argtypes = [P, P, P]
+    lib.klstm_set_state_host.argtypes = [P, P, P]
+    lib.klstm_propagate.argtypes = [P, P, I, I, P, I]
+    lib.klstm_backpropagate.argtypes = [P, P, I, P, I, P, I, I, F, I]
+    lib.klstm_apply_momentum.argtypes = [P, F]
+    lib.klstm_update.argtypes = [P, F, F]
+    lib.klstm_synchronize.argtypes = [P]
+    lib.klstm_get_activations_host.argtypes = [P, I, P]
+    lib.klstm_set_option.argtypes = [P, ctypes.c_char_p, I]
+    lib.klstm_profile_query.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_long)]
+    _LIB = lib
+    return lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine:
+    """One LstmProjectedStreams layer on one MI355X."""
+
+    def __init__(self, input_dim, cell_dim, recur_dim, num_stream, device=0, stream=None):
+        self.lib = load_library()
+        self.I, self.C, self.R, self.S = input_dim, cell_dim, recur_dim, num_stream
+        self.W = 7 * cell_dim + recur_dim
+        self._stream_obj = stream                      # keep a torch stream alive if given
+        handle = ctypes.c_void_p()
+        sptr = ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
+        self._chk(self.lib.klstm_create(input_dim, cell_dim, recur_dim, num_stream, device, sptr,
+                                        ctypes.byref(handle)))
+        self.h = handle
+        self.T = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.klstm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, status):
+        if status != 0:
+            raise KlstmError(status, self.lib.klstm_last_error().decode())
+
+    # ---- NumParams / GetParams (reference :152-189) ----
+    @property
+    def num_params(self):
+        return int(self.lib.klstm_num_params(self.h))
+
+    def set_params(self, flat):
+        flat = _f32(flat)
+        assert flat.size == self.num_params
+        self._chk(self.lib.klstm_set_params_host(self.h, flat.ctypes.data))
+
+    def get_params(self):
+        out = np.empty(self.num_params, np.float32)
+        self._chk(self.lib.klstm_get_params_host(self.h, out.ctypes.data))
+        return out
+
+    def get_corr(self):
+        out = np.empty(self.num_params, np.float32)
+        self._chk(self.lib.klstm_get_corr_host(self.h, out.ctypes.data))
+        return out
+
+    def set_corr(self, flat):
+        flat = _f32(flat)
+        assert flat.size == self.num_params
+        self._chk(self.lib.klstm_set_corr_host(self.h, flat.ctypes.data))
+
+    def get_grads(self):
+        out = np.empty(self.num_params, np.float32)
+        self._chk(self.lib.klstm_get_grads_host(self.h, out.ctypes.data))
+        return out
+
+    def grad_blob_ptr(self):
+        return int(self.lib.klstm_grad_blob(self.h))
+
+    def grad_blob_tensor(self):
+        """Zero-copy torch view of the device gradient blob (for dist.all_reduce)."""
+        import torch
+
+        class _Blob:
+            pass
+        b = _Blob()
+        b.__cuda_array_interface__ = {"shape": (self.num_params,), "typestr": "<f4",
+                                      "data": (self.grad_blob_ptr(), False), "version": 2}
+        return torch.as_tensor(b, device="cuda")
+
+    # ---- Reset (reference :212-220) ----
+    def reset(self, flags):
+        f = np.ascontiguousarray(flags, dtype=np.int32)
+        self._chk(self.lib.klstm_reset(self.h, f.ctypes.data, int(f.size)))
+
+    def get_state(self):
+        c = np.empty((self.S, self.C), np.float32)
+        r = np.empty((self.S, self.R), np.float32)
+        self._chk(self.lib.klstm_get_state_host(self.h, c.ctypes.data, r.ctypes.data))
+        return c, r
+
+    def set_state(self, c, r):
+        c, r = _f32(c), _f32(r)
+        assert c.shape == (self.S, self.C) and r.shape == (self.S, self.R)
+        self._chk(self.lib.klstm_set_state_host(self.h, c.ctypes.data, r.ctypes.data))
+
+    # ---- PropagateFnc / BackpropagateFnc / Update (reference :222, :334, :501) ----
+    def propagate(self, x, out):
+        """x [rows, I], out [rows, R]: torch CUDA float32, last dim contiguous."""
+        assert x.is_cuda and out.is_cuda and x.stride(1) == 1 and out.stride(1) == 1
+        rows = x.shape[0]
+        self._chk(self.lib.klstm_propagate(self.h, x.data_ptr(), rows, x.stride(0), out.data_ptr(), out.stride(0)))
+        self.T = rows // self.S
+
+    def backpropagate(self, x, out_diff, in_diff=None, momentum=0.0, flags=0):
+        assert x.is_cuda and out_diff.is_cuda and x.stride(1) == 1 and out_diff.stride(1) == 1
+        idp, ids = (in_diff.data_ptr(), in_diff.stride(0)) if in_diff is not None else (None, 0)
+        self._chk(self.lib.klstm_backpropagate(self.h, x.data_ptr(), x.stride(0), out_diff.data_ptr(),
+                                               out_diff.stride(0), idp, ids, x.shape[0],
+                                               float(momentum), int(flags)))
+
+    def apply_momentum(self, momentum):
+        self._chk(self.lib.klstm_apply_momentum(self.h, float(momentum)))
+
+    def update(self, learn_rate, clip_grad=0.0):
+        self._chk(self.lib.klstm_update(self.h, float(learn_rate), float(clip_grad)))
+
+    def synchronize(self):
+        self._chk(self.lib.klstm_synchronize(self.h))
+
+    def activations(self, which=0):
+        """Reference-layout slab [(T+2)S, 7C+R] of the last propagate (0) / backpropagate (1)."""
+        out = np.empty(((self.T + 2) * self.S, self.W), np.float32)
+        self._chk(self.lib.klstm_get_activations_host(self.h, which, out.ctypes.data))
+        return out
+
+    def set_option(self, key, value):
+        self._chk(self.lib.klstm_set_option(self.h, key.encode(), int(value)))
+
+    def profile_query(self, kernel):
+        tot, n = ctypes.c_double(), ctypes.c_long()
+        self._chk(self.lib.klstm_profile_query(self.h, kernel.encode(), ctypes.byref(tot), ctypes.byref(n)))
+        return tot.value, n.value

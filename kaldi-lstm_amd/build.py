@@ -1,0 +1,33 @@
+"""Build recipe for libklstm.so (hipcc, gfx950 only, in-tree so it travels with the repo)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRCS = ["csrc/klstm_kernels.hip", "csrc/klstm_engine.hip"]
+HDRS = ["csrc/klstm_kernels.h", "../include/klstm.h"]
+LIB = os.path.join(HERE, "libklstm.so")
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SRCS + HDRS + ["build.py"])
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-result", "-o", LIB] + [os.path.join(HERE, s) for s in SRCS]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    print(LIB)

@@ -1,0 +1,243 @@
+"""GPU parity tests: the HIP engine (through the C-ABI, include/klstm.h) against the CPU oracle
+on identical seeded inputs.  fp32 tolerances are stated per test; the contraction order of
+the MFMA kernels (K split over 8 waves, fixed-order combine) differs from the oracle's
+sequential dot products, so results are not bit-equal, but every elementwise formula is
+evaluated in the oracle's order (no FMA contraction).
+
+Tolerance convention: max|gpu - oracle| <= tol * max|oracle|  (per tensor).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import Oracle, make_params
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def make_engine(I, C, R, S, params):
+    import kaldi_lstm_amd as k
+    e = k.Engine(I, C, R, S)
+    e.set_params(params)
+    return e
+
+
+def run_chunks(I, C, R, S, T, nchunks, scale, momentum, lr, seed=0, want_in_diff=True, od_scale=1.0):
+    """Runs nchunks x (Propagate, Backpropagate, Update) on both sides; returns per-chunk records."""
+    rng = np.random.RandomState(seed)
+    p = make_params(I, C, R, scale=scale, seed=seed + 1)
+    o = Oracle(I, C, R, S, np.float32)
+    o.set_params(p)
+    e = make_engine(I, C, R, S, p)
+    recs = []
+    for ck in range(nchunks):
+        x = rng.randn(T * S, I).astype(np.float32)
+        od = (od_scale * rng.randn(T * S, R)).astype(np.float32)
+        xd, odd = dev(x), dev(od)
+        outd = torch.empty(T * S, R, device="cuda")
+        idd = torch.empty(T * S, I, device="cuda") if want_in_diff else None
+        torch.cuda.synchronize()
+        e.propagate(xd, outd)
+        e.backpropagate(xd, odd, idd, momentum=momentum)
+        e.synchronize()
+        out_o = o.propagate(x)
+        id_o = o.backpropagate(x, od, momentum=momentum, want_in_diff=want_in_diff)
+        rec = dict(out=(outd.cpu().numpy(), out_o), corr=(e.get_corr(), o.get_corr()),
+                   Y=(e.activations(0), o.prop_buf()), D=(e.activations(1), o.bprop_buf()))
+        if want_in_diff:
+            rec["in_diff"] = (idd.cpu().numpy(), id_o)
+        e.update(lr)
+        o.update(lr)
+        rec["params"] = (e.get_params(), o.get_params())
+        cs, rs = e.get_state()
+        st = o.get_state()
+        rec["state_c"] = (cs, st[:, 4 * C:5 * C])
+        rec["state_r"] = (rs, st[:, 7 * C:])
+        recs.append(rec)
+    e.close()
+    return recs
+
+
+def check(recs, tol_act, tol_grad, C, S, T):
+    for rec in recs:
+        assert relerr(*rec["out"]) <= tol_act
+        Yg, Yo = rec["Y"]
+        # frames 1..T, every column group; block 0 only C and R are defined on the engine side
+        assert relerr(Yg[S:(T + 1) * S], Yo[S:(T + 1) * S]) <= tol_act
+        assert relerr(Yg[:S, 4 * C:5 * C], Yo[:S, 4 * C:5 * C]) <= tol_act
+        assert relerr(Yg[:S, 7 * C:], Yo[:S, 7 * C:]) <= tol_act
+        Dg, Do = rec["D"]
+        for lo, hi in ((0, 5 * C), (7 * C, Dg.shape[1])):      # DG..DO, DC, DR (DH/DM are not materialised)
+            assert relerr(Dg[S:(T + 1) * S, lo:hi], Do[S:(T + 1) * S, lo:hi]) <= tol_grad
+        if "in_diff" in rec:
+            assert relerr(*rec["in_diff"]) <= tol_grad
+        assert relerr(*rec["corr"]) <= tol_grad
+        assert relerr(*rec["params"]) <= tol_act
+        assert relerr(*rec["state_c"]) <= tol_act
+        assert relerr(*rec["state_r"]) <= tol_act
+
+
+@pytest.mark.parametrize("I,C,R,S,T", [
+    (5, 7, 4, 3, 6),        # tiny, nothing aligned: scalar load paths, partial tiles
+    (5, 7, 4, 1, 9),        # single stream (standard/ LstmProjected shape)
+    (8, 16, 8, 16, 4),      # exactly one stream tile
+    (12, 20, 12, 20, 5),    # two stream tiles, C % 16 != 0
+    (40, 36, 24, 70, 3),    # 5 stream tiles -> NT=4 with a second stream group
+    (6, 10, 6, 130, 2),     # 9 stream tiles -> NT=8 path
+])
+def test_small_shapes_against_oracle(I, C, R, S, T):
+    recs = run_chunks(I, C, R, S, T, nchunks=3, scale=0.3, momentum=0.9, lr=1e-3)
+    check(recs, tol_act=2e-5, tol_grad=1e-4, C=C, S=S, T=T)
+
+
+def test_config_c2_shape_50_chunks():
+    """BASELINE.json configs[1]: 40 -> cell 800 / proj 512, NumStream 4, T_bptt 20, ParamScale 0.01,
+    lr 1e-5, momentum 0.9 (train_lstm_streams.sh:3-7), 5 chunks checked in full."""
+    I, C, R, S, T = 40, 800, 512, 4, 20
+    recs = run_chunks(I, C, R, S, T, nchunks=5, scale=0.01, momentum=0.9, lr=1e-5, od_scale=0.1)
+    check(recs, tol_act=2e-5, tol_grad=2e-4, C=C, S=S, T=T)
+
+
+def test_larger_weights_saturating_gates():
+    I, C, R, S, T = 40, 64, 32, 8, 20
+    recs = run_chunks(I, C, R, S, T, nchunks=2, scale=0.5, momentum=0.0, lr=1e-3)
+    check(recs, tol_act=5e-5, tol_grad=5e-4, C=C, S=S, T=T)
+
+
+def test_cell_clip_fires():
+    """c is clipped to +-50 in forward and treated as identity in BPTT (reference :296-297)."""
+    I, C, R, S, T = 4, 8, 4, 2, 6
+    p = make_params(I, C, R, scale=0.3, seed=5)
+    o = Oracle(I, C, R, S, np.float32); o.set_params(p)
+    e = make_engine(I, C, R, S, p)
+    rng = np.random.RandomState(1)
+    st = np.zeros((S, o.W), np.float32)
+    st[:, 4 * C:5 * C] = 60.0 * np.sign(rng.randn(S, C))
+    o.set_state(st)
+    e.set_state(st[:, 4 * C:5 * C], st[:, 7 * C:])
+    x = rng.randn(T * S, I).astype(np.float32); od = rng.randn(T * S, R).astype(np.float32)
+    outd = torch.empty(T * S, R, device="cuda"); idd = torch.empty(T * S, I, device="cuda")
+    e.propagate(dev(x), outd); e.backpropagate(dev(x), dev(od), idd)
+    out_o = o.propagate(x); id_o = o.backpropagate(x, od)
+    Y = e.activations(0)
+    assert np.abs(Y[S:2 * S, 4 * C:5 * C]).max() == 50.0
+    assert relerr(outd.cpu().numpy(), out_o) <= 2e-5
+    assert relerr(idd.cpu().numpy(), id_o) <= 1e-4
+    assert relerr(e.get_corr(), o.get_corr()) <= 1e-4
+    e.close()
+
+
+def test_chunked_equals_unchunked_and_reset():
+    I, C, R, S = 5, 12, 8, 3
+    p = make_params(I, C, R, scale=0.3, seed=2)
+    rng = np.random.RandomState(3)
+    x = rng.randn(12 * S, I).astype(np.float32)
+    a, b = make_engine(I, C, R, S, p), make_engine(I, C, R, S, p)
+    full = torch.empty(12 * S, R, device="cuda")
+    a.propagate(dev(x), full)
+    parts = []
+    for k in range(3):
+        o = torch.empty(4 * S, R, device="cuda")
+        b.propagate(dev(x[k * 4 * S:(k + 1) * 4 * S]), o)
+        parts.append(o)
+    a.synchronize(); b.synchronize()
+    assert torch.equal(full, torch.cat(parts, 0))          # bit-exact state bridge (:231, :331)
+    c0, r0 = b.get_state()
+    b.reset([0, 1, 0])
+    c1, r1 = b.get_state()
+    assert np.all(c1[1] == 0) and np.all(r1[1] == 0)
+    assert np.array_equal(c1[[0, 2]], c0[[0, 2]]) and np.array_equal(r1[[0, 2]], r0[[0, 2]])
+    a.close(); b.close()
+
+
+def test_graph_replay_equals_eager_bitwise():
+    I, C, R, S, T = 40, 64, 32, 4, 10
+    p = make_params(I, C, R, scale=0.1, seed=4)
+    rng = np.random.RandomState(4)
+    x = dev(rng.randn(T * S, I)); od = dev(rng.randn(T * S, R))
+    res = []
+    for graph in (1, 0):
+        e = make_engine(I, C, R, S, p)
+        e.set_option("graph", graph)
+        out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+        for _ in range(3):                                   # replays must not drift either
+            e.propagate(x, out); e.backpropagate(x, od, idf, momentum=0.5); e.update(1e-3)
+        e.synchronize()
+        res.append((out.cpu().numpy(), idf.cpu().numpy(), e.get_corr(), e.get_params()))
+        e.close()
+    for g, h in zip(*res):
+        assert np.array_equal(g, h)
+
+
+def test_deferred_momentum_matches_default():
+    """DP mode: pure gradient in the blob, momentum applied after the (here absent) all-reduce."""
+    I, C, R, S, T = 10, 24, 16, 4, 5
+    p = make_params(I, C, R, scale=0.2, seed=6)
+    rng = np.random.RandomState(6)
+    import kaldi_lstm_amd as k
+    a, b = make_engine(I, C, R, S, p), make_engine(I, C, R, S, p)
+    for _ in range(3):
+        x = dev(rng.randn(T * S, I)); od = dev(rng.randn(T * S, R))
+        out = torch.empty(T * S, R, device="cuda")
+        a.propagate(x, out); a.backpropagate(x, od, None, momentum=0.9); a.update(1e-2)
+        b.propagate(x, out); b.backpropagate(x, od, None, momentum=0.9, flags=k.DEFER_MOMENTUM)
+        b.apply_momentum(0.9); b.update(1e-2)
+    assert relerr(a.get_corr(), b.get_corr()) <= 1e-6
+    assert relerr(a.get_params(), b.get_params()) <= 1e-6
+    t = b.grad_blob_tensor()
+    assert t.is_cuda and t.numel() == b.num_params
+    assert np.array_equal(t.cpu().numpy(), b.get_grads())
+    a.close(); b.close()
+
+
+def test_pitched_rows_and_standard_clip_update():
+    """Strides are honoured (CuMatrix rows are pitched, cu-matrix.cc:67-73); clip_grad reproduces
+    standard/ LstmProjected::Update (standard/nnet/nnet-lstm-projected.h:480-493)."""
+    I, C, R, S, T = 6, 12, 8, 1, 7
+    p = make_params(I, C, R, scale=0.4, seed=8)
+    rng = np.random.RandomState(8)
+    x = rng.randn(T * S, I).astype(np.float32); od = (100 * rng.randn(T * S, R)).astype(np.float32)
+    xs = torch.zeros(T * S, I + 3, device="cuda"); xs[:, :I] = dev(x)
+    ods = torch.zeros(T * S, R + 5, device="cuda"); ods[:, :R] = dev(od)
+    outs = torch.full((T * S, R + 2), 7.0, device="cuda")
+    ids = torch.full((T * S, I + 1), 7.0, device="cuda")
+    e = make_engine(I, C, R, S, p)
+    e.propagate(xs[:, :I], outs[:, :R]); e.backpropagate(xs[:, :I], ods[:, :R], ids[:, :I])
+    e.update(1e-3, clip_grad=50.0); e.synchronize()
+    o = Oracle(I, C, R, S, np.float32); o.set_params(p)
+    out_o = o.propagate(x); id_o = o.backpropagate(x, od); o.update(1e-3, clip_grad=50.0)
+    assert relerr(outs[:, :R].cpu().numpy(), out_o) <= 2e-5
+    assert relerr(ids[:, :I].cpu().numpy(), id_o) <= 1e-4
+    assert torch.all(outs[:, R:] == 7.0) and torch.all(ids[:, I:] == 7.0)      # padding untouched
+    assert np.abs(o.get_corr()).max() == 50.0                                   # the clip did fire
+    assert relerr(e.get_corr(), o.get_corr()) <= 1e-4
+    assert relerr(e.get_params(), o.get_params()) <= 2e-5
+    e.close()
+
+
+def test_error_statuses():
+    import kaldi_lstm_amd as k
+    e = k.Engine(5, 7, 4, 3)
+    x = torch.zeros(7, 5, device="cuda"); out = torch.zeros(7, 4, device="cuda")
+    with pytest.raises(k.KlstmError) as ei:
+        e.propagate(x, out)                               # 7 % 3 != 0  (KALDI_ASSERT :225)
+    assert ei.value.status == 2
+    with pytest.raises(k.KlstmError) as ei:
+        e.reset([1, 0])                                   # flag count != num_stream (:214)
+    assert ei.value.status == 2
+    with pytest.raises(k.KlstmError) as ei:
+        e.backpropagate(x[:6], out[:6])                   # no preceding propagate
+    assert ei.value.status == 3
+    e.propagate(x[:6], out[:6])
+    with pytest.raises(k.KlstmError) as ei:
+        e.backpropagate(x[:3], out[:3])                   # rows differ from the propagate
+    assert ei.value.status == 2
+    e.close()
