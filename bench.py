@@ -142,9 +142,8 @@ def main():
         for i in range(3):
             step(args.warmup + args.steps + i)
         kern = {}
-        for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_gemm_xproj", "k_gemm_indiff",
-                     "k_gemm_dwx", "k_gemm_dwr", "k_gemm_dwm", "k_vec_grads", "k_update", "k_transpose",
-                     "k_begin", "k_end", "k_apply_momentum"):
+        for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj",
+                     "k_grads", "k_update_repack", "k_apply_momentum"):
             tot, n = eng.profile_query(name)
             if n:
                 kern[name] = {"avg_us": tot / n, "launches_per_step": n / 3.0, "us_per_step": tot / 3.0}

@@ -46,17 +46,20 @@ struct klstm_engine {
   bool own_stream = false;
   long nparams = 0;
   float *params = nullptr, *grads = nullptr, *corr = nullptr;
-  float *wrT = nullptr, *wmT = nullptr;
+  float *wrT = nullptr, *wmT = nullptr, *wxT = nullptr;   // transposed copies for the BPTT kernels
+  float *pk[4] = {nullptr, nullptr, nullptr, nullptr};    // packed MFMA-operand-ordered copies (vector kernels)
   float *prev_c = nullptr, *prev_r = nullptr;
   int *flags_dev = nullptr;
   // activation planes, (T_alloc+2) time blocks each
   int T_alloc = 0;
   float *gifo = nullptr, *cc = nullptr, *hh = nullptr, *mm = nullptr, *rr = nullptr;
-  float *dgifo = nullptr, *dc = nullptr, *dr = nullptr, *dr_part = nullptr;
+  float *dgifo = nullptr, *dc = nullptr, *dr = nullptr, *dr_part = nullptr, *dx_part = nullptr;
   int ks = 1;
   int T_fwd = -1;     // T of the last propagate (-1: none yet)
   int T_bwd = -1;
   bool use_graph = true;
+  bool use_vector = true;
+  int fuse_x = -1;    // -1 auto (small NumStream), 0 batched x-projection GEMM, 1 fused into the step kernel
   bool profile = false;
   std::vector<ProbeRec> probes;
   std::map<std::string, std::pair<double, long>> prof;   // name -> (total us, launches)
@@ -85,7 +88,7 @@ static LaunchProbe probe(klstm_engine *e, const char *name) {
 }
 
 static void free_planes(klstm_engine *e) {
-  float **ps[] = {&e->gifo, &e->cc, &e->hh, &e->mm, &e->rr, &e->dgifo, &e->dc, &e->dr, &e->dr_part};
+  float **ps[] = {&e->gifo, &e->cc, &e->hh, &e->mm, &e->rr, &e->dgifo, &e->dc, &e->dr, &e->dr_part, &e->dx_part};
   for (float **p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
 }
 static void drop_graphs(klstm_engine *e) {
@@ -110,6 +113,7 @@ static klstm_status ensure_planes(klstm_engine *e, int T) {
   HIPCHK(hipMalloc(&e->dc, nb * e->C * sizeof(float)));
   HIPCHK(hipMalloc(&e->dr, nb * e->R * sizeof(float)));
   HIPCHK(hipMalloc(&e->dr_part, (size_t)e->ks * e->S * e->R * sizeof(float)));
+  HIPCHK(hipMalloc(&e->dx_part, (size_t)e->ks * e->S * e->I * sizeof(float)));
   // kSetZero semantics of the reference slabs (...streams.h:230, :352)
   HIPCHK(hipMemsetAsync(e->gifo, 0, nb * 4 * e->C * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->cc, 0, nb * e->C * sizeof(float), e->stream));
@@ -123,9 +127,11 @@ static klstm_status ensure_planes(klstm_engine *e, int T) {
   return KLSTM_OK;
 }
 
-static klstm_status refresh_transposes(klstm_engine *e) {
-  HIPCHK(launch_transpose(e->params + e->o_wr(), 4 * e->C, e->R, e->wrT, e->stream, probe(e, "k_transpose")));
-  HIPCHK(launch_transpose(e->params + e->o_wm(), e->R, e->C, e->wmT, e->stream, probe(e, "k_transpose")));
+static klstm_status repack(klstm_engine *e) {
+  const Dims d{e->I, e->C, e->R, e->S, 0};
+  HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream,
+                              probe(e, "k_update_repack")));
+  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, e->stream, probe(e, "k_pack")));
   return KLSTM_OK;
 }
 
@@ -170,8 +176,17 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
   alloc0(&e->params, pb); alloc0(&e->grads, pb); alloc0(&e->corr, pb);
   alloc0(&e->wrT, (size_t)4 * e->C * e->R * sizeof(float));
   alloc0(&e->wmT, (size_t)e->R * e->C * sizeof(float));
+  alloc0(&e->wxT, (size_t)4 * e->C * e->I * sizeof(float));
   alloc0(&e->prev_c, (size_t)e->S * e->C * sizeof(float));
   alloc0(&e->prev_r, (size_t)e->S * e->R * sizeof(float));
+  {
+    const Dims d{e->I, e->C, e->R, e->S, 0};
+    if (pack_supported(d)) {
+      long n4[4];
+      pack_sizes(d, n4);
+      for (int i = 0; i < 4; i++) alloc0(&e->pk[i], (size_t)n4[i] * 16);
+    }
+  }
   if (st == KLSTM_OK && hipMalloc(&e->flags_dev, (size_t)e->S * sizeof(int)) != hipSuccess)
     st = fail(KLSTM_ERR_HIP, "hipMalloc(flags) failed");
   if (st != KLSTM_OK) { klstm_destroy(e); return st; }
@@ -186,7 +201,7 @@ void klstm_destroy(klstm_engine *e) {
   drop_graphs(e);
   for (auto &r : e->probes) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   free_planes(e);
-  float *ps[] = {e->params, e->grads, e->corr, e->wrT, e->wmT, e->prev_c, e->prev_r};
+  float *ps[] = {e->params, e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3]};
   for (float *p : ps) if (p) (void)hipFree(p);
   if (e->flags_dev) (void)hipFree(e->flags_dev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -219,13 +234,13 @@ static klstm_status blob_d2h(klstm_engine *e, float *dst, const float *src) {
 klstm_status klstm_set_params_host(klstm_engine *e, const float *flat) {
   klstm_status st = blob_h2d(e, e ? e->params : nullptr, flat);
   if (st != KLSTM_OK) return st;
-  return refresh_transposes(e);
+  return repack(e);
 }
 klstm_status klstm_set_params_device(klstm_engine *e, const float *flat_dev) {
   if (!e || !flat_dev) return fail(KLSTM_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMemcpyAsync(e->params, flat_dev, (size_t)e->nparams * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
-  return refresh_transposes(e);
+  return repack(e);
 }
 klstm_status klstm_get_params_host(klstm_engine *e, float *flat) { return blob_d2h(e, flat, e ? e->params : nullptr); }
 klstm_status klstm_get_corr_host(klstm_engine *e, float *flat) { return blob_d2h(e, flat, e ? e->corr : nullptr); }
@@ -278,30 +293,35 @@ static FwdPtrs fwd_ptrs(klstm_engine *e) {
   p.wm = e->params + e->o_wm();
   p.gifo = e->gifo; p.cc = e->cc; p.hh = e->hh; p.mm = e->mm; p.rr = e->rr;
   p.prev_c = e->prev_c; p.prev_r = e->prev_r;
+  p.pk_gates = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[0]) : nullptr;
+  p.pk_proj = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[1]) : nullptr;
   return p;
 }
 static BwdPtrs bwd_ptrs(klstm_engine *e) {
   BwdPtrs p;
-  p.wrT = e->wrT; p.wmT = e->wmT;
+  p.wrT = e->wrT; p.wmT = e->wmT; p.wxT = e->wxT;
   p.pi = e->params + e->o_pi(); p.pf = e->params + e->o_pf(); p.po = e->params + e->o_po();
   p.gifo = e->gifo; p.cc = e->cc; p.hh = e->hh;
-  p.dgifo = e->dgifo; p.dc = e->dc; p.dr = e->dr; p.dr_part = e->dr_part; p.ks = e->ks;
+  p.dgifo = e->dgifo; p.dc = e->dc; p.dr = e->dr; p.dr_part = e->dr_part; p.dx_part = e->dx_part; p.ks = e->ks;
+  p.pk_dr = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[2]) : nullptr;
+  p.pk_dm = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[3]) : nullptr;
   return p;
 }
+
+static bool use_fused_x(const klstm_engine *e) { return e->fuse_x < 0 ? e->S <= 16 : e->fuse_x != 0; }
 
 static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride, float *out, int out_stride, int T) {
   const Dims d{e->I, e->C, e->R, e->S, T};
   const FwdPtrs p = fwd_ptrs(e);
   hipStream_t st = e->stream;
-  HIPCHK(launch_begin(d, p, st, probe(e, "k_begin")));
-  // x -> g,i,f,o for all frames at once + bias (...streams.h:246, :259)
-  HIPCHK(launch_gemm(false, true, T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, 0.f,
-                     e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias, st, probe(e, "k_gemm_xproj")));
+  const bool fx = use_fused_x(e);
+  if (!fx)   // x -> g,i,f,o for all frames at once + bias (...streams.h:246, :259)
+    HIPCHK(launch_gemm(false, true, T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, 0.f,
+                       e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias, st, probe(e, "k_gemm_xproj")));
   for (int t = 1; t <= T; t++) {
-    HIPCHK(launch_gates_step(d, p, t, st, probe(e, "k_gates_step")));
+    HIPCHK(launch_gates_step(d, p, t, fx, in, in_stride, st, probe(e, "k_gates_step")));
     HIPCHK(launch_proj_step(d, p, t, out, out_stride, st, probe(e, "k_proj_step")));
   }
-  HIPCHK(launch_end(d, p, st, probe(e, "k_end")));
   return KLSTM_OK;
 }
 
@@ -310,26 +330,17 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
   const Dims d{e->I, e->C, e->R, e->S, T};
   const BwdPtrs p = bwd_ptrs(e);
   hipStream_t st = e->stream;
-  const int S = d.S, C = d.C, R = d.R, I = d.I;
   for (int t = T; t >= 1; t--) {
-    if (t < T) HIPCHK(launch_dr_step(d, p, t, st, probe(e, "k_dr_step")));
-    HIPCHK(launch_dm_step(d, p, t, out_diff, od_stride, st, probe(e, "k_dm_step")));
+    if (t < T) HIPCHK(launch_dr_step(d, p, t, in_diff, id_stride, st, probe(e, "k_dr_step")));
+    HIPCHK(launch_dm_step(d, p, t, out_diff, od_stride, in_diff, id_stride, st, probe(e, "k_dm_step")));
   }
-  const float *dg1 = e->dgifo + (size_t)S * 4 * C;            // DGIFO[1..T]
-  if (in_diff)                                                 // :457
-    HIPCHK(launch_gemm(false, false, T * S, I, 4 * C, dg1, 4 * C, e->params + e->o_wx(), I, 0.f, in_diff,
-                       id_stride, nullptr, st, probe(e, "k_gemm_indiff")));
+  if (in_diff)   // in_diff of frame 1 (:457); frames 2..T were reduced inside the loop
+    HIPCHK(launch_dr_step(d, p, 0, in_diff, id_stride, st, probe(e, "k_dr_step0")));
   const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
   float *dst = defer ? e->grads : e->corr;
   const float beta = defer ? 0.f : mmt;
-  HIPCHK(launch_gemm(true, false, 4 * C, I, T * S, dg1, 4 * C, in, in_stride, beta, dst + e->o_wx(), I,
-                     nullptr, st, probe(e, "k_gemm_dwx")));                                  // :468
-  HIPCHK(launch_gemm(true, false, 4 * C, R, T * S, dg1, 4 * C, e->rr, R, beta, dst + e->o_wr(), R,
-                     nullptr, st, probe(e, "k_gemm_dwr")));                                  // :471
-  HIPCHK(launch_vec_grads(d, e->dgifo, e->cc, beta, dst + e->o_b(), dst + e->o_pi(), dst + e->o_pf(),
-                          dst + e->o_po(), st, probe(e, "k_vec_grads")));                    // :474-484
-  HIPCHK(launch_gemm(true, false, R, C, T * S, e->dr + (size_t)S * R, R, e->mm + (size_t)S * C, C, beta,
-                     dst + e->o_wm(), C, nullptr, st, probe(e, "k_gemm_dwm")));              // :486
+  HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, beta, dst, st,
+                      probe(e, "k_grads")));                                                  // :468-487
   return KLSTM_OK;
 }
 
@@ -404,8 +415,12 @@ klstm_status klstm_apply_momentum(klstm_engine *e, float momentum) {
 klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(launch_update(e->params, e->corr, learn_rate, clip_grad, e->nparams, e->stream, probe(e, "k_update")));
-  return refresh_transposes(e);
+  const Dims d{e->I, e->C, e->R, e->S, 0};
+  // theta -= lr * corr, and the transposed copies the BPTT kernels read are refreshed in the same pass
+  HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT,
+                              e->stream, probe(e, "k_update_repack")));
+  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, e->stream, probe(e, "k_pack")));
+  return KLSTM_OK;
 }
 
 klstm_status klstm_synchronize(klstm_engine *e) {
@@ -454,6 +469,18 @@ klstm_status klstm_get_activations_host(klstm_engine *e, int which, float *dst) 
 klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
   if (!e || !key) return fail(KLSTM_ERR_ARG, "null argument");
   if (!strcmp(key, "graph")) { e->use_graph = value != 0; return KLSTM_OK; }
+  if (!strcmp(key, "vector")) {          // 0: force the generic kernels (testing)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    e->use_vector = value != 0;
+    return KLSTM_OK;
+  }
+  if (!strcmp(key, "fuse_x")) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    e->fuse_x = value;
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "profile")) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -483,6 +510,70 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
   auto it = e->prof.find(kernel);
   *total_us = it == e->prof.end() ? 0.0 : it->second.first;
   *launches = it == e->prof.end() ? 0 : it->second.second;
+  return KLSTM_OK;
+}
+
+// Diagnostic: cost of one kernel inside a dependent chain.  Captures `n` back-to-back launches of
+// the named step kernel(s) (t cycles 1..T of the last propagate) into a hipGraph, replays it 5
+// times and returns the best wall time per launch in microseconds (HIP events on the engine
+// stream).  Leaves the activation planes in an undefined state.
+klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *us_per_launch) {
+  if (!e || !what || !us_per_launch || n <= 0) return fail(KLSTM_ERR_ARG, "bad argument");
+  if (e->T_fwd < 0) return fail(KLSTM_ERR_STATE, "klstm_debug_chain: run a propagate first");
+  HIPCHK(hipSetDevice(e->device));
+  const int T = e->T_fwd;
+  const Dims d{e->I, e->C, e->R, e->S, T};
+  const FwdPtrs fp = fwd_ptrs(e);
+  const BwdPtrs bp = bwd_ptrs(e);
+  float *scratch_out = nullptr, *xin = nullptr, *xdiff = nullptr;
+  HIPCHK(hipMalloc(&scratch_out, (size_t)T * e->S * e->R * sizeof(float)));
+  HIPCHK(hipMalloc(&xin, (size_t)T * e->S * e->I * sizeof(float)));
+  HIPCHK(hipMalloc(&xdiff, (size_t)T * e->S * e->I * sizeof(float)));
+  HIPCHK(hipMemsetAsync(xin, 0, (size_t)T * e->S * e->I * sizeof(float), e->stream));
+  const bool fx = use_fused_x(e);
+  hipStream_t st = e->stream;
+  const std::string w(what);
+  auto seq = [&]() -> klstm_status {
+    for (int i = 0; i < n; i++) {
+      const int t = 1 + (i % T);
+      if (w == "gates") HIPCHK(launch_gates_step(d, fp, t, fx, xin, e->I, st));
+      else if (w == "proj") HIPCHK(launch_proj_step(d, fp, t, scratch_out, e->R, st));
+      else if (w == "gates+proj") { if (i & 1) HIPCHK(launch_proj_step(d, fp, t, scratch_out, e->R, st)); else HIPCHK(launch_gates_step(d, fp, t, fx, xin, e->I, st)); }
+      else if (w == "dr") HIPCHK(launch_dr_step(d, bp, t < T ? t : 1, xdiff, e->I, st));
+      else if (w == "dm") HIPCHK(launch_dm_step(d, bp, t, scratch_out, e->R, xdiff, e->I, st));
+      else if (w == "dr+dm") { if (i & 1) HIPCHK(launch_dm_step(d, bp, t, scratch_out, e->R, xdiff, e->I, st)); else HIPCHK(launch_dr_step(d, bp, t < T ? t : 1, xdiff, e->I, st)); }
+      else if (w == "grads") HIPCHK(launch_grads(d, e->dgifo, e->dr, xin, e->I, e->rr, e->mm, e->cc, 0.9f, e->corr, st));
+      else if (w == "update") HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, st));
+      else if (w == "pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, st));
+      else return fail(KLSTM_ERR_ARG, "klstm_debug_chain: unknown kernel '%s'", what);
+    }
+    return KLSTM_OK;
+  };
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  HIPCHK(hipMemsetAsync(scratch_out, 0, (size_t)T * e->S * e->R * sizeof(float), st));
+  HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  klstm_status rc = seq();
+  hipError_t er = hipStreamEndCapture(st, &graph);
+  if (rc != KLSTM_OK) return rc;
+  if (er != hipSuccess) return fail(KLSTM_ERR_HIP, "EndCapture: %s", hipGetErrorString(er));
+  HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; rep++) {
+    HIPCHK(hipEventRecord(e0, st));
+    HIPCHK(hipGraphLaunch(exec, st));
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep > 0 && ms < best) best = ms;
+  }
+  *us_per_launch = best * 1e3f / n;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+  (void)hipFree(scratch_out); (void)hipFree(xin); (void)hipFree(xdiff);
   return KLSTM_OK;
 }
 

@@ -5,39 +5,52 @@
 
 namespace klstm {
 
-// Dimensions + device pointers shared by the step kernels.  Planes are time-major
-// (row = tb*S + s, tb = time block 0..T+1 like the reference slab rows, ...streams.h:229-243)
-// but split per column group so that every kernel streams unit-stride rows:
-//   gifo [(T+2)S x 4C]  activated g|i|f|o         cc, hh, mm [(T+2)S x C]     rr [(T+2)S x R]
-//   dgifo[(T+2)S x 4C]  d(pre-activation) g|i|f|o dc [(T+2)S x C]             dr [(T+2)S x R]
+// Activation planes are time-major (row = tb*S + s, tb = time block 0..T+1 like the reference
+// slab rows, ...streams.h:229-243) but split per column group so every kernel streams
+// unit-stride rows:
+//   gifo [(T+2)S x 4C]  activated g|i|f|o           cc, hh, mm [(T+2)S x C]   rr [(T+2)S x R]
+//   dgifo[(T+2)S x 4C]  d(pre-activation) g|i|f|o   dc [(T+2)S x C]           dr [(T+2)S x R]
 struct Dims { int I, C, R, S, T; };
 
 struct FwdPtrs {
   const float *wx, *wr, *bias, *pi, *pf, *po, *wm;   // canonical [N x K] row-major weights
   float *gifo, *cc, *hh, *mm, *rr;
   float *prev_c, *prev_r;                            // carried state [S x C], [S x R]
+  const float4 *pk_gates, *pk_proj;                  // packed (MFMA-operand-ordered) weight copies, or null
 };
 
 struct BwdPtrs {
-  const float *wrT, *wmT;                            // transposed copies [R x 4C], [C x R]
+  const float *wrT, *wmT, *wxT;                      // transposed copies [R x 4C], [C x R], [I x 4C]
   const float *pi, *pf, *po;
   const float *gifo, *cc, *hh;
   float *dgifo, *dc, *dr;
   float *dr_part;                                    // split-K slabs [KS][S][R]
+  float *dx_part;                                    // split-K slabs [KS][S][I] (in_diff of one frame)
   int ks;                                            // number of slabs
+  const float4 *pk_dr, *pk_dm;                       // packed weight copies, or null
 };
 
 // optional per-launch timing through hipExtLaunchKernelGGL start/stop events
 struct LaunchProbe { hipEvent_t start = nullptr, stop = nullptr; };
 
-hipError_t launch_begin(const Dims &d, const FwdPtrs &p, hipStream_t st, LaunchProbe pr = {});
-hipError_t launch_end(const Dims &d, const FwdPtrs &p, hipStream_t st, LaunchProbe pr = {});
-hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, hipStream_t st, LaunchProbe pr = {});
+// forward step t (1..T).  fuse_x: the x_t * W_gifo_x^T + bias term (...streams.h:246,:259) is
+// contracted inside the step kernel (x = in rows of frame t); otherwise gifo already holds it.
+// The state bridge (:231, :331) is folded in: t==1 reads prev_c/prev_r and mirrors them into
+// time block 0, t==T writes c back to prev_c.
+hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, bool fuse_x, const float *in,
+                             int in_stride, hipStream_t st, LaunchProbe pr = {});
+// r(t) = m(t) W_r_m^T (:312) -> rr, out rows (:328); t==T also prev_r (:331)
 hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, int out_stride,
                             hipStream_t st, LaunchProbe pr = {});
-hipError_t launch_dr_step(const Dims &d, const BwdPtrs &p, int t, hipStream_t st, LaunchProbe pr = {});
-hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *out_diff, int od_stride,
+// backward step: partial d_r(t) = DGIFO(t+1) W_gifo_r (:391) as KS slabs; if in_diff != nullptr
+// also the partial in_diff of frame t+1 = DGIFO(t+1) W_gifo_x (:457).  t may be 0 (x part only,
+// written straight to in_diff rows of frame 1, single slice).
+hipError_t launch_dr_step(const Dims &d, const BwdPtrs &p, int t, float *in_diff, int id_stride,
                           hipStream_t st, LaunchProbe pr = {});
+// d_r(t) = out_diff(t) + slabs; d_m = d_r W_r_m (:408); elementwise BPTT (:411-440); also reduces
+// the in_diff slabs of frame t+1 when in_diff != nullptr and t < T.
+hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *out_diff, int od_stride,
+                          float *in_diff, int id_stride, hipStream_t st, LaunchProbe pr = {});
 
 // Generic batched GEMM  C[MxN] = beta*C + op(A)*op(B) (+ bias[n]).
 //   transA: A stored [K x M] (lda)   else [M x K]
@@ -46,16 +59,29 @@ hipError_t launch_gemm(bool transA, bool transB, int M, int N, int K, const floa
                        const float *B, int ldb, float beta, float *Cm, int ldc, const float *bias,
                        hipStream_t st, LaunchProbe pr = {});
 
-// bias / peephole gradient reductions (...streams.h:474-484), dst = beta*dst + sum
-hipError_t launch_vec_grads(const Dims &d, const float *dgifo, const float *cc, float beta,
-                            float *g_bias, float *g_pi, float *g_pf, float *g_po, hipStream_t st,
-                            LaunchProbe pr = {});
+// All seven gradient accumulations (...streams.h:468-487) in ONE launch: three A^T*B products
+// (w_gifo_x, w_gifo_r, w_r_m) plus the bias / peephole column sums.  dst = beta*dst + grad, dst is a
+// blob in GetParams order.
+hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
+                        const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,
+                        hipStream_t st, LaunchProbe pr = {});
 
-// elementwise blob kernels
+// Update (:504-512) + refresh of the transposed weight copies in ONE launch.
+//   grad != nullptr : corr = mmt*corr + grad first (DP mode, after the all-reduce)
+//   clip > 0        : corr clipped in place to +-clip (standard/ variant)
+//   lr == 0 && !grad: pure repack (after klstm_set_params)
+hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_blob, const float *grad_blob,
+                                float mmt, float lr, float clip, float *wrT, float *wmT, float *wxT,
+                                hipStream_t st, LaunchProbe pr = {});
+
+// Packed weight copies for the vector kernels (shapes with R, I, C multiples of 8):
+//   [0] gates [W_gifo_r | W_gifo_x]   [1] proj W_r_m   [2] dr [W_gifo_r^T ; W_gifo_x^T]   [3] dm W_r_m^T
+bool pack_supported(const Dims &d);
+void pack_sizes(const Dims &d, long n4[4]);         // float4 counts
+hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
+                       float *pk[4], hipStream_t st, LaunchProbe pr = {});
+
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {});
-hipError_t launch_update(float *param, float *corr, float lr, float clip, long n, hipStream_t st, LaunchProbe pr = {});
-hipError_t launch_transpose(const float *src, int rows, int cols, float *dst, hipStream_t st, LaunchProbe pr = {});
-hipError_t launch_zero_rows(float *base, int ld, const int *flags_dev, int nrows, int ncols, hipStream_t st);
 
 int dr_split_k(const Dims &d);   // number of split-K slabs launch_dr_step writes
 

@@ -4,15 +4,22 @@
 //
 // What each kernel replaces in the reference (google/nnet/bd-nnet-lstm-projected-streams.h):
 //   k_gates_step : per-step  AddMatMat(r(t-1),W_gifo_r^T) + 2x AddMatDiagVec + Sigmoid x3 + Tanh x2 +
-//                  3x AddMatDotMat + ApplyFloor/Ceiling                      (:275-309, 14 launches)
+//                  3x AddMatDotMat + ApplyFloor/Ceiling (:275-309, 14 launches); optionally also the
+//                  x(t) W_gifo_x^T + bias term (:246,:259) and the state bridge copies (:231,:331)
 //   k_proj_step  : per-step  y_r = y_m * W_r_m^T (:312) + the copy into `out` (:328)
-//   k_dr_step    : per-step  d_r += DGIFO(t+1) * W_gifo_r (:391), split-K partial slabs
+//   k_dr_step    : per-step  d_r += DGIFO(t+1) * W_gifo_r (:391) and in_diff(t+1) = DGIFO(t+1) * W_gifo_x
+//                  (:457), split-K partial slabs
 //   k_dm_step    : per-step  d_m = d_r * W_r_m (:408) + the 15 elementwise launches (:411-440)
-//   k_gemm       : the batched products outside the time loop (:246 + bias :259, :457, :468, :471, :486)
-//   k_vec_grads  : AddRowSumMat / AddDiagMatMat x3 (:474-484)
-//   k_update, k_apply_momentum : Update (:504-512) / DP-mode momentum
+//   k_grads      : all gradient accumulations (:468-487) in one grouped launch
+//   k_update_repack : Update (:504-512) + refresh of the transposed weight copies
+//   k_gemm       : batched x-projection (:246 + :259) when it is not fused into the step kernel
 //
-// Skinny-GEMM layout used by the four step kernels ("weights on M, streams on N"):
+// The recurrence is latency-bound at small NumStream (a dependent kernel boundary costs ~1.6 us on
+// this chip, a dependent HBM/L2 round trip 0.5-1 us), so every step kernel is written to make
+// exactly ONE memory round trip: all weight / activation / epilogue operands are requested before
+// the first MFMA issues.
+//
+// Skinny-GEMM layout of the step kernels ("weights on M, streams on N"):
 //   D[16 weight rows][16 streams] += A[row][k] * B[k][stream],  A lane l: row l&15, k-group l>>4;
 //   a lane loads 8 consecutive k (two dwordx4) of its weight row / stream row per 32-wide K chunk
 //   and feeds them to 8 MFMAs; the 8 waves of a workgroup split K, partial tiles are summed in a
@@ -29,14 +36,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int NW = 8;        // waves per workgroup in the step kernels (K split)
-constexpr int KCH = 32;      // K chunk one wave consumes per iteration (4 k-groups x 8)
+constexpr int KCH = 32;      // K chunk one wave consumes per MFMA group (4 k-groups x 8)
+constexpr int KSMAX = 4;     // max split-K slabs of k_dr_step
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------------------
-// scalar math: the overflow-safe forms Kaldi's CPU path uses, no FMA
-// contraction so that the elementwise results track the CPU formulation to the last bit where possible.
+// scalar math: the overflow-safe forms Kaldi's CPU path uses, no FMA contraction so that the
+// elementwise results track the CPU formulation to the last bit where possible.
 // ---------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
 __device__ __forceinline__ float k_sigmoid(float x) {
@@ -57,146 +65,252 @@ __device__ __forceinline__ float k_diff_tanh(float d, float y) {
   return (float)((double)d * (1.0 - (double)(y * y)));
 }
 
-__device__ __forceinline__ void load8(const float *__restrict__ row, int k, int K, bool ok, bool vec,
-                                      float (&v)[8]) {
-  if (ok && vec && k + 8 <= K) {
-    const float4 a = *reinterpret_cast<const float4 *>(row + k);
-    const float4 b = *reinterpret_cast<const float4 *>(row + k + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+// ---- operand fetch helpers -----------------------------------------------------------------------
+// VEC = true : rows are 16-byte aligned and every contraction length is a multiple of 8.  The load is
+//              branch-free: a lane that is out of range reads the (always valid) start of its row and
+//              the result is zeroed with selects, so every load of a kernel can be in flight at once.
+// VEC = false: generic per-element guarded loads (odd test shapes); correct but latency-serialised.
+template <bool VEC>
+__device__ __forceinline__ void load8(const float *__restrict__ row, int k, int K, bool ok, float (&v)[8]) {
+  if (VEC) {
+    const bool in = ok && (k + 8 <= K);
+    const float4 *p = reinterpret_cast<const float4 *>(row + (in ? k : 0));
+    const float4 a = p[0], b = p[1];
+    v[0] = in ? a.x : 0.f; v[1] = in ? a.y : 0.f; v[2] = in ? a.z : 0.f; v[3] = in ? a.w : 0.f;
+    v[4] = in ? b.x : 0.f; v[5] = in ? b.y : 0.f; v[6] = in ? b.z : 0.f; v[7] = in ? b.w : 0.f;
   } else {
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = (ok && k + j < K) ? row[k + j] : 0.f;
   }
 }
+template <bool VEC>
+__device__ __forceinline__ void store8(float *__restrict__ row, int k, int K, const float (&v)[8]) {
+  if (VEC) {
+    if (k + 8 <= K) {
+      *reinterpret_cast<float4 *>(row + k) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4 *>(row + k + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (k + j < K) row[k + j] = v[j];
+  }
+}
+// 4 consecutive columns c..c+3 of a row (VEC: C % 4 == 0, 16-byte aligned rows)
+template <bool VEC>
+__device__ __forceinline__ void load4(const float *__restrict__ p, int c, int C, bool ok, float (&v)[4]) {
+  if (VEC) {
+    const bool in = ok && (c + 4 <= C);
+    const float4 a = *reinterpret_cast<const float4 *>(p + (in ? c : 0));
+    v[0] = in ? a.x : 0.f; v[1] = in ? a.y : 0.f; v[2] = in ? a.z : 0.f; v[3] = in ? a.w : 0.f;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = (ok && c + j < C) ? p[c + j] : 0.f;
+  }
+}
+template <bool VEC>
+__device__ __forceinline__ void store4(float *__restrict__ p, int c, int C, const float (&v)[4]) {
+  if (VEC) { if (c + 4 <= C) *reinterpret_cast<float4 *>(p + c) = make_float4(v[0], v[1], v[2], v[3]); }
+  else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (c + j < C) p[c + j] = v[j];
+  }
+}
 
-// Sum the NW per-wave partial tiles of s-tile `nt` in fixed wave order (deterministic).
-template <int NT>
+// ---- tile geometry ---------------------------------------------------------------------------------
+// SMALL = false: v_mfma_f32_16x16x4_f32, D[16 rows][16 streams]; lane l feeds A row l&15 / B stream l&15
+//                of k-group l>>4 and receives rows 4*(l>>4)+{0..3} of stream l&15.
+// SMALL = true : NumStream <= 4.  v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4x1 blocks, same FLOP rate):
+//                block b = lane>>2 is used as (row group b&3, k-group b>>2), so a lane feeds the SAME A
+//                element as above (row l&15, k-group l>>4) but B stream l&3, and receives rows
+//                4*((l>>2)&3)+{0..3} of stream l&3 for ITS k-group; the 4 k-groups are added in the
+//                fixed-order LDS combine.  No lanes are wasted on padding streams (4x fewer MFMA cycles).
+template <bool SMALL> struct Geo {
+  static constexpr int STREAMS = SMALL ? 4 : 16;                       // streams per MFMA tile
+  __device__ static __forceinline__ int bstream(int lane) { return SMALL ? (lane & 3) : (lane & 15); }
+  __device__ static __forceinline__ int q(int lane) { return SMALL ? ((lane >> 2) & 3) : (lane >> 4); }
+  __device__ static __forceinline__ bool owner(int lane) { return SMALL ? lane < 16 : true; }
+  __device__ static __forceinline__ f32x4 mma(float a, float b, f32x4 c) {
+    if (SMALL) return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// Sum the per-wave (and, for SMALL, per-k-group) partial tiles of s-tile `nt` in a fixed order.
+template <int NT, bool SMALL>
 __device__ __forceinline__ f32x4 reduce_tile(const f32x4 (*red)[NT][64], int nt, int lane) {
   f32x4 v = red[0][nt][lane];
+  if (SMALL) {
 #pragma unroll
-  for (int w = 1; w < NW; w++) v += red[w][nt][lane];
+    for (int g = 1; g < 4; g++) v += red[0][nt][lane + 16 * g];
+  }
+#pragma unroll
+  for (int w = 1; w < NW; w++) {
+    v += red[w][nt][lane];
+    if (SMALL) {
+#pragma unroll
+      for (int g = 1; g < 4; g++) v += red[w][nt][lane + 16 * g];
+    }
+  }
   return v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// state bridge (...streams.h:231, :331): only the c and r column groups are ever consumed.
-// ---------------------------------------------------------------------------------------------
-__global__ void k_begin(int S, int C, int R, const float *__restrict__ prev_c, const float *__restrict__ prev_r,
-                        float *__restrict__ cc, float *__restrict__ rr) {
-  const int n = S * C + S * R;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (i < S * C) cc[i] = prev_c[i]; else rr[i - S * C] = prev_r[i - S * C];
+// K loop shared by the step kernels.  nch chunks of 32 are dealt round-robin to the NW waves; CPW
+// chunks per wave are fetched (A and every B tile) before any MFMA so that all loads of a
+// super-iteration are in flight together.  afetch(ch, on, av) / bfetch(ch, nt, on, bv) fill 8 floats;
+// bpost(ch, nt, on, bv) runs after the MFMAs (side stores of the fetched B operand).
+template <int NT, int CPW, bool SMALL, class AF, class BF, class BP>
+__device__ __forceinline__ void mma_k_loop(int nch, int wave, f32x4 (&acc)[NT][2], const AF &afetch,
+                                           const BF &bfetch, const BP &bpost) {
+  for (int base = 0; base < nch; base += CPW * NW) {
+    float av[CPW][8];
+    float bv[CPW][NT][8];
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+      const int ch = base + wave + c * NW;
+      const bool on = ch < nch;
+      afetch(ch, on, av[c]);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) bfetch(ch, nt, on, bv[c][nt]);
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; c++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[nt][j & 1] = Geo<SMALL>::mma(av[c][j], bv[c][nt][j], acc[nt][j & 1]);
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+      const int ch = base + wave + c * NW;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) bpost(ch, nt, ch < nch, bv[c][nt]);
+    }
   }
 }
-__global__ void k_end(int S, int C, int R, int T, float *__restrict__ prev_c, float *__restrict__ prev_r,
-                      const float *__restrict__ cc, const float *__restrict__ rr) {
-  const int n = S * C + S * R;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (i < S * C) prev_c[i] = cc[(size_t)T * S * C + i];
-    else prev_r[i - S * C] = rr[(size_t)T * S * R + (i - S * C)];
-  }
-}
+struct NoPost { template <class... A> __device__ __forceinline__ void operator()(A &&...) const {} };
+
+#define STEP_PROLOGUE()                                                                          \
+  const int lane = threadIdx.x & 63;                                                             \
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                             \
+  const int i16 = lane & 15, kg = lane >> 4;                                                     \
+  const int bs = Geo<SMALL>::bstream(lane), q = Geo<SMALL>::q(lane);                             \
+  constexpr int TS_ = Geo<SMALL>::STREAMS;                                                       \
+  (void)i16; (void)kg; (void)bs; (void)q
 
 // ---------------------------------------------------------------------------------------------
-// forward step 1/2: gates + cell.  One workgroup = 4 cells x 4 gates (16 weight rows) x 16*NT streams.
+// forward step 1/2: gates + cell.  One workgroup = 4 cells x 4 gates (16 weight rows) x NT stream tiles.
 // tile row i -> (cell c0 + i/4, gate i%4) so that after the MFMA a lane owns g,i,f,o of ONE
 // (cell, stream) pair in its four accumulator registers and the cell math is lane-local.
 // ---------------------------------------------------------------------------------------------
 struct GatesArgs {
-  int C, R, S, t;
-  const float *wr, *pi, *pf, *po;
+  int C, R, S, I, t;
+  const float *wr, *wx, *bias, *pi, *pf, *po;
   float *gifo, *cc, *hh, *mm;
-  const float *rr;
-  int vecW, vecB;
+  const float *cprev, *rprev;     // c(t-1) [S x C], r(t-1) [S x R]
+  const float *x; int x_stride;   // frame-t input rows [S x I] (FUSEX)
+  float *c_mirror, *r_mirror;     // time block 0 of cc / rr at t == 1 (BPTT reads them), else null
+  float *c_save;                  // prev_c at t == T, else null
 };
 
-template <int NT>
+template <int NT, int CPW, bool VEC, bool SMALL, bool FUSEX>
 __global__ __launch_bounds__(NW * 64) void k_gates_step(GatesArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i16 = lane & 15, kg = lane >> 4;
-  const int C = a.C, R = a.R, S = a.S, t = a.t;
+  STEP_PROLOGUE();
+  const int C = a.C, R = a.R, S = a.S, I = a.I, t = a.t;
   const int c0 = blockIdx.x * 4;
-  const int sbase = blockIdx.y * 16 * NT;
+  const int sbase = blockIdx.y * TS_ * NT;
 
+  // ---- epilogue operands first: wave nt owns s-tile nt; lane = (cell c0+q, stream bs) ----
+  const int e_cell = c0 + q;
+  const int e_s = sbase + wave * TS_ + bs;
+  const bool e_on = wave < NT && Geo<SMALL>::owner(lane) && e_cell < C && e_s < S;
+  const int l_cell = e_on ? e_cell : 0, l_s = e_on ? e_s : 0;          // clamped: loads are unconditional
+  const size_t e_row = (size_t)t * S + l_s;
+  float pre[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) pre[g] = FUSEX ? a.bias[g * C + l_cell] : a.gifo[e_row * 4 * C + g * C + l_cell];
+  const float cp = a.cprev[(size_t)l_s * C + l_cell];
+  const float wpi = a.pi[l_cell], wpf = a.pf[l_cell], wpo = a.po[l_cell];
+
+  // ---- contraction over [r(t-1) | x(t)] ----
   const int cell_a = c0 + (i16 >> 2), gate_a = i16 & 3;
   const bool row_ok = cell_a < C;
-  const float *wrow = a.wr + (size_t)(gate_a * C + (row_ok ? cell_a : 0)) * R;
-  const float *rprev = a.rr + (size_t)(t - 1) * S * R;
+  const size_t wrow_idx = (size_t)gate_a * C + (row_ok ? cell_a : 0);
+  const float *wr_row = a.wr + wrow_idx * R;
+  const float *wx_row = FUSEX ? a.wx + wrow_idx * I : nullptr;
+  const int nchR = (R + KCH - 1) / KCH;
+  const int nch = nchR + (FUSEX ? (I + KCH - 1) / KCH : 0);
+  const bool mirror_r = a.r_mirror != nullptr && blockIdx.x == 0 && (SMALL ? q == 0 : true);
 
   f32x4 acc[NT][2];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) { acc[nt][0] = (f32x4){0, 0, 0, 0}; acc[nt][1] = (f32x4){0, 0, 0, 0}; }
 
-  for (int ch = wave; ch * KCH < R; ch += NW) {
-    const int k = ch * KCH + kg * 8;
-    float av[8];
-    load8(wrow, k, R, row_ok, a.vecW, av);
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      const int s = sbase + nt * 16 + i16;
-      float bv[8];
-      load8(rprev + (size_t)(s < S ? s : 0) * R, k, R, s < S, a.vecB, bv);
-#pragma unroll
-      for (int j = 0; j < 8; j++) acc[nt][j & 1] = MFMA16(av[j], bv[j], acc[nt][j & 1]);
-    }
-  }
+  auto afetch = [&](int ch, bool on, float (&v)[8]) {
+    if (!FUSEX || ch < nchR) load8<VEC>(wr_row, ch * KCH + kg * 8, R, on && row_ok, v);
+    else load8<VEC>(wx_row, (ch - nchR) * KCH + kg * 8, I, on && row_ok, v);
+  };
+  auto bfetch = [&](int ch, int nt, bool on, float (&v)[8]) {
+    const int s = sbase + nt * TS_ + bs;
+    const bool ok = on && s < S;
+    if (!FUSEX || ch < nchR) load8<VEC>(a.rprev + (size_t)(ok ? s : 0) * R, ch * KCH + kg * 8, R, ok, v);
+    else load8<VEC>(a.x + (size_t)(ok ? s : 0) * a.x_stride, (ch - nchR) * KCH + kg * 8, I, ok, v);
+  };
+  auto bpost = [&](int ch, int nt, bool on, const float (&v)[8]) {      // :231 (r columns of block 0)
+    const int s = sbase + nt * TS_ + bs;
+    if (mirror_r && on && s < S && ch < nchR) store8<VEC>(a.r_mirror + (size_t)s * R, ch * KCH + kg * 8, R, v);
+  };
+  mma_k_loop<NT, CPW, SMALL>(nch, wave, acc, afetch, bfetch, bpost);
 
   __shared__ f32x4 red[NW][NT][64];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) red[wave][nt][lane] = acc[nt][0] + acc[nt][1];
   __syncthreads();
 
-  for (int nt = wave; nt < NT; nt += NW) {
-    const f32x4 v = reduce_tile<NT>(red, nt, lane);
-    const int cell = c0 + kg;
-    const int s = sbase + nt * 16 + i16;
-    if (cell < C && s < S) {
-      const size_t row = (size_t)t * S + s, rowp = row - S;
-      float *gp = a.gifo + row * 4 * C + cell;
-      const float cp = a.cc[rowp * C + cell];
-      float ag = v.x + gp[0];
-      float ai = v.y + gp[C];
-      float af = v.z + gp[2 * C];
-      float ao = v.w + gp[3 * C];
-      ai += a.pi[cell] * cp;                       // :278
-      af += a.pf[cell] * cp;                       // :281
-      const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
-      float c = gg * gi;                           // :291
-      c = c + cp * gf;                             // :294
-      c = c < -50.f ? -50.f : c;                   // :296
-      c = c > 50.f ? 50.f : c;                     // :297
-      const float h = k_tanh(c);                   // :300
-      ao += a.po[cell] * c;                        // :303
-      const float go = k_sigmoid(ao);              // :306
-      const float m = h * go;                      // :309
-      gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
-      a.cc[row * C + cell] = c;
-      a.hh[row * C + cell] = h;
-      a.mm[row * C + cell] = m;
-    }
+  if (e_on) {
+    const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
+    float ag = v.x + pre[0];
+    float ai = v.y + pre[1];
+    float af = v.z + pre[2];
+    float ao = v.w + pre[3];
+    ai += wpi * cp;                                // :278
+    af += wpf * cp;                                // :281
+    const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
+    float c = gg * gi;                             // :291
+    c = c + cp * gf;                               // :294
+    c = c < -50.f ? -50.f : c;                     // :296
+    c = c > 50.f ? 50.f : c;                       // :297
+    const float h = k_tanh(c);                     // :300
+    ao += wpo * c;                                 // :303
+    const float go = k_sigmoid(ao);                // :306
+    const float m = h * go;                        // :309
+    float *gp = a.gifo + e_row * 4 * C + e_cell;
+    gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
+    a.cc[e_row * C + e_cell] = c;
+    a.hh[e_row * C + e_cell] = h;
+    a.mm[e_row * C + e_cell] = m;
+    if (a.c_mirror) a.c_mirror[(size_t)e_s * C + e_cell] = cp;   // :231 (c columns)
+    if (a.c_save) a.c_save[(size_t)e_s * C + e_cell] = c;         // :331 (c columns)
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward step 2/2: recurrent projection r(t) = m(t) * W_r_m^T (:312), also written to `out` (:328).
-// One workgroup = 16 projection rows x 16*NT streams; lane owns 4 consecutive r columns.
+// forward step 2/2: recurrent projection r(t) = m(t) * W_r_m^T (:312), also written to `out` (:328)
+// and, at t == T, to the carried state (:331).  One workgroup = 16 projection rows x NT stream tiles;
+// lane owns 4 consecutive r columns.
 // ---------------------------------------------------------------------------------------------
 struct ProjArgs {
   int C, R, S, t;
   const float *wm, *mm;
-  float *rr, *out;
+  float *rr, *out, *r_save;
   int out_stride;
-  int vecW, vecB, vecR, vecOut;
+  int vecOut;
 };
 
-template <int NT>
+template <int NT, int CPW, bool VEC, bool SMALL>
 __global__ __launch_bounds__(NW * 64) void k_proj_step(ProjArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i16 = lane & 15, kg = lane >> 4;
+  STEP_PROLOGUE();
   const int C = a.C, R = a.R, S = a.S, t = a.t;
   const int n0 = blockIdx.x * 16;
-  const int sbase = blockIdx.y * 16 * NT;
+  const int sbase = blockIdx.y * TS_ * NT;
   const bool row_ok = n0 + i16 < R;
   const float *wrow = a.wm + (size_t)(row_ok ? n0 + i16 : 0) * C;
   const float *mrow = a.mm + (size_t)t * S * C;
@@ -204,110 +318,106 @@ __global__ __launch_bounds__(NW * 64) void k_proj_step(ProjArgs a) {
   f32x4 acc[NT][2];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) { acc[nt][0] = (f32x4){0, 0, 0, 0}; acc[nt][1] = (f32x4){0, 0, 0, 0}; }
+  auto afetch = [&](int ch, bool on, float (&v)[8]) { load8<VEC>(wrow, ch * KCH + kg * 8, C, on && row_ok, v); };
+  auto bfetch = [&](int ch, int nt, bool on, float (&v)[8]) {
+    const int s = sbase + nt * TS_ + bs;
+    const bool ok = on && s < S;
+    load8<VEC>(mrow + (size_t)(ok ? s : 0) * C, ch * KCH + kg * 8, C, ok, v);
+  };
+  mma_k_loop<NT, CPW, SMALL>((C + KCH - 1) / KCH, wave, acc, afetch, bfetch, NoPost());
 
-  for (int ch = wave; ch * KCH < C; ch += NW) {
-    const int k = ch * KCH + kg * 8;
-    float av[8];
-    load8(wrow, k, C, row_ok, a.vecW, av);
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      const int s = sbase + nt * 16 + i16;
-      float bv[8];
-      load8(mrow + (size_t)(s < S ? s : 0) * C, k, C, s < S, a.vecB, bv);
-#pragma unroll
-      for (int j = 0; j < 8; j++) acc[nt][j & 1] = MFMA16(av[j], bv[j], acc[nt][j & 1]);
-    }
-  }
   __shared__ f32x4 red[NW][NT][64];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) red[wave][nt][lane] = acc[nt][0] + acc[nt][1];
   __syncthreads();
 
-  for (int nt = wave; nt < NT; nt += NW) {
-    const f32x4 v = reduce_tile<NT>(red, nt, lane);
-    const int s = sbase + nt * 16 + i16;
-    const int n = n0 + 4 * kg;
+  if (wave < NT && Geo<SMALL>::owner(lane)) {
+    const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
+    const int s = sbase + wave * TS_ + bs;
+    const int n = n0 + 4 * q;
     if (s < S && n < R) {
-      float *rp = a.rr + ((size_t)t * S + s) * R + n;
-      float *op = a.out + (size_t)((t - 1) * S + s) * a.out_stride + n;
-      if (n + 3 < R && a.vecR) *reinterpret_cast<float4 *>(rp) = make_float4(v.x, v.y, v.z, v.w);
-      else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int j = 0; j < 4 && n + j < R; j++) rp[j] = e[j]; }
-      if (n + 3 < R && a.vecOut) *reinterpret_cast<float4 *>(op) = make_float4(v.x, v.y, v.z, v.w);
-      else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int j = 0; j < 4 && n + j < R; j++) op[j] = e[j]; }
+      const float e[4] = {v.x, v.y, v.z, v.w};
+      store4<VEC>(a.rr + ((size_t)t * S + s) * R, n, R, e);
+      float *op = a.out + (size_t)((t - 1) * S + s) * a.out_stride;
+      if (a.vecOut) store4<true>(op, n, R, e); else store4<false>(op, n, R, e);
+      if (a.r_save) store4<VEC>(a.r_save + (size_t)s * R, n, R, e);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward step 1/2: partial d_r(t) = DGIFO(t+1) * W_gifo_r (:391) over one K slice of the 4C gate
-// rows.  grid (R/16, stream groups, KS); slab ks holds the partial sum of its slice.  The consumer
-// (k_dm_step) adds the slabs in fixed order together with out_diff(t) (:367).
+// backward step 1/2: partial products of DGIFO(t+1) [S x 4C] with W_gifo_r (-> d_r(t), :391) and,
+// optionally, W_gifo_x (-> in_diff of frame t+1, :457) over one K slice of the 4C gate rows.
+// grid (R tiles + I tiles, stream groups, KS); slab ks holds the partial sum of its slice, the
+// consumer (k_dm_step) adds the slabs in fixed order.
 // ---------------------------------------------------------------------------------------------
 struct DrArgs {
-  int C, R, S, t;
-  const float *wrT;      // [R x 4C]
+  int C, R, I, S, t;
+  const float *wrT, *wxT;   // [R x 4C], [I x 4C]
   const float *dgifo;
-  float *part;           // [KS][S][R]
-  int klen;              // K slice length (multiple of KCH)
-  int vecW, vecB, vecR;
+  float *part;              // [KS][S][R]
+  float *xpart;             // [KS][S][x_ld]  (or in_diff rows of frame 1 when t == 0, KS == 1)
+  int x_ld;
+  int ntr;                  // number of 16-row tiles over R in grid.x (0 at t == 0)
+  int klen;                 // K slice length (multiple of KCH)
+  int vecX;
 };
 
-template <int NT>
+template <int NT, int CPW, bool VEC, bool SMALL>
 __global__ __launch_bounds__(NW * 64) void k_dr_step(DrArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i16 = lane & 15, kg = lane >> 4;
-  const int R = a.R, S = a.S, K = 4 * a.C;
-  const int n0 = blockIdx.x * 16;
-  const int sbase = blockIdx.y * 16 * NT;
+  STEP_PROLOGUE();
+  const int R = a.R, I = a.I, S = a.S, K = 4 * a.C;
+  const bool is_x = (int)blockIdx.x >= a.ntr;
+  const int n0 = (is_x ? (int)blockIdx.x - a.ntr : (int)blockIdx.x) * 16;
+  const int N = is_x ? I : R;
+  const int sbase = blockIdx.y * TS_ * NT;
   const int ks = blockIdx.z;
   const int kbeg = ks * a.klen;
   const int kend = min(K, kbeg + a.klen);
-  const bool row_ok = n0 + i16 < R;
-  const float *wrow = a.wrT + (size_t)(row_ok ? n0 + i16 : 0) * K;
+  const bool row_ok = n0 + i16 < N;
+  const float *wrow = (is_x ? a.wxT : a.wrT) + (size_t)(row_ok ? n0 + i16 : 0) * K;
   const float *drow = a.dgifo + (size_t)(a.t + 1) * S * K;
 
   f32x4 acc[NT][2];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) { acc[nt][0] = (f32x4){0, 0, 0, 0}; acc[nt][1] = (f32x4){0, 0, 0, 0}; }
+  auto afetch = [&](int ch, bool on, float (&v)[8]) { load8<VEC>(wrow, kbeg + ch * KCH + kg * 8, kend, on && row_ok, v); };
+  auto bfetch = [&](int ch, int nt, bool on, float (&v)[8]) {
+    const int s = sbase + nt * TS_ + bs;
+    const bool ok = on && s < S;
+    load8<VEC>(drow + (size_t)(ok ? s : 0) * K, kbeg + ch * KCH + kg * 8, kend, ok, v);
+  };
+  mma_k_loop<NT, CPW, SMALL>(kend > kbeg ? (kend - kbeg + KCH - 1) / KCH : 0, wave, acc, afetch, bfetch, NoPost());
 
-  for (int kc = kbeg + wave * KCH; kc < kend; kc += NW * KCH) {
-    const int k = kc + kg * 8;
-    float av[8];
-    load8(wrow, k, kend, row_ok, a.vecW, av);
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      const int s = sbase + nt * 16 + i16;
-      float bv[8];
-      load8(drow + (size_t)(s < S ? s : 0) * K, k, kend, s < S, a.vecB, bv);
-#pragma unroll
-      for (int j = 0; j < 8; j++) acc[nt][j & 1] = MFMA16(av[j], bv[j], acc[nt][j & 1]);
-    }
-  }
   __shared__ f32x4 red[NW][NT][64];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) red[wave][nt][lane] = acc[nt][0] + acc[nt][1];
   __syncthreads();
 
-  for (int nt = wave; nt < NT; nt += NW) {
-    const f32x4 v = reduce_tile<NT>(red, nt, lane);
-    const int s = sbase + nt * 16 + i16;
-    const int n = n0 + 4 * kg;
-    if (s < S && n < R) {
-      float *pp = a.part + ((size_t)ks * S + s) * R + n;
-      if (n + 3 < R && a.vecR) *reinterpret_cast<float4 *>(pp) = make_float4(v.x, v.y, v.z, v.w);
-      else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int j = 0; j < 4 && n + j < R; j++) pp[j] = e[j]; }
+  if (wave < NT && Geo<SMALL>::owner(lane)) {
+    const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
+    const int s = sbase + wave * TS_ + bs;
+    const int n = n0 + 4 * q;
+    if (s < S && n < N) {
+      const float e[4] = {v.x, v.y, v.z, v.w};
+      if (is_x) {
+        float *xp = a.xpart + ((size_t)ks * S + s) * a.x_ld;
+        if (a.vecX) store4<true>(xp, n, I, e); else store4<false>(xp, n, I, e);
+      } else {
+        store4<VEC>(a.part + ((size_t)ks * S + s) * R, n, R, e);
+      }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward step 2/2: d_r(t) = out_diff(t) + sum of slabs; d_m = d_r * W_r_m (:408) and the whole
-// elementwise BPTT cell math (:411-440).  One workgroup = 16 cells x 16*NT streams; lane owns 4
+// elementwise BPTT cell math (:411-440).  One workgroup = 16 cells x NT stream tiles; lane owns 4
 // consecutive cells of one stream.  Workgroup x==0 also materialises d_r(t) (needed by the
-// W_r_m gradient, :486).
+// W_r_m gradient, :486); the last workgroup also reduces the in_diff slabs of frame t+1.
 // ---------------------------------------------------------------------------------------------
 struct DmArgs {
-  int C, R, S, T, t;
+  int C, R, I, S, T, t;
   const float *wmT;       // [C x R]
   const float *pi, *pf, *po;
   const float *gifo, *cc, *hh;
@@ -316,121 +426,508 @@ struct DmArgs {
   int nslab;              // 0 at t == T (the t+1 block is all zero, :351)
   const float *out_diff;
   int od_stride;
-  int vecW, vecR, vecOD, vecC;
+  const float *xpart;     // [KS][S][I] in_diff slabs of frame t+1 (null: nothing to reduce)
+  float *in_diff;         // rows of frame t+1
+  int id_stride;
 };
 
-__device__ __forceinline__ void load_dr8(const DmArgs &a, int s, int k, bool ok, float (&v)[8]) {
-  const int R = a.R, S = a.S;
-  load8(a.out_diff + (size_t)((a.t - 1) * S + (ok ? s : 0)) * a.od_stride, k, R, ok, a.vecOD, v);
-  for (int ks = 0; ks < a.nslab; ks++) {
-    float p[8];
-    load8(a.part + ((size_t)ks * S + (ok ? s : 0)) * R, k, R, ok, a.vecR, p);
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] += p[j];
-  }
-}
-
-template <int NT>
+template <int NT, int CPW, bool VEC, bool SMALL>
 __global__ __launch_bounds__(NW * 64) void k_dm_step(DmArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i16 = lane & 15, kg = lane >> 4;
+  STEP_PROLOGUE();
   const int C = a.C, R = a.R, S = a.S, t = a.t;
   const int c0 = blockIdx.x * 16;
-  const int sbase = blockIdx.y * 16 * NT;
+  const int sbase = blockIdx.y * TS_ * NT;
+  const bool last = (t == a.T);
+
+  // ---- side job of the last workgroup: in_diff(t+1) = sum of its split-K slabs (:457) ----
+  if (a.xpart && blockIdx.x == gridDim.x - 1) {
+    const int I = a.I;
+    for (int idx = sbase * I + threadIdx.x; idx < min(S, sbase + TS_ * NT) * I; idx += NW * 64) {
+      const int s = idx / I, n = idx - s * I;
+      float p[KSMAX];
+#pragma unroll
+      for (int ks = 0; ks < KSMAX; ks++) p[ks] = a.xpart[((size_t)(ks < a.nslab ? ks : 0) * S + s) * I + n];
+      float sum = p[0];
+#pragma unroll
+      for (int ks = 1; ks < KSMAX; ks++) sum += ks < a.nslab ? p[ks] : 0.f;
+      a.in_diff[(size_t)s * a.id_stride + n] = sum;
+    }
+  }
+
+  // ---- epilogue operands first: wave nt owns s-tile nt; lane = (stream, cells cb..cb+3) ----
+  const int e_s = sbase + wave * TS_ + bs;
+  const int cb = c0 + 4 * q;
+  const bool e_on = wave < NT && Geo<SMALL>::owner(lane) && e_s < S && cb < C;
+  const size_t row = (size_t)t * S + (e_on ? e_s : 0), rown = row + S, rowp = row - S;
+  float yg[4], yi[4], yf[4], yo[4], yh[4], cpv[4], dcn[4], fn[4], din[4], dfn[4], wpi[4], wpf[4], wpo[4];
+  {
+    const float *yp = a.gifo + row * 4 * C;
+    load4<VEC>(yp, cb, C, e_on, yg);
+    load4<VEC>(yp + C, cb, C, e_on, yi);
+    load4<VEC>(yp + 2 * C, cb, C, e_on, yf);
+    load4<VEC>(yp + 3 * C, cb, C, e_on, yo);
+    load4<VEC>(a.hh + row * C, cb, C, e_on, yh);
+    load4<VEC>(a.cc + rowp * C, cb, C, e_on, cpv);
+    const bool n_on = e_on && !last;
+    const size_t rn = last ? row : rown;                 // clamped: block T+1 is never dereferenced
+    load4<VEC>(a.dc + rn * C, cb, C, n_on, dcn);
+    load4<VEC>(a.gifo + rn * 4 * C + 2 * C, cb, C, n_on, fn);
+    load4<VEC>(a.dgifo + rn * 4 * C + C, cb, C, n_on, din);
+    load4<VEC>(a.dgifo + rn * 4 * C + 2 * C, cb, C, n_on, dfn);
+    load4<VEC>(a.pi, cb, C, e_on, wpi);
+    load4<VEC>(a.pf, cb, C, e_on, wpf);
+    load4<VEC>(a.po, cb, C, e_on, wpo);
+  }
+
   const bool row_ok = c0 + i16 < C;
   const float *wrow = a.wmT + (size_t)(row_ok ? c0 + i16 : 0) * R;
+  const bool write_dr = blockIdx.x == 0 && (SMALL ? q == 0 : true);
 
   f32x4 acc[NT][2];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) { acc[nt][0] = (f32x4){0, 0, 0, 0}; acc[nt][1] = (f32x4){0, 0, 0, 0}; }
-
-  for (int ch = wave; ch * KCH < R; ch += NW) {
+  auto afetch = [&](int ch, bool on, float (&v)[8]) { load8<VEC>(wrow, ch * KCH + kg * 8, R, on && row_ok, v); };
+  auto bfetch = [&](int ch, int nt, bool on, float (&v)[8]) {
+    const int s = sbase + nt * TS_ + bs;
+    const bool ok = on && s < S;
     const int k = ch * KCH + kg * 8;
-    float av[8];
-    load8(wrow, k, R, row_ok, a.vecW, av);
+    const float *odp = a.out_diff + (size_t)((t - 1) * S + (ok ? s : 0)) * a.od_stride;          // :367
+    load8<VEC>(odp, k, R, ok, v);
+    float p[KSMAX][8];
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      const int s = sbase + nt * 16 + i16;
-      float bv[8];
-      load_dr8(a, s, k, s < S, bv);
-      if (blockIdx.x == 0 && s < S) {            // materialise d_r(t) exactly once
-        float *dp = a.dr + ((size_t)t * S + s) * R + k;
-        if (a.vecR && k + 8 <= R) {
-          *reinterpret_cast<float4 *>(dp) = make_float4(bv[0], bv[1], bv[2], bv[3]);
-          *reinterpret_cast<float4 *>(dp + 4) = make_float4(bv[4], bv[5], bv[6], bv[7]);
-        } else {
-          for (int j = 0; j < 8 && k + j < R; j++) dp[j] = bv[j];
-        }
-      }
+    for (int ks = 0; ks < KSMAX; ks++)
+      load8<VEC>(a.part + ((size_t)(ks < a.nslab ? ks : 0) * S + (ok ? s : 0)) * R, k, R, ok && ks < a.nslab, p[ks]);
 #pragma unroll
-      for (int j = 0; j < 8; j++) acc[nt][j & 1] = MFMA16(av[j], bv[j], acc[nt][j & 1]);
-    }
-  }
+    for (int ks = 0; ks < KSMAX; ks++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] += p[ks][j];                                               // :391
+  };
+  auto bpost = [&](int ch, int nt, bool on, const float (&v)[8]) {
+    const int s = sbase + nt * TS_ + bs;
+    if (write_dr && on && s < S) store8<VEC>(a.dr + ((size_t)t * S + s) * R, ch * KCH + kg * 8, R, v);
+  };
+  mma_k_loop<NT, CPW, SMALL>((R + KCH - 1) / KCH, wave, acc, afetch, bfetch, bpost);
+
   __shared__ f32x4 red[NW][NT][64];
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) red[wave][nt][lane] = acc[nt][0] + acc[nt][1];
   __syncthreads();
 
-  for (int nt = wave; nt < NT; nt += NW) {
-    const f32x4 v = reduce_tile<NT>(red, nt, lane);
-    const int s = sbase + nt * 16 + i16;
-    const int cb = c0 + 4 * kg;
-    if (s >= S || cb >= C) continue;
-    const size_t row = (size_t)t * S + s, rown = row + S, rowp = row - S;
-    const bool last = (t == a.T);
+  if (e_on) {
+    const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
     const float dm[4] = {v.x, v.y, v.z, v.w};
     float og[4], oi[4], of[4], oo[4], oc[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int c = cb + j;
-      if (c >= C) { og[j] = oi[j] = of[j] = oo[j] = oc[j] = 0.f; continue; }
-      const float *yp = a.gifo + row * 4 * C + c;
-      const float yg = yp[0], yi = yp[C], yf = yp[2 * C], yo = yp[3 * C];
-      const float yh = a.hh[row * C + c];
-      const float cprev = a.cc[rowp * C + c];
-      float dc_n = 0.f, f_n = 0.f, di_n = 0.f, df_n = 0.f;
-      if (!last) {
-        dc_n = a.dc[rown * C + c];
-        f_n = a.gifo[rown * 4 * C + 2 * C + c];
-        di_n = a.dgifo[rown * 4 * C + C + c];
-        df_n = a.dgifo[rown * 4 * C + 2 * C + c];
-      }
-      const float d_h = k_diff_tanh(dm[j] * yo, yh);           // :411-412
-      const float d_o = k_diff_sigmoid(dm[j] * yh, yo);        // :415-416
-      float d_c = d_h;                                         // :424
-      d_c = d_c + dc_n * f_n;                                  // :425
-      d_c = d_c + a.pi[c] * di_n;                              // :426
-      d_c = d_c + a.pf[c] * df_n;                              // :427
-      d_c = d_c + a.po[c] * d_o;                               // :428
-      of[j] = k_diff_sigmoid(d_c * cprev, yf);                 // :431-432
-      oi[j] = k_diff_sigmoid(d_c * yg, yi);                    // :435-436
-      og[j] = k_diff_tanh(d_c * yi, yg);                       // :439-440
+      const float d_h = k_diff_tanh(dm[j] * yo[j], yh[j]);       // :411-412
+      const float d_o = k_diff_sigmoid(dm[j] * yh[j], yo[j]);    // :415-416
+      float d_c = d_h;                                           // :424
+      d_c = d_c + dcn[j] * fn[j];                                // :425
+      d_c = d_c + wpi[j] * din[j];                               // :426
+      d_c = d_c + wpf[j] * dfn[j];                               // :427
+      d_c = d_c + wpo[j] * d_o;                                  // :428
+      of[j] = k_diff_sigmoid(d_c * cpv[j], yf[j]);               // :431-432
+      oi[j] = k_diff_sigmoid(d_c * yg[j], yi[j]);                // :435-436
+      og[j] = k_diff_tanh(d_c * yi[j], yg[j]);                   // :439-440
       oo[j] = d_o;
       oc[j] = d_c;
     }
-    float *dp = a.dgifo + row * 4 * C + cb;
-    float *dcp = a.dc + row * C + cb;
-    if (a.vecC && cb + 3 < C) {
-      *reinterpret_cast<float4 *>(dp) = make_float4(og[0], og[1], og[2], og[3]);
-      *reinterpret_cast<float4 *>(dp + C) = make_float4(oi[0], oi[1], oi[2], oi[3]);
-      *reinterpret_cast<float4 *>(dp + 2 * C) = make_float4(of[0], of[1], of[2], of[3]);
-      *reinterpret_cast<float4 *>(dp + 3 * C) = make_float4(oo[0], oo[1], oo[2], oo[3]);
-      *reinterpret_cast<float4 *>(dcp) = make_float4(oc[0], oc[1], oc[2], oc[3]);
-    } else {
-      for (int j = 0; j < 4 && cb + j < C; j++) {
-        dp[j] = og[j]; dp[C + j] = oi[j]; dp[2 * C + j] = of[j]; dp[3 * C + j] = oo[j]; dcp[j] = oc[j];
+    float *dp = a.dgifo + row * 4 * C;
+    store4<VEC>(dp, cb, C, og);
+    store4<VEC>(dp + C, cb, C, oi);
+    store4<VEC>(dp + 2 * C, cb, C, of);
+    store4<VEC>(dp + 3 * C, cb, C, oo);
+    store4<VEC>(a.dc + row * C, cb, C, oc);
+  }
+}
+
+// =============================================================================================
+// VECTOR PATH (aligned shapes: R, I, C multiples of 8).  Two rules measured on MI355X shape it
+// (tools/act_anatomy.hip, tools/step_anatomy.hip): a wave-load whose lanes hit 16+ scattered rows
+// costs ~64 L1 lookups (+0.7 us per kernel for an 8 KB operand), while the same bytes fetched
+// lane-contiguous cost +0.1 us.  Therefore
+//   * weights are read from PACKED copies laid out in MFMA A-operand order
+//       pk[tile][chunk][h][lane][4]:  row = rowmap(tile, lane&15), k = chunk*32 + (lane>>4)*8 + h*4 + e
+//     (zero padded), written once per Update by k_pack -> every weight load is a contiguous 1 KB;
+//   * activations are fetched lane-contiguous from their natural [stream][k] layout, staged in LDS
+//     (padded rows, conflict-free ds_read_b128) and read from there in B-operand order.
+// =============================================================================================
+template <int CPW, bool SMALL> struct VGeo {
+  static constexpr int SUPER = CPW * NW;                       // chunks per super-iteration
+  static constexpr int LDB = SUPER * KCH + (SMALL ? 16 : 4);   // LDS row stride (floats): b128 reads conflict-free
+};
+
+// One contraction: acc[nt] += A(tile rows, chunks [0,nch)) * B(streams, same chunks).
+//   apk   : packed weights of this tile, chunk c at apk + c*128 (float4 units)
+//   bload(s, k) -> float4 of B[s][k..k+3] in natural layout (zeros outside), k relative to chunk 0
+//   bside(s, k, v): optional side store of the staged natural-layout value (mirrors)
+template <int NT, int CPW, bool SMALL, class BL, class BS>
+__device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int nch, int rows, float *ldsB,
+                                             int lane, int wave, f32x4 (&acc)[NT][2], const BL &bload, const BS &bside) {
+  constexpr int SUPER = VGeo<CPW, SMALL>::SUPER, LDB = VGeo<CPW, SMALL>::LDB;
+  constexpr int TS_ = Geo<SMALL>::STREAMS;
+  const int bs = Geo<SMALL>::bstream(lane), kg = lane >> 4;
+  for (int base = 0; base < nch; base += SUPER) {
+    const int nc = min(SUPER, nch - base);
+    // (1) this wave's weight chunks: an even contiguous share [c0, c0 + per) of the super-iteration
+    const int per = (nc + NW - 1) / NW;
+    const int c0 = wave * per;
+    float4 a0[CPW], a1[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+      const int cl = min(c0 + c, nc - 1);                      // clamped: always a valid chunk, unused if off
+      const float4 *ap = apk + (size_t)(base + cl) * 128 + lane;
+      a0[c] = ap[0]; a1[c] = ap[64];
+    }
+    // (2) stage B[rows][nc*32] lane-contiguous into LDS
+    const int f4row = nc * 8;
+    for (int idx = threadIdx.x; idx < rows * f4row; idx += NW * 64) {
+      const int s = idx / f4row, k = (idx - s * f4row) * 4;
+      const float4 v = bload(s, base * KCH + k);
+      *reinterpret_cast<float4 *>(ldsB + s * LDB + k) = v;
+      bside(s, base * KCH + k, v);
+    }
+    __syncthreads();
+    // (3) MFMAs
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+      if (c < per && c0 + c < nc) {
+        const float av[8] = {a0[c].x, a0[c].y, a0[c].z, a0[c].w, a1[c].x, a1[c].y, a1[c].z, a1[c].w};
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          const float *bp = ldsB + (nt * TS_ + bs) * LDB + (c0 + c) * KCH + kg * 8;
+          const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(bp + 4);
+          const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+          for (int j = 0; j < 8; j++) acc[nt][j & 1] = Geo<SMALL>::mma(av[j], bv[j], acc[nt][j & 1]);
+        }
+      }
+    }
+    if (base + SUPER < nch) __syncthreads();
+  }
+}
+struct NoSide { __device__ __forceinline__ void operator()(int, int, const float4 &) const {} };
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+#define VEC_PROLOGUE()                                                                           \
+  const int lane = threadIdx.x & 63;                                                             \
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                             \
+  const int bs = Geo<SMALL>::bstream(lane), q = Geo<SMALL>::q(lane);                             \
+  constexpr int TS_ = Geo<SMALL>::STREAMS;                                                       \
+  __shared__ __attribute__((aligned(16))) float ldsB[NT * TS_ * VGeo<CPW, SMALL>::LDB];          \
+  __shared__ f32x4 red[NW][NT][64];                                                              \
+  f32x4 acc[NT][2];                                                                              \
+  _Pragma("unroll") for (int nt = 0; nt < NT; nt++) { acc[nt][0] = (f32x4){0, 0, 0, 0}; acc[nt][1] = (f32x4){0, 0, 0, 0}; } \
+  (void)bs; (void)q
+
+#define VEC_COMBINE()                                                                            \
+  _Pragma("unroll") for (int nt = 0; nt < NT; nt++) red[wave][nt][lane] = acc[nt][0] + acc[nt][1]; \
+  __syncthreads()
+
+struct GatesVArgs {
+  GatesArgs g;
+  const float4 *wpk;     // packed [W_gifo_r | W_gifo_x] : [C/4 tiles][nchR + nchX chunks][2][64]
+  int nch_total;         // chunks per tile in wpk (nchR + nchX)
+};
+
+template <int NT, int CPW, bool SMALL, bool FUSEX>
+__global__ __launch_bounds__(NW * 64) void k_gates_v(GatesVArgs va) {
+  const GatesArgs &a = va.g;
+  VEC_PROLOGUE();
+  const int C = a.C, R = a.R, S = a.S, I = a.I, t = a.t;
+  const int c0 = blockIdx.x * 4;
+  const int sbase = blockIdx.y * TS_ * NT;
+
+  // ---- epilogue operands first: wave nt owns s-tile nt; lane = (cell c0+q, stream bs) ----
+  const int e_cell = c0 + q;
+  const int e_s = sbase + wave * TS_ + bs;
+  const bool e_on = wave < NT && Geo<SMALL>::owner(lane) && e_cell < C && e_s < S;
+  const int l_cell = e_on ? e_cell : 0, l_s = e_on ? e_s : 0;
+  const size_t e_row = (size_t)t * S + l_s;
+  float pre[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) pre[g] = FUSEX ? a.bias[g * C + l_cell] : a.gifo[e_row * 4 * C + g * C + l_cell];
+  const float cp = a.cprev[(size_t)l_s * C + l_cell];
+  const float wpi = a.pi[l_cell], wpf = a.pf[l_cell], wpo = a.po[l_cell];
+
+  const int nchR = R / KCH + (R % KCH != 0);
+  const int Rp = nchR * KCH;
+  const int nch = nchR + (FUSEX ? (I + KCH - 1) / KCH : 0);
+  const bool mirror_r = a.r_mirror != nullptr && blockIdx.x == 0;
+  auto bload = [&](int sl, int k) -> float4 {             // B = [ r(t-1) | pad | x(t) | pad ]
+    const int s = sbase + sl;
+    if (s >= S) return f4zero();
+    if (k < R) return ldg4(a.rprev + (size_t)s * R + k);
+    if (FUSEX && k >= Rp && k - Rp < I) return ldg4(a.x + (size_t)s * a.x_stride + (k - Rp));
+    return f4zero();
+  };
+  auto bside = [&](int sl, int k, const float4 &v) {      // :231 (r columns of time block 0)
+    const int s = sbase + sl;
+    if (mirror_r && s < S && k < R) *reinterpret_cast<float4 *>(a.r_mirror + (size_t)s * R + k) = v;
+  };
+  vec_contract<NT, CPW, SMALL>(va.wpk + (size_t)blockIdx.x * va.nch_total * 128, nch, NT * TS_, ldsB, lane, wave, acc,
+                               bload, bside);
+  VEC_COMBINE();
+
+  if (e_on) {
+    const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
+    float ag = v.x + pre[0];
+    float ai = v.y + pre[1];
+    float af = v.z + pre[2];
+    float ao = v.w + pre[3];
+    ai += wpi * cp;                                // :278
+    af += wpf * cp;                                // :281
+    const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
+    float c = gg * gi;                             // :291
+    c = c + cp * gf;                               // :294
+    c = c < -50.f ? -50.f : c;                     // :296
+    c = c > 50.f ? 50.f : c;                       // :297
+    const float h = k_tanh(c);                     // :300
+    ao += wpo * c;                                 // :303
+    const float go = k_sigmoid(ao);                // :306
+    const float m = h * go;                        // :309
+    float *gp = a.gifo + e_row * 4 * C + e_cell;
+    gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
+    a.cc[e_row * C + e_cell] = c;
+    a.hh[e_row * C + e_cell] = h;
+    a.mm[e_row * C + e_cell] = m;
+    if (a.c_mirror) a.c_mirror[(size_t)e_s * C + e_cell] = cp;   // :231 (c columns)
+    if (a.c_save) a.c_save[(size_t)e_s * C + e_cell] = c;         // :331 (c columns)
+  }
+}
+
+struct ProjVArgs { ProjArgs g; const float4 *wpk; };   // packed W_r_m: [R/16 tiles][C/32 chunks][2][64]
+
+template <int NT, int CPW, bool SMALL>
+__global__ __launch_bounds__(NW * 64) void k_proj_v(ProjVArgs va) {
+  const ProjArgs &a = va.g;
+  VEC_PROLOGUE();
+  const int C = a.C, R = a.R, S = a.S, t = a.t;
+  const int n0 = blockIdx.x * 16;
+  const int sbase = blockIdx.y * TS_ * NT;
+  const int nch = (C + KCH - 1) / KCH;
+  const float *mrow = a.mm + (size_t)t * S * C;
+  auto bload = [&](int sl, int k) -> float4 {
+    const int s = sbase + sl;
+    return (s < S && k < C) ? ldg4(mrow + (size_t)s * C + k) : f4zero();
+  };
+  vec_contract<NT, CPW, SMALL>(va.wpk + (size_t)blockIdx.x * nch * 128, nch, NT * TS_, ldsB, lane, wave, acc, bload, NoSide());
+  VEC_COMBINE();
+  if (wave < NT && Geo<SMALL>::owner(lane)) {
+    const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
+    const int s = sbase + wave * TS_ + bs;
+    const int n = n0 + 4 * q;
+    if (s < S && n < R) {
+      const float e[4] = {v.x, v.y, v.z, v.w};
+      store4<true>(a.rr + ((size_t)t * S + s) * R, n, R, e);
+      float *op = a.out + (size_t)((t - 1) * S + s) * a.out_stride;
+      if (a.vecOut) store4<true>(op, n, R, e); else store4<false>(op, n, R, e);
+      if (a.r_save) store4<true>(a.r_save + (size_t)s * R, n, R, e);
+    }
+  }
+}
+
+struct DrVArgs { DrArgs g; const float4 *wpk; int nch_total; };   // packed [W_gifo_r^T ; W_gifo_x^T]: [(R+I)/16 tiles][4C/32][2][64]
+
+template <int NT, int CPW, bool SMALL>
+__global__ __launch_bounds__(NW * 64) void k_dr_v(DrVArgs va) {
+  const DrArgs &a = va.g;
+  VEC_PROLOGUE();
+  const int R = a.R, I = a.I, S = a.S, K = 4 * a.C;
+  const bool is_x = (int)blockIdx.x >= a.ntr;
+  const int ntR = (R + 15) / 16;                               // x tiles follow the R tiles in the packed array
+  const int tile = is_x ? ntR + ((int)blockIdx.x - a.ntr) : (int)blockIdx.x;
+  const int n0 = (is_x ? (int)blockIdx.x - a.ntr : (int)blockIdx.x) * 16;
+  const int N = is_x ? I : R;
+  const int sbase = blockIdx.y * TS_ * NT;
+  const int ks = blockIdx.z;
+  const int kbeg = ks * a.klen;
+  const int kend = min(K, kbeg + a.klen);
+  const float *drow = a.dgifo + (size_t)(a.t + 1) * S * K;
+  auto bload = [&](int sl, int k) -> float4 {
+    const int s = sbase + sl;
+    return (s < S && kbeg + k < kend) ? ldg4(drow + (size_t)s * K + kbeg + k) : f4zero();
+  };
+  vec_contract<NT, CPW, SMALL>(va.wpk + ((size_t)tile * va.nch_total + kbeg / KCH) * 128,
+                               kend > kbeg ? (kend - kbeg + KCH - 1) / KCH : 0, NT * TS_, ldsB, lane, wave, acc, bload, NoSide());
+  VEC_COMBINE();
+  if (wave < NT && Geo<SMALL>::owner(lane)) {
+    const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
+    const int s = sbase + wave * TS_ + bs;
+    const int n = n0 + 4 * q;
+    if (s < S && n < N) {
+      const float e[4] = {v.x, v.y, v.z, v.w};
+      if (is_x) {
+        float *xp = a.xpart + ((size_t)ks * S + s) * a.x_ld;
+        if (a.vecX) store4<true>(xp, n, I, e); else store4<false>(xp, n, I, e);
+      } else {
+        store4<true>(a.part + ((size_t)ks * S + s) * R, n, R, e);
       }
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// generic LDS-tiled MFMA GEMM for the batched products outside the time loop.
-// 64x64 output tile, BK = 16, 256 threads = 4 waves (2x2), each wave 32x32 = 2x2 MFMA tiles.
-// ---------------------------------------------------------------------------------------------
-constexpr int GT = 64, GK = 16, GLD = 80;   // LDS row stride 80 floats: k-groups land on disjoint banks
+struct DmVArgs { DmArgs g; const float4 *wpk; };   // packed W_r_m^T: [C/16 tiles][R/32 chunks][2][64]
 
-struct GemmArgs {
+template <int NT, int CPW, bool SMALL>
+__global__ __launch_bounds__(NW * 64) void k_dm_v(DmVArgs va) {
+  const DmArgs &a = va.g;
+  VEC_PROLOGUE();
+  const int C = a.C, R = a.R, S = a.S, t = a.t;
+  const int c0 = blockIdx.x * 16;
+  const int sbase = blockIdx.y * TS_ * NT;
+  const bool last = (t == a.T);
+
+  // ---- side job of the last workgroup: in_diff(t+1) = sum of its split-K slabs (:457) ----
+  if (a.xpart && blockIdx.x == gridDim.x - 1) {
+    const int I = a.I;
+    for (int idx = sbase * I + threadIdx.x; idx < min(S, sbase + TS_ * NT) * I; idx += NW * 64) {
+      const int s = idx / I, n = idx - s * I;
+      float p[KSMAX];
+#pragma unroll
+      for (int ks = 0; ks < KSMAX; ks++) p[ks] = a.xpart[((size_t)(ks < a.nslab ? ks : 0) * S + s) * I + n];
+      float sum = p[0];
+#pragma unroll
+      for (int ks = 1; ks < KSMAX; ks++) sum += ks < a.nslab ? p[ks] : 0.f;
+      a.in_diff[(size_t)s * a.id_stride + n] = sum;
+    }
+  }
+
+  // ---- epilogue operands first: wave nt owns s-tile nt; lane = (stream, cells cb..cb+3) ----
+  const int e_s = sbase + wave * TS_ + bs;
+  const int cb = c0 + 4 * q;
+  const bool e_on = wave < NT && Geo<SMALL>::owner(lane) && e_s < S && cb < C;
+  const size_t row = (size_t)t * S + (e_on ? e_s : 0), rown = row + S, rowp = row - S;
+  float yg[4], yi[4], yf[4], yo[4], yh[4], cpv[4], dcn[4], fn[4], din[4], dfn[4], wpi[4], wpf[4], wpo[4];
+  {
+    const float *yp = a.gifo + row * 4 * C;
+    load4<true>(yp, cb, C, e_on, yg);
+    load4<true>(yp + C, cb, C, e_on, yi);
+    load4<true>(yp + 2 * C, cb, C, e_on, yf);
+    load4<true>(yp + 3 * C, cb, C, e_on, yo);
+    load4<true>(a.hh + row * C, cb, C, e_on, yh);
+    load4<true>(a.cc + rowp * C, cb, C, e_on, cpv);
+    const bool n_on = e_on && !last;
+    const size_t rn = last ? row : rown;                 // clamped: block T+1 is never dereferenced
+    load4<true>(a.dc + rn * C, cb, C, n_on, dcn);
+    load4<true>(a.gifo + rn * 4 * C + 2 * C, cb, C, n_on, fn);
+    load4<true>(a.dgifo + rn * 4 * C + C, cb, C, n_on, din);
+    load4<true>(a.dgifo + rn * 4 * C + 2 * C, cb, C, n_on, dfn);
+    load4<true>(a.pi, cb, C, e_on, wpi);
+    load4<true>(a.pf, cb, C, e_on, wpf);
+    load4<true>(a.po, cb, C, e_on, wpo);
+  }
+
+  const int nch = (R + KCH - 1) / KCH;
+  const bool write_dr = blockIdx.x == 0;
+  auto bload = [&](int sl, int k) -> float4 {             // d_r(t) = out_diff(t) + slabs   (:367, :391)
+    const int s = sbase + sl;
+    if (s >= S || k >= R) return f4zero();
+    float4 v = ldg4(a.out_diff + (size_t)((t - 1) * S + s) * a.od_stride + k);
+    float4 p[KSMAX];
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ks++) p[ks] = ldg4(a.part + ((size_t)(ks < a.nslab ? ks : 0) * S + s) * R + k);
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ks++)
+      if (ks < a.nslab) { v.x += p[ks].x; v.y += p[ks].y; v.z += p[ks].z; v.w += p[ks].w; }
+    return v;
+  };
+  auto bside = [&](int sl, int k, const float4 &v) {
+    const int s = sbase + sl;
+    if (write_dr && s < S && k < R) *reinterpret_cast<float4 *>(a.dr + ((size_t)t * S + s) * R + k) = v;
+  };
+  vec_contract<NT, CPW, SMALL>(va.wpk + (size_t)blockIdx.x * nch * 128, nch, NT * TS_, ldsB, lane, wave, acc, bload, bside);
+  VEC_COMBINE();
+
+  if (e_on) {
+    const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
+    const float dm[4] = {v.x, v.y, v.z, v.w};
+    float og[4], oi[4], of[4], oo[4], oc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float d_h = k_diff_tanh(dm[j] * yo[j], yh[j]);       // :411-412
+      const float d_o = k_diff_sigmoid(dm[j] * yh[j], yo[j]);    // :415-416
+      float d_c = d_h;                                           // :424
+      d_c = d_c + dcn[j] * fn[j];                                // :425
+      d_c = d_c + wpi[j] * din[j];                               // :426
+      d_c = d_c + wpf[j] * dfn[j];                               // :427
+      d_c = d_c + wpo[j] * d_o;                                  // :428
+      of[j] = k_diff_sigmoid(d_c * cpv[j], yf[j]);               // :431-432
+      oi[j] = k_diff_sigmoid(d_c * yg[j], yi[j]);                // :435-436
+      og[j] = k_diff_tanh(d_c * yi[j], yg[j]);                   // :439-440
+      oo[j] = d_o;
+      oc[j] = d_c;
+    }
+    float *dp = a.dgifo + row * 4 * C;
+    store4<true>(dp, cb, C, og);
+    store4<true>(dp + C, cb, C, oi);
+    store4<true>(dp + 2 * C, cb, C, of);
+    store4<true>(dp + 3 * C, cb, C, oo);
+    store4<true>(a.dc + row * C, cb, C, oc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pack: (re)build the four packed weight copies from the natural blob + its transposes.
+// One thread per packed float4 (destination-contiguous, so the writes are coalesced 1 KB/wave).
+//   array 0 gates: rows (cell-major: tile row i -> gate i&3, cell 4*tile + i>>2), k over [R | pad | I | pad]
+//   array 1 proj : rows n of W_r_m   [R x C],   k over C
+//   array 2 dr   : rows n of [W_gifo_r^T ; W_gifo_x^T]  ([R x 4C] tiles then [I x 4C] tiles), k over 4C
+//   array 3 dm   : rows c of W_r_m^T [C x R],   k over R
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+  int C, R, I;
+  const float *wx, *wr, *wm, *wrT, *wmT, *wxT;
+  float4 *pk[4];
+  long n4[4];          // float4 count of each array
+  int nch[4];          // chunks per tile
+};
+
+__global__ __launch_bounds__(256) void k_pack(PackArgs a) {
+  const int C = a.C, R = a.R, I = a.I;
+  const long total = a.n4[0] + a.n4[1] + a.n4[2] + a.n4[3];
+  for (long gid = blockIdx.x * 256L + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    int arr = 0; long id = gid;
+    while (id >= a.n4[arr]) { id -= a.n4[arr]; arr++; }
+    const int lane = (int)(id & 63), h = (int)((id >> 6) & 1);
+    const long tc = id >> 7;
+    const int nch = a.nch[arr];
+    const int tile = (int)(tc / nch), ch = (int)(tc - (long)tile * nch);
+    const int i = lane & 15;
+    const int k = ch * KCH + (lane >> 4) * 8 + h * 4;
+    const float *src = nullptr;
+    int klim = 0, koff = k;
+    bool row_ok = false;
+    if (arr == 0) {
+      const int cell = tile * 4 + (i >> 2), gate = i & 3;
+      row_ok = cell < C;
+      const int nchR = (R + KCH - 1) / KCH;
+      if (ch < nchR) { src = a.wr + ((size_t)gate * C + (row_ok ? cell : 0)) * R; klim = R; }
+      else { src = a.wx + ((size_t)gate * C + (row_ok ? cell : 0)) * I; klim = I; koff = k - nchR * KCH; }
+    } else if (arr == 1) {
+      const int n = tile * 16 + i; row_ok = n < R; src = a.wm + (size_t)(row_ok ? n : 0) * C; klim = C;
+    } else if (arr == 2) {
+      const int ntR = (R + 15) / 16;
+      if (tile < ntR) { const int n = tile * 16 + i; row_ok = n < R; src = a.wrT + (size_t)(row_ok ? n : 0) * 4 * C; }
+      else { const int n = (tile - ntR) * 16 + i; row_ok = n < I; src = a.wxT + (size_t)(row_ok ? n : 0) * 4 * C; }
+      klim = 4 * C;
+    } else {
+      const int c = tile * 16 + i; row_ok = c < C; src = a.wmT + (size_t)(row_ok ? c : 0) * R; klim = R;
+    }
+    float4 v = f4zero();
+    if (row_ok && koff + 4 <= klim) v = ldg4(src + koff);     // all extents are multiples of 8 on this path
+    a.pk[arr][id] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-tiled MFMA GEMM tile (64x64 output, BK = 32, 256 threads = 2x2 waves of 32x32).  The next
+// K tile is fetched into registers while the current one is multiplied out of LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int GT = 64, GK = 32, GLD = 80;   // LDS row stride 80 floats: k-groups land on disjoint banks
+
+struct GemmJob {
   int M, N, K;
   const float *A; int lda;
   const float *B; int ldb;
@@ -440,72 +937,56 @@ struct GemmArgs {
   int vecA, vecB;
 };
 
+template <bool TA>
+__device__ __forceinline__ void fetch_tile(const float *__restrict__ P, int ld, bool vec, int X, int K, int x0, int k0,
+                                           int tid, float (&r)[8]) {
+  // operand stored [X x K] (TA=false: 8 consecutive k of one x) or [K x X] (TA=true: 8 consecutive x of one k).
+  // `vec` (block-uniform): rows 16-byte aligned and the contiguous extent a multiple of 8 -> branch-free loads.
+  if (!TA) {
+    const int x = x0 + (tid >> 2), k = k0 + (tid & 3) * 8;
+    const float *row = P + (size_t)(x < X ? x : 0) * ld;
+    if (vec) load8<true>(row, k, K, x < X, r); else load8<false>(row, k, K, x < X, r);
+  } else {
+    const int k = k0 + (tid >> 3), x = x0 + (tid & 7) * 8;
+    const float *row = P + (size_t)(k < K ? k : 0) * ld;
+    if (vec) load8<true>(row, x, X, k < K, r); else load8<false>(row, x, X, k < K, r);
+  }
+}
+template <bool TA>
+__device__ __forceinline__ void stash_tile(float (*Ls)[GLD], int tid, const float (&r)[8]) {
+  if (!TA) {
+    const int x = tid >> 2, k = (tid & 3) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) Ls[k + j][x] = r[j];
+  } else {
+    const int k = tid >> 3, x = (tid & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) Ls[k][x + j] = r[j];
+  }
+}
+
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
-  __shared__ float As[GK][GLD];
-  __shared__ float Bs[GK][GLD];
+__device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, float (*As)[GLD], float (*Bs)[GLD]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kg = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-  const int M = g.M, N = g.N, K = g.K;
-
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
 
-  for (int k0 = 0; k0 < K; k0 += GK) {
-    // ---- stage A tile into As[k][m] ----
-    if (TA) {   // A stored [K x M]
-      const int k = tid >> 4, m4 = (tid & 15) * 4;
-      const int gk = k0 + k, gm = m0 + m4;
-      float v[4] = {0, 0, 0, 0};
-      if (gk < K) {
-        const float *p = g.A + (size_t)gk * g.lda + gm;
-        if (g.vecA && gm + 3 < M) { const float4 q = *reinterpret_cast<const float4 *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-        else { for (int j = 0; j < 4; j++) if (gm + j < M) v[j] = p[j]; }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) As[k][m4 + j] = v[j];
-    } else {    // A stored [M x K]
-      const int m = tid >> 2, k4 = (tid & 3) * 4;
-      const int gm = m0 + m, gk = k0 + k4;
-      float v[4] = {0, 0, 0, 0};
-      if (gm < M) {
-        const float *p = g.A + (size_t)gm * g.lda + gk;
-        if (g.vecA && gk + 3 < K) { const float4 q = *reinterpret_cast<const float4 *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-        else { for (int j = 0; j < 4; j++) if (gk + j < K) v[j] = p[j]; }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) As[k4 + j][m] = v[j];
-    }
-    // ---- stage B tile into Bs[k][n] ----
-    if (TB) {   // B stored [N x K]
-      const int n = tid >> 2, k4 = (tid & 3) * 4;
-      const int gn = n0 + n, gk = k0 + k4;
-      float v[4] = {0, 0, 0, 0};
-      if (gn < N) {
-        const float *p = g.B + (size_t)gn * g.ldb + gk;
-        if (g.vecB && gk + 3 < K) { const float4 q = *reinterpret_cast<const float4 *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-        else { for (int j = 0; j < 4; j++) if (gk + j < K) v[j] = p[j]; }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) Bs[k4 + j][n] = v[j];
-    } else {    // B stored [K x N]
-      const int k = tid >> 4, n4 = (tid & 15) * 4;
-      const int gk = k0 + k, gn = n0 + n4;
-      float v[4] = {0, 0, 0, 0};
-      if (gk < K) {
-        const float *p = g.B + (size_t)gk * g.ldb + gn;
-        if (g.vecB && gn + 3 < N) { const float4 q = *reinterpret_cast<const float4 *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-        else { for (int j = 0; j < 4; j++) if (gn + j < N) v[j] = p[j]; }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) Bs[k][n4 + j] = v[j];
-    }
+  float ra[8], rb[8];
+  fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, 0, tid, ra);
+  fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, 0, tid, rb);   // B [N x K] when TB, else [K x N]
+  for (int k0 = 0; k0 < g.K; k0 += GK) {
+    stash_tile<TA>(As, tid, ra);
+    stash_tile<!TB>(Bs, tid, rb);
     __syncthreads();
+    if (k0 + GK < g.K) {
+      fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0 + GK, tid, ra);
+      fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, k0 + GK, tid, rb);
+    }
 #pragma unroll
     for (int kk = 0; kk < GK / 4; kk++) {
       const int k = kk * 4 + kg;
@@ -523,13 +1004,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
     for (int ni = 0; ni < 2; ni++) {
       const int n = n0 + wc * 32 + ni * 16 + i16;
-      if (n >= N) continue;
+      if (n >= g.N) continue;
       const float bv = g.bias ? g.bias[n] : 0.f;
       const float e[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int m = m0 + wr * 32 + mi * 16 + 4 * kg + r;
-        if (m >= M) continue;
+        if (m >= g.M) continue;
         float *cp = g.Cm + (size_t)m * g.ldc + n;
         float val = e[r] + bv;
         if (g.beta != 0.f) val = g.beta * *cp + val;
@@ -538,69 +1019,126 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     }
 }
 
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm(GemmJob g) {
+  __shared__ float As[GK][GLD];
+  __shared__ float Bs[GK][GLD];
+  gemm_tile<TA, TB>(g, blockIdx.y * GT, blockIdx.x * GT, As, Bs);
+}
+
 // ---------------------------------------------------------------------------------------------
-// bias and peephole gradients (...streams.h:474-484): column sums over the T*S frame rows.
-// block (64 columns x 8 row groups); one column of the 4C gate axis per thread.x.
+// all gradient accumulations of one minibatch in ONE launch (...streams.h:468-487):
+//   blocks [0, nb0)        W_gifo_x_corr = beta*corr + DGIFO^T * in
+//   blocks [nb0, nb1)      W_gifo_r_corr = beta*corr + DGIFO^T * YR[0..T-1]
+//   blocks [nb1, nb2)      W_r_m_corr    = beta*corr + DR^T * YM
+//   blocks [nb2, nb3)      bias / peephole column sums (AddRowSumMat, AddDiagMatMat x3)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_vec_grads(int C, int S, int T, const float *__restrict__ dgifo,
-                                                   const float *__restrict__ cc, float beta,
-                                                   float *__restrict__ g_bias, float *__restrict__ g_pi,
-                                                   float *__restrict__ g_pf, float *__restrict__ g_po) {
+struct GradsArgs {
+  GemmJob wx, wr, wm;
+  int nb0, nb1, nb2;
+  int C, S, T;
+  const float *dgifo, *cc;
+  float beta;
+  float *g_bias, *g_pi, *g_pf, *g_po;
+};
+
+__global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
+  __shared__ float As[GK][GLD];
+  __shared__ float Bs[GK][GLD];
+  const int b = blockIdx.x;
+  if (b < a.nb2) {
+    const GemmJob &g = b < a.nb0 ? a.wx : b < a.nb1 ? a.wr : a.wm;
+    const int lb = b < a.nb0 ? b : b < a.nb1 ? b - a.nb0 : b - a.nb1;
+    const int ntn = (g.N + GT - 1) / GT;
+    gemm_tile<true, false>(g, (lb / ntn) * GT, (lb % ntn) * GT, As, Bs);
+    return;
+  }
+  // column sums over the T*S frame rows; 64 columns of the 4C gate axis x 4 row groups
+  const int C = a.C, S = a.S, rows = a.T * a.S;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + tx;
-  const int rows = T * S;
+  const int col = (b - a.nb2) * 64 + tx;
   float sb = 0.f, sp = 0.f;
   if (col < 4 * C) {
     const int gate = col / C, cell = col - gate * C;
     // DI/DF[1..T] pair with YC[0..T-1]; DO[1..T] pairs with YC[1..T]
-    const float *cbase = cc + (gate == 3 ? (size_t)S * C : 0) + cell;
-    for (int r = ty; r < rows; r += 8) {
-      const float d = dgifo[(size_t)(S + r) * 4 * C + col];
-      sb += d;
-      if (gate != 0) sp += d * cbase[(size_t)r * C];
+    const float *cbase = a.cc + (gate == 3 ? (size_t)S * C : 0) + cell;
+    for (int r = ty; r < rows; r += 4) {
+      const float dv = a.dgifo[(size_t)(S + r) * 4 * C + col];
+      sb += dv;
+      if (gate != 0) sp += dv * cbase[(size_t)r * C];
     }
   }
-  __shared__ float rb[8][64], rp[8][64];
+  float(*rb)[64] = reinterpret_cast<float(*)[64]>(&As[0][0]);
+  float(*rp)[64] = reinterpret_cast<float(*)[64]>(&Bs[0][0]);
   rb[ty][tx] = sb; rp[ty][tx] = sp;
   __syncthreads();
   if (ty == 0 && col < 4 * C) {
-    for (int w = 1; w < 8; w++) { sb += rb[w][tx]; sp += rp[w][tx]; }
+    for (int w = 1; w < 4; w++) { sb += rb[w][tx]; sp += rp[w][tx]; }
     const int gate = col / C, cell = col - gate * C;
-    g_bias[col] = (beta != 0.f ? beta * g_bias[col] : 0.f) + sb;
-    float *gp = gate == 1 ? g_pi : gate == 2 ? g_pf : gate == 3 ? g_po : nullptr;
-    if (gp) gp[cell] = (beta != 0.f ? beta * gp[cell] : 0.f) + sp;
+    a.g_bias[col] = (a.beta != 0.f ? a.beta * a.g_bias[col] : 0.f) + sb;
+    float *gp = gate == 1 ? a.g_pi : gate == 2 ? a.g_pf : gate == 3 ? a.g_po : nullptr;
+    if (gp) gp[cell] = (a.beta != 0.f ? a.beta * gp[cell] : 0.f) + sp;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Update (:504-512) fused with the refresh of the transposed copies the backward kernels read.
+// 32x32 tiles of the three matrices (+ 1024-element chunks of the vector parameters).
+// ---------------------------------------------------------------------------------------------
+struct UpdArgs {
+  float *param, *corr;
+  const float *grad;        // DP: corr = mmt*corr + grad first
+  float mmt, lr, clip;
+  int touch;                // 0: pure repack (no corr / param writes)
+  // three matrices: offset into blob, rows, cols, transposed destination
+  long off[3]; int rows[3], cols[3]; float *dstT[3];
+  int tb[3];                // first block of matrix i;  vector blocks start at tb_vec
+  int tb_vec;
+  long voff, vlen;          // vector parameters (bias + 3 peepholes) are contiguous in the blob
+};
+
+__device__ __forceinline__ float upd_elem(const UpdArgs &a, long idx) {
+  float p = a.param[idx];
+  if (a.touch) {
+    float c = a.corr[idx];
+    if (a.grad) c = a.mmt * c + a.grad[idx];
+    if (a.clip > 0.f) { c = c < -a.clip ? -a.clip : c; c = c > a.clip ? a.clip : c; }
+    if (a.grad || a.clip > 0.f) a.corr[idx] = c;
+    p = p + (-a.lr) * c;
+    a.param[idx] = p;
+  }
+  return p;
+}
+
+__global__ __launch_bounds__(256) void k_update_repack(UpdArgs a) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (b >= a.tb_vec) {
+    const long base = (long)(b - a.tb_vec) * 1024;
+    for (int j = threadIdx.x; j < 1024; j += 256)
+      if (base + j < a.vlen) (void)upd_elem(a, a.voff + base + j);
+    return;
+  }
+  const int mi = b >= a.tb[2] ? 2 : b >= a.tb[1] ? 1 : 0;
+  const int rows = a.rows[mi], cols = a.cols[mi];
+  const int lb = b - a.tb[mi];
+  const int ntc = (cols + 31) / 32;
+  const int by = (lb / ntc) * 32, bx = (lb % ntc) * 32;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < rows && c < cols) ? upd_elem(a, a.off[mi] + (long)r * cols + c) : 0.f;
+  }
+  __syncthreads();
+  float *dst = a.dstT[mi];
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;     // dst[c][r]
+    if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[tx][j];
   }
 }
 
 __global__ void k_apply_momentum(float *__restrict__ corr, const float *__restrict__ grad, float mmt, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     corr[i] = mmt * corr[i] + grad[i];
-}
-// Update (:504-512), optional in-place +-clip of corr first (standard/...:480-493)
-__global__ void k_update(float *__restrict__ p, float *__restrict__ corr, float lr, float clip, long n) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float c = corr[i];
-    if (clip > 0.f) { c = c < -clip ? -clip : c; c = c > clip ? clip : c; corr[i] = c; }
-    p[i] = p[i] + (-lr) * c;
-  }
-}
-__global__ void k_transpose(const float *__restrict__ src, int rows, int cols, float *__restrict__ dst) {
-  __shared__ float tile[32][33];
-  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-  for (int j = threadIdx.y; j < 32; j += 8) {
-    const int r = by + j, c = bx + threadIdx.x;
-    tile[j][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
-  }
-  __syncthreads();
-  for (int j = threadIdx.y; j < 32; j += 8) {
-    const int c = bx + j, r = by + threadIdx.x;     // dst[c][r]
-    if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[threadIdx.x][j];
-  }
-}
-__global__ void k_zero_rows(float *base, int ld, const int *flags, int nrows, int ncols) {
-  const int r = blockIdx.x;
-  if (r >= nrows || flags[r] != 1) return;
-  for (int j = threadIdx.x; j < ncols; j += blockDim.x) base[(size_t)r * ld + j] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -613,40 +1151,76 @@ __global__ void k_zero_rows(float *base, int ld, const int *flags, int nrows, in
     return hipGetLastError();                                                                 \
   } while (0)
 
-// pick the number of 16-stream tiles a workgroup handles
+// ---- variant selection -------------------------------------------------------------------------
+// generic kernels (any shape): 16 x 16*NT stream tiles, NT in {1,2,4,8}
 static inline int pick_nt(int S) {
   const int tiles = cdiv(S, 16);
   return tiles >= 8 ? 8 : tiles >= 4 ? 4 : tiles >= 2 ? 2 : 1;
 }
-#define NT_DISPATCH(KERN, nt, grid, st, pr, args)                          \
-  switch (nt) {                                                            \
-    case 1: KLAUNCH(KERN<1>, grid, dim3(NW * 64), st, pr, args);           \
-    case 2: KLAUNCH(KERN<2>, grid, dim3(NW * 64), st, pr, args);           \
-    case 4: KLAUNCH(KERN<4>, grid, dim3(NW * 64), st, pr, args);           \
-    default: KLAUNCH(KERN<8>, grid, dim3(NW * 64), st, pr, args);          \
-  }
-
-hipError_t launch_begin(const Dims &d, const FwdPtrs &p, hipStream_t st, LaunchProbe pr) {
-  const int n = d.S * (d.C + d.R);
-  KLAUNCH(k_begin, dim3(cdiv(n, 256)), dim3(256), st, pr, d.S, d.C, d.R, (const float *)p.prev_c,
-          (const float *)p.prev_r, p.cc, p.rr);
+#define GEN_DISPATCH(KERN, nt, grid, st, pr, args, ...)                                           \
+  do {                                                                                            \
+    const dim3 _blk(NW * 64);                                                                     \
+    if (nt == 1) KLAUNCH((KERN<1, 1, false, false __VA_ARGS__>), grid, _blk, st, pr, args);       \
+    if (nt == 2) KLAUNCH((KERN<2, 1, false, false __VA_ARGS__>), grid, _blk, st, pr, args);       \
+    if (nt == 4) KLAUNCH((KERN<4, 1, false, false __VA_ARGS__>), grid, _blk, st, pr, args);       \
+    KLAUNCH((KERN<8, 1, false, false __VA_ARGS__>), grid, _blk, st, pr, args);                    \
+  } while (0)
+// vector kernels: SMALL (4x4x1_16b, S <= 4) with CPW in {1,2,4};  16x16x4 with (NT,CPW) in {(1,1),(1,2),(2,1),(4,1)}
+struct VecCfg { bool small; int nt, cpw; };
+static inline VecCfg pick_vec(int S, int nch) {
+  VecCfg c;
+  const int need = cdiv(nch, NW);
+  c.small = S <= 4;
+  if (c.small) { c.nt = 1; c.cpw = need <= 1 ? 1 : need == 2 ? 2 : 4; return c; }
+  c.nt = S <= 16 ? 1 : S <= 32 ? 2 : 4;
+  c.cpw = (c.nt == 1 && need >= 2) ? 2 : 1;
+  return c;
 }
-hipError_t launch_end(const Dims &d, const FwdPtrs &p, hipStream_t st, LaunchProbe pr) {
-  const int n = d.S * (d.C + d.R);
-  KLAUNCH(k_end, dim3(cdiv(n, 256)), dim3(256), st, pr, d.S, d.C, d.R, d.T, p.prev_c, p.prev_r,
-          (const float *)p.cc, (const float *)p.rr);
+#define VEC_DISPATCH(KERN, cfg, grid, st, pr, args, ...)                                          \
+  do {                                                                                            \
+    const dim3 _blk(NW * 64);                                                                     \
+    if (cfg.small) {                                                                              \
+      if (cfg.cpw == 1) KLAUNCH((KERN<1, 1, true __VA_ARGS__>), grid, _blk, st, pr, args);        \
+      if (cfg.cpw == 2) KLAUNCH((KERN<1, 2, true __VA_ARGS__>), grid, _blk, st, pr, args);        \
+      KLAUNCH((KERN<1, 4, true __VA_ARGS__>), grid, _blk, st, pr, args);                          \
+    }                                                                                             \
+    if (cfg.nt == 1 && cfg.cpw == 1) KLAUNCH((KERN<1, 1, false __VA_ARGS__>), grid, _blk, st, pr, args); \
+    if (cfg.nt == 1) KLAUNCH((KERN<1, 2, false __VA_ARGS__>), grid, _blk, st, pr, args);          \
+    if (cfg.nt == 2) KLAUNCH((KERN<2, 1, false __VA_ARGS__>), grid, _blk, st, pr, args);          \
+    KLAUNCH((KERN<4, 1, false __VA_ARGS__>), grid, _blk, st, pr, args);                           \
+  } while (0)
+#define COMMA ,
+static inline dim3 vec_grid(int ntiles, int S, const VecCfg &c, int z = 1) {
+  return dim3(ntiles, cdiv(S, (c.small ? 4 : 16) * c.nt), z);
 }
 
-hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, hipStream_t st, LaunchProbe pr) {
+hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, bool fuse_x, const float *in,
+                             int in_stride, hipStream_t st, LaunchProbe pr) {
   GatesArgs a;
-  a.C = d.C; a.R = d.R; a.S = d.S; a.t = t;
-  a.wr = p.wr; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
-  a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm; a.rr = p.rr;
-  a.vecW = aligned16(p.wr) && d.R % 4 == 0;
-  a.vecB = aligned16(p.rr) && d.R % 4 == 0;
+  a.C = d.C; a.R = d.R; a.S = d.S; a.I = d.I; a.t = t;
+  a.wr = p.wr; a.wx = p.wx; a.bias = p.bias; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
+  a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm;
+  a.cprev = t == 1 ? p.prev_c : p.cc + (size_t)(t - 1) * d.S * d.C;
+  a.rprev = t == 1 ? p.prev_r : p.rr + (size_t)(t - 1) * d.S * d.R;
+  a.x = fuse_x ? in + (size_t)(t - 1) * d.S * in_stride : nullptr;
+  a.x_stride = in_stride;
+  a.c_mirror = t == 1 ? p.cc : nullptr;
+  a.r_mirror = t == 1 ? p.rr : nullptr;
+  a.c_save = t == d.T ? p.prev_c : nullptr;
+  const bool vec = p.pk_gates != nullptr && aligned16(p.rr) && aligned16(p.prev_r) &&
+                   (!fuse_x || (aligned16(in) && in_stride % 4 == 0));
+  if (vec) {
+    GatesVArgs va; va.g = a; va.wpk = p.pk_gates;
+    va.nch_total = cdiv(d.R, KCH) + cdiv(d.I, KCH);
+    const VecCfg cfg = pick_vec(d.S, cdiv(d.R, KCH) + (fuse_x ? cdiv(d.I, KCH) : 0));
+    const dim3 grid = vec_grid(cdiv(d.C, 4), d.S, cfg);
+    if (fuse_x) VEC_DISPATCH(k_gates_v, cfg, grid, st, pr, va, COMMA true);
+    VEC_DISPATCH(k_gates_v, cfg, grid, st, pr, va, COMMA false);
+  }
   const int nt = pick_nt(d.S);
   const dim3 grid(cdiv(d.C, 4), cdiv(d.S, 16 * nt));
-  NT_DISPATCH(k_gates_step, nt, grid, st, pr, a);
+  if (fuse_x) GEN_DISPATCH(k_gates_step, nt, grid, st, pr, a, COMMA true);
+  GEN_DISPATCH(k_gates_step, nt, grid, st, pr, a, COMMA false);
 }
 
 hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, int out_stride,
@@ -654,63 +1228,115 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
   ProjArgs a;
   a.C = d.C; a.R = d.R; a.S = d.S; a.t = t;
   a.wm = p.wm; a.mm = p.mm; a.rr = p.rr; a.out = out; a.out_stride = out_stride;
-  a.vecW = aligned16(p.wm) && d.C % 4 == 0;
-  a.vecB = aligned16(p.mm) && d.C % 4 == 0;
-  a.vecR = aligned16(p.rr) && d.R % 4 == 0;
+  a.r_save = t == d.T ? p.prev_r : nullptr;
   a.vecOut = aligned16(out) && out_stride % 4 == 0 && d.R % 4 == 0;
+  const bool vec = p.pk_proj != nullptr && aligned16(p.mm) && aligned16(p.rr) && aligned16(p.prev_r);
+  if (vec) {
+    ProjVArgs va; va.g = a; va.wpk = p.pk_proj;
+    const VecCfg cfg = pick_vec(d.S, cdiv(d.C, KCH));
+    VEC_DISPATCH(k_proj_v, cfg, vec_grid(cdiv(d.R, 16), d.S, cfg), st, pr, va, );
+  }
   const int nt = pick_nt(d.S);
   const dim3 grid(cdiv(d.R, 16), cdiv(d.S, 16 * nt));
-  NT_DISPATCH(k_proj_step, nt, grid, st, pr, a);
+  GEN_DISPATCH(k_proj_step, nt, grid, st, pr, a, );
 }
 
 int dr_split_k(const Dims &d) {
-  // enough (R/16 x KS) workgroups to cover the chip at small S; slices are multiples of KCH
+  // enough (R/16 x KS) workgroups to spread the 4C-long contraction over the chip at small S
   const int K = 4 * d.C;
-  int ks = 8;
-  while (ks > 1 && cdiv(K, ks) < NW * KCH / 2) ks >>= 1;
+  int ks = KSMAX;
+  while (ks > 1 && cdiv(K, ks) < NW * KCH) ks >>= 1;
   return ks;
 }
 
-hipError_t launch_dr_step(const Dims &d, const BwdPtrs &p, int t, hipStream_t st, LaunchProbe pr) {
+hipError_t launch_dr_step(const Dims &d, const BwdPtrs &p, int t, float *in_diff, int id_stride,
+                          hipStream_t st, LaunchProbe pr) {
   DrArgs a;
-  a.C = d.C; a.R = d.R; a.S = d.S; a.t = t;
-  a.wrT = p.wrT; a.dgifo = p.dgifo; a.part = p.dr_part;
+  a.C = d.C; a.R = d.R; a.I = d.I; a.S = d.S; a.t = t;
+  a.wrT = p.wrT; a.wxT = p.wxT; a.dgifo = p.dgifo; a.part = p.dr_part;
   const int K = 4 * d.C;
-  a.klen = cdiv(cdiv(K, p.ks), KCH) * KCH;
-  a.vecW = aligned16(p.wrT) && K % 4 == 0;
-  a.vecB = aligned16(p.dgifo) && K % 4 == 0;
-  a.vecR = aligned16(p.dr_part) && d.R % 4 == 0;
+  const int ks = t == 0 ? 1 : p.ks;
+  a.klen = cdiv(cdiv(K, ks), KCH) * KCH;
+  a.ntr = t == 0 ? 0 : cdiv(d.R, 16);
+  const int ntx = in_diff ? cdiv(d.I, 16) : 0;
+  if (t == 0) { a.xpart = in_diff; a.x_ld = id_stride; }        // frame 1, written in place
+  else { a.xpart = p.dx_part; a.x_ld = d.I; }
+  a.vecX = aligned16(a.xpart) && a.x_ld % 4 == 0 && d.I % 4 == 0;
+  if (a.ntr + ntx == 0) return hipSuccess;
+  const bool vec = p.pk_dr != nullptr && aligned16(p.dgifo) && aligned16(p.dr_part);
+  if (vec) {
+    DrVArgs va; va.g = a; va.wpk = p.pk_dr; va.nch_total = cdiv(K, KCH);
+    const VecCfg cfg = pick_vec(d.S, cdiv(a.klen, KCH));
+    VEC_DISPATCH(k_dr_v, cfg, vec_grid(a.ntr + ntx, d.S, cfg, ks), st, pr, va, );
+  }
   const int nt = pick_nt(d.S);
-  const dim3 grid(cdiv(d.R, 16), cdiv(d.S, 16 * nt), p.ks);
-  NT_DISPATCH(k_dr_step, nt, grid, st, pr, a);
+  const dim3 grid(a.ntr + ntx, cdiv(d.S, 16 * nt), ks);
+  GEN_DISPATCH(k_dr_step, nt, grid, st, pr, a, );
 }
 
 hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *out_diff, int od_stride,
-                          hipStream_t st, LaunchProbe pr) {
+                          float *in_diff, int id_stride, hipStream_t st, LaunchProbe pr) {
   DmArgs a;
-  a.C = d.C; a.R = d.R; a.S = d.S; a.T = d.T; a.t = t;
+  a.C = d.C; a.R = d.R; a.I = d.I; a.S = d.S; a.T = d.T; a.t = t;
   a.wmT = p.wmT; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh;
   a.dgifo = p.dgifo; a.dc = p.dc; a.dr = p.dr;
   a.part = p.dr_part; a.nslab = (t == d.T) ? 0 : p.ks;
   a.out_diff = out_diff; a.od_stride = od_stride;
-  a.vecW = aligned16(p.wmT) && d.R % 4 == 0;
-  a.vecR = aligned16(p.dr_part) && aligned16(p.dr) && d.R % 4 == 0;
-  a.vecOD = aligned16(out_diff) && od_stride % 4 == 0 && d.R % 4 == 0;
-  a.vecC = aligned16(p.dgifo) && aligned16(p.dc) && d.C % 4 == 0;
+  const bool red_x = in_diff != nullptr && t < d.T;
+  a.xpart = red_x ? p.dx_part : nullptr;
+  a.in_diff = red_x ? in_diff + (size_t)t * d.S * id_stride : nullptr;     // rows of frame t+1
+  a.id_stride = id_stride;
+  const bool vec = p.pk_dm != nullptr && aligned16(p.dr_part) && aligned16(p.dr) && aligned16(out_diff) &&
+                   od_stride % 4 == 0 && aligned16(p.dgifo) && aligned16(p.dc) && aligned16(p.gifo) &&
+                   aligned16(p.cc) && aligned16(p.hh) && aligned16(p.pi) && aligned16(p.pf) && aligned16(p.po);
+  if (vec) {
+    DmVArgs va; va.g = a; va.wpk = p.pk_dm;
+    const VecCfg cfg = pick_vec(d.S, cdiv(d.R, KCH));
+    VEC_DISPATCH(k_dm_v, cfg, vec_grid(cdiv(d.C, 16), d.S, cfg), st, pr, va, );
+  }
   const int nt = pick_nt(d.S);
   const dim3 grid(cdiv(d.C, 16), cdiv(d.S, 16 * nt));
-  NT_DISPATCH(k_dm_step, nt, grid, st, pr, a);
+  GEN_DISPATCH(k_dm_step, nt, grid, st, pr, a, );
+}
+
+bool pack_supported(const Dims &d) { return d.R % 8 == 0 && d.I % 8 == 0 && d.C % 8 == 0; }
+void pack_sizes(const Dims &d, long n4[4]) {
+  n4[0] = (long)cdiv(d.C, 4) * (cdiv(d.R, KCH) + cdiv(d.I, KCH)) * 128;
+  n4[1] = (long)cdiv(d.R, 16) * cdiv(d.C, KCH) * 128;
+  n4[2] = (long)(cdiv(d.R, 16) + cdiv(d.I, 16)) * cdiv(4 * d.C, KCH) * 128;
+  n4[3] = (long)cdiv(d.C, 16) * cdiv(d.R, KCH) * 128;
+}
+hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
+                       float *pk[4], hipStream_t st, LaunchProbe pr) {
+  PackArgs a;
+  a.C = d.C; a.R = d.R; a.I = d.I;
+  const long o_wr = (long)4 * d.C * d.I, o_wm = o_wr + (long)4 * d.C * d.R + 7 * d.C;
+  a.wx = param_blob; a.wr = param_blob + o_wr; a.wm = param_blob + o_wm;
+  a.wrT = wrT; a.wmT = wmT; a.wxT = wxT;
+  pack_sizes(d, a.n4);
+  a.nch[0] = cdiv(d.R, KCH) + cdiv(d.I, KCH); a.nch[1] = cdiv(d.C, KCH); a.nch[2] = cdiv(4 * d.C, KCH); a.nch[3] = cdiv(d.R, KCH);
+  long total = 0;
+  for (int i = 0; i < 4; i++) { a.pk[i] = reinterpret_cast<float4 *>(pk[i]); total += a.n4[i]; }
+  const long nb = (total + 255) / 256;
+  KLAUNCH(k_pack, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), st, pr, a);
+}
+
+static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const float *A, int lda, const float *B,
+                        int ldb, float beta, float *Cm, int ldc, const float *bias) {
+  GemmJob g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.beta = beta;
+  g.Cm = Cm; g.ldc = ldc; g.bias = bias;
+  // branch-free 8-wide fetches need aligned rows and a contiguous extent that is a multiple of 8
+  g.vecA = aligned16(A) && lda % 4 == 0 && (transA ? M : K) % 8 == 0;
+  g.vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K : N) % 8 == 0;
+  return g;
 }
 
 hipError_t launch_gemm(bool transA, bool transB, int M, int N, int K, const float *A, int lda,
                        const float *B, int ldb, float beta, float *Cm, int ldc, const float *bias,
                        hipStream_t st, LaunchProbe pr) {
-  GemmArgs g;
-  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.beta = beta;
-  g.Cm = Cm; g.ldc = ldc; g.bias = bias;
-  g.vecA = aligned16(A) && lda % 4 == 0;
-  g.vecB = aligned16(B) && ldb % 4 == 0;
+  const GemmJob g = make_job(transA, transB, M, N, K, A, lda, B, ldb, beta, Cm, ldc, bias);
   const dim3 grid(cdiv(N, GT), cdiv(M, GT)), block(256);
   if (transA && transB) KLAUNCH((k_gemm<true, true>), grid, block, st, pr, g);
   if (transA && !transB) KLAUNCH((k_gemm<true, false>), grid, block, st, pr, g);
@@ -718,27 +1344,49 @@ hipError_t launch_gemm(bool transA, bool transB, int M, int N, int K, const floa
   KLAUNCH((k_gemm<false, false>), grid, block, st, pr, g);
 }
 
-hipError_t launch_vec_grads(const Dims &d, const float *dgifo, const float *cc, float beta,
-                            float *g_bias, float *g_pi, float *g_pf, float *g_po, hipStream_t st,
-                            LaunchProbe pr) {
-  KLAUNCH(k_vec_grads, dim3(cdiv(4 * d.C, 64)), dim3(512), st, pr, d.C, d.S, d.T, dgifo, cc, beta,
-          g_bias, g_pi, g_pf, g_po);
+hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
+                        const float *rr, const float *mm, const float *cc, float beta, float *dst,
+                        hipStream_t st, LaunchProbe pr) {
+  const int S = d.S, C = d.C, R = d.R, I = d.I, TS = d.T * d.S;
+  const long o_wx = 0, o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_pi = o_b + 4 * C,
+             o_pf = o_pi + C, o_po = o_pf + C, o_wm = o_po + C;
+  const float *dg1 = dgifo + (size_t)S * 4 * C;                      // DGIFO[1..T]
+  GradsArgs a;
+  a.wx = make_job(true, false, 4 * C, I, TS, dg1, 4 * C, in, in_stride, beta, dst + o_wx, I, nullptr);             // :468
+  a.wr = make_job(true, false, 4 * C, R, TS, dg1, 4 * C, rr, R, beta, dst + o_wr, R, nullptr);                      // :471 (YR[0..T-1])
+  a.wm = make_job(true, false, R, C, TS, dr + (size_t)S * R, R, mm + (size_t)S * C, C, beta, dst + o_wm, C, nullptr); // :486
+  a.nb0 = cdiv(4 * C, GT) * cdiv(I, GT);
+  a.nb1 = a.nb0 + cdiv(4 * C, GT) * cdiv(R, GT);
+  a.nb2 = a.nb1 + cdiv(R, GT) * cdiv(C, GT);
+  a.C = C; a.S = S; a.T = d.T; a.dgifo = dgifo; a.cc = cc; a.beta = beta;
+  a.g_bias = dst + o_b; a.g_pi = dst + o_pi; a.g_pf = dst + o_pf; a.g_po = dst + o_po;
+  const int nb3 = a.nb2 + cdiv(4 * C, 64);
+  KLAUNCH(k_grads, dim3(nb3), dim3(256), st, pr, a);
+}
+
+hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_blob, const float *grad_blob,
+                                float mmt, float lr, float clip, float *wrT, float *wmT, float *wxT,
+                                hipStream_t st, LaunchProbe pr) {
+  const int C = d.C, R = d.R, I = d.I;
+  UpdArgs a;
+  a.param = param_blob; a.corr = corr_blob; a.grad = grad_blob; a.mmt = mmt; a.lr = lr; a.clip = clip;
+  a.touch = (lr != 0.f || grad_blob != nullptr || clip > 0.f) ? 1 : 0;
+  const long o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_wm = o_b + 7 * C;
+  a.off[0] = 0;    a.rows[0] = 4 * C; a.cols[0] = I; a.dstT[0] = wxT;
+  a.off[1] = o_wr; a.rows[1] = 4 * C; a.cols[1] = R; a.dstT[1] = wrT;
+  a.off[2] = o_wm; a.rows[2] = R;     a.cols[2] = C; a.dstT[2] = wmT;
+  int nb = 0;
+  for (int i = 0; i < 3; i++) { a.tb[i] = nb; nb += cdiv(a.rows[i], 32) * cdiv(a.cols[i], 32); }
+  a.tb_vec = nb;
+  a.voff = o_b; a.vlen = 7 * C;
+  nb += cdiv(7 * C, 1024);
+  KLAUNCH(k_update_repack, dim3(nb), dim3(256), st, pr, a);
 }
 
 static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); }
 
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr) {
   KLAUNCH(k_apply_momentum, dim3(ew_grid(n)), dim3(256), st, pr, corr, grad, mmt, n);
-}
-hipError_t launch_update(float *param, float *corr, float lr, float clip, long n, hipStream_t st, LaunchProbe pr) {
-  KLAUNCH(k_update, dim3(ew_grid(n)), dim3(256), st, pr, param, corr, lr, clip, n);
-}
-hipError_t launch_transpose(const float *src, int rows, int cols, float *dst, hipStream_t st, LaunchProbe pr) {
-  KLAUNCH(k_transpose, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), st, pr, src, rows, cols, dst);
-}
-hipError_t launch_zero_rows(float *base, int ld, const int *flags_dev, int nrows, int ncols, hipStream_t st) {
-  LaunchProbe pr;
-  KLAUNCH(k_zero_rows, dim3(nrows), dim3(256), st, pr, base, ld, flags_dev, nrows, ncols);
 }
 
 }  // namespace klstm

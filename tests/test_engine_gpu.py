@@ -30,13 +30,16 @@ def make_engine(I, C, R, S, params):
     return e
 
 
-def run_chunks(I, C, R, S, T, nchunks, scale, momentum, lr, seed=0, want_in_diff=True, od_scale=1.0):
+def run_chunks(I, C, R, S, T, nchunks, scale, momentum, lr, seed=0, want_in_diff=True, od_scale=1.0, fuse_x=-1,
+               vector=1):
     """Runs nchunks x (Propagate, Backpropagate, Update) on both sides; returns per-chunk records."""
     rng = np.random.RandomState(seed)
     p = make_params(I, C, R, scale=scale, seed=seed + 1)
     o = Oracle(I, C, R, S, np.float32)
     o.set_params(p)
     e = make_engine(I, C, R, S, p)
+    e.set_option("fuse_x", fuse_x)
+    e.set_option("vector", vector)
     recs = []
     for ck in range(nchunks):
         x = rng.randn(T * S, I).astype(np.float32)
@@ -98,6 +101,33 @@ def test_small_shapes_against_oracle(I, C, R, S, T):
     check(recs, tol_act=2e-5, tol_grad=1e-4, C=C, S=S, T=T)
 
 
+@pytest.mark.parametrize("fuse_x", [0, 1])
+@pytest.mark.parametrize("I,C,R,S,T,want_in_diff", [(5, 7, 4, 3, 6, True), (40, 36, 24, 20, 3, False), (70, 12, 8, 4, 4, True)])
+def test_fused_and_batched_x_projection(I, C, R, S, T, want_in_diff, fuse_x):
+    """Both ways of computing x(t) W_gifo_x^T + bias (reference :246,:259): one batched GEMM, or
+    contracted inside the step kernel.  Also covers in_diff == NULL."""
+    recs = run_chunks(I, C, R, S, T, nchunks=2, scale=0.3, momentum=0.5, lr=1e-3, want_in_diff=want_in_diff,
+                      fuse_x=fuse_x)
+    check(recs, tol_act=2e-5, tol_grad=1e-4, C=C, S=S, T=T)
+
+
+@pytest.mark.parametrize("vector", [0, 1])
+@pytest.mark.parametrize("I,C,R,S,T", [
+    (40, 64, 32, 4, 6),      # S<=4: 4x4x1_16b geometry, one super-iteration
+    (8, 16, 8, 3, 5),        # S<=4, partial stream tile, single K chunk
+    (40, 72, 48, 2, 4),      # C not a multiple of 16 (partial cell tile in BPTT), R not a multiple of 32
+    (16, 24, 16, 16, 3),     # 16x16x4 geometry, NT=1
+    (24, 40, 24, 24, 3),     # NT=2
+    (8, 16, 16, 70, 2),      # NT=4 with a partial second stream group
+    (64, 264, 136, 4, 3),    # several super-iterations in the 4C-long BPTT contraction
+])
+def test_vector_and_generic_kernels(I, C, R, S, T, vector):
+    """Aligned shapes (R, I, C multiples of 8) run the packed-weight / LDS-staged vector kernels;
+    vector=0 forces the generic kernels on the same shapes.  Both must match the oracle."""
+    recs = run_chunks(I, C, R, S, T, nchunks=3, scale=0.3, momentum=0.9, lr=1e-3, vector=vector)
+    check(recs, tol_act=2e-5, tol_grad=1e-4, C=C, S=S, T=T)
+
+
 def test_config_c2_shape_50_chunks():
     """BASELINE.json configs[1]: 40 -> cell 800 / proj 512, NumStream 4, T_bptt 20, ParamScale 0.01,
     lr 1e-5, momentum 0.9 (train_lstm_streams.sh:3-7), 5 chunks checked in full."""
@@ -143,10 +173,13 @@ def test_chunked_equals_unchunked_and_reset():
     a, b = make_engine(I, C, R, S, p), make_engine(I, C, R, S, p)
     full = torch.empty(12 * S, R, device="cuda")
     a.propagate(dev(x), full)
-    parts = []
+    parts, keep = [], []
     for k in range(3):
         o = torch.empty(4 * S, R, device="cuda")
-        b.propagate(dev(x[k * 4 * S:(k + 1) * 4 * S]), o)
+        xk = dev(x[k * 4 * S:(k + 1) * 4 * S])
+        keep.append(xk)                       # engine calls are stream-ordered: inputs must outlive them
+        torch.cuda.synchronize()
+        b.propagate(xk, o)
         parts.append(o)
     a.synchronize(); b.synchronize()
     assert torch.equal(full, torch.cat(parts, 0))          # bit-exact state bridge (:231, :331)
