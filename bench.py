@@ -143,7 +143,7 @@ def main():
             step(args.warmup + args.steps + i)
         kern = {}
         for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj",
-                     "k_grads", "k_update_repack", "k_apply_momentum"):
+                     "k_grads", "k_update_repack", "k_pack", "k_apply_momentum"):
             tot, n = eng.profile_query(name)
             if n:
                 kern[name] = {"avg_us": tot / n, "launches_per_step": n / 3.0, "us_per_step": tot / 3.0}
@@ -153,8 +153,12 @@ def main():
     value = frames / dt
     res = None
     if rank == 0:
-        dom = max((n for n in kern if n in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step")),
-                  key=lambda n: kern[n]["us_per_step"])
+        # dominant kernel = the step kernel that carries the most algorithmic FLOPs per minibatch
+        # (k_gates_step forward, k_dr_step backward: 2*S*4C*R each); of those, the slower one.
+        for n in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step"):
+            if n in kern:
+                kern[n]["tflops"] = kernel_flops(n, S) / (kern[n]["avg_us"] * 1e-6) / 1e12
+        dom = max((n for n in kern if n in ("k_gates_step", "k_dr_step")), key=lambda n: kern[n]["us_per_step"])
         ach = kernel_flops(dom, S) / (kern[dom]["avg_us"] * 1e-6) / 1e12
         res = {
             "metric": "frames/sec fwd+BPTT, 40in/800cell/512proj LSTM at 1/2/4/8 MI355X",

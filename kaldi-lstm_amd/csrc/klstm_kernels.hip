@@ -47,15 +47,15 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // elementwise results track the CPU formulation to the last bit where possible.
 // ---------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
+// sigmoid / tanh on the hardware transcendental units (v_exp_f32, v_rcp_f32: ~1 ulp each).  The
+// reference CPU forms (overflow-safe split, expf, IEEE divide) cost a ~500-cycle dependent chain on
+// the 16 lanes that own a tile's cell math; IEEE inf arithmetic makes the single-branch forms below
+// saturate correctly (exp2(+big) = inf -> rcp = 0), and the deviation is <= 3e-7 absolute.
 __device__ __forceinline__ float k_sigmoid(float x) {
-  if (x > 0.f) return 1.f / (1.f + expf(-x));
-  const float ex = expf(x);
-  return ex / (ex + 1.f);
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 __device__ __forceinline__ float k_tanh(float x) {
-  if (x > 0.f) { const float inv = expf(-x); return -1.f + 2.f / (1.f + inv * inv); }
-  const float e = expf(x);
-  return 1.f - 2.f / (1.f + e * e);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
 }
 // DiffSigmoid / DiffTanh with the reference's double literal (kaldi-matrix.cc:2562-2593)
 __device__ __forceinline__ float k_diff_sigmoid(float d, float y) {
