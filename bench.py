@@ -101,21 +101,12 @@ def main():
     out = torch.empty(T_BPTT * S, R_DIM, device="cuda")
     in_diff = torch.empty(T_BPTT * S, I_DIM, device="cuda")
     ones = np.ones(S, np.int32)
-    gblob = eng.grad_blob_tensor() if world > 1 else None
+    dp = k.DataParallelLstm(eng)          # N>1: one all-reduce (sum, fp32) of the 8.73 MB gradient blob per minibatch
     torch.cuda.synchronize()
 
     def step(i):
-        c = i % nchunk
-        if c == 0:
-            eng.reset(ones)                         # new utterances on every stream (lock-step)
-        eng.propagate(feats[c], out)
-        if world > 1:
-            eng.backpropagate(feats[c], odiff[c], in_diff, MOMENTUM, k.DEFER_MOMENTUM)
-            dist.all_reduce(gblob)                  # sum, fp32, one contiguous 8.73 MB blob
-            eng.apply_momentum(MOMENTUM)
-        else:
-            eng.backpropagate(feats[c], odiff[c], in_diff, MOMENTUM)
-        eng.update(LR)
+        c = i % nchunk                      # new utterances on every stream (lock-step) every 50 chunks
+        dp.train_step(feats[c], out, odiff[c], in_diff, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
 
     def fence():
         torch.cuda.synchronize()

@@ -1,0 +1,333 @@
+// include/klstm_component.hpp -- C++ host-side mirror of the reference components for the hot path,
+// written against the C-ABI of klstm.h (header-only, no Kaldi dependency).
+//
+//   klstm_kaldi::LstmProjectedStreams  <->  google/nnet/bd-nnet-lstm-projected-streams.h:25-621
+//   klstm_kaldi::LstmProjected         <->  standard/nnet/nnet-lstm-projected.h (S = 1, whole-utterance
+//                                           BPTT, zero initial state, +-50 gradient clip in Update)
+//
+// Same method names, argument meaning and error behaviour as the reference classes:
+//   InitData / ReadData / WriteData / NumParams / GetParams / Info / InfoGradient / Reset /
+//   PropagateFnc / BackpropagateFnc / Update / Copy,  KALDI_ASSERT / KALDI_ERR -> std::runtime_error.
+// MatrixView is layout-identical to CuMatrixBase<BaseFloat> (cu-matrix.h:479-489: data_, num_cols_,
+// num_rows_, stride_), so a Kaldi build can reinterpret_cast a CuMatrixBase<float> to it -- the actual
+// Kaldi-side subclass a maintainer would add is shown in INTEGRATION.md.
+//
+// Parameters live on the device inside the engine; this class keeps a host shadow so that model
+// I/O (ReadData / WriteData / InitData) works without a GPU and the engine is created lazily at the
+// first Reset / PropagateFnc.
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "klstm.h"
+#include "klstm_kaldi_io.hpp"
+
+namespace klstm_kaldi {
+
+struct MatrixView {            // == CuMatrixBase<BaseFloat> field order
+  BaseFloat *data_;
+  int32 num_cols_;
+  int32 num_rows_;
+  int32 stride_;
+  MatrixView() : data_(nullptr), num_cols_(0), num_rows_(0), stride_(0) {}
+  MatrixView(BaseFloat *d, int32 rows, int32 cols, int32 stride) : data_(d), num_cols_(cols), num_rows_(rows), stride_(stride) {}
+  int32 NumRows() const { return num_rows_; }
+  int32 NumCols() const { return num_cols_; }
+  int32 Stride() const { return stride_; }
+  const BaseFloat *Data() const { return data_; }
+  BaseFloat *Data() { return data_; }
+};
+
+struct NnetTrainOptions {      // [UPSTREAM-unvendored nnet-trnopts.h]; only these two are read (:465, :502)
+  BaseFloat learn_rate, momentum, l2_penalty, l1_penalty;
+  NnetTrainOptions() : learn_rate(0.008f), momentum(0.f), l2_penalty(0.f), l1_penalty(0.f) {}
+};
+
+// [UPSTREAM-unvendored nnet-various.h] MomentStatistics: same fields, same order.
+inline std::string MomentStatistics(const BaseFloat *v, size_t n) {
+  double mean = 0, var = 0, skew = 0, kurt = 0, mn = 0, mx = 0;
+  if (n) {
+    mn = mx = v[0];
+    for (size_t i = 0; i < n; i++) { mean += v[i]; if (v[i] < mn) mn = v[i]; if (v[i] > mx) mx = v[i]; }
+    mean /= n;
+    for (size_t i = 0; i < n; i++) { const double d = v[i] - mean; var += d * d; skew += d * d * d; kurt += d * d * d * d; }
+    var /= n; skew /= n; kurt /= n;
+    if (var > 0) { skew /= std::pow(var, 1.5); kurt = kurt / (var * var) - 3.0; }
+  }
+  std::ostringstream os;
+  os << " ( min " << mn << ", max " << mx << ", mean " << mean << ", variance " << var << ", skewness " << skew
+     << ", kurtosis " << kurt << " ) ";
+  return os.str();
+}
+
+class LstmProjectedStreams {
+ public:
+  LstmProjectedStreams(int32 input_dim, int32 output_dim)          // ...streams.h:27-33
+      : input_dim_(input_dim), output_dim_(output_dim), ncell_(0), nrecur_(output_dim), nstream_(0),
+        device_(0), stream_(nullptr), eng_(nullptr), host_fresh_(true), corr_pending_(false) {}
+  virtual ~LstmProjectedStreams() { if (eng_) klstm_destroy(eng_); }
+  LstmProjectedStreams(const LstmProjectedStreams &o)               // Copy() copy-constructs every buffer (:38)
+      : input_dim_(o.input_dim_), output_dim_(o.output_dim_), ncell_(o.ncell_), nrecur_(o.nrecur_),
+        nstream_(o.nstream_), opts_(o.opts_), device_(o.device_), stream_(o.stream_), eng_(nullptr),
+        host_fresh_(true), corr_pending_(false) {
+    o.PullParams();
+    params_ = o.params_;
+    corr_ = o.HostCorr();
+    corr_pending_ = !corr_.empty();
+  }
+  LstmProjectedStreams &operator=(const LstmProjectedStreams &) = delete;
+  virtual LstmProjectedStreams *Copy() const { return new LstmProjectedStreams(*this); }
+  virtual const char *Marker() const { return "<LstmProjectedStreams>"; }
+
+  int32 InputDim() const { return input_dim_; }
+  int32 OutputDim() const { return output_dim_; }
+  void SetTrainOptions(const NnetTrainOptions &opts) { opts_ = opts; }
+  const NnetTrainOptions &GetTrainOptions() const { return opts_; }
+  // where the engine lives (not part of the reference API: Kaldi has one process-wide CuDevice)
+  void SetDevice(int device, void *hip_stream = nullptr) { device_ = device; stream_ = hip_stream; }
+
+  // InitData, ...streams.h:55-99.  Proto tokens <CellDim> <NumStream> <ParamScale>.
+  virtual void InitData(std::istream &is) {
+    float param_scale = 0.02f;
+    std::string token;
+    while (!is.eof()) {
+      ReadToken(is, false, &token);
+      if (token == "<CellDim>") ReadBasicType(is, false, &ncell_);
+      else if (token == "<NumStream>" && HasStreams()) ReadBasicType(is, false, &nstream_);
+      else if (token == "<ParamScale>") ReadBasicType(is, false, &param_scale);
+      else KLSTM_ERR("Unknown token " << token << ", a typo in config?" << (HasStreams() ? " (CellDim|NumStream|ParamScale)" : " (CellDim|ParamScale)"));
+      is >> std::ws;
+    }
+    DropEngine();
+    params_.resize(NumParams());
+    for (size_t i = 0; i < params_.size(); i++)       // uniform in [-scale, +scale] (:41-53)
+      params_[i] = (BaseFloat)((RandUniform() - 0.5) * 2 * param_scale);
+    host_fresh_ = true;
+  }
+
+  // ReadData, ...streams.h:101-131
+  virtual void ReadData(std::istream &is, bool binary) {
+    ExpectToken(is, binary, "<CellDim>");
+    ReadBasicType(is, binary, &ncell_);
+    if (HasStreams()) {
+      ExpectToken(is, binary, "<NumStream>");
+      ReadBasicType(is, binary, &nstream_);
+    }
+    DropEngine();
+    const int32 C = ncell_, R = nrecur_, I = input_dim_;
+    params_.assign(NumParams(), 0.f);
+    size_t off = 0;
+    ReadMat(is, binary, 4 * C, I, "w_gifo_x_", &off);
+    ReadMat(is, binary, 4 * C, R, "w_gifo_r_", &off);
+    ReadVec(is, binary, 4 * C, "bias_", &off);
+    ReadVec(is, binary, C, "peephole_i_c_", &off);
+    ReadVec(is, binary, C, "peephole_f_c_", &off);
+    ReadVec(is, binary, C, "peephole_o_c_", &off);
+    ReadMat(is, binary, R, C, "w_r_m_", &off);
+    host_fresh_ = true;      // state and *_corr_ start at zero, like the Resize(kSetZero) calls (:119-130)
+  }
+
+  // WriteData, ...streams.h:133-150
+  virtual void WriteData(std::ostream &os, bool binary) const {
+    PullParams();
+    WriteToken(os, binary, "<CellDim>");
+    WriteBasicType(os, binary, ncell_);
+    if (HasStreams()) {
+      WriteToken(os, binary, "<NumStream>");
+      WriteBasicType(os, binary, nstream_);
+    }
+    const int32 C = ncell_, R = nrecur_, I = input_dim_;
+    const BaseFloat *p = params_.data();
+    WriteMatrix(os, binary, p, 4 * C, I, I); p += (size_t)4 * C * I;
+    WriteMatrix(os, binary, p, 4 * C, R, R); p += (size_t)4 * C * R;
+    WriteVector(os, binary, p, 4 * C); p += 4 * C;
+    WriteVector(os, binary, p, C); p += C;
+    WriteVector(os, binary, p, C); p += C;
+    WriteVector(os, binary, p, C); p += C;
+    WriteMatrix(os, binary, p, R, C, C);
+  }
+
+  // Component::Write / Read framing [UPSTREAM-unvendored nnet-component.cc]: marker, OUTPUT dim,
+  // INPUT dim, then the payload (cf. "<LstmProjectedStreams> 512 40 <CellDim> 800 <NumStream> 4  [",
+  // README.md:40).
+  void Write(std::ostream &os, bool binary) const {
+    WriteToken(os, binary, Marker());
+    WriteBasicType(os, binary, output_dim_);
+    WriteBasicType(os, binary, input_dim_);
+    WriteData(os, binary);
+  }
+
+  int32 NumParams() const {                              // :152-160
+    return 4 * ncell_ * input_dim_ + 4 * ncell_ * nrecur_ + 4 * ncell_ + 3 * ncell_ + nrecur_ * ncell_;
+  }
+  void GetParams(std::vector<BaseFloat> *wei_copy) const {   // :162-189 (flat, same order)
+    PullParams();
+    *wei_copy = params_;
+  }
+  void SetParams(const std::vector<BaseFloat> &wei) {
+    KLSTM_ASSERT((int32)wei.size() == NumParams());
+    params_ = wei;
+    host_fresh_ = true;
+    if (eng_) Check(klstm_set_params_host(eng_, params_.data()));
+  }
+
+  std::string Info() const {                              // :190-199
+    PullParams();
+    return std::string("    ") + Stats(params_);
+  }
+  std::string InfoGradient() const {                      // :201-210
+    return std::string("    ") + Stats(HostCorr(), "_corr_");
+  }
+
+  // Reset, ...streams.h:212-220
+  void Reset(std::vector<int> &stream_reset_flag) {
+    KLSTM_ASSERT(nstream_ == (int32)stream_reset_flag.size());   // :214
+    EnsureEngine();
+    Check(klstm_reset(eng_, stream_reset_flag.data(), (int)stream_reset_flag.size()));
+  }
+
+  // PropagateFnc, ...streams.h:222-332.  in/out hold DEVICE pointers (a CuMatrix with the GPU enabled).
+  virtual void PropagateFnc(const MatrixView &in, MatrixView *out) {
+    KLSTM_ASSERT(in.NumRows() % nstream_ == 0);                   // :225
+    KLSTM_ASSERT(in.NumCols() == input_dim_ && out->NumCols() == output_dim_ && out->NumRows() == in.NumRows());
+    EnsureEngine();
+    Check(klstm_propagate(eng_, in.Data(), in.NumRows(), in.Stride(), out->Data(), out->Stride()));
+  }
+
+  // BackpropagateFnc, ...streams.h:334-499
+  virtual void BackpropagateFnc(const MatrixView &in, const MatrixView &out, const MatrixView &out_diff,
+                                MatrixView *in_diff) {
+    (void)out;
+    EnsureEngine();
+    Check(klstm_backpropagate(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
+                              in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
+                              opts_.momentum, KLSTM_BPTT_DEFAULT));
+    host_fresh_ = host_fresh_ && true;
+  }
+
+  // Update, ...streams.h:501-512 (arguments unused there too)
+  virtual void Update(const MatrixView &input, const MatrixView &diff) {
+    (void)input; (void)diff;
+    EnsureEngine();
+    Check(klstm_update(eng_, opts_.learn_rate, ClipGrad()));
+    host_fresh_ = false;
+  }
+
+  int32 CellDim() const { return ncell_; }
+  int32 NumStream() const { return nstream_; }
+  klstm_engine *Engine() { EnsureEngine(); return eng_; }
+
+ protected:
+  virtual bool HasStreams() const { return true; }       // <NumStream> is serialised (:136-137)
+  virtual float ClipGrad() const { return 0.f; }
+
+  static double RandUniform() { return (std::rand() + 1.0) / (RAND_MAX + 2.0); }   // [UPSTREAM-unvendored kaldi-math.h]
+
+  void Check(klstm_status st) const {
+    if (st != KLSTM_OK) KLSTM_ERR("klstm: " << klstm_last_error() << " (status " << (int)st << ")");
+  }
+  void DropEngine() {
+    if (eng_) { klstm_destroy(eng_); eng_ = nullptr; }
+    corr_.clear(); corr_pending_ = false;
+  }
+  void EnsureEngine() {
+    if (eng_) return;
+    KLSTM_ASSERT(ncell_ > 0 && nstream_ > 0);
+    Check(klstm_create(input_dim_, ncell_, nrecur_, nstream_, device_, stream_, &eng_));
+    if ((int32)params_.size() == NumParams()) Check(klstm_set_params_host(eng_, params_.data()));
+    if (corr_pending_ && (int32)corr_.size() == NumParams()) Check(klstm_set_corr_host(eng_, corr_.data()));
+    corr_pending_ = false;
+  }
+  void PullParams() const {
+    if (eng_ && !host_fresh_) {
+      params_.resize(NumParams());
+      Check(klstm_get_params_host(eng_, params_.data()));
+      host_fresh_ = true;
+    }
+  }
+  std::vector<BaseFloat> HostCorr() const {
+    if (!eng_) return corr_pending_ ? corr_ : std::vector<BaseFloat>(ncell_ > 0 ? NumParams() : 0, 0.f);
+    std::vector<BaseFloat> c(NumParams());
+    Check(klstm_get_corr_host(eng_, c.data()));
+    return c;
+  }
+  std::string Stats(const std::vector<BaseFloat> &b, const char *suffix = "_") const {
+    const int32 C = ncell_, R = nrecur_, I = input_dim_;
+    const size_t len[7] = {(size_t)4 * C * I, (size_t)4 * C * R, (size_t)4 * C, (size_t)C, (size_t)C, (size_t)C, (size_t)R * C};
+    const char *names[7] = {"w_gifo_x", "w_gifo_r", "bias", "peephole_i_c", "peephole_f_c", "peephole_o_c", "w_r_m"};
+    std::string s;
+    size_t off = 0;
+    for (int i = 0; i < 7; i++) {
+      s += std::string("\n  ") + names[i] + suffix + "  " + (b.empty() ? std::string("( empty )") : MomentStatistics(b.data() + off, len[i]));
+      off += len[i];
+    }
+    return s;
+  }
+  void ReadMat(std::istream &is, bool binary, int32 rows, int32 cols, const char *name, size_t *off) {
+    std::vector<BaseFloat> d;
+    int32 r = 0, c = 0;
+    ReadMatrix(is, binary, &d, &r, &c);
+    if (r != rows || c != cols) KLSTM_ERR("ReadData: " << name << " is " << r << " x " << c << ", expected " << rows << " x " << cols);
+    std::copy(d.begin(), d.end(), params_.begin() + *off);
+    *off += d.size();
+  }
+  void ReadVec(std::istream &is, bool binary, int32 dim, const char *name, size_t *off) {
+    std::vector<BaseFloat> d;
+    ReadVector(is, binary, &d);
+    if ((int32)d.size() != dim) KLSTM_ERR("ReadData: " << name << " has dim " << d.size() << ", expected " << dim);
+    std::copy(d.begin(), d.end(), params_.begin() + *off);
+    *off += d.size();
+  }
+
+  int32 input_dim_, output_dim_;
+  int32 ncell_, nrecur_, nstream_;
+  NnetTrainOptions opts_;
+  int device_;
+  void *stream_;
+  klstm_engine *eng_;
+  mutable std::vector<BaseFloat> params_;   // host shadow, GetParams order
+  mutable bool host_fresh_;                 // params_ == device parameters
+  std::vector<BaseFloat> corr_;             // only to carry *_corr_ across Copy()
+  bool corr_pending_;
+};
+
+// standard/nnet/nnet-lstm-projected.h: one utterance per call, no state bridge (:228-231, :314-315 are
+// commented out there), <NumStream> absent from the model file, Update clips every *_corr_ to +-50 first
+// (:480-493).
+class LstmProjected : public LstmProjectedStreams {
+ public:
+  LstmProjected(int32 input_dim, int32 output_dim) : LstmProjectedStreams(input_dim, output_dim) { nstream_ = 1; }
+  LstmProjected(const LstmProjected &o) : LstmProjectedStreams(o) {}
+  LstmProjectedStreams *Copy() const override { return new LstmProjected(*this); }
+  const char *Marker() const override { return "<LstmProjected>"; }
+  void PropagateFnc(const MatrixView &in, MatrixView *out) override {
+    std::vector<int> one(1, 1);
+    Reset(one);                      // history is never bridged between sentences
+    LstmProjectedStreams::PropagateFnc(in, out);
+  }
+ protected:
+  bool HasStreams() const override { return false; }
+  float ClipGrad() const override { return 50.f; }
+};
+
+// Component::Read framing: "<Marker> out_dim in_dim" then ReadData.  Returns nullptr at "</Nnet>".
+inline LstmProjectedStreams *ReadLstmComponent(std::istream &is, bool binary) {
+  std::string token;
+  ReadToken(is, binary, &token);
+  if (token == "<Nnet>") ReadToken(is, binary, &token);
+  if (token == "</Nnet>") return nullptr;
+  int32 dim_out, dim_in;
+  ReadBasicType(is, binary, &dim_out);
+  ReadBasicType(is, binary, &dim_in);
+  std::unique_ptr<LstmProjectedStreams> c;
+  if (token == "<LstmProjectedStreams>") c.reset(new LstmProjectedStreams(dim_in, dim_out));
+  else if (token == "<LstmProjected>") c.reset(new LstmProjected(dim_in, dim_out));
+  else KLSTM_ERR("Unknown component marker " << token << " (this reader covers <LstmProjectedStreams> and <LstmProjected>)");
+  c->ReadData(is, binary);
+  return c.release();
+}
+
+}  // namespace klstm_kaldi

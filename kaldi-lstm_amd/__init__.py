@@ -7,3 +7,4 @@ launch; it contains no arithmetic and NO CPU fallback: if the library or a GPU i
 calls raise.
 """
 from .binding import Engine, KlstmError, lib_path, load_library, DEFER_MOMENTUM  # noqa: F401
+from .dp import DataParallelLstm, shard_time_major  # noqa: F401,E402

@@ -1,0 +1,131 @@
+// tests/cpp/component_test.cpp -- drives include/klstm_component.hpp (the C++ mirror of the reference
+// component) for tests/test_component.py.  Host-only modes need no GPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "../../include/klstm_component.hpp"
+
+using namespace klstm_kaldi;
+
+static std::vector<float> read_raw(const std::string &path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) KLSTM_ERR("cannot open " << path);
+  f.seekg(0, std::ios::end);
+  const size_t n = (size_t)f.tellg() / sizeof(float);
+  f.seekg(0);
+  std::vector<float> v(n);
+  f.read(reinterpret_cast<char *>(v.data()), n * sizeof(float));
+  return v;
+}
+static void write_raw(const std::string &path, const float *p, size_t n) {
+  std::ofstream f(path, std::ios::binary);
+  f.write(reinterpret_cast<const char *>(p), n * sizeof(float));
+}
+static LstmProjectedStreams *load_model(const std::string &path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) KLSTM_ERR("cannot open " << path);
+  const bool binary = InitKaldiInputStream(f);
+  LstmProjectedStreams *c = ReadLstmComponent(f, binary);
+  if (!c) KLSTM_ERR("no component in " << path);
+  return c;
+}
+#define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) KLSTM_ERR(#x << ": " << hipGetErrorString(e_)); } while (0)
+
+int main(int argc, char **argv) {
+  try {
+    const std::string mode = argc > 1 ? argv[1] : "";
+    if (mode == "init_write") {
+      // init_write <marker> <in> <out> "<proto tokens>" <binary> <file> <params_raw>
+      const std::string marker = argv[2];
+      const int I = atoi(argv[3]), O = atoi(argv[4]);
+      std::unique_ptr<LstmProjectedStreams> c(marker == "<LstmProjected>" ? new LstmProjected(I, O) : new LstmProjectedStreams(I, O));
+      std::istringstream proto(argv[5]);
+      c->InitData(proto);
+      const bool binary = atoi(argv[6]) != 0;
+      std::ofstream f(argv[7], std::ios::binary);
+      InitKaldiOutputStream(f, binary);
+      c->Write(f, binary);
+      std::vector<float> p;
+      c->GetParams(&p);
+      write_raw(argv[8], p.data(), p.size());
+      std::cout << "OK " << c->NumParams() << "\n";
+    } else if (mode == "dump_params") {
+      // dump_params <model> <params_raw>  -> prints "marker in out cell nstream"
+      std::unique_ptr<LstmProjectedStreams> c(load_model(argv[2]));
+      std::vector<float> p;
+      c->GetParams(&p);
+      write_raw(argv[3], p.data(), p.size());
+      std::cout << c->Marker() << " " << c->InputDim() << " " << c->OutputDim() << " " << c->CellDim() << " " << c->NumStream() << "\n";
+    } else if (mode == "convert") {
+      // convert <model_in> <binary> <model_out>   (nnet-copy for one component)
+      std::unique_ptr<LstmProjectedStreams> c(load_model(argv[2]));
+      const bool binary = atoi(argv[3]) != 0;
+      std::ofstream f(argv[4], std::ios::binary);
+      InitKaldiOutputStream(f, binary);
+      c->Write(f, binary);
+      std::cout << "OK\n";
+    } else if (mode == "bad_proto") {
+      LstmProjectedStreams c(5, 4);
+      std::istringstream proto("<CellDim> 7 <Bogus> 3");
+      c.InitData(proto);       // must throw: "Unknown token <Bogus>, a typo in config?"
+      std::cout << "NOT THROWN\n";
+      return 1;
+    } else if (mode == "run_gpu") {
+      // run_gpu <model> <in_raw> <od_raw> <rows> <lr> <momentum> <nsteps> <out_prefix>
+      std::unique_ptr<LstmProjectedStreams> c(load_model(argv[2]));
+      const std::vector<float> x = read_raw(argv[3]), od = read_raw(argv[4]);
+      const int rows = atoi(argv[5]);
+      NnetTrainOptions opts;
+      opts.learn_rate = (float)atof(argv[6]);
+      opts.momentum = (float)atof(argv[7]);
+      const int nsteps = atoi(argv[8]);
+      const std::string prefix = argv[9];
+      c->SetTrainOptions(opts);
+      const int I = c->InputDim(), R = c->OutputDim();
+      // pitched device matrices, like CuMatrix (cu-matrix.cc:67-73): stride > cols
+      const int xs = I + 4, os = R + 8, ds = R + 4, is = I + 12;
+      float *dx, *dout, *dod, *did;
+      HIPOK(hipMalloc(&dx, (size_t)rows * xs * 4)); HIPOK(hipMalloc(&dout, (size_t)rows * os * 4));
+      HIPOK(hipMalloc(&dod, (size_t)rows * ds * 4)); HIPOK(hipMalloc(&did, (size_t)rows * is * 4));
+      HIPOK(hipMemcpy2D(dx, xs * 4, x.data(), I * 4, I * 4, rows, hipMemcpyHostToDevice));
+      HIPOK(hipMemcpy2D(dod, ds * 4, od.data(), R * 4, R * 4, rows, hipMemcpyHostToDevice));
+      MatrixView in(dx, rows, I, xs), out(dout, rows, R, os), out_diff(dod, rows, R, ds), in_diff(did, rows, I, is);
+      std::vector<int> flags(c->NumStream(), 1);
+      std::vector<float> hout((size_t)rows * R), hid((size_t)rows * I);
+      for (int step = 0; step < nsteps; step++) {
+        if (step == 0) c->Reset(flags);
+        c->PropagateFnc(in, &out);
+        c->BackpropagateFnc(in, out, out_diff, &in_diff);
+        if (step == nsteps - 1) {
+          HIPOK(hipDeviceSynchronize());
+          HIPOK(hipMemcpy2D(hout.data(), R * 4, dout, os * 4, R * 4, rows, hipMemcpyDeviceToHost));
+          HIPOK(hipMemcpy2D(hid.data(), I * 4, did, is * 4, I * 4, rows, hipMemcpyDeviceToHost));
+          std::ofstream g(prefix + ".gradinfo");
+          g << c->InfoGradient() << "\n";
+        }
+        c->Update(in, out_diff);
+      }
+      write_raw(prefix + ".out", hout.data(), hout.size());
+      write_raw(prefix + ".in_diff", hid.data(), hid.size());
+      std::vector<float> p;
+      c->GetParams(&p);
+      write_raw(prefix + ".params", p.data(), p.size());
+      std::ofstream f(prefix + ".model", std::ios::binary);   // trained model, binary Kaldi format
+      InitKaldiOutputStream(f, true);
+      c->Write(f, true);
+      std::cout << "OK\n" << c->Info() << "\n";
+    } else {
+      std::cerr << "usage: component_test init_write|dump_params|convert|bad_proto|run_gpu ...\n";
+      return 2;
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    std::cout << "EXCEPTION: " << e.what() << "\n";
+    return 3;
+  }
+}

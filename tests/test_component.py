@@ -1,0 +1,146 @@
+"""The C++ mirror of the reference component (include/klstm_component.hpp + klstm_kaldi_io.hpp),
+driven through tests/cpp/component_test.  Model-file tests are CPU-only; the *_gpu tests run the
+component's PropagateFnc/BackpropagateFnc/Update on the device and compare with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle, make_params
+from tests import kaldi_fmt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "component_test")
+SRC = EXE + ".cpp"
+HDRS = [os.path.join(ROOT, "include", h) for h in ("klstm.h", "klstm_component.hpp", "klstm_kaldi_io.hpp")]
+
+
+def build_driver():
+    import kaldi_lstm_amd as k
+    lib = k.lib_path()
+    assert os.path.exists(lib), "libklstm.so missing: run __graft_entry__.build()"
+    stale = (not os.path.exists(EXE)) or any(os.path.getmtime(f) > os.path.getmtime(EXE) for f in [SRC] + HDRS)
+    if stale:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), SRC,
+                               "-L" + os.path.dirname(lib), "-lklstm", "-Wl,-rpath,$ORIGIN/../../kaldi-lstm_amd", "-o", EXE])
+    return EXE
+
+
+def run(*args, ok=True):
+    r = subprocess.run([build_driver()] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    if ok:
+        assert r.returncode == 0, r.stdout + r.stderr
+    return r
+
+
+def raw(path):
+    return np.fromfile(path, dtype=np.float32)
+
+
+DIMS = dict(I=5, C=7, R=4, S=3)
+
+
+def test_binary_model_bytes_match_independent_assembly(tmp_path):
+    I, C, R, S = DIMS["I"], DIMS["C"], DIMS["R"], DIMS["S"]
+    flat = make_params(I, C, R, scale=0.5, seed=3)
+    ref = kaldi_fmt.binary_model(flat, I, C, R, S)
+    (tmp_path / "ref.nnet").write_bytes(ref)
+    out = run("dump_params", tmp_path / "ref.nnet", tmp_path / "p.raw").stdout.split()
+    assert out == ["<LstmProjectedStreams>", str(I), str(R), str(C), str(S)]
+    assert np.array_equal(raw(tmp_path / "p.raw"), flat)                       # reader: bit-exact
+    run("convert", tmp_path / "ref.nnet", 1, tmp_path / "again.nnet")
+    assert (tmp_path / "again.nnet").read_bytes() == ref                       # writer: byte-identical
+
+
+@pytest.mark.parametrize("rowsep", ["\n", ";"])
+def test_text_model_and_roundtrips(tmp_path, rowsep):
+    I, C, R, S = DIMS["I"], DIMS["C"], DIMS["R"], DIMS["S"]
+    flat = make_params(I, C, R, scale=0.5, seed=4)
+    (tmp_path / "m.txt").write_bytes(kaldi_fmt.text_model(flat, I, C, R, S, rowsep=rowsep))
+    run("dump_params", tmp_path / "m.txt", tmp_path / "p.raw")
+    assert np.array_equal(raw(tmp_path / "p.raw"), flat)        # %.9g text is lossless for float32
+    # text -> binary -> text(6 digits, Kaldi's default ostream precision) -> binary
+    run("convert", tmp_path / "m.txt", 1, tmp_path / "m.bin")
+    assert (tmp_path / "m.bin").read_bytes() == kaldi_fmt.binary_model(flat, I, C, R, S)
+    run("convert", tmp_path / "m.bin", 0, tmp_path / "m2.txt")
+    txt = (tmp_path / "m2.txt").read_text()
+    assert txt.startswith("<LstmProjectedStreams> %d %d <CellDim> %d <NumStream> %d  [\n  " % (R, I, C, S))   # README.md:40
+    run("dump_params", tmp_path / "m2.txt", tmp_path / "p2.raw")
+    np.testing.assert_allclose(raw(tmp_path / "p2.raw"), flat, rtol=1e-5)
+
+
+def test_init_from_proto_and_param_range(tmp_path):
+    proto = "<CellDim> 7 <ParamScale> 0.25 <NumStream> 3"        # google/nnet.proto:3 token set
+    r = run("init_write", "<LstmProjectedStreams>", 5, 4, proto, 1, tmp_path / "m.bin", tmp_path / "p.raw")
+    assert r.stdout.split() == ["OK", str(4 * 7 * 5 + 4 * 7 * 4 + 7 * 7 + 4 * 7)]
+    p = raw(tmp_path / "p.raw")
+    assert np.abs(p).max() <= 0.25 and np.abs(p).max() > 0.2 and abs(p.mean()) < 0.05     # U[-scale, scale] (:41-53)
+    run("dump_params", tmp_path / "m.bin", tmp_path / "q.raw")
+    assert np.array_equal(raw(tmp_path / "q.raw"), p)
+    r = run("bad_proto", ok=False)
+    assert r.returncode == 3 and "Unknown token <Bogus>, a typo in config?" in r.stdout       # KALDI_ERR :70
+
+
+def test_google_to_standard_conversion_by_text_edit(tmp_path):
+    """README.md:18-30: rename LstmProjectedStreams -> LstmProjected and drop the NumStream tag."""
+    I, C, R, S = DIMS["I"], DIMS["C"], DIMS["R"], DIMS["S"]
+    flat = make_params(I, C, R, scale=0.5, seed=5)
+    txt = kaldi_fmt.text_model(flat, I, C, R, S).decode()
+    txt = txt.replace("<LstmProjectedStreams>", "<LstmProjected>").replace("<NumStream> %d " % S, "")
+    (tmp_path / "std.txt").write_text(txt)
+    out = run("dump_params", tmp_path / "std.txt", tmp_path / "p.raw").stdout.split()
+    assert out == ["<LstmProjected>", str(I), str(R), str(C), "1"]
+    assert np.array_equal(raw(tmp_path / "p.raw"), flat)
+    assert (tmp_path / "std.txt").read_bytes() == kaldi_fmt.text_model(flat, I, C, R, 1, marker="<LstmProjected>")
+
+
+def test_truncated_and_malformed_models_raise(tmp_path):
+    I, C, R, S = DIMS["I"], DIMS["C"], DIMS["R"], DIMS["S"]
+    ref = kaldi_fmt.binary_model(make_params(I, C, R, seed=6), I, C, R, S)
+    (tmp_path / "trunc.nnet").write_bytes(ref[:len(ref) - 10])
+    r = run("dump_params", tmp_path / "trunc.nnet", tmp_path / "p.raw", ok=False)
+    assert r.returncode == 3 and "Failed to read matrix" in r.stdout
+    (tmp_path / "bad.nnet").write_bytes(ref.replace(b"<CellDim>", b"<CellDum>"))
+    r = run("dump_params", tmp_path / "bad.nnet", tmp_path / "p.raw", ok=False)
+    assert r.returncode == 3 and 'Expected token "<CellDim>"' in r.stdout
+    wrong = kaldi_fmt.binary_model(make_params(I, C + 1, R, seed=6), I, C + 1, R, S).replace(
+        b"<CellDim> \x04" + bytes([C + 1, 0, 0, 0]), b"<CellDim> \x04" + bytes([C, 0, 0, 0]))
+    (tmp_path / "dims.nnet").write_bytes(wrong)
+    r = run("dump_params", tmp_path / "dims.nnet", tmp_path / "p.raw", ok=False)
+    assert r.returncode == 3 and "expected" in r.stdout
+
+
+def _relerr(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("marker,S", [("<LstmProjectedStreams>", 4), ("<LstmProjected>", 1)])
+def test_component_train_steps_gpu(tmp_path, marker, S):
+    """Reset -> (PropagateFnc, BackpropagateFnc, Update) x3 through the C++ mirror, pitched device
+    matrices; <LstmProjected> = standard/ semantics (zero history per call, +-50 clip in Update)."""
+    I, C, R, T = 40, 64, 32, 6
+    flat = make_params(I, C, R, scale=0.2, seed=7)
+    (tmp_path / "m.nnet").write_bytes(kaldi_fmt.binary_model(flat, I, C, R, S, marker=marker))
+    rng = np.random.RandomState(0)
+    x = rng.randn(T * S, I).astype(np.float32)
+    od = (300.0 * rng.randn(T * S, R)).astype(np.float32) if S == 1 else rng.randn(T * S, R).astype(np.float32)
+    x.tofile(tmp_path / "x.raw"); od.tofile(tmp_path / "od.raw")
+    lr, mmt, nsteps = 1e-4, 0.9, 3
+    run("run_gpu", tmp_path / "m.nnet", tmp_path / "x.raw", tmp_path / "od.raw", T * S, lr, mmt, nsteps, tmp_path / "res")
+    o = Oracle(I, C, R, S, np.float32); o.set_params(flat)
+    std = marker == "<LstmProjected>"
+    for _ in range(nsteps):
+        if std:
+            o.reset([1])
+        out_o = o.propagate(x); id_o = o.backpropagate(x, od, momentum=mmt); o.update(lr, clip_grad=50.0 if std else 0.0)
+    if std:
+        assert np.abs(o.get_corr()).max() == 50.0            # the clip is exercised
+    assert _relerr(raw(tmp_path / "res.out").reshape(T * S, R), out_o) <= 5e-5
+    assert _relerr(raw(tmp_path / "res.in_diff").reshape(T * S, I), id_o) <= 2e-4
+    assert _relerr(raw(tmp_path / "res.params"), o.get_params()) <= 5e-5
+    # the trained model written by the component is a valid Kaldi binary model of the same numbers
+    expect = kaldi_fmt.binary_model(raw(tmp_path / "res.params"), I, C, R, S, marker=marker)
+    assert (tmp_path / "res.model").read_bytes() == expect
+    assert "w_gifo_x_corr_" in (tmp_path / "res.gradinfo").read_text()
