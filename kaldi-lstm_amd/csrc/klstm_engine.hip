@@ -58,6 +58,8 @@ struct klstm_engine {
   int T_fwd = -1;     // T of the last propagate (-1: none yet)
   int T_bwd = -1;
   bool use_graph = true;
+  bool mmt_pending = false;   // DP: corr = mmt*corr + grads is folded into the next Update
+  float mmt_value = 0.f;
   bool use_vector = true;
   int fuse_x = -1;    // -1 auto (small NumStream), 0 batched x-projection GEMM, 1 fused into the step kernel
   bool profile = false;
@@ -124,6 +126,13 @@ static klstm_status ensure_planes(klstm_engine *e, int T) {
   HIPCHK(hipMemsetAsync(e->dc, 0, nb * e->C * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->dr, 0, nb * e->R * sizeof(float), e->stream));
   e->T_alloc = T;
+  return KLSTM_OK;
+}
+
+static klstm_status flush_momentum(klstm_engine *e) {
+  if (!e->mmt_pending) return KLSTM_OK;
+  e->mmt_pending = false;
+  HIPCHK(launch_apply_momentum(e->corr, e->grads, e->mmt_value, e->nparams, e->stream, probe(e, "k_apply_momentum")));
   return KLSTM_OK;
 }
 
@@ -243,8 +252,14 @@ klstm_status klstm_set_params_device(klstm_engine *e, const float *flat_dev) {
   return repack(e);
 }
 klstm_status klstm_get_params_host(klstm_engine *e, float *flat) { return blob_d2h(e, flat, e ? e->params : nullptr); }
-klstm_status klstm_get_corr_host(klstm_engine *e, float *flat) { return blob_d2h(e, flat, e ? e->corr : nullptr); }
-klstm_status klstm_set_corr_host(klstm_engine *e, const float *flat) { return blob_h2d(e, e ? e->corr : nullptr, flat); }
+klstm_status klstm_get_corr_host(klstm_engine *e, float *flat) {
+  if (e) { klstm_status st = flush_momentum(e); if (st != KLSTM_OK) return st; }
+  return blob_d2h(e, flat, e ? e->corr : nullptr);
+}
+klstm_status klstm_set_corr_host(klstm_engine *e, const float *flat) {
+  if (e) e->mmt_pending = false;
+  return blob_h2d(e, e ? e->corr : nullptr, flat);
+}
 klstm_status klstm_get_grads_host(klstm_engine *e, float *flat) { return blob_d2h(e, flat, e ? e->grads : nullptr); }
 
 klstm_status klstm_reset(klstm_engine *e, const int *flags, int n) {
@@ -395,6 +410,7 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
   if (in_stride < e->I || out_diff_stride < e->R || (in_diff && in_diff_stride < e->I))
     return fail(KLSTM_ERR_ARG, "klstm_backpropagate: stride smaller than row width");
   HIPCHK(hipSetDevice(e->device));
+  { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }   // grads is about to be overwritten
   const int T = e->T_fwd;
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum, flags);
   klstm_status st = run_graphed(e, key, [&]() {
@@ -408,7 +424,12 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
 klstm_status klstm_apply_momentum(klstm_engine *e, float momentum) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(launch_apply_momentum(e->corr, e->grads, momentum, e->nparams, e->stream, probe(e, "k_apply_momentum")));
+  // Deferred: the following klstm_update performs corr = momentum*corr + grads in its own pass over the blob
+  // (one launch instead of two).  Anything else that observes corr or grads flushes it first.
+  klstm_status st = flush_momentum(e);
+  if (st != KLSTM_OK) return st;
+  e->mmt_pending = true;
+  e->mmt_value = momentum;
   return KLSTM_OK;
 }
 
@@ -417,8 +438,10 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
   HIPCHK(hipSetDevice(e->device));
   const Dims d{e->I, e->C, e->R, e->S, 0};
   // theta -= lr * corr, and the transposed copies the BPTT kernels read are refreshed in the same pass
-  HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT,
-                              e->stream, probe(e, "k_update_repack")));
+  const float *fold_grad = e->mmt_pending ? e->grads : nullptr;
+  e->mmt_pending = false;
+  HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
+                              e->wxT, e->stream, probe(e, "k_update_repack")));
   if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, e->stream, probe(e, "k_pack")));
   return KLSTM_OK;
 }

@@ -32,12 +32,14 @@ class DataParallelLstm:
 
     DEFER_MOMENTUM = 1
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, force_collective=False):
         import torch.distributed as dist
         self.engine = engine
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collective: take the all-reduce code path even with one rank (tests)
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self._blob = None
 
     def broadcast_params(self, src=0):
@@ -55,7 +57,7 @@ class DataParallelLstm:
         if reset_flags is not None:
             e.reset(reset_flags)
         e.propagate(x, out)
-        if self.world == 1:
+        if not self.collective:
             e.backpropagate(x, out_diff, in_diff, momentum, 0)
         else:
             e.backpropagate(x, out_diff, in_diff, momentum, self.DEFER_MOMENTUM)

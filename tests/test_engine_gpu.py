@@ -274,3 +274,38 @@ def test_error_statuses():
         e.backpropagate(x[:3], out[:3])                   # rows differ from the propagate
     assert ei.value.status == 2
     e.close()
+
+
+def test_dp_code_path_with_rccl_single_rank():
+    """The N>1 code path (deferred momentum -> all_reduce of the device gradient blob over the 'nccl'
+    = RCCL backend -> momentum folded into Update) with a one-rank group must equal the default path."""
+    import os
+    import torch.distributed as dist
+    import kaldi_lstm_amd as k
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    I, C, R, S, T = 40, 64, 32, 4, 5
+    p = make_params(I, C, R, scale=0.2, seed=9)
+    rng = np.random.RandomState(9)
+    stream = torch.cuda.Stream()
+    a = k.Engine(I, C, R, S, stream=stream); a.set_params(p)
+    b = make_engine(I, C, R, S, p)
+    dp = k.DataParallelLstm(a, force_collective=True)
+    assert dp.collective
+    out_a = torch.empty(T * S, R, device="cuda"); out_b = torch.empty(T * S, R, device="cuda")
+    for i in range(3):
+        x = dev(rng.randn(T * S, I)); od = dev(rng.randn(T * S, R))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            dp.train_step(x, out_a, od, None, 0.9, 1e-2, reset_flags=[1] * S if i == 0 else None)
+        if i == 0:
+            b.reset([1] * S)
+        b.propagate(x, out_b); b.backpropagate(x, od, None, momentum=0.9); b.update(1e-2)
+        a.synchronize(); b.synchronize()
+    assert relerr(out_a.cpu().numpy(), out_b.cpu().numpy()) <= 1e-6
+    assert relerr(a.get_corr(), b.get_corr()) <= 1e-6
+    assert relerr(a.get_params(), b.get_params()) <= 1e-6
+    a.close(); b.close()
+    dist.destroy_process_group()
