@@ -39,9 +39,42 @@ def make_inputs(S, seed, device):
     return feats.to(device), odiff.to(device)
 
 
+PEAK_HBM_TBS = 8.0                                     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
 def kernel_flops(name, S):
-    return {"k_gates_step": 2.0 * S * 4 * C_DIM * R_DIM, "k_proj_step": 2.0 * S * R_DIM * C_DIM,
-            "k_dr_step": 2.0 * S * 4 * C_DIM * R_DIM, "k_dm_step": 2.0 * S * R_DIM * C_DIM}[name]
+    """Algorithmic FLOPs of one launch (contraction only)."""
+    return {"k_gates_step": 2.0 * S * 4 * C_DIM * (R_DIM + I_DIM), "k_proj_step": 2.0 * S * R_DIM * C_DIM,
+            "k_dr_step": 2.0 * S * 4 * C_DIM * (R_DIM + I_DIM), "k_dm_step": 2.0 * S * R_DIM * C_DIM}[name]
+
+
+def kernel_bytes(name, S):
+    """Algorithmic HBM bytes of one launch: the weight operand has to be streamed once per step (nothing
+    on-chip survives a kernel boundary) plus the activation rows read and written."""
+    C, R, I = C_DIM, R_DIM, I_DIM
+    w = {"k_gates_step": 4 * C * (R + I), "k_proj_step": R * C, "k_dr_step": (R + I) * 4 * C, "k_dm_step": C * R}[name]
+    act = {"k_gates_step": S * (R + I + C) + 7 * C + S * 7 * C,              # r, x, c(t-1), bias+peepholes | gifo, c, h, m
+           "k_proj_step": S * C + 2 * S * R,                                 # m | r, out
+           "k_dr_step": S * 4 * C + 4 * S * (R + I),                         # dgifo(t+1) | 4 split-K slabs
+           "k_dm_step": S * R * 5 + S * C * 10 + 3 * C + S * R + S * C * 5   # out_diff + slabs, 10 cell operands | d_r, dgifo, dc
+           }[name]
+    return 4.0 * (w + act)
+
+
+def pmc_traffic(kernel_tag):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        kern = json.load(open(files[-1]))["kernels"]
+        for name, v in kern.items():
+            if name.startswith(kernel_tag):
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+    return None
 
 
 def cpu_baseline(S, budget_s):
@@ -150,7 +183,13 @@ def main():
             if n in kern:
                 kern[n]["tflops"] = kernel_flops(n, S) / (kern[n]["avg_us"] * 1e-6) / 1e12
         dom = max((n for n in kern if n in ("k_gates_step", "k_dr_step")), key=lambda n: kern[n]["us_per_step"])
-        ach = kernel_flops(dom, S) / (kern[dom]["avg_us"] * 1e-6) / 1e12
+        # roofline side: arithmetic intensity of a step kernel is ~S/2 FLOP/B (weights are re-streamed every step),
+        # the ridge is 157.3 TF / 8 TB/s ~ 20 FLOP/B  ->  HBM-bound below S ~ 40, MFMA-bound above
+        intensity = kernel_flops(dom, S) / kernel_bytes(dom, S)
+        hbm_bound = intensity < PEAK_F32_MFMA_TF / PEAK_HBM_TBS
+        tflops = kernel_flops(dom, S) / (kern[dom]["avg_us"] * 1e-6) / 1e12
+        gbs = kernel_bytes(dom, S) / (kern[dom]["avg_us"] * 1e-6) / 1e9
+        tag = {"k_gates_step": "k_gates_v", "k_dr_step": "k_dr_v"}[dom]
         res = {
             "metric": "frames/sec fwd+BPTT, 40in/800cell/512proj LSTM at 1/2/4/8 MI355X",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,12 +201,17 @@ def main():
                        "streams_per_gpu": S, "total_streams": S * world, "bptt": T_BPTT,
                        "frames_per_step": T_BPTT * S * world,
                        "parallelism": "dp%d over streams, 1 all-reduce/minibatch" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F32_MFMA_TF, "traffic": None,
-                         "avg_us": kern[dom]["avg_us"], "flops_per_launch": kernel_flops(dom, S)},
+            "roofline": ({"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                          "frac": gbs / (PEAK_HBM_TBS * 1e3)} if hbm_bound else
+                         {"bound": "mfma", "kernel": dom, "achieved": tflops, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                          "frac": tflops / PEAK_F32_MFMA_TF}),
             "whole_path_tflops": value * FLOPS_PER_FRAME / 1e12 / world,
             "kernels": kern,
         }
+        res["roofline"].update({"traffic": pmc_traffic(tag) if S == 4 else None, "avg_us": kern[dom]["avg_us"],
+                                "bytes_per_launch": kernel_bytes(dom, S), "flops_per_launch": kernel_flops(dom, S),
+                                "flop_per_byte": intensity, "mfma_tflops": tflops,
+                                "mfma_frac": tflops / PEAK_F32_MFMA_TF})
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(S, args.cpu_seconds)
         print(json.dumps(res))
