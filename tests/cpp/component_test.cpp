@@ -9,6 +9,7 @@
 #include <sstream>
 
 #include "../../include/klstm_component.hpp"
+#include "../../include/klstm_trainer.hpp"
 
 using namespace klstm_kaldi;
 
@@ -75,6 +76,32 @@ int main(int argc, char **argv) {
       c.InitData(proto);       // must throw: "Unknown token <Bogus>, a typo in config?"
       std::cout << "NOT THROWN\n";
       return 1;
+    } else if (mode == "batcher") {
+      // batcher <utts_raw> <S> <T> <delay> <out_raw>
+      // utts_raw (float32 stream): nutt, then per utterance: len, dim, ntargets, feats[len*dim], targets[ntargets]
+      const std::vector<float> raw = read_raw(argv[2]);
+      size_t o = 0;
+      const int nutt = (int)raw[o++];
+      std::vector<Utterance> utts(nutt);
+      for (auto &u : utts) {
+        u.num_frames = (int)raw[o++]; u.dim = (int)raw[o++];
+        const int nt = (int)raw[o++];
+        u.feats.assign(raw.begin() + o, raw.begin() + o + (size_t)u.num_frames * u.dim); o += (size_t)u.num_frames * u.dim;
+        for (int i = 0; i < nt; i++) u.targets.push_back((int32)raw[o++]);
+      }
+      MultiStreamBatcher mb(&utts, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
+      StreamBatch b;
+      std::vector<float> out;       // per batch: feat, target, mask, flags
+      int nb = 0;
+      while (mb.Next(&b)) {
+        out.insert(out.end(), b.feat.begin(), b.feat.end());
+        for (int32 v : b.target) out.push_back((float)v);
+        out.insert(out.end(), b.frame_mask.begin(), b.frame_mask.end());
+        for (int v : b.new_utt_flags) out.push_back((float)v);
+        nb++;
+      }
+      write_raw(argv[6], out.data(), out.size());
+      std::cout << "OK " << nb << " " << mb.NumDone() << " " << mb.NumOtherError() << "\n";
     } else if (mode == "run_gpu") {
       // run_gpu <model> <in_raw> <od_raw> <rows> <lr> <momentum> <nsteps> <out_prefix>
       std::unique_ptr<LstmProjectedStreams> c(load_model(argv[2]));

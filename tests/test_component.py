@@ -13,7 +13,7 @@ from tests import kaldi_fmt
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "component_test")
 SRC = EXE + ".cpp"
-HDRS = [os.path.join(ROOT, "include", h) for h in ("klstm.h", "klstm_component.hpp", "klstm_kaldi_io.hpp")]
+HDRS = [os.path.join(ROOT, "include", h) for h in ("klstm.h", "klstm_component.hpp", "klstm_kaldi_io.hpp", "klstm_trainer.hpp")]
 
 
 def build_driver():
@@ -144,3 +144,46 @@ def test_component_train_steps_gpu(tmp_path, marker, S):
     expect = kaldi_fmt.binary_model(raw(tmp_path / "res.params"), I, C, R, S, marker=marker)
     assert (tmp_path / "res.model").read_bytes() == expect
     assert "w_gifo_x_corr_" in (tmp_path / "res.gradinfo").read_text()
+
+
+def _pack_utts(utts):
+    parts = [np.float32([len(utts)])]
+    for f, t in utts:
+        parts += [np.float32([f.shape[0], f.shape[1], len(t)]), f.astype(np.float32).ravel(), np.asarray(t, np.float32)]
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("S,T,delay,lens", [
+    (4, 20, 5, [53, 20, 7, 41, 100, 3, 64]),      # ragged, refills at batch boundaries only, shorter-than-delay utterance
+    (2, 5, 0, [5, 10, 1]),                        # exact multiples, no delay
+    (3, 4, 2, [9, 9, 9]),                         # exactly S utterances
+])
+def test_multistream_batcher_matches_reference_bookkeeping(tmp_path, S, T, delay, lens):
+    """klstm_kaldi::MultiStreamBatcher vs the numpy restatement of bd-nnet-train-lstm-streams.cc:128-206."""
+    from oracle.components import MultiStreamBatcher
+    rng = np.random.RandomState(0)
+    dim = 3
+    utts = [(rng.randn(n, dim).astype(np.float32), rng.randint(0, 50, n)) for n in lens]
+    utts.insert(2, (rng.randn(6, dim).astype(np.float32), rng.randint(0, 50, 4)))      # length mismatch: skipped (:160-164)
+    _pack_utts(utts).tofile(tmp_path / "u.raw")
+    r = run("batcher", tmp_path / "u.raw", S, T, delay, tmp_path / "b.raw").stdout.split()
+    ob = MultiStreamBatcher(utts, S, T, delay)
+    exp, nb = [], 0
+    while True:
+        b = ob.next()
+        if b is None:
+            break
+        feat, target, mask, flags = b
+        exp += [feat.ravel(), target.astype(np.float32), mask, np.float32(flags)]
+        nb += 1
+    assert r == ["OK", str(nb), str(len(lens)), "1"]
+    assert np.array_equal(raw(tmp_path / "b.raw"), np.concatenate(exp))
+    assert sum(e.sum() for e in exp[2::4]) == sum(lens)            # every real frame is a valid frame exactly once
+
+
+def test_batcher_refuses_fewer_utterances_than_streams(tmp_path):
+    rng = np.random.RandomState(1)
+    utts = [(rng.randn(5, 2).astype(np.float32), rng.randint(0, 9, 5))]
+    _pack_utts(utts).tofile(tmp_path / "u.raw")
+    r = run("batcher", tmp_path / "u.raw", 2, 4, 1, tmp_path / "b.raw", ok=False)
+    assert r.returncode == 3 and "fewer utterances than streams" in r.stdout
