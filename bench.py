@@ -167,7 +167,7 @@ def main():
             step(args.warmup + args.steps + i)
         kern = {}
         for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj",
-                     "k_grads", "k_update_repack", "k_pack", "k_apply_momentum"):
+                     "k_grads", "k_update_repack", "k_pack", "k_pack_fwd", "k_pack_bwd", "k_apply_momentum"):
             tot, n = eng.profile_query(name)
             if n:
                 kern[name] = {"avg_us": tot / n, "launches_per_step": n / 3.0, "us_per_step": tot / 3.0}

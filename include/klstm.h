@@ -133,6 +133,14 @@ klstm_status klstm_synchronize(klstm_engine *e);
  * Row-blocks the engine never materialises (the slab's dummy blocks) read as zero. */
 klstm_status klstm_get_activations_host(klstm_engine *e, int which, float *dst);
 
+/* Stateless helpers for the two trivial components the reference puts in front of the LSTM
+ * (README.md:46-49).  Device pointers, strides in elements, enqueued on hip_stream (NULL = default).
+ *   TimeShift::PropagateFnc (standard/nnet/nnet-time-shift.h:42-51): out[t] = in[clamp(t + shift, 0, rows-1)]
+ *   TransmitComponent::PropagateFnc / BackpropagateFnc (standard/nnet/nnet-transmit-component.h:26-33):
+ *   identity = shift 0. */
+klstm_status klstm_time_shift(const float *in, int rows, int cols, int in_stride, float *out,
+                              int out_stride, int shift, void *hip_stream);
+
 /* Engine knobs (not part of the reference interface).  Keys:
  *   "graph"   0/1  replay the per-minibatch launch sequence from a hipGraph (default 1)
  *   "profile" 0/1  run every kernel eagerly between its own start/stop HIP events on the

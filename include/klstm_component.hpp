@@ -313,6 +313,72 @@ class LstmProjected : public LstmProjectedStreams {
   float ClipGrad() const override { return 50.f; }
 };
 
+// standard/nnet/nnet-time-shift.h: out[t] = in[clamp(t + shift)], no backprop (:53-56).  Gives the targets
+// delay at decode time (README.md:46-49).
+class TimeShift {
+ public:
+  TimeShift(int32 dim_in, int32 dim_out) : input_dim_(dim_in), output_dim_(dim_out), shift_(0), stream_(nullptr) {}
+  const char *Marker() const { return "<TimeShift>"; }
+  int32 InputDim() const { return input_dim_; }
+  int32 OutputDim() const { return output_dim_; }
+  int32 Shift() const { return shift_; }
+  void SetStream(void *hip_stream) { stream_ = hip_stream; }
+  void InitData(std::istream &is) {                           // :29-37
+    std::string token;
+    while (!is.eof()) {
+      ReadToken(is, false, &token);
+      if (token == "<Shift>") ReadBasicType(is, false, &shift_);
+      else KLSTM_ERR("Unknown token " << token << ", a typo in config?" << " (Shift)");
+      is >> std::ws;
+    }
+  }
+  void ReadData(std::istream &is, bool binary) { ExpectToken(is, binary, "<Shift>"); ReadBasicType(is, binary, &shift_); }   // :38-41
+  void WriteData(std::ostream &os, bool binary) const {       // :42-46 (the reference appends a newline)
+    WriteToken(os, binary, "<Shift>");
+    WriteBasicType(os, binary, shift_);
+    os << "\n";
+  }
+  void Write(std::ostream &os, bool binary) const {
+    WriteToken(os, binary, Marker()); WriteBasicType(os, binary, output_dim_); WriteBasicType(os, binary, input_dim_);
+    WriteData(os, binary);
+  }
+  void PropagateFnc(const MatrixView &in, MatrixView *out) {   // :42-51
+    KLSTM_ASSERT(in.NumRows() == out->NumRows() && in.NumCols() == out->NumCols());
+    const klstm_status st = klstm_time_shift(in.Data(), in.NumRows(), in.NumCols(), in.Stride(), out->Data(), out->Stride(), shift_, stream_);
+    if (st != KLSTM_OK) KLSTM_ERR("klstm: " << klstm_last_error());
+  }
+  void BackpropagateFnc(const MatrixView &, const MatrixView &, const MatrixView &, MatrixView *) {}   // :53-56: meaningless
+ private:
+  int32 input_dim_, output_dim_, shift_;
+  void *stream_;
+};
+
+// standard/nnet/nnet-transmit-component.h: identity forward and backward; exists only so that the LSTM is
+// not component 0 (README.md:49).
+class TransmitComponent {
+ public:
+  TransmitComponent(int32 dim_in, int32 dim_out) : input_dim_(dim_in), output_dim_(dim_out), stream_(nullptr) {}
+  const char *Marker() const { return "<Transmit>"; }
+  int32 InputDim() const { return input_dim_; }
+  int32 OutputDim() const { return output_dim_; }
+  void SetStream(void *hip_stream) { stream_ = hip_stream; }
+  void Write(std::ostream &os, bool binary) const {
+    WriteToken(os, binary, Marker()); WriteBasicType(os, binary, output_dim_); WriteBasicType(os, binary, input_dim_);
+  }
+  void PropagateFnc(const MatrixView &in, MatrixView *out) { Copy(in, out); }                                      // :26-28
+  void BackpropagateFnc(const MatrixView &, const MatrixView &, const MatrixView &out_diff, MatrixView *in_diff) { // :30-33
+    if (in_diff) Copy(out_diff, in_diff);
+  }
+ private:
+  void Copy(const MatrixView &a, MatrixView *b) {
+    KLSTM_ASSERT(a.NumRows() == b->NumRows() && a.NumCols() == b->NumCols());
+    const klstm_status st = klstm_time_shift(a.Data(), a.NumRows(), a.NumCols(), a.Stride(), b->Data(), b->Stride(), 0, stream_);
+    if (st != KLSTM_OK) KLSTM_ERR("klstm: " << klstm_last_error());
+  }
+  int32 input_dim_, output_dim_;
+  void *stream_;
+};
+
 // Component::Read framing: "<Marker> out_dim in_dim" then ReadData.  Returns nullptr at "</Nnet>".
 inline LstmProjectedStreams *ReadLstmComponent(std::istream &is, bool binary) {
   std::string token;

@@ -62,6 +62,7 @@ def load_library():
     lib.klstm_set_option.argtypes = [P, ctypes.c_char_p, I]
     lib.klstm_profile_query.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_long)]
+    lib.klstm_time_shift.argtypes = [P, I, I, I, P, I, I, P]
     _LIB = lib
     return lib
 
@@ -200,3 +201,13 @@ class Engine:
         tot, n = ctypes.c_double(), ctypes.c_long()
         self._chk(self.lib.klstm_profile_query(self.h, kernel.encode(), ctypes.byref(tot), ctypes.byref(n)))
         return tot.value, n.value
+
+
+def time_shift(x, out, shift, stream=None):
+    """TimeShift::PropagateFnc / TransmitComponent (shift = 0) on torch CUDA tensors (rows = frames)."""
+    lib = load_library()
+    assert x.is_cuda and out.is_cuda and x.shape == out.shape and x.stride(1) == 1 and out.stride(1) == 1
+    sp = ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
+    st = lib.klstm_time_shift(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), out.stride(0), int(shift), sp)
+    if st != 0:
+        raise KlstmError(st, lib.klstm_last_error().decode())

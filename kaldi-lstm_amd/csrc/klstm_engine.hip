@@ -44,6 +44,9 @@ struct klstm_engine {
   int I = 0, C = 0, R = 0, S = 0, device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t side = nullptr;          // second stream for work that overlaps the main chain
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
+  bool pack_inflight = false;          // BPTT-operand pack queued on `side`, not yet joined
   long nparams = 0;
   float *params = nullptr, *grads = nullptr, *corr = nullptr;
   float *wrT = nullptr, *wmT = nullptr, *wxT = nullptr;   // transposed copies for the BPTT kernels
@@ -136,11 +139,21 @@ static klstm_status flush_momentum(klstm_engine *e) {
   return KLSTM_OK;
 }
 
+static klstm_status join_pack(klstm_engine *e);
 static klstm_status repack(klstm_engine *e) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
+  { klstm_status js = join_pack(e); if (js != KLSTM_OK) return js; }
   HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream,
                               probe(e, "k_update_repack")));
-  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, e->stream, probe(e, "k_pack")));
+  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->stream, probe(e, "k_pack")));
+  return KLSTM_OK;
+}
+
+// main stream must not run BPTT before the side-stream pack of its operands has finished
+static klstm_status join_pack(klstm_engine *e) {
+  if (!e->pack_inflight) return KLSTM_OK;
+  HIPCHK(hipStreamWaitEvent(e->stream, e->ev_pack, 0));
+  e->pack_inflight = false;
   return KLSTM_OK;
 }
 
@@ -173,6 +186,13 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
     hipError_t er = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (er != hipSuccess) { delete e; return fail(KLSTM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(er)); }
     e->own_stream = true;
+  }
+  if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_pack, hipEventDisableTiming) != hipSuccess) {
+    klstm_destroy(e);
+    return fail(KLSTM_ERR_HIP, "klstm_create: side stream / events");
   }
   const size_t pb = (size_t)e->nparams * sizeof(float);
   klstm_status st = KLSTM_OK;
@@ -207,7 +227,12 @@ void klstm_destroy(klstm_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->side) (void)hipStreamSynchronize(e->side);
   drop_graphs(e);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->ev_pack) (void)hipEventDestroy(e->ev_pack);
+  if (e->side) (void)hipStreamDestroy(e->side);
   for (auto &r : e->probes) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   free_planes(e);
   float *ps[] = {e->params, e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3]};
@@ -349,8 +374,10 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     if (t < T) HIPCHK(launch_dr_step(d, p, t, in_diff, id_stride, st, probe(e, "k_dr_step")));
     HIPCHK(launch_dm_step(d, p, t, out_diff, od_stride, in_diff, id_stride, st, probe(e, "k_dm_step")));
   }
-  if (in_diff)   // in_diff of frame 1 (:457); frames 2..T were reduced inside the loop
-    HIPCHK(launch_dr_step(d, p, 0, in_diff, id_stride, st, probe(e, "k_dr_step0")));
+  // in_diff of frame 1 (:457); frames 2..T were reduced inside the loop.  (Measured: running this as a
+  // parallel graph branch next to k_grads makes the whole replay ~120 us SLOWER on ROCm 7.2 -- cross-queue
+  // dependencies inside a hipGraph are far more expensive than the 6 us this kernel costs in line.)
+  if (in_diff) HIPCHK(launch_dr_step(d, p, 0, in_diff, id_stride, st, probe(e, "k_dr_step0")));
   const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
   float *dst = defer ? e->grads : e->corr;
   const float beta = defer ? 0.f : mmt;
@@ -411,6 +438,7 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
     return fail(KLSTM_ERR_ARG, "klstm_backpropagate: stride smaller than row width");
   HIPCHK(hipSetDevice(e->device));
   { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }   // grads is about to be overwritten
+  { klstm_status js = join_pack(e); if (js != KLSTM_OK) return js; }
   const int T = e->T_fwd;
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum, flags);
   klstm_status st = run_graphed(e, key, [&]() {
@@ -442,7 +470,9 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
   e->mmt_pending = false;
   HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
                               e->wxT, e->stream, probe(e, "k_update_repack")));
-  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, e->stream, probe(e, "k_pack")));
+  // (Packing the BPTT operands on a second stream, overlapped with the next forward pass, was measured to cost
+  // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
+  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->stream, probe(e, "k_pack")));
   return KLSTM_OK;
 }
 
@@ -450,6 +480,7 @@ klstm_status klstm_synchronize(klstm_engine *e) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipStreamSynchronize(e->side));
   return KLSTM_OK;
 }
 
@@ -536,6 +567,15 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
   return KLSTM_OK;
 }
 
+klstm_status klstm_time_shift(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, int shift,
+                              void *hip_stream) {
+  if (!in || !out) return fail(KLSTM_ERR_ARG, "klstm_time_shift: null argument");
+  if (rows < 0 || cols < 0 || in_stride < cols || out_stride < cols) return fail(KLSTM_ERR_ARG, "klstm_time_shift: bad shape");
+  if (rows == 0 || cols == 0) return KLSTM_OK;
+  HIPCHK(launch_time_shift(in, rows, cols, in_stride, out, out_stride, shift, (hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+
 // Diagnostic: cost of one kernel inside a dependent chain.  Captures `n` back-to-back launches of
 // the named step kernel(s) (t cycles 1..T of the last propagate) into a hipGraph, replays it 5
 // times and returns the best wall time per launch in microseconds (HIP events on the engine
@@ -567,7 +607,8 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
       else if (w == "dr+dm") { if (i & 1) HIPCHK(launch_dm_step(d, bp, t, scratch_out, e->R, xdiff, e->I, st)); else HIPCHK(launch_dr_step(d, bp, t < T ? t : 1, xdiff, e->I, st)); }
       else if (w == "grads") HIPCHK(launch_grads(d, e->dgifo, e->dr, xin, e->I, e->rr, e->mm, e->cc, 0.9f, e->corr, st));
       else if (w == "update") HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, st));
-      else if (w == "pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, st));
+      else if (w == "pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, st));
+      else if (w == "pack_fwd") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 3, st));
       else return fail(KLSTM_ERR_ARG, "klstm_debug_chain: unknown kernel '%s'", what);
     }
     return KLSTM_OK;

@@ -78,8 +78,13 @@ hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_bl
 //   [0] gates [W_gifo_r | W_gifo_x]   [1] proj W_r_m   [2] dr [W_gifo_r^T ; W_gifo_x^T]   [3] dm W_r_m^T
 bool pack_supported(const Dims &d);
 void pack_sizes(const Dims &d, long n4[4]);         // float4 counts
+// mask: bit i selects array i (forward operands = 3, BPTT operands = 12)
 hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
-                       float *pk[4], hipStream_t st, LaunchProbe pr = {});
+                       float *pk[4], int mask, hipStream_t st, LaunchProbe pr = {});
+
+// out[dst] = in[clamp(dst + shift)] row gather (TimeShift; shift 0 = Transmit copy)
+hipError_t launch_time_shift(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, int shift,
+                             hipStream_t st, LaunchProbe pr = {});
 
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {});
 

@@ -880,7 +880,7 @@ struct PackArgs {
   int C, R, I;
   const float *wx, *wr, *wm, *wrT, *wmT, *wxT;
   float4 *pk[4];
-  long n4[4];          // float4 count of each array
+  long n4[4];          // float4 count of each array (0: array not selected in this launch)
   int nch[4];          // chunks per tile
 };
 
@@ -1136,6 +1136,24 @@ __global__ __launch_bounds__(256) void k_update_repack(UpdArgs a) {
   }
 }
 
+// TimeShift::PropagateFnc (standard/nnet/nnet-time-shift.h:42-51): out[dst] = in[clamp(dst + shift, 0, rows-1)]
+// (shift == 0 is TransmitComponent's copy, nnet-transmit-component.h:26-33).  One row per blockIdx.y, lane-contiguous.
+__global__ void k_time_shift(const float *__restrict__ in, int rows, int cols, int in_stride, float *__restrict__ out,
+                             int out_stride, int shift, int vec) {
+  const int dst = blockIdx.y;
+  int src = dst + shift;
+  src = src < 0 ? 0 : src;
+  src = src > rows - 1 ? rows - 1 : src;
+  const float *ip = in + (size_t)src * in_stride;
+  float *op = out + (size_t)dst * out_stride;
+  if (vec) {
+    for (int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4; c < cols; c += gridDim.x * blockDim.x * 4)
+      *reinterpret_cast<float4 *>(op + c) = *reinterpret_cast<const float4 *>(ip + c);
+  } else {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) op[c] = ip[c];
+  }
+}
+
 __global__ void k_apply_momentum(float *__restrict__ corr, const float *__restrict__ grad, float mmt, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     corr[i] = mmt * corr[i] + grad[i];
@@ -1308,16 +1326,18 @@ void pack_sizes(const Dims &d, long n4[4]) {
   n4[3] = (long)cdiv(d.C, 16) * cdiv(d.R, KCH) * 128;
 }
 hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
-                       float *pk[4], hipStream_t st, LaunchProbe pr) {
+                       float *pk[4], int mask, hipStream_t st, LaunchProbe pr) {
   PackArgs a;
   a.C = d.C; a.R = d.R; a.I = d.I;
   const long o_wr = (long)4 * d.C * d.I, o_wm = o_wr + (long)4 * d.C * d.R + 7 * d.C;
   a.wx = param_blob; a.wr = param_blob + o_wr; a.wm = param_blob + o_wm;
   a.wrT = wrT; a.wmT = wmT; a.wxT = wxT;
   pack_sizes(d, a.n4);
+  for (int i = 0; i < 4; i++) if (!(mask & (1 << i))) a.n4[i] = 0;
   a.nch[0] = cdiv(d.R, KCH) + cdiv(d.I, KCH); a.nch[1] = cdiv(d.C, KCH); a.nch[2] = cdiv(4 * d.C, KCH); a.nch[3] = cdiv(d.R, KCH);
   long total = 0;
   for (int i = 0; i < 4; i++) { a.pk[i] = reinterpret_cast<float4 *>(pk[i]); total += a.n4[i]; }
+  if (total == 0) return hipSuccess;
   const long nb = (total + 255) / 256;
   KLAUNCH(k_pack, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), st, pr, a);
 }
@@ -1381,6 +1401,14 @@ hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_bl
   a.voff = o_b; a.vlen = 7 * C;
   nb += cdiv(7 * C, 1024);
   KLAUNCH(k_update_repack, dim3(nb), dim3(256), st, pr, a);
+}
+
+hipError_t launch_time_shift(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, int shift,
+                             hipStream_t st, LaunchProbe pr) {
+  const int vec = aligned16(in) && aligned16(out) && in_stride % 4 == 0 && out_stride % 4 == 0 && cols % 4 == 0;
+  const int per = vec ? 4 : 1;
+  KLAUNCH(k_time_shift, dim3(cdiv(cdiv(cols, per), 256), rows), dim3(256), st, pr, in, rows, cols, in_stride, out, out_stride,
+          shift, vec);
 }
 
 static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); }

@@ -309,3 +309,19 @@ def test_dp_code_path_with_rccl_single_rank():
     assert relerr(a.get_params(), b.get_params()) <= 1e-6
     a.close(); b.close()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows,cols,shift,pad", [(23, 40, 5, 0), (7, 13, -2, 3), (5, 8, 0, 4), (3, 4, 10, 0)])
+def test_time_shift_and_transmit(rows, cols, shift, pad):
+    """TimeShift (standard/nnet/nnet-time-shift.h:42-51) and Transmit (shift 0) against the numpy restatement."""
+    import kaldi_lstm_amd as k
+    from oracle.components import time_shift
+    rng = np.random.RandomState(rows)
+    x = rng.randn(rows, cols).astype(np.float32)
+    xs = torch.zeros(rows, cols + pad, device="cuda"); xs[:, :cols] = dev(x)
+    out = torch.full((rows, cols + pad), 9.0, device="cuda")
+    torch.cuda.synchronize()
+    k.time_shift(xs[:, :cols], out[:, :cols], shift)
+    torch.cuda.synchronize()
+    assert np.array_equal(out[:, :cols].cpu().numpy(), time_shift(x, shift))      # a gather: bit-exact
+    assert torch.all(out[:, cols:] == 9.0)
