@@ -31,6 +31,8 @@
 #ifndef KLSTM_H_
 #define KLSTM_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -140,6 +142,40 @@ klstm_status klstm_get_activations_host(klstm_engine *e, int which, float *dst);
  *   identity = shift 0. */
 klstm_status klstm_time_shift(const float *in, int rows, int cols, int in_stride, float *out,
                               int out_stride, int shift, void *hip_stream);
+
+/* Device memory helpers so that FFI users (the C++ mirror, ctypes) need no HIP headers.  The memcpy
+ * calls synchronise hip_stream. */
+klstm_status klstm_malloc(void **p, size_t bytes);
+klstm_status klstm_free(void *p);
+klstm_status klstm_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *hip_stream);
+klstm_status klstm_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *hip_stream);
+klstm_status klstm_memset_zero(void *dst_dev, size_t bytes, void *hip_stream);
+klstm_status klstm_stream_synchronize(void *hip_stream);
+
+/* Output tail of the nnet the trainer runs behind the LSTM (README.md:24-29): stateless ops on device
+ * matrices, strides in elements.  The AffineTransform / Softmax classes themselves are NOT vendored in the
+ * reference ([UPSTREAM] nnet-affine-transform.h, nnet-activation.h); only their use is (google/nnet.proto:4-5).
+ *   affine_propagate     out = in * W^T + bias                (W is [out_dim x in_dim], Kaldi's linearity_)
+ *   affine_backpropagate in_diff = out_diff * W
+ *   affine_update        W_corr = momentum*W_corr + out_diff^T * in ; bias_corr = momentum*bias_corr + colsum(out_diff);
+ *                        W -= lr * W_corr ; bias -= lr_bias * bias_corr
+ *   softmax              per-row softmax
+ *   xent_eval_masked     Xent::EvalMasked, google/nnet/nnet-loss.cc:76-142, for one-hot targets:
+ *                        diff = (net_out - onehot(target)) * mask ; row_xent[r] = -mask*log(net_out[r][target]) ;
+ *                        row_correct[r] = (mask == 1 && argmax(net_out[r]) == target).  The caller sums the two
+ *                        per-row arrays on the host (the reference also copies scalars back, :110-141). */
+klstm_status klstm_affine_propagate(const float *in, int rows, int in_dim, int in_stride, const float *W,
+                                    const float *bias, float *out, int out_dim, int out_stride, void *hip_stream);
+klstm_status klstm_affine_backpropagate(const float *out_diff, int rows, int out_dim, int od_stride,
+                                        const float *W, int in_dim, float *in_diff, int id_stride, void *hip_stream);
+klstm_status klstm_affine_update(const float *in, int in_stride, const float *out_diff, int od_stride, int rows,
+                                 int in_dim, int out_dim, float *W, float *bias, float *W_corr, float *bias_corr,
+                                 float lr, float lr_bias, float momentum, void *hip_stream);
+klstm_status klstm_softmax(const float *in, int rows, int cols, int in_stride, float *out, int out_stride,
+                           void *hip_stream);
+klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, int stride, const int *targets_dev,
+                                    const float *mask_dev, float *diff, int diff_stride, float *row_xent_dev,
+                                    float *row_correct_dev, void *hip_stream);
 
 /* Engine knobs (not part of the reference interface).  Keys:
  *   "graph"   0/1  replay the per-minibatch launch sequence from a hipGraph (default 1)

@@ -63,6 +63,11 @@ def load_library():
     lib.klstm_profile_query.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_long)]
     lib.klstm_time_shift.argtypes = [P, I, I, I, P, I, I, P]
+    lib.klstm_affine_propagate.argtypes = [P, I, I, I, P, P, P, I, I, P]
+    lib.klstm_affine_backpropagate.argtypes = [P, I, I, I, P, I, P, I, P]
+    lib.klstm_affine_update.argtypes = [P, I, P, I, I, I, I, P, P, P, P, F, F, F, P]
+    lib.klstm_softmax.argtypes = [P, I, I, I, P, I, P]
+    lib.klstm_xent_eval_masked.argtypes = [P, I, I, I, P, P, P, I, P, P, P]
     _LIB = lib
     return lib
 
@@ -211,3 +216,54 @@ def time_shift(x, out, shift, stream=None):
     st = lib.klstm_time_shift(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), out.stride(0), int(shift), sp)
     if st != 0:
         raise KlstmError(st, lib.klstm_last_error().decode())
+
+
+def _sp(stream):
+    return ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
+
+
+def _chk(st):
+    if st != 0:
+        raise KlstmError(st, load_library().klstm_last_error().decode())
+
+
+def affine_propagate(x, W, bias, out, stream=None):
+    """out = x @ W.T + bias on torch CUDA tensors (W [out_dim, in_dim] contiguous)."""
+    lib = load_library()
+    assert W.is_contiguous() and bias.is_contiguous() and x.stride(1) == 1 and out.stride(1) == 1
+    _chk(lib.klstm_affine_propagate(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), W.data_ptr(), bias.data_ptr(),
+                                    out.data_ptr(), W.shape[0], out.stride(0), _sp(stream)))
+
+
+def affine_backpropagate(out_diff, W, in_diff, stream=None):
+    lib = load_library()
+    _chk(lib.klstm_affine_backpropagate(out_diff.data_ptr(), out_diff.shape[0], W.shape[0], out_diff.stride(0), W.data_ptr(),
+                                        W.shape[1], in_diff.data_ptr(), in_diff.stride(0), _sp(stream)))
+
+
+def affine_update(x, out_diff, W, bias, W_corr, bias_corr, lr, lr_bias, momentum, stream=None):
+    lib = load_library()
+    _chk(lib.klstm_affine_update(x.data_ptr(), x.stride(0), out_diff.data_ptr(), out_diff.stride(0), x.shape[0], W.shape[1],
+                                 W.shape[0], W.data_ptr(), bias.data_ptr(), W_corr.data_ptr(), bias_corr.data_ptr(),
+                                 float(lr), float(lr_bias), float(momentum), _sp(stream)))
+
+
+def softmax(x, out, stream=None):
+    lib = load_library()
+    _chk(lib.klstm_softmax(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), out.stride(0), _sp(stream)))
+
+
+def xent_eval_masked(net_out, target, mask, diff, stream=None):
+    """Returns (cross_entropy_sum, correct, valid_frames); fills diff = (net_out - onehot) * mask."""
+    import torch
+    lib = load_library()
+    assert target.dtype == torch.int32 and mask.dtype == torch.float32
+    rows = net_out.shape[0]
+    rx = torch.empty(rows, device=net_out.device); rc = torch.empty(rows, device=net_out.device)
+    _chk(lib.klstm_xent_eval_masked(net_out.data_ptr(), rows, net_out.shape[1], net_out.stride(0), target.data_ptr(),
+                                    mask.data_ptr(), diff.data_ptr(), diff.stride(0), rx.data_ptr(), rc.data_ptr(), _sp(stream)))
+    if stream is not None:
+        stream.synchronize()
+    else:
+        torch.cuda.synchronize()
+    return float(rx.double().sum().item()), int(rc.sum().item()), int(mask.sum().item())

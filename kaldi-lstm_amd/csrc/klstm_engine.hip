@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -573,6 +574,73 @@ klstm_status klstm_time_shift(const float *in, int rows, int cols, int in_stride
   if (rows < 0 || cols < 0 || in_stride < cols || out_stride < cols) return fail(KLSTM_ERR_ARG, "klstm_time_shift: bad shape");
   if (rows == 0 || cols == 0) return KLSTM_OK;
   HIPCHK(launch_time_shift(in, rows, cols, in_stride, out, out_stride, shift, (hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+
+// ---- device memory helpers (keep the C++ mirror and other FFI users free of HIP headers) ----
+klstm_status klstm_malloc(void **p, size_t bytes) {
+  if (!p) return fail(KLSTM_ERR_ARG, "klstm_malloc: null argument");
+  HIPCHK(hipMalloc(p, bytes ? bytes : 4));
+  return KLSTM_OK;
+}
+klstm_status klstm_free(void *p) { if (p) HIPCHK(hipFree(p)); return KLSTM_OK; }
+klstm_status klstm_memcpy_h2d(void *dst, const void *src, size_t bytes, void *hip_stream) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+klstm_status klstm_memcpy_d2h(void *dst, const void *src, size_t bytes, void *hip_stream) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+klstm_status klstm_memset_zero(void *dst, size_t bytes, void *hip_stream) {
+  HIPCHK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+klstm_status klstm_stream_synchronize(void *hip_stream) {
+  HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+
+// ---- AffineTransform / Softmax / Xent::EvalMasked (stateless) ----
+klstm_status klstm_affine_propagate(const float *in, int rows, int in_dim, int in_stride, const float *W,
+                                    const float *bias, float *out, int out_dim, int out_stride, void *hip_stream) {
+  if (!in || !W || !out) return fail(KLSTM_ERR_ARG, "klstm_affine_propagate: null argument");
+  HIPCHK(launch_gemm(false, true, rows, out_dim, in_dim, in, in_stride, W, in_dim, 0.f, out, out_stride, bias,
+                     (hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+klstm_status klstm_affine_backpropagate(const float *out_diff, int rows, int out_dim, int od_stride, const float *W,
+                                        int in_dim, float *in_diff, int id_stride, void *hip_stream) {
+  if (!out_diff || !W || !in_diff) return fail(KLSTM_ERR_ARG, "klstm_affine_backpropagate: null argument");
+  HIPCHK(launch_gemm(false, false, rows, in_dim, out_dim, out_diff, od_stride, W, in_dim, 0.f, in_diff, id_stride, nullptr,
+                     (hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+klstm_status klstm_affine_update(const float *in, int in_stride, const float *out_diff, int od_stride, int rows, int in_dim,
+                                 int out_dim, float *W, float *bias, float *W_corr, float *bias_corr, float lr,
+                                 float lr_bias, float momentum, void *hip_stream) {
+  if (!in || !out_diff || !W || !bias || !W_corr || !bias_corr) return fail(KLSTM_ERR_ARG, "klstm_affine_update: null argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIPCHK(launch_gemm(true, false, out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, momentum, W_corr, in_dim, nullptr, st));
+  HIPCHK(launch_col_sum(out_diff, rows, out_dim, od_stride, momentum, bias_corr, st));
+  HIPCHK(launch_axpy(W, W_corr, -lr, (long)out_dim * in_dim, st));
+  HIPCHK(launch_axpy(bias, bias_corr, -lr_bias, out_dim, st));
+  return KLSTM_OK;
+}
+klstm_status klstm_softmax(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, void *hip_stream) {
+  if (!in || !out) return fail(KLSTM_ERR_ARG, "klstm_softmax: null argument");
+  if (rows > 0) HIPCHK(launch_softmax(in, rows, cols, in_stride, out, out_stride, (hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, int stride, const int *targets_dev,
+                                    const float *mask_dev, float *diff, int diff_stride, float *row_xent_dev,
+                                    float *row_correct_dev, void *hip_stream) {
+  if (!net_out || !targets_dev || !mask_dev || !diff || !row_xent_dev || !row_correct_dev)
+    return fail(KLSTM_ERR_ARG, "klstm_xent_eval_masked: null argument");
+  if (rows > 0) HIPCHK(launch_xent(net_out, rows, cols, stride, targets_dev, mask_dev, diff, diff_stride, row_xent_dev,
+                                   row_correct_dev, (hipStream_t)hip_stream));
   return KLSTM_OK;
 }
 

@@ -86,6 +86,13 @@ hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT,
 hipError_t launch_time_shift(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, int shift,
                              hipStream_t st, LaunchProbe pr = {});
 
+// output tail (Softmax, Xent::EvalMasked) and AffineTransform::Update helpers
+hipError_t launch_softmax(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, hipStream_t st);
+hipError_t launch_xent(const float *y, int rows, int cols, int stride, const int *target, const float *mask, float *diff,
+                       int diff_stride, float *row_xent, float *row_correct, hipStream_t st);
+hipError_t launch_col_sum(const float *src, int rows, int cols, int stride, float beta, float *dst, hipStream_t st);
+hipError_t launch_axpy(float *y, const float *x, float a, long n, hipStream_t st);
+
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {});
 
 int dr_split_k(const Dims &d);   // number of split-K slabs launch_dr_step writes

@@ -1154,6 +1154,82 @@ __global__ void k_time_shift(const float *__restrict__ in, int rows, int cols, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// output tail of the nnet: Softmax rows, Xent::EvalMasked, and the small vector ops of
+// AffineTransform::Update.  One 256-thread workgroup per frame row, lane-contiguous column sweeps.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_reduce(float v, float *sm, bool is_max) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) { const float w = __shfl_xor(v, o); v = is_max ? fmaxf(v, w) : v + w; }
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  float r = sm[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); w++) r = is_max ? fmaxf(r, sm[w]) : r + sm[w];
+  return r;
+}
+// Softmax::PropagateFnc [UPSTREAM-unvendored nnet-activation.h -> CuMatrix::ApplySoftMaxPerRow]: y = exp(x - max) / sum
+__global__ __launch_bounds__(256) void k_softmax_rows(const float *__restrict__ in, int cols, int in_stride,
+                                                      float *__restrict__ out, int out_stride) {
+  __shared__ float sm[4];
+  const float *ip = in + (size_t)blockIdx.x * in_stride;
+  float *op = out + (size_t)blockIdx.x * out_stride;
+  float mx = -3.4e38f;
+  for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, ip[c]);
+  mx = block_reduce(mx, sm, true);
+  float sum = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) { const float e = expf(ip[c] - mx); op[c] = e; sum += e; }
+  sum = block_reduce(sum, sm, false);
+  const float inv = 1.f / sum;
+  for (int c = threadIdx.x; c < cols; c += 256) op[c] *= inv;
+}
+// Xent::EvalMasked (google/nnet/nnet-loss.cc:76-142) for one-hot targets (alignments): per frame row
+//   diff = (y - t) * mask (:102-107), row_xent = -mask * log(y[target]) (:122-128),
+//   row_correct = mask == 1 && argmax(y) == target (:109-120; first maximum wins like FindRowMaxId).
+__global__ __launch_bounds__(256) void k_xent_rows(const float *__restrict__ y, int cols, int stride,
+                                                   const int *__restrict__ target, const float *__restrict__ mask,
+                                                   float *__restrict__ diff, int diff_stride,
+                                                   float *__restrict__ row_xent, float *__restrict__ row_correct) {
+  __shared__ float smv[4];
+  __shared__ int smi[4];
+  const int row = blockIdx.x;
+  const float *yp = y + (size_t)row * stride;
+  float *dp = diff + (size_t)row * diff_stride;
+  const int tgt = target[row];
+  const float m = mask[row];
+  float best = -3.4e38f; int bi = 0x7fffffff;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float v = yp[c];
+    dp[c] = (v - (c == tgt ? 1.f : 0.f)) * m;
+    if (v > best) { best = v; bi = c; }
+  }
+  // argmax with lowest-index tie break
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { smv[wave] = best; smi[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) if (smv[w] > best || (smv[w] == best && smi[w] < bi)) { best = smv[w]; bi = smi[w]; }
+    row_xent[row] = (tgt >= 0 && tgt < cols) ? -m * logf(yp[tgt]) : 0.f;
+    row_correct[row] = (m == 1.f && bi == tgt) ? 1.f : 0.f;
+  }
+}
+// dst[j] = beta*dst[j] + sum_rows src[row][j]   (AddRowSumMat)
+__global__ __launch_bounds__(256) void k_col_sum(const float *__restrict__ src, int rows, int cols, int stride, float beta,
+                                                 float *__restrict__ dst) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; r++) s += src[(size_t)r * stride + j];
+  dst[j] = (beta != 0.f ? beta * dst[j] : 0.f) + s;
+}
+__global__ void k_axpy(float *__restrict__ y, const float *__restrict__ x, float a, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = y[i] + a * x[i];
+}
+
 __global__ void k_apply_momentum(float *__restrict__ corr, const float *__restrict__ grad, float mmt, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     corr[i] = mmt * corr[i] + grad[i];
@@ -1409,6 +1485,25 @@ hipError_t launch_time_shift(const float *in, int rows, int cols, int in_stride,
   const int per = vec ? 4 : 1;
   KLAUNCH(k_time_shift, dim3(cdiv(cdiv(cols, per), 256), rows), dim3(256), st, pr, in, rows, cols, in_stride, out, out_stride,
           shift, vec);
+}
+
+hipError_t launch_softmax(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, hipStream_t st) {
+  LaunchProbe pr;
+  KLAUNCH(k_softmax_rows, dim3(rows), dim3(256), st, pr, in, cols, in_stride, out, out_stride);
+}
+hipError_t launch_xent(const float *y, int rows, int cols, int stride, const int *target, const float *mask, float *diff,
+                       int diff_stride, float *row_xent, float *row_correct, hipStream_t st) {
+  LaunchProbe pr;
+  KLAUNCH(k_xent_rows, dim3(rows), dim3(256), st, pr, y, cols, stride, target, mask, diff, diff_stride, row_xent, row_correct);
+}
+hipError_t launch_col_sum(const float *src, int rows, int cols, int stride, float beta, float *dst, hipStream_t st) {
+  LaunchProbe pr;
+  KLAUNCH(k_col_sum, dim3(cdiv(cols, 256)), dim3(256), st, pr, src, rows, cols, stride, beta, dst);
+}
+static inline int ew_grid(long n);
+hipError_t launch_axpy(float *y, const float *x, float a, long n, hipStream_t st) {
+  LaunchProbe pr;
+  KLAUNCH(k_axpy, dim3(ew_grid(n)), dim3(256), st, pr, y, x, a, n);
 }
 
 static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); }

@@ -75,3 +75,43 @@ class MultiStreamBatcher:
                     feat[t * S + s] = self.feats[s][ln - 1]
                 self.curt[s] += 1
         return feat, target, mask, list(self.new_utt_flags)
+
+
+# ---- output tail: AffineTransform / Softmax are [UPSTREAM-unvendored] nnet1 components (only their use is in
+# the reference: google/nnet.proto:4-5, README.md:27-28); Xent::EvalMasked is vendored. ----
+
+def affine_propagate(x, W, b):
+    """AffineTransform::PropagateFnc: out = in * linearity^T + bias (linearity is [out_dim x in_dim])."""
+    return (x @ W.T + b).astype(x.dtype)
+
+
+def affine_backpropagate(out_diff, W):
+    """AffineTransform::BackpropagateFnc: in_diff = out_diff * linearity."""
+    return (out_diff @ W).astype(out_diff.dtype)
+
+
+def affine_update(x, out_diff, W, b, W_corr, b_corr, lr, lr_bias, momentum):
+    """AffineTransform::Update without l1/l2 (the recipe sets none, train_lstm_streams.sh):
+    corr = momentum*corr + grad ; param -= lr*corr.  Arrays are updated in place."""
+    W_corr[...] = momentum * W_corr + out_diff.T @ x
+    b_corr[...] = momentum * b_corr + out_diff.sum(0)
+    W -= lr * W_corr
+    b -= lr_bias * b_corr
+
+
+def softmax(x):
+    e = np.exp(x - x.max(1, keepdims=True))
+    return (e / e.sum(1, keepdims=True)).astype(x.dtype)
+
+
+def xent_eval_masked(net_out, target, frame_mask):
+    """Xent::EvalMasked, /root/reference/google/nnet/nnet-loss.cc:76-142, for one-hot targets.
+    Returns diff, cross_entropy (sum), entropy (sum), correct (count), valid_frames."""
+    n, d = net_out.shape
+    t = np.zeros((n, d), net_out.dtype)                      # :86-96 posterior -> dense matrix
+    t[np.arange(n), target] += 1.0
+    diff = (net_out - t) * frame_mask[:, None]               # :102-107
+    correct = int(np.sum((frame_mask == 1) & (net_out.argmax(1) == t.argmax(1))))      # :109-120
+    cross_entropy = float(-np.sum(np.log(net_out) * t * frame_mask[:, None]))           # :122-128
+    entropy = float(-np.sum(np.log(t + 1e-20) * t * frame_mask[:, None]))               # :130-136
+    return diff, cross_entropy, entropy, correct, int(frame_mask.sum())

@@ -325,3 +325,43 @@ def test_time_shift_and_transmit(rows, cols, shift, pad):
     torch.cuda.synchronize()
     assert np.array_equal(out[:, :cols].cpu().numpy(), time_shift(x, shift))      # a gather: bit-exact
     assert torch.all(out[:, cols:] == 9.0)
+
+
+@pytest.mark.parametrize("N,K,M", [(80, 512, 1000), (12, 24, 37), (640, 32, 129)])
+def test_affine_softmax_xent_tail(N, K, M):
+    """AffineTransform fwd/bwd/update, Softmax and Xent::EvalMasked (nnet-loss.cc:76-142) vs numpy restatements.
+    Tolerances: fp32 GEMMs with K-ordered MFMA sums vs numpy's BLAS: 2e-5 of the tensor maximum."""
+    import kaldi_lstm_amd as k
+    from oracle import components as oc
+    rng = np.random.RandomState(N)
+    x = rng.randn(N, K).astype(np.float32)
+    W = (0.1 * rng.randn(M, K)).astype(np.float32); b = (0.1 * rng.randn(M)).astype(np.float32)
+    target = rng.randint(0, M, N).astype(np.int32)
+    mask = (rng.rand(N) > 0.25).astype(np.float32)
+    xd, Wd, bd = dev(x), dev(W), dev(b)
+    a = torch.empty(N, M, device="cuda"); y = torch.empty(N, M, device="cuda"); diff = torch.empty(N, M, device="cuda")
+    ind = torch.empty(N, K, device="cuda")
+    Wc = torch.zeros(M, K, device="cuda"); bc = torch.zeros(M, device="cuda")
+    torch.cuda.synchronize()
+    k.affine_propagate(xd, Wd, bd, a)
+    k.softmax(a, y)
+    xe, correct, valid = k.xent_eval_masked(y, torch.from_numpy(target).cuda(), torch.from_numpy(mask).cuda(), diff)
+    k.affine_backpropagate(diff, Wd, ind)
+    for _ in range(2):                                    # second pass exercises momentum
+        k.affine_update(xd, diff, Wd, bd, Wc, bc, 1e-3, 2e-3, 0.9)
+    torch.cuda.synchronize()
+    a_o = oc.affine_propagate(x, W, b); y_o = oc.softmax(a_o)
+    diff_o, xe_o, ent_o, correct_o, valid_o = oc.xent_eval_masked(y_o, target, mask)
+    ind_o = oc.affine_backpropagate(diff_o, W)
+    W2, b2 = W.copy(), b.copy(); Wc_o = np.zeros_like(W); bc_o = np.zeros_like(b)
+    for _ in range(2):
+        oc.affine_update(x, diff_o, W2, b2, Wc_o, bc_o, 1e-3, 2e-3, 0.9)
+    assert relerr(a.cpu().numpy(), a_o) <= 2e-5
+    assert relerr(y.cpu().numpy(), y_o) <= 2e-5
+    assert relerr(diff.cpu().numpy(), diff_o) <= 2e-5
+    assert relerr(ind.cpu().numpy(), ind_o) <= 5e-5
+    assert abs(xe - xe_o) <= 1e-4 * abs(xe_o) and ent_o == 0.0
+    assert (correct, valid) == (correct_o, valid_o)
+    assert relerr(Wc.cpu().numpy(), Wc_o) <= 5e-5 and relerr(bc.cpu().numpy(), bc_o) <= 5e-5
+    assert relerr(Wd.cpu().numpy(), W2) <= 2e-5 and relerr(bd.cpu().numpy(), b2) <= 2e-5
+    assert np.all(diff.cpu().numpy()[mask == 0] == 0.0)         # masked frames give exactly zero diff (:107)
