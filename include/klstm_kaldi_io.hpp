@@ -9,13 +9,14 @@
 //   token / basic-type / vector encoding: Kaldi base/io-funcs and matrix/kaldi-vector.cc are NOT
 //   vendored in the reference; their well-known on-disk forms are restated here
 //   ("<Tok> " ; binary ints/floats = one size byte + little-endian payload ; vector = "FV" + int32
-//   dim + raw floats, text " [ a b c ]\n") and pinned by tests/test_kaldi_io.py against
+//   dim + raw floats, text " [ a b c ]\n") and pinned by tests/test_component.py and tests/test_nnet.py against
 //   hand-assembled byte strings and the reference's text samples (README.md:24-45,
 //   google/feature_transform.nnet.txt).
 #pragma once
 #include <cctype>
 #include <cstdint>
 #include <cstring>
+#include <fstream>
 #include <istream>
 #include <limits>
 #include <ostream>

@@ -184,7 +184,11 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
   e->nparams = e->o_wm() + (long)e->R * e->C;
   if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
   else {
-    hipError_t er = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    // A BLOCKING stream: it synchronises implicitly with the legacy default (NULL) stream, which is where a
+    // Kaldi build (and the stateless klstm_* helpers called with hip_stream = NULL) put everything else, so the
+    // engine's work is ordered with the caller's exactly as if it ran on the default stream.  (The NULL stream
+    // itself cannot be used: hipGraph capture is not allowed on it.)
+    hipError_t er = hipStreamCreateWithFlags(&e->stream, hipStreamDefault);
     if (er != hipSuccess) { delete e; return fail(KLSTM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(er)); }
     e->own_stream = true;
   }

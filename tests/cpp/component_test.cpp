@@ -10,6 +10,7 @@
 
 #include "../../include/klstm_component.hpp"
 #include "../../include/klstm_trainer.hpp"
+#include "../../include/klstm_nnet.hpp"
 
 using namespace klstm_kaldi;
 
@@ -26,6 +27,20 @@ static std::vector<float> read_raw(const std::string &path) {
 static void write_raw(const std::string &path, const float *p, size_t n) {
   std::ofstream f(path, std::ios::binary);
   f.write(reinterpret_cast<const char *>(p), n * sizeof(float));
+}
+static std::vector<Utterance> read_utts(const std::string &path) {
+  // float32 stream: nutt, then per utterance: len, dim, ntargets, feats[len*dim], targets[ntargets]
+  const std::vector<float> raw = read_raw(path);
+  size_t o = 0;
+  const int nutt = (int)raw[o++];
+  std::vector<Utterance> utts(nutt);
+  for (auto &u : utts) {
+    u.num_frames = (int)raw[o++]; u.dim = (int)raw[o++];
+    const int nt = (int)raw[o++];
+    u.feats.assign(raw.begin() + o, raw.begin() + o + (size_t)u.num_frames * u.dim); o += (size_t)u.num_frames * u.dim;
+    for (int i = 0; i < nt; i++) u.targets.push_back((int32)raw[o++]);
+  }
+  return utts;
 }
 static LstmProjectedStreams *load_model(const std::string &path) {
   std::ifstream f(path, std::ios::binary);
@@ -79,16 +94,7 @@ int main(int argc, char **argv) {
     } else if (mode == "batcher") {
       // batcher <utts_raw> <S> <T> <delay> <out_raw>
       // utts_raw (float32 stream): nutt, then per utterance: len, dim, ntargets, feats[len*dim], targets[ntargets]
-      const std::vector<float> raw = read_raw(argv[2]);
-      size_t o = 0;
-      const int nutt = (int)raw[o++];
-      std::vector<Utterance> utts(nutt);
-      for (auto &u : utts) {
-        u.num_frames = (int)raw[o++]; u.dim = (int)raw[o++];
-        const int nt = (int)raw[o++];
-        u.feats.assign(raw.begin() + o, raw.begin() + o + (size_t)u.num_frames * u.dim); o += (size_t)u.num_frames * u.dim;
-        for (int i = 0; i < nt; i++) u.targets.push_back((int32)raw[o++]);
-      }
+      std::vector<Utterance> utts = read_utts(argv[2]);
       MultiStreamBatcher mb(&utts, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
       StreamBatch b;
       std::vector<float> out;       // per batch: feat, target, mask, flags
@@ -102,6 +108,39 @@ int main(int argc, char **argv) {
       }
       write_raw(argv[6], out.data(), out.size());
       std::cout << "OK " << nb << " " << mb.NumDone() << " " << mb.NumOtherError() << "\n";
+    } else if (mode == "nnet_copy") {
+      // nnet_copy <nnet_in> <binary> <nnet_out>          (nnet-copy workalike; host only)
+      Nnet nnet; nnet.Read(argv[2]);
+      nnet.Write(argv[4], atoi(argv[3]) != 0);
+      std::cout << "OK " << nnet.NumComponents();
+      for (int i = 0; i < nnet.NumComponents(); i++) std::cout << " " << nnet.GetComponent(i).Marker();
+      std::cout << "\n";
+    } else if (mode == "nnet_train") {
+      // nnet_train <nnet_in> <utts_raw> <S> <T> <delay> <lr> <momentum> <crossvalidate> <nnet_out>
+      Nnet nnet; nnet.Read(argv[2]);
+      std::vector<Utterance> utts = read_utts(argv[3]);
+      TrainLstmStreamsOptions o;
+      o.num_stream = atoi(argv[4]); o.batch_size = atoi(argv[5]); o.targets_delay = atoi(argv[6]);
+      o.trn_opts.learn_rate = (float)atof(argv[7]); o.trn_opts.momentum = (float)atof(argv[8]);
+      o.crossvalidate = atoi(argv[9]) != 0;
+      std::string report;
+      const TrainLstmStreamsStats st = TrainLstmStreams(&nnet, utts, o, &report);
+      if (!o.crossvalidate) nnet.Write(argv[10], true);                     // :294-296
+      std::cout.precision(10);
+      std::cout << "OK " << st.num_done << " " << st.num_minibatches << " " << st.total_frames << " " << st.avg_loss << " "
+                << st.frame_accuracy << " " << st.total_frames / st.seconds << "\n" << report << "\n";
+    } else if (mode == "nnet_forward") {
+      // nnet_forward <nnet> <feats_raw> <rows> <out_raw>     (nnet-forward workalike: one utterance, Feedforward)
+      Nnet nnet; nnet.Read(argv[2]);
+      const std::vector<float> x = read_raw(argv[3]);
+      const int rows = atoi(argv[4]);
+      DeviceMatrix in, out;
+      in.CopyFromHost(x.data(), rows, nnet.InputDim());
+      nnet.Feedforward(in.View(), &out);
+      std::vector<float> h;
+      out.CopyToHost(&h);
+      write_raw(argv[5], h.data(), h.size());
+      std::cout << "OK " << out.NumRows() << " " << out.NumCols() << "\n";
     } else if (mode == "run_gpu") {
       // run_gpu <model> <in_raw> <od_raw> <rows> <lr> <momentum> <nsteps> <out_prefix>
       std::unique_ptr<LstmProjectedStreams> c(load_model(argv[2]));

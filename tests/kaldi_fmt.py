@@ -66,3 +66,51 @@ def text_model(flat, I, C, R, S, marker="<LstmProjectedStreams>", rowsep="\n"):
         s += "<NumStream> %d " % S
     s += _tmat(wx, rowsep) + _tmat(wr, rowsep) + _tvec(b) + _tvec(pi) + _tvec(pf) + _tvec(po) + _tmat(wm, rowsep)
     return s.encode()
+
+
+# ---- whole nets: "<Nnet>" components "</Nnet>" (README.md:24-45) ----
+def _f32(v):
+    return b"\x04" + struct.pack("<f", v)
+
+
+def nnet_binary(layers):
+    """layers: list of tuples ("transmit", dim) | ("timeshift", dim, shift) | ("lstm_streams", flat, I, C, R, S) |
+    ("lstm", flat, I, C, R) | ("affine", W [out x in], b) | ("softmax", dim)"""
+    out = b"\x00B" + _tok("<Nnet>")
+    for l in layers:
+        kind = l[0]
+        if kind == "transmit":
+            out += _tok("<Transmit>") + _i32(l[1]) + _i32(l[1])
+        elif kind == "timeshift":
+            out += _tok("<TimeShift>") + _i32(l[1]) + _i32(l[1]) + _tok("<Shift>") + _i32(l[2]) + b"\n"
+        elif kind in ("lstm_streams", "lstm"):
+            marker = "<LstmProjectedStreams>" if kind == "lstm_streams" else "<LstmProjected>"
+            S = l[5] if kind == "lstm_streams" else 1
+            out += binary_model(l[1], l[2], l[3], l[4], S, marker=marker)[2:]
+        elif kind == "affine":
+            W, b = l[1], l[2]
+            out += (_tok("<AffineTransform>") + _i32(W.shape[0]) + _i32(W.shape[1]) + _tok("<LearnRateCoef>") + _f32(1.0) +
+                    _tok("<BiasLearnRateCoef>") + _f32(1.0) + _tok("<MaxNorm>") + _f32(0.0) + _mat(W) + _vec(b))
+        elif kind == "softmax":
+            out += _tok("<Softmax>") + _i32(l[1]) + _i32(l[1])
+    return out + _tok("</Nnet>")
+
+
+def nnet_text(layers):
+    s = "<Nnet> \n"
+    for l in layers:
+        kind = l[0]
+        if kind == "transmit":
+            s += "<Transmit> %d %d \n" % (l[1], l[1])
+        elif kind == "timeshift":
+            s += "<TimeShift> %d %d <Shift> %d \n" % (l[1], l[1], l[2])
+        elif kind in ("lstm_streams", "lstm"):
+            marker = "<LstmProjectedStreams>" if kind == "lstm_streams" else "<LstmProjected>"
+            S = l[5] if kind == "lstm_streams" else 1
+            s += text_model(l[1], l[2], l[3], l[4], S, marker=marker).decode()
+        elif kind == "affine":
+            W, b = l[1], l[2]
+            s += "<AffineTransform> %d %d <LearnRateCoef> 1 <BiasLearnRateCoef> 1 <MaxNorm> 0 " % W.shape + _tmat(W) + _tvec(b)
+        elif kind == "softmax":
+            s += "<Softmax> %d %d \n" % (l[1], l[1])
+    return (s + "</Nnet> \n").encode()

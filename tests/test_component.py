@@ -13,7 +13,7 @@ from tests import kaldi_fmt
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "component_test")
 SRC = EXE + ".cpp"
-HDRS = [os.path.join(ROOT, "include", h) for h in ("klstm.h", "klstm_component.hpp", "klstm_kaldi_io.hpp", "klstm_trainer.hpp")]
+HDRS = [os.path.join(ROOT, "include", h) for h in ("klstm.h", "klstm_component.hpp", "klstm_kaldi_io.hpp", "klstm_trainer.hpp", "klstm_nnet.hpp")]
 
 
 def build_driver():
