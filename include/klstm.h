@@ -67,8 +67,9 @@ const char *klstm_version(void);
  * Parameters start at zero, momentum buffers and stream state at zero (kSetZero, :76-97).
  * device: HIP device ordinal.  hip_stream: a hipStream_t to run on (e.g. the caller
  * framework's current stream; must not be the legacy NULL stream, graphs cannot be captured
- * on it) or NULL to let the engine create its own BLOCKING stream, which is implicitly ordered
- * with the legacy default stream like everything in a Kaldi process. */
+ * on it) or NULL to use the library's process-wide per-device BLOCKING stream: it is shared by
+ * all engines created this way (stacked LSTM components stay ordered with each other) and is
+ * implicitly ordered with the legacy default stream like everything else in a Kaldi process. */
 klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_stream,
                           int device, void *hip_stream, klstm_engine **out);
 void klstm_destroy(klstm_engine *e);

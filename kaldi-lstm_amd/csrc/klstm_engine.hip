@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -184,13 +185,23 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
   e->nparams = e->o_wm() + (long)e->R * e->C;
   if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
   else {
-    // A BLOCKING stream: it synchronises implicitly with the legacy default (NULL) stream, which is where a
-    // Kaldi build (and the stateless klstm_* helpers called with hip_stream = NULL) put everything else, so the
-    // engine's work is ordered with the caller's exactly as if it ran on the default stream.  (The NULL stream
-    // itself cannot be used: hipGraph capture is not allowed on it.)
-    hipError_t er = hipStreamCreateWithFlags(&e->stream, hipStreamDefault);
-    if (er != hipSuccess) { delete e; return fail(KLSTM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(er)); }
-    e->own_stream = true;
+    // One process-wide stream per device, shared by every engine created with hip_stream = NULL, and BLOCKING:
+    // it synchronises implicitly with the legacy default (NULL) stream, which is where a Kaldi build (and the
+    // stateless klstm_* helpers called with hip_stream = NULL) put everything else.  All engines of a stacked net
+    // are thereby ordered with each other and with the caller's default-stream work exactly as the reference's
+    // single-stream CuMatrix calls were.  (The NULL stream itself cannot be used: hipGraph capture is not allowed on it.)
+    static std::mutex mu;
+    static std::map<int, hipStream_t> shared;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = shared.find(device);
+    if (it == shared.end()) {
+      hipStream_t s = nullptr;
+      hipError_t er = hipStreamCreateWithFlags(&s, hipStreamDefault);
+      if (er != hipSuccess) { delete e; return fail(KLSTM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(er)); }
+      it = shared.emplace(device, s).first;
+    }
+    e->stream = it->second;
+    e->own_stream = false;
   }
   if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||

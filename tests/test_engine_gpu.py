@@ -365,3 +365,16 @@ def test_affine_softmax_xent_tail(N, K, M):
     assert relerr(Wc.cpu().numpy(), Wc_o) <= 5e-5 and relerr(bc.cpu().numpy(), bc_o) <= 5e-5
     assert relerr(Wd.cpu().numpy(), W2) <= 2e-5 and relerr(bd.cpu().numpy(), b2) <= 2e-5
     assert np.all(diff.cpu().numpy()[mask == 0] == 0.0)         # masked frames give exactly zero diff (:107)
+
+
+@pytest.mark.parametrize("I,C,R,S", [
+    (512, 800, 512, 4),      # BASELINE.json configs[3] second layer (40->512->512, cell 800), 32 streams over 8 GPUs = 4 per GPU
+    (512, 1024, 512, 32),    # configs[4] inner layers (cell 1024 / proj 512), 256 streams over 8 GPUs = 32 per GPU
+    (40, 800, 512, 8),       # configs[2]: 64 streams over 8 GPUs = 8 per GPU
+])
+def test_full_size_layer_shapes_of_the_larger_configs(I, C, R, S):
+    """One BPTT minibatch at the full layer shapes of BASELINE.json configs[2..4] (per-GPU stream counts), fp32,
+    against the oracle (a few seconds of host time each).  Batched x-projection where S > 16, fused otherwise."""
+    T = 20
+    recs = run_chunks(I, C, R, S, T, nchunks=1, scale=0.01, momentum=0.9, lr=1e-5, od_scale=0.1)
+    check(recs, tol_act=3e-5, tol_grad=3e-4, C=C, S=S, T=T)

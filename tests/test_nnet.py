@@ -115,3 +115,47 @@ def test_nnet_forward_workalike_standard_topology(tmp_path):
     got = raw(tmp_path / "y.raw").reshape(n, NPDF)
     assert np.abs(got - y).max() <= 2e-5
     np.testing.assert_allclose(got.sum(1), 1.0, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_two_stacked_lstm_layers_train_end_to_end(tmp_path):
+    """README.md:32-45 / BASELINE.json configs[3] topology in miniature: Transmit -> LSTM -> LSTM -> Affine -> Softmax.
+    in_diff of the upper LSTM feeds the lower one; Reset fans out to both (nnet-nnet.h:132-138)."""
+    S, T, delay, lr, mmt = 2, 6, 1, 5e-3, 0.5
+    rng = np.random.RandomState(11)
+    f1 = make_params(I, C, R, scale=0.3, seed=21); f2 = make_params(R, C, R, scale=0.3, seed=22)
+    W = (0.3 * rng.randn(NPDF, R)).astype(np.float32); b = (0.1 * rng.randn(NPDF)).astype(np.float32)
+    layers = [("transmit", I), ("lstm_streams", f1, I, C, R, S), ("lstm_streams", f2, R, C, R, S), ("affine", W, b), ("softmax", NPDF)]
+    utts = [(rng.randn(n, I).astype(np.float32), rng.randint(0, NPDF, n)) for n in (19, 31, 12, 7)]
+    (tmp_path / "n.bin").write_bytes(kaldi_fmt.nnet_binary(layers))
+    _pack_utts(utts).tofile(tmp_path / "u.raw")
+    r = run("nnet_train", tmp_path / "n.bin", tmp_path / "u.raw", S, T, delay, lr, mmt, 0, tmp_path / "out.bin")
+    head = r.stdout.splitlines()[0].split()
+    l1 = Oracle(I, C, R, S, np.float32); l1.set_params(f1)
+    l2 = Oracle(R, C, R, S, np.float32); l2.set_params(f2)
+    Wo, bo = W.copy(), b.copy(); Wc, bc = np.zeros_like(W), np.zeros_like(b)
+    batcher = oc.MultiStreamBatcher(utts, S, T, delay)
+    loss = frames = 0.0
+    while True:
+        nxt = batcher.next()
+        if nxt is None:
+            break
+        feat, target, mask, flags = nxt
+        l1.reset(flags); l2.reset(flags)
+        h1 = l1.propagate(feat); h2 = l2.propagate(h1)
+        y = oc.softmax(oc.affine_propagate(h2, Wo, bo))
+        diff, xe, ent, cor, valid = oc.xent_eval_masked(y, target, mask)
+        loss += xe - ent; frames += valid
+        d2 = oc.affine_backpropagate(diff, Wo); oc.affine_update(h2, diff, Wo, bo, Wc, bc, lr, lr, mmt)
+        d1 = l2.backpropagate(h1, d2, momentum=mmt); l2.update(lr)
+        l1.backpropagate(feat, d1, momentum=mmt); l1.update(lr)
+    assert head[0] == "OK" and float(head[3]) == frames
+    assert abs(float(head[4]) - loss / frames) <= 3e-4 * abs(loss / frames)
+    trained = [("transmit", I), ("lstm_streams", l1.get_params(), I, C, R, S), ("lstm_streams", l2.get_params(), R, C, R, S),
+               ("affine", Wo, bo), ("softmax", NPDF)]
+    (tmp_path / "exp.bin").write_bytes(kaldi_fmt.nnet_binary(trained))
+    run("nnet_copy", tmp_path / "out.bin", 0, tmp_path / "out.txt")
+    run("nnet_copy", tmp_path / "exp.bin", 0, tmp_path / "exp.txt")
+    num = lambda p: np.array([float(v) for v in p.read_text().replace("[", " ").replace("]", " ").split() if v[0] in "-0123456789."])
+    got, want = num(tmp_path / "out.txt"), num(tmp_path / "exp.txt")
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
