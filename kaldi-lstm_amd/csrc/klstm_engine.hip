@@ -46,9 +46,6 @@ struct klstm_engine {
   int I = 0, C = 0, R = 0, S = 0, device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t side = nullptr;          // second stream for work that overlaps the main chain
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
-  bool pack_inflight = false;          // BPTT-operand pack queued on `side`, not yet joined
   long nparams = 0;
   float *params = nullptr, *grads = nullptr, *corr = nullptr;
   float *wrT = nullptr, *wmT = nullptr, *wxT = nullptr;   // transposed copies for the BPTT kernels
@@ -66,6 +63,7 @@ struct klstm_engine {
   bool mmt_pending = false;   // DP: corr = mmt*corr + grads is folded into the next Update
   float mmt_value = 0.f;
   bool use_vector = true;
+  bool use_fat = true;
   int fuse_x = -1;    // -1 auto (small NumStream), 0 batched x-projection GEMM, 1 fused into the step kernel
   bool profile = false;
   std::vector<ProbeRec> probes;
@@ -141,21 +139,11 @@ static klstm_status flush_momentum(klstm_engine *e) {
   return KLSTM_OK;
 }
 
-static klstm_status join_pack(klstm_engine *e);
 static klstm_status repack(klstm_engine *e) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
-  { klstm_status js = join_pack(e); if (js != KLSTM_OK) return js; }
   HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream,
                               probe(e, "k_update_repack")));
   if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->stream, probe(e, "k_pack")));
-  return KLSTM_OK;
-}
-
-// main stream must not run BPTT before the side-stream pack of its operands has finished
-static klstm_status join_pack(klstm_engine *e) {
-  if (!e->pack_inflight) return KLSTM_OK;
-  HIPCHK(hipStreamWaitEvent(e->stream, e->ev_pack, 0));
-  e->pack_inflight = false;
   return KLSTM_OK;
 }
 
@@ -203,13 +191,6 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
     e->stream = it->second;
     e->own_stream = false;
   }
-  if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_pack, hipEventDisableTiming) != hipSuccess) {
-    klstm_destroy(e);
-    return fail(KLSTM_ERR_HIP, "klstm_create: side stream / events");
-  }
   const size_t pb = (size_t)e->nparams * sizeof(float);
   klstm_status st = KLSTM_OK;
   auto alloc0 = [&](float **p, size_t bytes) {
@@ -243,12 +224,7 @@ void klstm_destroy(klstm_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  if (e->side) (void)hipStreamSynchronize(e->side);
   drop_graphs(e);
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-  if (e->ev_pack) (void)hipEventDestroy(e->ev_pack);
-  if (e->side) (void)hipStreamDestroy(e->side);
   for (auto &r : e->probes) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   free_planes(e);
   float *ps[] = {e->params, e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3]};
@@ -351,6 +327,7 @@ static FwdPtrs fwd_ptrs(klstm_engine *e) {
   p.prev_c = e->prev_c; p.prev_r = e->prev_r;
   p.pk_gates = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[0]) : nullptr;
   p.pk_proj = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[1]) : nullptr;
+  p.fat = e->use_fat;
   return p;
 }
 static BwdPtrs bwd_ptrs(klstm_engine *e) {
@@ -361,6 +338,7 @@ static BwdPtrs bwd_ptrs(klstm_engine *e) {
   p.dgifo = e->dgifo; p.dc = e->dc; p.dr = e->dr; p.dr_part = e->dr_part; p.dx_part = e->dx_part; p.ks = e->ks;
   p.pk_dr = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[2]) : nullptr;
   p.pk_dm = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[3]) : nullptr;
+  p.fat = e->use_fat;
   return p;
 }
 
@@ -454,7 +432,6 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
     return fail(KLSTM_ERR_ARG, "klstm_backpropagate: stride smaller than row width");
   HIPCHK(hipSetDevice(e->device));
   { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }   // grads is about to be overwritten
-  { klstm_status js = join_pack(e); if (js != KLSTM_OK) return js; }
   const int T = e->T_fwd;
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum, flags);
   klstm_status st = run_graphed(e, key, [&]() {
@@ -496,7 +473,6 @@ klstm_status klstm_synchronize(klstm_engine *e) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipStreamSynchronize(e->side));
   return KLSTM_OK;
 }
 
@@ -543,6 +519,12 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
     e->use_vector = value != 0;
+    return KLSTM_OK;
+  }
+  if (!strcmp(key, "fat")) {             // 0: keep the 16-row tile kernels also for NumStream > 16 (testing / A-B)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    e->use_fat = value != 0;
     return KLSTM_OK;
   }
   if (!strcmp(key, "fuse_x")) {

@@ -17,6 +17,7 @@ struct FwdPtrs {
   float *gifo, *cc, *hh, *mm, *rr;
   float *prev_c, *prev_r;                            // carried state [S x C], [S x R]
   const float4 *pk_gates, *pk_proj;                  // packed (MFMA-operand-ordered) weight copies, or null
+  bool fat;                                          // allow the 64-row x 32-stream kernels when S > 16
 };
 
 struct BwdPtrs {
@@ -28,6 +29,7 @@ struct BwdPtrs {
   float *dx_part;                                    // split-K slabs [KS][S][I] (in_diff of one frame)
   int ks;                                            // number of slabs
   const float4 *pk_dr, *pk_dm;                       // packed weight copies, or null
+  bool fat;
 };
 
 // optional per-launch timing through hipExtLaunchKernelGGL start/stop events

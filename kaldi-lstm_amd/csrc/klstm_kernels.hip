@@ -188,6 +188,10 @@ __device__ __forceinline__ void mma_k_loop(int nch, int wave, f32x4 (&acc)[NT][2
 }
 struct NoPost { template <class... A> __device__ __forceinline__ void operator()(A &&...) const {} };
 
+// GENERIC kernels (any shape; used when R, I or C is not a multiple of 8): per-element guarded loads straight
+// from the natural layouts, 16x16x4 geometry, one K chunk per wave per iteration.
+#define GENERIC_GEOMETRY() constexpr int CPW = 1; constexpr bool VEC = false, SMALL = false
+
 #define STEP_PROLOGUE()                                                                          \
   const int lane = threadIdx.x & 63;                                                             \
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                             \
@@ -211,8 +215,9 @@ struct GatesArgs {
   float *c_save;                  // prev_c at t == T, else null
 };
 
-template <int NT, int CPW, bool VEC, bool SMALL, bool FUSEX>
+template <int NT, bool FUSEX>
 __global__ __launch_bounds__(NW * 64) void k_gates_step(GatesArgs a) {
+  GENERIC_GEOMETRY();
   STEP_PROLOGUE();
   const int C = a.C, R = a.R, S = a.S, I = a.I, t = a.t;
   const int c0 = blockIdx.x * 4;
@@ -305,8 +310,9 @@ struct ProjArgs {
   int vecOut;
 };
 
-template <int NT, int CPW, bool VEC, bool SMALL>
+template <int NT>
 __global__ __launch_bounds__(NW * 64) void k_proj_step(ProjArgs a) {
+  GENERIC_GEOMETRY();
   STEP_PROLOGUE();
   const int C = a.C, R = a.R, S = a.S, t = a.t;
   const int n0 = blockIdx.x * 16;
@@ -363,8 +369,9 @@ struct DrArgs {
   int vecX;
 };
 
-template <int NT, int CPW, bool VEC, bool SMALL>
+template <int NT>
 __global__ __launch_bounds__(NW * 64) void k_dr_step(DrArgs a) {
+  GENERIC_GEOMETRY();
   STEP_PROLOGUE();
   const int R = a.R, I = a.I, S = a.S, K = 4 * a.C;
   const bool is_x = (int)blockIdx.x >= a.ntr;
@@ -431,8 +438,9 @@ struct DmArgs {
   int id_stride;
 };
 
-template <int NT, int CPW, bool VEC, bool SMALL>
+template <int NT>
 __global__ __launch_bounds__(NW * 64) void k_dm_step(DmArgs a) {
+  GENERIC_GEOMETRY();
   STEP_PROLOGUE();
   const int C = a.C, R = a.R, S = a.S, t = a.t;
   const int c0 = blockIdx.x * 16;
@@ -559,11 +567,13 @@ template <int CPW, bool SMALL> struct VGeo {
 
 // One contraction: acc[nt] += A(tile rows, chunks [0,nch)) * B(streams, same chunks).
 //   apk   : packed weights of this tile, chunk c at apk + c*128 (float4 units)
-//   bload(s, k) -> float4 of B[s][k..k+3] in natural layout (zeros outside), k relative to chunk 0
+//   bload(s, k, on) -> float4 of B[s][k..k+3] in natural layout (zeros outside / when !on), k relative to chunk 0;
+//                      must be branch-free (clamped addresses + selects) so that all loads of a slab overlap
 //   bside(s, k, v): optional side store of the staged natural-layout value (mirrors)
 template <int NT, int CPW, bool SMALL, class BL, class BS>
 __device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int nch, int rows, float *ldsB,
                                              int lane, int wave, f32x4 (&acc)[NT][2], const BL &bload, const BS &bside) {
+  (void)rows;
   constexpr int SUPER = VGeo<CPW, SMALL>::SUPER, LDB = VGeo<CPW, SMALL>::LDB;
   constexpr int TS_ = Geo<SMALL>::STREAMS;
   const int bs = Geo<SMALL>::bstream(lane), kg = lane >> 4;
@@ -579,13 +589,24 @@ __device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int
       const float4 *ap = apk + (size_t)(base + cl) * 128 + lane;
       a0[c] = ap[0]; a1[c] = ap[64];
     }
-    // (2) stage B[rows][nc*32] lane-contiguous into LDS
-    const int f4row = nc * 8;
-    for (int idx = threadIdx.x; idx < rows * f4row; idx += NW * 64) {
-      const int s = idx / f4row, k = (idx - s * f4row) * 4;
-      const float4 v = bload(s, base * KCH + k);
-      *reinterpret_cast<float4 *>(ldsB + s * LDB + k) = v;
-      bside(s, base * KCH + k, v);
+    // (2) stage B[rows][nc*32] lane-contiguous into LDS: every load of the slab is issued before the first store
+    constexpr int ROWS = NT * TS_, F4ROW = SUPER * 8;
+    constexpr int U = (ROWS * F4ROW + NW * 64 - 1) / (NW * 64);
+    float4 sv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int idx = threadIdx.x + u * NW * 64;
+      const int sl = idx / F4ROW, k = (idx % F4ROW) * 4;
+      sv[u] = bload(sl < ROWS ? sl : 0, base * KCH + k, sl < ROWS && k < nc * KCH);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int idx = threadIdx.x + u * NW * 64;
+      const int sl = idx / F4ROW, k = (idx % F4ROW) * 4;
+      if (sl < ROWS && k < nc * KCH) {
+        *reinterpret_cast<float4 *>(ldsB + sl * LDB + k) = sv[u];
+        bside(sl, base * KCH + k, sv[u]);
+      }
     }
     __syncthreads();
     // (3) MFMAs
@@ -655,12 +676,12 @@ __global__ __launch_bounds__(NW * 64) void k_gates_v(GatesVArgs va) {
   const int Rp = nchR * KCH;
   const int nch = nchR + (FUSEX ? (I + KCH - 1) / KCH : 0);
   const bool mirror_r = a.r_mirror != nullptr && blockIdx.x == 0;
-  auto bload = [&](int sl, int k) -> float4 {             // B = [ r(t-1) | pad | x(t) | pad ]
-    const int s = sbase + sl;
-    if (s >= S) return f4zero();
-    if (k < R) return ldg4(a.rprev + (size_t)s * R + k);
-    if (FUSEX && k >= Rp && k - Rp < I) return ldg4(a.x + (size_t)s * a.x_stride + (k - Rp));
-    return f4zero();
+  auto bload = [&](int sl, int k, bool on) -> float4 {    // B = [ r(t-1) | pad | x(t) | pad ], branch-free
+    const int s = min(sbase + sl, S - 1);
+    const bool inr = k < R, inx = FUSEX && k >= Rp && k - Rp < I;
+    const float *p = inr ? a.rprev + (size_t)s * R + k : inx ? a.x + (size_t)s * a.x_stride + (k - Rp) : a.rprev;
+    const float4 v = ldg4(p);
+    return (on && sbase + sl < S && (inr || inx)) ? v : f4zero();
   };
   auto bside = [&](int sl, int k, const float4 &v) {      // :231 (r columns of time block 0)
     const int s = sbase + sl;
@@ -708,9 +729,9 @@ __global__ __launch_bounds__(NW * 64) void k_proj_v(ProjVArgs va) {
   const int sbase = blockIdx.y * TS_ * NT;
   const int nch = (C + KCH - 1) / KCH;
   const float *mrow = a.mm + (size_t)t * S * C;
-  auto bload = [&](int sl, int k) -> float4 {
-    const int s = sbase + sl;
-    return (s < S && k < C) ? ldg4(mrow + (size_t)s * C + k) : f4zero();
+  auto bload = [&](int sl, int k, bool on) -> float4 {
+    const float4 v = ldg4(mrow + (size_t)min(sbase + sl, S - 1) * C + min(k, C - 4));
+    return (on && sbase + sl < S && k < C) ? v : f4zero();
   };
   vec_contract<NT, CPW, SMALL>(va.wpk + (size_t)blockIdx.x * nch * 128, nch, NT * TS_, ldsB, lane, wave, acc, bload, NoSide());
   VEC_COMBINE();
@@ -745,9 +766,9 @@ __global__ __launch_bounds__(NW * 64) void k_dr_v(DrVArgs va) {
   const int kbeg = ks * a.klen;
   const int kend = min(K, kbeg + a.klen);
   const float *drow = a.dgifo + (size_t)(a.t + 1) * S * K;
-  auto bload = [&](int sl, int k) -> float4 {
-    const int s = sbase + sl;
-    return (s < S && kbeg + k < kend) ? ldg4(drow + (size_t)s * K + kbeg + k) : f4zero();
+  auto bload = [&](int sl, int k, bool on) -> float4 {
+    const float4 v = ldg4(drow + (size_t)min(sbase + sl, S - 1) * K + min(kbeg + k, K - 4));
+    return (on && sbase + sl < S && kbeg + k < kend) ? v : f4zero();
   };
   vec_contract<NT, CPW, SMALL>(va.wpk + ((size_t)tile * va.nch_total + kbeg / KCH) * 128,
                                kend > kbeg ? (kend - kbeg + KCH - 1) / KCH : 0, NT * TS_, ldsB, lane, wave, acc, bload, NoSide());
@@ -821,17 +842,19 @@ __global__ __launch_bounds__(NW * 64) void k_dm_v(DmVArgs va) {
 
   const int nch = (R + KCH - 1) / KCH;
   const bool write_dr = blockIdx.x == 0;
-  auto bload = [&](int sl, int k) -> float4 {             // d_r(t) = out_diff(t) + slabs   (:367, :391)
-    const int s = sbase + sl;
-    if (s >= S || k >= R) return f4zero();
-    float4 v = ldg4(a.out_diff + (size_t)((t - 1) * S + s) * a.od_stride + k);
+  auto bload = [&](int sl, int k, bool on) -> float4 {    // d_r(t) = out_diff(t) + slabs   (:367, :391), branch-free
+    const int s = min(sbase + sl, S - 1), kk = min(k, R - 4);
+    float4 v = ldg4(a.out_diff + (size_t)((t - 1) * S + s) * a.od_stride + kk);
     float4 p[KSMAX];
 #pragma unroll
-    for (int ks = 0; ks < KSMAX; ks++) p[ks] = ldg4(a.part + ((size_t)(ks < a.nslab ? ks : 0) * S + s) * R + k);
+    for (int ks = 0; ks < KSMAX; ks++) p[ks] = ldg4(a.part + ((size_t)(ks < a.nslab ? ks : 0) * S + s) * R + kk);
 #pragma unroll
-    for (int ks = 0; ks < KSMAX; ks++)
-      if (ks < a.nslab) { v.x += p[ks].x; v.y += p[ks].y; v.z += p[ks].z; v.w += p[ks].w; }
-    return v;
+    for (int ks = 0; ks < KSMAX; ks++) {
+      const bool use = ks < a.nslab;                     // fixed summation order; unused slabs add exactly +0 (select, not
+      v.x += use ? p[ks].x : 0.f; v.y += use ? p[ks].y : 0.f;   // multiply: a never-written slab may hold NaN bit patterns)
+      v.z += use ? p[ks].z : 0.f; v.w += use ? p[ks].w : 0.f;
+    }
+    return (on && sbase + sl < S && k < R) ? v : f4zero();
   };
   auto bside = [&](int sl, int k, const float4 &v) {
     const int s = sbase + sl;
@@ -842,6 +865,332 @@ __global__ __launch_bounds__(NW * 64) void k_dm_v(DmVArgs va) {
 
   if (e_on) {
     const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
+    const float dm[4] = {v.x, v.y, v.z, v.w};
+    float og[4], oi[4], of[4], oo[4], oc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float d_h = k_diff_tanh(dm[j] * yo[j], yh[j]);       // :411-412
+      const float d_o = k_diff_sigmoid(dm[j] * yh[j], yo[j]);    // :415-416
+      float d_c = d_h;                                           // :424
+      d_c = d_c + dcn[j] * fn[j];                                // :425
+      d_c = d_c + wpi[j] * din[j];                               // :426
+      d_c = d_c + wpf[j] * dfn[j];                               // :427
+      d_c = d_c + wpo[j] * d_o;                                  // :428
+      of[j] = k_diff_sigmoid(d_c * cpv[j], yf[j]);               // :431-432
+      oi[j] = k_diff_sigmoid(d_c * yg[j], yi[j]);                // :435-436
+      og[j] = k_diff_tanh(d_c * yi[j], yg[j]);                   // :439-440
+      oo[j] = d_o;
+      oc[j] = d_c;
+    }
+    float *dp = a.dgifo + row * 4 * C;
+    store4<true>(dp, cb, C, og);
+    store4<true>(dp + C, cb, C, oi);
+    store4<true>(dp + 2 * C, cb, C, of);
+    store4<true>(dp + 3 * C, cb, C, oo);
+    store4<true>(a.dc + row * C, cb, C, oc);
+  }
+}
+
+// =============================================================================================
+// MANY-STREAM VECTOR PATH (NumStream > 16 per GPU).  The tiles above make every workgroup re-stage the
+// activations of ALL its streams and finish with stream-major (scattered) epilogues -- fine while a step is
+// latency-bound, 10x off the MFMA roofline at 64+ streams.  Here the unit of work is one
+// (16-row weight tile, 16-stream tile) pair per wave so that every SIMD gets an MFMA chain of 50-64
+// instructions: a workgroup = MTW row tiles x KSW K-splits on ONE 16-stream tile (MTW*KSW = 8 waves),
+// grid = (row tiles / MTW) x (stream tiles).  The B slab (16 streams x up to 512 k) is staged once and
+// shared by the MTW row tiles, the K splits are combined through LDS in fixed order, and the result tile
+// [16 streams][MTW*16 rows] is consumed by a coalesced elementwise pass (thread = one stream x one 16-byte
+// row segment) whose operands were requested at kernel start.
+// =============================================================================================
+constexpr int FST = 16;                    // streams per workgroup
+// FS = K chunks per slab (16 or 32: the whole contraction in one slab whenever K <= 1024);
+// LDS row stride of the B slab FS*32 + 4 floats: conflict-free b128 reads
+
+template <int MTW, int KSW, int FS, class BL, class BS>
+__device__ __forceinline__ void fat_contract(const float4 *__restrict__ apk, int nch, float *ldsB, int lane, int ksp,
+                                             f32x4 (&acc)[2], const BL &bload, const BS &bside) {
+  constexpr int FLDB = FS * KCH + 4;
+  constexpr int PER = FS / KSW;              // max chunks of a slab per K split
+  const int bs = lane & 15, kg = lane >> 4;
+  for (int base = 0; base < nch; base += FS) {
+    const int nc = min(FS, nch - base);
+    const int per = (nc + KSW - 1) / KSW;
+    const int c0 = ksp * per;
+    float4 a0[PER], a1[PER];
+#pragma unroll
+    for (int c = 0; c < PER; c++) {
+      const int cl = min(c0 + c, nc - 1);
+      const float4 *ap = apk + (size_t)(base + cl) * 128 + lane;
+      a0[c] = ap[0]; a1[c] = ap[64];
+    }
+    constexpr int F4ROW = FS * 8, U = (FST * F4ROW) / (NW * 64);
+    float4 sv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int idx = threadIdx.x + u * NW * 64;
+      const int sl = idx / F4ROW, k = (idx % F4ROW) * 4;
+      sv[u] = bload(sl, base * KCH + k, k < nc * KCH);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int idx = threadIdx.x + u * NW * 64;
+      const int sl = idx / F4ROW, k = (idx % F4ROW) * 4;
+      if (k < nc * KCH) {
+        *reinterpret_cast<float4 *>(ldsB + sl * FLDB + k) = sv[u];
+        bside(sl, base * KCH + k, sv[u]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PER; c++) {
+      if (c < per && c0 + c < nc) {
+        const float av[8] = {a0[c].x, a0[c].y, a0[c].z, a0[c].w, a1[c].x, a1[c].y, a1[c].z, a1[c].w};
+        const float *bp = ldsB + bs * FLDB + (c0 + c) * KCH + kg * 8;
+        const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(bp + 4);
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j & 1] = MFMA16(av[j], bv[j], acc[j & 1]);
+      }
+    }
+    if (base + FS < nch) __syncthreads();
+  }
+}
+
+// K-split combine (fixed order) + scatter of the MFMA tiles into the result tile rt[stream][row], row stride RTS.
+// GATES: tile row 4q+reg is (cell mt*4+q, gate reg) -> rt column gate*(4*MTW) + cell;  else row mt*16 + 4q + reg.
+template <int MTW, int KSW, bool GATES>
+__device__ __forceinline__ void fat_combine(f32x4 (&acc)[2], f32x4 (*red)[MTW][64], float *rt, int lane, int mt, int ksp) {
+  constexpr int RTS = MTW * 16 + 4;
+  if (ksp > 0) red[ksp - 1][mt][lane] = acc[0] + acc[1];
+  __syncthreads();
+  if (ksp == 0) {
+    f32x4 v = acc[0] + acc[1];
+#pragma unroll
+    for (int p = 0; p < KSW - 1; p++) v += red[p][mt][lane];
+    const int q = lane >> 4;
+    float *rp = rt + (lane & 15) * RTS;
+    if (GATES) { const int cl = mt * 4 + q; rp[cl] = v.x; rp[4 * MTW + cl] = v.y; rp[8 * MTW + cl] = v.z; rp[12 * MTW + cl] = v.w; }
+    else *reinterpret_cast<float4 *>(rp + mt * 16 + 4 * q) = make_float4(v.x, v.y, v.z, v.w);
+  }
+  __syncthreads();
+}
+
+#define FAT_PROLOGUE()                                                                           \
+  const int lane = threadIdx.x & 63;                                                             \
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                             \
+  const int mt = wave % MTW, ksp = wave / MTW;                                                   \
+  constexpr int RTS = MTW * 16 + 4;                                                              \
+  __shared__ __attribute__((aligned(16))) float ldsB[FST * (FS * KCH + 4)];                      \
+  __shared__ f32x4 red[KSW - 1][MTW][64];                                                        \
+  __shared__ __attribute__((aligned(16))) float rt[FST * RTS];                                   \
+  f32x4 acc[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}}
+
+template <int MTW, int KSW, int FS, bool FUSEX>
+__global__ __launch_bounds__(NW * 64) void k_gates_f(GatesVArgs va) {
+  const GatesArgs &a = va.g;
+  FAT_PROLOGUE();
+  constexpr int CELLS = 4 * MTW;
+  const int C = a.C, R = a.R, S = a.S, I = a.I, t = a.t;
+  const int c0 = blockIdx.x * CELLS;
+  const int sbase = blockIdx.y * FST;
+  // elementwise operands: thread = (stream sbase + tid/CELLS, cell c0 + tid%CELLS)
+  const int sl_e = threadIdx.x / CELLS, j_e = threadIdx.x % CELLS;
+  const int e_s = sbase + sl_e, e_cell = c0 + j_e;
+  const bool e_on = sl_e < FST && e_s < S && e_cell < C;
+  const int l_cell = e_on ? e_cell : 0, l_s = e_on ? e_s : 0;
+  const size_t e_row = (size_t)t * S + l_s;
+  float pre[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) pre[g] = FUSEX ? a.bias[g * C + l_cell] : a.gifo[e_row * 4 * C + g * C + l_cell];
+  const float cp = a.cprev[(size_t)l_s * C + l_cell];
+  const float wpi = a.pi[l_cell], wpf = a.pf[l_cell], wpo = a.po[l_cell];
+
+  const int nchR = (R + KCH - 1) / KCH, Rp = nchR * KCH;
+  const int nch = nchR + (FUSEX ? (I + KCH - 1) / KCH : 0);
+  const bool mirror_r = a.r_mirror != nullptr && blockIdx.x == 0;
+  auto bload = [&](int sl, int k, bool on) -> float4 {    // B = [ r(t-1) | pad | x(t) | pad ], branch-free
+    const int s = min(sbase + sl, S - 1);
+    const bool inr = k < R, inx = FUSEX && k >= Rp && k - Rp < I;
+    const float *p = inr ? a.rprev + (size_t)s * R + k : inx ? a.x + (size_t)s * a.x_stride + (k - Rp) : a.rprev;
+    const float4 v = ldg4(p);
+    return (on && sbase + sl < S && (inr || inx)) ? v : f4zero();
+  };
+  auto bside = [&](int sl, int k, const float4 &v) {
+    const int s = sbase + sl;
+    if (mirror_r && s < S && k < R) *reinterpret_cast<float4 *>(a.r_mirror + (size_t)s * R + k) = v;
+  };
+  fat_contract<MTW, KSW, FS>(va.wpk + (size_t)(blockIdx.x * MTW + mt) * va.nch_total * 128, nch, ldsB, lane, ksp, acc, bload, bside);
+  fat_combine<MTW, KSW, true>(acc, red, rt, lane, mt, ksp);
+
+  if (e_on) {
+    const float *rp = rt + sl_e * RTS + j_e;
+    float ag = rp[0] + pre[0];
+    float ai = rp[CELLS] + pre[1];
+    float af = rp[2 * CELLS] + pre[2];
+    float ao = rp[3 * CELLS] + pre[3];
+    ai += wpi * cp;                                // :278
+    af += wpf * cp;                                // :281
+    const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
+    float c = gg * gi;                             // :291
+    c = c + cp * gf;                               // :294
+    c = c < -50.f ? -50.f : c;                     // :296
+    c = c > 50.f ? 50.f : c;                       // :297
+    const float h = k_tanh(c);                     // :300
+    ao += wpo * c;                                 // :303
+    const float go = k_sigmoid(ao);                // :306
+    const float m = h * go;                        // :309
+    float *gp = a.gifo + e_row * 4 * C + e_cell;
+    gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
+    a.cc[e_row * C + e_cell] = c;
+    a.hh[e_row * C + e_cell] = h;
+    a.mm[e_row * C + e_cell] = m;
+    if (a.c_mirror) a.c_mirror[(size_t)e_s * C + e_cell] = cp;   // :231 (c columns)
+    if (a.c_save) a.c_save[(size_t)e_s * C + e_cell] = c;         // :331 (c columns)
+  }
+}
+
+template <int MTW, int KSW, int FS>
+__global__ __launch_bounds__(NW * 64) void k_proj_f(ProjVArgs va) {
+  const ProjArgs &a = va.g;
+  FAT_PROLOGUE();
+  constexpr int Q = MTW * 4;                         // 16-byte row segments per stream
+  const int C = a.C, R = a.R, S = a.S, t = a.t;
+  const int n0 = blockIdx.x * MTW * 16;
+  const int sbase = blockIdx.y * FST;
+  const int nch = (C + KCH - 1) / KCH;
+  const int ntile = min((int)blockIdx.x * MTW + mt, (R + 15) / 16 - 1);      // clamped: rows past R are dropped below
+  const float *mrow = a.mm + (size_t)t * S * C;
+  auto bload = [&](int sl, int k, bool on) -> float4 {
+    const float4 v = ldg4(mrow + (size_t)min(sbase + sl, S - 1) * C + min(k, C - 4));
+    return (on && sbase + sl < S && k < C) ? v : f4zero();
+  };
+  fat_contract<MTW, KSW, FS>(va.wpk + (size_t)ntile * nch * 128, nch, ldsB, lane, ksp, acc, bload, NoSide());
+  fat_combine<MTW, KSW, false>(acc, red, rt, lane, mt, ksp);
+  const int sl_e = threadIdx.x / Q, j_e = threadIdx.x % Q;
+  const int s = sbase + sl_e, n = n0 + 4 * j_e;
+  if (sl_e < FST && s < S && n < R) {
+    const float4 v = *reinterpret_cast<const float4 *>(rt + sl_e * RTS + 4 * j_e);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    store4<true>(a.rr + ((size_t)t * S + s) * R, n, R, e);
+    float *op = a.out + (size_t)((t - 1) * S + s) * a.out_stride;
+    if (a.vecOut) store4<true>(op, n, R, e); else store4<false>(op, n, R, e);
+    if (a.r_save) store4<true>(a.r_save + (size_t)s * R, n, R, e);
+  }
+}
+
+template <int MTW, int KSW, int FS>
+__global__ __launch_bounds__(NW * 64) void k_dr_f(DrVArgs va) {
+  const DrArgs &a = va.g;
+  FAT_PROLOGUE();
+  constexpr int Q = MTW * 4;
+  const int R = a.R, I = a.I, S = a.S, K = 4 * a.C;
+  const int ntR16 = (R + 15) / 16, ntX16 = (I + 15) / 16;
+  const bool is_x = (int)blockIdx.x >= a.ntr;                      // a.ntr counts MTW-tile groups over R here
+  const int g = is_x ? (int)blockIdx.x - a.ntr : (int)blockIdx.x;
+  const int tile = is_x ? ntR16 + min(g * MTW + mt, ntX16 - 1) : min(g * MTW + mt, ntR16 - 1);
+  const int n0 = g * MTW * 16;
+  const int N = is_x ? I : R;
+  const int sbase = blockIdx.y * FST;
+  const int ks = blockIdx.z;
+  const int kbeg = ks * a.klen;
+  const int kend = min(K, kbeg + a.klen);
+  const float *drow = a.dgifo + (size_t)(a.t + 1) * S * K;
+  auto bload = [&](int sl, int k, bool on) -> float4 {
+    const float4 v = ldg4(drow + (size_t)min(sbase + sl, S - 1) * K + min(kbeg + k, K - 4));
+    return (on && sbase + sl < S && kbeg + k < kend) ? v : f4zero();
+  };
+  fat_contract<MTW, KSW, FS>(va.wpk + ((size_t)tile * va.nch_total + kbeg / KCH) * 128,
+                         kend > kbeg ? (kend - kbeg + KCH - 1) / KCH : 0, ldsB, lane, ksp, acc, bload, NoSide());
+  fat_combine<MTW, KSW, false>(acc, red, rt, lane, mt, ksp);
+  const int sl_e = threadIdx.x / Q, j_e = threadIdx.x % Q;
+  const int s = sbase + sl_e, n = n0 + 4 * j_e;
+  if (sl_e < FST && s < S && n < N) {
+    const float4 v = *reinterpret_cast<const float4 *>(rt + sl_e * RTS + 4 * j_e);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    if (is_x) {
+      float *xp = a.xpart + ((size_t)ks * S + s) * a.x_ld;
+      if (a.vecX) store4<true>(xp, n, I, e); else store4<false>(xp, n, I, e);
+    } else {
+      store4<true>(a.part + ((size_t)ks * S + s) * R, n, R, e);
+    }
+  }
+}
+
+template <int MTW, int KSW, int FS>
+__global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
+  const DmArgs &a = va.g;
+  FAT_PROLOGUE();
+  constexpr int Q = MTW * 4;
+  const int C = a.C, R = a.R, S = a.S, t = a.t;
+  const int c0 = blockIdx.x * MTW * 16;
+  const int sbase = blockIdx.y * FST;
+  const bool last = (t == a.T);
+
+  if (a.xpart && blockIdx.x == gridDim.x - 1) {          // in_diff(t+1) = sum of its split-K slabs (:457)
+    const int I = a.I;
+    for (int idx = sbase * I + threadIdx.x; idx < min(S, sbase + FST) * I; idx += NW * 64) {
+      const int s = idx / I, n = idx - s * I;
+      float p[KSMAX];
+#pragma unroll
+      for (int ks = 0; ks < KSMAX; ks++) p[ks] = a.xpart[((size_t)(ks < a.nslab ? ks : 0) * S + s) * I + n];
+      float sum = p[0];
+#pragma unroll
+      for (int ks = 1; ks < KSMAX; ks++) sum += ks < a.nslab ? p[ks] : 0.f;
+      a.in_diff[(size_t)s * a.id_stride + n] = sum;
+    }
+  }
+
+  // elementwise operands: thread = (stream, cells cb..cb+3), requested before the contraction
+  const int sl_e = threadIdx.x / Q, j_e = threadIdx.x % Q;
+  const int e_s = sbase + sl_e, cb = c0 + 4 * j_e;
+  const bool e_on = sl_e < FST && e_s < S && cb < C;
+  const size_t row = (size_t)t * S + (e_on ? e_s : 0), rown = row + S, rowp = row - S;
+  float yg[4], yi[4], yf[4], yo[4], yh[4], cpv[4], dcn[4], fn[4], din[4], dfn[4], wpi[4], wpf[4], wpo[4];
+  {
+    const float *yp = a.gifo + row * 4 * C;
+    load4<true>(yp, cb, C, e_on, yg);
+    load4<true>(yp + C, cb, C, e_on, yi);
+    load4<true>(yp + 2 * C, cb, C, e_on, yf);
+    load4<true>(yp + 3 * C, cb, C, e_on, yo);
+    load4<true>(a.hh + row * C, cb, C, e_on, yh);
+    load4<true>(a.cc + rowp * C, cb, C, e_on, cpv);
+    const bool n_on = e_on && !last;
+    const size_t rn = last ? row : rown;
+    load4<true>(a.dc + rn * C, cb, C, n_on, dcn);
+    load4<true>(a.gifo + rn * 4 * C + 2 * C, cb, C, n_on, fn);
+    load4<true>(a.dgifo + rn * 4 * C + C, cb, C, n_on, din);
+    load4<true>(a.dgifo + rn * 4 * C + 2 * C, cb, C, n_on, dfn);
+    load4<true>(a.pi, cb, C, e_on, wpi);
+    load4<true>(a.pf, cb, C, e_on, wpf);
+    load4<true>(a.po, cb, C, e_on, wpo);
+  }
+
+  const int nch = (R + KCH - 1) / KCH;
+  const int ctile = min((int)blockIdx.x * MTW + mt, (C + 15) / 16 - 1);
+  const bool write_dr = blockIdx.x == 0;
+  auto bload = [&](int sl, int k, bool on) -> float4 {    // d_r(t) = out_diff(t) + slabs   (:367, :391), branch-free
+    const int s = min(sbase + sl, S - 1), kk = min(k, R - 4);
+    float4 v = ldg4(a.out_diff + (size_t)((t - 1) * S + s) * a.od_stride + kk);
+    float4 p[KSMAX];
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ks++) p[ks] = ldg4(a.part + ((size_t)(ks < a.nslab ? ks : 0) * S + s) * R + kk);
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ks++) {
+      const bool use = ks < a.nslab;                     // fixed summation order; unused slabs add exactly +0 (select, not
+      v.x += use ? p[ks].x : 0.f; v.y += use ? p[ks].y : 0.f;   // multiply: a never-written slab may hold NaN bit patterns)
+      v.z += use ? p[ks].z : 0.f; v.w += use ? p[ks].w : 0.f;
+    }
+    return (on && sbase + sl < S && k < R) ? v : f4zero();
+  };
+  auto bside = [&](int sl, int k, const float4 &v) {
+    const int s = sbase + sl;
+    if (write_dr && s < S && k < R) *reinterpret_cast<float4 *>(a.dr + ((size_t)t * S + s) * R + k) = v;
+  };
+  fat_contract<MTW, KSW, FS>(va.wpk + (size_t)ctile * nch * 128, nch, ldsB, lane, ksp, acc, bload, bside);
+  fat_combine<MTW, KSW, false>(acc, red, rt, lane, mt, ksp);
+
+  if (e_on) {
+    const float4 v = *reinterpret_cast<const float4 *>(rt + sl_e * RTS + 4 * j_e);
     const float dm[4] = {v.x, v.y, v.z, v.w};
     float og[4], oi[4], of[4], oo[4], oc[4];
 #pragma unroll
@@ -925,7 +1274,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
 // LDS-tiled MFMA GEMM tile (64x64 output, BK = 32, 256 threads = 2x2 waves of 32x32).  The next
 // K tile is fetched into registers while the current one is multiplied out of LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int GT = 64, GK = 32, GLD = 80;   // LDS row stride 80 floats: k-groups land on disjoint banks
+constexpr int GT = 64, GK = 64, GLD = 80;   // LDS row stride 80 floats: k-groups land on disjoint banks
 
 struct GemmJob {
   int M, N, K;
@@ -937,34 +1286,43 @@ struct GemmJob {
   int vecA, vecB;
 };
 
+// One operand tile = GT x GK elements = 2 x (8 floats per thread).  Operand stored [X x K] (TA=false: 8 consecutive k
+// of one x) or [K x X] (TA=true: 8 consecutive x of one k).  `vec` (block-uniform): rows 16-byte aligned and the
+// contiguous extent a multiple of 8 -> branch-free loads.
 template <bool TA>
 __device__ __forceinline__ void fetch_tile(const float *__restrict__ P, int ld, bool vec, int X, int K, int x0, int k0,
-                                           int tid, float (&r)[8]) {
-  // operand stored [X x K] (TA=false: 8 consecutive k of one x) or [K x X] (TA=true: 8 consecutive x of one k).
-  // `vec` (block-uniform): rows 16-byte aligned and the contiguous extent a multiple of 8 -> branch-free loads.
-  if (!TA) {
-    const int x = x0 + (tid >> 2), k = k0 + (tid & 3) * 8;
-    const float *row = P + (size_t)(x < X ? x : 0) * ld;
-    if (vec) load8<true>(row, k, K, x < X, r); else load8<false>(row, k, K, x < X, r);
-  } else {
-    const int k = k0 + (tid >> 3), x = x0 + (tid & 7) * 8;
-    const float *row = P + (size_t)(k < K ? k : 0) * ld;
-    if (vec) load8<true>(row, x, X, k < K, r); else load8<false>(row, x, X, k < K, r);
+                                           int tid, float (&r)[2][8]) {
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    if (!TA) {
+      const int x = x0 + (tid >> 2), k = k0 + h * 32 + (tid & 3) * 8;
+      const float *row = P + (size_t)(x < X ? x : 0) * ld;
+      if (vec) load8<true>(row, k, K, x < X, r[h]); else load8<false>(row, k, K, x < X, r[h]);
+    } else {
+      const int k = k0 + h * 32 + (tid >> 3), x = x0 + (tid & 7) * 8;
+      const float *row = P + (size_t)(k < K ? k : 0) * ld;
+      if (vec) load8<true>(row, x, X, k < K, r[h]); else load8<false>(row, x, X, k < K, r[h]);
+    }
   }
 }
 template <bool TA>
-__device__ __forceinline__ void stash_tile(float (*Ls)[GLD], int tid, const float (&r)[8]) {
-  if (!TA) {
-    const int x = tid >> 2, k = (tid & 3) * 8;
+__device__ __forceinline__ void stash_tile(float (*Ls)[GLD], int tid, const float (&r)[2][8]) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) Ls[k + j][x] = r[j];
-  } else {
-    const int k = tid >> 3, x = (tid & 7) * 8;
+  for (int h = 0; h < 2; h++) {
+    if (!TA) {
+      const int x = tid >> 2, k = h * 32 + (tid & 3) * 8;
 #pragma unroll
-    for (int j = 0; j < 8; j++) Ls[k][x + j] = r[j];
+      for (int j = 0; j < 8; j++) Ls[k + j][x] = r[h][j];
+    } else {
+      const int k = h * 32 + (tid >> 3), x = (tid & 7) * 8;
+      *reinterpret_cast<float4 *>(&Ls[k][x]) = make_float4(r[h][0], r[h][1], r[h][2], r[h][3]);
+      *reinterpret_cast<float4 *>(&Ls[k][x + 4]) = make_float4(r[h][4], r[h][5], r[h][6], r[h][7]);
+    }
   }
 }
 
+// 64x64 output tile, 4 waves (2x2) of 32x32, K tile 64.  The next K tile is fetched into registers while the
+// current one is multiplied out of LDS (global latency hides under 16 k-steps x 4 MFMAs per wave).
 template <bool TA, bool TB>
 __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, float (*As)[GLD], float (*Bs)[GLD]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -976,7 +1334,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
 #pragma unroll
     for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
 
-  float ra[8], rb[8];
+  float ra[2][8], rb[2][8];
   fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, 0, tid, ra);
   fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, 0, tid, rb);   // B [N x K] when TB, else [K x N]
   for (int k0 = 0; k0 < g.K; k0 += GK) {
@@ -987,8 +1345,9 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
       fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0 + GK, tid, ra);
       fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, k0 + GK, tid, rb);
     }
-#pragma unroll
-    for (int kk = 0; kk < GK / 4; kk++) {
+    const int ksteps = min(GK, g.K - k0 + 3) / 4;                    // skip all-zero tail steps of a short last tile
+#pragma unroll 4
+    for (int kk = 0; kk < ksteps; kk++) {
       const int k = kk * 4 + kg;
       const float a0 = As[k][wr * 32 + i16], a1 = As[k][wr * 32 + 16 + i16];
       const float b0 = Bs[k][wc * 32 + i16], b1 = Bs[k][wc * 32 + 16 + i16];
@@ -1254,10 +1613,10 @@ static inline int pick_nt(int S) {
 #define GEN_DISPATCH(KERN, nt, grid, st, pr, args, ...)                                           \
   do {                                                                                            \
     const dim3 _blk(NW * 64);                                                                     \
-    if (nt == 1) KLAUNCH((KERN<1, 1, false, false __VA_ARGS__>), grid, _blk, st, pr, args);       \
-    if (nt == 2) KLAUNCH((KERN<2, 1, false, false __VA_ARGS__>), grid, _blk, st, pr, args);       \
-    if (nt == 4) KLAUNCH((KERN<4, 1, false, false __VA_ARGS__>), grid, _blk, st, pr, args);       \
-    KLAUNCH((KERN<8, 1, false, false __VA_ARGS__>), grid, _blk, st, pr, args);                    \
+    if (nt == 1) KLAUNCH((KERN<1 __VA_ARGS__>), grid, _blk, st, pr, args);                        \
+    if (nt == 2) KLAUNCH((KERN<2 __VA_ARGS__>), grid, _blk, st, pr, args);                        \
+    if (nt == 4) KLAUNCH((KERN<4 __VA_ARGS__>), grid, _blk, st, pr, args);                        \
+    KLAUNCH((KERN<8 __VA_ARGS__>), grid, _blk, st, pr, args);                                     \
   } while (0)
 // vector kernels: SMALL (4x4x1_16b, S <= 4) with CPW in {1,2,4};  16x16x4 with (NT,CPW) in {(1,1),(1,2),(2,1),(4,1)}
 struct VecCfg { bool small; int nt, cpw; };
@@ -1306,6 +1665,14 @@ hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, bool fuse_x
   if (vec) {
     GatesVArgs va; va.g = a; va.wpk = p.pk_gates;
     va.nch_total = cdiv(d.R, KCH) + cdiv(d.I, KCH);
+    if (p.fat && d.S > 16) {                                 // 4 row tiles (16 cells) x 2 K splits per workgroup
+      const dim3 fgrid(cdiv(d.C, 16), cdiv(d.S, FST));
+      const bool big = (fuse_x ? cdiv(d.R, KCH) + cdiv(d.I, KCH) : cdiv(d.R, KCH)) > 16;
+      if (fuse_x && big) KLAUNCH((k_gates_f<4, 2, 32, true>), fgrid, dim3(NW * 64), st, pr, va);
+      if (fuse_x) KLAUNCH((k_gates_f<4, 2, 16, true>), fgrid, dim3(NW * 64), st, pr, va);
+      if (big) KLAUNCH((k_gates_f<4, 2, 32, false>), fgrid, dim3(NW * 64), st, pr, va);
+      KLAUNCH((k_gates_f<4, 2, 16, false>), fgrid, dim3(NW * 64), st, pr, va);
+    }
     const VecCfg cfg = pick_vec(d.S, cdiv(d.R, KCH) + (fuse_x ? cdiv(d.I, KCH) : 0));
     const dim3 grid = vec_grid(cdiv(d.C, 4), d.S, cfg);
     if (fuse_x) VEC_DISPATCH(k_gates_v, cfg, grid, st, pr, va, COMMA true);
@@ -1327,6 +1694,11 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
   const bool vec = p.pk_proj != nullptr && aligned16(p.mm) && aligned16(p.rr) && aligned16(p.prev_r);
   if (vec) {
     ProjVArgs va; va.g = a; va.wpk = p.pk_proj;
+    if (p.fat && d.S > 16) {
+      const dim3 fgrid(cdiv(d.R, 32), cdiv(d.S, FST));
+      if (cdiv(d.C, KCH) > 16) KLAUNCH((k_proj_f<2, 4, 32>), fgrid, dim3(NW * 64), st, pr, va);
+      KLAUNCH((k_proj_f<2, 4, 16>), fgrid, dim3(NW * 64), st, pr, va);
+    }
     const VecCfg cfg = pick_vec(d.S, cdiv(d.C, KCH));
     VEC_DISPATCH(k_proj_v, cfg, vec_grid(cdiv(d.R, 16), d.S, cfg), st, pr, va, );
   }
@@ -1360,6 +1732,13 @@ hipError_t launch_dr_step(const Dims &d, const BwdPtrs &p, int t, float *in_diff
   const bool vec = p.pk_dr != nullptr && aligned16(p.dgifo) && aligned16(p.dr_part);
   if (vec) {
     DrVArgs va; va.g = a; va.wpk = p.pk_dr; va.nch_total = cdiv(K, KCH);
+    if (p.fat && d.S > 16) {
+      va.g.ntr = t == 0 ? 0 : cdiv(d.R, 32);                       // 32-row groups (2 row tiles x 4 K splits)
+      const int gx = va.g.ntr + (in_diff ? cdiv(d.I, 32) : 0);
+      // (a 32-chunk slab was measured slower here: 66 KB of LDS and 16 weight registers per lane cost more in
+      //  occupancy than the second staging round trip they save)
+      KLAUNCH((k_dr_f<2, 4, 16>), dim3(gx, cdiv(d.S, FST), ks), dim3(NW * 64), st, pr, va);
+    }
     const VecCfg cfg = pick_vec(d.S, cdiv(a.klen, KCH));
     VEC_DISPATCH(k_dr_v, cfg, vec_grid(a.ntr + ntx, d.S, cfg, ks), st, pr, va, );
   }
@@ -1386,6 +1765,11 @@ hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *o
                    aligned16(p.cc) && aligned16(p.hh) && aligned16(p.pi) && aligned16(p.pf) && aligned16(p.po);
   if (vec) {
     DmVArgs va; va.g = a; va.wpk = p.pk_dm;
+    if (p.fat && d.S > 16) {
+      const dim3 fgrid(cdiv(d.C, 32), cdiv(d.S, FST));
+      if (cdiv(d.R, KCH) > 16) KLAUNCH((k_dm_f<2, 4, 32>), fgrid, dim3(NW * 64), st, pr, va);
+      KLAUNCH((k_dm_f<2, 4, 16>), fgrid, dim3(NW * 64), st, pr, va);
+    }
     const VecCfg cfg = pick_vec(d.S, cdiv(d.R, KCH));
     VEC_DISPATCH(k_dm_v, cfg, vec_grid(cdiv(d.C, 16), d.S, cfg), st, pr, va, );
   }
@@ -1396,7 +1780,8 @@ hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *o
 
 bool pack_supported(const Dims &d) { return d.R % 8 == 0 && d.I % 8 == 0 && d.C % 8 == 0; }
 void pack_sizes(const Dims &d, long n4[4]) {
-  n4[0] = (long)cdiv(d.C, 4) * (cdiv(d.R, KCH) + cdiv(d.I, KCH)) * 128;
+  // gates tiles are 4 cells each; a fat workgroup walks 4 of them, so round up to 16 cells (zero rows)
+  n4[0] = (long)cdiv(d.C, 16) * 4 * (cdiv(d.R, KCH) + cdiv(d.I, KCH)) * 128;
   n4[1] = (long)cdiv(d.R, 16) * cdiv(d.C, KCH) * 128;
   n4[2] = (long)(cdiv(d.R, 16) + cdiv(d.I, 16)) * cdiv(4 * d.C, KCH) * 128;
   n4[3] = (long)cdiv(d.C, 16) * cdiv(d.R, KCH) * 128;

@@ -31,7 +31,7 @@ def make_engine(I, C, R, S, params):
 
 
 def run_chunks(I, C, R, S, T, nchunks, scale, momentum, lr, seed=0, want_in_diff=True, od_scale=1.0, fuse_x=-1,
-               vector=1):
+               vector=1, fat=1):
     """Runs nchunks x (Propagate, Backpropagate, Update) on both sides; returns per-chunk records."""
     rng = np.random.RandomState(seed)
     p = make_params(I, C, R, scale=scale, seed=seed + 1)
@@ -40,6 +40,7 @@ def run_chunks(I, C, R, S, T, nchunks, scale, momentum, lr, seed=0, want_in_diff
     e = make_engine(I, C, R, S, p)
     e.set_option("fuse_x", fuse_x)
     e.set_option("vector", vector)
+    e.set_option("fat", fat)
     recs = []
     for ck in range(nchunks):
         x = rng.randn(T * S, I).astype(np.float32)
@@ -125,6 +126,19 @@ def test_vector_and_generic_kernels(I, C, R, S, T, vector):
     """Aligned shapes (R, I, C multiples of 8) run the packed-weight / LDS-staged vector kernels;
     vector=0 forces the generic kernels on the same shapes.  Both must match the oracle."""
     recs = run_chunks(I, C, R, S, T, nchunks=3, scale=0.3, momentum=0.9, lr=1e-3, vector=vector)
+    check(recs, tol_act=2e-5, tol_grad=1e-4, C=C, S=S, T=T)
+
+
+@pytest.mark.parametrize("fat", [0, 1])
+@pytest.mark.parametrize("I,C,R,S,T,want_in_diff", [
+    (24, 40, 24, 24, 3, True),       # partial 16-cell group (C=40), partial second stream tile
+    (40, 72, 48, 33, 3, True),       # two stream groups (33 > 32), partial 64-row groups everywhere
+    (16, 136, 72, 64, 2, False),     # several K slabs in BPTT (4C = 544), in_diff skipped
+    (264, 64, 40, 17, 2, True),      # wide input: x-projection batched (S > 16), x tiles in the dr kernel span 5 row groups
+])
+def test_fat_kernels_for_many_streams(I, C, R, S, T, want_in_diff, fat):
+    """NumStream > 16 runs the 64-row x 32-stream kernels; fat=0 keeps the 16-row tiles.  Same oracle, same tolerances."""
+    recs = run_chunks(I, C, R, S, T, nchunks=2, scale=0.3, momentum=0.9, lr=1e-3, want_in_diff=want_in_diff, fat=fat)
     check(recs, tol_act=2e-5, tol_grad=1e-4, C=C, S=S, T=T)
 
 
