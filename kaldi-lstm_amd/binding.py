@@ -170,14 +170,14 @@ class Engine:
     # ---- PropagateFnc / BackpropagateFnc / Update (reference :222, :334, :501) ----
     def propagate(self, x, out):
         """x [rows, I], out [rows, R]: torch CUDA float32, last dim contiguous."""
-        assert x.is_cuda and out.is_cuda and x.stride(1) == 1 and out.stride(1) == 1
+        assert x.is_cuda and out.is_cuda and (x.shape[0] == 0 or (x.stride(1) == 1 and out.stride(1) == 1))
         rows = x.shape[0]
         self._keep = [x, out]
         self._chk(self.lib.klstm_propagate(self.h, x.data_ptr(), rows, x.stride(0), out.data_ptr(), out.stride(0)))
         self.T = rows // self.S
 
     def backpropagate(self, x, out_diff, in_diff=None, momentum=0.0, flags=0):
-        assert x.is_cuda and out_diff.is_cuda and x.stride(1) == 1 and out_diff.stride(1) == 1
+        assert x.is_cuda and out_diff.is_cuda and (x.shape[0] == 0 or (x.stride(1) == 1 and out_diff.stride(1) == 1))
         idp, ids = (in_diff.data_ptr(), in_diff.stride(0)) if in_diff is not None else (None, 0)
         self._keep += [x, out_diff, in_diff]
         self._chk(self.lib.klstm_backpropagate(self.h, x.data_ptr(), x.stride(0), out_diff.data_ptr(),

@@ -405,11 +405,16 @@ static klstm_status run_graphed(klstm_engine *e, const klstm_engine::Key &key, F
 extern "C" {
 
 klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_stride, float *out, int out_stride) {
-  if (!e || !in || !out) return fail(KLSTM_ERR_ARG, "klstm_propagate: null argument");
-  if (rows <= 0 || rows % e->S != 0)
+  if (!e || ((!in || !out) && rows != 0)) return fail(KLSTM_ERR_ARG, "klstm_propagate: null argument");
+  if (rows < 0 || rows % e->S != 0)
     return fail(KLSTM_ERR_SHAPE, "klstm_propagate: rows (%d) %% num_stream (%d) != 0", rows, e->S);
-  if (in_stride < e->I || out_stride < e->R) return fail(KLSTM_ERR_ARG, "klstm_propagate: stride smaller than row width");
+  if (rows == 0) {          // T = 0: the reference's loops simply do not run (:261, :328 with zero rows); state is unchanged
+    e->T_fwd = 0;
+    e->T_bwd = -1;
+    return KLSTM_OK;
+  }
   HIPCHK(hipSetDevice(e->device));
+  if (in_stride < e->I || out_stride < e->R) return fail(KLSTM_ERR_ARG, "klstm_propagate: stride smaller than row width");
   const int T = rows / e->S;
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
@@ -424,14 +429,24 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
 klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride, const float *out_diff,
                                  int out_diff_stride, float *in_diff, int in_diff_stride, int rows,
                                  float momentum, int flags) {
-  if (!e || !in || !out_diff) return fail(KLSTM_ERR_ARG, "klstm_backpropagate: null argument");
+  if (!e || ((!in || !out_diff) && rows != 0)) return fail(KLSTM_ERR_ARG, "klstm_backpropagate: null argument");
   if (e->T_fwd < 0) return fail(KLSTM_ERR_STATE, "klstm_backpropagate: no preceding klstm_propagate");
   if (rows != e->T_fwd * e->S)
     return fail(KLSTM_ERR_SHAPE, "klstm_backpropagate: rows (%d) differ from the preceding propagate (%d)", rows, e->T_fwd * e->S);
-  if (in_stride < e->I || out_diff_stride < e->R || (in_diff && in_diff_stride < e->I))
+  if (rows != 0 && (in_stride < e->I || out_diff_stride < e->R || (in_diff && in_diff_stride < e->I)))
     return fail(KLSTM_ERR_ARG, "klstm_backpropagate: stride smaller than row width");
   HIPCHK(hipSetDevice(e->device));
   { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }   // grads is about to be overwritten
+  if (rows == 0) {          // T = 0: every gradient GEMM has K = 0 -> corr = momentum*corr (:468-487), grads = 0
+    const bool defer0 = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
+    if (defer0) HIPCHK(hipMemsetAsync(e->grads, 0, (size_t)e->nparams * sizeof(float), e->stream));
+    else {
+      HIPCHK(hipMemsetAsync(e->grads, 0, (size_t)e->nparams * sizeof(float), e->stream));
+      HIPCHK(launch_apply_momentum(e->corr, e->grads, momentum, e->nparams, e->stream, probe(e, "k_apply_momentum")));
+    }
+    e->T_bwd = 0;
+    return KLSTM_OK;
+  }
   const int T = e->T_fwd;
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum, flags);
   klstm_status st = run_graphed(e, key, [&]() {
@@ -480,6 +495,7 @@ klstm_status klstm_get_activations_host(klstm_engine *e, int which, float *dst) 
   if (!e || !dst) return fail(KLSTM_ERR_ARG, "null argument");
   const int T = which == 0 ? e->T_fwd : e->T_bwd;
   if (T < 0) return fail(KLSTM_ERR_STATE, "klstm_get_activations_host: nothing has run yet");
+  if (T == 0 || !e->gifo) { memset(dst, 0, (size_t)2 * e->S * (7 * e->C + e->R) * sizeof(float)); return KLSTM_OK; }
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
   const int S = e->S, C = e->C, R = e->R, W = 7 * C + R;

@@ -392,3 +392,61 @@ def test_full_size_layer_shapes_of_the_larger_configs(I, C, R, S):
     T = 20
     recs = run_chunks(I, C, R, S, T, nchunks=1, scale=0.01, momentum=0.9, lr=1e-5, od_scale=0.1)
     check(recs, tol_act=3e-5, tol_grad=3e-4, C=C, S=S, T=T)
+
+
+def test_varying_batch_length_regrows_planes_and_graphs():
+    """T changes between calls (last batch of an epoch, standard/ whole utterances of different length): planes are
+    re-allocated when T grows, graphs are keyed by T; state still bridges exactly (chunk boundaries are arbitrary)."""
+    I, C, R, S = 40, 64, 32, 2
+    p = make_params(I, C, R, scale=0.2, seed=12)
+    rng = np.random.RandomState(12)
+    e = make_engine(I, C, R, S, p)
+    o = Oracle(I, C, R, S, np.float32); o.set_params(p)
+    for T in (3, 11, 5, 11, 40, 1):
+        x = rng.randn(T * S, I).astype(np.float32); od = rng.randn(T * S, R).astype(np.float32)
+        xd, odd = dev(x), dev(od)
+        out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
+        torch.cuda.synchronize()
+        e.propagate(xd, out); e.backpropagate(xd, odd, ind, momentum=0.5); e.update(1e-3); e.synchronize()
+        out_o = o.propagate(x); ind_o = o.backpropagate(x, od, momentum=0.5); o.update(1e-3)
+        assert relerr(out.cpu().numpy(), out_o) <= 3e-5 and relerr(ind.cpu().numpy(), ind_o) <= 2e-4
+    assert relerr(e.get_params(), o.get_params()) <= 3e-5
+    e.close()
+
+
+def test_empty_minibatch_is_a_no_op():
+    """rows == 0 satisfies rows % NumStream == 0 (:225): T = 0, nothing runs, state and parameters unchanged;
+    Backpropagate leaves corr = momentum*corr (every gradient product has K = 0)."""
+    I, C, R, S = 8, 16, 8, 3
+    p = make_params(I, C, R, scale=0.2, seed=13)
+    e = make_engine(I, C, R, S, p)
+    rng = np.random.RandomState(13)
+    x = dev(rng.randn(2 * S, I)); od = dev(rng.randn(2 * S, R)); out = torch.empty(2 * S, R, device="cuda")
+    e.propagate(x, out); e.backpropagate(x, od, None, momentum=0.0); e.synchronize()
+    c0, r0 = e.get_state(); corr0 = e.get_corr()
+    x0 = torch.empty(0, I, device="cuda"); o0 = torch.empty(0, R, device="cuda")
+    e.propagate(x0, o0); e.backpropagate(x0, o0, None, momentum=0.5); e.update(0.0); e.synchronize()
+    c1, r1 = e.get_state()
+    assert np.array_equal(c0, c1) and np.array_equal(r0, r1)
+    assert np.array_equal(e.get_corr(), 0.5 * corr0)
+    assert np.array_equal(e.get_params(), p)
+    e.close()
+
+
+def test_nonfinite_inputs_propagate_like_the_oracle():
+    """No silent masking: a NaN feature poisons exactly the frames/streams it reaches in the oracle too."""
+    I, C, R, S, T = 8, 16, 8, 4, 5
+    p = make_params(I, C, R, scale=0.2, seed=14)
+    rng = np.random.RandomState(14)
+    x = rng.randn(T * S, I).astype(np.float32)
+    x[2 * S + 1, 3] = np.nan                     # frame 2, stream 1
+    e = make_engine(I, C, R, S, p)
+    o = Oracle(I, C, R, S, np.float32); o.set_params(p)
+    out = torch.empty(T * S, R, device="cuda")
+    e.propagate(dev(x), out); e.synchronize()
+    out_o = o.propagate(x)
+    g, w = out.cpu().numpy(), out_o
+    assert np.array_equal(np.isnan(g), np.isnan(w))
+    assert np.isnan(g).reshape(T, S, R)[2:, 1].all() and not np.isnan(g).reshape(T, S, R)[:, [0, 2, 3]].any()
+    assert relerr(g[~np.isnan(g)], w[~np.isnan(w)]) <= 2e-5
+    e.close()
