@@ -647,6 +647,7 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
   __syncthreads()
 
 struct GatesVArgs {
+  int gx;                // real number of row-tile groups (many-stream kernels pad grid.x to a multiple of 8)
   GatesArgs g;
   const float4 *wpk;     // packed [W_gifo_r | W_gifo_x] : [C/4 tiles][nchR + nchX chunks][2][64]
   int nch_total;         // chunks per tile in wpk (nchR + nchX)
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(NW * 64) void k_gates_v(GatesVArgs va) {
   }
 }
 
-struct ProjVArgs { ProjArgs g; const float4 *wpk; };   // packed W_r_m: [R/16 tiles][C/32 chunks][2][64]
+struct ProjVArgs { int gx; ProjArgs g; const float4 *wpk; };   // packed W_r_m: [R/16 tiles][C/32 chunks][2][64]
 
 template <int NT, int CPW, bool SMALL>
 __global__ __launch_bounds__(NW * 64) void k_proj_v(ProjVArgs va) {
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(NW * 64) void k_proj_v(ProjVArgs va) {
   }
 }
 
-struct DrVArgs { DrArgs g; const float4 *wpk; int nch_total; };   // packed [W_gifo_r^T ; W_gifo_x^T]: [(R+I)/16 tiles][4C/32][2][64]
+struct DrVArgs { int gx; DrArgs g; const float4 *wpk; int nch_total; };   // packed [W_gifo_r^T ; W_gifo_x^T]: [(R+I)/16 tiles][4C/32][2][64]
 
 template <int NT, int CPW, bool SMALL>
 __global__ __launch_bounds__(NW * 64) void k_dr_v(DrVArgs va) {
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(NW * 64) void k_dr_v(DrVArgs va) {
   }
 }
 
-struct DmVArgs { DmArgs g; const float4 *wpk; };   // packed W_r_m^T: [C/16 tiles][R/32 chunks][2][64]
+struct DmVArgs { int gx; DmArgs g; const float4 *wpk; };   // packed W_r_m^T: [C/16 tiles][R/32 chunks][2][64]
 
 template <int NT, int CPW, bool SMALL>
 __global__ __launch_bounds__(NW * 64) void k_dm_v(DmVArgs va) {
@@ -976,6 +977,7 @@ __device__ __forceinline__ void fat_combine(f32x4 (&acc)[2], f32x4 (*red)[MTW][6
 }
 
 #define FAT_PROLOGUE()                                                                           \
+  if ((int)blockIdx.x >= va.gx) return;      /* grid.x is padded to a multiple of 8 (XCD affinity of row tiles) */ \
   const int lane = threadIdx.x & 63;                                                             \
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                             \
   const int mt = wave % MTW, ksp = wave / MTW;                                                   \
@@ -1126,7 +1128,7 @@ __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
   const int sbase = blockIdx.y * FST;
   const bool last = (t == a.T);
 
-  if (a.xpart && blockIdx.x == gridDim.x - 1) {          // in_diff(t+1) = sum of its split-K slabs (:457)
+  if (a.xpart && (int)blockIdx.x == va.gx - 1) {         // in_diff(t+1) = sum of its split-K slabs (:457)
     const int I = a.I;
     for (int idx = sbase * I + threadIdx.x; idx < min(S, sbase + FST) * I; idx += NW * 64) {
       const int s = idx / I, n = idx - s * I;
@@ -1394,7 +1396,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmJob g) {
 // ---------------------------------------------------------------------------------------------
 struct GradsArgs {
   GemmJob wx, wr, wm;
-  int nb0, nb1, nb2;
+  int nb0, nb1, nb2, nvec;   // tile-id ranges of the three products, then nvec column-sum blocks
   int C, S, T;
   const float *dgifo, *cc;
   float beta;
@@ -1404,7 +1406,13 @@ struct GradsArgs {
 __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
   __shared__ float As[GK][GLD];
   __shared__ float Bs[GK][GLD];
-  const int b = blockIdx.x;
+  // XCD-aware order: workgroup w lands on XCD w % 8 (observed dispatch rule, speed only); XCD x gets the contiguous
+  // m-major tile range [x*cpx, (x+1)*cpx), so its private L2 holds a few A row panels and the B column panels
+  // instead of streaming every A panel once per XCD.
+  const int nbt = a.nb2 + a.nvec;
+  const int cpx = (nbt + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * cpx + (int)(blockIdx.x >> 3);
+  if (b >= nbt) return;
   if (b < a.nb2) {
     const GemmJob &g = b < a.nb0 ? a.wx : b < a.nb1 ? a.wr : a.wm;
     const int lb = b < a.nb0 ? b : b < a.nb1 ? b - a.nb0 : b - a.nb1;
@@ -1666,7 +1674,8 @@ hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, bool fuse_x
     GatesVArgs va; va.g = a; va.wpk = p.pk_gates;
     va.nch_total = cdiv(d.R, KCH) + cdiv(d.I, KCH);
     if (p.fat && d.S > 16) {                                 // 4 row tiles (16 cells) x 2 K splits per workgroup
-      const dim3 fgrid(cdiv(d.C, 16), cdiv(d.S, FST));
+      va.gx = cdiv(d.C, 16);
+      const dim3 fgrid(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
       const bool big = (fuse_x ? cdiv(d.R, KCH) + cdiv(d.I, KCH) : cdiv(d.R, KCH)) > 16;
       if (fuse_x && big) KLAUNCH((k_gates_f<4, 2, 32, true>), fgrid, dim3(NW * 64), st, pr, va);
       if (fuse_x) KLAUNCH((k_gates_f<4, 2, 16, true>), fgrid, dim3(NW * 64), st, pr, va);
@@ -1695,7 +1704,8 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
   if (vec) {
     ProjVArgs va; va.g = a; va.wpk = p.pk_proj;
     if (p.fat && d.S > 16) {
-      const dim3 fgrid(cdiv(d.R, 32), cdiv(d.S, FST));
+      va.gx = cdiv(d.R, 32);
+      const dim3 fgrid(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
       if (cdiv(d.C, KCH) > 16) KLAUNCH((k_proj_f<2, 4, 32>), fgrid, dim3(NW * 64), st, pr, va);
       KLAUNCH((k_proj_f<2, 4, 16>), fgrid, dim3(NW * 64), st, pr, va);
     }
@@ -1734,7 +1744,8 @@ hipError_t launch_dr_step(const Dims &d, const BwdPtrs &p, int t, float *in_diff
     DrVArgs va; va.g = a; va.wpk = p.pk_dr; va.nch_total = cdiv(K, KCH);
     if (p.fat && d.S > 16) {
       va.g.ntr = t == 0 ? 0 : cdiv(d.R, 32);                       // 32-row groups (2 row tiles x 4 K splits)
-      const int gx = va.g.ntr + (in_diff ? cdiv(d.I, 32) : 0);
+      const int gx = cdiv(va.g.ntr + (in_diff ? cdiv(d.I, 32) : 0), 8) * 8;
+      va.gx = va.g.ntr + (in_diff ? cdiv(d.I, 32) : 0);
       // (a 32-chunk slab was measured slower here: 66 KB of LDS and 16 weight registers per lane cost more in
       //  occupancy than the second staging round trip they save)
       KLAUNCH((k_dr_f<2, 4, 16>), dim3(gx, cdiv(d.S, FST), ks), dim3(NW * 64), st, pr, va);
@@ -1766,7 +1777,8 @@ hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *o
   if (vec) {
     DmVArgs va; va.g = a; va.wpk = p.pk_dm;
     if (p.fat && d.S > 16) {
-      const dim3 fgrid(cdiv(d.C, 32), cdiv(d.S, FST));
+      va.gx = cdiv(d.C, 32);
+      const dim3 fgrid(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
       if (cdiv(d.R, KCH) > 16) KLAUNCH((k_dm_f<2, 4, 32>), fgrid, dim3(NW * 64), st, pr, va);
       KLAUNCH((k_dm_f<2, 4, 16>), fgrid, dim3(NW * 64), st, pr, va);
     }
@@ -1841,8 +1853,8 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
   a.nb2 = a.nb1 + cdiv(R, GT) * cdiv(C, GT);
   a.C = C; a.S = S; a.T = d.T; a.dgifo = dgifo; a.cc = cc; a.beta = beta;
   a.g_bias = dst + o_b; a.g_pi = dst + o_pi; a.g_pf = dst + o_pf; a.g_po = dst + o_po;
-  const int nb3 = a.nb2 + cdiv(4 * C, 64);
-  KLAUNCH(k_grads, dim3(nb3), dim3(256), st, pr, a);
+  a.nvec = cdiv(4 * C, 64);
+  KLAUNCH(k_grads, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
 }
 
 hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_blob, const float *grad_blob,
