@@ -537,6 +537,12 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     e->use_vector = value != 0;
     return KLSTM_OK;
   }
+  if (!strcmp(key, "small_max")) {       // process-wide tuning knob (A-B experiments)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    set_small_max(value);
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "fat")) {             // 0: keep the 16-row tile kernels also for NumStream > 16 (testing / A-B)
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);

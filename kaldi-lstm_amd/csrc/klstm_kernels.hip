@@ -1628,10 +1628,12 @@ static inline int pick_nt(int S) {
   } while (0)
 // vector kernels: SMALL (4x4x1_16b, S <= 4) with CPW in {1,2,4};  16x16x4 with (NT,CPW) in {(1,1),(1,2),(2,1),(4,1)}
 struct VecCfg { bool small; int nt, cpw; };
+int g_small_max = 12;           // largest NumStream served by the 4x4x1_16b geometry (4 streams per workgroup, grid.y = S/4);
+                                // measured at 40/800/512: S=8 406 vs 471 us, S=12 473 vs 491, S=16 522 vs 515 (16x16x4 wins)
 static inline VecCfg pick_vec(int S, int nch) {
   VecCfg c;
   const int need = cdiv(nch, NW);
-  c.small = S <= 4;
+  c.small = S <= g_small_max;
   if (c.small) { c.nt = 1; c.cpw = need <= 1 ? 1 : need == 2 ? 2 : 4; return c; }
   c.nt = S <= 16 ? 1 : S <= 32 ? 2 : 4;
   c.cpw = (c.nt == 1 && need >= 2) ? 2 : 1;
@@ -1716,6 +1718,8 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
   const dim3 grid(cdiv(d.R, 16), cdiv(d.S, 16 * nt));
   GEN_DISPATCH(k_proj_step, nt, grid, st, pr, a, );
 }
+
+void set_small_max(int s) { g_small_max = s; }
 
 int dr_split_k(const Dims &d) {
   // enough (R/16 x KS) workgroups to spread the 4C-long contraction over the chip at small S

@@ -118,6 +118,8 @@ def test_fused_and_batched_x_projection(I, C, R, S, T, want_in_diff, fuse_x):
     (8, 16, 8, 3, 5),        # S<=4, partial stream tile, single K chunk
     (40, 72, 48, 2, 4),      # C not a multiple of 16 (partial cell tile in BPTT), R not a multiple of 32
     (16, 24, 16, 16, 3),     # 16x16x4 geometry, NT=1
+    (16, 24, 16, 7, 3),      # 4x4x1 geometry with two stream groups (S <= 12), the second one partial
+    (8, 16, 16, 12, 2),      # three full stream groups
     (24, 40, 24, 24, 3),     # NT=2
     (8, 16, 16, 70, 2),      # NT=4 with a partial second stream group
     (64, 264, 136, 4, 3),    # several super-iterations in the 4C-long BPTT contraction

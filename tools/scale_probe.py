@@ -6,8 +6,10 @@ import kaldi_lstm_amd as k
 from oracle.oracle import make_params
 I, C, R = 40, 800, 512
 FL = 6 * (4 * C * I + 4 * C * R + R * C)
-def run(S, T, n=50):
+def run(S, T, n=50, small_max=None):
     e = k.Engine(I, C, R, S)
+    if small_max is not None:
+        e.set_option("small_max", small_max)
     e.set_params(make_params(I, C, R, 0.01, 7))
     x = torch.randn(T * S, I, device="cuda"); od = 0.1 * torch.randn(T * S, R, device="cuda")
     out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
@@ -21,6 +23,11 @@ def run(S, T, n=50):
     print("S=%3d T=%4d : %8.1f us/minibatch  %9.0f frames/s  %6.2f TF/s  (first call incl. graph capture %.0f ms)" %
           (S, T, dt * 1e6, T * S / dt, T * S / dt * FL / 1e12, first * 1e3), flush=True)
     e.close()
+if len(sys.argv) > 1 and sys.argv[1] == "small":
+    for S in (8, 12, 16):
+        for sm in (4, 16):
+            print("small_max=%d " % sm, end=""); run(S, 20, small_max=sm)
+    sys.exit(0)
 for S in (1, 2, 4, 8, 16, 32, 64, 128, 256):
     run(S, 20)
 run(1, 1000, n=5)
