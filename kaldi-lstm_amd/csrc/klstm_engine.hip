@@ -385,7 +385,9 @@ static klstm_status run_graphed(klstm_engine *e, const klstm_engine::Key &key, F
   if (!e->use_graph || e->profile) return seq();
   auto it = e->graphs.find(key);
   if (it == e->graphs.end()) {
-    if (e->graphs.size() >= 64) drop_graphs(e);
+    // graphs bake the caller's pointers; a trainer that cycles through a pool of minibatch buffers needs one
+    // graph per buffer (bench.py: 50 feature chunks x {fwd, bwd}).  Bounded so a pathological caller cannot leak.
+    if (e->graphs.size() >= 4096) drop_graphs(e);
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     klstm_status st = seq();
