@@ -1347,9 +1347,9 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
       fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0 + GK, tid, ra);
       fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, k0 + GK, tid, rb);
     }
-    const int ksteps = min(GK, g.K - k0 + 3) / 4;                    // skip all-zero tail steps of a short last tile
-#pragma unroll 4
-    for (int kk = 0; kk < ksteps; kk++) {
+    // full K tiles run a fully unrolled 16-step body (a runtime trip count defeats the unroller and leaves a rolled
+    // ds_read -> MFMA loop); only the last, short tile takes the rolled path and skips its all-zero tail steps
+    auto kstep = [&](int kk) {
       const int k = kk * 4 + kg;
       const float a0 = As[k][wr * 32 + i16], a1 = As[k][wr * 32 + 16 + i16];
       const float b0 = Bs[k][wc * 32 + i16], b1 = Bs[k][wc * 32 + 16 + i16];
@@ -1357,6 +1357,13 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
       acc[0][1] = MFMA16(a0, b1, acc[0][1]);
       acc[1][0] = MFMA16(a1, b0, acc[1][0]);
       acc[1][1] = MFMA16(a1, b1, acc[1][1]);
+    };
+    if (k0 + GK <= g.K) {
+#pragma unroll
+      for (int kk = 0; kk < GK / 4; kk++) kstep(kk);
+    } else {
+      const int ksteps = (g.K - k0 + 3) / 4;
+      for (int kk = 0; kk < ksteps; kk++) kstep(kk);
     }
     __syncthreads();
   }
