@@ -64,6 +64,7 @@ struct klstm_engine {
   float mmt_value = 0.f;
   bool use_vector = true;
   bool use_fat = true;
+  bool use_bf16 = false;   // bf16 operands in the step kernels (option "bf16"); masters/planes/gradients stay fp32
   int fuse_x = -1;    // -1 auto (small NumStream), 0 batched x-projection GEMM, 1 fused into the step kernel
   bool profile = false;
   std::vector<ProbeRec> probes;
@@ -143,7 +144,7 @@ static klstm_status repack(klstm_engine *e) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
   HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream,
                               probe(e, "k_update_repack")));
-  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->stream, probe(e, "k_pack")));
+  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream, probe(e, "k_pack")));
   return KLSTM_OK;
 }
 
@@ -328,6 +329,7 @@ static FwdPtrs fwd_ptrs(klstm_engine *e) {
   p.pk_gates = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[0]) : nullptr;
   p.pk_proj = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[1]) : nullptr;
   p.fat = e->use_fat;
+  p.bf16 = e->use_bf16;
   return p;
 }
 static BwdPtrs bwd_ptrs(klstm_engine *e) {
@@ -339,6 +341,7 @@ static BwdPtrs bwd_ptrs(klstm_engine *e) {
   p.pk_dr = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[2]) : nullptr;
   p.pk_dm = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[3]) : nullptr;
   p.fat = e->use_fat;
+  p.bf16 = e->use_bf16;
   return p;
 }
 
@@ -482,7 +485,7 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
                               e->wxT, e->stream, probe(e, "k_update_repack")));
   // (Packing the BPTT operands on a second stream, overlapped with the next forward pass, was measured to cost
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
-  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->stream, probe(e, "k_pack")));
+  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream, probe(e, "k_pack")));
   return KLSTM_OK;
 }
 
@@ -549,6 +552,15 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
     e->use_fat = value != 0;
+    return KLSTM_OK;
+  }
+  if (!strcmp(key, "bf16")) {            // 1: bf16 weight/activation operands with fp32 accumulate in the step kernels
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    if (value != 0 && !e->pk[0]) return fail(KLSTM_ERR_SHAPE, "bf16 mode needs I, C, R multiples of 8");
+    e->use_bf16 = value != 0;
+    HIPCHK(launch_pack(Dims{e->I, e->C, e->R, e->S, 0}, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream));
     return KLSTM_OK;
   }
   if (!strcmp(key, "fuse_x")) {
@@ -696,8 +708,8 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
       else if (w == "dr+dm") { if (i & 1) HIPCHK(launch_dm_step(d, bp, t, scratch_out, e->R, xdiff, e->I, st)); else HIPCHK(launch_dr_step(d, bp, t < T ? t : 1, xdiff, e->I, st)); }
       else if (w == "grads") HIPCHK(launch_grads(d, e->dgifo, e->dr, xin, e->I, e->rr, e->mm, e->cc, 0.9f, e->corr, st));
       else if (w == "update") HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, st));
-      else if (w == "pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, st));
-      else if (w == "pack_fwd") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 3, st));
+      else if (w == "pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, st));
+      else if (w == "pack_fwd") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 3, e->use_bf16, st));
       else return fail(KLSTM_ERR_ARG, "klstm_debug_chain: unknown kernel '%s'", what);
     }
     return KLSTM_OK;

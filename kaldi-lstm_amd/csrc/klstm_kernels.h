@@ -18,6 +18,7 @@ struct FwdPtrs {
   float *prev_c, *prev_r;                            // carried state [S x C], [S x R]
   const float4 *pk_gates, *pk_proj;                  // packed (MFMA-operand-ordered) weight copies, or null
   bool fat;                                          // allow the 64-row x 32-stream kernels when S > 16
+  bool bf16;                                         // pk_* hold bf16 operands; activations are rounded to bf16 when staged
 };
 
 struct BwdPtrs {
@@ -30,6 +31,7 @@ struct BwdPtrs {
   int ks;                                            // number of slabs
   const float4 *pk_dr, *pk_dm;                       // packed weight copies, or null
   bool fat;
+  bool bf16;
 };
 
 // optional per-launch timing through hipExtLaunchKernelGGL start/stop events
@@ -80,9 +82,10 @@ hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_bl
 //   [0] gates [W_gifo_r | W_gifo_x]   [1] proj W_r_m   [2] dr [W_gifo_r^T ; W_gifo_x^T]   [3] dm W_r_m^T
 bool pack_supported(const Dims &d);
 void pack_sizes(const Dims &d, long n4[4]);         // float4 counts
-// mask: bit i selects array i (forward operands = 3, BPTT operands = 12)
+// mask: bit i selects array i (forward operands = 3, BPTT operands = 12);  bf16: pack as bf16 (same tile/chunk/lane
+// order, one 16-byte vector of 8 bf16 per lane and chunk -> half the bytes of the fp32 copies)
 hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
-                       float *pk[4], int mask, hipStream_t st, LaunchProbe pr = {});
+                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr = {});
 
 // out[dst] = in[clamp(dst + shift)] row gather (TimeShift; shift 0 = Transmit copy)
 hipError_t launch_time_shift(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, int shift,

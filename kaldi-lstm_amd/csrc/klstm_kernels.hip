@@ -34,6 +34,15 @@ namespace klstm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// bf16 operand mode (engine option "bf16"): weights packed as bf16, activations rounded to bf16 (RNE) when
+// they are staged into LDS, fp32 accumulate; masters, planes and gradients stay fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 pack_bf16x4(const float4 &v) {
+  const bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  return __builtin_bit_cast(uint2, h);
+}
 
 constexpr int NW = 8;        // waves per workgroup in the step kernels (K split)
 constexpr int KCH = 32;      // K chunk one wave consumes per MFMA group (4 k-groups x 8)
@@ -563,6 +572,7 @@ __global__ __launch_bounds__(NW * 64) void k_dm_step(DmArgs a) {
 template <int CPW, bool SMALL> struct VGeo {
   static constexpr int SUPER = CPW * NW;                       // chunks per super-iteration
   static constexpr int LDB = SUPER * KCH + (SMALL ? 16 : 4);   // LDS row stride (floats): b128 reads conflict-free
+  static constexpr int LDBH = SUPER * KCH + (SMALL ? 32 : 8);  // same padding in bytes for the bf16 slab (halves)
 };
 
 // One contraction: acc[nt] += A(tile rows, chunks [0,nch)) * B(streams, same chunks).
@@ -570,12 +580,16 @@ template <int CPW, bool SMALL> struct VGeo {
 //   bload(s, k, on) -> float4 of B[s][k..k+3] in natural layout (zeros outside / when !on), k relative to chunk 0;
 //                      must be branch-free (clamped addresses + selects) so that all loads of a slab overlap
 //   bside(s, k, v): optional side store of the staged natural-layout value (mirrors)
-template <int NT, int CPW, bool SMALL, class BL, class BS>
+//   BF    : bf16 operands -- chunk c of the packed weights at apk + c*64 (one 16-byte vector of 8 bf16 per lane),
+//           B staged as bf16; one 16x16x32 (or two 4x4x4_16b) MFMAs per chunk instead of eight f32 ones
+template <int NT, int CPW, bool SMALL, bool BF, class BL, class BS>
 __device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int nch, int rows, float *ldsB,
                                              int lane, int wave, f32x4 (&acc)[NT][2], const BL &bload, const BS &bside) {
   (void)rows;
-  constexpr int SUPER = VGeo<CPW, SMALL>::SUPER, LDB = VGeo<CPW, SMALL>::LDB;
+  constexpr int SUPER = VGeo<CPW, SMALL>::SUPER, LDB = VGeo<CPW, SMALL>::LDB, LDBH = VGeo<CPW, SMALL>::LDBH;
   constexpr int TS_ = Geo<SMALL>::STREAMS;
+  constexpr int AU = BF ? 64 : 128;                            // float4 units per packed chunk
+  unsigned short *ldsH = reinterpret_cast<unsigned short *>(ldsB);
   const int bs = Geo<SMALL>::bstream(lane), kg = lane >> 4;
   for (int base = 0; base < nch; base += SUPER) {
     const int nc = min(SUPER, nch - base);
@@ -586,8 +600,8 @@ __device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int
 #pragma unroll
     for (int c = 0; c < CPW; c++) {
       const int cl = min(c0 + c, nc - 1);                      // clamped: always a valid chunk, unused if off
-      const float4 *ap = apk + (size_t)(base + cl) * 128 + lane;
-      a0[c] = ap[0]; a1[c] = ap[64];
+      const float4 *ap = apk + (size_t)(base + cl) * AU + lane;
+      a0[c] = ap[0]; a1[c] = BF ? a0[c] : ap[64];
     }
     // (2) stage B[rows][nc*32] lane-contiguous into LDS: every load of the slab is issued before the first store
     constexpr int ROWS = NT * TS_, F4ROW = SUPER * 8;
@@ -604,7 +618,8 @@ __device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int
       const int idx = threadIdx.x + u * NW * 64;
       const int sl = idx / F4ROW, k = (idx % F4ROW) * 4;
       if (sl < ROWS && k < nc * KCH) {
-        *reinterpret_cast<float4 *>(ldsB + sl * LDB + k) = sv[u];
+        if constexpr (BF) *reinterpret_cast<uint2 *>(ldsH + sl * LDBH + k) = pack_bf16x4(sv[u]);
+        else *reinterpret_cast<float4 *>(ldsB + sl * LDB + k) = sv[u];
         bside(sl, base * KCH + k, sv[u]);
       }
     }
@@ -613,6 +628,21 @@ __device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int
 #pragma unroll
     for (int c = 0; c < CPW; c++) {
       if (c < per && c0 + c < nc) {
+        if constexpr (BF) {
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            const float4 braw = *reinterpret_cast<const float4 *>(ldsH + (nt * TS_ + bs) * LDBH + (c0 + c) * KCH + kg * 8);
+            if constexpr (SMALL) {
+              const float2 alo = make_float2(a0[c].x, a0[c].y), ahi = make_float2(a0[c].z, a0[c].w);
+              const float2 blo = make_float2(braw.x, braw.y), bhi = make_float2(braw.z, braw.w);
+              acc[nt][0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, alo), __builtin_bit_cast(s16x4, blo), acc[nt][0], 0, 0, 0);
+              acc[nt][1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, ahi), __builtin_bit_cast(s16x4, bhi), acc[nt][1], 0, 0, 0);
+            } else {
+              acc[nt][c & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0[c]), __builtin_bit_cast(bf16x8, braw), acc[nt][c & 1], 0, 0, 0);
+            }
+          }
+          continue;
+        }
         const float av[8] = {a0[c].x, a0[c].y, a0[c].z, a0[c].w, a1[c].x, a1[c].y, a1[c].z, a1[c].w};
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
@@ -653,7 +683,7 @@ struct GatesVArgs {
   int nch_total;         // chunks per tile in wpk (nchR + nchX)
 };
 
-template <int NT, int CPW, bool SMALL, bool FUSEX>
+template <int NT, int CPW, bool SMALL, bool FUSEX, bool BF>
 __global__ __launch_bounds__(NW * 64) void k_gates_v(GatesVArgs va) {
   const GatesArgs &a = va.g;
   VEC_PROLOGUE();
@@ -688,7 +718,7 @@ __global__ __launch_bounds__(NW * 64) void k_gates_v(GatesVArgs va) {
     const int s = sbase + sl;
     if (mirror_r && s < S && k < R) *reinterpret_cast<float4 *>(a.r_mirror + (size_t)s * R + k) = v;
   };
-  vec_contract<NT, CPW, SMALL>(va.wpk + (size_t)blockIdx.x * va.nch_total * 128, nch, NT * TS_, ldsB, lane, wave, acc,
+  vec_contract<NT, CPW, SMALL, BF>(va.wpk + (size_t)blockIdx.x * va.nch_total * (BF ? 64 : 128), nch, NT * TS_, ldsB, lane, wave, acc,
                                bload, bside);
   VEC_COMBINE();
 
@@ -721,7 +751,7 @@ __global__ __launch_bounds__(NW * 64) void k_gates_v(GatesVArgs va) {
 
 struct ProjVArgs { int gx; ProjArgs g; const float4 *wpk; };   // packed W_r_m: [R/16 tiles][C/32 chunks][2][64]
 
-template <int NT, int CPW, bool SMALL>
+template <int NT, int CPW, bool SMALL, bool BF>
 __global__ __launch_bounds__(NW * 64) void k_proj_v(ProjVArgs va) {
   const ProjArgs &a = va.g;
   VEC_PROLOGUE();
@@ -734,7 +764,7 @@ __global__ __launch_bounds__(NW * 64) void k_proj_v(ProjVArgs va) {
     const float4 v = ldg4(mrow + (size_t)min(sbase + sl, S - 1) * C + min(k, C - 4));
     return (on && sbase + sl < S && k < C) ? v : f4zero();
   };
-  vec_contract<NT, CPW, SMALL>(va.wpk + (size_t)blockIdx.x * nch * 128, nch, NT * TS_, ldsB, lane, wave, acc, bload, NoSide());
+  vec_contract<NT, CPW, SMALL, BF>(va.wpk + (size_t)blockIdx.x * nch * (BF ? 64 : 128), nch, NT * TS_, ldsB, lane, wave, acc, bload, NoSide());
   VEC_COMBINE();
   if (wave < NT && Geo<SMALL>::owner(lane)) {
     const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
@@ -752,7 +782,7 @@ __global__ __launch_bounds__(NW * 64) void k_proj_v(ProjVArgs va) {
 
 struct DrVArgs { int gx; DrArgs g; const float4 *wpk; int nch_total; };   // packed [W_gifo_r^T ; W_gifo_x^T]: [(R+I)/16 tiles][4C/32][2][64]
 
-template <int NT, int CPW, bool SMALL>
+template <int NT, int CPW, bool SMALL, bool BF>
 __global__ __launch_bounds__(NW * 64) void k_dr_v(DrVArgs va) {
   const DrArgs &a = va.g;
   VEC_PROLOGUE();
@@ -771,7 +801,7 @@ __global__ __launch_bounds__(NW * 64) void k_dr_v(DrVArgs va) {
     const float4 v = ldg4(drow + (size_t)min(sbase + sl, S - 1) * K + min(kbeg + k, K - 4));
     return (on && sbase + sl < S && kbeg + k < kend) ? v : f4zero();
   };
-  vec_contract<NT, CPW, SMALL>(va.wpk + ((size_t)tile * va.nch_total + kbeg / KCH) * 128,
+  vec_contract<NT, CPW, SMALL, BF>(va.wpk + ((size_t)tile * va.nch_total + kbeg / KCH) * (BF ? 64 : 128),
                                kend > kbeg ? (kend - kbeg + KCH - 1) / KCH : 0, NT * TS_, ldsB, lane, wave, acc, bload, NoSide());
   VEC_COMBINE();
   if (wave < NT && Geo<SMALL>::owner(lane)) {
@@ -792,7 +822,7 @@ __global__ __launch_bounds__(NW * 64) void k_dr_v(DrVArgs va) {
 
 struct DmVArgs { int gx; DmArgs g; const float4 *wpk; };   // packed W_r_m^T: [C/16 tiles][R/32 chunks][2][64]
 
-template <int NT, int CPW, bool SMALL>
+template <int NT, int CPW, bool SMALL, bool BF>
 __global__ __launch_bounds__(NW * 64) void k_dm_v(DmVArgs va) {
   const DmArgs &a = va.g;
   VEC_PROLOGUE();
@@ -861,7 +891,7 @@ __global__ __launch_bounds__(NW * 64) void k_dm_v(DmVArgs va) {
     const int s = sbase + sl;
     if (write_dr && s < S && k < R) *reinterpret_cast<float4 *>(a.dr + ((size_t)t * S + s) * R + k) = v;
   };
-  vec_contract<NT, CPW, SMALL>(va.wpk + (size_t)blockIdx.x * nch * 128, nch, NT * TS_, ldsB, lane, wave, acc, bload, bside);
+  vec_contract<NT, CPW, SMALL, BF>(va.wpk + (size_t)blockIdx.x * nch * (BF ? 64 : 128), nch, NT * TS_, ldsB, lane, wave, acc, bload, bside);
   VEC_COMBINE();
 
   if (e_on) {
@@ -907,11 +937,13 @@ constexpr int FST = 16;                    // streams per workgroup
 // FS = K chunks per slab (16 or 32: the whole contraction in one slab whenever K <= 1024);
 // LDS row stride of the B slab FS*32 + 4 floats: conflict-free b128 reads
 
-template <int MTW, int KSW, int FS, class BL, class BS>
+template <int MTW, int KSW, int FS, bool BF, class BL, class BS>
 __device__ __forceinline__ void fat_contract(const float4 *__restrict__ apk, int nch, float *ldsB, int lane, int ksp,
                                              f32x4 (&acc)[2], const BL &bload, const BS &bside) {
-  constexpr int FLDB = FS * KCH + 4;
+  constexpr int FLDB = FS * KCH + 4, FLDBH = FS * KCH + 8;
   constexpr int PER = FS / KSW;              // max chunks of a slab per K split
+  constexpr int AU = BF ? 64 : 128;
+  unsigned short *ldsH = reinterpret_cast<unsigned short *>(ldsB);
   const int bs = lane & 15, kg = lane >> 4;
   for (int base = 0; base < nch; base += FS) {
     const int nc = min(FS, nch - base);
@@ -921,8 +953,8 @@ __device__ __forceinline__ void fat_contract(const float4 *__restrict__ apk, int
 #pragma unroll
     for (int c = 0; c < PER; c++) {
       const int cl = min(c0 + c, nc - 1);
-      const float4 *ap = apk + (size_t)(base + cl) * 128 + lane;
-      a0[c] = ap[0]; a1[c] = ap[64];
+      const float4 *ap = apk + (size_t)(base + cl) * AU + lane;
+      a0[c] = ap[0]; a1[c] = BF ? a0[c] : ap[64];
     }
     constexpr int F4ROW = FS * 8, U = (FST * F4ROW) / (NW * 64);
     float4 sv[U];
@@ -937,7 +969,8 @@ __device__ __forceinline__ void fat_contract(const float4 *__restrict__ apk, int
       const int idx = threadIdx.x + u * NW * 64;
       const int sl = idx / F4ROW, k = (idx % F4ROW) * 4;
       if (k < nc * KCH) {
-        *reinterpret_cast<float4 *>(ldsB + sl * FLDB + k) = sv[u];
+        if constexpr (BF) *reinterpret_cast<uint2 *>(ldsH + sl * FLDBH + k) = pack_bf16x4(sv[u]);
+        else *reinterpret_cast<float4 *>(ldsB + sl * FLDB + k) = sv[u];
         bside(sl, base * KCH + k, sv[u]);
       }
     }
@@ -945,6 +978,11 @@ __device__ __forceinline__ void fat_contract(const float4 *__restrict__ apk, int
 #pragma unroll
     for (int c = 0; c < PER; c++) {
       if (c < per && c0 + c < nc) {
+        if constexpr (BF) {
+          const float4 braw = *reinterpret_cast<const float4 *>(ldsH + bs * FLDBH + (c0 + c) * KCH + kg * 8);
+          acc[c & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0[c]), __builtin_bit_cast(bf16x8, braw), acc[c & 1], 0, 0, 0);
+          continue;
+        }
         const float av[8] = {a0[c].x, a0[c].y, a0[c].z, a0[c].w, a1[c].x, a1[c].y, a1[c].z, a1[c].w};
         const float *bp = ldsB + bs * FLDB + (c0 + c) * KCH + kg * 8;
         const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(bp + 4);
@@ -987,7 +1025,7 @@ __device__ __forceinline__ void fat_combine(f32x4 (&acc)[2], f32x4 (*red)[MTW][6
   __shared__ __attribute__((aligned(16))) float rt[FST * RTS];                                   \
   f32x4 acc[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}}
 
-template <int MTW, int KSW, int FS, bool FUSEX>
+template <int MTW, int KSW, int FS, bool FUSEX, bool BF>
 __global__ __launch_bounds__(NW * 64) void k_gates_f(GatesVArgs va) {
   const GatesArgs &a = va.g;
   FAT_PROLOGUE();
@@ -1021,7 +1059,7 @@ __global__ __launch_bounds__(NW * 64) void k_gates_f(GatesVArgs va) {
     const int s = sbase + sl;
     if (mirror_r && s < S && k < R) *reinterpret_cast<float4 *>(a.r_mirror + (size_t)s * R + k) = v;
   };
-  fat_contract<MTW, KSW, FS>(va.wpk + (size_t)(blockIdx.x * MTW + mt) * va.nch_total * 128, nch, ldsB, lane, ksp, acc, bload, bside);
+  fat_contract<MTW, KSW, FS, BF>(va.wpk + (size_t)(blockIdx.x * MTW + mt) * va.nch_total * (BF ? 64 : 128), nch, ldsB, lane, ksp, acc, bload, bside);
   fat_combine<MTW, KSW, true>(acc, red, rt, lane, mt, ksp);
 
   if (e_on) {
@@ -1051,7 +1089,7 @@ __global__ __launch_bounds__(NW * 64) void k_gates_f(GatesVArgs va) {
   }
 }
 
-template <int MTW, int KSW, int FS>
+template <int MTW, int KSW, int FS, bool BF>
 __global__ __launch_bounds__(NW * 64) void k_proj_f(ProjVArgs va) {
   const ProjArgs &a = va.g;
   FAT_PROLOGUE();
@@ -1066,7 +1104,7 @@ __global__ __launch_bounds__(NW * 64) void k_proj_f(ProjVArgs va) {
     const float4 v = ldg4(mrow + (size_t)min(sbase + sl, S - 1) * C + min(k, C - 4));
     return (on && sbase + sl < S && k < C) ? v : f4zero();
   };
-  fat_contract<MTW, KSW, FS>(va.wpk + (size_t)ntile * nch * 128, nch, ldsB, lane, ksp, acc, bload, NoSide());
+  fat_contract<MTW, KSW, FS, BF>(va.wpk + (size_t)ntile * nch * (BF ? 64 : 128), nch, ldsB, lane, ksp, acc, bload, NoSide());
   fat_combine<MTW, KSW, false>(acc, red, rt, lane, mt, ksp);
   const int sl_e = threadIdx.x / Q, j_e = threadIdx.x % Q;
   const int s = sbase + sl_e, n = n0 + 4 * j_e;
@@ -1080,7 +1118,7 @@ __global__ __launch_bounds__(NW * 64) void k_proj_f(ProjVArgs va) {
   }
 }
 
-template <int MTW, int KSW, int FS>
+template <int MTW, int KSW, int FS, bool BF>
 __global__ __launch_bounds__(NW * 64) void k_dr_f(DrVArgs va) {
   const DrArgs &a = va.g;
   FAT_PROLOGUE();
@@ -1101,7 +1139,7 @@ __global__ __launch_bounds__(NW * 64) void k_dr_f(DrVArgs va) {
     const float4 v = ldg4(drow + (size_t)min(sbase + sl, S - 1) * K + min(kbeg + k, K - 4));
     return (on && sbase + sl < S && kbeg + k < kend) ? v : f4zero();
   };
-  fat_contract<MTW, KSW, FS>(va.wpk + ((size_t)tile * va.nch_total + kbeg / KCH) * 128,
+  fat_contract<MTW, KSW, FS, BF>(va.wpk + ((size_t)tile * va.nch_total + kbeg / KCH) * (BF ? 64 : 128),
                          kend > kbeg ? (kend - kbeg + KCH - 1) / KCH : 0, ldsB, lane, ksp, acc, bload, NoSide());
   fat_combine<MTW, KSW, false>(acc, red, rt, lane, mt, ksp);
   const int sl_e = threadIdx.x / Q, j_e = threadIdx.x % Q;
@@ -1118,7 +1156,7 @@ __global__ __launch_bounds__(NW * 64) void k_dr_f(DrVArgs va) {
   }
 }
 
-template <int MTW, int KSW, int FS>
+template <int MTW, int KSW, int FS, bool BF>
 __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
   const DmArgs &a = va.g;
   FAT_PROLOGUE();
@@ -1188,7 +1226,7 @@ __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
     const int s = sbase + sl;
     if (write_dr && s < S && k < R) *reinterpret_cast<float4 *>(a.dr + ((size_t)t * S + s) * R + k) = v;
   };
-  fat_contract<MTW, KSW, FS>(va.wpk + (size_t)ctile * nch * 128, nch, ldsB, lane, ksp, acc, bload, bside);
+  fat_contract<MTW, KSW, FS, BF>(va.wpk + (size_t)ctile * nch * (BF ? 64 : 128), nch, ldsB, lane, ksp, acc, bload, bside);
   fat_combine<MTW, KSW, false>(acc, red, rt, lane, mt, ksp);
 
   if (e_on) {
@@ -1231,8 +1269,9 @@ struct PackArgs {
   int C, R, I;
   const float *wx, *wr, *wm, *wrT, *wmT, *wxT;
   float4 *pk[4];
-  long n4[4];          // float4 count of each array (0: array not selected in this launch)
+  long n4[4];          // 16-byte vector count of each array (0: array not selected in this launch)
   int nch[4];          // chunks per tile
+  int bf16;            // 1: entries are 8 bf16 (RNE of the fp32 master) covering k..k+7 -> half as many vectors
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
@@ -1241,8 +1280,8 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
   for (long gid = blockIdx.x * 256L + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
     int arr = 0; long id = gid;
     while (id >= a.n4[arr]) { id -= a.n4[arr]; arr++; }
-    const int lane = (int)(id & 63), h = (int)((id >> 6) & 1);
-    const long tc = id >> 7;
+    const int lane = (int)(id & 63), h = a.bf16 ? 0 : (int)((id >> 6) & 1);
+    const long tc = a.bf16 ? id >> 6 : id >> 7;
     const int nch = a.nch[arr];
     const int tile = (int)(tc / nch), ch = (int)(tc - (long)tile * nch);
     const int i = lane & 15;
@@ -1268,6 +1307,12 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
     }
     float4 v = f4zero();
     if (row_ok && koff + 4 <= klim) v = ldg4(src + koff);     // all extents are multiples of 8 on this path
+    if (a.bf16) {
+      float4 w = f4zero();
+      if (row_ok && koff + 8 <= klim) w = ldg4(src + koff + 4);
+      const uint2 lo = pack_bf16x4(v), hi = pack_bf16x4(w);
+      v = __builtin_bit_cast(float4, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    }
     a.pk[arr][id] = v;
   }
 }
@@ -1686,15 +1731,25 @@ hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, bool fuse_x
       va.gx = cdiv(d.C, 16);
       const dim3 fgrid(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
       const bool big = (fuse_x ? cdiv(d.R, KCH) + cdiv(d.I, KCH) : cdiv(d.R, KCH)) > 16;
-      if (fuse_x && big) KLAUNCH((k_gates_f<4, 2, 32, true>), fgrid, dim3(NW * 64), st, pr, va);
-      if (fuse_x) KLAUNCH((k_gates_f<4, 2, 16, true>), fgrid, dim3(NW * 64), st, pr, va);
-      if (big) KLAUNCH((k_gates_f<4, 2, 32, false>), fgrid, dim3(NW * 64), st, pr, va);
-      KLAUNCH((k_gates_f<4, 2, 16, false>), fgrid, dim3(NW * 64), st, pr, va);
+      if (p.bf16) {
+        if (fuse_x && big) KLAUNCH((k_gates_f<4, 2, 32, true, true>), fgrid, dim3(NW * 64), st, pr, va);
+        if (fuse_x) KLAUNCH((k_gates_f<4, 2, 16, true, true>), fgrid, dim3(NW * 64), st, pr, va);
+        if (big) KLAUNCH((k_gates_f<4, 2, 32, false, true>), fgrid, dim3(NW * 64), st, pr, va);
+        KLAUNCH((k_gates_f<4, 2, 16, false, true>), fgrid, dim3(NW * 64), st, pr, va);
+      }
+      if (fuse_x && big) KLAUNCH((k_gates_f<4, 2, 32, true, false>), fgrid, dim3(NW * 64), st, pr, va);
+      if (fuse_x) KLAUNCH((k_gates_f<4, 2, 16, true, false>), fgrid, dim3(NW * 64), st, pr, va);
+      if (big) KLAUNCH((k_gates_f<4, 2, 32, false, false>), fgrid, dim3(NW * 64), st, pr, va);
+      KLAUNCH((k_gates_f<4, 2, 16, false, false>), fgrid, dim3(NW * 64), st, pr, va);
     }
     const VecCfg cfg = pick_vec(d.S, cdiv(d.R, KCH) + (fuse_x ? cdiv(d.I, KCH) : 0));
     const dim3 grid = vec_grid(cdiv(d.C, 4), d.S, cfg);
-    if (fuse_x) VEC_DISPATCH(k_gates_v, cfg, grid, st, pr, va, COMMA true);
-    VEC_DISPATCH(k_gates_v, cfg, grid, st, pr, va, COMMA false);
+    if (p.bf16) {
+      if (fuse_x) VEC_DISPATCH(k_gates_v, cfg, grid, st, pr, va, COMMA true COMMA true);
+      VEC_DISPATCH(k_gates_v, cfg, grid, st, pr, va, COMMA false COMMA true);
+    }
+    if (fuse_x) VEC_DISPATCH(k_gates_v, cfg, grid, st, pr, va, COMMA true COMMA false);
+    VEC_DISPATCH(k_gates_v, cfg, grid, st, pr, va, COMMA false COMMA false);
   }
   const int nt = pick_nt(d.S);
   const dim3 grid(cdiv(d.C, 4), cdiv(d.S, 16 * nt));
@@ -1715,11 +1770,16 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
     if (p.fat && d.S > 16) {
       va.gx = cdiv(d.R, 32);
       const dim3 fgrid(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
-      if (cdiv(d.C, KCH) > 16) KLAUNCH((k_proj_f<2, 4, 32>), fgrid, dim3(NW * 64), st, pr, va);
-      KLAUNCH((k_proj_f<2, 4, 16>), fgrid, dim3(NW * 64), st, pr, va);
+      if (p.bf16) {
+        if (cdiv(d.C, KCH) > 16) KLAUNCH((k_proj_f<2, 4, 32, true>), fgrid, dim3(NW * 64), st, pr, va);
+        KLAUNCH((k_proj_f<2, 4, 16, true>), fgrid, dim3(NW * 64), st, pr, va);
+      }
+      if (cdiv(d.C, KCH) > 16) KLAUNCH((k_proj_f<2, 4, 32, false>), fgrid, dim3(NW * 64), st, pr, va);
+      KLAUNCH((k_proj_f<2, 4, 16, false>), fgrid, dim3(NW * 64), st, pr, va);
     }
     const VecCfg cfg = pick_vec(d.S, cdiv(d.C, KCH));
-    VEC_DISPATCH(k_proj_v, cfg, vec_grid(cdiv(d.R, 16), d.S, cfg), st, pr, va, );
+    if (p.bf16) VEC_DISPATCH(k_proj_v, cfg, vec_grid(cdiv(d.R, 16), d.S, cfg), st, pr, va, COMMA true);
+    VEC_DISPATCH(k_proj_v, cfg, vec_grid(cdiv(d.R, 16), d.S, cfg), st, pr, va, COMMA false);
   }
   const int nt = pick_nt(d.S);
   const dim3 grid(cdiv(d.R, 16), cdiv(d.S, 16 * nt));
@@ -1759,10 +1819,12 @@ hipError_t launch_dr_step(const Dims &d, const BwdPtrs &p, int t, float *in_diff
       va.gx = va.g.ntr + (in_diff ? cdiv(d.I, 32) : 0);
       // (a 32-chunk slab was measured slower here: 66 KB of LDS and 16 weight registers per lane cost more in
       //  occupancy than the second staging round trip they save)
-      KLAUNCH((k_dr_f<2, 4, 16>), dim3(gx, cdiv(d.S, FST), ks), dim3(NW * 64), st, pr, va);
+      if (p.bf16) KLAUNCH((k_dr_f<2, 4, 16, true>), dim3(gx, cdiv(d.S, FST), ks), dim3(NW * 64), st, pr, va);
+      KLAUNCH((k_dr_f<2, 4, 16, false>), dim3(gx, cdiv(d.S, FST), ks), dim3(NW * 64), st, pr, va);
     }
     const VecCfg cfg = pick_vec(d.S, cdiv(a.klen, KCH));
-    VEC_DISPATCH(k_dr_v, cfg, vec_grid(a.ntr + ntx, d.S, cfg, ks), st, pr, va, );
+    if (p.bf16) VEC_DISPATCH(k_dr_v, cfg, vec_grid(a.ntr + ntx, d.S, cfg, ks), st, pr, va, COMMA true);
+    VEC_DISPATCH(k_dr_v, cfg, vec_grid(a.ntr + ntx, d.S, cfg, ks), st, pr, va, COMMA false);
   }
   const int nt = pick_nt(d.S);
   const dim3 grid(a.ntr + ntx, cdiv(d.S, 16 * nt), ks);
@@ -1790,11 +1852,16 @@ hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *o
     if (p.fat && d.S > 16) {
       va.gx = cdiv(d.C, 32);
       const dim3 fgrid(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
-      if (cdiv(d.R, KCH) > 16) KLAUNCH((k_dm_f<2, 4, 32>), fgrid, dim3(NW * 64), st, pr, va);
-      KLAUNCH((k_dm_f<2, 4, 16>), fgrid, dim3(NW * 64), st, pr, va);
+      if (p.bf16) {
+        if (cdiv(d.R, KCH) > 16) KLAUNCH((k_dm_f<2, 4, 32, true>), fgrid, dim3(NW * 64), st, pr, va);
+        KLAUNCH((k_dm_f<2, 4, 16, true>), fgrid, dim3(NW * 64), st, pr, va);
+      }
+      if (cdiv(d.R, KCH) > 16) KLAUNCH((k_dm_f<2, 4, 32, false>), fgrid, dim3(NW * 64), st, pr, va);
+      KLAUNCH((k_dm_f<2, 4, 16, false>), fgrid, dim3(NW * 64), st, pr, va);
     }
     const VecCfg cfg = pick_vec(d.S, cdiv(d.R, KCH));
-    VEC_DISPATCH(k_dm_v, cfg, vec_grid(cdiv(d.C, 16), d.S, cfg), st, pr, va, );
+    if (p.bf16) VEC_DISPATCH(k_dm_v, cfg, vec_grid(cdiv(d.C, 16), d.S, cfg), st, pr, va, COMMA true);
+    VEC_DISPATCH(k_dm_v, cfg, vec_grid(cdiv(d.C, 16), d.S, cfg), st, pr, va, COMMA false);
   }
   const int nt = pick_nt(d.S);
   const dim3 grid(cdiv(d.C, 16), cdiv(d.S, 16 * nt));
@@ -1810,14 +1877,15 @@ void pack_sizes(const Dims &d, long n4[4]) {
   n4[3] = (long)cdiv(d.C, 16) * cdiv(d.R, KCH) * 128;
 }
 hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
-                       float *pk[4], int mask, hipStream_t st, LaunchProbe pr) {
+                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr) {
   PackArgs a;
+  a.bf16 = bf16 ? 1 : 0;
   a.C = d.C; a.R = d.R; a.I = d.I;
   const long o_wr = (long)4 * d.C * d.I, o_wm = o_wr + (long)4 * d.C * d.R + 7 * d.C;
   a.wx = param_blob; a.wr = param_blob + o_wr; a.wm = param_blob + o_wm;
   a.wrT = wrT; a.wmT = wmT; a.wxT = wxT;
   pack_sizes(d, a.n4);
-  for (int i = 0; i < 4; i++) if (!(mask & (1 << i))) a.n4[i] = 0;
+  for (int i = 0; i < 4; i++) { if (!(mask & (1 << i))) a.n4[i] = 0; if (bf16) a.n4[i] /= 2; }
   a.nch[0] = cdiv(d.R, KCH) + cdiv(d.I, KCH); a.nch[1] = cdiv(d.C, KCH); a.nch[2] = cdiv(4 * d.C, KCH); a.nch[3] = cdiv(d.R, KCH);
   long total = 0;
   for (int i = 0; i < 4; i++) { a.pk[i] = reinterpret_cast<float4 *>(pk[i]); total += a.n4[i]; }

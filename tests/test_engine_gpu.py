@@ -452,3 +452,75 @@ def test_nonfinite_inputs_propagate_like_the_oracle():
     assert np.isnan(g).reshape(T, S, R)[2:, 1].all() and not np.isnan(g).reshape(T, S, R)[:, [0, 2, 3]].any()
     assert relerr(g[~np.isnan(g)], w[~np.isnan(w)]) <= 2e-5
     e.close()
+
+
+@pytest.mark.parametrize("I,C,R,S,T,fuse_x,fat", [
+    (40, 64, 32, 4, 6, 1, 1),       # 4x4x4_16b geometry (S <= 12), x term fused
+    (40, 64, 32, 12, 4, 1, 1),      # 4x4x4_16b geometry, three stream groups
+    (40, 64, 32, 16, 4, 1, 1),      # 16x16x32 tile, one stream tile
+    (40, 64, 32, 20, 4, 0, 0),      # 16x16x32 tiles NT=2, batched fp32 x-projection GEMM
+    (40, 96, 64, 40, 3, 0, 1),      # many-stream kernels
+    (40, 96, 64, 40, 3, 1, 1),      # many-stream kernels, x term fused
+    (72, 1056, 544, 36, 2, 0, 1),   # more than 16 K chunks: 32-chunk slabs in gates/proj/dm, two slab rounds in dr
+    (40, 800, 512, 4, 20, 1, 1),    # BASELINE.json configs[1] shape
+])
+def test_bf16_operand_mode(I, C, R, S, T, fuse_x, fat):
+    """Option "bf16" (BASELINE.json configs[4]: bf16 storage/MFMA, fp32 accumulate, fp32 masters -- a build extension,
+    the reference is fp32 only).  Checked (a) against tests/bf16_emul.py, which rounds exactly the operands the
+    engine rounds: tol 4e-3 of the tensor's max (fp32 summation order + the occasional 1-ulp bf16 flip it causes,
+    bf16 ulp = 2^-8 relative), and (b) against the fp32 oracle at bf16 accuracy: 3e-2."""
+    from tests import bf16_emul
+    from oracle.oracle import split_blob, param_sizes
+    rng = np.random.RandomState(11)
+    scale = 0.3 if C < 200 else 0.02
+    p = make_params(I, C, R, scale=scale, seed=12)
+    o = Oracle(I, C, R, S, np.float32)
+    o.set_params(p)
+    e = make_engine(I, C, R, S, p)
+    e.set_option("fuse_x", fuse_x)
+    e.set_option("fat", fat)
+    e.set_option("bf16", 1)
+    c0, r0 = np.zeros((S, C)), np.zeros((S, R))
+    pe = p.astype(np.float32).copy()
+    corr = np.zeros_like(pe, dtype=np.float64)
+    mmt, lr = 0.9, 1e-3
+    for ck in range(2):
+        x = rng.randn(T * S, I).astype(np.float32)
+        od = (0.5 * rng.randn(T * S, R)).astype(np.float32)
+        xd, odd = dev(x), dev(od)
+        outd = torch.empty(T * S, R, device="cuda")
+        idd = torch.empty(T * S, I, device="cuda")
+        torch.cuda.synchronize()
+        e.propagate(xd, outd)
+        e.backpropagate(xd, odd, idd, momentum=mmt)
+        e.synchronize()
+        parts = [split_blob(pe, I, C, R)[n] for n, _ in param_sizes(I, C, R)]
+        out_m, id_m, grads, cT, rT = bf16_emul.minibatch(parts, x, od, c0, r0, S, fuse_x)
+        corr = mmt * corr + np.concatenate([a.ravel() for a in grads])
+        out_o = o.propagate(x)
+        id_o = o.backpropagate(x, od, momentum=mmt)
+        assert relerr(outd.cpu().numpy(), out_m) <= 4e-3
+        assert relerr(idd.cpu().numpy(), id_m) <= 4e-3
+        assert relerr(e.get_corr(), corr) <= 4e-3
+        assert relerr(outd.cpu().numpy(), out_o) <= 3e-2
+        assert relerr(idd.cpu().numpy(), id_o) <= 3e-2
+        assert relerr(e.get_corr(), o.get_corr()) <= 3e-2
+        e.update(lr)
+        o.update(lr)
+        pe = (pe.astype(np.float64) - lr * corr).astype(np.float32)
+        assert relerr(e.get_params(), pe) <= 1e-4           # masters are fp32
+        cs, rs = e.get_state()
+        assert relerr(cs, cT) <= 4e-3 and relerr(rs, rT) <= 4e-3
+        c0, r0 = cs.astype(np.float64), rs.astype(np.float64)   # continue the emulation from the engine's state
+    # switching back re-packs fp32 operands: fp32 parity again
+    e.set_option("bf16", 0)
+    o.set_params(e.get_params())
+    e.reset(np.ones(S, np.int32)); o.reset(np.ones(S, np.int32))
+    x = rng.randn(T * S, I).astype(np.float32)
+    outd = torch.empty(T * S, R, device="cuda")
+    xd = dev(x)
+    torch.cuda.synchronize()
+    e.propagate(xd, outd)
+    e.synchronize()
+    assert relerr(outd.cpu().numpy(), o.propagate(x)) <= 3e-5
+    e.close()

@@ -6,8 +6,11 @@ import kaldi_lstm_amd as k
 from oracle.oracle import make_params
 I, C, R = 40, 800, 512
 FL = 6 * (4 * C * I + 4 * C * R + R * C)
-def run(S, T, n=50, small_max=None):
+def run(S, T, n=50, small_max=None, bf16=0, dims=None):
+    global I, C, R, FL
+    if dims: I, C, R = dims; FL = 6 * (4 * C * I + 4 * C * R + R * C)
     e = k.Engine(I, C, R, S)
+    e.set_option("bf16", bf16)
     if small_max is not None:
         e.set_option("small_max", small_max)
     e.set_params(make_params(I, C, R, 0.01, 7))
@@ -27,6 +30,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "small":
     for S in (8, 12, 16):
         for sm in (4, 16):
             print("small_max=%d " % sm, end=""); run(S, 20, small_max=sm)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "bf16":
+    for S in (4, 8, 16, 32, 64, 256):
+        for b in (0, 1):
+            print("bf16=%d " % b, end=""); run(S, 20, bf16=b)
+    for b in (0, 1):                                  # BASELINE.json configs[4] inner layer, 32 streams per GPU
+        print("c5 layer 512->1024/512 bf16=%d " % b, end=""); run(32, 20, bf16=b, dims=(512, 1024, 512))
     sys.exit(0)
 for S in (1, 2, 4, 8, 16, 32, 64, 128, 256):
     run(S, 20)
