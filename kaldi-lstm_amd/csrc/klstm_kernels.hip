@@ -447,6 +447,26 @@ struct DmArgs {
   int id_stride;
 };
 
+// Side job of the d_m kernels: in_diff(t+1) = sum of its split-K slabs (:457), the (streams x I) elements of a
+// stream tile spread evenly over the gx row-tile workgroups of that tile (one workgroup alone takes 16 dependent
+// rounds at I = 512, the stacked-layer shape).
+__device__ __forceinline__ void reduce_x_slabs(const DmArgs &a, int s_lo, int s_hi, int bx, int gx) {
+  if (!a.xpart) return;
+  const int I = a.I, S = a.S;
+  const int per = ((s_hi - s_lo) * I + gx - 1) / gx;
+  const int lo = s_lo * I + bx * per, hi = min(s_hi * I, lo + per);
+  for (int idx = lo + (int)threadIdx.x; idx < hi; idx += NW * 64) {
+    const int s = idx / I, n = idx - s * I;
+    float p[KSMAX];
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ks++) p[ks] = a.xpart[((size_t)(ks < a.nslab ? ks : 0) * S + s) * I + n];
+    float sum = p[0];
+#pragma unroll
+    for (int ks = 1; ks < KSMAX; ks++) sum += ks < a.nslab ? p[ks] : 0.f;
+    a.in_diff[(size_t)s * a.id_stride + n] = sum;
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NW * 64) void k_dm_step(DmArgs a) {
   GENERIC_GEOMETRY();
@@ -456,20 +476,7 @@ __global__ __launch_bounds__(NW * 64) void k_dm_step(DmArgs a) {
   const int sbase = blockIdx.y * TS_ * NT;
   const bool last = (t == a.T);
 
-  // ---- side job of the last workgroup: in_diff(t+1) = sum of its split-K slabs (:457) ----
-  if (a.xpart && blockIdx.x == gridDim.x - 1) {
-    const int I = a.I;
-    for (int idx = sbase * I + threadIdx.x; idx < min(S, sbase + TS_ * NT) * I; idx += NW * 64) {
-      const int s = idx / I, n = idx - s * I;
-      float p[KSMAX];
-#pragma unroll
-      for (int ks = 0; ks < KSMAX; ks++) p[ks] = a.xpart[((size_t)(ks < a.nslab ? ks : 0) * S + s) * I + n];
-      float sum = p[0];
-#pragma unroll
-      for (int ks = 1; ks < KSMAX; ks++) sum += ks < a.nslab ? p[ks] : 0.f;
-      a.in_diff[(size_t)s * a.id_stride + n] = sum;
-    }
-  }
+  reduce_x_slabs(a, sbase, min(S, sbase + TS_ * NT), blockIdx.x, gridDim.x);
 
   // ---- epilogue operands first: wave nt owns s-tile nt; lane = (stream, cells cb..cb+3) ----
   const int e_s = sbase + wave * TS_ + bs;
@@ -831,20 +838,7 @@ __global__ __launch_bounds__(NW * 64) void k_dm_v(DmVArgs va) {
   const int sbase = blockIdx.y * TS_ * NT;
   const bool last = (t == a.T);
 
-  // ---- side job of the last workgroup: in_diff(t+1) = sum of its split-K slabs (:457) ----
-  if (a.xpart && blockIdx.x == gridDim.x - 1) {
-    const int I = a.I;
-    for (int idx = sbase * I + threadIdx.x; idx < min(S, sbase + TS_ * NT) * I; idx += NW * 64) {
-      const int s = idx / I, n = idx - s * I;
-      float p[KSMAX];
-#pragma unroll
-      for (int ks = 0; ks < KSMAX; ks++) p[ks] = a.xpart[((size_t)(ks < a.nslab ? ks : 0) * S + s) * I + n];
-      float sum = p[0];
-#pragma unroll
-      for (int ks = 1; ks < KSMAX; ks++) sum += ks < a.nslab ? p[ks] : 0.f;
-      a.in_diff[(size_t)s * a.id_stride + n] = sum;
-    }
-  }
+  reduce_x_slabs(a, sbase, min(S, sbase + TS_ * NT), blockIdx.x, gridDim.x);
 
   // ---- epilogue operands first: wave nt owns s-tile nt; lane = (stream, cells cb..cb+3) ----
   const int e_s = sbase + wave * TS_ + bs;
@@ -1166,19 +1160,7 @@ __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
   const int sbase = blockIdx.y * FST;
   const bool last = (t == a.T);
 
-  if (a.xpart && (int)blockIdx.x == va.gx - 1) {         // in_diff(t+1) = sum of its split-K slabs (:457)
-    const int I = a.I;
-    for (int idx = sbase * I + threadIdx.x; idx < min(S, sbase + FST) * I; idx += NW * 64) {
-      const int s = idx / I, n = idx - s * I;
-      float p[KSMAX];
-#pragma unroll
-      for (int ks = 0; ks < KSMAX; ks++) p[ks] = a.xpart[((size_t)(ks < a.nslab ? ks : 0) * S + s) * I + n];
-      float sum = p[0];
-#pragma unroll
-      for (int ks = 1; ks < KSMAX; ks++) sum += ks < a.nslab ? p[ks] : 0.f;
-      a.in_diff[(size_t)s * a.id_stride + n] = sum;
-    }
-  }
+  reduce_x_slabs(a, sbase, min(S, sbase + FST), blockIdx.x, va.gx);
 
   // elementwise operands: thread = (stream, cells cb..cb+3), requested before the contraction
   const int sl_e = threadIdx.x / Q, j_e = threadIdx.x % Q;

@@ -6,7 +6,10 @@ import kaldi_lstm_amd as k
 from oracle.oracle import make_params
 I, C, R, T = 40, 800, 512, 20
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+BF = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if len(sys.argv) > 5: I, C, R = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 e = k.Engine(I, C, R, S)
+e.set_option("bf16", BF)
 e.set_params(make_params(I, C, R, 0.01, 7))
 x = torch.randn(T * S, I, device="cuda"); od = 0.1 * torch.randn(T * S, R, device="cuda")
 out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
@@ -16,7 +19,7 @@ def timeit(fn, n=100):
     e.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     e.synchronize(); return (time.perf_counter() - t0) / n * 1e6
-print("S=%d" % S)
+print("S=%d bf16=%d dims %d/%d/%d" % (S, BF, I, C, R))
 print("fwd graph        : %8.1f us" % timeit(lambda: e.propagate(x, out)))
 def fb(): e.propagate(x, out); e.backpropagate(x, od, ind, 0.9)
 def fb2(): e.propagate(x, out); e.backpropagate(x, od, None, 0.9)
