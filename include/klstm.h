@@ -120,6 +120,20 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
                                  float *in_diff, int in_diff_stride, int rows,
                                  float momentum, int flags);
 
+/* The same two calls for HOST matrices (a Kaldi CuMatrix holds host memory when the process runs with
+ * --use-gpu=no, cu-matrix.h:479-481; SURVEY 8(b) "data type at the boundary").  Rows are staged through
+ * engine-owned device buffers with stream-ordered 2-D copies, the computation is the device path above (there is
+ * no CPU path), and the call returns after out / in_diff have landed in host memory. */
+klstm_status klstm_propagate_host(klstm_engine *e, const float *in_host, int rows, int in_stride,
+                                  float *out_host, int out_stride);
+klstm_status klstm_backpropagate_host(klstm_engine *e, const float *in_host, int in_stride,
+                                      const float *out_diff_host, int out_diff_stride,
+                                      float *in_diff_host, int in_diff_stride, int rows,
+                                      float momentum, int flags);
+/* 1 if p is device-accessible memory of the engine's GPU (hipMalloc / managed / registered host memory),
+ * 0 if it is plain host memory, <0 on error: lets an adapter pick the right pair of calls once per matrix. */
+int klstm_pointer_on_device(const klstm_engine *e, const void *p);
+
 /* DP mode only, after the all-reduce of klstm_grad_blob():  corr = momentum*corr + grad. */
 klstm_status klstm_apply_momentum(klstm_engine *e, float momentum);
 

@@ -189,12 +189,16 @@ class LstmProjectedStreams {
     Check(klstm_reset(eng_, stream_reset_flag.data(), (int)stream_reset_flag.size()));
   }
 
-  // PropagateFnc, ...streams.h:222-332.  in/out hold DEVICE pointers (a CuMatrix with the GPU enabled).
+  // PropagateFnc, ...streams.h:222-332.  in/out hold device pointers (a CuMatrix with the GPU enabled) or host pointers.
   virtual void PropagateFnc(const MatrixView &in, MatrixView *out) {
     KLSTM_ASSERT(in.NumRows() % nstream_ == 0);                   // :225
     KLSTM_ASSERT(in.NumCols() == input_dim_ && out->NumCols() == output_dim_ && out->NumRows() == in.NumRows());
     EnsureEngine();
-    Check(klstm_propagate(eng_, in.Data(), in.NumRows(), in.Stride(), out->Data(), out->Stride()));
+    // a CuMatrix holds host memory when Kaldi runs with the GPU disabled (cu-matrix.h:479-481): staged, same device path
+    if (in.NumRows() > 0 && klstm_pointer_on_device(eng_, in.Data()) == 0)
+      Check(klstm_propagate_host(eng_, in.Data(), in.NumRows(), in.Stride(), out->Data(), out->Stride()));
+    else
+      Check(klstm_propagate(eng_, in.Data(), in.NumRows(), in.Stride(), out->Data(), out->Stride()));
   }
 
   // BackpropagateFnc, ...streams.h:334-499
@@ -202,9 +206,14 @@ class LstmProjectedStreams {
                                 MatrixView *in_diff) {
     (void)out;
     EnsureEngine();
-    Check(klstm_backpropagate(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
-                              in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
-                              opts_.momentum, KLSTM_BPTT_DEFAULT));
+    if (in.NumRows() > 0 && klstm_pointer_on_device(eng_, in.Data()) == 0)
+      Check(klstm_backpropagate_host(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
+                                     in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
+                                     opts_.momentum, KLSTM_BPTT_DEFAULT));
+    else
+      Check(klstm_backpropagate(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
+                                in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
+                                opts_.momentum, KLSTM_BPTT_DEFAULT));
     host_fresh_ = host_fresh_ && true;
   }
 

@@ -63,6 +63,10 @@ def load_library():
     lib.klstm_set_state_host.argtypes = [P, P, P]
     lib.klstm_propagate.argtypes = [P, P, I, I, P, I]
     lib.klstm_backpropagate.argtypes = [P, P, I, P, I, P, I, I, F, I]
+    lib.klstm_propagate_host.argtypes = [P, P, I, I, P, I]
+    lib.klstm_backpropagate_host.argtypes = [P, P, I, P, I, P, I, I, F, I]
+    lib.klstm_pointer_on_device.argtypes = [P, P]
+    lib.klstm_pointer_on_device.restype = I
     lib.klstm_apply_momentum.argtypes = [P, F]
     lib.klstm_update.argtypes = [P, F, F]
     lib.klstm_synchronize.argtypes = [P]
@@ -191,6 +195,22 @@ class Engine:
         self._chk(self.lib.klstm_backpropagate(self.h, x.data_ptr(), x.stride(0), out_diff.data_ptr(),
                                                out_diff.stride(0), idp, ids, x.shape[0],
                                                float(momentum), int(flags)))
+
+    # ---- host-matrix variants (numpy float32, row stride = ld elements): staged through the device path ----
+    def propagate_host(self, x, out, x_ld=None, out_ld=None):
+        rows = x.shape[0]
+        self._chk(self.lib.klstm_propagate_host(self.h, x.ctypes.data, rows, x_ld or x.strides[0] // 4,
+                                                out.ctypes.data, out_ld or out.strides[0] // 4))
+        self.T = rows // self.S
+
+    def backpropagate_host(self, x, out_diff, in_diff=None, momentum=0.0, flags=0):
+        idp, ids = (in_diff.ctypes.data, in_diff.strides[0] // 4) if in_diff is not None else (None, 0)
+        self._chk(self.lib.klstm_backpropagate_host(self.h, x.ctypes.data, x.strides[0] // 4, out_diff.ctypes.data,
+                                                    out_diff.strides[0] // 4, idp, ids, x.shape[0],
+                                                    float(momentum), int(flags)))
+
+    def pointer_on_device(self, ptr):
+        return int(self.lib.klstm_pointer_on_device(self.h, ptr))
 
     def apply_momentum(self, momentum):
         self._chk(self.lib.klstm_apply_momentum(self.h, float(momentum)))

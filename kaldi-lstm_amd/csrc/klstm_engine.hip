@@ -52,6 +52,8 @@ struct klstm_engine {
   float *pk[4] = {nullptr, nullptr, nullptr, nullptr};    // packed MFMA-operand-ordered copies (vector kernels)
   float *prev_c = nullptr, *prev_r = nullptr;
   int *flags_dev = nullptr;
+  float *stage[4] = {nullptr, nullptr, nullptr, nullptr};   // host-matrix staging: in, out, out_diff, in_diff (dense rows)
+  int stage_rows = 0;
   // activation planes, (T_alloc+2) time blocks each
   int T_alloc = 0;
   float *gifo = nullptr, *cc = nullptr, *hh = nullptr, *mm = nullptr, *rr = nullptr;
@@ -231,6 +233,7 @@ void klstm_destroy(klstm_engine *e) {
   float *ps[] = {e->params, e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3]};
   for (float *p : ps) if (p) (void)hipFree(p);
   if (e->flags_dev) (void)hipFree(e->flags_dev);
+  for (float *p : e->stage) if (p) (void)hipFree(p);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -459,6 +462,66 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
   });
   if (st != KLSTM_OK) return st;
   e->T_bwd = T;
+  return KLSTM_OK;
+}
+
+// ---- host-matrix variants: stage through dense device buffers, run the device path, copy back ----
+static klstm_status ensure_stage(klstm_engine *e, int rows) {
+  if (rows <= e->stage_rows) return KLSTM_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (float *&p : e->stage) { if (p) (void)hipFree(p); p = nullptr; }
+  e->stage_rows = 0;
+  const int w[4] = {e->I, e->R, e->R, e->I};
+  for (int i = 0; i < 4; i++) HIPCHK(hipMalloc(&e->stage[i], (size_t)rows * w[i] * sizeof(float)));
+  e->stage_rows = rows;
+  return KLSTM_OK;
+}
+static klstm_status copy_rows(klstm_engine *e, float *dst, int dst_ld, const float *src, int src_ld, int cols, int rows,
+                              hipMemcpyKind kind) {
+  HIPCHK(hipMemcpy2DAsync(dst, (size_t)dst_ld * sizeof(float), src, (size_t)src_ld * sizeof(float),
+                          (size_t)cols * sizeof(float), rows, kind, e->stream));
+  return KLSTM_OK;
+}
+
+int klstm_pointer_on_device(const klstm_engine *e, const void *p) {
+  if (!e || !p) return -1;
+  if (hipSetDevice(e->device) != hipSuccess) return -1;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return 0; }   // unknown to the runtime: pageable host
+  return (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged || at.devicePointer != nullptr) ? 1 : 0;
+}
+
+klstm_status klstm_propagate_host(klstm_engine *e, const float *in, int rows, int in_stride, float *out, int out_stride) {
+  if (!e || ((!in || !out) && rows != 0)) return fail(KLSTM_ERR_ARG, "klstm_propagate_host: null argument");
+  if (rows <= 0 || rows % e->S != 0) return klstm_propagate(e, in, rows, in_stride, out, out_stride);   // status / no-op as above
+  if (in_stride < e->I || out_stride < e->R) return fail(KLSTM_ERR_ARG, "klstm_propagate_host: stride smaller than row width");
+  HIPCHK(hipSetDevice(e->device));
+  klstm_status st = ensure_stage(e, rows);
+  if (st != KLSTM_OK) return st;
+  if ((st = copy_rows(e, e->stage[0], e->I, in, in_stride, e->I, rows, hipMemcpyHostToDevice)) != KLSTM_OK) return st;
+  if ((st = klstm_propagate(e, e->stage[0], rows, e->I, e->stage[1], e->R)) != KLSTM_OK) return st;
+  if ((st = copy_rows(e, out, out_stride, e->stage[1], e->R, e->R, rows, hipMemcpyDeviceToHost)) != KLSTM_OK) return st;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return KLSTM_OK;
+}
+
+klstm_status klstm_backpropagate_host(klstm_engine *e, const float *in, int in_stride, const float *out_diff,
+                                      int out_diff_stride, float *in_diff, int in_diff_stride, int rows,
+                                      float momentum, int flags) {
+  if (!e || ((!in || !out_diff) && rows != 0)) return fail(KLSTM_ERR_ARG, "klstm_backpropagate_host: null argument");
+  if (rows <= 0 || e->T_fwd < 0 || rows != e->T_fwd * e->S)
+    return klstm_backpropagate(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, rows, momentum, flags);
+  if (in_stride < e->I || out_diff_stride < e->R || (in_diff && in_diff_stride < e->I))
+    return fail(KLSTM_ERR_ARG, "klstm_backpropagate_host: stride smaller than row width");
+  HIPCHK(hipSetDevice(e->device));
+  klstm_status st = ensure_stage(e, rows);
+  if (st != KLSTM_OK) return st;
+  if ((st = copy_rows(e, e->stage[0], e->I, in, in_stride, e->I, rows, hipMemcpyHostToDevice)) != KLSTM_OK) return st;
+  if ((st = copy_rows(e, e->stage[2], e->R, out_diff, out_diff_stride, e->R, rows, hipMemcpyHostToDevice)) != KLSTM_OK) return st;
+  st = klstm_backpropagate(e, e->stage[0], e->I, e->stage[2], e->R, in_diff ? e->stage[3] : nullptr, e->I, rows, momentum, flags);
+  if (st != KLSTM_OK) return st;
+  if (in_diff && (st = copy_rows(e, in_diff, in_diff_stride, e->stage[3], e->I, e->I, rows, hipMemcpyDeviceToHost)) != KLSTM_OK) return st;
+  HIPCHK(hipStreamSynchronize(e->stream));
   return KLSTM_OK;
 }
 

@@ -141,8 +141,10 @@ int main(int argc, char **argv) {
       out.CopyToHost(&h);
       write_raw(argv[5], h.data(), h.size());
       std::cout << "OK " << out.NumRows() << " " << out.NumCols() << "\n";
-    } else if (mode == "run_gpu") {
+    } else if (mode == "run_gpu" || mode == "run_gpu_host") {
       // run_gpu <model> <in_raw> <od_raw> <rows> <lr> <momentum> <nsteps> <out_prefix>
+      // run_gpu_host: the four matrices live in HOST memory (CuMatrix with the GPU disabled, cu-matrix.h:479-481)
+      const bool host = mode == "run_gpu_host";
       std::unique_ptr<LstmProjectedStreams> c(load_model(argv[2]));
       const std::vector<float> x = read_raw(argv[3]), od = read_raw(argv[4]);
       const int rows = atoi(argv[5]);
@@ -156,10 +158,18 @@ int main(int argc, char **argv) {
       // pitched device matrices, like CuMatrix (cu-matrix.cc:67-73): stride > cols
       const int xs = I + 4, os = R + 8, ds = R + 4, is = I + 12;
       float *dx, *dout, *dod, *did;
-      HIPOK(hipMalloc(&dx, (size_t)rows * xs * 4)); HIPOK(hipMalloc(&dout, (size_t)rows * os * 4));
-      HIPOK(hipMalloc(&dod, (size_t)rows * ds * 4)); HIPOK(hipMalloc(&did, (size_t)rows * is * 4));
-      HIPOK(hipMemcpy2D(dx, xs * 4, x.data(), I * 4, I * 4, rows, hipMemcpyHostToDevice));
-      HIPOK(hipMemcpy2D(dod, ds * 4, od.data(), R * 4, R * 4, rows, hipMemcpyHostToDevice));
+      std::vector<float> hx, hodm, houtm, hidm;
+      const hipMemcpyKind up = host ? hipMemcpyHostToHost : hipMemcpyHostToDevice;
+      const hipMemcpyKind down = host ? hipMemcpyHostToHost : hipMemcpyDeviceToHost;
+      if (host) {
+        hx.resize((size_t)rows * xs); hodm.resize((size_t)rows * ds); houtm.resize((size_t)rows * os); hidm.resize((size_t)rows * is);
+        dx = hx.data(); dod = hodm.data(); dout = houtm.data(); did = hidm.data();
+      } else {
+        HIPOK(hipMalloc(&dx, (size_t)rows * xs * 4)); HIPOK(hipMalloc(&dout, (size_t)rows * os * 4));
+        HIPOK(hipMalloc(&dod, (size_t)rows * ds * 4)); HIPOK(hipMalloc(&did, (size_t)rows * is * 4));
+      }
+      HIPOK(hipMemcpy2D(dx, xs * 4, x.data(), I * 4, I * 4, rows, up));
+      HIPOK(hipMemcpy2D(dod, ds * 4, od.data(), R * 4, R * 4, rows, up));
       MatrixView in(dx, rows, I, xs), out(dout, rows, R, os), out_diff(dod, rows, R, ds), in_diff(did, rows, I, is);
       std::vector<int> flags(c->NumStream(), 1);
       std::vector<float> hout((size_t)rows * R), hid((size_t)rows * I);
@@ -169,8 +179,8 @@ int main(int argc, char **argv) {
         c->BackpropagateFnc(in, out, out_diff, &in_diff);
         if (step == nsteps - 1) {
           HIPOK(hipDeviceSynchronize());
-          HIPOK(hipMemcpy2D(hout.data(), R * 4, dout, os * 4, R * 4, rows, hipMemcpyDeviceToHost));
-          HIPOK(hipMemcpy2D(hid.data(), I * 4, did, is * 4, I * 4, rows, hipMemcpyDeviceToHost));
+          HIPOK(hipMemcpy2D(hout.data(), R * 4, dout, os * 4, R * 4, rows, down));
+          HIPOK(hipMemcpy2D(hid.data(), I * 4, did, is * 4, I * 4, rows, down));
           std::ofstream g(prefix + ".gradinfo");
           g << c->InfoGradient() << "\n";
         }
@@ -186,7 +196,7 @@ int main(int argc, char **argv) {
       c->Write(f, true);
       std::cout << "OK\n" << c->Info() << "\n";
     } else {
-      std::cerr << "usage: component_test init_write|dump_params|convert|bad_proto|run_gpu ...\n";
+      std::cerr << "usage: component_test init_write|dump_params|convert|bad_proto|run_gpu|run_gpu_host ...\n";
       return 2;
     }
     return 0;

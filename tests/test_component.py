@@ -116,10 +116,12 @@ def _relerr(a, b):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("marker,S", [("<LstmProjectedStreams>", 4), ("<LstmProjected>", 1)])
-def test_component_train_steps_gpu(tmp_path, marker, S):
+@pytest.mark.parametrize("marker,S,mode", [("<LstmProjectedStreams>", 4, "run_gpu"), ("<LstmProjected>", 1, "run_gpu"),
+                                           ("<LstmProjectedStreams>", 4, "run_gpu_host")])
+def test_component_train_steps_gpu(tmp_path, marker, S, mode):
     """Reset -> (PropagateFnc, BackpropagateFnc, Update) x3 through the C++ mirror, pitched device
-    matrices; <LstmProjected> = standard/ semantics (zero history per call, +-50 clip in Update)."""
+    matrices (run_gpu_host: pitched HOST matrices, staged by the adapter); <LstmProjected> = standard/
+    semantics (zero history per call, +-50 clip in Update)."""
     I, C, R, T = 40, 64, 32, 6
     flat = make_params(I, C, R, scale=0.2, seed=7)
     (tmp_path / "m.nnet").write_bytes(kaldi_fmt.binary_model(flat, I, C, R, S, marker=marker))
@@ -128,7 +130,7 @@ def test_component_train_steps_gpu(tmp_path, marker, S):
     od = (300.0 * rng.randn(T * S, R)).astype(np.float32) if S == 1 else rng.randn(T * S, R).astype(np.float32)
     x.tofile(tmp_path / "x.raw"); od.tofile(tmp_path / "od.raw")
     lr, mmt, nsteps = 1e-4, 0.9, 3
-    run("run_gpu", tmp_path / "m.nnet", tmp_path / "x.raw", tmp_path / "od.raw", T * S, lr, mmt, nsteps, tmp_path / "res")
+    run(mode, tmp_path / "m.nnet", tmp_path / "x.raw", tmp_path / "od.raw", T * S, lr, mmt, nsteps, tmp_path / "res")
     o = Oracle(I, C, R, S, np.float32); o.set_params(flat)
     std = marker == "<LstmProjected>"
     for _ in range(nsteps):

@@ -524,3 +524,36 @@ def test_bf16_operand_mode(I, C, R, S, T, fuse_x, fat):
     e.synchronize()
     assert relerr(outd.cpu().numpy(), o.propagate(x)) <= 3e-5
     e.close()
+
+
+def test_host_matrices_are_staged_through_the_device_path():
+    """klstm_propagate_host / klstm_backpropagate_host (a Kaldi CuMatrix holds host memory with --use-gpu=no,
+    cu-matrix.h:479-481): pitched numpy matrices in, results land in host memory on return; same tolerances as the
+    device-pointer path, and the two paths are bit-identical to each other."""
+    I, C, R, S, T = 40, 64, 32, 4, 5
+    rng = np.random.RandomState(5)
+    p = make_params(I, C, R, scale=0.3, seed=6)
+    o = Oracle(I, C, R, S, np.float32)
+    o.set_params(p)
+    e, e2 = make_engine(I, C, R, S, p), make_engine(I, C, R, S, p)
+    for ck in range(2):
+        xbuf = np.zeros((T * S, I + 8), np.float32); x = xbuf[:, :I]; x[:] = rng.randn(T * S, I)
+        odbuf = np.zeros((T * S, R + 4), np.float32); od = odbuf[:, :R]; od[:] = rng.randn(T * S, R)
+        outbuf = np.full((T * S, R + 12), 7.0, np.float32); out = outbuf[:, :R]
+        idbuf = np.full((T * S, I + 4), 7.0, np.float32); idf = idbuf[:, :I]
+        assert e.pointer_on_device(x.ctypes.data) == 0
+        e.propagate_host(x, out)
+        e.backpropagate_host(x, od, idf, momentum=0.9)
+        out_o = o.propagate(np.ascontiguousarray(x))
+        id_o = o.backpropagate(np.ascontiguousarray(x), np.ascontiguousarray(od), momentum=0.9)
+        assert relerr(out, out_o) <= 2e-5 and relerr(idf, id_o) <= 1e-4
+        assert relerr(e.get_corr(), o.get_corr()) <= 1e-4
+        assert np.all(outbuf[:, R:] == 7.0) and np.all(idbuf[:, I:] == 7.0)      # row padding untouched
+        xd, odd = dev(np.ascontiguousarray(x)), dev(np.ascontiguousarray(od))
+        assert e2.pointer_on_device(xd.data_ptr()) == 1
+        outd = torch.empty(T * S, R, device="cuda"); idd = torch.empty(T * S, I, device="cuda")
+        torch.cuda.synchronize()
+        e2.propagate(xd, outd); e2.backpropagate(xd, odd, idd, momentum=0.9); e2.synchronize()
+        assert np.array_equal(outd.cpu().numpy(), out) and np.array_equal(idd.cpu().numpy(), idf)
+        e.update(1e-3); e2.update(1e-3); o.update(1e-3)
+    e.close(); e2.close()
