@@ -77,26 +77,42 @@ def pmc_traffic(kernel_tag):
     return None
 
 
+def init_params(seed=7):
+    """U[-ParamScale, +ParamScale] parameters from a fixed-seed host RNG (InitMatParam/InitVecParam semantics,
+    ...streams.h:41-53), GetParams order; identical on every rank."""
+    rng = np.random.RandomState(seed)
+    n = 4 * C_DIM * I_DIM + 4 * C_DIM * R_DIM + 7 * C_DIM + R_DIM * C_DIM
+    return ((rng.rand(n) - 0.5) * 2 * PARAM_SCALE).astype(np.float32)
+
+
 def cpu_baseline(S, budget_s):
-    """The oracle (reference op sequence, un-fused, 1 thread) timed on this host on a bounded
-    sample of the same workload."""
-    from oracle.oracle import Oracle, make_params
-    o = Oracle(I_DIM, C_DIM, R_DIM, S, np.float32, threads=1)
-    o.set_params(make_params(I_DIM, C_DIM, R_DIM, scale=PARAM_SCALE, seed=7))
+    """The oracle (reference op sequence, un-fused) timed on this host on a bounded sample of the same workload:
+    1 thread (Kaldi nnet1 is single-threaded outside BLAS) = `value`, and with the GEMMs threaded over all host cores
+    (what a multi-threaded BLAS under Kaldi would give) = `value_all_cores`.  The ONLY place bench.py touches oracle/."""
+    from oracle.oracle import Oracle
     rng = np.random.RandomState(0)
     x = rng.randn(T_BPTT * S, I_DIM).astype(np.float32)
     od = (0.1 * rng.randn(T_BPTT * S, R_DIM)).astype(np.float32)
-    o.propagate(x); o.backpropagate(x, od, MOMENTUM); o.update(LR)      # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        o.propagate(x); o.backpropagate(x, od, MOMENTUM); o.update(LR)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s and n >= 3:
-            break
-    return {"value": n * T_BPTT * S / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} minibatches of {T_BPTT}x{S} frames ({dt:.1f} s), oracle/lstmp_oracle.c fp32, "
-                      f"1 thread of {os.cpu_count()} host cores"}
+
+    def timed(threads, budget):
+        o = Oracle(I_DIM, C_DIM, R_DIM, S, np.float32, threads=threads)
+        o.set_params(init_params())
+        o.propagate(x); o.backpropagate(x, od, MOMENTUM); o.update(LR)      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            o.propagate(x); o.backpropagate(x, od, MOMENTUM); o.update(LR)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget and n >= 3:
+                return n, dt
+
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n1, dt1 = timed(1, budget_s)
+    na, dta = timed(ncores, max(2.0, budget_s / 3))
+    return {"value": n1 * T_BPTT * S / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
+            "value_all_cores": na * T_BPTT * S / dta, "cores_all": ncores,
+            "sample": f"{n1} minibatches of {T_BPTT}x{S} frames ({dt1:.1f} s) on 1 thread, {na} ({dta:.1f} s) on "
+                      f"{ncores} OpenMP threads; oracle/lstmp_oracle.c fp32, un-fused reference op order"}
 
 
 def main():
@@ -124,11 +140,10 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     import kaldi_lstm_amd as k
-    from oracle.oracle import make_params          # host-side parameter init only (never timed)
     S = args.streams_per_gpu
     stream = torch.cuda.Stream()
     eng = k.Engine(I_DIM, C_DIM, R_DIM, S, device=local_rank, stream=stream)
-    eng.set_params(make_params(I_DIM, C_DIM, R_DIM, scale=PARAM_SCALE, seed=7))   # identical on all ranks
+    eng.set_params(init_params())   # identical on all ranks
     feats, odiff = make_inputs(S, 1234 + rank, "cuda")
     nchunk = feats.shape[0]
     out = torch.empty(T_BPTT * S, R_DIM, device="cuda")
