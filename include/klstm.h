@@ -94,6 +94,10 @@ klstm_status klstm_get_grads_host(klstm_engine *e, float *flat);  /* pure gradie
 /* Device address of the contiguous gradient blob (num_params floats) for an in-place
  * all-reduce (RCCL ncclAllReduce / torch.distributed.all_reduce) in DP mode. */
 float *klstm_grad_blob(klstm_engine *e);
+/* Use caller-owned device storage (num_params floats, 16-byte aligned) as this engine's gradient blob from now
+ * on: a stacked net places the blobs of all its layers back to back in ONE buffer so that a minibatch needs one
+ * all-reduce for the whole model.  NULL returns to the engine's own buffer. */
+klstm_status klstm_bind_grad_blob(klstm_engine *e, float *grad_dev);
 float *klstm_param_blob(klstm_engine *e);
 
 /* Reset (...streams.h:212-220): for every s with flags[s] == 1 zero stream s's carried
@@ -188,6 +192,12 @@ klstm_status klstm_affine_backpropagate(const float *out_diff, int rows, int out
 klstm_status klstm_affine_update(const float *in, int in_stride, const float *out_diff, int od_stride, int rows,
                                  int in_dim, int out_dim, float *W, float *bias, float *W_corr, float *bias_corr,
                                  float lr, float lr_bias, float momentum, void *hip_stream);
+/* data-parallel pieces of the same layer: the pure local gradient (no momentum, no update) into caller storage,
+ * and the post-all-reduce step  corr = momentum*corr + grad ; param -= lr*corr  on any flat tensor */
+klstm_status klstm_affine_gradient(const float *in, int in_stride, const float *out_diff, int od_stride, int rows,
+                                   int in_dim, int out_dim, float *W_grad, float *bias_grad, void *hip_stream);
+klstm_status klstm_sgd_momentum_update(float *param, float *corr, const float *grad, long n, float momentum, float lr,
+                                       void *hip_stream);
 klstm_status klstm_softmax(const float *in, int rows, int cols, int in_stride, float *out, int out_stride,
                            void *hip_stream);
 klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, int stride, const int *targets_dev,

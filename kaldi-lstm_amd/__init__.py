@@ -7,5 +7,7 @@ launch; it contains no arithmetic and NO CPU fallback: if the library or a GPU i
 calls raise.
 """
 from .binding import (Engine, KlstmError, lib_path, load_library, time_shift, affine_propagate,  # noqa: F401
-                      affine_backpropagate, affine_update, softmax, xent_eval_masked, DEFER_MOMENTUM)
-from .dp import DataParallelLstm, shard_time_major  # noqa: F401,E402
+                      affine_backpropagate, affine_update, affine_gradient, sgd_momentum_update, softmax,
+                      xent_eval_masked, DEFER_MOMENTUM)
+from .dp import (DataParallelLstm, DataParallelNnet, LstmDP, AffineDP, SoftmaxXentDP,  # noqa: F401,E402
+                 shard_time_major)

@@ -79,6 +79,9 @@ def load_library():
     lib.klstm_affine_backpropagate.argtypes = [P, I, I, I, P, I, P, I, P]
     lib.klstm_affine_update.argtypes = [P, I, P, I, I, I, I, P, P, P, P, F, F, F, P]
     lib.klstm_softmax.argtypes = [P, I, I, I, P, I, P]
+    lib.klstm_bind_grad_blob.argtypes = [P, P]
+    lib.klstm_affine_gradient.argtypes = [P, I, P, I, I, I, I, P, P, P]
+    lib.klstm_sgd_momentum_update.argtypes = [P, P, P, ctypes.c_long, F, F, P]
     lib.klstm_xent_eval_masked.argtypes = [P, I, I, I, P, P, P, I, P, P, P]
     _LIB = lib
     return lib
@@ -212,6 +215,16 @@ class Engine:
     def pointer_on_device(self, ptr):
         return int(self.lib.klstm_pointer_on_device(self.h, ptr))
 
+    def bind_grad_blob(self, t):
+        """Use the torch CUDA float32 tensor `t` (num_params elements, contiguous) as the gradient blob."""
+        if t is None:
+            self._chk(self.lib.klstm_bind_grad_blob(self.h, None))
+            self._bound = None
+            return
+        assert t.is_cuda and t.is_contiguous() and t.numel() == self.num_params
+        self._chk(self.lib.klstm_bind_grad_blob(self.h, t.data_ptr()))
+        self._bound = t
+
     def apply_momentum(self, momentum):
         self._chk(self.lib.klstm_apply_momentum(self.h, float(momentum)))
 
@@ -274,6 +287,21 @@ def affine_update(x, out_diff, W, bias, W_corr, bias_corr, lr, lr_bias, momentum
     _chk(lib.klstm_affine_update(x.data_ptr(), x.stride(0), out_diff.data_ptr(), out_diff.stride(0), x.shape[0], W.shape[1],
                                  W.shape[0], W.data_ptr(), bias.data_ptr(), W_corr.data_ptr(), bias_corr.data_ptr(),
                                  float(lr), float(lr_bias), float(momentum), _sp(stream)))
+
+
+def affine_gradient(x, out_diff, W_grad, bias_grad, stream=None):
+    """Pure local gradient of an AffineTransform: W_grad = out_diff^T x, bias_grad = colsum(out_diff)."""
+    lib = load_library()
+    _chk(lib.klstm_affine_gradient(x.data_ptr(), x.stride(0), out_diff.data_ptr(), out_diff.stride(0), x.shape[0],
+                                   x.shape[1], out_diff.shape[1], W_grad.data_ptr(), bias_grad.data_ptr(), _sp(stream)))
+
+
+def sgd_momentum_update(param, corr, grad, momentum, lr, stream=None):
+    """corr = momentum*corr + grad ; param -= lr*corr  on flat contiguous CUDA tensors."""
+    lib = load_library()
+    assert param.is_contiguous() and corr.is_contiguous() and grad.is_contiguous()
+    _chk(lib.klstm_sgd_momentum_update(param.data_ptr(), corr.data_ptr(), grad.data_ptr(), param.numel(),
+                                       float(momentum), float(lr), _sp(stream)))
 
 
 def softmax(x, out, stream=None):

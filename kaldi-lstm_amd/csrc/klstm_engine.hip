@@ -48,6 +48,7 @@ struct klstm_engine {
   bool own_stream = false;
   long nparams = 0;
   float *params = nullptr, *grads = nullptr, *corr = nullptr;
+  float *grads_own = nullptr;   // the engine's own gradient blob (grads points elsewhere after klstm_bind_grad_blob)
   float *wrT = nullptr, *wmT = nullptr, *wxT = nullptr;   // transposed copies for the BPTT kernels
   float *pk[4] = {nullptr, nullptr, nullptr, nullptr};    // packed MFMA-operand-ordered copies (vector kernels)
   float *prev_c = nullptr, *prev_r = nullptr;
@@ -230,7 +231,7 @@ void klstm_destroy(klstm_engine *e) {
   drop_graphs(e);
   for (auto &r : e->probes) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   free_planes(e);
-  float *ps[] = {e->params, e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3]};
+  float *ps[] = {e->params, e->grads_own ? e->grads_own : e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3]};
   for (float *p : ps) if (p) (void)hipFree(p);
   if (e->flags_dev) (void)hipFree(e->flags_dev);
   for (float *p : e->stage) if (p) (void)hipFree(p);
@@ -244,6 +245,17 @@ int klstm_recur_dim(const klstm_engine *e) { return e ? e->R : -1; }
 int klstm_num_stream(const klstm_engine *e) { return e ? e->S : -1; }
 long klstm_num_params(const klstm_engine *e) { return e ? e->nparams : -1; }
 float *klstm_grad_blob(klstm_engine *e) { return e ? e->grads : nullptr; }
+klstm_status klstm_bind_grad_blob(klstm_engine *e, float *grad_dev) {
+  if (!e) return fail(KLSTM_ERR_ARG, "null argument");
+  if (grad_dev && (reinterpret_cast<uintptr_t>(grad_dev) & 15)) return fail(KLSTM_ERR_ARG, "klstm_bind_grad_blob: blob must be 16-byte aligned");
+  HIPCHK(hipSetDevice(e->device));
+  { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  drop_graphs(e);                                   // captured launches hold the old address
+  if (!e->grads_own) e->grads_own = e->grads;
+  e->grads = grad_dev ? grad_dev : e->grads_own;
+  return KLSTM_OK;
+}
 float *klstm_param_blob(klstm_engine *e) { return e ? e->params : nullptr; }
 
 static klstm_status blob_h2d(klstm_engine *e, float *dst, const float *src) {
@@ -723,6 +735,23 @@ klstm_status klstm_affine_update(const float *in, int in_stride, const float *ou
   HIPCHK(launch_col_sum(out_diff, rows, out_dim, od_stride, momentum, bias_corr, st));
   HIPCHK(launch_axpy(W, W_corr, -lr, (long)out_dim * in_dim, st));
   HIPCHK(launch_axpy(bias, bias_corr, -lr_bias, out_dim, st));
+  return KLSTM_OK;
+}
+klstm_status klstm_affine_gradient(const float *in, int in_stride, const float *out_diff, int od_stride, int rows, int in_dim,
+                                   int out_dim, float *W_grad, float *bias_grad, void *hip_stream) {
+  if (!in || !out_diff || !W_grad || !bias_grad) return fail(KLSTM_ERR_ARG, "klstm_affine_gradient: null argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIPCHK(launch_gemm(true, false, out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, 0.f, W_grad, in_dim, nullptr, st));
+  HIPCHK(launch_col_sum(out_diff, rows, out_dim, od_stride, 0.f, bias_grad, st));
+  return KLSTM_OK;
+}
+klstm_status klstm_sgd_momentum_update(float *param, float *corr, const float *grad, long n, float momentum, float lr,
+                                       void *hip_stream) {
+  if (!param || !corr || !grad || n < 0) return fail(KLSTM_ERR_ARG, "klstm_sgd_momentum_update: bad argument");
+  if (n == 0) return KLSTM_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIPCHK(launch_apply_momentum(corr, grad, momentum, n, st));
+  HIPCHK(launch_axpy(param, corr, -lr, n, st));
   return KLSTM_OK;
 }
 klstm_status klstm_softmax(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, void *hip_stream) {

@@ -66,3 +66,132 @@ class DataParallelLstm:
             self.dist.all_reduce(self._blob, op=self.dist.ReduceOp.SUM, group=self.group)
             e.apply_momentum(momentum)
         e.update(learn_rate)
+
+
+# ------------------------------------------------------------------------------------------------
+# Stacked nets (BASELINE.json configs[3]: LSTM x2 + AffineTransform + Softmax + masked Xent): the gradient blobs of
+# ALL layers live back to back in one buffer and a minibatch still needs exactly ONE all-reduce.
+#
+# Layer protocol (duck-typed; the device classes below wrap the C-ABI, the CPU tests plug in oracle-backed twins):
+#   num_params                      int
+#   bind_grad(view)                 this layer's slice of the fused blob (flat tensor)
+#   reset(flags)                    new-utterance flags (layers without state ignore it)
+#   propagate(x) -> out
+#   backpropagate(x, out_diff, want_in_diff) -> in_diff | None     pure LOCAL gradient into the bound slice
+#   apply(momentum, lr)             corr = momentum*corr + grad ; theta -= lr*corr   (after the all-reduce)
+# Loss protocol:  eval(net_out, targets, mask) -> (diff, xent_sum, correct, valid)
+# ------------------------------------------------------------------------------------------------
+class LstmDP:
+    """One LstmProjectedStreams engine as a layer of DataParallelNnet."""
+
+    def __init__(self, engine):
+        self.e = engine
+        self.num_params = engine.num_params
+        self._out = self._ind = None
+
+    def bind_grad(self, view):
+        self.e.bind_grad_blob(view)
+
+    def reset(self, flags):
+        self.e.reset(flags)
+
+    def propagate(self, x):
+        if self._out is None or self._out.shape[0] != x.shape[0]:
+            self._out = torch.empty(x.shape[0], self.e.R, device=x.device)
+        self.e.propagate(x, self._out)
+        return self._out
+
+    def backpropagate(self, x, out_diff, want_in_diff):
+        if want_in_diff and (self._ind is None or self._ind.shape[0] != x.shape[0]):
+            self._ind = torch.empty(x.shape[0], self.e.I, device=x.device)
+        self.e.backpropagate(x, out_diff, self._ind if want_in_diff else None, 0.0, DataParallelLstm.DEFER_MOMENTUM)
+        return self._ind if want_in_diff else None
+
+    def apply(self, momentum, lr):
+        self.e.apply_momentum(momentum)
+        self.e.update(lr)
+
+
+class AffineDP:
+    """AffineTransform (W [out, in], bias [out]) on the device ops of the C-ABI (klstm_affine_*)."""
+
+    def __init__(self, W, bias, ops):
+        self.W, self.bias, self.ops = W.contiguous(), bias.contiguous(), ops
+        self.num_params = W.numel() + bias.numel()
+        self.W_corr, self.b_corr = torch.zeros_like(self.W), torch.zeros_like(self.bias)
+        self._out = self._ind = None
+
+    def bind_grad(self, view):
+        n = self.W.numel()
+        self.gW, self.gb = view[:n].view_as(self.W), view[n:]
+
+    def reset(self, flags):
+        pass
+
+    def propagate(self, x):
+        if self._out is None or self._out.shape[0] != x.shape[0]:
+            self._out = torch.empty(x.shape[0], self.W.shape[0], device=x.device)
+        self.ops.affine_propagate(x, self.W, self.bias, self._out)
+        return self._out
+
+    def backpropagate(self, x, out_diff, want_in_diff):
+        self.ops.affine_gradient(x, out_diff, self.gW, self.gb)
+        if not want_in_diff:
+            return None
+        if self._ind is None or self._ind.shape[0] != x.shape[0]:
+            self._ind = torch.empty(x.shape[0], self.W.shape[1], device=x.device)
+        self.ops.affine_backpropagate(out_diff, self.W, self._ind)
+        return self._ind
+
+    def apply(self, momentum, lr):
+        self.ops.sgd_momentum_update(self.W.view(-1), self.W_corr.view(-1), self.gW.reshape(-1), momentum, lr)
+        self.ops.sgd_momentum_update(self.bias, self.b_corr, self.gb, momentum, lr)
+
+
+class SoftmaxXentDP:
+    """Softmax + Xent::EvalMasked (google/nnet/nnet-loss.cc:76-142) on the device ops of the C-ABI."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self._post = self._diff = None
+
+    def eval(self, net_out, targets, mask):
+        if self._post is None or self._post.shape != net_out.shape:
+            self._post, self._diff = torch.empty_like(net_out), torch.empty_like(net_out)
+        self.ops.softmax(net_out, self._post)
+        xe, correct, valid = self.ops.xent_eval_masked(self._post, targets, mask, self._diff)
+        return self._diff, xe, correct, valid
+
+
+class DataParallelNnet:
+    """Reset -> Propagate -> loss -> Backpropagate of a stack of layers, then ONE all-reduce (sum) of the fused
+    gradient blob and the momentum/update step on every rank (bd-nnet-train-lstm-streams.cc:209-228 per rank, on this
+    rank's streams).  `alloc(n)` returns the flat blob storage (torch CUDA float32 for the device layers)."""
+
+    def __init__(self, layers, loss, alloc, group=None, force_collective=False):
+        import torch.distributed as dist
+        self.layers, self.loss, self.dist, self.group = layers, loss, dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
+        pad4 = lambda n: (n + 3) // 4 * 4                  # every slice starts 16-byte aligned (float4 stores)
+        self.blob = alloc(sum(pad4(l.num_params) for l in layers))
+        off = 0
+        for l in layers:
+            l.bind_grad(self.blob[off:off + l.num_params])
+            off += pad4(l.num_params)
+
+    def train_step(self, x, targets, mask, momentum, learn_rate, reset_flags=None):
+        if reset_flags is not None:
+            for l in self.layers:
+                l.reset(reset_flags)
+        acts = [x]
+        for l in self.layers:
+            acts.append(l.propagate(acts[-1]))
+        diff, xent, correct, valid = self.loss.eval(acts[-1], targets, mask)
+        for i in range(len(self.layers) - 1, -1, -1):
+            diff = self.layers[i].backpropagate(acts[i], diff, i > 0)     # the first layer's in_diff is never used (:228)
+        if self.collective:
+            self.dist.all_reduce(self.blob, op=self.dist.ReduceOp.SUM, group=self.group)
+        for l in self.layers:
+            l.apply(momentum, learn_rate)
+        return xent, correct, valid

@@ -128,3 +128,76 @@ def test_shard_time_major_layout():
     assert np.array_equal(a[:, 0] // 2, [2, 3, 6, 7, 10, 11])      # rows t*4+s for s in {2,3}
     with pytest.raises(AssertionError):
         k.shard_time_major(m, 4, 0, 3)
+
+
+# ---- stacked net (LSTM x2 + Affine + Softmax + masked Xent), ONE all-reduce of the fused blob per minibatch ----
+DIMS = (6, 8, 5, 2, 11)      # I, C, R, n_lstm, n_out
+
+
+def stack_data():
+    rng = np.random.RandomState(3)
+    xs = [rng.randn(T * S_TOTAL, DIMS[0]) for _ in range(NSTEP)]
+    tg = [rng.randint(0, DIMS[4], T * S_TOTAL).astype(np.int32) for _ in range(NSTEP)]
+    mk = [(rng.rand(T * S_TOTAL) > 0.2).astype(np.float32) for _ in range(NSTEP)]     # padded tail frames
+    return xs, tg, mk
+
+
+def stack_worker(rank, world, port, q):
+    import kaldi_lstm_amd as k
+    from tests import nnet_twins as tw
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s_local = S_TOTAL // world
+    lstm, W, b = tw.make_stack(DIMS, s_local, seed=5)
+    layers = tw.cpu_layers(DIMS, s_local, lstm, W, b)
+    calls = {"n": 0}
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(*a, **kw):
+        calls["n"] += 1
+        return real_all_reduce(*a, **kw)
+    dist.all_reduce = counting_all_reduce
+    net = k.DataParallelNnet(layers, tw.NumpyLoss(), alloc=lambda n: torch.zeros(n, dtype=torch.float64))
+    xs, tg, mk = stack_data()
+    stats = []
+    for i in range(NSTEP):
+        x = torch.from_numpy(np.ascontiguousarray(k.shard_time_major(xs[i], S_TOTAL, rank, world)))
+        t = torch.from_numpy(np.ascontiguousarray(k.shard_time_major(tg[i][:, None], S_TOTAL, rank, world)[:, 0]))
+        m = torch.from_numpy(np.ascontiguousarray(k.shard_time_major(mk[i][:, None], S_TOTAL, rank, world)[:, 0]))
+        stats.append(net.train_step(x, t, m, MMT, LR, reset_flags=[1] * s_local if i == 0 else None))
+    q.put((rank, [l.params() for l in layers], stats, calls["n"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_stacked_net_one_allreduce_equals_single_process():
+    from tests import nnet_twins as tw
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=stack_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, all streams, no collective
+    import kaldi_lstm_amd as k
+    lstm, W, b = tw.make_stack(DIMS, S_TOTAL, seed=5)
+    layers = tw.cpu_layers(DIMS, S_TOTAL, lstm, W, b)
+    net = k.DataParallelNnet(layers, tw.NumpyLoss(), alloc=lambda n: torch.zeros(n, dtype=torch.float64))
+    xs, tg, mk = stack_data()
+    full = [net.train_step(torch.from_numpy(xs[i]), torch.from_numpy(tg[i]), torch.from_numpy(mk[i]), MMT, LR,
+                           reset_flags=[1] * S_TOTAL if i == 0 else None) for i in range(NSTEP)]
+    for rank, params, stats, ncalls in res:
+        assert ncalls == NSTEP                                   # exactly ONE collective per minibatch for the whole model
+        for pr, l in zip(params, layers):
+            np.testing.assert_allclose(pr, l.params(), rtol=1e-9, atol=1e-12)
+    for i in range(NSTEP):                                       # loss statistics add up over ranks
+        assert abs(res[0][2][i][0] + res[1][2][i][0] - full[i][0]) <= 1e-9 * abs(full[i][0])
+        assert res[0][2][i][1] + res[1][2][i][1] == full[i][1]
+        assert res[0][2][i][2] + res[1][2][i][2] == full[i][2]

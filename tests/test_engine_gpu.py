@@ -557,3 +557,47 @@ def test_host_matrices_are_staged_through_the_device_path():
         assert np.array_equal(outd.cpu().numpy(), out) and np.array_equal(idd.cpu().numpy(), idf)
         e.update(1e-3); e2.update(1e-3); o.update(1e-3)
     e.close(); e2.close()
+
+
+def test_stacked_net_dp_device_layers_against_cpu_twins():
+    """BASELINE.json configs[3] topology at test size (LSTM x2 + AffineTransform + Softmax + masked Xent) through
+    DataParallelNnet with the DEVICE layers (klstm engines bound to slices of one fused gradient blob, klstm_affine_*,
+    klstm_softmax, klstm_xent_eval_masked) and the all-reduce over RCCL (one-rank group), against the oracle-backed CPU
+    twins of the same protocol.  fp32: parameters 5e-5, loss statistics 1e-4 / exact counts."""
+    import os
+    import torch.distributed as dist
+    import kaldi_lstm_amd as k
+    from tests import nnet_twins as tw
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dims = (40, 64, 32, 2, 131)          # I, C, R, n_lstm, n_out
+    I, C, R, n_lstm, n_out = dims
+    S, T, mmt, lr = 4, 6, 0.9, 1e-3
+    lstm, W, b = tw.make_stack(dims, S, seed=21, dtype=np.float32, scale=0.2)
+    cpu = tw.cpu_layers(dims, S, lstm, W, b, dtype=np.float32)
+    cpu_net = k.DataParallelNnet(cpu, tw.NumpyLoss(), alloc=lambda n: torch.zeros(n, dtype=torch.float32))
+    engines = [make_engine(I if l == 0 else R, C, R, S, lstm[l]) for l in range(n_lstm)]
+    layers = [k.LstmDP(e) for e in engines] + [k.AffineDP(dev(W), dev(b), k)]
+    net = k.DataParallelNnet(layers, k.SoftmaxXentDP(k), alloc=lambda n: torch.zeros(n, device="cuda"), force_collective=True)
+    assert net.collective and net.blob.numel() >= sum(l.num_params for l in layers)
+    assert engines[1].grad_blob_ptr() == net.blob.data_ptr() + 4 * ((engines[0].num_params + 3) // 4 * 4)
+    rng = np.random.RandomState(22)
+    for i in range(3):
+        x = rng.randn(T * S, I).astype(np.float32)
+        tg = rng.randint(0, n_out, T * S).astype(np.int32)
+        mk = (rng.rand(T * S) > 0.25).astype(np.float32)
+        flags = [1] * S if i == 0 else None
+        xe, correct, valid = net.train_step(dev(x), torch.from_numpy(tg).cuda(), dev(mk), mmt, lr, reset_flags=flags)
+        xe_o, correct_o, valid_o = cpu_net.train_step(torch.from_numpy(x), torch.from_numpy(tg), torch.from_numpy(mk), mmt, lr,
+                                                      reset_flags=flags)
+        assert abs(xe - xe_o) <= 1e-4 * abs(xe_o) and (correct, valid) == (correct_o, valid_o)
+    torch.cuda.synchronize()
+    for e, c in zip(engines, cpu[:n_lstm]):
+        assert relerr(e.get_params(), c.params()) <= 5e-5
+    aff = layers[-1]
+    assert relerr(np.concatenate([aff.W.cpu().numpy().ravel(), aff.bias.cpu().numpy()]), cpu[-1].params()) <= 5e-5
+    for e in engines:
+        e.close()
+    dist.destroy_process_group()
