@@ -719,11 +719,39 @@ klstm_status klstm_affine_propagate(const float *in, int rows, int in_dim, int i
                      (hipStream_t)hip_stream));
   return KLSTM_OK;
 }
+// split-K workspace of the stateless ops: one growing buffer per (device, stream), owned by the library
+static klstm_status splitk_workspace(hipStream_t st, size_t floats, float **ws) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, std::pair<float *, size_t>> pool;
+  int devid = 0;
+  HIPCHK(hipGetDevice(&devid));
+  std::lock_guard<std::mutex> lk(mu);
+  auto &slot = pool[std::make_pair(devid, st)];
+  if (slot.second < floats) {
+    HIPCHK(hipStreamSynchronize(st));                // earlier launches may still read the old buffer
+    if (slot.first) (void)hipFree(slot.first);
+    slot.first = nullptr; slot.second = 0;
+    HIPCHK(hipMalloc(&slot.first, floats * sizeof(float)));
+    slot.second = floats;
+  }
+  *ws = slot.first;
+  return KLSTM_OK;
+}
 klstm_status klstm_affine_backpropagate(const float *out_diff, int rows, int out_dim, int od_stride, const float *W,
                                         int in_dim, float *in_diff, int id_stride, void *hip_stream) {
   if (!out_diff || !W || !in_diff) return fail(KLSTM_ERR_ARG, "klstm_affine_backpropagate: null argument");
-  HIPCHK(launch_gemm(false, false, rows, in_dim, out_dim, out_diff, od_stride, W, in_dim, 0.f, in_diff, id_stride, nullptr,
-                     (hipStream_t)hip_stream));
+  hipStream_t st = (hipStream_t)hip_stream;
+  int klen = 0;
+  const int ks = gemm_splitk_plan(rows, in_dim, out_dim, &klen);       // contraction over the (long) output axis
+  if (ks > 1) {
+    float *ws = nullptr;
+    klstm_status s = splitk_workspace(st, (size_t)ks * rows * in_dim, &ws);
+    if (s != KLSTM_OK) return s;
+    HIPCHK(launch_gemm_splitk(false, false, rows, in_dim, out_dim, out_diff, od_stride, W, in_dim, 0.f, in_diff, id_stride,
+                              nullptr, ws, ks, klen, st));
+    return KLSTM_OK;
+  }
+  HIPCHK(launch_gemm(false, false, rows, in_dim, out_dim, out_diff, od_stride, W, in_dim, 0.f, in_diff, id_stride, nullptr, st));
   return KLSTM_OK;
 }
 klstm_status klstm_affine_update(const float *in, int in_stride, const float *out_diff, int od_stride, int rows, int in_dim,

@@ -63,6 +63,13 @@ hipError_t launch_gemm(bool transA, bool transB, int M, int N, int K, const floa
                        const float *B, int ldb, float beta, float *Cm, int ldc, const float *bias,
                        hipStream_t st, LaunchProbe pr = {});
 
+// Split-K form of the same product for few-tile / long-K shapes: ks = gemm_splitk_plan(...) slices of klen, partial
+// tiles in ws (ks*M*N floats), summed in fixed order by a second kernel.  ks == 1: use launch_gemm.
+int gemm_splitk_plan(int M, int N, int K, int *klen);
+hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, const float *A, int lda, const float *B,
+                              int ldb, float beta, float *Cm, int ldc, const float *bias, float *ws, int ks, int klen,
+                              hipStream_t st);
+
 // All seven gradient accumulations (...streams.h:468-487) in ONE launch: three A^T*B products
 // (w_gifo_x, w_gifo_r, w_r_m) plus the bias / peephole column sums.  dst = beta*dst + grad, dst is a
 // blob in GetParams order.

@@ -1421,6 +1421,37 @@ __global__ __launch_bounds__(256) void k_gemm(GemmJob g) {
   gemm_tile<TA, TB>(g, blockIdx.y * GT, blockIdx.x * GT, As, Bs);
 }
 
+// Split-K variant for short-and-wide products whose 64x64 output tiles cannot fill the chip (AffineTransform
+// in_diff: 80 x 512 over K = 16624 is 16 tiles): blockIdx.z owns K slice z and writes its partial tile to
+// ws[z][M][N]; k_splitk_reduce sums the slices in fixed order (deterministic, no atomics).
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm_splitk(GemmJob g, int klen, float *ws) {
+  __shared__ float As[GK][GLD];
+  __shared__ float Bs[GK][GLD];
+  const int k0 = blockIdx.z * klen;
+  GemmJob s = g;
+  s.K = min(g.K - k0, klen);
+  s.A = TA ? g.A + (size_t)k0 * g.lda : g.A + k0;
+  s.B = TB ? g.B + k0 : g.B + (size_t)k0 * g.ldb;
+  s.vecA = g.vecA && (TA || s.K % 8 == 0);
+  s.vecB = g.vecB && (!TB || s.K % 8 == 0);
+  s.beta = 0.f; s.bias = nullptr;
+  s.Cm = ws + (size_t)blockIdx.z * g.M * g.N; s.ldc = g.N;
+  gemm_tile<TA, TB>(s, blockIdx.y * GT, blockIdx.x * GT, As, Bs);
+}
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__ ws, int ks, int M, int N, float beta,
+                                                       float *__restrict__ Cm, int ldc, const float *__restrict__ bias) {
+  const long total = (long)M * N;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / N), n = (int)(i - (long)m * N);
+    float v = ws[i];
+    for (int z = 1; z < ks; z++) v += ws[(size_t)z * total + i];
+    if (bias) v += bias[n];
+    float *cp = Cm + (size_t)m * ldc + n;
+    *cp = beta != 0.f ? beta * *cp + v : v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // all gradient accumulations of one minibatch in ONE launch (...streams.h:468-487):
 //   blocks [0, nb0)        W_gifo_x_corr = beta*corr + DGIFO^T * in
@@ -1896,6 +1927,32 @@ hipError_t launch_gemm(bool transA, bool transB, int M, int N, int K, const floa
   if (transA && !transB) KLAUNCH((k_gemm<true, false>), grid, block, st, pr, g);
   if (!transA && transB) KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
   KLAUNCH((k_gemm<false, false>), grid, block, st, pr, g);
+}
+
+// Split-K plan: worth it when the output tiles cover less than half the chip and K is long.
+int gemm_splitk_plan(int M, int N, int K, int *klen) {
+  const int tiles = cdiv(M, GT) * cdiv(N, GT);
+  if (tiles >= 128 || K < 1024) { *klen = K; return 1; }
+  int ks = cdiv(768, tiles);                         // ~3 workgroups per CU
+  int kl = cdiv(cdiv(K, ks), GK) * GK;
+  if (kl < 2 * GK) kl = 2 * GK;
+  *klen = kl;
+  return cdiv(K, kl);
+}
+hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, const float *A, int lda, const float *B,
+                              int ldb, float beta, float *Cm, int ldc, const float *bias, float *ws, int ks, int klen,
+                              hipStream_t st) {
+  const GemmJob g = make_job(transA, transB, M, N, K, A, lda, B, ldb, 0.f, nullptr, N, nullptr);
+  const dim3 grid(cdiv(N, GT), cdiv(M, GT), ks), block(256);
+  if (transA && transB) hipLaunchKernelGGL((k_gemm_splitk<true, true>), grid, block, 0, st, g, klen, ws);
+  else if (transA) hipLaunchKernelGGL((k_gemm_splitk<true, false>), grid, block, 0, st, g, klen, ws);
+  else if (transB) hipLaunchKernelGGL((k_gemm_splitk<false, true>), grid, block, 0, st, g, klen, ws);
+  else hipLaunchKernelGGL((k_gemm_splitk<false, false>), grid, block, 0, st, g, klen, ws);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  const long nb = ((long)M * N + 255) / 256;
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)(nb > 2048 ? 2048 : nb)), block, 0, st, ws, ks, M, N, beta, Cm, ldc, bias);
+  return hipGetLastError();
 }
 
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
