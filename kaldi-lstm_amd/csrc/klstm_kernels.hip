@@ -1366,6 +1366,24 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
   float ra[2][8], rb[2][8];
   fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, 0, tid, ra);
   fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, 0, tid, rb);   // B [N x K] when TB, else [K x N]
+  // beta != 0 (momentum folded into the gradient products, :468-487): the old C tile is requested now so that its
+  // HBM latency hides under the K loop instead of sitting in front of the stores
+  float cold[2][2][4];
+  if (g.beta != 0.f) {
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+      for (int ni = 0; ni < 2; ni++) {
+        const int n = n0 + wc * 32 + ni * 16 + i16;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int m = m0 + wr * 32 + mi * 16 + 4 * kg + r;
+          const bool ok = n < g.N && m < g.M;
+          const float v = g.Cm[ok ? (size_t)m * g.ldc + n : 0];
+          cold[mi][ni][r] = ok ? v : 0.f;
+        }
+      }
+  }
   for (int k0 = 0; k0 < g.K; k0 += GK) {
     stash_tile<TA>(As, tid, ra);
     stash_tile<!TB>(Bs, tid, rb);
@@ -1408,7 +1426,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
         if (m >= g.M) continue;
         float *cp = g.Cm + (size_t)m * g.ldc + n;
         float val = e[r] + bv;
-        if (g.beta != 0.f) val = g.beta * *cp + val;
+        if (g.beta != 0.f) val = g.beta * cold[mi][ni][r] + val;
         *cp = val;
       }
     }
