@@ -88,7 +88,7 @@ def init_params(seed=7):
 def cpu_baseline(S, budget_s):
     """The oracle (reference op sequence, un-fused) timed on this host on a bounded sample of the same workload:
     1 thread (Kaldi nnet1 is single-threaded outside BLAS) = `value`, and with the GEMMs threaded over all host cores
-    (what a multi-threaded BLAS under Kaldi would give) = `value_all_cores`.  The ONLY place bench.py touches oracle/."""
+    (what a multi-threaded BLAS under Kaldi would give) = `value_threaded`.  The ONLY place bench.py touches oracle/."""
     from oracle.oracle import Oracle
     rng = np.random.RandomState(0)
     x = rng.randn(T_BPTT * S, I_DIM).astype(np.float32)
@@ -107,12 +107,13 @@ def cpu_baseline(S, budget_s):
                 return n, dt
 
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nthr = min(ncores, 16)      # the products are GEMV-sized (M = NumStream): more threads only add fork/join cost
     n1, dt1 = timed(1, budget_s)
-    na, dta = timed(ncores, max(2.0, budget_s / 3))
+    na, dta = timed(nthr, max(2.0, budget_s / 3))
     return {"value": n1 * T_BPTT * S / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
-            "value_all_cores": na * T_BPTT * S / dta, "cores_all": ncores,
+            "value_threaded": na * T_BPTT * S / dta, "cores_threaded": nthr, "host_cores": ncores,
             "sample": f"{n1} minibatches of {T_BPTT}x{S} frames ({dt1:.1f} s) on 1 thread, {na} ({dta:.1f} s) on "
-                      f"{ncores} OpenMP threads; oracle/lstmp_oracle.c fp32, un-fused reference op order"}
+                      f"{nthr} OpenMP threads (host has {ncores} cores); oracle/lstmp_oracle.c fp32, un-fused reference op order"}
 
 
 def main():
@@ -123,6 +124,9 @@ def main():
     ap.add_argument("--streams-per-gpu", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch", choices=("auto", "graph", "eager"), default="auto",
+                    help="engine option 'graph': hipGraph replay per call (robust against a busy host thread) or plain "
+                         "stream launches (no ~6 us fixed cost per graph); auto = time both during the warm-up, keep the faster")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,7 +167,27 @@ def main():
         torch.cuda.synchronize()
 
     with torch.cuda.stream(stream):
-        for i in range(args.warmup):
+        launch = args.launch
+        if launch == "auto" and args.warmup < 20:
+            launch = "graph"
+        if launch == "auto":                 # inside the untimed warm-up: half the steps per mode, keep the faster
+            half, tm = args.warmup // 2, []
+            for mode in (1, 0):
+                eng.set_option("graph", mode)
+                for i in range(4):
+                    step(i)
+                fence()
+                t0 = time.perf_counter()
+                for i in range(half):
+                    step(i)
+                fence()
+                tm.append(time.perf_counter() - t0)
+            tt = torch.tensor(tm, device="cuda", dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # same decision on every rank
+            launch = "graph" if float(tt[0]) <= float(tt[1]) else "eager"
+        eng.set_option("graph", 1 if launch == "graph" else 0)
+        for i in range(args.warmup if args.launch != "auto" or args.warmup < 20 else 8):
             step(i)
         fence()
         t0 = time.perf_counter()
@@ -177,15 +201,20 @@ def main():
             dt = float(tmax.item())
 
         # ---- roofline leg: per-kernel device time from HIP start/stop events on the engine stream
+        NPROF = 10
         eng.set_option("profile", 1)
-        for i in range(3):
+        for i in range(3):                   # untimed pass: creates the event pool
             step(args.warmup + args.steps + i)
+        eng.profile_query("k_gates_step")
+        eng.set_option("profile", 1)         # clears the accumulators, keeps the pool
+        for i in range(NPROF):
+            step(args.warmup + args.steps + 3 + i)
         kern = {}
         for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj",
                      "k_grads", "k_update_repack", "k_pack", "k_pack_fwd", "k_pack_bwd", "k_apply_momentum"):
             tot, n = eng.profile_query(name)
             if n:
-                kern[name] = {"avg_us": tot / n, "launches_per_step": n / 3.0, "us_per_step": tot / 3.0}
+                kern[name] = {"avg_us": tot / n, "launches_per_step": n / NPROF, "us_per_step": tot / NPROF}
         eng.set_option("profile", 0)
 
     frames = args.steps * T_BPTT * S * world
@@ -214,7 +243,7 @@ def main():
                                    "T_bptt=20, 1000-frame synthetic utterances, fwd+BPTT+update "
                                    "(BASELINE.json configs[1])" % S,
                        "streams_per_gpu": S, "total_streams": S * world, "bptt": T_BPTT,
-                       "frames_per_step": T_BPTT * S * world,
+                       "frames_per_step": T_BPTT * S * world, "launch": launch,
                        "parallelism": "dp%d over streams, 1 all-reduce/minibatch" % world if world > 1 else "single GPU"},
             "roofline": ({"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
                           "frac": gbs / (PEAK_HBM_TBS * 1e3)} if hbm_bound else

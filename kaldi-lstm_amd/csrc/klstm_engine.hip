@@ -71,6 +71,7 @@ struct klstm_engine {
   int fuse_x = -1;    // -1 auto (small NumStream), 0 batched x-projection GEMM, 1 fused into the step kernel
   bool profile = false;
   std::vector<ProbeRec> probes;
+  std::vector<hipEvent_t> event_pool;   // recycled by klstm_profile_query: no hipEventCreate on the launch path after the first pass
   std::map<std::string, std::pair<double, long>> prof;   // name -> (total us, launches)
   typedef std::tuple<int, const void *, int, const void *, int, const void *, int, float, int> Key;
   std::map<Key, hipGraphExec_t> graphs;
@@ -90,7 +91,10 @@ static LaunchProbe probe(klstm_engine *e, const char *name) {
   if (!e->profile) return pr;
   ProbeRec r;
   r.name = name;
-  if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return pr;
+  if (e->event_pool.size() >= 2) {
+    r.start = e->event_pool.back(); e->event_pool.pop_back();
+    r.stop = e->event_pool.back(); e->event_pool.pop_back();
+  } else if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return pr;
   e->probes.push_back(r);
   pr.start = r.start; pr.stop = r.stop;
   return pr;
@@ -230,6 +234,7 @@ void klstm_destroy(klstm_engine *e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   drop_graphs(e);
   for (auto &r : e->probes) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+  for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
   free_planes(e);
   float *ps[] = {e->params, e->grads_own ? e->grads_own : e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3]};
   for (float *p : ps) if (p) (void)hipFree(p);
@@ -667,7 +672,7 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
       acc.first += (double)ms * 1e3;
       acc.second += 1;
     }
-    (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
+    e->event_pool.push_back(r.start); e->event_pool.push_back(r.stop);
   }
   e->probes.clear();
   auto it = e->prof.find(kernel);
