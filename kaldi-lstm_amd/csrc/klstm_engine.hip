@@ -67,6 +67,14 @@ struct klstm_engine {
   float mmt_value = 0.f;
   bool use_vector = true;
   bool use_fat = true;
+  int use_fold = -1;       // folded recurrence (W_rm = W_gifo_r W_r_m): -1 auto, 0 off, 1 on (whenever the shape allows)
+  bool fold_dirty = true;  // W_rm / its packed copies are older than the parameters
+  int pk_stale = 0;        // unfolded operand arrays (bits 1..3) not refreshed by the last Update because the folded path is in use
+  bool fwd_folded = false; // the last propagate ran the folded chain (its backpropagate follows suit)
+  float *wrm = nullptr, *wrmT = nullptr, *pk_fold[2] = {nullptr, nullptr};
+  float *Pm = nullptr;     // out_diff * W_r_m for all frames [(T_alloc) S x C]
+  float *ws = nullptr;     // split-K workspace of the batched d_r / in_diff products
+  size_t ws_floats = 0;
   bool use_bf16 = false;   // bf16 operands in the step kernels (option "bf16"); masters/planes/gradients stay fp32
   int fuse_x = -1;    // -1 auto (small NumStream), 0 batched x-projection GEMM, 1 fused into the step kernel
   bool profile = false;
@@ -101,7 +109,7 @@ static LaunchProbe probe(klstm_engine *e, const char *name) {
 }
 
 static void free_planes(klstm_engine *e) {
-  float **ps[] = {&e->gifo, &e->cc, &e->hh, &e->mm, &e->rr, &e->dgifo, &e->dc, &e->dr, &e->dr_part, &e->dx_part};
+  float **ps[] = {&e->gifo, &e->cc, &e->hh, &e->mm, &e->rr, &e->dgifo, &e->dc, &e->dr, &e->dr_part, &e->dx_part, &e->Pm, &e->ws};
   for (float **p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
 }
 static void drop_graphs(klstm_engine *e) {
@@ -127,6 +135,18 @@ static klstm_status ensure_planes(klstm_engine *e, int T) {
   HIPCHK(hipMalloc(&e->dr, nb * e->R * sizeof(float)));
   HIPCHK(hipMalloc(&e->dr_part, (size_t)e->ks * e->S * e->R * sizeof(float)));
   HIPCHK(hipMalloc(&e->dx_part, (size_t)e->ks * e->S * e->I * sizeof(float)));
+  {                                   // folded path: P plane and the split-K workspace of its two batched products
+    HIPCHK(hipMalloc(&e->Pm, (size_t)T * e->S * e->C * sizeof(float)));
+    int kl = 0;
+    const size_t M = (size_t)T * e->S;
+    const size_t need[4] = {(size_t)gemm_splitk_plan((int)M, e->R, 4 * e->C, &kl) * M * e->R,      // d_r
+                            (size_t)gemm_splitk_plan((int)M, e->I, 4 * e->C, &kl) * M * e->I,      // in_diff
+                            (size_t)gemm_splitk_plan((int)M, e->R, e->C, &kl) * M * e->R,          // r
+                            (size_t)gemm_splitk_plan((int)M, e->C, e->R, &kl) * M * e->C};         // P
+    e->ws_floats = 0;
+    for (size_t n : need) if (n > e->ws_floats) e->ws_floats = n;
+    HIPCHK(hipMalloc(&e->ws, e->ws_floats * sizeof(float)));
+  }
   // kSetZero semantics of the reference slabs (...streams.h:230, :352)
   HIPCHK(hipMemsetAsync(e->gifo, 0, nb * 4 * e->C * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->cc, 0, nb * e->C * sizeof(float), e->stream));
@@ -152,6 +172,40 @@ static klstm_status repack(klstm_engine *e) {
   HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream,
                               probe(e, "k_update_repack")));
   if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream, probe(e, "k_pack")));
+  e->fold_dirty = true;
+  e->pk_stale = 0;
+  return KLSTM_OK;
+}
+
+// ---- folded recurrence: policy, buffers, refresh of W_rm and its packed copies ----
+static bool fold_wanted(const klstm_engine *e, int T) {
+  if (e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || e->S > get_small_max()) return false;
+  // one fold GEMM (2*4C*C*R flop) per Update against (T-1) saved projection launches and T-1 saved d_r launches
+  return e->use_fold == 1 ? T >= 2 : T >= 12;
+}
+static klstm_status ensure_packs(klstm_engine *e) {
+  if (!e->pk_stale || !e->pk[0]) { e->pk_stale = 0; return KLSTM_OK; }
+  const Dims d{e->I, e->C, e->R, e->S, 0};
+  HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, e->pk_stale, e->use_bf16, e->stream, probe(e, "k_pack")));
+  e->pk_stale = 0;
+  return KLSTM_OK;
+}
+static klstm_status ensure_fold(klstm_engine *e) {
+  const Dims d{e->I, e->C, e->R, e->S, 0};
+  if (!e->wrm) {
+    long nf[2];
+    pack_sizes_fold(d, nf);
+    HIPCHK(hipMalloc(&e->wrm, (size_t)4 * e->C * e->C * sizeof(float)));
+    HIPCHK(hipMalloc(&e->wrmT, (size_t)4 * e->C * e->C * sizeof(float)));
+    HIPCHK(hipMalloc(&e->pk_fold[0], (size_t)nf[0] * 16));
+    HIPCHK(hipMalloc(&e->pk_fold[1], (size_t)nf[1] * 16));
+    e->fold_dirty = true;
+  }
+  if (!e->fold_dirty) return KLSTM_OK;
+  HIPCHK(launch_fold(d, e->params, e->wrm, e->wrmT, e->stream, probe(e, "k_fold")));
+  HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, e->stream, probe(e, "k_pack_fold"), e->wrm, e->wrmT,
+                     e->pk_fold));
+  e->fold_dirty = false;
   return KLSTM_OK;
 }
 
@@ -236,7 +290,8 @@ void klstm_destroy(klstm_engine *e) {
   for (auto &r : e->probes) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
   free_planes(e);
-  float *ps[] = {e->params, e->grads_own ? e->grads_own : e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3]};
+  float *ps[] = {e->params, e->grads_own ? e->grads_own : e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3],
+                 e->wrm, e->wrmT, e->pk_fold[0], e->pk_fold[1]};
   for (float *p : ps) if (p) (void)hipFree(p);
   if (e->flags_dev) (void)hipFree(e->flags_dev);
   for (float *p : e->stage) if (p) (void)hipFree(p);
@@ -348,6 +403,7 @@ static FwdPtrs fwd_ptrs(klstm_engine *e) {
   p.prev_c = e->prev_c; p.prev_r = e->prev_r;
   p.pk_gates = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[0]) : nullptr;
   p.pk_proj = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[1]) : nullptr;
+  p.pk_fold = reinterpret_cast<const float4 *>(e->pk_fold[0]);
   p.fat = e->use_fat;
   p.bf16 = e->use_bf16;
   return p;
@@ -360,6 +416,7 @@ static BwdPtrs bwd_ptrs(klstm_engine *e) {
   p.dgifo = e->dgifo; p.dc = e->dc; p.dr = e->dr; p.dr_part = e->dr_part; p.dx_part = e->dx_part; p.ks = e->ks;
   p.pk_dr = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[2]) : nullptr;
   p.pk_dm = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[3]) : nullptr;
+  p.pk_fold = reinterpret_cast<const float4 *>(e->pk_fold[1]);
   p.fat = e->use_fat;
   p.bf16 = e->use_bf16;
   return p;
@@ -375,6 +432,15 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
   if (!fx)   // x -> g,i,f,o for all frames at once + bias (...streams.h:246, :259)
     HIPCHK(launch_gemm(false, true, T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, 0.f,
                        e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias, st, probe(e, "k_gemm_xproj")));
+  if (e->fwd_folded) {
+    // step 1 closes over the CARRIED r (set by Reset / the previous minibatch, possibly under older weights): unfolded
+    // gates kernel, r(0) mirrored into time block 0; steps 2..T close over m(t-1) through W_rm; r(1..T) in one GEMM
+    HIPCHK(launch_gates_step(d, p, 1, fx, in, in_stride, st, probe(e, "k_gates_step")));
+    for (int t = 2; t <= T; t++)
+      HIPCHK(launch_gates_step(d, p, t, fx, in, in_stride, st, probe(e, "k_gates_fold"), true));
+    HIPCHK(launch_rbatch(d, p, out, out_stride, e->ws, st, probe(e, "k_gemm_rbatch"), probe(e, "k_reduce_rbatch")));
+    return KLSTM_OK;
+  }
   for (int t = 1; t <= T; t++) {
     HIPCHK(launch_gates_step(d, p, t, fx, in, in_stride, st, probe(e, "k_gates_step")));
     HIPCHK(launch_proj_step(d, p, t, out, out_stride, st, probe(e, "k_proj_step")));
@@ -387,6 +453,31 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
   const Dims d{e->I, e->C, e->R, e->S, T};
   const BwdPtrs p = bwd_ptrs(e);
   hipStream_t st = e->stream;
+  if (e->fwd_folded) {
+    const float *wx = e->params + e->o_wx(), *wr = e->params + e->o_wr(), *wm = e->params + e->o_wm();
+    const int M = T * d.S, K4 = 4 * d.C;
+    // P = out_diff W_r_m for all frames; chain of T folded steps; then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r
+    // (:391, feeds the W_r_m gradient :486) and in_diff = dgifo W_gifo_x (:457) as split-K products
+    int kl = 0;
+    int ks = gemm_splitk_plan(M, d.C, d.R, &kl);
+    if (ks > 1) HIPCHK(launch_gemm_splitk(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, e->ws, ks, kl,
+                                          st, nullptr, 0, probe(e, "k_gemm_P"), probe(e, "k_reduce_P")));
+    else HIPCHK(launch_gemm(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
+    for (int t = T; t >= 1; t--) HIPCHK(launch_dmf_step(d, p, t, e->Pm, st, probe(e, "k_dmf_step")));
+    ks = gemm_splitk_plan(M, d.R, K4, &kl);
+    HIPCHK(launch_gemm_splitk(false, false, M, d.R, K4, e->dgifo + (size_t)2 * d.S * K4, K4, wr, d.R, 0.f,
+                              e->dr + (size_t)d.S * d.R, d.R, nullptr, e->ws, ks, kl, st, out_diff, od_stride,
+                              probe(e, "k_gemm_dr"), probe(e, "k_reduce_dr")));
+    if (in_diff) {
+      ks = gemm_splitk_plan(M, d.I, K4, &kl);
+      HIPCHK(launch_gemm_splitk(false, false, M, d.I, K4, e->dgifo + (size_t)d.S * K4, K4, wx, d.I, 0.f, in_diff, id_stride,
+                                nullptr, e->ws, ks, kl, st, nullptr, 0, probe(e, "k_gemm_dx"), probe(e, "k_reduce_dx")));
+    }
+    const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
+    HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, defer ? 0.f : mmt, defer ? e->grads : e->corr, st,
+                        probe(e, "k_grads")));
+    return KLSTM_OK;
+  }
   for (int t = T; t >= 1; t--) {
     if (t < T) HIPCHK(launch_dr_step(d, p, t, in_diff, id_stride, st, probe(e, "k_dr_step")));
     HIPCHK(launch_dm_step(d, p, t, out_diff, od_stride, in_diff, id_stride, st, probe(e, "k_dm_step")));
@@ -443,7 +534,10 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   const int T = rows / e->S;
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
-  klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, -1);
+  e->fwd_folded = fold_wanted(e, T);
+  if (e->fwd_folded && (st = ensure_fold(e)) != KLSTM_OK) return st;     // outside the graph: only after an Update
+  if (!e->fwd_folded && (st = ensure_packs(e)) != KLSTM_OK) return st;
+  klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, e->fwd_folded ? -2 : -1);
   st = run_graphed(e, key, [&]() { return seq_forward(e, in, in_stride, out, out_stride, T); });
   if (st != KLSTM_OK) return st;
   e->T_fwd = T;
@@ -473,7 +567,9 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
     return KLSTM_OK;
   }
   const int T = e->T_fwd;
-  klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum, flags);
+  if (e->fwd_folded) { klstm_status fs = ensure_fold(e); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
+  klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
+                        flags | (e->fwd_folded ? 256 : 0));
   klstm_status st = run_graphed(e, key, [&]() {
     return seq_backward(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, T, momentum, flags);
   });
@@ -565,7 +661,11 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
                               e->wxT, e->stream, probe(e, "k_update_repack")));
   // (Packing the BPTT operands on a second stream, overlapped with the next forward pass, was measured to cost
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
-  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream, probe(e, "k_pack")));
+  // while the folded chain is in use only the step-1 gates operand (array 0) is read; the others are refreshed on demand
+  const int mask = e->fwd_folded ? 1 : 15;
+  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, mask, e->use_bf16, e->stream, probe(e, "k_pack")));
+  e->pk_stale = 15 & ~mask;
+  e->fold_dirty = true;
   return KLSTM_OK;
 }
 
@@ -641,6 +741,12 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     if (value != 0 && !e->pk[0]) return fail(KLSTM_ERR_SHAPE, "bf16 mode needs I, C, R multiples of 8");
     e->use_bf16 = value != 0;
     HIPCHK(launch_pack(Dims{e->I, e->C, e->R, e->S, 0}, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream));
+    return KLSTM_OK;
+  }
+  if (!strcmp(key, "fold")) {            // -1 auto, 0 never, 1 whenever NumStream <= small_max
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    e->use_fold = value;
     return KLSTM_OK;
   }
   if (!strcmp(key, "fuse_x")) {
@@ -812,6 +918,13 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
   HIPCHK(hipSetDevice(e->device));
   const int T = e->T_fwd;
   const Dims d{e->I, e->C, e->R, e->S, T};
+  { klstm_status ps = ensure_packs(e); if (ps != KLSTM_OK) return ps; }
+  const std::string w0(what);
+  if (w0 == "gates_fold" || w0 == "dmf" || w0 == "fold" || w0 == "rbatch" || w0 == "bwd_tail") {
+    if (!e->pk[0] || e->use_bf16) return fail(KLSTM_ERR_SHAPE, "folded path not available for this engine");
+    klstm_status fs = ensure_fold(e);
+    if (fs != KLSTM_OK) return fs;
+  }
   const FwdPtrs fp = fwd_ptrs(e);
   const BwdPtrs bp = bwd_ptrs(e);
   float *scratch_out = nullptr, *xin = nullptr, *xdiff = nullptr;
@@ -825,7 +938,23 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
   auto seq = [&]() -> klstm_status {
     for (int i = 0; i < n; i++) {
       const int t = 1 + (i % T);
-      if (w == "gates") HIPCHK(launch_gates_step(d, fp, t, fx, xin, e->I, st));
+      if (w == "gates_fold") HIPCHK(launch_gates_step(d, fp, t < 2 ? 2 : t, fx, xin, e->I, st, LaunchProbe(), true));
+      else if (w == "dmf") HIPCHK(launch_dmf_step(d, bp, t < T ? t : 1, e->Pm, st));
+      else if (w == "fold") {
+        HIPCHK(launch_fold(d, e->params, e->wrm, e->wrmT, st));
+        HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, st, LaunchProbe(), e->wrm, e->wrmT, e->pk_fold));
+      }
+      else if (w == "rbatch") HIPCHK(launch_rbatch(d, fp, scratch_out, e->R, e->ws, st));
+      else if (w == "bwd_tail") {
+        int kl = 0, ks = gemm_splitk_plan(T * d.S, d.R, 4 * d.C, &kl);
+        HIPCHK(launch_gemm_splitk(false, false, T * d.S, d.R, 4 * d.C, e->dgifo + (size_t)2 * d.S * 4 * d.C, 4 * d.C,
+                                  e->params + e->o_wr(), d.R, 0.f, e->dr + (size_t)d.S * d.R, d.R, nullptr, e->ws, ks, kl, st,
+                                  scratch_out, e->R));
+        ks = gemm_splitk_plan(T * d.S, d.I, 4 * d.C, &kl);
+        HIPCHK(launch_gemm_splitk(false, false, T * d.S, d.I, 4 * d.C, e->dgifo + (size_t)d.S * 4 * d.C, 4 * d.C,
+                                  e->params + e->o_wx(), d.I, 0.f, xdiff, e->I, nullptr, e->ws, ks, kl, st));
+      }
+      else if (w == "gates") HIPCHK(launch_gates_step(d, fp, t, fx, xin, e->I, st));
       else if (w == "proj") HIPCHK(launch_proj_step(d, fp, t, scratch_out, e->R, st));
       else if (w == "gates+proj") { if (i & 1) HIPCHK(launch_proj_step(d, fp, t, scratch_out, e->R, st)); else HIPCHK(launch_gates_step(d, fp, t, fx, xin, e->I, st)); }
       else if (w == "dr") HIPCHK(launch_dr_step(d, bp, t < T ? t : 1, xdiff, e->I, st));

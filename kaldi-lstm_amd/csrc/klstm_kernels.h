@@ -17,6 +17,7 @@ struct FwdPtrs {
   float *gifo, *cc, *hh, *mm, *rr;
   float *prev_c, *prev_r;                            // carried state [S x C], [S x R]
   const float4 *pk_gates, *pk_proj;                  // packed (MFMA-operand-ordered) weight copies, or null
+  const float4 *pk_fold;                             // packed [W_rm | W_x] of the folded recurrence, or null
   bool fat;                                          // allow the 64-row x 32-stream kernels when S > 16
   bool bf16;                                         // pk_* hold bf16 operands; activations are rounded to bf16 when staged
 };
@@ -30,6 +31,7 @@ struct BwdPtrs {
   float *dx_part;                                    // split-K slabs [KS][S][I] (in_diff of one frame)
   int ks;                                            // number of slabs
   const float4 *pk_dr, *pk_dm;                       // packed weight copies, or null
+  const float4 *pk_fold;                             // packed W_rm^T (4-row geometry) of the folded recurrence, or null
   bool fat;
   bool bf16;
 };
@@ -42,7 +44,18 @@ struct LaunchProbe { hipEvent_t start = nullptr, stop = nullptr; };
 // The state bridge (:231, :331) is folded in: t==1 reads prev_c/prev_r and mirrors them into
 // time block 0, t==T writes c back to prev_c.
 hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, bool fuse_x, const float *in,
-                             int in_stride, hipStream_t st, LaunchProbe pr = {});
+                             int in_stride, hipStream_t st, LaunchProbe pr = {}, bool fold = false);
+
+// Folded recurrence (NumStream <= small_max; see the FOLDED RECURRENCE section of klstm_kernels.hip):
+//   launch_fold     W_rm = W_gifo_r * W_r_m (natural + transposed), once per Update
+//   launch_gates_step(..., fold = true)   a(t) = W_x x(t) + b + W_rm m(t-1), t >= 2
+//   launch_rbatch   r(1..T) = m(1..T) W_r_m^T -> rr rows, out rows, prev_r
+//   launch_dmf_step d_m(t) = P(t) + dgifo(t+1) W_rm with P = out_diff W_r_m, then the elementwise BPTT (:411-440)
+hipError_t launch_fold(const Dims &d, const float *param_blob, float *wrm, float *wrmT, hipStream_t st, LaunchProbe pr = {});
+hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_stride, float *ws, hipStream_t st,
+                         LaunchProbe pr = {}, LaunchProbe pr2 = {});   // ws: split-K workspace (gemm_splitk_plan(T*S, R, C) slices)
+hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *P, hipStream_t st, LaunchProbe pr = {});
+void pack_sizes_fold(const Dims &d, long n4[2]);   // float4 counts of the two folded operands
 // r(t) = m(t) W_r_m^T (:312) -> rr, out rows (:328); t==T also prev_r (:331)
 hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, int out_stride,
                             hipStream_t st, LaunchProbe pr = {});
@@ -68,7 +81,9 @@ hipError_t launch_gemm(bool transA, bool transB, int M, int N, int K, const floa
 int gemm_splitk_plan(int M, int N, int K, int *klen);
 hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, const float *A, int lda, const float *B,
                               int ldb, float beta, float *Cm, int ldc, const float *bias, float *ws, int ks, int klen,
-                              hipStream_t st);
+                              hipStream_t st, const float *add = nullptr, int add_ld = 0, LaunchProbe pr = {},
+                              LaunchProbe pr2 = {}, float *C2 = nullptr, int ldc2 = 0, float *C3 = nullptr, int tail0 = 0);
+                              // add: C = beta*C + add + sum of slices;  C2 / C3: mirrors of the result (second copy; rows >= tail0)
 
 // All seven gradient accumulations (...streams.h:468-487) in ONE launch: three A^T*B products
 // (w_gifo_x, w_gifo_r, w_r_m) plus the bias / peephole column sums.  dst = beta*dst + grad, dst is a
@@ -92,7 +107,8 @@ void pack_sizes(const Dims &d, long n4[4]);         // float4 counts
 // mask: bit i selects array i (forward operands = 3, BPTT operands = 12);  bf16: pack as bf16 (same tile/chunk/lane
 // order, one 16-byte vector of 8 bf16 per lane and chunk -> half the bytes of the fp32 copies)
 hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
-                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr = {});
+                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr = {}, const float *wrm = nullptr,
+                       const float *wrmT = nullptr, float *pk_fold[2] = nullptr);   // mask bits 4, 5: folded operands
 
 // out[dst] = in[clamp(dst + shift)] row gather (TimeShift; shift 0 = Transmit copy)
 hipError_t launch_time_shift(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, int shift,
@@ -107,6 +123,7 @@ hipError_t launch_axpy(float *y, const float *x, float a, long n, hipStream_t st
 
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {});
 
+int get_small_max();
 void set_small_max(int s);        // tuning knob: largest NumStream that uses the 4x4x1_16b geometry
 int dr_split_k(const Dims &d);   // number of split-K slabs launch_dr_step writes
 

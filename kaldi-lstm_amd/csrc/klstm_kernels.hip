@@ -1239,6 +1239,151 @@ __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
   }
 }
 
+// =============================================================================================
+// FOLDED RECURRENCE (NumStream <= small_max, engine option "fold").  At 4-12 streams a step is pure latency:
+// two dependent kernels per direction (gates needs all of r, the projection all of m), ~4 us each, MFMA idle.
+// With  W_rm = W_gifo_r * W_r_m  [4C x C]  (recomputed after every Update) the recurrence closes over m alone:
+//     forward   a(t)   = W_x x(t) + b + W_rm m(t-1)                          (t >= 2; t = 1 uses the carried r, :275)
+//     backward  d_m(t) = out_diff(t) W_r_m + dgifo(t+1) W_rm                 (:391 substituted into :408)
+// ONE kernel per step and direction; r(1..T) (:312), d_r(1..T) (:391) and in_diff (:457) become batched GEMMs
+// outside the chain.  Same algebra as the reference up to fp32 summation order (the parity tests run both paths).
+// The forward step is k_gates_v itself with B = m(t-1) and the packed [W_rm | W_x]; the backward step needs a
+// contraction over K = 4C for only C rows, i.e. 4-row tiles to fill the chip:
+//   4-row geometry of the 4x4x1_16b MFMA: block b = k-group (16 of them), A lane 4b+i = row i, B lane 4b+j = stream j,
+//   chunk = 16 k-groups x 8 = 128 k;  packed weights pk[tile4][chunk][h][lane][4]: row = 4*tile + (lane&3),
+//   k = 128*chunk + 64h + 4*(lane>>2) + e.
+// =============================================================================================
+constexpr int KCH4 = 128;
+
+// acc += A(4 rows, chunks [0,nch)) * B(4 streams, same chunks).  Chunk c is dealt to wave c % NW.  No LDS: a lane's
+// B operand (stream j = lane&3, k-group b = lane>>2) is 8 consecutive floats of that stream's row, so a wave-load of one
+// chunk is 4 x 256 contiguous bytes per load instruction -- coalesced as it stands (the lane's 8 k-values are the float4
+// at 4*(lane>>2) of each 64-float half of the chunk; the packed weights use the same k order).  brow: row pointer of
+// the lane's stream (clamped), bok: stream exists.
+template <int CPW>
+__device__ __forceinline__ void vec_contract_r4(const float4 *__restrict__ apk, int nch, int K, const float *__restrict__ brow,
+                                                bool bok, int lane, int wave, f32x4 (&acc)[2]) {
+  const int kg = lane >> 2;
+  for (int base = 0; base < nch; base += CPW * NW) {
+    float4 a0[CPW], a1[CPW], b0[CPW], b1[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+      const int ch = base + c * NW + wave;
+      const int cl = min(ch, nch - 1);                             // clamped: always a valid chunk, unused if off
+      const float4 *ap = apk + (size_t)cl * 128 + lane;
+      a0[c] = ap[0]; a1[c] = ap[64];
+      const int k = cl * KCH4 + kg * 4;                            // h = 0: floats [0,64) of the chunk, h = 1: [64,128)
+      b0[c] = ldg4(brow + min(k, K - 4)); b1[c] = ldg4(brow + min(k + 64, K - 4));
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+      const int ch = base + c * NW + wave;
+      const bool on0 = ch < nch && bok && ch * KCH4 + kg * 4 < K, on1 = ch < nch && bok && ch * KCH4 + 64 + kg * 4 < K;
+      const float av[8] = {a0[c].x, a0[c].y, a0[c].z, a0[c].w, a1[c].x, a1[c].y, a1[c].z, a1[c].w};
+      const float bv[8] = {on0 ? b0[c].x : 0.f, on0 ? b0[c].y : 0.f, on0 ? b0[c].z : 0.f, on0 ? b0[c].w : 0.f,
+                           on1 ? b1[c].x : 0.f, on1 ? b1[c].y : 0.f, on1 ? b1[c].z : 0.f, on1 ? b1[c].w : 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 1], 0, 0, 0);
+    }
+  }
+}
+
+struct DmfArgs {
+  int C, S, T, t;
+  const float *pi, *pf, *po;
+  const float *gifo, *cc, *hh;
+  float *dgifo, *dc;
+  const float *P;          // out_diff * W_r_m for all frames [T*S x C]
+  const float4 *wpk;       // packed W_rm^T, 4-row geometry: [C/4 tiles][nch_total chunks][2][64]
+  int nch_total;           // chunks of 128 over 4C
+  int nch;                 // chunks to contract: nch_total, or 0 at t == T (dgifo(T+1) = 0, :351)
+};
+
+template <int CPW>
+__global__ __launch_bounds__(NW * 64) void k_dmf_v(DmfArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __shared__ f32x4 red[NW][4];
+  const int C = a.C, S = a.S, t = a.t, K = 4 * a.C;
+  const int c0 = blockIdx.x * 4;
+  const int sbase = blockIdx.y * 4;
+  const bool last = (t == a.T);
+
+  // ---- epilogue operands first: lanes 0..3 of wave 0 = streams sbase..sbase+3, cells c0..c0+3 each ----
+  const int e_s = sbase + lane;
+  const bool e_on = wave == 0 && lane < 4 && e_s < S;
+  const size_t row = (size_t)t * S + (e_on ? e_s : 0), rown = row + S, rowp = row - S;
+  float yg[4], yi[4], yf[4], yo[4], yh[4], cpv[4], dcn[4], fn[4], din[4], dfn[4], wpi[4], wpf[4], wpo[4], pv[4];
+  {
+    const float *yp = a.gifo + row * 4 * C;
+    load4<true>(yp, c0, C, e_on, yg);
+    load4<true>(yp + C, c0, C, e_on, yi);
+    load4<true>(yp + 2 * C, c0, C, e_on, yf);
+    load4<true>(yp + 3 * C, c0, C, e_on, yo);
+    load4<true>(a.hh + row * C, c0, C, e_on, yh);
+    load4<true>(a.cc + rowp * C, c0, C, e_on, cpv);
+    const bool n_on = e_on && !last;
+    const size_t rn = last ? row : rown;                 // clamped: block T+1 is never dereferenced
+    load4<true>(a.dc + rn * C, c0, C, n_on, dcn);
+    load4<true>(a.gifo + rn * 4 * C + 2 * C, c0, C, n_on, fn);
+    load4<true>(a.dgifo + rn * 4 * C + C, c0, C, n_on, din);
+    load4<true>(a.dgifo + rn * 4 * C + 2 * C, c0, C, n_on, dfn);
+    load4<true>(a.pi, c0, C, e_on, wpi);
+    load4<true>(a.pf, c0, C, e_on, wpf);
+    load4<true>(a.po, c0, C, e_on, wpo);
+    load4<true>(a.P + (row - S) * C, c0, C, e_on, pv);   // frame t is row block t-1 of P
+  }
+
+  f32x4 acc[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
+  const int bj = sbase + (lane & 3);
+  const float *brow = a.dgifo + ((size_t)(last ? t : t + 1) * S + min(bj, S - 1)) * K;
+  vec_contract_r4<CPW>(a.wpk + (size_t)blockIdx.x * a.nch_total * 128, a.nch, K, brow, bj < S, lane, wave, acc);
+
+  // the 16 k-groups of a (row, stream) pair sit in the lanes with equal lane&3: xor butterfly (a+b == b+a bitwise, so
+  // every lane ends with the same sum), then the 8 waves in fixed order
+  f32x4 v = acc[0] + acc[1];
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1) {
+    v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
+  }
+  if (lane < 4) red[wave][lane] = v;
+  __syncthreads();
+
+  if (e_on) {
+    f32x4 s = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < NW; w++) s += red[w][lane];
+    const float dm[4] = {s.x + pv[0], s.y + pv[1], s.z + pv[2], s.w + pv[3]};      // :408 with :391 substituted
+    float og[4], oi[4], of[4], oo[4], oc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float d_h = k_diff_tanh(dm[j] * yo[j], yh[j]);       // :411-412
+      const float d_o = k_diff_sigmoid(dm[j] * yh[j], yo[j]);    // :415-416
+      float d_c = d_h;                                           // :424
+      d_c = d_c + dcn[j] * fn[j];                                // :425
+      d_c = d_c + wpi[j] * din[j];                               // :426
+      d_c = d_c + wpf[j] * dfn[j];                               // :427
+      d_c = d_c + wpo[j] * d_o;                                  // :428
+      of[j] = k_diff_sigmoid(d_c * cpv[j], yf[j]);               // :431-432
+      oi[j] = k_diff_sigmoid(d_c * yg[j], yi[j]);                // :435-436
+      og[j] = k_diff_tanh(d_c * yi[j], yg[j]);                   // :439-440
+      oo[j] = d_o;
+      oc[j] = d_c;
+    }
+    float *dp = a.dgifo + row * 4 * C;
+    store4<true>(dp, c0, C, og);
+    store4<true>(dp + C, c0, C, oi);
+    store4<true>(dp + 2 * C, c0, C, of);
+    store4<true>(dp + 3 * C, c0, C, oo);
+    store4<true>(a.dc + row * C, c0, C, oc);
+    if (last) {     // the batched d_r product reads dgifo(T+1) as rows of its operand: keep that block zero (:351) even
+      const float z[4] = {0.f, 0.f, 0.f, 0.f};              // after a longer minibatch has used it
+      float *zp = a.dgifo + rown * 4 * C;
+      store4<true>(zp, c0, C, z); store4<true>(zp + C, c0, C, z); store4<true>(zp + 2 * C, c0, C, z); store4<true>(zp + 3 * C, c0, C, z);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_pack: (re)build the four packed weight copies from the natural blob + its transposes.
 // One thread per packed float4 (destination-contiguous, so the writes are coalesced 1 KB/wave).
@@ -1250,28 +1395,38 @@ __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
 struct PackArgs {
   int C, R, I;
   const float *wx, *wr, *wm, *wrT, *wmT, *wxT;
-  float4 *pk[4];
-  long n4[4];          // 16-byte vector count of each array (0: array not selected in this launch)
-  int nch[4];          // chunks per tile
+  const float *wrm, *wrmT;   // folded product W_gifo_r * W_r_m [4C x C] and its transpose [C x 4C] (arrays 4, 5)
+  float4 *pk[6];
+  long n4[6];          // 16-byte vector count of each array (0: array not selected in this launch)
+  int nch[6];          // chunks per tile
   int bf16;            // 1: entries are 8 bf16 (RNE of the fp32 master) covering k..k+7 -> half as many vectors
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
   const int C = a.C, R = a.R, I = a.I;
-  const long total = a.n4[0] + a.n4[1] + a.n4[2] + a.n4[3];
+  const long total = a.n4[0] + a.n4[1] + a.n4[2] + a.n4[3] + a.n4[4] + a.n4[5];
   for (long gid = blockIdx.x * 256L + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
     int arr = 0; long id = gid;
-    while (id >= a.n4[arr]) { id -= a.n4[arr]; arr++; }
+    while (id >= a.n4[arr]) { id -= a.n4[arr]; arr++; }   // gid < total, so arr stays < 6
     const int lane = (int)(id & 63), h = a.bf16 ? 0 : (int)((id >> 6) & 1);
     const long tc = a.bf16 ? id >> 6 : id >> 7;
     const int nch = a.nch[arr];
     const int tile = (int)(tc / nch), ch = (int)(tc - (long)tile * nch);
     const int i = lane & 15;
-    const int k = ch * KCH + (lane >> 4) * 8 + h * 4;
+    const int k = arr == 5 ? ch * KCH4 + h * 64 + (lane >> 2) * 4 : ch * KCH + (lane >> 4) * 8 + h * 4;
     const float *src = nullptr;
     int klim = 0, koff = k;
     bool row_ok = false;
-    if (arr == 0) {
+    if (arr == 4) {           // folded gates: rows as array 0, k over [C | pad | I | pad] from W_rm and W_x
+      const int cell = tile * 4 + (i >> 2), gate = i & 3;
+      row_ok = cell < C;
+      const int nchM = (C + KCH - 1) / KCH;
+      if (ch < nchM) { src = a.wrm + ((size_t)gate * C + (row_ok ? cell : 0)) * C; klim = C; }
+      else { src = a.wx + ((size_t)gate * C + (row_ok ? cell : 0)) * I; klim = I; koff = k - nchM * KCH; }
+    } else if (arr == 5) {    // folded d_m: 4-row geometry, rows = cells of W_rm^T [C x 4C], k over 4C
+      const int c = tile * 4 + (lane & 3);
+      row_ok = c < C; src = a.wrmT + (size_t)(row_ok ? c : 0) * 4 * C; klim = 4 * C;
+    } else if (arr == 0) {
       const int cell = tile * 4 + (i >> 2), gate = i & 3;
       row_ok = cell < C;
       const int nchR = (R + KCH - 1) / KCH;
@@ -1313,6 +1468,10 @@ struct GemmJob {
   float *Cm; int ldc;
   const float *bias;
   int vecA, vecB;
+  // optional extra destinations of the same result (all null by default):
+  float *Ct; int ldct;    // transposed copy  Ct[n][m]  (M % 4 == 0)
+  float *C2; int ldc2;    // second copy      C2[m][n]
+  float *C3; int tail0;   // rows m >= tail0 also to C3[m - tail0][n], dense (ld = N)
 };
 
 // One operand tile = GT x GK elements = 2 x (8 floats per thread).  Operand stored [X x K] (TA=false: 8 consecutive k
@@ -1334,26 +1493,27 @@ __device__ __forceinline__ void fetch_tile(const float *__restrict__ P, int ld, 
     }
   }
 }
+// LDS layout of an operand tile follows its storage so that the stash is two 16-byte stores either way:
+//   TA (stored [K x X]):  Ls[k*GLD + x]   (GLD = 80: the four k-groups of an MFMA read land on disjoint banks)
+//   !TA (stored [X x K]): Ls[x*GLX + k]   (GLX = 68: row x shifts the bank by 4, again disjoint for 16 rows x 4 k-groups)
+constexpr int GLX = 68;
+constexpr int GLDS = GK * GLD;               // floats per operand buffer (>= GT * GLX)
 template <bool TA>
-__device__ __forceinline__ void stash_tile(float (*Ls)[GLD], int tid, const float (&r)[2][8]) {
+__device__ __forceinline__ void stash_tile(float *Ls, int tid, const float (&r)[2][8]) {
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    if (!TA) {
-      const int x = tid >> 2, k = h * 32 + (tid & 3) * 8;
-#pragma unroll
-      for (int j = 0; j < 8; j++) Ls[k + j][x] = r[h][j];
-    } else {
-      const int k = h * 32 + (tid >> 3), x = (tid & 7) * 8;
-      *reinterpret_cast<float4 *>(&Ls[k][x]) = make_float4(r[h][0], r[h][1], r[h][2], r[h][3]);
-      *reinterpret_cast<float4 *>(&Ls[k][x + 4]) = make_float4(r[h][4], r[h][5], r[h][6], r[h][7]);
-    }
+    float *dst = TA ? Ls + (h * 32 + (tid >> 3)) * GLD + (tid & 7) * 8 : Ls + (tid >> 2) * GLX + h * 32 + (tid & 3) * 8;
+    *reinterpret_cast<float4 *>(dst) = make_float4(r[h][0], r[h][1], r[h][2], r[h][3]);
+    *reinterpret_cast<float4 *>(dst + 4) = make_float4(r[h][4], r[h][5], r[h][6], r[h][7]);
   }
 }
+template <bool TA>
+__device__ __forceinline__ float lds_operand(const float *Ls, int k, int x) { return TA ? Ls[k * GLD + x] : Ls[x * GLX + k]; }
 
 // 64x64 output tile, 4 waves (2x2) of 32x32, K tile 64.  The next K tile is fetched into registers while the
 // current one is multiplied out of LDS (global latency hides under 16 k-steps x 4 MFMAs per wave).
 template <bool TA, bool TB>
-__device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, float (*As)[GLD], float (*Bs)[GLD]) {
+__device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, float *As, float *Bs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kg = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
@@ -1396,8 +1556,8 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
     // ds_read -> MFMA loop); only the last, short tile takes the rolled path and skips its all-zero tail steps
     auto kstep = [&](int kk) {
       const int k = kk * 4 + kg;
-      const float a0 = As[k][wr * 32 + i16], a1 = As[k][wr * 32 + 16 + i16];
-      const float b0 = Bs[k][wc * 32 + i16], b1 = Bs[k][wc * 32 + 16 + i16];
+      const float a0 = lds_operand<TA>(As, k, wr * 32 + i16), a1 = lds_operand<TA>(As, k, wr * 32 + 16 + i16);
+      const float b0 = lds_operand<!TB>(Bs, k, wc * 32 + i16), b1 = lds_operand<!TB>(Bs, k, wc * 32 + 16 + i16);
       acc[0][0] = MFMA16(a0, b0, acc[0][0]);
       acc[0][1] = MFMA16(a0, b1, acc[0][1]);
       acc[1][0] = MFMA16(a1, b0, acc[1][0]);
@@ -1428,14 +1588,20 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
         float val = e[r] + bv;
         if (g.beta != 0.f) val = g.beta * cold[mi][ni][r] + val;
         *cp = val;
+        if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = val;
+        if (g.C3 && m >= g.tail0) g.C3[(size_t)(m - g.tail0) * g.N + n] = val;
+      }
+      if (g.Ct) {               // beta == 0 and no bias on this path (launch_fold)
+        const int m = m0 + wr * 32 + mi * 16 + 4 * kg;
+        if (m + 4 <= g.M) *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(e[0], e[1], e[2], e[3]);
       }
     }
 }
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm(GemmJob g) {
-  __shared__ float As[GK][GLD];
-  __shared__ float Bs[GK][GLD];
+  __shared__ __attribute__((aligned(16))) float As[GLDS];
+  __shared__ __attribute__((aligned(16))) float Bs[GLDS];
   gemm_tile<TA, TB>(g, blockIdx.y * GT, blockIdx.x * GT, As, Bs);
 }
 
@@ -1444,8 +1610,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmJob g) {
 // ws[z][M][N]; k_splitk_reduce sums the slices in fixed order (deterministic, no atomics).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm_splitk(GemmJob g, int klen, float *ws) {
-  __shared__ float As[GK][GLD];
-  __shared__ float Bs[GK][GLD];
+  __shared__ __attribute__((aligned(16))) float As[GLDS];
+  __shared__ __attribute__((aligned(16))) float Bs[GLDS];
   const int k0 = blockIdx.z * klen;
   GemmJob s = g;
   s.K = min(g.K - k0, klen);
@@ -1457,16 +1623,33 @@ __global__ __launch_bounds__(256) void k_gemm_splitk(GemmJob g, int klen, float 
   s.Cm = ws + (size_t)blockIdx.z * g.M * g.N; s.ldc = g.N;
   gemm_tile<TA, TB>(s, blockIdx.y * GT, blockIdx.x * GT, As, Bs);
 }
-__global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__ ws, int ks, int M, int N, float beta,
-                                                       float *__restrict__ Cm, int ldc, const float *__restrict__ bias) {
-  const long total = (long)M * N;
+struct ReduceArgs {
+  const float *ws; int ks, M, N;
+  float beta; float *Cm; int ldc;
+  const float *bias;
+  const float *add; int add_ld;       // C = beta*C + add + bias + sum of slices
+  float *C2; int ldc2;                // mirrors, as in GemmJob
+  float *C3; int tail0;
+};
+__global__ __launch_bounds__(256) void k_splitk_reduce(ReduceArgs a) {
+  const long total = (long)a.M * a.N;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int m = (int)(i / N), n = (int)(i - (long)m * N);
-    float v = ws[i];
-    for (int z = 1; z < ks; z++) v += ws[(size_t)z * total + i];
-    if (bias) v += bias[n];
-    float *cp = Cm + (size_t)m * ldc + n;
-    *cp = beta != 0.f ? beta * *cp + v : v;
+    const int m = (int)(i / a.N), n = (int)(i - (long)m * a.N);
+    float v = 0.f;
+    for (int z0 = 0; z0 < a.ks; z0 += 8) {           // 8 independent loads in flight, summed in slice order
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) t[j] = a.ws[(size_t)min(z0 + j, a.ks - 1) * total + i];
+#pragma unroll
+      for (int j = 0; j < 8; j++) v += (z0 + j < a.ks) ? t[j] : 0.f;
+    }
+    if (a.bias) v += a.bias[n];
+    if (a.add) v = a.add[(size_t)m * a.add_ld + n] + v;
+    float *cp = a.Cm + (size_t)m * a.ldc + n;
+    if (a.beta != 0.f) v = a.beta * *cp + v;
+    *cp = v;
+    if (a.C2) a.C2[(size_t)m * a.ldc2 + n] = v;
+    if (a.C3 && m >= a.tail0) a.C3[(size_t)(m - a.tail0) * a.N + n] = v;
   }
 }
 
@@ -1487,8 +1670,8 @@ struct GradsArgs {
 };
 
 __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
-  __shared__ float As[GK][GLD];
-  __shared__ float Bs[GK][GLD];
+  __shared__ __attribute__((aligned(16))) float As[GLDS];
+  __shared__ __attribute__((aligned(16))) float Bs[GLDS];
   // XCD-aware order: workgroup w lands on XCD w % 8 (observed dispatch rule, speed only); XCD x gets the contiguous
   // m-major tile range [x*cpx, (x+1)*cpx), so its private L2 holds a few A row panels and the B column panels
   // instead of streaming every A panel once per XCD.
@@ -1518,8 +1701,8 @@ __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
       if (gate != 0) sp += dv * cbase[(size_t)r * C];
     }
   }
-  float(*rb)[64] = reinterpret_cast<float(*)[64]>(&As[0][0]);
-  float(*rp)[64] = reinterpret_cast<float(*)[64]>(&Bs[0][0]);
+  float(*rb)[64] = reinterpret_cast<float(*)[64]>(&As[0]);
+  float(*rp)[64] = reinterpret_cast<float(*)[64]>(&Bs[0]);
   rb[ty][tx] = sb; rp[ty][tx] = sp;
   __syncthreads();
   if (ty == 0 && col < 4 * C) {
@@ -1740,23 +1923,29 @@ static inline dim3 vec_grid(int ntiles, int S, const VecCfg &c, int z = 1) {
   return dim3(ntiles, cdiv(S, (c.small ? 4 : 16) * c.nt), z);
 }
 
-hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, bool fuse_x, const float *in,
-                             int in_stride, hipStream_t st, LaunchProbe pr) {
+hipError_t launch_gates_step(const Dims &d0, const FwdPtrs &p, int t, bool fuse_x, const float *in,
+                             int in_stride, hipStream_t st, LaunchProbe pr, bool fold) {
+  // fold (t >= 2, S <= small_max): the recurrent operand is m(t-1) and the packed weights are [W_rm | W_x]; the kernel
+  // is the same with R := C
+  Dims d = d0;
+  if (fold) d.R = d0.C;
   GatesArgs a;
   a.C = d.C; a.R = d.R; a.S = d.S; a.I = d.I; a.t = t;
   a.wr = p.wr; a.wx = p.wx; a.bias = p.bias; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm;
   a.cprev = t == 1 ? p.prev_c : p.cc + (size_t)(t - 1) * d.S * d.C;
-  a.rprev = t == 1 ? p.prev_r : p.rr + (size_t)(t - 1) * d.S * d.R;
+  a.rprev = fold ? p.mm + (size_t)(t - 1) * d.S * d.C : t == 1 ? p.prev_r : p.rr + (size_t)(t - 1) * d.S * d.R;
   a.x = fuse_x ? in + (size_t)(t - 1) * d.S * in_stride : nullptr;
   a.x_stride = in_stride;
   a.c_mirror = t == 1 ? p.cc : nullptr;
-  a.r_mirror = t == 1 ? p.rr : nullptr;
+  a.r_mirror = (t == 1 && !fold) ? p.rr : nullptr;
   a.c_save = t == d.T ? p.prev_c : nullptr;
-  const bool vec = p.pk_gates != nullptr && aligned16(p.rr) && aligned16(p.prev_r) &&
+  const float4 *wpk = fold ? p.pk_fold : p.pk_gates;
+  const bool vec = wpk != nullptr && aligned16(p.rr) && aligned16(p.prev_r) && aligned16(p.mm) &&
                    (!fuse_x || (aligned16(in) && in_stride % 4 == 0));
+  if (fold && !vec) return hipErrorInvalidValue;      // the engine only folds on the vector path
   if (vec) {
-    GatesVArgs va; va.g = a; va.wpk = p.pk_gates;
+    GatesVArgs va; va.g = a; va.wpk = wpk;
     va.nch_total = cdiv(d.R, KCH) + cdiv(d.I, KCH);
     if (p.fat && d.S > 16) {                                 // 4 row tiles (16 cells) x 2 K splits per workgroup
       va.gx = cdiv(d.C, 16);
@@ -1818,6 +2007,7 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
 }
 
 void set_small_max(int s) { g_small_max = s; }
+int get_small_max() { return g_small_max; }
 
 int dr_split_k(const Dims &d) {
   // enough (R/16 x KS) workgroups to spread the 4C-long contraction over the chip at small S
@@ -1899,7 +2089,54 @@ hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *o
   GEN_DISPATCH(k_dm_step, nt, grid, st, pr, a, );
 }
 
+static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const float *A, int lda, const float *B,
+                        int ldb, float beta, float *Cm, int ldc, const float *bias);
+
+hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *P, hipStream_t st, LaunchProbe pr) {
+  DmfArgs a;
+  a.C = d.C; a.S = d.S; a.T = d.T; a.t = t;
+  a.pi = p.pi; a.pf = p.pf; a.po = p.po; a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh;
+  a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.wpk = p.pk_fold;
+  a.nch_total = cdiv(4 * d.C, KCH4);
+  a.nch = t == d.T ? 0 : a.nch_total;
+  const dim3 grid(cdiv(d.C, 4), cdiv(d.S, 4)), blk(NW * 64);
+  const int need = cdiv(a.nch_total, NW);
+  if (need <= 1) KLAUNCH((k_dmf_v<1>), grid, blk, st, pr, a);
+  if (need == 2) KLAUNCH((k_dmf_v<2>), grid, blk, st, pr, a);
+  KLAUNCH((k_dmf_v<4>), grid, blk, st, pr, a);
+}
+
+// W_rm = W_gifo_r [4C x R] * W_r_m [R x C], natural [4C x C] and transposed [C x 4C], once per Update
+hipError_t launch_fold(const Dims &d, const float *param_blob, float *wrm, float *wrmT, hipStream_t st, LaunchProbe pr) {
+  const long o_wr = (long)4 * d.C * d.I, o_wm = o_wr + (long)4 * d.C * d.R + 7 * d.C;
+  GemmJob g = make_job(false, false, 4 * d.C, d.C, d.R, param_blob + o_wr, d.R, param_blob + o_wm, d.C, 0.f, wrm, d.C, nullptr);
+  g.Ct = wrmT; g.ldct = 4 * d.C;
+  const dim3 grid(cdiv(d.C, GT), cdiv(4 * d.C, GT)), block(256);
+  KLAUNCH((k_gemm<false, false>), grid, block, st, pr, g);
+}
+
+// r(1..T) = m(1..T) W_r_m^T (:312) for all frames at once -> rr rows, out rows (:328), last block -> prev_r (:331)
+hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_stride, float *ws, hipStream_t st,
+                         LaunchProbe pr, LaunchProbe pr2) {
+  const int M = d.T * d.S;
+  int kl = 0;
+  const int ks = gemm_splitk_plan(M, d.R, d.C, &kl);
+  if (ks > 1 && ws)
+    return launch_gemm_splitk(false, true, M, d.R, d.C, p.mm + (size_t)d.S * d.C, d.C, p.wm, d.C, 0.f, p.rr + (size_t)d.S * d.R,
+                              d.R, nullptr, ws, ks, kl, st, nullptr, 0, pr, pr2, out, out_stride, p.prev_r, M - d.S);
+  GemmJob g = make_job(false, true, M, d.R, d.C, p.mm + (size_t)d.S * d.C, d.C, p.wm, d.C, 0.f,
+                       p.rr + (size_t)d.S * d.R, d.R, nullptr);
+  g.C2 = out; g.ldc2 = out_stride;
+  g.C3 = p.prev_r; g.tail0 = M - d.S;
+  const dim3 grid(cdiv(d.R, GT), cdiv(M, GT)), block(256);
+  KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
+}
+
 bool pack_supported(const Dims &d) { return d.R % 8 == 0 && d.I % 8 == 0 && d.C % 8 == 0; }
+void pack_sizes_fold(const Dims &d, long n4[2]) {
+  n4[0] = (long)cdiv(d.C, 16) * 4 * (cdiv(d.C, KCH) + cdiv(d.I, KCH)) * 128;
+  n4[1] = (long)cdiv(d.C, 4) * cdiv(4 * d.C, KCH4) * 128;
+}
 void pack_sizes(const Dims &d, long n4[4]) {
   // gates tiles are 4 cells each; a fat workgroup walks 4 of them, so round up to 16 cells (zero rows)
   n4[0] = (long)cdiv(d.C, 16) * 4 * (cdiv(d.R, KCH) + cdiv(d.I, KCH)) * 128;
@@ -1908,9 +2145,18 @@ void pack_sizes(const Dims &d, long n4[4]) {
   n4[3] = (long)cdiv(d.C, 16) * cdiv(d.R, KCH) * 128;
 }
 hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
-                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr) {
+                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr, const float *wrm,
+                       const float *wrmT, float *pk_fold[2]) {
   PackArgs a;
   a.bf16 = bf16 ? 1 : 0;
+  a.wrm = wrm; a.wrmT = wrmT;
+  a.n4[4] = a.n4[5] = 0; a.pk[4] = a.pk[5] = nullptr;
+  a.nch[4] = cdiv(d.C, KCH) + cdiv(d.I, KCH); a.nch[5] = cdiv(4 * d.C, KCH4);
+  if (pk_fold && !bf16) {                      // mask bits 4, 5: the two folded operands (fp32 only)
+    long nf[2];
+    pack_sizes_fold(d, nf);
+    for (int i = 0; i < 2; i++) if (mask & (16 << i)) { a.n4[4 + i] = nf[i]; a.pk[4 + i] = reinterpret_cast<float4 *>(pk_fold[i]); }
+  }
   a.C = d.C; a.R = d.R; a.I = d.I;
   const long o_wr = (long)4 * d.C * d.I, o_wm = o_wr + (long)4 * d.C * d.R + 7 * d.C;
   a.wx = param_blob; a.wr = param_blob + o_wr; a.wm = param_blob + o_wm;
@@ -1918,7 +2164,7 @@ hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT,
   pack_sizes(d, a.n4);
   for (int i = 0; i < 4; i++) { if (!(mask & (1 << i))) a.n4[i] = 0; if (bf16) a.n4[i] /= 2; }
   a.nch[0] = cdiv(d.R, KCH) + cdiv(d.I, KCH); a.nch[1] = cdiv(d.C, KCH); a.nch[2] = cdiv(4 * d.C, KCH); a.nch[3] = cdiv(d.R, KCH);
-  long total = 0;
+  long total = a.n4[4] + a.n4[5];
   for (int i = 0; i < 4; i++) { a.pk[i] = reinterpret_cast<float4 *>(pk[i]); total += a.n4[i]; }
   if (total == 0) return hipSuccess;
   const long nb = (total + 255) / 256;
@@ -1930,6 +2176,7 @@ static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const flo
   GemmJob g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.beta = beta;
   g.Cm = Cm; g.ldc = ldc; g.bias = bias;
+  g.Ct = nullptr; g.ldct = 0; g.C2 = nullptr; g.ldc2 = 0; g.C3 = nullptr; g.tail0 = 0;
   // branch-free 8-wide fetches need aligned rows and a contiguous extent that is a multiple of 8
   g.vecA = aligned16(A) && lda % 4 == 0 && (transA ? M : K) % 8 == 0;
   g.vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K : N) % 8 == 0;
@@ -1950,27 +2197,31 @@ hipError_t launch_gemm(bool transA, bool transB, int M, int N, int K, const floa
 // Split-K plan: worth it when the output tiles cover less than half the chip and K is long.
 int gemm_splitk_plan(int M, int N, int K, int *klen) {
   const int tiles = cdiv(M, GT) * cdiv(N, GT);
-  if (tiles >= 128 || K < 1024) { *klen = K; return 1; }
-  int ks = cdiv(768, tiles);                         // ~3 workgroups per CU
-  int kl = cdiv(cdiv(K, ks), GK) * GK;
-  if (kl < 2 * GK) kl = 2 * GK;
+  if (tiles >= 128 || K <= GK) { *klen = K; return 1; }
+  const int ks = cdiv(768, tiles);                   // ~3 workgroups per CU
+  const int kl = cdiv(cdiv(K, ks), GK) * GK;         // whole K tiles; a slice is at least one
   *klen = kl;
   return cdiv(K, kl);
 }
 hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, const float *A, int lda, const float *B,
                               int ldb, float beta, float *Cm, int ldc, const float *bias, float *ws, int ks, int klen,
-                              hipStream_t st) {
+                              hipStream_t st, const float *add, int add_ld, LaunchProbe pr, LaunchProbe pr2, float *C2,
+                              int ldc2, float *C3, int tail0) {
   const GemmJob g = make_job(transA, transB, M, N, K, A, lda, B, ldb, 0.f, nullptr, N, nullptr);
   const dim3 grid(cdiv(N, GT), cdiv(M, GT), ks), block(256);
-  if (transA && transB) hipLaunchKernelGGL((k_gemm_splitk<true, true>), grid, block, 0, st, g, klen, ws);
-  else if (transA) hipLaunchKernelGGL((k_gemm_splitk<true, false>), grid, block, 0, st, g, klen, ws);
-  else if (transB) hipLaunchKernelGGL((k_gemm_splitk<false, true>), grid, block, 0, st, g, klen, ws);
-  else hipLaunchKernelGGL((k_gemm_splitk<false, false>), grid, block, 0, st, g, klen, ws);
-  hipError_t err = hipGetLastError();
+  auto first = [&]() -> hipError_t {
+    if (transA && transB) KLAUNCH((k_gemm_splitk<true, true>), grid, block, st, pr, g, klen, ws);
+    if (transA) KLAUNCH((k_gemm_splitk<true, false>), grid, block, st, pr, g, klen, ws);
+    if (transB) KLAUNCH((k_gemm_splitk<false, true>), grid, block, st, pr, g, klen, ws);
+    KLAUNCH((k_gemm_splitk<false, false>), grid, block, st, pr, g, klen, ws);
+  };
+  hipError_t err = first();
   if (err != hipSuccess) return err;
+  ReduceArgs r;
+  r.ws = ws; r.ks = ks; r.M = M; r.N = N; r.beta = beta; r.Cm = Cm; r.ldc = ldc; r.bias = bias; r.add = add; r.add_ld = add_ld;
+  r.C2 = C2; r.ldc2 = ldc2; r.C3 = C3; r.tail0 = tail0;
   const long nb = ((long)M * N + 255) / 256;
-  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)(nb > 2048 ? 2048 : nb)), block, 0, st, ws, ks, M, N, beta, Cm, ldc, bias);
-  return hipGetLastError();
+  KLAUNCH(k_splitk_reduce, dim3((unsigned)(nb > 2048 ? 2048 : nb)), block, st, pr2, r);
 }
 
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,

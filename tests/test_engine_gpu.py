@@ -31,7 +31,7 @@ def make_engine(I, C, R, S, params):
 
 
 def run_chunks(I, C, R, S, T, nchunks, scale, momentum, lr, seed=0, want_in_diff=True, od_scale=1.0, fuse_x=-1,
-               vector=1, fat=1):
+               vector=1, fat=1, fold=-1):
     """Runs nchunks x (Propagate, Backpropagate, Update) on both sides; returns per-chunk records."""
     rng = np.random.RandomState(seed)
     p = make_params(I, C, R, scale=scale, seed=seed + 1)
@@ -41,6 +41,7 @@ def run_chunks(I, C, R, S, T, nchunks, scale, momentum, lr, seed=0, want_in_diff
     e.set_option("fuse_x", fuse_x)
     e.set_option("vector", vector)
     e.set_option("fat", fat)
+    e.set_option("fold", fold)
     recs = []
     for ck in range(nchunks):
         x = rng.randn(T * S, I).astype(np.float32)
@@ -602,3 +603,46 @@ def test_stacked_net_dp_device_layers_against_cpu_twins():
     for e in engines:
         e.close()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fold", [0, 1])
+@pytest.mark.parametrize("I,C,R,S,T,want_in_diff,fuse_x", [
+    (40, 64, 32, 4, 6, True, -1),       # one stream group
+    (40, 64, 32, 12, 4, True, -1),      # three stream groups
+    (8, 16, 8, 3, 5, False, -1),        # ragged stream group, no in_diff
+    (72, 136, 40, 5, 7, True, -1),      # 4C = 544: last 128-chunk of the d_m contraction partially filled
+    (40, 64, 32, 4, 1, True, -1),       # T = 1: only the unfolded first step + the batched products
+    (40, 64, 32, 4, 6, True, 0),        # batched x-projection GEMM in front of the folded chain
+])
+def test_folded_recurrence(I, C, R, S, T, want_in_diff, fuse_x, fold):
+    """Option "fold": steps 2..T close over m(t-1) through W_rm = W_gifo_r W_r_m (one kernel per step and direction,
+    r / d_r / in_diff as batched products).  Same algebra as the reference up to fp32 summation order: same tolerances
+    as the unfolded path, over 3 chained minibatches (carried state crosses an Update: step 1 stays unfolded)."""
+    recs = run_chunks(I, C, R, S, T, nchunks=3, scale=0.3, momentum=0.9, lr=1e-3, want_in_diff=want_in_diff, fuse_x=fuse_x,
+                      fold=fold)
+    check(recs, tol_act=2e-5, tol_grad=1e-4, C=C, S=S, T=T)
+
+
+def test_folded_recurrence_config_shape_and_varying_T():
+    """BASELINE.json configs[1] shape with the folded chain (auto policy: T >= 12), 5 chunks; then T changes between
+    calls (graphs / planes regrow, block T+1 of dgifo must read as zero after a longer minibatch)."""
+    I, C, R, S = 40, 800, 512, 4
+    recs = run_chunks(I, C, R, S, 20, nchunks=5, scale=0.01, momentum=0.9, lr=1e-5, od_scale=0.1)
+    check(recs, tol_act=3e-5, tol_grad=3e-4, C=C, S=S, T=20)
+    I, C, R, S = 40, 64, 32, 4
+    p = make_params(I, C, R, scale=0.3, seed=3)
+    o = Oracle(I, C, R, S, np.float32); o.set_params(p)
+    e = make_engine(I, C, R, S, p); e.set_option("fold", 1)
+    rng = np.random.RandomState(4)
+    for T in (9, 3, 14, 2, 14):
+        x = rng.randn(T * S, I).astype(np.float32); od = rng.randn(T * S, R).astype(np.float32)
+        xd, odd = dev(x), dev(od)
+        outd = torch.empty(T * S, R, device="cuda"); idd = torch.empty(T * S, I, device="cuda")
+        torch.cuda.synchronize()
+        e.propagate(xd, outd); e.backpropagate(xd, odd, idd, momentum=0.9); e.synchronize()
+        out_o = o.propagate(x); id_o = o.backpropagate(x, od, momentum=0.9)
+        assert relerr(outd.cpu().numpy(), out_o) <= 2e-5 and relerr(idd.cpu().numpy(), id_o) <= 1e-4
+        assert relerr(e.get_corr(), o.get_corr()) <= 1e-4
+        e.update(1e-3); o.update(1e-3)
+        assert relerr(e.get_params(), o.get_params()) <= 2e-5
+    e.close()

@@ -10,6 +10,8 @@ BF = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 if len(sys.argv) > 5: I, C, R = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 e = k.Engine(I, C, R, S)
 e.set_option("bf16", BF)
+FOLD = int(os.environ.get("FOLD", "-1"))
+e.set_option("fold", FOLD)
 e.set_params(make_params(I, C, R, 0.01, 7))
 x = torch.randn(T * S, I, device="cuda"); od = 0.1 * torch.randn(T * S, R, device="cuda")
 out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
@@ -29,7 +31,7 @@ print("fwd+bwd(no indiff): %8.1f us" % timeit(fb2))
 print("fwd+bwd+update   : %8.1f us" % timeit(fbu))
 lib = e.lib
 lib.klstm_debug_chain.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
-for w in ("gates", "proj", "gates+proj", "dr", "dm", "dr+dm", "grads", "update", "pack", "pack_fwd"):
+for w in ("gates_fold", "dmf", "fold", "rbatch", "bwd_tail", "gates", "proj", "gates+proj", "dr", "dm", "dr+dm", "grads", "update", "pack", "pack_fwd"):
     us = ctypes.c_float()
     rc = lib.klstm_debug_chain(e.h, w.encode(), 200, ctypes.byref(us))
     print("chain %-11s: %6.2f us/launch (rc=%d)" % (w, us.value, rc))
