@@ -743,6 +743,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(launch_pack(Dims{e->I, e->C, e->R, e->S, 0}, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream));
     return KLSTM_OK;
   }
+  if (!strcmp(key, "dmf_dbg")) { set_dmf_dbg(value); return KLSTM_OK; }
   if (!strcmp(key, "fold")) {            // -1 auto, 0 never, 1 whenever NumStream <= small_max
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
@@ -920,7 +921,7 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
   const Dims d{e->I, e->C, e->R, e->S, T};
   { klstm_status ps = ensure_packs(e); if (ps != KLSTM_OK) return ps; }
   const std::string w0(what);
-  if (w0 == "gates_fold" || w0 == "dmf" || w0 == "fold" || w0 == "rbatch" || w0 == "bwd_tail") {
+  if (w0 == "gates_fold" || w0 == "dmf" || w0 == "fold" || w0 == "fold_gemm" || w0 == "fold_pack" || w0 == "rbatch" || w0 == "bwd_tail") {
     if (!e->pk[0] || e->use_bf16) return fail(KLSTM_ERR_SHAPE, "folded path not available for this engine");
     klstm_status fs = ensure_fold(e);
     if (fs != KLSTM_OK) return fs;
@@ -944,6 +945,8 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
         HIPCHK(launch_fold(d, e->params, e->wrm, e->wrmT, st));
         HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, st, LaunchProbe(), e->wrm, e->wrmT, e->pk_fold));
       }
+      else if (w == "fold_gemm") HIPCHK(launch_fold(d, e->params, e->wrm, e->wrmT, st));
+      else if (w == "fold_pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, st, LaunchProbe(), e->wrm, e->wrmT, e->pk_fold));
       else if (w == "rbatch") HIPCHK(launch_rbatch(d, fp, scratch_out, e->R, e->ws, st));
       else if (w == "bwd_tail") {
         int kl = 0, ks = gemm_splitk_plan(T * d.S, d.R, 4 * d.C, &kl);

@@ -1255,33 +1255,44 @@ __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
 // =============================================================================================
 constexpr int KCH4 = 128;
 
-// acc += A(4 rows, chunks [0,nch)) * B(4 streams, same chunks).  Chunk c is dealt to wave c % NW.  No LDS: a lane's
-// B operand (stream j = lane&3, k-group b = lane>>2) is 8 consecutive floats of that stream's row, so a wave-load of one
-// chunk is 4 x 256 contiguous bytes per load instruction -- coalesced as it stands (the lane's 8 k-values are the float4
-// at 4*(lane>>2) of each 64-float half of the chunk; the packed weights use the same k order).  brow: row pointer of
-// the lane's stream (clamped), bok: stream exists.
+// acc += A(4 rows, chunks [0,nch)) * B(4 streams, same chunks).  Chunk c is dealt to wave c % NW.  No LDS staging: the B
+// operand of consumer lane 4b+j (k-group b, stream j) is float4 b of each 64-float half of the chunk in stream j's row;
+// it is FETCHED by loader lane 16j+b, so that a load instruction covers 4 x 256 contiguous bytes (lanes of a quad on
+// one cache line -- a quad spread over four rows costs four tag lookups), and moved with ds_bpermute.
+// brow: row pointer of the LOADER lane's stream (clamped), bok: the CONSUMER lane's stream exists.
+__device__ __forceinline__ float perm(int byte_idx, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_idx, __builtin_bit_cast(int, v)));
+}
 template <int CPW>
 __device__ __forceinline__ void vec_contract_r4(const float4 *__restrict__ apk, int nch, int K, const float *__restrict__ brow,
-                                                bool bok, int lane, int wave, f32x4 (&acc)[2]) {
+                                                bool bok, int lane, int wave, int rot, int dbg, f32x4 (&acc)[2]) {
   const int kg = lane >> 2;
   for (int base = 0; base < nch; base += CPW * NW) {
     float4 a0[CPW], a1[CPW], b0[CPW], b1[CPW];
 #pragma unroll
     for (int c = 0; c < CPW; c++) {
       const int ch = base + c * NW + wave;
-      const int cl = min(ch, nch - 1);                             // clamped: always a valid chunk, unused if off
+      int cl = min(ch, nch - 1) + rot;                             // clamped: always a valid chunk, unused if off
+      cl = cl >= nch ? cl - nch : cl;                              // rotated: see k_dmf_v
       const float4 *ap = apk + (size_t)cl * 128 + lane;
-      a0[c] = ap[0]; a1[c] = ap[64];
-      const int k = cl * KCH4 + kg * 4;                            // h = 0: floats [0,64) of the chunk, h = 1: [64,128)
-      b0[c] = ldg4(brow + min(k, K - 4)); b1[c] = ldg4(brow + min(k + 64, K - 4));
+      if (dbg != 5) { a0[c] = ap[0]; a1[c] = ap[64]; } else { a0[c] = f4zero(); a1[c] = f4zero(); }
+      // loader role: lane = 16*stream + q fetches float4 q of each 64-float half of the chunk (4 x 256 contiguous bytes
+      // per instruction); the consumer lane 4b+j takes its operand from loader lane 16j+b below
+      const int k = cl * KCH4 + (lane & 15) * 4;
+      if (dbg != 4) { b0[c] = ldg4(brow + min(k, K - 4)); b1[c] = ldg4(brow + min(k + 64, K - 4)); } else { b0[c] = f4zero(); b1[c] = f4zero(); }
     }
 #pragma unroll
     for (int c = 0; c < CPW; c++) {
       const int ch = base + c * NW + wave;
-      const bool on0 = ch < nch && bok && ch * KCH4 + kg * 4 < K, on1 = ch < nch && bok && ch * KCH4 + 64 + kg * 4 < K;
+      int cl = min(ch, nch - 1) + rot;
+      cl = cl >= nch ? cl - nch : cl;
+      const bool on0 = ch < nch && bok && cl * KCH4 + kg * 4 < K, on1 = ch < nch && bok && cl * KCH4 + 64 + kg * 4 < K;
       const float av[8] = {a0[c].x, a0[c].y, a0[c].z, a0[c].w, a1[c].x, a1[c].y, a1[c].z, a1[c].w};
-      const float bv[8] = {on0 ? b0[c].x : 0.f, on0 ? b0[c].y : 0.f, on0 ? b0[c].z : 0.f, on0 ? b0[c].w : 0.f,
-                           on1 ? b1[c].x : 0.f, on1 ? b1[c].y : 0.f, on1 ? b1[c].z : 0.f, on1 ? b1[c].w : 0.f};
+      const int src = (((lane & 3) << 4) | kg) << 2;               // byte index of loader lane 16j+b
+      const float p[8] = {perm(src, b0[c].x), perm(src, b0[c].y), perm(src, b0[c].z), perm(src, b0[c].w),
+                          perm(src, b1[c].x), perm(src, b1[c].y), perm(src, b1[c].z), perm(src, b1[c].w)};
+      const float bv[8] = {on0 ? p[0] : 0.f, on0 ? p[1] : 0.f, on0 ? p[2] : 0.f, on0 ? p[3] : 0.f,
+                           on1 ? p[4] : 0.f, on1 ? p[5] : 0.f, on1 ? p[6] : 0.f, on1 ? p[7] : 0.f};
 #pragma unroll
       for (int j = 0; j < 8; j++) acc[j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 1], 0, 0, 0);
     }
@@ -1297,6 +1308,7 @@ struct DmfArgs {
   const float4 *wpk;       // packed W_rm^T, 4-row geometry: [C/4 tiles][nch_total chunks][2][64]
   int nch_total;           // chunks of 128 over 4C
   int nch;                 // chunks to contract: nch_total, or 0 at t == T (dgifo(T+1) = 0, :351)
+  int dbg;                 // diagnostics (tools/dmf_dbg.py): 4 = no B loads, 5 = no A loads
 };
 
 template <int CPW>
@@ -1335,9 +1347,12 @@ __global__ __launch_bounds__(NW * 64) void k_dmf_v(DmfArgs a) {
   }
 
   f32x4 acc[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
-  const int bj = sbase + (lane & 3);
-  const float *brow = a.dgifo + ((size_t)(last ? t : t + 1) * S + min(bj, S - 1)) * K;
-  vec_contract_r4<CPW>(a.wpk + (size_t)blockIdx.x * a.nch_total * 128, a.nch, K, brow, bj < S, lane, wave, acc);
+  const int bj = sbase + (lane & 3);                             // consumer role: stream of the B operand
+  const float *brow = a.dgifo + ((size_t)(last ? t : t + 1) * S + min(sbase + (lane >> 4), S - 1)) * K;   // loader role
+  // every workgroup reads the SAME 4 x 4C activation rows: started at the same chunk they would all hit one L2 channel at
+  // a time, so workgroup w walks the chunks rotated by 7w (the weights are private, their order does not matter)
+  const int rot = a.nch > 0 ? (int)((blockIdx.x * 7u) % (unsigned)a.nch) : 0;
+  vec_contract_r4<CPW>(a.wpk + (size_t)blockIdx.x * a.nch_total * 128, a.nch, K, brow, bj < S, lane, wave, rot, a.dbg, acc);
 
   // the 16 k-groups of a (row, stream) pair sit in the lanes with equal lane&3: xor butterfly (a+b == b+a bitwise, so
   // every lane ends with the same sum), then the 8 waves in fixed order
@@ -2006,6 +2021,8 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
   GEN_DISPATCH(k_proj_step, nt, grid, st, pr, a, );
 }
 
+int g_dmf_dbg = 0;
+void set_dmf_dbg(int v) { g_dmf_dbg = v; }
 void set_small_max(int s) { g_small_max = s; }
 int get_small_max() { return g_small_max; }
 
@@ -2092,6 +2109,7 @@ hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *o
 static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const float *A, int lda, const float *B,
                         int ldb, float beta, float *Cm, int ldc, const float *bias);
 
+extern int g_dmf_dbg;
 hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *P, hipStream_t st, LaunchProbe pr) {
   DmfArgs a;
   a.C = d.C; a.S = d.S; a.T = d.T; a.t = t;
@@ -2099,8 +2117,12 @@ hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *
   a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.wpk = p.pk_fold;
   a.nch_total = cdiv(4 * d.C, KCH4);
   a.nch = t == d.T ? 0 : a.nch_total;
+  if (g_dmf_dbg == 1) a.nch = 0;
+  a.dbg = g_dmf_dbg;
   const dim3 grid(cdiv(d.C, 4), cdiv(d.S, 4)), blk(NW * 64);
-  const int need = cdiv(a.nch_total, NW);
+  int need = cdiv(a.nch_total, NW);
+  if (g_dmf_dbg == 2) need = 2;
+  if (g_dmf_dbg == 3) need = 1;
   if (need <= 1) KLAUNCH((k_dmf_v<1>), grid, blk, st, pr, a);
   if (need == 2) KLAUNCH((k_dmf_v<2>), grid, blk, st, pr, a);
   KLAUNCH((k_dmf_v<4>), grid, blk, st, pr, a);
