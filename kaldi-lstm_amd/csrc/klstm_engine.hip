@@ -202,7 +202,7 @@ static klstm_status ensure_fold(klstm_engine *e) {
     e->fold_dirty = true;
   }
   if (!e->fold_dirty) return KLSTM_OK;
-  HIPCHK(launch_fold(d, e->params, e->wrm, e->wrmT, e->stream, probe(e, "k_fold")));
+  HIPCHK(launch_fold(d, e->params, e->wmT, e->wrm, e->wrmT, e->stream, probe(e, "k_fold")));
   HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, e->stream, probe(e, "k_pack_fold"), e->wrm, e->wrmT,
                      e->pk_fold));
   e->fold_dirty = false;
@@ -942,10 +942,10 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
       if (w == "gates_fold") HIPCHK(launch_gates_step(d, fp, t < 2 ? 2 : t, fx, xin, e->I, st, LaunchProbe(), true));
       else if (w == "dmf") HIPCHK(launch_dmf_step(d, bp, t < T ? t : 1, e->Pm, st));
       else if (w == "fold") {
-        HIPCHK(launch_fold(d, e->params, e->wrm, e->wrmT, st));
+        HIPCHK(launch_fold(d, e->params, e->wmT, e->wrm, e->wrmT, st));
         HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, st, LaunchProbe(), e->wrm, e->wrmT, e->pk_fold));
       }
-      else if (w == "fold_gemm") HIPCHK(launch_fold(d, e->params, e->wrm, e->wrmT, st));
+      else if (w == "fold_gemm") HIPCHK(launch_fold(d, e->params, e->wmT, e->wrm, e->wrmT, st));
       else if (w == "fold_pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, st, LaunchProbe(), e->wrm, e->wrmT, e->pk_fold));
       else if (w == "rbatch") HIPCHK(launch_rbatch(d, fp, scratch_out, e->R, e->ws, st));
       else if (w == "bwd_tail") {

@@ -51,7 +51,8 @@ hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, bool fuse_x
 //   launch_gates_step(..., fold = true)   a(t) = W_x x(t) + b + W_rm m(t-1), t >= 2
 //   launch_rbatch   r(1..T) = m(1..T) W_r_m^T -> rr rows, out rows, prev_r
 //   launch_dmf_step d_m(t) = P(t) + dgifo(t+1) W_rm with P = out_diff W_r_m, then the elementwise BPTT (:411-440)
-hipError_t launch_fold(const Dims &d, const float *param_blob, float *wrm, float *wrmT, hipStream_t st, LaunchProbe pr = {});
+hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *wrm, float *wrmT, hipStream_t st,
+                       LaunchProbe pr = {});
 hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_stride, float *ws, hipStream_t st,
                          LaunchProbe pr = {}, LaunchProbe pr2 = {});   // ws: split-K workspace (gemm_splitk_plan(T*S, R, C) slices)
 hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *P, hipStream_t st, LaunchProbe pr = {});

@@ -1487,6 +1487,7 @@ struct GemmJob {
   float *Ct; int ldct;    // transposed copy  Ct[n][m]  (M % 4 == 0)
   float *C2; int ldc2;    // second copy      C2[m][n]
   float *C3; int tail0;   // rows m >= tail0 also to C3[m - tail0][n], dense (ld = N)
+  int dbg;                // diagnostics: 6 = no result stores, 7 = no global fetch inside the K loop
 };
 
 // One operand tile = GT x GK elements = 2 x (8 floats per thread).  Operand stored [X x K] (TA=false: 8 consecutive k
@@ -1563,7 +1564,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
     stash_tile<TA>(As, tid, ra);
     stash_tile<!TB>(Bs, tid, rb);
     __syncthreads();
-    if (k0 + GK < g.K) {
+    if (k0 + GK < g.K && g.dbg != 7) {
       fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0 + GK, tid, ra);
       fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, k0 + GK, tid, rb);
     }
@@ -1578,7 +1579,28 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
       acc[1][0] = MFMA16(a1, b0, acc[1][0]);
       acc[1][1] = MFMA16(a1, b1, acc[1][1]);
     };
-    if (k0 + GK <= g.K) {
+    if (!TA && TB) {
+      // both operands k-contiguous in LDS ([x][k]): one 16-byte read per operand block feeds FOUR k-steps.  Within a
+      // group of 16 k the MFMA k-lane kg of step e contracts k = 16j + 4kg + e -- the same bijection for A and B, so the
+      // sum is over every k exactly once (zero-filled past K)
+#pragma unroll
+      for (int j = 0; j < GK / 16; j++) {
+        const int ko = 16 * j + 4 * kg;
+        const float4 a0 = *reinterpret_cast<const float4 *>(As + (wr * 32 + i16) * GLX + ko);
+        const float4 a1 = *reinterpret_cast<const float4 *>(As + (wr * 32 + 16 + i16) * GLX + ko);
+        const float4 b0 = *reinterpret_cast<const float4 *>(Bs + (wc * 32 + i16) * GLX + ko);
+        const float4 b1 = *reinterpret_cast<const float4 *>(Bs + (wc * 32 + 16 + i16) * GLX + ko);
+        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          acc[0][0] = MFMA16(av0[e], bv0[e], acc[0][0]);
+          acc[0][1] = MFMA16(av0[e], bv1[e], acc[0][1]);
+          acc[1][0] = MFMA16(av1[e], bv0[e], acc[1][0]);
+          acc[1][1] = MFMA16(av1[e], bv1[e], acc[1][1]);
+        }
+      }
+    } else if (k0 + GK <= g.K) {
 #pragma unroll
       for (int kk = 0; kk < GK / 4; kk++) kstep(kk);
     } else {
@@ -1593,6 +1615,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
     for (int ni = 0; ni < 2; ni++) {
       const int n = n0 + wc * 32 + ni * 16 + i16;
       if (n >= g.N) continue;
+      if (g.dbg == 6 && acc[mi][ni].x != 12345.678f) continue;
       const float bv = g.bias ? g.bias[n] : 0.f;
       const float e[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
 #pragma unroll
@@ -1613,11 +1636,18 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
     }
 }
 
+// 1-D grid padded to a multiple of 8.  XCD-aware order: workgroup w lands on XCD w % 8 (observed dispatch rule, speed
+// only); XCD x gets the contiguous m-major tile range [x*cpx, (x+1)*cpx), so its private L2 keeps a few A row panels and
+// the B column panels instead of every XCD streaming every panel from the fabric.
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm(GemmJob g) {
   __shared__ __attribute__((aligned(16))) float As[GLDS];
   __shared__ __attribute__((aligned(16))) float Bs[GLDS];
-  gemm_tile<TA, TB>(g, blockIdx.y * GT, blockIdx.x * GT, As, Bs);
+  const int ntn = (g.N + GT - 1) / GT, nbt = ((g.M + GT - 1) / GT) * ntn;
+  const int cpx = (nbt + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * cpx + (int)(blockIdx.x >> 3);
+  if (b >= nbt) return;
+  gemm_tile<TA, TB>(g, (b / ntn) * GT, (b % ntn) * GT, As, Bs);
 }
 
 // Split-K variant for short-and-wide products whose 64x64 output tiles cannot fill the chip (AffineTransform
@@ -2129,12 +2159,16 @@ hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *
 }
 
 // W_rm = W_gifo_r [4C x R] * W_r_m [R x C], natural [4C x C] and transposed [C x 4C], once per Update
-hipError_t launch_fold(const Dims &d, const float *param_blob, float *wrm, float *wrmT, hipStream_t st, LaunchProbe pr) {
-  const long o_wr = (long)4 * d.C * d.I, o_wm = o_wr + (long)4 * d.C * d.R + 7 * d.C;
-  GemmJob g = make_job(false, false, 4 * d.C, d.C, d.R, param_blob + o_wr, d.R, param_blob + o_wm, d.C, 0.f, wrm, d.C, nullptr);
+extern int g_dmf_dbg;
+hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *wrm, float *wrmT, hipStream_t st,
+                       LaunchProbe pr) {
+  // NT form on the transposed copy W_r_m^T [C x R]: both operands k-contiguous (the 16-byte LDS operand reads)
+  const long o_wr = (long)4 * d.C * d.I;
+  GemmJob g = make_job(false, true, 4 * d.C, d.C, d.R, param_blob + o_wr, d.R, wmT, d.R, 0.f, wrm, d.C, nullptr);
   g.Ct = wrmT; g.ldct = 4 * d.C;
-  const dim3 grid(cdiv(d.C, GT), cdiv(4 * d.C, GT)), block(256);
-  KLAUNCH((k_gemm<false, false>), grid, block, st, pr, g);
+  g.dbg = g_dmf_dbg;
+  const dim3 grid(cdiv(cdiv(d.C, GT) * cdiv(4 * d.C, GT), 8) * 8), block(256);
+  KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
 }
 
 // r(1..T) = m(1..T) W_r_m^T (:312) for all frames at once -> rr rows, out rows (:328), last block -> prev_r (:331)
@@ -2150,7 +2184,7 @@ hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_st
                        p.rr + (size_t)d.S * d.R, d.R, nullptr);
   g.C2 = out; g.ldc2 = out_stride;
   g.C3 = p.prev_r; g.tail0 = M - d.S;
-  const dim3 grid(cdiv(d.R, GT), cdiv(M, GT)), block(256);
+  const dim3 grid(cdiv(cdiv(d.R, GT) * cdiv(M, GT), 8) * 8), block(256);
   KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
 }
 
@@ -2198,7 +2232,7 @@ static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const flo
   GemmJob g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.beta = beta;
   g.Cm = Cm; g.ldc = ldc; g.bias = bias;
-  g.Ct = nullptr; g.ldct = 0; g.C2 = nullptr; g.ldc2 = 0; g.C3 = nullptr; g.tail0 = 0;
+  g.Ct = nullptr; g.ldct = 0; g.C2 = nullptr; g.ldc2 = 0; g.C3 = nullptr; g.tail0 = 0; g.dbg = 0;
   // branch-free 8-wide fetches need aligned rows and a contiguous extent that is a multiple of 8
   g.vecA = aligned16(A) && lda % 4 == 0 && (transA ? M : K) % 8 == 0;
   g.vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K : N) % 8 == 0;
@@ -2209,7 +2243,7 @@ hipError_t launch_gemm(bool transA, bool transB, int M, int N, int K, const floa
                        const float *B, int ldb, float beta, float *Cm, int ldc, const float *bias,
                        hipStream_t st, LaunchProbe pr) {
   const GemmJob g = make_job(transA, transB, M, N, K, A, lda, B, ldb, beta, Cm, ldc, bias);
-  const dim3 grid(cdiv(N, GT), cdiv(M, GT)), block(256);
+  const dim3 grid(cdiv(cdiv(N, GT) * cdiv(M, GT), 8) * 8), block(256);
   if (transA && transB) KLAUNCH((k_gemm<true, true>), grid, block, st, pr, g);
   if (transA && !transB) KLAUNCH((k_gemm<true, false>), grid, block, st, pr, g);
   if (!transA && transB) KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
