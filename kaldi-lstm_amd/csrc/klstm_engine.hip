@@ -139,8 +139,8 @@ static klstm_status ensure_planes(klstm_engine *e, int T) {
     HIPCHK(hipMalloc(&e->Pm, (size_t)T * e->S * e->C * sizeof(float)));
     int kl = 0;
     const size_t M = (size_t)T * e->S;
-    const size_t need[4] = {(size_t)gemm_splitk_plan((int)M, e->R, 4 * e->C, &kl) * M * e->R,      // d_r
-                            (size_t)gemm_splitk_plan((int)M, e->I, 4 * e->C, &kl) * M * e->I,      // in_diff
+    const size_t need[4] = {bwd_tail_ws_floats(d),                                                 // d_r + in_diff
+                            0,
                             (size_t)gemm_splitk_plan((int)M, e->R, e->C, &kl) * M * e->R,          // r
                             (size_t)gemm_splitk_plan((int)M, e->C, e->R, &kl) * M * e->C};         // P
     e->ws_floats = 0;
@@ -464,15 +464,8 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
                                           st, nullptr, 0, probe(e, "k_gemm_P"), probe(e, "k_reduce_P")));
     else HIPCHK(launch_gemm(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
     for (int t = T; t >= 1; t--) HIPCHK(launch_dmf_step(d, p, t, e->Pm, st, probe(e, "k_dmf_step")));
-    ks = gemm_splitk_plan(M, d.R, K4, &kl);
-    HIPCHK(launch_gemm_splitk(false, false, M, d.R, K4, e->dgifo + (size_t)2 * d.S * K4, K4, wr, d.R, 0.f,
-                              e->dr + (size_t)d.S * d.R, d.R, nullptr, e->ws, ks, kl, st, out_diff, od_stride,
-                              probe(e, "k_gemm_dr"), probe(e, "k_reduce_dr")));
-    if (in_diff) {
-      ks = gemm_splitk_plan(M, d.I, K4, &kl);
-      HIPCHK(launch_gemm_splitk(false, false, M, d.I, K4, e->dgifo + (size_t)d.S * K4, K4, wx, d.I, 0.f, in_diff, id_stride,
-                                nullptr, e->ws, ks, kl, st, nullptr, 0, probe(e, "k_gemm_dx"), probe(e, "k_reduce_dx")));
-    }
+    HIPCHK(launch_bwd_tail(d, e->dgifo, wr, wx, out_diff, od_stride, e->dr, in_diff, id_stride, e->ws, st,
+                           probe(e, "k_gemm_tail"), probe(e, "k_reduce_tail")));
     const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
     HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, defer ? 0.f : mmt, defer ? e->grads : e->corr, st,
                         probe(e, "k_grads")));
@@ -948,15 +941,8 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
       else if (w == "fold_gemm") HIPCHK(launch_fold(d, e->params, e->wmT, e->wrm, e->wrmT, st));
       else if (w == "fold_pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, st, LaunchProbe(), e->wrm, e->wrmT, e->pk_fold));
       else if (w == "rbatch") HIPCHK(launch_rbatch(d, fp, scratch_out, e->R, e->ws, st));
-      else if (w == "bwd_tail") {
-        int kl = 0, ks = gemm_splitk_plan(T * d.S, d.R, 4 * d.C, &kl);
-        HIPCHK(launch_gemm_splitk(false, false, T * d.S, d.R, 4 * d.C, e->dgifo + (size_t)2 * d.S * 4 * d.C, 4 * d.C,
-                                  e->params + e->o_wr(), d.R, 0.f, e->dr + (size_t)d.S * d.R, d.R, nullptr, e->ws, ks, kl, st,
-                                  scratch_out, e->R));
-        ks = gemm_splitk_plan(T * d.S, d.I, 4 * d.C, &kl);
-        HIPCHK(launch_gemm_splitk(false, false, T * d.S, d.I, 4 * d.C, e->dgifo + (size_t)d.S * 4 * d.C, 4 * d.C,
-                                  e->params + e->o_wx(), d.I, 0.f, xdiff, e->I, nullptr, e->ws, ks, kl, st));
-      }
+      else if (w == "bwd_tail") HIPCHK(launch_bwd_tail(d, e->dgifo, e->params + e->o_wr(), e->params + e->o_wx(), scratch_out, e->R,
+                                                       e->dr, xdiff, e->I, e->ws, st));
       else if (w == "gates") HIPCHK(launch_gates_step(d, fp, t, fx, xin, e->I, st));
       else if (w == "proj") HIPCHK(launch_proj_step(d, fp, t, scratch_out, e->R, st));
       else if (w == "gates+proj") { if (i & 1) HIPCHK(launch_proj_step(d, fp, t, scratch_out, e->R, st)); else HIPCHK(launch_gates_step(d, fp, t, fx, xin, e->I, st)); }

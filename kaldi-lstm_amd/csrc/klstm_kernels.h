@@ -56,6 +56,11 @@ hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT,
 hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_stride, float *ws, hipStream_t st,
                          LaunchProbe pr = {}, LaunchProbe pr2 = {});   // ws: split-K workspace (gemm_splitk_plan(T*S, R, C) slices)
 hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *P, hipStream_t st, LaunchProbe pr = {});
+//   launch_bwd_tail d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r and in_diff = dgifo(1..T) W_gifo_x, one split-K launch pair
+size_t bwd_tail_ws_floats(const Dims &d);
+hipError_t launch_bwd_tail(const Dims &d, const float *dgifo, const float *wr, const float *wx, const float *out_diff,
+                           int od_stride, float *dr, float *in_diff, int id_stride, float *ws, hipStream_t st,
+                           LaunchProbe pr = {}, LaunchProbe pr2 = {});
 void pack_sizes_fold(const Dims &d, long n4[2]);   // float4 counts of the two folded operands
 // r(t) = m(t) W_r_m^T (:312) -> rr, out rows (:328); t==T also prev_r (:331)
 hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, int out_stride,

@@ -1698,6 +1698,46 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ReduceArgs a) {
   }
 }
 
+// Two NN split-K products that share K and the slice length in ONE launch pair (the folded BPTT tail: d_r and in_diff
+// both contract dgifo rows over 4C): tiles [0, nb1) belong to job 1, the rest to job 2.
+__global__ __launch_bounds__(256) void k_gemm_splitk2(GemmJob g1, GemmJob g2, int nb1, int klen, float *ws1, float *ws2) {
+  __shared__ __attribute__((aligned(16))) float As[GLDS];
+  __shared__ __attribute__((aligned(16))) float Bs[GLDS];
+  const bool second = (int)blockIdx.x >= nb1;
+  const GemmJob &g = second ? g2 : g1;
+  const int lb = second ? (int)blockIdx.x - nb1 : (int)blockIdx.x;
+  const int ntn = (g.N + GT - 1) / GT;
+  const int k0 = blockIdx.z * klen;
+  GemmJob s = g;
+  s.K = min(g.K - k0, klen);
+  s.A = g.A + k0;
+  s.B = g.B + (size_t)k0 * g.ldb;
+  s.vecA = g.vecA && s.K % 8 == 0;
+  s.beta = 0.f; s.bias = nullptr;
+  s.Cm = (second ? ws2 : ws1) + (size_t)blockIdx.z * g.M * g.N; s.ldc = g.N;
+  gemm_tile<false, false>(s, (lb / ntn) * GT, (lb % ntn) * GT, As, Bs);
+}
+__global__ __launch_bounds__(256) void k_splitk_reduce2(ReduceArgs r1, ReduceArgs r2, int nbr1) {
+  const bool second = (int)blockIdx.x >= nbr1;
+  const ReduceArgs &a = second ? r2 : r1;
+  const int nb = second ? (int)gridDim.x - nbr1 : nbr1;
+  const int bid = second ? (int)blockIdx.x - nbr1 : (int)blockIdx.x;
+  const long total = (long)a.M * a.N;
+  for (long i = bid * 256L + threadIdx.x; i < total; i += (long)nb * 256) {
+    const int m = (int)(i / a.N), n = (int)(i - (long)m * a.N);
+    float v = 0.f;
+    for (int z0 = 0; z0 < a.ks; z0 += 8) {
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) t[j] = a.ws[(size_t)min(z0 + j, a.ks - 1) * total + i];
+#pragma unroll
+      for (int j = 0; j < 8; j++) v += (z0 + j < a.ks) ? t[j] : 0.f;
+    }
+    if (a.add) v = a.add[(size_t)m * a.add_ld + n] + v;
+    a.Cm[(size_t)m * a.ldc + n] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // all gradient accumulations of one minibatch in ONE launch (...streams.h:468-487):
 //   blocks [0, nb0)        W_gifo_x_corr = beta*corr + DGIFO^T * in
@@ -2278,6 +2318,35 @@ hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, con
   r.C2 = C2; r.ldc2 = ldc2; r.C3 = C3; r.tail0 = tail0;
   const long nb = ((long)M * N + 255) / 256;
   KLAUNCH(k_splitk_reduce, dim3((unsigned)(nb > 2048 ? 2048 : nb)), block, st, pr2, r);
+}
+
+// Folded BPTT tail: d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r (:391) and, if in_diff != nullptr,
+// in_diff = dgifo(1..T) W_gifo_x (:457).  ws: bwd_tail_ws_floats(d) floats.
+size_t bwd_tail_ws_floats(const Dims &d) {
+  int kl = 0;
+  const int ks = gemm_splitk_plan(d.T * d.S, d.R, 4 * d.C, &kl);
+  return (size_t)ks * d.T * d.S * (d.R + d.I);
+}
+hipError_t launch_bwd_tail(const Dims &d, const float *dgifo, const float *wr, const float *wx, const float *out_diff,
+                           int od_stride, float *dr, float *in_diff, int id_stride, float *ws, hipStream_t st, LaunchProbe pr,
+                           LaunchProbe pr2) {
+  const int M = d.T * d.S, K4 = 4 * d.C;
+  int kl = 0;
+  const int ks = gemm_splitk_plan(M, d.R, K4, &kl);
+  const GemmJob g1 = make_job(false, false, M, d.R, K4, dgifo + (size_t)2 * d.S * K4, K4, wr, d.R, 0.f, nullptr, d.R, nullptr);
+  const GemmJob g2 = make_job(false, false, M, d.I, K4, dgifo + (size_t)d.S * K4, K4, wx, d.I, 0.f, nullptr, d.I, nullptr);
+  const int nb1 = cdiv(M, GT) * cdiv(d.R, GT), nb2 = in_diff ? cdiv(M, GT) * cdiv(d.I, GT) : 0;
+  float *ws2 = ws + (size_t)ks * M * d.R;
+  auto first = [&]() -> hipError_t { KLAUNCH(k_gemm_splitk2, dim3(nb1 + nb2, 1, ks), dim3(256), st, pr, g1, g2, nb1, kl, ws, ws2); };
+  hipError_t err = first();
+  if (err != hipSuccess) return err;
+  ReduceArgs r1, r2;
+  r1.ws = ws; r1.ks = ks; r1.M = M; r1.N = d.R; r1.beta = 0.f; r1.Cm = dr + (size_t)d.S * d.R; r1.ldc = d.R; r1.bias = nullptr;
+  r1.add = out_diff; r1.add_ld = od_stride; r1.C2 = nullptr; r1.ldc2 = 0; r1.C3 = nullptr; r1.tail0 = 0;
+  r2 = r1;
+  r2.ws = ws2; r2.N = d.I; r2.Cm = in_diff; r2.ldc = id_stride; r2.add = nullptr; r2.add_ld = 0;
+  const int nbr1 = cdiv(M * d.R, 256), nbr2 = in_diff ? cdiv(M * d.I, 256) : 0;
+  KLAUNCH(k_splitk_reduce2, dim3(nbr1 + nbr2), dim3(256), st, pr2, r1, r2, nbr1);
 }
 
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
