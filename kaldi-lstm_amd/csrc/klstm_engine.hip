@@ -71,7 +71,7 @@ struct klstm_engine {
   bool fold_dirty = true;  // W_rm / its packed copies are older than the parameters
   int pk_stale = 0;        // unfolded operand arrays (bits 1..3) not refreshed by the last Update because the folded path is in use
   bool fwd_folded = false; // the last propagate ran the folded chain (its backpropagate follows suit)
-  float *wrm = nullptr, *wrmT = nullptr, *pk_fold[2] = {nullptr, nullptr};
+  float *pk_fold[2] = {nullptr, nullptr};   // packed [W_rm | W_x] (gates order) and W_rm^T (4-row geometry)
   float *Pm = nullptr;     // out_diff * W_r_m for all frames [(T_alloc) S x C]
   float *ws = nullptr;     // split-K workspace of the batched d_r / in_diff products
   size_t ws_floats = 0;
@@ -192,19 +192,17 @@ static klstm_status ensure_packs(klstm_engine *e) {
 }
 static klstm_status ensure_fold(klstm_engine *e) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
-  if (!e->wrm) {
+  if (!e->pk_fold[0]) {
     long nf[2];
     pack_sizes_fold(d, nf);
-    HIPCHK(hipMalloc(&e->wrm, (size_t)4 * e->C * e->C * sizeof(float)));
-    HIPCHK(hipMalloc(&e->wrmT, (size_t)4 * e->C * e->C * sizeof(float)));
-    HIPCHK(hipMalloc(&e->pk_fold[0], (size_t)nf[0] * 16));
-    HIPCHK(hipMalloc(&e->pk_fold[1], (size_t)nf[1] * 16));
+    for (int i = 0; i < 2; i++) {
+      HIPCHK(hipMalloc(&e->pk_fold[i], (size_t)nf[i] * 16));
+      HIPCHK(hipMemsetAsync(e->pk_fold[i], 0, (size_t)nf[i] * 16, e->stream));   // padding rows / k tails stay zero
+    }
     e->fold_dirty = true;
   }
   if (!e->fold_dirty) return KLSTM_OK;
-  HIPCHK(launch_fold(d, e->params, e->wmT, e->wrm, e->wrmT, e->stream, probe(e, "k_fold")));
-  HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, e->stream, probe(e, "k_pack_fold"), e->wrm, e->wrmT,
-                     e->pk_fold));
+  HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, e->stream, probe(e, "k_fold"), probe(e, "k_pack_foldx")));
   e->fold_dirty = false;
   return KLSTM_OK;
 }
@@ -291,7 +289,7 @@ void klstm_destroy(klstm_engine *e) {
   for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
   free_planes(e);
   float *ps[] = {e->params, e->grads_own ? e->grads_own : e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3],
-                 e->wrm, e->wrmT, e->pk_fold[0], e->pk_fold[1]};
+                 e->pk_fold[0], e->pk_fold[1]};
   for (float *p : ps) if (p) (void)hipFree(p);
   if (e->flags_dev) (void)hipFree(e->flags_dev);
   for (float *p : e->stage) if (p) (void)hipFree(p);
@@ -455,7 +453,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
   hipStream_t st = e->stream;
   if (e->fwd_folded) {
     const float *wx = e->params + e->o_wx(), *wr = e->params + e->o_wr(), *wm = e->params + e->o_wm();
-    const int M = T * d.S, K4 = 4 * d.C;
+    const int M = T * d.S;
     // P = out_diff W_r_m for all frames; chain of T folded steps; then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r
     // (:391, feeds the W_r_m gradient :486) and in_diff = dgifo W_gifo_x (:457) as split-K products
     int kl = 0;
@@ -914,7 +912,7 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
   const Dims d{e->I, e->C, e->R, e->S, T};
   { klstm_status ps = ensure_packs(e); if (ps != KLSTM_OK) return ps; }
   const std::string w0(what);
-  if (w0 == "gates_fold" || w0 == "dmf" || w0 == "fold" || w0 == "fold_gemm" || w0 == "fold_pack" || w0 == "rbatch" || w0 == "bwd_tail") {
+  if (w0 == "gates_fold" || w0 == "dmf" || w0 == "fold" || w0 == "fold_gemm" || w0 == "rbatch" || w0 == "bwd_tail") {
     if (!e->pk[0] || e->use_bf16) return fail(KLSTM_ERR_SHAPE, "folded path not available for this engine");
     klstm_status fs = ensure_fold(e);
     if (fs != KLSTM_OK) return fs;
@@ -934,12 +932,7 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
       const int t = 1 + (i % T);
       if (w == "gates_fold") HIPCHK(launch_gates_step(d, fp, t < 2 ? 2 : t, fx, xin, e->I, st, LaunchProbe(), true));
       else if (w == "dmf") HIPCHK(launch_dmf_step(d, bp, t < T ? t : 1, e->Pm, st));
-      else if (w == "fold") {
-        HIPCHK(launch_fold(d, e->params, e->wmT, e->wrm, e->wrmT, st));
-        HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, st, LaunchProbe(), e->wrm, e->wrmT, e->pk_fold));
-      }
-      else if (w == "fold_gemm") HIPCHK(launch_fold(d, e->params, e->wmT, e->wrm, e->wrmT, st));
-      else if (w == "fold_pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 48, false, st, LaunchProbe(), e->wrm, e->wrmT, e->pk_fold));
+      else if (w == "fold" || w == "fold_gemm") HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, st));
       else if (w == "rbatch") HIPCHK(launch_rbatch(d, fp, scratch_out, e->R, e->ws, st));
       else if (w == "bwd_tail") HIPCHK(launch_bwd_tail(d, e->dgifo, e->params + e->o_wr(), e->params + e->o_wx(), scratch_out, e->R,
                                                        e->dr, xdiff, e->I, e->ws, st));

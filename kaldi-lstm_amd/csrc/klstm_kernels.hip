@@ -1410,38 +1410,28 @@ __global__ __launch_bounds__(NW * 64) void k_dmf_v(DmfArgs a) {
 struct PackArgs {
   int C, R, I;
   const float *wx, *wr, *wm, *wrT, *wmT, *wxT;
-  const float *wrm, *wrmT;   // folded product W_gifo_r * W_r_m [4C x C] and its transpose [C x 4C] (arrays 4, 5)
-  float4 *pk[6];
-  long n4[6];          // 16-byte vector count of each array (0: array not selected in this launch)
-  int nch[6];          // chunks per tile
+  float4 *pk[4];
+  long n4[4];          // 16-byte vector count of each array (0: array not selected in this launch)
+  int nch[4];          // chunks per tile
   int bf16;            // 1: entries are 8 bf16 (RNE of the fp32 master) covering k..k+7 -> half as many vectors
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
   const int C = a.C, R = a.R, I = a.I;
-  const long total = a.n4[0] + a.n4[1] + a.n4[2] + a.n4[3] + a.n4[4] + a.n4[5];
+  const long total = a.n4[0] + a.n4[1] + a.n4[2] + a.n4[3];
   for (long gid = blockIdx.x * 256L + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
     int arr = 0; long id = gid;
-    while (id >= a.n4[arr]) { id -= a.n4[arr]; arr++; }   // gid < total, so arr stays < 6
+    while (id >= a.n4[arr]) { id -= a.n4[arr]; arr++; }
     const int lane = (int)(id & 63), h = a.bf16 ? 0 : (int)((id >> 6) & 1);
     const long tc = a.bf16 ? id >> 6 : id >> 7;
     const int nch = a.nch[arr];
     const int tile = (int)(tc / nch), ch = (int)(tc - (long)tile * nch);
     const int i = lane & 15;
-    const int k = arr == 5 ? ch * KCH4 + h * 64 + (lane >> 2) * 4 : ch * KCH + (lane >> 4) * 8 + h * 4;
+    const int k = ch * KCH + (lane >> 4) * 8 + h * 4;
     const float *src = nullptr;
     int klim = 0, koff = k;
     bool row_ok = false;
-    if (arr == 4) {           // folded gates: rows as array 0, k over [C | pad | I | pad] from W_rm and W_x
-      const int cell = tile * 4 + (i >> 2), gate = i & 3;
-      row_ok = cell < C;
-      const int nchM = (C + KCH - 1) / KCH;
-      if (ch < nchM) { src = a.wrm + ((size_t)gate * C + (row_ok ? cell : 0)) * C; klim = C; }
-      else { src = a.wx + ((size_t)gate * C + (row_ok ? cell : 0)) * I; klim = I; koff = k - nchM * KCH; }
-    } else if (arr == 5) {    // folded d_m: 4-row geometry, rows = cells of W_rm^T [C x 4C], k over 4C
-      const int c = tile * 4 + (lane & 3);
-      row_ok = c < C; src = a.wrmT + (size_t)(row_ok ? c : 0) * 4 * C; klim = 4 * C;
-    } else if (arr == 0) {
+    if (arr == 0) {
       const int cell = tile * 4 + (i >> 2), gate = i & 3;
       row_ok = cell < C;
       const int nchR = (R + KCH - 1) / KCH;
@@ -1488,6 +1478,11 @@ struct GemmJob {
   float *C2; int ldc2;    // second copy      C2[m][n]
   float *C3; int tail0;   // rows m >= tail0 also to C3[m - tail0][n], dense (ld = N)
   int dbg;                // diagnostics: 6 = no result stores, 7 = no global fetch inside the K loop
+  // fold product only (launch_fold): rows of A are read in gates-packed order (gperm = C) and the result goes straight
+  // into the two packed operand arrays of the folded step kernels instead of Cm
+  int gperm;
+  float4 *pk1; int nch1;  // [W_rm | W_x] gates array: [C/4 tiles][nch1 chunks of 32][2][64]
+  float4 *pk2; int nch2;  // W_rm^T 4-row array:       [C/4 tiles][nch2 chunks of 128][2][64]
 };
 
 // One operand tile = GT x GK elements = 2 x (8 floats per thread).  Operand stored [X x K] (TA=false: 8 consecutive k
@@ -1495,12 +1490,14 @@ struct GemmJob {
 // contiguous extent a multiple of 8 -> branch-free loads.
 template <bool TA>
 __device__ __forceinline__ void fetch_tile(const float *__restrict__ P, int ld, bool vec, int X, int K, int x0, int k0,
-                                           int tid, float (&r)[2][8]) {
+                                           int tid, float (&r)[2][8], int gperm = 0) {
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     if (!TA) {
       const int x = x0 + (tid >> 2), k = k0 + h * 32 + (tid & 3) * 8;
-      const float *row = P + (size_t)(x < X ? x : 0) * ld;
+      // gperm = C: logical row x = 4*cell + gate of the gates-packed order reads stored row gate*C + cell
+      const int xs = x < X ? (gperm ? (x & 3) * gperm + (x >> 2) : x) : 0;
+      const float *row = P + (size_t)xs * ld;
       if (vec) load8<true>(row, k, K, x < X, r[h]); else load8<false>(row, k, K, x < X, r[h]);
     } else {
       const int k = k0 + h * 32 + (tid >> 3), x = x0 + (tid & 7) * 8;
@@ -1540,7 +1537,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
     for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
 
   float ra[2][8], rb[2][8];
-  fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, 0, tid, ra);
+  fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, 0, tid, ra, g.gperm);
   fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, 0, tid, rb);   // B [N x K] when TB, else [K x N]
   // beta != 0 (momentum folded into the gradient products, :468-487): the old C tile is requested now so that its
   // HBM latency hides under the K loop instead of sitting in front of the stores
@@ -1565,7 +1562,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
     stash_tile<!TB>(Bs, tid, rb);
     __syncthreads();
     if (k0 + GK < g.K && g.dbg != 7) {
-      fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0 + GK, tid, ra);
+      fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0 + GK, tid, ra, g.gperm);
       fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, k0 + GK, tid, rb);
     }
     // full K tiles run a fully unrolled 16-step body (a runtime trip count defeats the unroller and leaves a rolled
@@ -1608,6 +1605,47 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
       for (int kk = 0; kk < ksteps; kk++) kstep(kk);
     }
     __syncthreads();
+  }
+  if (g.pk1) {
+    // tile rows are in gates-packed order: row r = 4*(cell - cell0) + gate, cell0 = m0/4 (a multiple of 16); columns are
+    // the k axis of the folded gates operand and the row (cell) axis of the folded d_m operand.  Stage the tile in LDS,
+    // then every thread writes 16-byte pieces in DESTINATION order (runs of 1 KB / 256 B).
+    constexpr int CLD = 68;
+    float *Cs = As;                                    // 64 x 68 floats <= GLDS; the K loop ended with a barrier
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+      for (int ni = 0; ni < 2; ni++) {
+        const float e[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) Cs[(wr * 32 + mi * 16 + 4 * kg + r) * CLD + wc * 32 + ni * 16 + i16] = e[r];
+      }
+    __syncthreads();
+    const int C = g.gperm, cell0 = m0 >> 2;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int p = tid + 256 * u;
+      {   // gates array: piece = (packed tile pt, chunk half chl, h, lane16 = kgrp*16 + i) -> row pt*16 + i, cols chl*32 + kgrp*8 + h*4
+        const int pt = p >> 8, chl = (p >> 7) & 1, h = (p >> 6) & 1, l16 = p & 63, i = l16 & 15;
+        const int nl = chl * 32 + (l16 >> 4) * 8 + h * 4, n = n0 + nl;
+        const int cell = cell0 + pt * 4 + (i >> 2);
+        if (cell < C && n < g.N) {
+          const float4 v = *reinterpret_cast<const float4 *>(Cs + (pt * 16 + i) * CLD + nl);
+          g.pk1[(((size_t)(cell >> 2) * g.nch1 + (n >> 5)) * 2 + h) * 64 + l16] = v;
+        }
+      }
+      {   // d_m array: piece = (column quad ct, gate, cell quad kq, cq = column % 4) -> 4 cells of one gate at one column
+        const int cq = p & 3, kq = (p >> 2) & 3, gate = (p >> 4) & 3, ct = p >> 6;
+        const int c = n0 + ct * 4 + cq, cell = cell0 + kq * 4;
+        if (c < g.N && cell < C) {
+          const float *cp = Cs + (kq * 16 + gate) * CLD + ct * 4 + cq;
+          const float4 v = make_float4(cp[0], cp[4 * CLD], cp[8 * CLD], cp[12 * CLD]);
+          const int k = gate * C + cell;
+          g.pk2[(((size_t)(c >> 2) * g.nch2 + (k >> 7)) * 2 + ((k >> 6) & 1)) * 64 + ((k & 63) >> 2) * 4 + cq] = v;
+        }
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int mi = 0; mi < 2; mi++)
@@ -2199,16 +2237,38 @@ hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *
 }
 
 // W_rm = W_gifo_r [4C x R] * W_r_m [R x C], natural [4C x C] and transposed [C x 4C], once per Update
-extern int g_dmf_dbg;
-hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *wrm, float *wrmT, hipStream_t st,
-                       LaunchProbe pr) {
-  // NT form on the transposed copy W_r_m^T [C x R]: both operands k-contiguous (the 16-byte LDS operand reads)
+// x chunks of the folded gates array (the W_rm chunks are written by the fold product itself)
+__global__ __launch_bounds__(256) void k_pack_foldx(const float *__restrict__ wx, float4 *__restrict__ pk, int C, int I, int nch1) {
+  const int nchM = (C + KCH - 1) / KCH, nchX = nch1 - nchM;
+  const long total = (long)((C + 3) / 4) * nchX * 128;
+  for (long id = blockIdx.x * 256L + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int lane = (int)(id & 63), h = (int)((id >> 6) & 1);
+    const long tc = id >> 7;
+    const int tile = (int)(tc / nchX), chx = (int)(tc - (long)tile * nchX);
+    const int i = lane & 15, cell = tile * 4 + (i >> 2), gate = i & 3;
+    const int k = chx * KCH + (lane >> 4) * 8 + h * 4;
+    float4 v = f4zero();
+    if (cell < C && k + 4 <= I) v = ldg4(wx + ((size_t)gate * C + cell) * I + k);
+    pk[(((size_t)tile * nch1 + nchM + chx) * 2 + h) * 64 + lane] = v;
+  }
+}
+
+// W_rm = W_gifo_r [4C x R] * W_r_m [R x C] once per Update, written directly as the two packed operands of the folded
+// step kernels (NT form on the transposed copy W_r_m^T [C x R]: both operands k-contiguous); then the x chunks.
+// pk_fold[0/1] must have been zero-filled once (padding rows / k tails are never written).
+hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], hipStream_t st,
+                       LaunchProbe pr, LaunchProbe pr2) {
   const long o_wr = (long)4 * d.C * d.I;
-  GemmJob g = make_job(false, true, 4 * d.C, d.C, d.R, param_blob + o_wr, d.R, wmT, d.R, 0.f, wrm, d.C, nullptr);
-  g.Ct = wrmT; g.ldct = 4 * d.C;
-  g.dbg = g_dmf_dbg;
+  GemmJob g = make_job(false, true, 4 * d.C, d.C, d.R, param_blob + o_wr, d.R, wmT, d.R, 0.f, nullptr, d.C, nullptr);
+  g.gperm = d.C;
+  g.pk1 = reinterpret_cast<float4 *>(pk_fold[0]); g.nch1 = cdiv(d.C, KCH) + cdiv(d.I, KCH);
+  g.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); g.nch2 = cdiv(4 * d.C, KCH4);
   const dim3 grid(cdiv(cdiv(d.C, GT) * cdiv(4 * d.C, GT), 8) * 8), block(256);
-  KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
+  auto first = [&]() -> hipError_t { KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g); };
+  hipError_t err = first();
+  if (err != hipSuccess) return err;
+  const long nx = (long)cdiv(d.C, 4) * cdiv(d.I, KCH) * 128;
+  KLAUNCH(k_pack_foldx, dim3((unsigned)cdiv((int)nx, 256)), block, st, pr2, param_blob, g.pk1, d.C, d.I, g.nch1);
 }
 
 // r(1..T) = m(1..T) W_r_m^T (:312) for all frames at once -> rr rows, out rows (:328), last block -> prev_r (:331)
@@ -2241,18 +2301,9 @@ void pack_sizes(const Dims &d, long n4[4]) {
   n4[3] = (long)cdiv(d.C, 16) * cdiv(d.R, KCH) * 128;
 }
 hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
-                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr, const float *wrm,
-                       const float *wrmT, float *pk_fold[2]) {
+                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr) {
   PackArgs a;
   a.bf16 = bf16 ? 1 : 0;
-  a.wrm = wrm; a.wrmT = wrmT;
-  a.n4[4] = a.n4[5] = 0; a.pk[4] = a.pk[5] = nullptr;
-  a.nch[4] = cdiv(d.C, KCH) + cdiv(d.I, KCH); a.nch[5] = cdiv(4 * d.C, KCH4);
-  if (pk_fold && !bf16) {                      // mask bits 4, 5: the two folded operands (fp32 only)
-    long nf[2];
-    pack_sizes_fold(d, nf);
-    for (int i = 0; i < 2; i++) if (mask & (16 << i)) { a.n4[4 + i] = nf[i]; a.pk[4 + i] = reinterpret_cast<float4 *>(pk_fold[i]); }
-  }
   a.C = d.C; a.R = d.R; a.I = d.I;
   const long o_wr = (long)4 * d.C * d.I, o_wm = o_wr + (long)4 * d.C * d.R + 7 * d.C;
   a.wx = param_blob; a.wr = param_blob + o_wr; a.wm = param_blob + o_wm;
@@ -2260,7 +2311,7 @@ hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT,
   pack_sizes(d, a.n4);
   for (int i = 0; i < 4; i++) { if (!(mask & (1 << i))) a.n4[i] = 0; if (bf16) a.n4[i] /= 2; }
   a.nch[0] = cdiv(d.R, KCH) + cdiv(d.I, KCH); a.nch[1] = cdiv(d.C, KCH); a.nch[2] = cdiv(4 * d.C, KCH); a.nch[3] = cdiv(d.R, KCH);
-  long total = a.n4[4] + a.n4[5];
+  long total = 0;
   for (int i = 0; i < 4; i++) { a.pk[i] = reinterpret_cast<float4 *>(pk[i]); total += a.n4[i]; }
   if (total == 0) return hipSuccess;
   const long nb = (total + 255) / 256;
@@ -2273,6 +2324,7 @@ static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const flo
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.beta = beta;
   g.Cm = Cm; g.ldc = ldc; g.bias = bias;
   g.Ct = nullptr; g.ldct = 0; g.C2 = nullptr; g.ldc2 = 0; g.C3 = nullptr; g.tail0 = 0; g.dbg = 0;
+  g.gperm = 0; g.pk1 = nullptr; g.nch1 = 0; g.pk2 = nullptr; g.nch2 = 0;
   // branch-free 8-wide fetches need aligned rows and a contiguous extent that is a multiple of 8
   g.vecA = aligned16(A) && lda % 4 == 0 && (transA ? M : K) % 8 == 0;
   g.vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K : N) % 8 == 0;

@@ -31,7 +31,7 @@ print("fwd+bwd(no indiff): %8.1f us" % timeit(fb2))
 print("fwd+bwd+update   : %8.1f us" % timeit(fbu))
 lib = e.lib
 lib.klstm_debug_chain.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
-for w in ("gates_fold", "dmf", "fold", "fold_gemm", "fold_pack", "rbatch", "bwd_tail", "gates", "proj", "gates+proj", "dr", "dm", "dr+dm", "grads", "update", "pack", "pack_fwd"):
+for w in ("gates_fold", "dmf", "fold", "rbatch", "bwd_tail", "gates", "proj", "gates+proj", "dr", "dm", "dr+dm", "grads", "update", "pack", "pack_fwd"):
     us = ctypes.c_float()
     rc = lib.klstm_debug_chain(e.h, w.encode(), 200, ctypes.byref(us))
     print("chain %-11s: %6.2f us/launch (rc=%d)" % (w, us.value, rc))
