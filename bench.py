@@ -43,20 +43,26 @@ PEAK_HBM_TBS = 8.0                                     # MI355X_MICROARCH.md: HB
 
 
 def kernel_flops(name, S):
-    """Algorithmic FLOPs of one launch (contraction only)."""
-    return {"k_gates_step": 2.0 * S * 4 * C_DIM * (R_DIM + I_DIM), "k_proj_step": 2.0 * S * R_DIM * C_DIM,
-            "k_dr_step": 2.0 * S * 4 * C_DIM * (R_DIM + I_DIM), "k_dm_step": 2.0 * S * R_DIM * C_DIM}[name]
+    """FLOPs of one launch (contraction only).  The folded step kernels contract over the cell axis through
+    W_rm = W_gifo_r W_r_m: more FLOPs per step than the reference's two products, one launch instead of two."""
+    C, R, I = C_DIM, R_DIM, I_DIM
+    return {"k_gates_step": 2.0 * S * 4 * C * (R + I), "k_proj_step": 2.0 * S * R * C,
+            "k_dr_step": 2.0 * S * 4 * C * (R + I), "k_dm_step": 2.0 * S * R * C,
+            "k_gates_fold": 2.0 * S * 4 * C * (C + I), "k_dmf_step": 2.0 * S * C * 4 * C}[name]
 
 
 def kernel_bytes(name, S):
     """Algorithmic HBM bytes of one launch: the weight operand has to be streamed once per step (nothing
     on-chip survives a kernel boundary) plus the activation rows read and written."""
     C, R, I = C_DIM, R_DIM, I_DIM
-    w = {"k_gates_step": 4 * C * (R + I), "k_proj_step": R * C, "k_dr_step": (R + I) * 4 * C, "k_dm_step": C * R}[name]
+    w = {"k_gates_step": 4 * C * (R + I), "k_proj_step": R * C, "k_dr_step": (R + I) * 4 * C, "k_dm_step": C * R,
+         "k_gates_fold": 4 * C * (C + I), "k_dmf_step": C * 4 * C}[name]
     act = {"k_gates_step": S * (R + I + C) + 7 * C + S * 7 * C,              # r, x, c(t-1), bias+peepholes | gifo, c, h, m
            "k_proj_step": S * C + 2 * S * R,                                 # m | r, out
            "k_dr_step": S * 4 * C + 4 * S * (R + I),                         # dgifo(t+1) | 4 split-K slabs
-           "k_dm_step": S * R * 5 + S * C * 10 + 3 * C + S * R + S * C * 5   # out_diff + slabs, 10 cell operands | d_r, dgifo, dc
+           "k_dm_step": S * R * 5 + S * C * 10 + 3 * C + S * R + S * C * 5,  # out_diff + slabs, 10 cell operands | d_r, dgifo, dc
+           "k_gates_fold": S * (C + I + C) + 7 * C + S * 7 * C,              # m(t-1), x, c(t-1), bias+peepholes | gifo, c, h, m
+           "k_dmf_step": S * 4 * C + S * C * 11 + 3 * C + S * C * 5          # dgifo(t+1), P + 10 cell operands | dgifo, dc
            }[name]
     return 4.0 * (w + act)
 
@@ -211,6 +217,8 @@ def main():
             step(args.warmup + args.steps + 3 + i)
         kern = {}
         for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj",
+                     "k_gates_fold", "k_gemm_rbatch", "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step",
+                     "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx",
                      "k_grads", "k_update_repack", "k_pack", "k_pack_fwd", "k_pack_bwd", "k_apply_momentum"):
             tot, n = eng.profile_query(name)
             if n:
@@ -223,17 +231,23 @@ def main():
     if rank == 0:
         # dominant kernel = the step kernel that carries the most algorithmic FLOPs per minibatch
         # (k_gates_step forward, k_dr_step backward: 2*S*4C*R each); of those, the slower one.
-        for n in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step"):
+        step_kernels = ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_gates_fold", "k_dmf_step")
+        for n in step_kernels:
             if n in kern:
                 kern[n]["tflops"] = kernel_flops(n, S) / (kern[n]["avg_us"] * 1e-6) / 1e12
-        dom = max((n for n in kern if n in ("k_gates_step", "k_dr_step")), key=lambda n: kern[n]["us_per_step"])
+                kern[n]["gbs"] = kernel_bytes(n, S) / (kern[n]["avg_us"] * 1e-6) / 1e9
+        folded = "k_dmf_step" in kern
+        # dominant kernel = the step kernel with the most device time per minibatch (folded chain: k_gates_fold forward,
+        # k_dmf_step backward; reference-shaped chain: k_gates_step / k_dr_step, which carry the FLOPs)
+        cand = ("k_gates_fold", "k_dmf_step") if folded else ("k_gates_step", "k_dr_step")
+        dom = max((n for n in kern if n in cand), key=lambda n: kern[n]["us_per_step"])
         # roofline side: arithmetic intensity of a step kernel is ~S/2 FLOP/B (weights are re-streamed every step),
         # the ridge is 157.3 TF / 8 TB/s ~ 20 FLOP/B  ->  HBM-bound below S ~ 40, MFMA-bound above
         intensity = kernel_flops(dom, S) / kernel_bytes(dom, S)
         hbm_bound = intensity < PEAK_F32_MFMA_TF / PEAK_HBM_TBS
         tflops = kernel_flops(dom, S) / (kern[dom]["avg_us"] * 1e-6) / 1e12
         gbs = kernel_bytes(dom, S) / (kern[dom]["avg_us"] * 1e-6) / 1e9
-        tag = {"k_gates_step": "k_gates_v", "k_dr_step": "k_dr_v"}[dom]
+        tag = {"k_gates_step": "k_gates_v", "k_dr_step": "k_dr_v", "k_gates_fold": "k_gates_v", "k_dmf_step": "k_dmf_v"}[dom]
         res = {
             "metric": "frames/sec fwd+BPTT, 40in/800cell/512proj LSTM at 1/2/4/8 MI355X",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,6 +258,8 @@ def main():
                                    "(BASELINE.json configs[1])" % S,
                        "streams_per_gpu": S, "total_streams": S * world, "bptt": T_BPTT,
                        "frames_per_step": T_BPTT * S * world, "launch": launch,
+                       "recurrence": "folded (W_rm = W_gifo_r W_r_m, one kernel per step and direction)" if folded
+                                     else "reference-shaped (gates + projection, d_r + d_m kernels per step)",
                        "parallelism": "dp%d over streams, 1 all-reduce/minibatch" % world if world > 1 else "single GPU"},
             "roofline": ({"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
                           "frac": gbs / (PEAK_HBM_TBS * 1e3)} if hbm_bound else

@@ -68,6 +68,7 @@ struct klstm_engine {
   bool use_vector = true;
   bool use_fat = true;
   int use_fold = -1;       // folded recurrence (W_rm = W_gifo_r W_r_m): -1 auto, 0 off, 1 on (whenever the shape allows)
+  bool foldx_fresh = false; // the W_x chunks of pk_fold[0] were written by the last k_pack
   bool fold_dirty = true;  // W_rm / its packed copies are older than the parameters
   int pk_stale = 0;        // unfolded operand arrays (bits 1..3) not refreshed by the last Update because the folded path is in use
   bool fwd_folded = false; // the last propagate ran the folded chain (its backpropagate follows suit)
@@ -173,6 +174,7 @@ static klstm_status repack(klstm_engine *e) {
                               probe(e, "k_update_repack")));
   if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream, probe(e, "k_pack")));
   e->fold_dirty = true;
+  e->foldx_fresh = false;
   e->pk_stale = 0;
   return KLSTM_OK;
 }
@@ -180,8 +182,10 @@ static klstm_status repack(klstm_engine *e) {
 // ---- folded recurrence: policy, buffers, refresh of W_rm and its packed copies ----
 static bool fold_wanted(const klstm_engine *e, int T) {
   if (e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || e->S > get_small_max()) return false;
-  // one fold GEMM (2*4C*C*R flop) per Update against (T-1) saved projection launches and T-1 saved d_r launches
-  return e->use_fold == 1 ? T >= 2 : T >= 12;
+  // auto: one fold product (2*4C*C*R flop, ~41 us at 800/512) per Update against T-1 saved projection launches and T-1
+  // saved d_r launches; every group of 4 streams re-reads the (larger) folded operands, so the gain is gone by 12 streams
+  // (measured at 40/800/512, T = 20, fwd+bwd+update: 1 stream 361 -> 296 us, 4: 377 -> 311, 8: 406 -> 396, 12: 472 -> 522)
+  return e->use_fold == 1 ? T >= 2 : (T >= 12 && e->S <= 8);
 }
 static klstm_status ensure_packs(klstm_engine *e) {
   if (!e->pk_stale || !e->pk[0]) { e->pk_stale = 0; return KLSTM_OK; }
@@ -202,7 +206,9 @@ static klstm_status ensure_fold(klstm_engine *e) {
     e->fold_dirty = true;
   }
   if (!e->fold_dirty) return KLSTM_OK;
-  HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, e->stream, probe(e, "k_fold"), probe(e, "k_pack_foldx")));
+  HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, !e->foldx_fresh, e->stream, probe(e, "k_fold"),
+                     e->foldx_fresh ? LaunchProbe() : probe(e, "k_pack_foldx")));
+  e->foldx_fresh = true;
   e->fold_dirty = false;
   return KLSTM_OK;
 }
@@ -654,9 +660,11 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
   // while the folded chain is in use only the step-1 gates operand (array 0) is read; the others are refreshed on demand
   const int mask = e->fwd_folded ? 1 : 15;
-  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, mask, e->use_bf16, e->stream, probe(e, "k_pack")));
+  float *foldx = (e->fwd_folded && !e->use_bf16) ? e->pk_fold[0] : nullptr;
+  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, mask, e->use_bf16, e->stream, probe(e, "k_pack"), foldx));
   e->pk_stale = 15 & ~mask;
   e->fold_dirty = true;
+  e->foldx_fresh = foldx != nullptr;
   return KLSTM_OK;
 }
 
@@ -772,6 +780,7 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
     }
     e->event_pool.push_back(r.start); e->event_pool.push_back(r.stop);
   }
+  (void)hipGetLastError();      // a probe whose launch was skipped leaves a sticky error from hipEventElapsedTime
   e->probes.clear();
   auto it = e->prof.find(kernel);
   *total_us = it == e->prof.end() ? 0.0 : it->second.first;
@@ -932,7 +941,7 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
       const int t = 1 + (i % T);
       if (w == "gates_fold") HIPCHK(launch_gates_step(d, fp, t < 2 ? 2 : t, fx, xin, e->I, st, LaunchProbe(), true));
       else if (w == "dmf") HIPCHK(launch_dmf_step(d, bp, t < T ? t : 1, e->Pm, st));
-      else if (w == "fold" || w == "fold_gemm") HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, st));
+      else if (w == "fold" || w == "fold_gemm") HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, true, st));
       else if (w == "rbatch") HIPCHK(launch_rbatch(d, fp, scratch_out, e->R, e->ws, st));
       else if (w == "bwd_tail") HIPCHK(launch_bwd_tail(d, e->dgifo, e->params + e->o_wr(), e->params + e->o_wx(), scratch_out, e->R,
                                                        e->dr, xdiff, e->I, e->ws, st));

@@ -51,8 +51,9 @@ hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, bool fuse_x
 //   launch_gates_step(..., fold = true)   a(t) = W_x x(t) + b + W_rm m(t-1), t >= 2
 //   launch_rbatch   r(1..T) = m(1..T) W_r_m^T -> rr rows, out rows, prev_r
 //   launch_dmf_step d_m(t) = P(t) + dgifo(t+1) W_rm with P = out_diff W_r_m, then the elementwise BPTT (:411-440)
-hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], hipStream_t st,
-                       LaunchProbe pr = {}, LaunchProbe pr2 = {});   // pk_fold zero-filled once by the caller
+hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
+                       hipStream_t st, LaunchProbe pr = {}, LaunchProbe pr2 = {});
+                       // pk_fold zero-filled once by the caller; pack_x = false: launch_pack(.., foldx) already wrote the W_x chunks
 hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_stride, float *ws, hipStream_t st,
                          LaunchProbe pr = {}, LaunchProbe pr2 = {});   // ws: split-K workspace (gemm_splitk_plan(T*S, R, C) slices)
 hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *P, hipStream_t st, LaunchProbe pr = {});
@@ -113,7 +114,8 @@ void pack_sizes(const Dims &d, long n4[4]);         // float4 counts
 // mask: bit i selects array i (forward operands = 3, BPTT operands = 12);  bf16: pack as bf16 (same tile/chunk/lane
 // order, one 16-byte vector of 8 bf16 per lane and chunk -> half the bytes of the fp32 copies)
 hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
-                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr = {});
+                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr = {}, float *foldx = nullptr);
+                       // foldx (with mask bit 0, fp32): also write the W_x chunks into the folded gates array
 
 // out[dst] = in[clamp(dst + shift)] row gather (TimeShift; shift 0 = Transmit copy)
 hipError_t launch_time_shift(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, int shift,

@@ -1414,6 +1414,8 @@ struct PackArgs {
   long n4[4];          // 16-byte vector count of each array (0: array not selected in this launch)
   int nch[4];          // chunks per tile
   int bf16;            // 1: entries are 8 bf16 (RNE of the fp32 master) covering k..k+7 -> half as many vectors
+  float4 *foldx;       // fp32 only: the W_x chunks of array 0 are also the W_x chunks of the folded gates array
+  int nch_fold, nchm_fold;
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
@@ -1456,6 +1458,10 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
       v = __builtin_bit_cast(float4, make_uint4(lo.x, lo.y, hi.x, hi.y));
     }
     a.pk[arr][id] = v;
+    if (arr == 0 && a.foldx && !a.bf16) {
+      const int nchR = (R + KCH - 1) / KCH;
+      if (ch >= nchR) a.foldx[(((size_t)tile * a.nch_fold + a.nchm_fold + (ch - nchR)) * 2 + h) * 64 + lane] = v;
+    }
   }
 }
 
@@ -2256,8 +2262,8 @@ __global__ __launch_bounds__(256) void k_pack_foldx(const float *__restrict__ wx
 // W_rm = W_gifo_r [4C x R] * W_r_m [R x C] once per Update, written directly as the two packed operands of the folded
 // step kernels (NT form on the transposed copy W_r_m^T [C x R]: both operands k-contiguous); then the x chunks.
 // pk_fold[0/1] must have been zero-filled once (padding rows / k tails are never written).
-hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], hipStream_t st,
-                       LaunchProbe pr, LaunchProbe pr2) {
+hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
+                       hipStream_t st, LaunchProbe pr, LaunchProbe pr2) {
   const long o_wr = (long)4 * d.C * d.I;
   GemmJob g = make_job(false, true, 4 * d.C, d.C, d.R, param_blob + o_wr, d.R, wmT, d.R, 0.f, nullptr, d.C, nullptr);
   g.gperm = d.C;
@@ -2266,7 +2272,7 @@ hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT,
   const dim3 grid(cdiv(cdiv(d.C, GT) * cdiv(4 * d.C, GT), 8) * 8), block(256);
   auto first = [&]() -> hipError_t { KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g); };
   hipError_t err = first();
-  if (err != hipSuccess) return err;
+  if (err != hipSuccess || !pack_x) return err;
   const long nx = (long)cdiv(d.C, 4) * cdiv(d.I, KCH) * 128;
   KLAUNCH(k_pack_foldx, dim3((unsigned)cdiv((int)nx, 256)), block, st, pr2, param_blob, g.pk1, d.C, d.I, g.nch1);
 }
@@ -2301,9 +2307,11 @@ void pack_sizes(const Dims &d, long n4[4]) {
   n4[3] = (long)cdiv(d.C, 16) * cdiv(d.R, KCH) * 128;
 }
 hipError_t launch_pack(const Dims &d, const float *param_blob, const float *wrT, const float *wmT, const float *wxT,
-                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr) {
+                       float *pk[4], int mask, bool bf16, hipStream_t st, LaunchProbe pr, float *foldx) {
   PackArgs a;
   a.bf16 = bf16 ? 1 : 0;
+  a.foldx = reinterpret_cast<float4 *>(foldx);
+  a.nchm_fold = cdiv(d.C, KCH); a.nch_fold = a.nchm_fold + cdiv(d.I, KCH);
   a.C = d.C; a.R = d.R; a.I = d.I;
   const long o_wr = (long)4 * d.C * d.I, o_wm = o_wr + (long)4 * d.C * d.R + 7 * d.C;
   a.wx = param_blob; a.wr = param_blob + o_wr; a.wm = param_blob + o_wm;
