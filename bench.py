@@ -112,6 +112,14 @@ def cpu_baseline(S, budget_s):
             if dt >= budget and n >= 3:
                 return n, dt
 
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     nthr = min(ncores, 16)      # the products are GEMV-sized (M = NumStream): more threads only add fork/join cost
     n1, dt1 = timed(1, budget_s)
@@ -119,7 +127,7 @@ def cpu_baseline(S, budget_s):
     return {"value": n1 * T_BPTT * S / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
             "value_threaded": na * T_BPTT * S / dta, "cores_threaded": nthr, "host_cores": ncores,
             "sample": f"{n1} minibatches of {T_BPTT}x{S} frames ({dt1:.1f} s) on 1 thread, {na} ({dta:.1f} s) on "
-                      f"{nthr} OpenMP threads (host has {ncores} cores); oracle/lstmp_oracle.c fp32, un-fused reference op order"}
+                      f"{nthr} OpenMP threads ({cpu_model}, {ncores} logical cores); oracle/lstmp_oracle.c fp32, un-fused reference op order"}
 
 
 def main():
