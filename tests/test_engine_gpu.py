@@ -646,3 +646,62 @@ def test_folded_recurrence_config_shape_and_varying_T():
         e.update(1e-3); o.update(1e-3)
         assert relerr(e.get_params(), o.get_params()) <= 2e-5
     e.close()
+
+
+def test_folded_recurrence_state_bridge_reset_replay_and_deferred_momentum():
+    """The engine-level behaviours re-checked with the folded chain forced on: (a) chunked forward with carried state
+    equals the unchunked one to fp32 tolerance (NOT bit-exact here: the first step of every chunk is the unfolded kernel
+    over the carried r, inside one long call the same step runs folded) and Reset zeroes exactly the flagged streams;
+    (b) hipGraph replay equals plain launches bit for bit, also across Updates (the fold product is re-run outside the
+    graph); (c) deferred momentum (DP mode) equals the default path."""
+    import kaldi_lstm_amd as k
+    I, C, R, S = 40, 64, 32, 3
+    p = make_params(I, C, R, scale=0.2, seed=31)
+    rng = np.random.RandomState(31)
+    # (a)
+    a, b = make_engine(I, C, R, S, p), make_engine(I, C, R, S, p)
+    a.set_option("fold", 1); b.set_option("fold", 1)
+    x = rng.randn(12 * S, I).astype(np.float32)
+    full = torch.empty(12 * S, R, device="cuda"); xd = dev(x)
+    torch.cuda.synchronize()
+    a.propagate(xd, full)
+    parts, keep = [], []
+    for ck in range(3):
+        xk = dev(x[ck * 4 * S:(ck + 1) * 4 * S]); o = torch.empty(4 * S, R, device="cuda"); keep += [xk, o]
+        torch.cuda.synchronize()
+        b.propagate(xk, o); parts.append(o)
+    a.synchronize(); b.synchronize()
+    assert relerr(torch.cat(parts, 0).cpu().numpy(), full.cpu().numpy()) <= 2e-5
+    ca, ra = a.get_state(); cb, rb = b.get_state()
+    assert relerr(cb, ca) <= 2e-5 and relerr(rb, ra) <= 2e-5
+    b.reset([0, 1, 0])
+    c1, r1 = b.get_state()
+    assert np.all(c1[1] == 0) and np.all(r1[1] == 0) and np.array_equal(c1[[0, 2]], cb[[0, 2]])
+    a.close(); b.close()
+    # (b)
+    T = 6
+    x = dev(rng.randn(T * S, I)); od = dev(rng.randn(T * S, R))
+    res = []
+    for graph in (1, 0):
+        e = make_engine(I, C, R, S, p); e.set_option("fold", 1); e.set_option("graph", graph)
+        out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+        for _ in range(3):
+            e.propagate(x, out); e.backpropagate(x, od, idf, momentum=0.5); e.update(1e-3)
+        e.synchronize()
+        res.append((out.cpu().numpy(), idf.cpu().numpy(), e.get_corr(), e.get_params()))
+        e.close()
+    for g, h in zip(*res):
+        assert np.array_equal(g, h)
+    # (c)
+    a, b = make_engine(I, C, R, S, p), make_engine(I, C, R, S, p)
+    a.set_option("fold", 1); b.set_option("fold", 1)
+    for _ in range(3):
+        x = dev(rng.randn(T * S, I)); od = dev(rng.randn(T * S, R))
+        out = torch.empty(T * S, R, device="cuda")
+        torch.cuda.synchronize()
+        a.propagate(x, out); a.backpropagate(x, od, None, momentum=0.9); a.update(1e-2)
+        b.propagate(x, out); b.backpropagate(x, od, None, momentum=0.9, flags=k.DEFER_MOMENTUM)
+        b.apply_momentum(0.9); b.update(1e-2)
+        a.synchronize(); b.synchronize()
+    assert relerr(a.get_corr(), b.get_corr()) <= 1e-6 and relerr(a.get_params(), b.get_params()) <= 1e-6
+    a.close(); b.close()
