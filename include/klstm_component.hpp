@@ -228,6 +228,8 @@ class LstmProjectedStreams {
   int32 CellDim() const { return ncell_; }
   int32 NumStream() const { return nstream_; }
   klstm_engine *Engine() { EnsureEngine(); return eng_; }
+  // Engine tuning knobs without a reference counterpart ("fold", "bf16", "graph", ...; include/klstm.h klstm_set_option)
+  void SetEngineOption(const char *key, int value) { EnsureEngine(); Check(klstm_set_option(eng_, key, value)); }
 
  protected:
   virtual bool HasStreams() const { return true; }       // <NumStream> is serialised (:136-137)

@@ -154,6 +154,7 @@ int main(int argc, char **argv) {
       const int nsteps = atoi(argv[8]);
       const std::string prefix = argv[9];
       c->SetTrainOptions(opts);
+      if (const char *f = getenv("KLSTM_TEST_FOLD")) c->SetEngineOption("fold", atoi(f));   // folded recurrence forced on/off
       const int I = c->InputDim(), R = c->OutputDim();
       // pitched device matrices, like CuMatrix (cu-matrix.cc:67-73): stride > cols
       const int xs = I + 4, os = R + 8, ds = R + 4, is = I + 12;

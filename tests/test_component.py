@@ -117,8 +117,9 @@ def _relerr(a, b):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("marker,S,mode", [("<LstmProjectedStreams>", 4, "run_gpu"), ("<LstmProjected>", 1, "run_gpu"),
-                                           ("<LstmProjectedStreams>", 4, "run_gpu_host")])
-def test_component_train_steps_gpu(tmp_path, marker, S, mode):
+                                           ("<LstmProjectedStreams>", 4, "run_gpu_host"),
+                                           ("<LstmProjectedStreams>", 4, "run_gpu_fold"), ("<LstmProjected>", 1, "run_gpu_fold")])
+def test_component_train_steps_gpu(tmp_path, marker, S, mode, monkeypatch):
     """Reset -> (PropagateFnc, BackpropagateFnc, Update) x3 through the C++ mirror, pitched device
     matrices (run_gpu_host: pitched HOST matrices, staged by the adapter); <LstmProjected> = standard/
     semantics (zero history per call, +-50 clip in Update)."""
@@ -130,6 +131,9 @@ def test_component_train_steps_gpu(tmp_path, marker, S, mode):
     od = (300.0 * rng.randn(T * S, R)).astype(np.float32) if S == 1 else rng.randn(T * S, R).astype(np.float32)
     x.tofile(tmp_path / "x.raw"); od.tofile(tmp_path / "od.raw")
     lr, mmt, nsteps = 1e-4, 0.9, 3
+    if mode == "run_gpu_fold":                 # SetEngineOption("fold", 1): the folded chain behind the same Component calls
+        monkeypatch.setenv("KLSTM_TEST_FOLD", "1")
+        mode = "run_gpu"
     run(mode, tmp_path / "m.nnet", tmp_path / "x.raw", tmp_path / "od.raw", T * S, lr, mmt, nsteps, tmp_path / "res")
     o = Oracle(I, C, R, S, np.float32); o.set_params(flat)
     std = marker == "<LstmProjected>"
