@@ -1263,38 +1263,45 @@ constexpr int KCH4 = 128;
 __device__ __forceinline__ float perm(int byte_idx, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_idx, __builtin_bit_cast(int, v)));
 }
-template <int CPW>
-__device__ __forceinline__ void vec_contract_r4(const float4 *__restrict__ apk, int nch, int K, const float *__restrict__ brow,
-                                                bool bok, int lane, int wave, int rot, int dbg, f32x4 (&acc)[2]) {
+// NG stream groups of 4 share one fetch of the weight chunk.  brow: row pointer of the LOADER lane's stream within group 0
+// (clamped per group by the caller through gstride = 4*K or 0), bok[g]: the CONSUMER lane's stream of group g exists.
+template <int CPW, int NG>
+__device__ __forceinline__ void vec_contract_r4(const float4 *__restrict__ apk, int nch, int K, const float *const (&brow)[NG],
+                                                const bool (&bok)[NG], int lane, int wave, int rot, f32x4 (&acc)[NG][2]) {
   const int kg = lane >> 2;
   for (int base = 0; base < nch; base += CPW * NW) {
-    float4 a0[CPW], a1[CPW], b0[CPW], b1[CPW];
+    float4 a0[CPW], a1[CPW], b0[NG][CPW], b1[NG][CPW];
 #pragma unroll
     for (int c = 0; c < CPW; c++) {
       const int ch = base + c * NW + wave;
       int cl = min(ch, nch - 1) + rot;                             // clamped: always a valid chunk, unused if off
       cl = cl >= nch ? cl - nch : cl;                              // rotated: see k_dmf_v
       const float4 *ap = apk + (size_t)cl * 128 + lane;
-      if (dbg != 5) { a0[c] = ap[0]; a1[c] = ap[64]; } else { a0[c] = f4zero(); a1[c] = f4zero(); }
+      a0[c] = ap[0]; a1[c] = ap[64];
       // loader role: lane = 16*stream + q fetches float4 q of each 64-float half of the chunk (4 x 256 contiguous bytes
       // per instruction); the consumer lane 4b+j takes its operand from loader lane 16j+b below
       const int k = cl * KCH4 + (lane & 15) * 4;
-      if (dbg != 4) { b0[c] = ldg4(brow + min(k, K - 4)); b1[c] = ldg4(brow + min(k + 64, K - 4)); } else { b0[c] = f4zero(); b1[c] = f4zero(); }
+#pragma unroll
+      for (int g = 0; g < NG; g++) { b0[g][c] = ldg4(brow[g] + min(k, K - 4)); b1[g][c] = ldg4(brow[g] + min(k + 64, K - 4)); }
     }
 #pragma unroll
     for (int c = 0; c < CPW; c++) {
       const int ch = base + c * NW + wave;
       int cl = min(ch, nch - 1) + rot;
       cl = cl >= nch ? cl - nch : cl;
-      const bool on0 = ch < nch && bok && cl * KCH4 + kg * 4 < K, on1 = ch < nch && bok && cl * KCH4 + 64 + kg * 4 < K;
+      const bool k0 = ch < nch && cl * KCH4 + kg * 4 < K, k1 = ch < nch && cl * KCH4 + 64 + kg * 4 < K;
       const float av[8] = {a0[c].x, a0[c].y, a0[c].z, a0[c].w, a1[c].x, a1[c].y, a1[c].z, a1[c].w};
       const int src = (((lane & 3) << 4) | kg) << 2;               // byte index of loader lane 16j+b
-      const float p[8] = {perm(src, b0[c].x), perm(src, b0[c].y), perm(src, b0[c].z), perm(src, b0[c].w),
-                          perm(src, b1[c].x), perm(src, b1[c].y), perm(src, b1[c].z), perm(src, b1[c].w)};
-      const float bv[8] = {on0 ? p[0] : 0.f, on0 ? p[1] : 0.f, on0 ? p[2] : 0.f, on0 ? p[3] : 0.f,
-                           on1 ? p[4] : 0.f, on1 ? p[5] : 0.f, on1 ? p[6] : 0.f, on1 ? p[7] : 0.f};
 #pragma unroll
-      for (int j = 0; j < 8; j++) acc[j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 1], 0, 0, 0);
+      for (int g = 0; g < NG; g++) {
+        const bool on0 = k0 && bok[g], on1 = k1 && bok[g];
+        const float p[8] = {perm(src, b0[g][c].x), perm(src, b0[g][c].y), perm(src, b0[g][c].z), perm(src, b0[g][c].w),
+                            perm(src, b1[g][c].x), perm(src, b1[g][c].y), perm(src, b1[g][c].z), perm(src, b1[g][c].w)};
+        const float bv[8] = {on0 ? p[0] : 0.f, on0 ? p[1] : 0.f, on0 ? p[2] : 0.f, on0 ? p[3] : 0.f,
+                             on1 ? p[4] : 0.f, on1 ? p[5] : 0.f, on1 ? p[6] : 0.f, on1 ? p[7] : 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[g][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[g][j & 1], 0, 0, 0);
+      }
     }
   }
 }
@@ -1308,22 +1315,21 @@ struct DmfArgs {
   const float4 *wpk;       // packed W_rm^T, 4-row geometry: [C/4 tiles][nch_total chunks][2][64]
   int nch_total;           // chunks of 128 over 4C
   int nch;                 // chunks to contract: nch_total, or 0 at t == T (dgifo(T+1) = 0, :351)
-  int dbg;                 // diagnostics (tools/dmf_dbg.py): 4 = no B loads, 5 = no A loads
 };
 
-template <int CPW>
+template <int CPW, int NG>
 __global__ __launch_bounds__(NW * 64) void k_dmf_v(DmfArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  __shared__ f32x4 red[NW][4];
+  __shared__ f32x4 red[NW][NG][4];
   const int C = a.C, S = a.S, t = a.t, K = 4 * a.C;
   const int c0 = blockIdx.x * 4;
-  const int sbase = blockIdx.y * 4;
+  const int sbase = blockIdx.y * 4 * NG;
   const bool last = (t == a.T);
 
-  // ---- epilogue operands first: lanes 0..3 of wave 0 = streams sbase..sbase+3, cells c0..c0+3 each ----
-  const int e_s = sbase + lane;
-  const bool e_on = wave == 0 && lane < 4 && e_s < S;
+  // ---- epilogue operands first: lanes 0..3 of wave g = streams sbase+4g..sbase+4g+3, cells c0..c0+3 each ----
+  const int e_s = sbase + 4 * wave + lane;
+  const bool e_on = wave < NG && lane < 4 && e_s < S;
   const size_t row = (size_t)t * S + (e_on ? e_s : 0), rown = row + S, rowp = row - S;
   float yg[4], yi[4], yf[4], yo[4], yh[4], cpv[4], dcn[4], fn[4], din[4], dfn[4], wpi[4], wpf[4], wpo[4], pv[4];
   {
@@ -1346,28 +1352,37 @@ __global__ __launch_bounds__(NW * 64) void k_dmf_v(DmfArgs a) {
     load4<true>(a.P + (row - S) * C, c0, C, e_on, pv);   // frame t is row block t-1 of P
   }
 
-  f32x4 acc[2] = {(f32x4){0, 0, 0, 0}, (f32x4){0, 0, 0, 0}};
-  const int bj = sbase + (lane & 3);                             // consumer role: stream of the B operand
-  const float *brow = a.dgifo + ((size_t)(last ? t : t + 1) * S + min(sbase + (lane >> 4), S - 1)) * K;   // loader role
-  // every workgroup reads the SAME 4 x 4C activation rows: started at the same chunk they would all hit one L2 channel at
-  // a time, so workgroup w walks the chunks rotated by 7w (the weights are private, their order does not matter)
+  f32x4 acc[NG][2];
+  const float *brow[NG];
+  bool bok[NG];
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    acc[g][0] = (f32x4){0, 0, 0, 0}; acc[g][1] = (f32x4){0, 0, 0, 0};
+    bok[g] = sbase + 4 * g + (lane & 3) < S;                                                          // consumer role
+    brow[g] = a.dgifo + ((size_t)(last ? t : t + 1) * S + min(sbase + 4 * g + (lane >> 4), S - 1)) * K;   // loader role
+  }
+  // every workgroup reads the SAME activation rows: started at the same chunk they would all hit one L2 channel at a
+  // time, so workgroup w walks the chunks rotated by 7w (the weights are private, their order does not matter)
   const int rot = a.nch > 0 ? (int)((blockIdx.x * 7u) % (unsigned)a.nch) : 0;
-  vec_contract_r4<CPW>(a.wpk + (size_t)blockIdx.x * a.nch_total * 128, a.nch, K, brow, bj < S, lane, wave, rot, a.dbg, acc);
+  vec_contract_r4<CPW, NG>(a.wpk + (size_t)blockIdx.x * a.nch_total * 128, a.nch, K, brow, bok, lane, wave, rot, acc);
 
   // the 16 k-groups of a (row, stream) pair sit in the lanes with equal lane&3: xor butterfly (a+b == b+a bitwise, so
   // every lane ends with the same sum), then the 8 waves in fixed order
-  f32x4 v = acc[0] + acc[1];
 #pragma unroll
-  for (int m = 4; m < 64; m <<= 1) {
-    v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
+  for (int g = 0; g < NG; g++) {
+    f32x4 v = acc[g][0] + acc[g][1];
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) {
+      v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
+    }
+    if (lane < 4) red[wave][g][lane] = v;
   }
-  if (lane < 4) red[wave][lane] = v;
   __syncthreads();
 
   if (e_on) {
-    f32x4 s = red[0][lane];
+    f32x4 s = red[0][wave][lane];
 #pragma unroll
-    for (int w = 1; w < NW; w++) s += red[w][lane];
+    for (int w = 1; w < NW; w++) s += red[w][wave][lane];
     const float dm[4] = {s.x + pv[0], s.y + pv[1], s.z + pv[2], s.w + pv[3]};      // :408 with :391 substituted
     float og[4], oi[4], of[4], oo[4], oc[4];
 #pragma unroll
@@ -1483,7 +1498,6 @@ struct GemmJob {
   float *Ct; int ldct;    // transposed copy  Ct[n][m]  (M % 4 == 0)
   float *C2; int ldc2;    // second copy      C2[m][n]
   float *C3; int tail0;   // rows m >= tail0 also to C3[m - tail0][n], dense (ld = N)
-  int dbg;                // diagnostics: 6 = no result stores, 7 = no global fetch inside the K loop
   // fold product only (launch_fold): rows of A are read in gates-packed order (gperm = C) and the result goes straight
   // into the two packed operand arrays of the folded step kernels instead of Cm
   int gperm;
@@ -1567,7 +1581,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
     stash_tile<TA>(As, tid, ra);
     stash_tile<!TB>(Bs, tid, rb);
     __syncthreads();
-    if (k0 + GK < g.K && g.dbg != 7) {
+    if (k0 + GK < g.K) {
       fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0 + GK, tid, ra, g.gperm);
       fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, k0 + GK, tid, rb);
     }
@@ -1659,7 +1673,6 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
     for (int ni = 0; ni < 2; ni++) {
       const int n = n0 + wc * 32 + ni * 16 + i16;
       if (n >= g.N) continue;
-      if (g.dbg == 6 && acc[mi][ni].x != 12345.678f) continue;
       const float bv = g.bias ? g.bias[n] : 0.f;
       const float e[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
 #pragma unroll
@@ -2023,13 +2036,16 @@ static inline int pick_nt(int S) {
   } while (0)
 // vector kernels: SMALL (4x4x1_16b, S <= 4) with CPW in {1,2,4};  16x16x4 with (NT,CPW) in {(1,1),(1,2),(2,1),(4,1)}
 struct VecCfg { bool small; int nt, cpw; };
+int g_small_nt2 = -1;         // -1 auto, 0 never, 1 always
 int g_small_max = 12;           // largest NumStream served by the 4x4x1_16b geometry (4 streams per workgroup, grid.y = S/4);
                                 // measured at 40/800/512: S=8 406 vs 471 us, S=12 473 vs 491, S=16 522 vs 515 (16x16x4 wins)
-static inline VecCfg pick_vec(int S, int nch) {
+static inline VecCfg pick_vec(int S, int nch, bool gates = false) {
   VecCfg c;
   const int need = cdiv(nch, NW);
   c.small = S <= g_small_max;
-  if (c.small) { c.nt = 1; c.cpw = need <= 1 ? 1 : need == 2 ? 2 : 4; return c; }
+  // two stream groups per workgroup share one fetch of the weight tile: measured at 40/800/512 (g_small_nt2 = 1 forces
+  // it everywhere) it only pays for the gates kernel at 9+ streams (7.0 -> 5.7 us at 12; proj/dr/dm lose 0.4-1.0 us)
+  if (c.small) { c.nt = (S > 4 && (g_small_nt2 == 1 || (g_small_nt2 < 0 && gates && S > 8))) ? 2 : 1; c.cpw = need <= 1 ? 1 : need == 2 ? 2 : 4; return c; }
   c.nt = S <= 16 ? 1 : S <= 32 ? 2 : 4;
   c.cpw = (c.nt == 1 && need >= 2) ? 2 : 1;
   return c;
@@ -2037,6 +2053,11 @@ static inline VecCfg pick_vec(int S, int nch) {
 #define VEC_DISPATCH(KERN, cfg, grid, st, pr, args, ...)                                          \
   do {                                                                                            \
     const dim3 _blk(NW * 64);                                                                     \
+    if (cfg.small && cfg.nt == 2) {                                                               \
+      if (cfg.cpw == 1) KLAUNCH((KERN<2, 1, true __VA_ARGS__>), grid, _blk, st, pr, args);        \
+      if (cfg.cpw == 2) KLAUNCH((KERN<2, 2, true __VA_ARGS__>), grid, _blk, st, pr, args);        \
+      KLAUNCH((KERN<2, 4, true __VA_ARGS__>), grid, _blk, st, pr, args);                          \
+    }                                                                                             \
     if (cfg.small) {                                                                              \
       if (cfg.cpw == 1) KLAUNCH((KERN<1, 1, true __VA_ARGS__>), grid, _blk, st, pr, args);        \
       if (cfg.cpw == 2) KLAUNCH((KERN<1, 2, true __VA_ARGS__>), grid, _blk, st, pr, args);        \
@@ -2091,7 +2112,7 @@ hipError_t launch_gates_step(const Dims &d0, const FwdPtrs &p, int t, bool fuse_
       if (big) KLAUNCH((k_gates_f<4, 2, 32, false, false>), fgrid, dim3(NW * 64), st, pr, va);
       KLAUNCH((k_gates_f<4, 2, 16, false, false>), fgrid, dim3(NW * 64), st, pr, va);
     }
-    const VecCfg cfg = pick_vec(d.S, cdiv(d.R, KCH) + (fuse_x ? cdiv(d.I, KCH) : 0));
+    const VecCfg cfg = pick_vec(d.S, cdiv(d.R, KCH) + (fuse_x ? cdiv(d.I, KCH) : 0), true);
     const dim3 grid = vec_grid(cdiv(d.C, 4), d.S, cfg);
     if (p.bf16) {
       if (fuse_x) VEC_DISPATCH(k_gates_v, cfg, grid, st, pr, va, COMMA true COMMA true);
@@ -2135,9 +2156,8 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
   GEN_DISPATCH(k_proj_step, nt, grid, st, pr, a, );
 }
 
-int g_dmf_dbg = 0;
-void set_dmf_dbg(int v) { g_dmf_dbg = v; }
 void set_small_max(int s) { g_small_max = s; }
+void set_small_nt2(int v) { g_small_nt2 = v; }
 int get_small_max() { return g_small_max; }
 
 int dr_split_k(const Dims &d) {
@@ -2223,7 +2243,6 @@ hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *o
 static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const float *A, int lda, const float *B,
                         int ldb, float beta, float *Cm, int ldc, const float *bias);
 
-extern int g_dmf_dbg;
 hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *P, hipStream_t st, LaunchProbe pr) {
   DmfArgs a;
   a.C = d.C; a.S = d.S; a.T = d.T; a.t = t;
@@ -2231,18 +2250,20 @@ hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *
   a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.wpk = p.pk_fold;
   a.nch_total = cdiv(4 * d.C, KCH4);
   a.nch = t == d.T ? 0 : a.nch_total;
-  if (g_dmf_dbg == 1) a.nch = 0;
-  a.dbg = g_dmf_dbg;
-  const dim3 grid(cdiv(d.C, 4), cdiv(d.S, 4)), blk(NW * 64);
-  int need = cdiv(a.nch_total, NW);
-  if (g_dmf_dbg == 2) need = 2;
-  if (g_dmf_dbg == 3) need = 1;
-  if (need <= 1) KLAUNCH((k_dmf_v<1>), grid, blk, st, pr, a);
-  if (need == 2) KLAUNCH((k_dmf_v<2>), grid, blk, st, pr, a);
-  KLAUNCH((k_dmf_v<4>), grid, blk, st, pr, a);
+  const dim3 blk(NW * 64);
+  const int need = cdiv(a.nch_total, NW);
+  if (d.S > 4) {                               // two stream groups per workgroup share the weight fetch
+    const dim3 grid(cdiv(d.C, 4), cdiv(d.S, 8));
+    if (need <= 1) KLAUNCH((k_dmf_v<1, 2>), grid, blk, st, pr, a);
+    if (need == 2) KLAUNCH((k_dmf_v<2, 2>), grid, blk, st, pr, a);
+    KLAUNCH((k_dmf_v<4, 2>), grid, blk, st, pr, a);
+  }
+  const dim3 grid(cdiv(d.C, 4), cdiv(d.S, 4));
+  if (need <= 1) KLAUNCH((k_dmf_v<1, 1>), grid, blk, st, pr, a);
+  if (need == 2) KLAUNCH((k_dmf_v<2, 1>), grid, blk, st, pr, a);
+  KLAUNCH((k_dmf_v<4, 1>), grid, blk, st, pr, a);
 }
 
-// W_rm = W_gifo_r [4C x R] * W_r_m [R x C], natural [4C x C] and transposed [C x 4C], once per Update
 // x chunks of the folded gates array (the W_rm chunks are written by the fold product itself)
 __global__ __launch_bounds__(256) void k_pack_foldx(const float *__restrict__ wx, float4 *__restrict__ pk, int C, int I, int nch1) {
   const int nchM = (C + KCH - 1) / KCH, nchX = nch1 - nchM;
@@ -2331,7 +2352,7 @@ static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const flo
   GemmJob g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.beta = beta;
   g.Cm = Cm; g.ldc = ldc; g.bias = bias;
-  g.Ct = nullptr; g.ldct = 0; g.C2 = nullptr; g.ldc2 = 0; g.C3 = nullptr; g.tail0 = 0; g.dbg = 0;
+  g.Ct = nullptr; g.ldct = 0; g.C2 = nullptr; g.ldc2 = 0; g.C3 = nullptr; g.tail0 = 0;
   g.gperm = 0; g.pk1 = nullptr; g.nch1 = 0; g.pk2 = nullptr; g.nch2 = 0;
   // branch-free 8-wide fetches need aligned rows and a contiguous extent that is a multiple of 8
   g.vecA = aligned16(A) && lda % 4 == 0 && (transA ? M : K) % 8 == 0;
