@@ -705,3 +705,28 @@ def test_folded_recurrence_state_bridge_reset_replay_and_deferred_momentum():
         a.synchronize(); b.synchronize()
     assert relerr(a.get_corr(), b.get_corr()) <= 1e-6 and relerr(a.get_params(), b.get_params()) <= 1e-6
     a.close(); b.close()
+
+
+def test_auto_policy_switches_between_folded_and_reference_chain():
+    """Default options: T >= 12 runs the folded chain, shorter minibatches the reference-shaped one.  While folded, Update
+    refreshes only the operands that chain reads; the others are re-packed on demand when a short minibatch follows
+    (and the fold product is re-run when a long one follows an Update)."""
+    I, C, R, S = 40, 64, 32, 4
+    p = make_params(I, C, R, scale=0.3, seed=41)
+    o = Oracle(I, C, R, S, np.float32); o.set_params(p)
+    e = make_engine(I, C, R, S, p)
+    rng = np.random.RandomState(42)
+    for T in (14, 3, 3, 14, 14, 5, 12):
+        x = rng.randn(T * S, I).astype(np.float32); od = rng.randn(T * S, R).astype(np.float32)
+        xd, odd = dev(x), dev(od)
+        outd = torch.empty(T * S, R, device="cuda"); idd = torch.empty(T * S, I, device="cuda")
+        torch.cuda.synchronize()
+        e.propagate(xd, outd); e.backpropagate(xd, odd, idd, momentum=0.9); e.synchronize()
+        out_o = o.propagate(x); id_o = o.backpropagate(x, od, momentum=0.9)
+        assert relerr(outd.cpu().numpy(), out_o) <= 2e-5 and relerr(idd.cpu().numpy(), id_o) <= 1e-4
+        assert relerr(e.get_corr(), o.get_corr()) <= 1e-4
+        e.update(1e-3); o.update(1e-3)
+        assert relerr(e.get_params(), o.get_params()) <= 2e-5
+        cs, rs = e.get_state(); st = o.get_state()
+        assert relerr(cs, st[:, 4 * C:5 * C]) <= 2e-5 and relerr(rs, st[:, 7 * C:]) <= 2e-5
+    e.close()
