@@ -168,16 +168,23 @@ class DataParallelNnet:
     gradient blob and the momentum/update step on every rank (bd-nnet-train-lstm-streams.cc:209-228 per rank, on this
     rank's streams).  `alloc(n)` returns the flat blob storage (torch CUDA float32 for the device layers)."""
 
-    def __init__(self, layers, loss, alloc, group=None, force_collective=False):
+    def __init__(self, layers, loss, alloc, group=None, force_collective=False, overlap=False):
+        """overlap=False: ONE all-reduce of the whole blob after the last Backpropagate (fewest, largest collective).
+        overlap=True: one asynchronous all-reduce per layer slice, issued as soon as that layer's gradient exists, so
+        the output layer's 34 MB (configs[3]) travel over xGMI while the LSTM layers below still run their BPTT chains;
+        all of them are waited for before the first apply().  Same sums either way (disjoint slices)."""
         import torch.distributed as dist
         self.layers, self.loss, self.dist, self.group = layers, loss, dist, group
+        self.overlap = overlap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         pad4 = lambda n: (n + 3) // 4 * 4                  # every slice starts 16-byte aligned (float4 stores)
         self.blob = alloc(sum(pad4(l.num_params) for l in layers))
         off = 0
+        self.slices = []
         for l in layers:
             l.bind_grad(self.blob[off:off + l.num_params])
+            self.slices.append(self.blob[off:off + pad4(l.num_params)])
             off += pad4(l.num_params)
 
     def train_step(self, x, targets, mask, momentum, learn_rate, reset_flags=None):
@@ -188,10 +195,15 @@ class DataParallelNnet:
         for l in self.layers:
             acts.append(l.propagate(acts[-1]))
         diff, xent, correct, valid = self.loss.eval(acts[-1], targets, mask)
+        pending = []
         for i in range(len(self.layers) - 1, -1, -1):
             diff = self.layers[i].backpropagate(acts[i], diff, i > 0)     # the first layer's in_diff is never used (:228)
-        if self.collective:
+            if self.collective and self.overlap:
+                pending.append(self.dist.all_reduce(self.slices[i], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.collective and not self.overlap:
             self.dist.all_reduce(self.blob, op=self.dist.ReduceOp.SUM, group=self.group)
+        for w in pending:
+            w.wait()
         for l in self.layers:
             l.apply(momentum, learn_rate)
         return xent, correct, valid

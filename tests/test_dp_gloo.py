@@ -142,7 +142,7 @@ def stack_data():
     return xs, tg, mk
 
 
-def stack_worker(rank, world, port, q):
+def stack_worker(rank, world, port, q, overlap=False):
     import kaldi_lstm_amd as k
     from tests import nnet_twins as tw
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -158,7 +158,7 @@ def stack_worker(rank, world, port, q):
         calls["n"] += 1
         return real_all_reduce(*a, **kw)
     dist.all_reduce = counting_all_reduce
-    net = k.DataParallelNnet(layers, tw.NumpyLoss(), alloc=lambda n: torch.zeros(n, dtype=torch.float64))
+    net = k.DataParallelNnet(layers, tw.NumpyLoss(), alloc=lambda n: torch.zeros(n, dtype=torch.float64), overlap=overlap)
     xs, tg, mk = stack_data()
     stats = []
     for i in range(NSTEP):
@@ -171,14 +171,17 @@ def stack_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_stacked_net_one_allreduce_equals_single_process():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_stacked_net_one_allreduce_equals_single_process(overlap):
+    """overlap=False: exactly ONE collective per minibatch for the whole model; overlap=True: one asynchronous collective
+    per layer, issued as that layer's gradient appears (3 per minibatch here).  Both equal the single-process run."""
     from tests import nnet_twins as tw
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=stack_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=stack_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
@@ -194,7 +197,7 @@ def test_two_rank_stacked_net_one_allreduce_equals_single_process():
     full = [net.train_step(torch.from_numpy(xs[i]), torch.from_numpy(tg[i]), torch.from_numpy(mk[i]), MMT, LR,
                            reset_flags=[1] * S_TOTAL if i == 0 else None) for i in range(NSTEP)]
     for rank, params, stats, ncalls in res:
-        assert ncalls == NSTEP                                   # exactly ONE collective per minibatch for the whole model
+        assert ncalls == NSTEP * (len(layers) if overlap else 1)
         for pr, l in zip(params, layers):
             np.testing.assert_allclose(pr, l.params(), rtol=1e-9, atol=1e-12)
     for i in range(NSTEP):                                       # loss statistics add up over ranks

@@ -561,7 +561,8 @@ def test_host_matrices_are_staged_through_the_device_path():
     e.close(); e2.close()
 
 
-def test_stacked_net_dp_device_layers_against_cpu_twins():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_stacked_net_dp_device_layers_against_cpu_twins(overlap):
     """BASELINE.json configs[3] topology at test size (LSTM x2 + AffineTransform + Softmax + masked Xent) through
     DataParallelNnet with the DEVICE layers (klstm engines bound to slices of one fused gradient blob, klstm_affine_*,
     klstm_softmax, klstm_xent_eval_masked) and the all-reduce over RCCL (one-rank group), against the oracle-backed CPU
@@ -582,7 +583,8 @@ def test_stacked_net_dp_device_layers_against_cpu_twins():
     cpu_net = k.DataParallelNnet(cpu, tw.NumpyLoss(), alloc=lambda n: torch.zeros(n, dtype=torch.float32))
     engines = [make_engine(I if l == 0 else R, C, R, S, lstm[l]) for l in range(n_lstm)]
     layers = [k.LstmDP(e) for e in engines] + [k.AffineDP(dev(W), dev(b), k)]
-    net = k.DataParallelNnet(layers, k.SoftmaxXentDP(k), alloc=lambda n: torch.zeros(n, device="cuda"), force_collective=True)
+    net = k.DataParallelNnet(layers, k.SoftmaxXentDP(k), alloc=lambda n: torch.zeros(n, device="cuda"), force_collective=True,
+                             overlap=overlap)     # overlap: one asynchronous RCCL all-reduce per layer slice
     assert net.collective and net.blob.numel() >= sum(l.num_params for l in layers)
     assert engines[1].grad_blob_ptr() == net.blob.data_ptr() + 4 * ((engines[0].num_params + 3) // 4 * 4)
     rng = np.random.RandomState(22)
