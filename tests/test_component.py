@@ -193,3 +193,33 @@ def test_batcher_refuses_fewer_utterances_than_streams(tmp_path):
     _pack_utts(utts).tofile(tmp_path / "u.raw")
     r = run("batcher", tmp_path / "u.raw", 2, 4, 1, tmp_path / "b.raw", ok=False)
     assert r.returncode == 3 and "fewer utterances than streams" in r.stdout
+
+
+def test_format_against_the_reference_data_files(tmp_path):
+    """tests/golden/ holds the reference's own prototype file (google/nnet.proto) and the component header lines of its
+    README's example models (tests/golden/make_fixtures.py).  InitData must accept the prototype line verbatim, and the
+    text models written here must start with exactly the README's header lines (marker, output-dim, input-dim, then the
+    WriteData tokens) -- the format side of the drop-in boundary pinned to reference-provided data."""
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    proto = [l.split() for l in open(os.path.join(gold, "nnet.proto")) if l.startswith("<LstmProjectedStreams>")][0]
+    headers = open(os.path.join(gold, "model_headers.txt")).read().splitlines()
+    assert proto[1] == "<InputDim>" and proto[3] == "<OutputDim>"
+    I, O, rest = int(proto[2]), int(proto[4]), " ".join(proto[5:])
+    r = run("init_write", "<LstmProjectedStreams>", I, O, rest, 0, tmp_path / "m.txt", tmp_path / "p.raw")
+    assert r.stdout.split() == ["OK", "2181600"]                     # BASELINE.md: 2 181 600 parameters at 40/800/512
+    p = raw(tmp_path / "p.raw")
+    assert p.size == 2181600 and np.abs(p).max() <= 0.01 and np.abs(p).max() > 0.0099 and abs(p.mean()) < 1e-4   # <ParamScale> 0.01
+    first = (tmp_path / "m.txt").read_text().split("[", 1)[0].split()
+    assert " ".join(first) == "<LstmProjectedStreams> 512 40 <CellDim> 800 <NumStream> 4" and " ".join(first) in headers
+    # the standard/ component: same prototype without <NumStream>; header as in the README's converted model
+    rest_std = " ".join(t for i, t in enumerate(proto[5:]) if t != "<NumStream>" and proto[5:][i - 1] != "<NumStream>")
+    run("init_write", "<LstmProjected>", I, O, rest_std, 0, tmp_path / "s.txt", tmp_path / "ps.raw")
+    first = (tmp_path / "s.txt").read_text().split("[", 1)[0].split()
+    assert " ".join(first) == "<LstmProjected> 512 40 <CellDim> 800" and " ".join(first) in headers
+    # TimeShift / Transmit header lines survive an nnet-copy round trip byte for byte
+    ts = [h for h in headers if h.startswith("<TimeShift>")][0]
+    tr = [h for h in headers if h.startswith("<Transmit>")][0]
+    (tmp_path / "n.txt").write_text("<Nnet>\n%s\n%s\n</Nnet>\n" % (ts, tr))
+    run("nnet_copy", tmp_path / "n.txt", 0, tmp_path / "n2.txt")
+    lines = [l.strip() for l in (tmp_path / "n2.txt").read_text().splitlines() if l.strip()]
+    assert lines == ["<Nnet>", ts, tr, "</Nnet>"]
