@@ -85,6 +85,26 @@ int main(int argc, char **argv) {
       InitKaldiOutputStream(f, binary);
       c->Write(f, binary);
       std::cout << "OK\n";
+    } else if (mode == "read_vectors") {
+      // read_vectors <kaldi text/binary nnet made of vector-parameter components> <out_raw>
+      // (a genuine Kaldi-written file, e.g. the reference's feature_transform.nnet.txt: <Nnet> <AddShift> d d [ v ] <Rescale> d d [ v ] </Nnet>)
+      std::ifstream f(argv[2], std::ios::binary);
+      const bool binary = InitKaldiInputStream(f);
+      ExpectToken(f, binary, "<Nnet>");
+      std::vector<float> all;
+      std::string tok;
+      while (true) {
+        ReadToken(f, binary, &tok);
+        if (tok == "</Nnet>") break;
+        int32 dout = 0, din = 0;
+        ReadBasicType(f, binary, &dout);
+        ReadBasicType(f, binary, &din);
+        std::vector<BaseFloat> v;
+        ReadVector(f, binary, &v);
+        std::cout << tok << " " << dout << " " << din << " " << v.size() << "\n";
+        all.insert(all.end(), v.begin(), v.end());
+      }
+      write_raw(argv[3], all.data(), all.size());
     } else if (mode == "bad_proto") {
       LstmProjectedStreams c(5, 4);
       std::istringstream proto("<CellDim> 7 <Bogus> 3");

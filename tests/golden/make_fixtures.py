@@ -7,7 +7,11 @@
                            input-dim, then the WriteData tokens, ...streams.h:133-150): what a model written by the
                            reference looks like on disk, up to the first matrix bracket
 
-Neither is source code; no arithmetic is pinned by them (the reference ships no numeric vectors) --
+  feature_transform.nnet.txt <- google/feature_transform.nnet.txt: a model file WRITTEN BY KALDI (text mode, two
+                           vector-parameter components, 860 bytes): a genuine sample of the on-disk token / vector
+                           encoding for the reader in include/klstm_kaldi_io.hpp
+
+None is source code; no arithmetic is pinned by them (the reference ships no numeric vectors) --
 they pin the FORMAT side of the drop-in boundary (SURVEY 8(b) "file format") to reference-provided data."""
 import os
 import re
@@ -17,6 +21,7 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 shutil.copy(os.path.join(REF, "google", "nnet.proto"), os.path.join(HERE, "nnet.proto"))
+shutil.copy(os.path.join(REF, "google", "feature_transform.nnet.txt"), os.path.join(HERE, "feature_transform.nnet.txt"))
 lines = []
 for line in open(os.path.join(REF, "README.md")):
     m = re.match(r"^(<(?:LstmProjectedStreams|LstmProjected|TimeShift|Transmit)>[^\[]*?)\s*(\[ \.\.\.)?\s*$", line)

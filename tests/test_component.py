@@ -223,3 +223,16 @@ def test_format_against_the_reference_data_files(tmp_path):
     run("nnet_copy", tmp_path / "n.txt", 0, tmp_path / "n2.txt")
     lines = [l.strip() for l in (tmp_path / "n2.txt").read_text().splitlines() if l.strip()]
     assert lines == ["<Nnet>", ts, tr, "</Nnet>"]
+
+
+def test_reader_on_a_kaldi_written_file(tmp_path):
+    """tests/golden/feature_transform.nnet.txt is the reference's own (Kaldi-written, text mode) feature transform:
+    <Nnet> <AddShift> 40 40 [ v ] <Rescale> 40 40 [ v ] </Nnet>.  The token / integer / vector readers of
+    include/klstm_kaldi_io.hpp must consume it and return the numbers printed in the file."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "feature_transform.nnet.txt")
+    r = run("read_vectors", path, tmp_path / "v.raw")
+    assert r.stdout.split("\n")[:2] == ["<AddShift> 40 40 40", "<Rescale> 40 40 40"]
+    txt = open(path).read()
+    expect = [float(t) for blk in txt.split("[")[1:] for t in blk.split("]")[0].split()]
+    assert len(expect) == 80
+    assert np.array_equal(raw(tmp_path / "v.raw"), np.float32(expect))
