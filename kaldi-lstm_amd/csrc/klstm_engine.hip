@@ -487,7 +487,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
   float *dst = defer ? e->grads : e->corr;
   const float beta = defer ? 0.f : mmt;
   HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, beta, dst, st,
-                      probe(e, "k_grads")));                                                  // :468-487
+                      probe(e, "k_grads"), e->use_bf16));                                     // :468-487
   return KLSTM_OK;
 }
 
@@ -956,7 +956,7 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
       else if (w == "dr") HIPCHK(launch_dr_step(d, bp, t < T ? t : 1, xdiff, e->I, st));
       else if (w == "dm") HIPCHK(launch_dm_step(d, bp, t, scratch_out, e->R, xdiff, e->I, st));
       else if (w == "dr+dm") { if (i & 1) HIPCHK(launch_dm_step(d, bp, t, scratch_out, e->R, xdiff, e->I, st)); else HIPCHK(launch_dr_step(d, bp, t < T ? t : 1, xdiff, e->I, st)); }
-      else if (w == "grads") HIPCHK(launch_grads(d, e->dgifo, e->dr, xin, e->I, e->rr, e->mm, e->cc, 0.9f, e->corr, st));
+      else if (w == "grads") HIPCHK(launch_grads(d, e->dgifo, e->dr, xin, e->I, e->rr, e->mm, e->cc, 0.9f, e->corr, st, LaunchProbe(), e->use_bf16));
       else if (w == "update") HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, st));
       else if (w == "pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, st));
       else if (w == "pack_fwd") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 3, e->use_bf16, st));

@@ -97,7 +97,7 @@ hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, con
 // blob in GetParams order.
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,
-                        hipStream_t st, LaunchProbe pr = {});
+                        hipStream_t st, LaunchProbe pr = {}, bool bf16 = false);   // bf16: operands rounded to bf16, 16x16x32 MFMA, fp32 accumulate
 
 // Update (:504-512) + refresh of the transposed weight copies in ONE launch.
 //   grad != nullptr : corr = mmt*corr + grad first (DP mode, after the all-reduce)

@@ -1811,6 +1811,35 @@ struct GradsArgs {
   float *g_bias, *g_pi, *g_pf, *g_po;
 };
 
+// bias / peephole column sums of k_grads: block vb covers 64 columns of the 4C gate axis with 4 row groups
+__device__ __forceinline__ void grads_column_sums(const GradsArgs &a, int vb, float *lds0, float *lds1) {
+  const int C = a.C, S = a.S, rows = a.T * a.S;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = vb * 64 + tx;
+  float sb = 0.f, sp = 0.f;
+  if (col < 4 * C) {
+    const int gate = col / C, cell = col - gate * C;
+    // DI/DF[1..T] pair with YC[0..T-1]; DO[1..T] pairs with YC[1..T]
+    const float *cbase = a.cc + (gate == 3 ? (size_t)S * C : 0) + cell;
+    for (int r = ty; r < rows; r += 4) {
+      const float dv = a.dgifo[(size_t)(S + r) * 4 * C + col];
+      sb += dv;
+      if (gate != 0) sp += dv * cbase[(size_t)r * C];
+    }
+  }
+  float(*rb)[64] = reinterpret_cast<float(*)[64]>(lds0);
+  float(*rp)[64] = reinterpret_cast<float(*)[64]>(lds1);
+  rb[ty][tx] = sb; rp[ty][tx] = sp;
+  __syncthreads();
+  if (ty == 0 && col < 4 * C) {
+    for (int w = 1; w < 4; w++) { sb += rb[w][tx]; sp += rp[w][tx]; }
+    const int gate = col / C, cell = col - gate * C;
+    a.g_bias[col] = (a.beta != 0.f ? a.beta * a.g_bias[col] : 0.f) + sb;
+    float *gp = gate == 1 ? a.g_pi : gate == 2 ? a.g_pf : gate == 3 ? a.g_po : nullptr;
+    if (gp) gp[cell] = (a.beta != 0.f ? a.beta * gp[cell] : 0.f) + sp;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
   __shared__ __attribute__((aligned(16))) float As[GLDS];
   __shared__ __attribute__((aligned(16))) float Bs[GLDS];
@@ -1828,32 +1857,123 @@ __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
     gemm_tile<true, false>(g, (lb / ntn) * GT, (lb % ntn) * GT, As, Bs);
     return;
   }
-  // column sums over the T*S frame rows; 64 columns of the 4C gate axis x 4 row groups
-  const int C = a.C, S = a.S, rows = a.T * a.S;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = (b - a.nb2) * 64 + tx;
-  float sb = 0.f, sp = 0.f;
-  if (col < 4 * C) {
-    const int gate = col / C, cell = col - gate * C;
-    // DI/DF[1..T] pair with YC[0..T-1]; DO[1..T] pairs with YC[1..T]
-    const float *cbase = a.cc + (gate == 3 ? (size_t)S * C : 0) + cell;
-    for (int r = ty; r < rows; r += 4) {
-      const float dv = a.dgifo[(size_t)(S + r) * 4 * C + col];
-      sb += dv;
-      if (gate != 0) sp += dv * cbase[(size_t)r * C];
+  grads_column_sums(a, b - a.nb2, As, Bs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 operand mode: the three gradient products on v_mfma_f32_16x16x32_bf16.  128x128 output tiles (the 64x64 fp32
+// tile is L2-bandwidth-bound long before the 16x faster bf16 pipe is busy), K tile 64 (the K loop exposes one memory
+// latency per tile: 64 KB in flight per workgroup).  Both operands are stored
+// [K x X] (fp32 planes); a thread fetches two consecutive k rows x four x columns, rounds to bf16 (RNE) and writes the
+// (k, k+1) pairs as 32-bit words into a k-contiguous LDS layout  word[(x&3)*PLANE + (x>>2)*LDQ + k/2]: four planes by
+// x mod 4 (the four columns a thread holds go to four planes), LDQ = 36 and PLANE = 16 mod 64 make the 16-byte operand
+// reads of 16 rows x 4 k-groups conflict-free and leave the 32-bit stash writes 2-way (a plain [x][k/2] layout is 8-way:
+// its writes alone cost more than the MFMAs).  An MFMA operand (8 consecutive k of one row) is one ds_read_b128.
+// fp32 accumulate, beta and the column-sum blocks exactly as in k_grads.
+// ---------------------------------------------------------------------------------------------
+constexpr int GRADS_BF16_MIN_ROWS = 256;
+constexpr int BT = 128, BK = 64, LDQ = 36, PLANE = 32 * LDQ + 16;   // see the layout note above
+
+__device__ __forceinline__ void fetch_pair(const float *__restrict__ P, int ld, int X, int K, int x0, int k0, int u,
+                                           float4 (&r)[2]) {
+  const int kp = u >> 5, xq = u & 31;
+  const int k = k0 + 2 * kp, x = x0 + 4 * xq;
+  const bool xin = x + 4 <= X;                       // X % 4 == 0 on this path
+  const float *p0 = P + (size_t)min(k, K - 1) * ld + (xin ? x : 0);
+  const float *p1 = P + (size_t)min(k + 1, K - 1) * ld + (xin ? x : 0);
+  const float4 a = ldg4(p0), b = ldg4(p1);
+  r[0] = (xin && k < K) ? a : f4zero();
+  r[1] = (xin && k + 1 < K) ? b : f4zero();
+}
+__device__ __forceinline__ unsigned pack_pair(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 h = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ void stash_pair(unsigned *Ls, int u, const float4 (&r)[2]) {
+  const int kp = u >> 5, xq = u & 31;
+  unsigned *d = Ls + xq * LDQ + kp;
+  d[0] = pack_pair(r[0].x, r[1].x);
+  d[PLANE] = pack_pair(r[0].y, r[1].y);
+  d[2 * PLANE] = pack_pair(r[0].z, r[1].z);
+  d[3 * PLANE] = pack_pair(r[0].w, r[1].w);
+}
+
+__device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int n0, unsigned *As, unsigned *Bs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
+  constexpr int NU = (BK / 2) * 32 / 256;            // (k pair, x quad) units per thread and operand
+  float4 ra[NU][2], rb[NU][2];
+#pragma unroll
+  for (int h = 0; h < NU; h++) {
+    fetch_pair(g.A, g.lda, g.M, g.K, m0, 0, tid + 256 * h, ra[h]);
+    fetch_pair(g.B, g.ldb, g.N, g.K, n0, 0, tid + 256 * h, rb[h]);
+  }
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+#pragma unroll
+    for (int h = 0; h < NU; h++) { stash_pair(As, tid + 256 * h, ra[h]); stash_pair(Bs, tid + 256 * h, rb[h]); }
+    __syncthreads();
+    if (k0 + BK < g.K) {
+#pragma unroll
+      for (int h = 0; h < NU; h++) {
+        fetch_pair(g.A, g.lda, g.M, g.K, m0, k0 + BK, tid + 256 * h, ra[h]);
+        fetch_pair(g.B, g.ldb, g.N, g.K, n0, k0 + BK, tid + 256 * h, rb[h]);
+      }
     }
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ks++) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int xa = wr * 64 + i * 16 + i16, xb = wc * 64 + i * 16 + i16;
+        af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(As + (xa & 3) * PLANE + (xa >> 2) * LDQ + ks * 16 + kg * 4));
+        bfr[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(Bs + (xb & 3) * PLANE + (xb >> 2) * LDQ + ks * 16 + kg * 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
   }
-  float(*rb)[64] = reinterpret_cast<float(*)[64]>(&As[0]);
-  float(*rp)[64] = reinterpret_cast<float(*)[64]>(&Bs[0]);
-  rb[ty][tx] = sb; rp[ty][tx] = sp;
-  __syncthreads();
-  if (ty == 0 && col < 4 * C) {
-    for (int w = 1; w < 4; w++) { sb += rb[w][tx]; sp += rp[w][tx]; }
-    const int gate = col / C, cell = col - gate * C;
-    a.g_bias[col] = (a.beta != 0.f ? a.beta * a.g_bias[col] : 0.f) + sb;
-    float *gp = gate == 1 ? a.g_pi : gate == 2 ? a.g_pf : gate == 3 ? a.g_po : nullptr;
-    if (gp) gp[cell] = (a.beta != 0.f ? a.beta * gp[cell] : 0.f) + sp;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n = n0 + wc * 64 + j * 16 + i16;
+      if (n >= g.N) continue;
+      const float e[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = m0 + wr * 64 + i * 16 + 4 * kg + r;
+        if (m >= g.M) continue;
+        float *cp = g.Cm + (size_t)m * g.ldc + n;
+        *cp = g.beta != 0.f ? g.beta * *cp + e[r] : e[r];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned As[4 * PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned Bs[4 * PLANE];
+  const int nbt = a.nb2 + a.nvec;
+  const int cpx = (nbt + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * cpx + (int)(blockIdx.x >> 3);
+  if (b >= nbt) return;
+  if (b < a.nb2) {
+    const GemmJob &g = b < a.nb0 ? a.wx : b < a.nb1 ? a.wr : a.wm;
+    const int lb = b < a.nb0 ? b : b < a.nb1 ? b - a.nb0 : b - a.nb1;
+    const int ntn = (g.N + BT - 1) / BT;
+    gemm_tile_bf16_tn(g, (lb / ntn) * BT, (lb % ntn) * BT, As, Bs);
+    return;
   }
+  grads_column_sums(a, b - a.nb2, reinterpret_cast<float *>(As), reinterpret_cast<float *>(Bs));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2432,7 +2552,7 @@ hipError_t launch_bwd_tail(const Dims &d, const float *dgifo, const float *wr, c
 
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst,
-                        hipStream_t st, LaunchProbe pr) {
+                        hipStream_t st, LaunchProbe pr, bool bf16) {
   const int S = d.S, C = d.C, R = d.R, I = d.I, TS = d.T * d.S;
   const long o_wx = 0, o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_pi = o_b + 4 * C,
              o_pf = o_pi + C, o_po = o_pf + C, o_wm = o_po + C;
@@ -2447,6 +2567,16 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
   a.C = C; a.S = S; a.T = d.T; a.dgifo = dgifo; a.cc = cc; a.beta = beta;
   a.g_bias = dst + o_b; a.g_pi = dst + o_pi; a.g_pf = dst + o_pf; a.g_po = dst + o_po;
   a.nvec = cdiv(4 * C, 64);
+  // below ~256 frames per minibatch the products are write-bound and the 64x64 fp32 tiles are faster (80 frames: 13.4 vs
+  // 16.5 us); from there on the bf16 tiles win (640 frames at 512/1024/512: 99 -> 55 us)
+  const bool bf_ok = bf16 && TS >= GRADS_BF16_MIN_ROWS && aligned16(dgifo) && aligned16(dr) && aligned16(in) && aligned16(rr) && aligned16(mm) &&
+                     in_stride % 4 == 0 && C % 4 == 0 && R % 4 == 0 && I % 4 == 0;
+  if (bf_ok) {                                        // 128x128 tiles on the bf16 pipe
+    a.nb0 = cdiv(4 * C, BT) * cdiv(I, BT);
+    a.nb1 = a.nb0 + cdiv(4 * C, BT) * cdiv(R, BT);
+    a.nb2 = a.nb1 + cdiv(R, BT) * cdiv(C, BT);
+    KLAUNCH(k_grads_bf16, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
+  }
   KLAUNCH(k_grads, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
 }
 

@@ -2,8 +2,8 @@
 
 Semantics being pinned: in the four per-step contractions (gates :275 [+ :246 when the x term is fused], projection
 :312, d_r/in_diff :391/:457, d_m :408) BOTH operands are rounded to bf16 (round-to-nearest-even) and the products
-are accumulated in fp32; everything else -- elementwise math, activation planes, the gradient accumulations
-:468-487, momentum, Update, the fp32 master weights -- is unchanged fp32.  Products of bf16 values are exact in
+are accumulated in fp32; so are the three gradient products (:468, :471, :486) from 256 frames per minibatch on.  Everything else -- elementwise math,
+activation planes, the bias / peephole sums, momentum, Update, the fp32 master weights -- is unchanged fp32.  Products of bf16 values are exact in
 fp64, so this emulation accumulates in fp64 and differs from the GPU only by fp32 summation order and by the rare
 1-ulp bf16 flips that order causes (tolerances in tests/test_engine_gpu.py).
 """
@@ -19,6 +19,9 @@ def rb(a):
 
 def sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
+
+
+GRADS_BF16_MIN_ROWS = 256      # klstm_kernels.hip: the gradient products run on the bf16 pipe from this many frames on
 
 
 def minibatch(parts, x, od, c0, r0, S, fuse_x, want_in_diff=True):
@@ -65,6 +68,9 @@ def minibatch(parts, x, od, c0, r0, S, fuse_x, want_in_diff=True):
     Rm1 = r[0:T].reshape(T * S, R)
     Cm1 = c[0:T].reshape(T * S, C)
     C1 = c[1:T + 1].reshape(T * S, C)
-    grads = [D.T @ x, D.T @ Rm1, D.sum(0), (D[:, C:2 * C] * Cm1).sum(0), (D[:, 2 * C:3 * C] * Cm1).sum(0),
-             (D[:, 3 * C:] * C1).sum(0), dr[1:T + 1].reshape(T * S, R).T @ m[1:T + 1].reshape(T * S, C)]
+    # the three gradient PRODUCTS (:468, :471, :486) round both operands to bf16; the bias / peephole sums stay fp32
+    rg = rb if T * S >= GRADS_BF16_MIN_ROWS else (lambda a: np.asarray(a, np.float64))
+    Db = rg(D)
+    grads = [Db.T @ rg(x), Db.T @ rg(Rm1), D.sum(0), (D[:, C:2 * C] * Cm1).sum(0), (D[:, 2 * C:3 * C] * Cm1).sum(0),
+             (D[:, 3 * C:] * C1).sum(0), rg(dr[1:T + 1].reshape(T * S, R)).T @ rg(m[1:T + 1].reshape(T * S, C))]
     return out, in_diff, grads, c[T], r[T]
