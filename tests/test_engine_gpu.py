@@ -734,3 +734,53 @@ def test_auto_policy_switches_between_folded_and_reference_chain():
         cs, rs = e.get_state(); st = o.get_state()
         assert relerr(cs, st[:, 4 * C:5 * C]) <= 2e-5 and relerr(rs, st[:, 7 * C:]) <= 2e-5
     e.close()
+
+
+def test_full_size_properties_without_the_oracle():
+    """BASELINE.json configs[1] at full size (40/800/512, 4 streams, T = 20), properties that need no oracle:
+    (a) streams are independent: the 4-stream engine equals four 1-stream engines fed the same utterances (fp32 order);
+    (b) BPTT is linear in out_diff: in_diff and the gradient of a*od1 + b*od2 are the same combination of the separate runs;
+    (c) a Reset stream behaves like a fresh engine, the other streams are untouched."""
+    I, C, R, S, T = 40, 800, 512, 4, 20
+    p = make_params(I, C, R, scale=0.01, seed=51)
+    rng = np.random.RandomState(52)
+    x = rng.randn(T * S, I).astype(np.float32)
+    od1 = (0.1 * rng.randn(T * S, R)).astype(np.float32); od2 = (0.1 * rng.randn(T * S, R)).astype(np.float32)
+
+    def run(S_, xs, ods, reset=None, warm=None):
+        e = make_engine(I, C, R, S_, p)
+        out = torch.empty(xs.shape[0], R, device="cuda"); idf = torch.empty(xs.shape[0], I, device="cuda")
+        if warm is not None:                      # a first minibatch that leaves carried state behind
+            xw = dev(warm); e.propagate(xw, out); e.synchronize()
+        if reset is not None:
+            e.reset(reset)
+        xd, odd = dev(xs), dev(ods)
+        torch.cuda.synchronize()
+        e.propagate(xd, out); e.backpropagate(xd, odd, idf, momentum=0.0); e.synchronize()
+        res = (out.cpu().numpy(), idf.cpu().numpy(), e.get_corr())
+        e.close()
+        return res
+
+    out4, id4, g4 = run(S, x, od1)
+    # (a)
+    gsum = np.zeros_like(g4, dtype=np.float64)
+    for s in range(S):
+        o1, i1, g1 = run(1, np.ascontiguousarray(x[s::S]), np.ascontiguousarray(od1[s::S]))
+        assert relerr(out4[s::S], o1) <= 2e-5 and relerr(id4[s::S], i1) <= 1e-4
+        gsum += g1
+    assert relerr(g4, gsum) <= 2e-4                               # the only cross-stream coupling is the gradient sum
+    # (b)
+    a, b = 0.75, -1.5
+    _, id_2, g_2 = run(S, x, od2)
+    _, id_c, g_c = run(S, x, a * od1 + b * od2)
+    assert relerr(id_c, a * id4.astype(np.float64) + b * id_2) <= 1e-4
+    assert relerr(g_c, a * g4.astype(np.float64) + b * g_2) <= 2e-4
+    # (c)
+    warm = rng.randn(T * S, I).astype(np.float32)
+    out_r, _, _ = run(S, x, od1, reset=[0, 1, 0, 1], warm=warm)
+    out_w, _, _ = run(S, x, od1, reset=[0, 0, 0, 0], warm=warm)
+    for s in (1, 3):
+        assert relerr(out_r[s::S], out4[s::S]) <= 1e-6           # reset stream == fresh engine
+    for s in (0, 2):
+        assert np.array_equal(out_r[s::S], out_w[s::S])          # untouched streams: bit-identical to the un-reset run
+        assert relerr(out_r[s::S], out4[s::S]) > 1e-4            # and they do carry state
