@@ -205,14 +205,22 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
                                     float *row_correct_dev, void *hip_stream);
 
 /* Engine knobs (not part of the reference interface).  Keys:
- *   "graph"   0/1  replay the per-minibatch launch sequence from a hipGraph (default 1)
+ *   "graph"   0/1  replay the per-call launch sequence from a hipGraph (default 1: robust against a busy host
+ *                  thread) or issue plain stream launches (no fixed cost per graph launch)
+ *   "fold"    -1/0/1  folded recurrence W_rm = W_gifo_r * W_r_m: one kernel per step and direction instead of two
+ *                  (DESIGN.md 3a); -1 = auto (NumStream <= 8 and >= 12 frames per stream), 1 = whenever NumStream <=
+ *                  12 and I, C, R are multiples of 8.  Same results up to fp32 summation order.
+ *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
+ *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.
+ *   "fuse_x"  -1/0/1  x(t) W_gifo_x^T inside the step kernel (auto: NumStream <= 16) or as one batched product (:246)
+ *   "vector", "fat", "small_max", "small_nt2"  kernel-family selection for A-B experiments and tests
  *   "profile" 0/1  run every kernel eagerly between its own start/stop HIP events on the
  *                  engine's stream (hipExtLaunchKernelGGL); setting the key clears the
  *                  statistics.  Used by bench.py for the roofline line. */
 klstm_status klstm_set_option(klstm_engine *e, const char *key, int value);
 
 /* With "profile" on: device time (microseconds, summed) and launch count of `kernel`
- * ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_gemm_xproj", "k_gemm_dwr", ...)
+ * ("k_gates_step", "k_gates_fold", "k_dmf_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_fold", "k_grads", ...)
  * over everything executed since the option was set.  Synchronises the stream. */
 klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *total_us,
                                  long *launches);
