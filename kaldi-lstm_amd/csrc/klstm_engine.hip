@@ -895,8 +895,7 @@ klstm_status klstm_sgd_momentum_update(float *param, float *corr, const float *g
   if (!param || !corr || !grad || n < 0) return fail(KLSTM_ERR_ARG, "klstm_sgd_momentum_update: bad argument");
   if (n == 0) return KLSTM_OK;
   hipStream_t st = (hipStream_t)hip_stream;
-  HIPCHK(launch_apply_momentum(corr, grad, momentum, n, st));
-  HIPCHK(launch_axpy(param, corr, -lr, n, st));
+  HIPCHK(launch_sgd_momentum(param, corr, grad, momentum, lr, n, st));
   return KLSTM_OK;
 }
 klstm_status klstm_softmax(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, void *hip_stream) {

@@ -128,6 +128,7 @@ hipError_t launch_xent(const float *y, int rows, int cols, int stride, const int
 hipError_t launch_col_sum(const float *src, int rows, int cols, int stride, float beta, float *dst, hipStream_t st);
 hipError_t launch_axpy(float *y, const float *x, float a, long n, hipStream_t st);
 
+hipError_t launch_sgd_momentum(float *param, float *corr, const float *grad, float mmt, float lr, long n, hipStream_t st);
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {});
 
 int get_small_max();
