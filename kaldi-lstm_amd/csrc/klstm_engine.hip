@@ -742,6 +742,12 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(launch_pack(Dims{e->I, e->C, e->R, e->S, 0}, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream));
     return KLSTM_OK;
   }
+  if (!strcmp(key, "fat_fine")) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    set_fat_fine(value);
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "small_nt2")) {       // process-wide tuning knob (A-B experiments)
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);

@@ -132,6 +132,7 @@ hipError_t launch_sgd_momentum(float *param, float *corr, const float *grad, flo
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {});
 
 int get_small_max();
+void set_fat_fine(int v);       // A-B knob: half-size row tiles in the many-stream kernels (-1 auto, 0, 1)
 void set_small_nt2(int v);     // A-B knob: two stream groups per workgroup at 5..small_max streams
 void set_small_max(int s);        // tuning knob: largest NumStream that uses the 4x4x1_16b geometry
 int dr_split_k(const Dims &d);   // number of split-K slabs launch_dr_step writes

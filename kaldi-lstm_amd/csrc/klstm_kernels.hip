@@ -2260,6 +2260,11 @@ static inline int pick_nt(int S) {
   } while (0)
 // vector kernels: SMALL (4x4x1_16b, S <= 4) with CPW in {1,2,4};  16x16x4 with (NT,CPW) in {(1,1),(1,2),(2,1),(4,1)}
 struct VecCfg { bool small; int nt, cpw; };
+int g_fat_fine = -1;            // many-stream kernels with half-size row tiles: -1 auto (<= 64 streams), 0 never, 1 always
+// measured, fwd+bwd+update us with full-size / half-size row tiles: 512->1024/512 at 32 streams 744 / 653 (gates 6.7 -> 5.3,
+// proj 5.7 -> 4.1 us: the full-size tiles leave half the chip without a workgroup); 40/800/512: 32 streams 650 / 561,
+// 64: 755 / 710, 128: 1056 / 1102
+static inline bool fat_fine(int S) { return g_fat_fine >= 1 || (g_fat_fine < 0 && S <= 64); }
 int g_small_nt2 = -1;         // -1 auto, 0 never, 1 always
 int g_small_max = 12;           // largest NumStream served by the 4x4x1_16b geometry (4 streams per workgroup, grid.y = S/4);
                                 // measured at 40/800/512: S=8 406 vs 471 us, S=12 473 vs 491, S=16 522 vs 515 (16x16x4 wins)
@@ -2322,6 +2327,21 @@ hipError_t launch_gates_step(const Dims &d0, const FwdPtrs &p, int t, bool fuse_
     GatesVArgs va; va.g = a; va.wpk = wpk;
     va.nch_total = cdiv(d.R, KCH) + cdiv(d.I, KCH);
     if (p.fat && d.S > 16) {                                 // 4 row tiles (16 cells) x 2 K splits per workgroup
+      if (fat_fine(d.S)) {                       // few stream tiles: 8 cells x 4 K splits per workgroup -> twice the workgroups
+        va.gx = cdiv(d.C, 8);
+        const dim3 fg(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
+        const bool bigf = (fuse_x ? cdiv(d.R, KCH) + cdiv(d.I, KCH) : cdiv(d.R, KCH)) > 16;
+        if (p.bf16) {
+          if (fuse_x && bigf) KLAUNCH((k_gates_f<2, 4, 32, true, true>), fg, dim3(NW * 64), st, pr, va);
+          if (fuse_x) KLAUNCH((k_gates_f<2, 4, 16, true, true>), fg, dim3(NW * 64), st, pr, va);
+          if (bigf) KLAUNCH((k_gates_f<2, 4, 32, false, true>), fg, dim3(NW * 64), st, pr, va);
+          KLAUNCH((k_gates_f<2, 4, 16, false, true>), fg, dim3(NW * 64), st, pr, va);
+        }
+        if (fuse_x && bigf) KLAUNCH((k_gates_f<2, 4, 32, true, false>), fg, dim3(NW * 64), st, pr, va);
+        if (fuse_x) KLAUNCH((k_gates_f<2, 4, 16, true, false>), fg, dim3(NW * 64), st, pr, va);
+        if (bigf) KLAUNCH((k_gates_f<2, 4, 32, false, false>), fg, dim3(NW * 64), st, pr, va);
+        KLAUNCH((k_gates_f<2, 4, 16, false, false>), fg, dim3(NW * 64), st, pr, va);
+      }
       va.gx = cdiv(d.C, 16);
       const dim3 fgrid(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
       const bool big = (fuse_x ? cdiv(d.R, KCH) + cdiv(d.I, KCH) : cdiv(d.R, KCH)) > 16;
@@ -2362,6 +2382,16 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
   if (vec) {
     ProjVArgs va; va.g = a; va.wpk = p.pk_proj;
     if (p.fat && d.S > 16) {
+      if (fat_fine(d.S)) {                       // one 16-row tile x 8 K splits per workgroup
+        va.gx = cdiv(d.R, 16);
+        const dim3 fg(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
+        if (p.bf16) {
+          if (cdiv(d.C, KCH) > 16) KLAUNCH((k_proj_f<1, 8, 32, true>), fg, dim3(NW * 64), st, pr, va);
+          KLAUNCH((k_proj_f<1, 8, 16, true>), fg, dim3(NW * 64), st, pr, va);
+        }
+        if (cdiv(d.C, KCH) > 16) KLAUNCH((k_proj_f<1, 8, 32, false>), fg, dim3(NW * 64), st, pr, va);
+        KLAUNCH((k_proj_f<1, 8, 16, false>), fg, dim3(NW * 64), st, pr, va);
+      }
       va.gx = cdiv(d.R, 32);
       const dim3 fgrid(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
       if (p.bf16) {
@@ -2382,6 +2412,7 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
 
 void set_small_max(int s) { g_small_max = s; }
 void set_small_nt2(int v) { g_small_nt2 = v; }
+void set_fat_fine(int v) { g_fat_fine = v; }
 int get_small_max() { return g_small_max; }
 
 int dr_split_k(const Dims &d) {
@@ -2415,6 +2446,13 @@ hipError_t launch_dr_step(const Dims &d, const BwdPtrs &p, int t, float *in_diff
       va.gx = va.g.ntr + (in_diff ? cdiv(d.I, 32) : 0);
       // (a 32-chunk slab was measured slower here: 66 KB of LDS and 16 weight registers per lane cost more in
       //  occupancy than the second staging round trip they save)
+      if (fat_fine(d.S)) {                       // 16-row groups (one row tile x 8 K splits)
+        va.g.ntr = t == 0 ? 0 : cdiv(d.R, 16);
+        va.gx = va.g.ntr + (in_diff ? cdiv(d.I, 16) : 0);
+        const int gxf = cdiv(va.gx, 8) * 8;
+        if (p.bf16) KLAUNCH((k_dr_f<1, 8, 16, true>), dim3(gxf, cdiv(d.S, FST), ks), dim3(NW * 64), st, pr, va);
+        KLAUNCH((k_dr_f<1, 8, 16, false>), dim3(gxf, cdiv(d.S, FST), ks), dim3(NW * 64), st, pr, va);
+      }
       if (p.bf16) KLAUNCH((k_dr_f<2, 4, 16, true>), dim3(gx, cdiv(d.S, FST), ks), dim3(NW * 64), st, pr, va);
       KLAUNCH((k_dr_f<2, 4, 16, false>), dim3(gx, cdiv(d.S, FST), ks), dim3(NW * 64), st, pr, va);
     }
@@ -2446,6 +2484,16 @@ hipError_t launch_dm_step(const Dims &d, const BwdPtrs &p, int t, const float *o
   if (vec) {
     DmVArgs va; va.g = a; va.wpk = p.pk_dm;
     if (p.fat && d.S > 16) {
+      if (fat_fine(d.S)) {
+        va.gx = cdiv(d.C, 16);
+        const dim3 fg(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
+        if (p.bf16) {
+          if (cdiv(d.R, KCH) > 16) KLAUNCH((k_dm_f<1, 8, 32, true>), fg, dim3(NW * 64), st, pr, va);
+          KLAUNCH((k_dm_f<1, 8, 16, true>), fg, dim3(NW * 64), st, pr, va);
+        }
+        if (cdiv(d.R, KCH) > 16) KLAUNCH((k_dm_f<1, 8, 32, false>), fg, dim3(NW * 64), st, pr, va);
+        KLAUNCH((k_dm_f<1, 8, 16, false>), fg, dim3(NW * 64), st, pr, va);
+      }
       va.gx = cdiv(d.C, 32);
       const dim3 fgrid(cdiv(va.gx, 8) * 8, cdiv(d.S, FST));
       if (p.bf16) {

@@ -12,6 +12,7 @@ e = k.Engine(I, C, R, S)
 e.set_option("bf16", BF)
 FOLD = int(os.environ.get("FOLD", "-1"))
 e.set_option("fold", FOLD)
+if "FINE" in os.environ: e.set_option("fat_fine", int(os.environ["FINE"]))
 if "NT2" in os.environ: e.set_option("small_nt2", int(os.environ["NT2"]))
 e.set_params(make_params(I, C, R, 0.01, 7))
 x = torch.randn(T * S, I, device="cuda"); od = 0.1 * torch.randn(T * S, R, device="cuda")
