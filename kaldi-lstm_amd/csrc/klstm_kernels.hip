@@ -1821,10 +1821,22 @@ __device__ __forceinline__ void grads_column_sums(const GradsArgs &a, int vb, fl
     const int gate = col / C, cell = col - gate * C;
     // DI/DF[1..T] pair with YC[0..T-1]; DO[1..T] pairs with YC[1..T]
     const float *cbase = a.cc + (gate == 3 ? (size_t)S * C : 0) + cell;
-    for (int r = ty; r < rows; r += 4) {
-      const float dv = a.dgifo[(size_t)(S + r) * 4 * C + col];
-      sb += dv;
-      if (gate != 0) sp += dv * cbase[(size_t)r * C];
+    const float *dbase = a.dgifo + (size_t)S * 4 * C + col;
+    // 8 row pairs in flight per thread (a serial loop pays one memory latency per row), summed in row order
+    for (int r0 = ty; r0 < rows; r0 += 32) {
+      float dv[8], cv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int r = min(r0 + 4 * u, rows - 1);
+        dv[u] = dbase[(size_t)r * 4 * C];
+        cv[u] = cbase[(size_t)r * C];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const bool on = r0 + 4 * u < rows;
+        sb += on ? dv[u] : 0.f;
+        if (gate != 0) sp += on ? dv[u] * cv[u] : 0.f;
+      }
     }
   }
   float(*rb)[64] = reinterpret_cast<float(*)[64]>(lds0);
