@@ -785,3 +785,25 @@ def test_full_size_properties_without_the_oracle():
     for s in (0, 2):
         assert np.array_equal(out_r[s::S], out_w[s::S])          # untouched streams: bit-identical to the un-reset run
         assert relerr(out_r[s::S], out4[s::S]) > 1e-4            # and they do carry state
+
+
+def test_config_c1_whole_utterance_forward():
+    """BASELINE.json configs[0]: standard/ LstmProjected 40 -> cell 800 / proj 512, ONE 1000-frame utterance, forward only
+    (what nnet-forward runs): S = 1, zero history, T = 1000 in one call -- the folded chain by default -- against the
+    oracle.  1000 recurrent steps compound fp32 summation-order differences: tolerance 2e-4 of max|out|."""
+    I, C, R, S, T = 40, 800, 512, 1, 1000
+    p = make_params(I, C, R, scale=0.01, seed=61)
+    rng = np.random.RandomState(62)
+    x = rng.randn(T, I).astype(np.float32)
+    o = Oracle(I, C, R, S, np.float32); o.set_params(p)
+    out_o = o.propagate(x)
+    for fold in (-1, 0):
+        e = make_engine(I, C, R, S, p); e.set_option("fold", fold)
+        e.reset([1])
+        xd = dev(x); outd = torch.empty(T, R, device="cuda")
+        torch.cuda.synchronize()
+        e.propagate(xd, outd); e.synchronize()
+        assert relerr(outd.cpu().numpy(), out_o) <= 2e-4
+        cs, rs = e.get_state(); st = o.get_state()
+        assert relerr(cs, st[:, 4 * C:5 * C]) <= 2e-4 and relerr(rs, st[:, 7 * C:]) <= 2e-4
+        e.close()
