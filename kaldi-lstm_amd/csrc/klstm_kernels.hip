@@ -598,19 +598,16 @@ __device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int
   constexpr int AU = BF ? 64 : 128;                            // float4 units per packed chunk
   unsigned short *ldsH = reinterpret_cast<unsigned short *>(ldsB);
   const int bs = Geo<SMALL>::bstream(lane), kg = lane >> 4;
-  for (int base = 0; base < nch; base += SUPER) {
+  // The first super-iteration is PEELED out of the loop (it is the only one whenever K <= SUPER*32, i.e. in every
+  // latency-critical shape): at a loop header the compiler drains all outstanding loads (s_waitcnt vmcnt(0)), which made
+  // the epilogue operands the callers request up front a full memory round trip in FRONT of the weight fetch.
+  auto iter = [&](int base) {
     const int nc = min(SUPER, nch - base);
     // (1) this wave's weight chunks: an even contiguous share [c0, c0 + per) of the super-iteration
     const int per = (nc + NW - 1) / NW;
     const int c0 = wave * per;
-    float4 a0[CPW], a1[CPW];
-#pragma unroll
-    for (int c = 0; c < CPW; c++) {
-      const int cl = min(c0 + c, nc - 1);                      // clamped: always a valid chunk, unused if off
-      const float4 *ap = apk + (size_t)(base + cl) * AU + lane;
-      a0[c] = ap[0]; a1[c] = BF ? a0[c] : ap[64];
-    }
-    // (2) stage B[rows][nc*32] lane-contiguous into LDS: every load of the slab is issued before the first store
+    // (2a) the B slab is requested FIRST: loads return in order, and the slab (LDS store, barrier) is needed before the
+    //      weights (first MFMA) -- behind 8 weight loads its wait would drain them too
     constexpr int ROWS = NT * TS_, F4ROW = SUPER * 8;
     constexpr int U = (ROWS * F4ROW + NW * 64 - 1) / (NW * 64);
     float4 sv[U];
@@ -620,6 +617,14 @@ __device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int
       const int sl = idx / F4ROW, k = (idx % F4ROW) * 4;
       sv[u] = bload(sl < ROWS ? sl : 0, base * KCH + k, sl < ROWS && k < nc * KCH);
     }
+    float4 a0[CPW], a1[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+      const int cl = min(c0 + c, nc - 1);                      // clamped: always a valid chunk, unused if off
+      const float4 *ap = apk + (size_t)(base + cl) * AU + lane;
+      a0[c] = ap[0]; a1[c] = BF ? a0[c] : ap[64];
+    }
+    // (2b) stage B[rows][nc*32] lane-contiguous into LDS: every load of the slab is issued before the first store
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int idx = threadIdx.x + u * NW * 64;
@@ -662,7 +667,9 @@ __device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int
       }
     }
     if (base + SUPER < nch) __syncthreads();
-  }
+  };
+  if (nch > 0) iter(0);
+  for (int base = SUPER; base < nch; base += SUPER) iter(base);
 }
 struct NoSide { __device__ __forceinline__ void operator()(int, int, const float4 &) const {} };
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
