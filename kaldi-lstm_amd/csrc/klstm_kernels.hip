@@ -676,6 +676,17 @@ __device__ __forceinline__ void vec_contract(const float4 *__restrict__ apk, int
   if (nch > 0) iter(0); else epi();
   for (int base = SUPER; base < nch; base += SUPER) iter(base);
 }
+// Zero a fetched vector where the lane's element is padding.  Written as a bitwise AND with an OPAQUE lane mask: as a
+// select the compiler sinks the load into a conditional block and drains every outstanding load (s_waitcnt vmcnt(0)) at
+// its join -- the activation slab of the gates kernel was two serialized memory round trips in front of the weight fetch.
+__device__ __forceinline__ float4 keep_if(const float4 &v, bool c) {
+  unsigned m = c ? 0xffffffffu : 0u;
+  asm volatile("" : "+v"(m));
+  return make_float4(__builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.x) & m),
+                     __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.y) & m),
+                     __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.z) & m),
+                     __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.w) & m));
+}
 struct NoSide { __device__ __forceinline__ void operator()(int, int, const float4 &) const {} };
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -732,7 +743,7 @@ __global__ __launch_bounds__(NW * 64) void k_gates_v(GatesVArgs va) {
     const bool inr = k < R, inx = FUSEX && k >= Rp && k - Rp < I;
     const float *p = inr ? a.rprev + (size_t)s * R + k : inx ? a.x + (size_t)s * a.x_stride + (k - Rp) : a.rprev;
     const float4 v = ldg4(p);
-    return (on && sbase + sl < S && (inr || inx)) ? v : f4zero();
+    return keep_if(v, on && sbase + sl < S && (inr || inx));
   };
   auto bside = [&](int sl, int k, const float4 &v) {      // :231 (r columns of time block 0)
     const int s = sbase + sl;
@@ -782,7 +793,7 @@ __global__ __launch_bounds__(NW * 64) void k_proj_v(ProjVArgs va) {
   const float *mrow = a.mm + (size_t)t * S * C;
   auto bload = [&](int sl, int k, bool on) -> float4 {
     const float4 v = ldg4(mrow + (size_t)min(sbase + sl, S - 1) * C + min(k, C - 4));
-    return (on && sbase + sl < S && k < C) ? v : f4zero();
+    return keep_if(v, on && sbase + sl < S && k < C);
   };
   vec_contract<NT, CPW, SMALL, BF>(va.wpk + (size_t)blockIdx.x * nch * (BF ? 64 : 128), nch, NT * TS_, ldsB, lane, wave, acc, bload, NoSide());
   VEC_COMBINE();
@@ -819,7 +830,7 @@ __global__ __launch_bounds__(NW * 64) void k_dr_v(DrVArgs va) {
   const float *drow = a.dgifo + (size_t)(a.t + 1) * S * K;
   auto bload = [&](int sl, int k, bool on) -> float4 {
     const float4 v = ldg4(drow + (size_t)min(sbase + sl, S - 1) * K + min(kbeg + k, K - 4));
-    return (on && sbase + sl < S && kbeg + k < kend) ? v : f4zero();
+    return keep_if(v, on && sbase + sl < S && kbeg + k < kend);
   };
   vec_contract<NT, CPW, SMALL, BF>(va.wpk + ((size_t)tile * va.nch_total + kbeg / KCH) * (BF ? 64 : 128),
                                kend > kbeg ? (kend - kbeg + KCH - 1) / KCH : 0, NT * TS_, ldsB, lane, wave, acc, bload, NoSide());
@@ -893,7 +904,7 @@ __global__ __launch_bounds__(NW * 64) void k_dm_v(DmVArgs va) {
       v.x += use ? p[ks].x : 0.f; v.y += use ? p[ks].y : 0.f;   // multiply: a never-written slab may hold NaN bit patterns)
       v.z += use ? p[ks].z : 0.f; v.w += use ? p[ks].w : 0.f;
     }
-    return (on && sbase + sl < S && k < R) ? v : f4zero();
+    return keep_if(v, on && sbase + sl < S && k < R);
   };
   auto bside = [&](int sl, int k, const float4 &v) {
     const int s = sbase + sl;
@@ -1061,7 +1072,7 @@ __global__ __launch_bounds__(NW * 64) void k_gates_f(GatesVArgs va) {
     const bool inr = k < R, inx = FUSEX && k >= Rp && k - Rp < I;
     const float *p = inr ? a.rprev + (size_t)s * R + k : inx ? a.x + (size_t)s * a.x_stride + (k - Rp) : a.rprev;
     const float4 v = ldg4(p);
-    return (on && sbase + sl < S && (inr || inx)) ? v : f4zero();
+    return keep_if(v, on && sbase + sl < S && (inr || inx));
   };
   auto bside = [&](int sl, int k, const float4 &v) {
     const int s = sbase + sl;
@@ -1110,7 +1121,7 @@ __global__ __launch_bounds__(NW * 64) void k_proj_f(ProjVArgs va) {
   const float *mrow = a.mm + (size_t)t * S * C;
   auto bload = [&](int sl, int k, bool on) -> float4 {
     const float4 v = ldg4(mrow + (size_t)min(sbase + sl, S - 1) * C + min(k, C - 4));
-    return (on && sbase + sl < S && k < C) ? v : f4zero();
+    return keep_if(v, on && sbase + sl < S && k < C);
   };
   fat_contract<MTW, KSW, FS, BF>(va.wpk + (size_t)ntile * nch * (BF ? 64 : 128), nch, ldsB, lane, ksp, acc, bload, NoSide());
   fat_combine<MTW, KSW, false>(acc, red, rt, lane, mt, ksp);
@@ -1145,7 +1156,7 @@ __global__ __launch_bounds__(NW * 64) void k_dr_f(DrVArgs va) {
   const float *drow = a.dgifo + (size_t)(a.t + 1) * S * K;
   auto bload = [&](int sl, int k, bool on) -> float4 {
     const float4 v = ldg4(drow + (size_t)min(sbase + sl, S - 1) * K + min(kbeg + k, K - 4));
-    return (on && sbase + sl < S && kbeg + k < kend) ? v : f4zero();
+    return keep_if(v, on && sbase + sl < S && kbeg + k < kend);
   };
   fat_contract<MTW, KSW, FS, BF>(va.wpk + ((size_t)tile * va.nch_total + kbeg / KCH) * (BF ? 64 : 128),
                          kend > kbeg ? (kend - kbeg + KCH - 1) / KCH : 0, ldsB, lane, ksp, acc, bload, NoSide());
@@ -1216,7 +1227,7 @@ __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
       v.x += use ? p[ks].x : 0.f; v.y += use ? p[ks].y : 0.f;   // multiply: a never-written slab may hold NaN bit patterns)
       v.z += use ? p[ks].z : 0.f; v.w += use ? p[ks].w : 0.f;
     }
-    return (on && sbase + sl < S && k < R) ? v : f4zero();
+    return keep_if(v, on && sbase + sl < S && k < R);
   };
   auto bside = [&](int sl, int k, const float4 &v) {
     const int s = sbase + sl;
