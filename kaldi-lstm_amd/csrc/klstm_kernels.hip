@@ -1551,6 +1551,38 @@ __device__ __forceinline__ void fetch_tile(const float *__restrict__ P, int ld, 
     }
   }
 }
+// The same tile for operands whose rows are 16-byte aligned with a contiguous extent that is a multiple of 8 (every
+// product of the engine itself): straight-line code -- clamped addresses, unconditional 16-byte loads, padding zeroed
+// with keep_if.  (fetch_tile's runtime `vec` switch and its selects compile to conditional blocks whose joins drain
+// every outstanding load: the four fetches of a K tile became four serialized memory round trips.)
+template <bool TA>
+__device__ __forceinline__ void fetch_tile_vec(const float *__restrict__ P, int ld, int X, int K, int x0, int k0, int tid,
+                                               float (&r)[2][8], int gperm = 0) {
+  float4 v[2][2];
+  bool ok[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const float *p;
+    if (!TA) {
+      const int x = x0 + (tid >> 2), k = k0 + h * 32 + (tid & 3) * 8;
+      ok[h] = x < X && k < K;                              // K % 8 == 0: an 8-group never straddles the end
+      const int xc = x < X ? x : 0;
+      const int xs = gperm ? (xc & 3) * gperm + (xc >> 2) : xc;
+      p = P + (size_t)xs * ld + min(k, K - 8);
+    } else {
+      const int k = k0 + h * 32 + (tid >> 3), x = x0 + (tid & 7) * 8;
+      ok[h] = k < K && x < X;                              // X % 8 == 0
+      p = P + (size_t)min(k, K - 1) * ld + min(x, X - 8);
+    }
+    v[h][0] = ldg4(p); v[h][1] = ldg4(p + 4);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const float4 a = keep_if(v[h][0], ok[h]), b = keep_if(v[h][1], ok[h]);
+    r[h][0] = a.x; r[h][1] = a.y; r[h][2] = a.z; r[h][3] = a.w;
+    r[h][4] = b.x; r[h][5] = b.y; r[h][6] = b.z; r[h][7] = b.w;
+  }
+}
 // LDS layout of an operand tile follows its storage so that the stash is two 16-byte stores either way:
 //   TA (stored [K x X]):  Ls[k*GLD + x]   (GLD = 80: the four k-groups of an MFMA read land on disjoint banks)
 //   !TA (stored [X x K]): Ls[x*GLX + k]   (GLX = 68: row x shifts the bank by 4, again disjoint for 16 rows x 4 k-groups)
@@ -1570,8 +1602,8 @@ __device__ __forceinline__ float lds_operand(const float *Ls, int k, int x) { re
 
 // 64x64 output tile, 4 waves (2x2) of 32x32, K tile 64.  The next K tile is fetched into registers while the
 // current one is multiplied out of LDS (global latency hides under 16 k-steps x 4 MFMAs per wave).
-template <bool TA, bool TB>
-__device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, float *As, float *Bs) {
+template <bool TA, bool TB, bool VEC>
+__device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0, float *As, float *Bs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kg = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
@@ -1582,8 +1614,16 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
     for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
 
   float ra[2][8], rb[2][8];
-  fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, 0, tid, ra, g.gperm);
-  fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, 0, tid, rb);   // B [N x K] when TB, else [K x N]
+  auto fetch = [&](int k0) {
+    if constexpr (VEC) {
+      fetch_tile_vec<TA>(g.A, g.lda, g.M, g.K, m0, k0, tid, ra, g.gperm);
+      fetch_tile_vec<!TB>(g.B, g.ldb, g.N, g.K, n0, k0, tid, rb);   // B [N x K] when TB, else [K x N]
+    } else {
+      fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0, tid, ra, g.gperm);
+      fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, k0, tid, rb);
+    }
+  };
+  fetch(0);
   // beta != 0 (momentum folded into the gradient products, :468-487): the old C tile is requested now so that its
   // HBM latency hides under the K loop instead of sitting in front of the stores
   float cold[2][2][4];
@@ -1606,10 +1646,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
     stash_tile<TA>(As, tid, ra);
     stash_tile<!TB>(Bs, tid, rb);
     __syncthreads();
-    if (k0 + GK < g.K) {
-      fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0 + GK, tid, ra, g.gperm);
-      fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, k0 + GK, tid, rb);
-    }
+    if (k0 + GK < g.K) fetch(k0 + GK);
     // full K tiles run a fully unrolled 16-step body (a runtime trip count defeats the unroller and leaves a rolled
     // ds_read -> MFMA loop); only the last, short tile takes the rolled path and skips its all-zero tail steps
     auto kstep = [&](int kk) {
@@ -1716,6 +1753,12 @@ __device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, floa
         if (m + 4 <= g.M) *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(e[0], e[1], e[2], e[3]);
       }
     }
+}
+
+template <bool TA, bool TB>
+__device__ __forceinline__ void gemm_tile(const GemmJob &g, int m0, int n0, float *As, float *Bs) {
+  if (g.vecA && g.vecB) gemm_tile_impl<TA, TB, true>(g, m0, n0, As, Bs);     // block-uniform: the whole K loop is one of two versions
+  else gemm_tile_impl<TA, TB, false>(g, m0, n0, As, Bs);
 }
 
 // 1-D grid padded to a multiple of 8.  XCD-aware order: workgroup w lands on XCD w % 8 (observed dispatch rule, speed
