@@ -1555,30 +1555,33 @@ __device__ __forceinline__ void fetch_tile(const float *__restrict__ P, int ld, 
 // product of the engine itself): straight-line code -- clamped addresses, unconditional 16-byte loads, padding zeroed
 // with keep_if.  (fetch_tile's runtime `vec` switch and its selects compile to conditional blocks whose joins drain
 // every outstanding load: the four fetches of a K tile became four serialized memory round trips.)
+struct RawTile { float4 v[2][2]; bool ok[2]; };
 template <bool TA>
 __device__ __forceinline__ void fetch_tile_vec(const float *__restrict__ P, int ld, int X, int K, int x0, int k0, int tid,
-                                               float (&r)[2][8], int gperm = 0) {
-  float4 v[2][2];
-  bool ok[2];
+                                               RawTile &t, int gperm = 0) {
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const float *p;
     if (!TA) {
       const int x = x0 + (tid >> 2), k = k0 + h * 32 + (tid & 3) * 8;
-      ok[h] = x < X && k < K;                              // K % 8 == 0: an 8-group never straddles the end
+      t.ok[h] = x < X && k < K;                            // K % 8 == 0: an 8-group never straddles the end
       const int xc = x < X ? x : 0;
       const int xs = gperm ? (xc & 3) * gperm + (xc >> 2) : xc;
       p = P + (size_t)xs * ld + min(k, K - 8);
     } else {
       const int k = k0 + h * 32 + (tid >> 3), x = x0 + (tid & 7) * 8;
-      ok[h] = k < K && x < X;                              // X % 8 == 0
+      t.ok[h] = k < K && x < X;                            // X % 8 == 0
       p = P + (size_t)min(k, K - 1) * ld + min(x, X - 8);
     }
-    v[h][0] = ldg4(p); v[h][1] = ldg4(p + 4);
+    t.v[h][0] = ldg4(p); t.v[h][1] = ldg4(p + 4);
   }
+}
+// the padding mask is applied HERE, one K tile later: touching the fetched registers any earlier makes the wave wait for
+// the loads before it multiplies the current tile
+__device__ __forceinline__ void unpack_tile(const RawTile &t, float (&r)[2][8]) {
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    const float4 a = keep_if(v[h][0], ok[h]), b = keep_if(v[h][1], ok[h]);
+    const float4 a = keep_if(t.v[h][0], t.ok[h]), b = keep_if(t.v[h][1], t.ok[h]);
     r[h][0] = a.x; r[h][1] = a.y; r[h][2] = a.z; r[h][3] = a.w;
     r[h][4] = b.x; r[h][5] = b.y; r[h][6] = b.z; r[h][7] = b.w;
   }
@@ -1614,10 +1617,11 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
     for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
 
   float ra[2][8], rb[2][8];
+  RawTile ta, tb;
   auto fetch = [&](int k0) {
     if constexpr (VEC) {
-      fetch_tile_vec<TA>(g.A, g.lda, g.M, g.K, m0, k0, tid, ra, g.gperm);
-      fetch_tile_vec<!TB>(g.B, g.ldb, g.N, g.K, n0, k0, tid, rb);   // B [N x K] when TB, else [K x N]
+      fetch_tile_vec<TA>(g.A, g.lda, g.M, g.K, m0, k0, tid, ta, g.gperm);
+      fetch_tile_vec<!TB>(g.B, g.ldb, g.N, g.K, n0, k0, tid, tb);   // B [N x K] when TB, else [K x N]
     } else {
       fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0, tid, ra, g.gperm);
       fetch_tile<!TB>(g.B, g.ldb, g.vecB, g.N, g.K, n0, k0, tid, rb);
@@ -1643,6 +1647,7 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
       }
   }
   for (int k0 = 0; k0 < g.K; k0 += GK) {
+    if constexpr (VEC) { unpack_tile(ta, ra); unpack_tile(tb, rb); }
     stash_tile<TA>(As, tid, ra);
     stash_tile<!TB>(Bs, tid, rb);
     __syncthreads();
