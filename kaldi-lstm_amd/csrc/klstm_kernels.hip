@@ -1960,22 +1960,22 @@ constexpr int GRADS_BF16_MIN_ROWS = 256;
 constexpr int BT = 128, BK = 64, LDQ = 36, PLANE = 32 * LDQ + 16;   // see the layout note above
 
 __device__ __forceinline__ void fetch_pair(const float *__restrict__ P, int ld, int X, int K, int x0, int k0, int u,
-                                           float4 (&r)[2]) {
+                                           float4 (&r)[2], int &ok) {
   const int kp = u >> 5, xq = u & 31;
   const int k = k0 + 2 * kp, x = x0 + 4 * xq;
   const bool xin = x + 4 <= X;                       // X % 4 == 0 on this path
   const float *p0 = P + (size_t)min(k, K - 1) * ld + (xin ? x : 0);
   const float *p1 = P + (size_t)min(k + 1, K - 1) * ld + (xin ? x : 0);
-  const float4 a = ldg4(p0), b = ldg4(p1);
-  r[0] = (xin && k < K) ? a : f4zero();
-  r[1] = (xin && k + 1 < K) ? b : f4zero();
+  r[0] = ldg4(p0); r[1] = ldg4(p1);
+  ok = (xin && k < K ? 1 : 0) | (xin && k + 1 < K ? 2 : 0);     // applied by stash_pair, one K tile later (see unpack_tile)
 }
 __device__ __forceinline__ unsigned pack_pair(float lo, float hi) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   const bf16x2 h = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(unsigned, h);
 }
-__device__ __forceinline__ void stash_pair(unsigned *Ls, int u, const float4 (&r)[2]) {
+__device__ __forceinline__ void stash_pair(unsigned *Ls, int u, const float4 (&rr)[2], int ok) {
+  const float4 r[2] = {keep_if(rr[0], (ok & 1) != 0), keep_if(rr[1], (ok & 2) != 0)};
   const int kp = u >> 5, xq = u & 31;
   unsigned *d = Ls + xq * LDQ + kp;
   d[0] = pack_pair(r[0].x, r[1].x);
@@ -1995,20 +1995,21 @@ __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int 
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
   constexpr int NU = (BK / 2) * 32 / 256;            // (k pair, x quad) units per thread and operand
   float4 ra[NU][2], rb[NU][2];
+  int oa[NU], ob[NU];
 #pragma unroll
   for (int h = 0; h < NU; h++) {
-    fetch_pair(g.A, g.lda, g.M, g.K, m0, 0, tid + 256 * h, ra[h]);
-    fetch_pair(g.B, g.ldb, g.N, g.K, n0, 0, tid + 256 * h, rb[h]);
+    fetch_pair(g.A, g.lda, g.M, g.K, m0, 0, tid + 256 * h, ra[h], oa[h]);
+    fetch_pair(g.B, g.ldb, g.N, g.K, n0, 0, tid + 256 * h, rb[h], ob[h]);
   }
   for (int k0 = 0; k0 < g.K; k0 += BK) {
 #pragma unroll
-    for (int h = 0; h < NU; h++) { stash_pair(As, tid + 256 * h, ra[h]); stash_pair(Bs, tid + 256 * h, rb[h]); }
+    for (int h = 0; h < NU; h++) { stash_pair(As, tid + 256 * h, ra[h], oa[h]); stash_pair(Bs, tid + 256 * h, rb[h], ob[h]); }
     __syncthreads();
     if (k0 + BK < g.K) {
 #pragma unroll
       for (int h = 0; h < NU; h++) {
-        fetch_pair(g.A, g.lda, g.M, g.K, m0, k0 + BK, tid + 256 * h, ra[h]);
-        fetch_pair(g.B, g.ldb, g.N, g.K, n0, k0 + BK, tid + 256 * h, rb[h]);
+        fetch_pair(g.A, g.lda, g.M, g.K, m0, k0 + BK, tid + 256 * h, ra[h], oa[h]);
+        fetch_pair(g.B, g.ldb, g.N, g.K, n0, k0 + BK, tid + 256 * h, rb[h], ob[h]);
       }
     }
 #pragma unroll
