@@ -964,17 +964,11 @@ __device__ __forceinline__ void fat_contract(const float4 *__restrict__ apk, int
   constexpr int AU = BF ? 64 : 128;
   unsigned short *ldsH = reinterpret_cast<unsigned short *>(ldsB);
   const int bs = lane & 15, kg = lane >> 4;
-  for (int base = 0; base < nch; base += FS) {
+  // first slab peeled out of the loop and the activation slab requested before the weights: see vec_contract
+  auto iter = [&](int base) {
     const int nc = min(FS, nch - base);
     const int per = (nc + KSW - 1) / KSW;
     const int c0 = ksp * per;
-    float4 a0[PER], a1[PER];
-#pragma unroll
-    for (int c = 0; c < PER; c++) {
-      const int cl = min(c0 + c, nc - 1);
-      const float4 *ap = apk + (size_t)(base + cl) * AU + lane;
-      a0[c] = ap[0]; a1[c] = BF ? a0[c] : ap[64];
-    }
     constexpr int F4ROW = FS * 8, U = (FST * F4ROW) / (NW * 64);
     float4 sv[U];
 #pragma unroll
@@ -982,6 +976,13 @@ __device__ __forceinline__ void fat_contract(const float4 *__restrict__ apk, int
       const int idx = threadIdx.x + u * NW * 64;
       const int sl = idx / F4ROW, k = (idx % F4ROW) * 4;
       sv[u] = bload(sl, base * KCH + k, k < nc * KCH);
+    }
+    float4 a0[PER], a1[PER];
+#pragma unroll
+    for (int c = 0; c < PER; c++) {
+      const int cl = min(c0 + c, nc - 1);
+      const float4 *ap = apk + (size_t)(base + cl) * AU + lane;
+      a0[c] = ap[0]; a1[c] = BF ? a0[c] : ap[64];
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -1011,7 +1012,9 @@ __device__ __forceinline__ void fat_contract(const float4 *__restrict__ apk, int
       }
     }
     if (base + FS < nch) __syncthreads();
-  }
+  };
+  if (nch > 0) iter(0);
+  for (int base = FS; base < nch; base += FS) iter(base);
 }
 
 // K-split combine (fixed order) + scatter of the MFMA tiles into the result tile rt[stream][row], row stride RTS.
