@@ -1,0 +1,19 @@
+import sys, os, time
+sys.path.insert(0, "/root/repo")
+import torch, numpy as np
+import kaldi_lstm_amd as k
+I, C, R, T = 40, 800, 512, 20
+def run(S, fold, graph):
+    e = k.Engine(I, C, R, S); e.set_option("fold", fold); e.set_option("graph", graph)
+    rng = np.random.RandomState(7)
+    e.set_params(((rng.rand(e.num_params) - 0.5) * 0.02).astype(np.float32))
+    x = torch.randn(T * S, I, device="cuda"); od = 0.1 * torch.randn(T * S, R, device="cuda")
+    out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
+    def fbu(): e.propagate(x, out); e.backpropagate(x, od, ind, 0.9); e.update(1e-5)
+    for _ in range(20): fbu()
+    e.synchronize(); t0 = time.perf_counter()
+    for _ in range(300): fbu()
+    e.synchronize(); dt = (time.perf_counter() - t0) / 300
+    e.close(); return dt * 1e6
+for S in (1, 4, 8, 12):
+    print("S=%d" % S, " ".join("fold=%d graph=%d: %.1f" % (f, g, run(S, f, g)) for f in (0, 1) for g in (1, 0)))
