@@ -144,22 +144,12 @@ template <bool SMALL> struct Geo {
   }
 };
 
-// Sum the per-wave (and, for SMALL, per-k-group) partial tiles of s-tile `nt` in a fixed order.
+// Sum the per-wave partial tiles of s-tile `nt` in a fixed order.
 template <int NT, bool SMALL>
 __device__ __forceinline__ f32x4 reduce_tile(const f32x4 (*red)[NT][64], int nt, int lane) {
-  f32x4 v = red[0][nt][lane];
-  if (SMALL) {
+  f32x4 v = red[0][nt][lane];          // SMALL: the k-groups were already combined in-wave (VEC_COMBINE)
 #pragma unroll
-    for (int g = 1; g < 4; g++) v += red[0][nt][lane + 16 * g];
-  }
-#pragma unroll
-  for (int w = 1; w < NW; w++) {
-    v += red[w][nt][lane];
-    if (SMALL) {
-#pragma unroll
-      for (int g = 1; g < 4; g++) v += red[w][nt][lane + 16 * g];
-    }
-  }
+  for (int w = 1; w < NW; w++) v += red[w][nt][lane];
   return v;
 }
 
@@ -702,8 +692,18 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
   _Pragma("unroll") for (int nt = 0; nt < NT; nt++) { acc[nt][0] = (f32x4){0, 0, 0, 0}; acc[nt][1] = (f32x4){0, 0, 0, 0}; } \
   (void)bs; (void)q
 
+// 4x4x1_16b geometry: the four k-groups of a (row, stream) pair sit 16 lanes apart -> xor butterfly first (a+b == b+a
+// bitwise, so every lane ends with the same sum), then 8 per-wave partials instead of 32 go through LDS
 #define VEC_COMBINE()                                                                            \
-  _Pragma("unroll") for (int nt = 0; nt < NT; nt++) red[wave][nt][lane] = acc[nt][0] + acc[nt][1]; \
+  _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {                                            \
+    f32x4 _v = acc[nt][0] + acc[nt][1];                                                          \
+    if (SMALL) {                                                                                 \
+      _Pragma("unroll") for (int _m = 16; _m < 64; _m <<= 1) {                                   \
+        _v.x += __shfl_xor(_v.x, _m); _v.y += __shfl_xor(_v.y, _m); _v.z += __shfl_xor(_v.z, _m); _v.w += __shfl_xor(_v.w, _m); \
+      }                                                                                          \
+    }                                                                                            \
+    red[wave][nt][lane] = _v;                                                                    \
+  }                                                                                              \
   __syncthreads()
 
 struct GatesVArgs {
