@@ -1355,30 +1355,22 @@ __global__ __launch_bounds__(NW * 64) void k_dmf_v(DmfArgs a) {
   const int sbase = blockIdx.y * 4 * NG;
   const bool last = (t == a.T);
 
-  // ---- epilogue operands first: lanes 0..3 of wave g = streams sbase+4g..sbase+4g+3, cells c0..c0+3 each ----
-  const int e_s = sbase + 4 * wave + lane;
-  const bool e_on = wave < NG && lane < 4 && e_s < S;
+  // ---- epilogue operands first: lanes 0..15 of wave g = (cell c0 + lane/4, stream sbase + 4g + lane%4): one cell per
+  //      lane, so the 15-operation cell math is one short dependent chain instead of four in a row ----
+  const int e_i = (lane >> 2) & 3, e_j = lane & 3;
+  const int e_s = sbase + 4 * wave + e_j, e_c = c0 + e_i;
+  const bool e_on = wave < NG && lane < 16 && e_s < S && e_c < C;
   const size_t row = (size_t)t * S + (e_on ? e_s : 0), rown = row + S, rowp = row - S;
-  float yg[4], yi[4], yf[4], yo[4], yh[4], cpv[4], dcn[4], fn[4], din[4], dfn[4], wpi[4], wpf[4], wpo[4], pv[4];
-  {
-    const float *yp = a.gifo + row * 4 * C;
-    load4<true>(yp, c0, C, e_on, yg);
-    load4<true>(yp + C, c0, C, e_on, yi);
-    load4<true>(yp + 2 * C, c0, C, e_on, yf);
-    load4<true>(yp + 3 * C, c0, C, e_on, yo);
-    load4<true>(a.hh + row * C, c0, C, e_on, yh);
-    load4<true>(a.cc + rowp * C, c0, C, e_on, cpv);
-    const bool n_on = e_on && !last;
-    const size_t rn = last ? row : rown;                 // clamped: block T+1 is never dereferenced
-    load4<true>(a.dc + rn * C, c0, C, n_on, dcn);
-    load4<true>(a.gifo + rn * 4 * C + 2 * C, c0, C, n_on, fn);
-    load4<true>(a.dgifo + rn * 4 * C + C, c0, C, n_on, din);
-    load4<true>(a.dgifo + rn * 4 * C + 2 * C, c0, C, n_on, dfn);
-    load4<true>(a.pi, c0, C, e_on, wpi);
-    load4<true>(a.pf, c0, C, e_on, wpf);
-    load4<true>(a.po, c0, C, e_on, wpo);
-    load4<true>(a.P + (row - S) * C, c0, C, e_on, pv);   // frame t is row block t-1 of P
-  }
+  const int lc = e_on ? e_c : 0;
+  const bool n_on = e_on && !last;
+  const size_t rn = last ? row : rown;                   // clamped: block T+1 is never dereferenced
+  const float *yp = a.gifo + row * 4 * C + lc;
+  const float yg = yp[0], yi = yp[C], yf = yp[2 * C], yo = yp[3 * C];
+  const float yh = a.hh[row * C + lc], cpv = a.cc[rowp * C + lc];
+  const float dcn_r = a.dc[rn * C + lc], fn_r = a.gifo[rn * 4 * C + 2 * C + lc];
+  const float din_r = a.dgifo[rn * 4 * C + C + lc], dfn_r = a.dgifo[rn * 4 * C + 2 * C + lc];
+  const float wpi = a.pi[lc], wpf = a.pf[lc], wpo = a.po[lc];
+  const float pv = a.P[(row - S) * C + lc];              // frame t is row block t-1 of P
 
   f32x4 acc[NG][2];
   const float *brow[NG];
@@ -1408,36 +1400,29 @@ __global__ __launch_bounds__(NW * 64) void k_dmf_v(DmfArgs a) {
   __syncthreads();
 
   if (e_on) {
-    f32x4 s = red[0][wave][lane];
+    // row (cell) e_i of stream e_j: component e_i of red[w][wave][e_j]
+    const float *rp = reinterpret_cast<const float *>(&red[0][0][0]) + (wave * 4 + e_j) * 4 + e_i;
+    float sum = rp[0];
 #pragma unroll
-    for (int w = 1; w < NW; w++) s += red[w][wave][lane];
-    const float dm[4] = {s.x + pv[0], s.y + pv[1], s.z + pv[2], s.w + pv[3]};      // :408 with :391 substituted
-    float og[4], oi[4], of[4], oo[4], oc[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float d_h = k_diff_tanh(dm[j] * yo[j], yh[j]);       // :411-412
-      const float d_o = k_diff_sigmoid(dm[j] * yh[j], yo[j]);    // :415-416
-      float d_c = d_h;                                           // :424
-      d_c = d_c + dcn[j] * fn[j];                                // :425
-      d_c = d_c + wpi[j] * din[j];                               // :426
-      d_c = d_c + wpf[j] * dfn[j];                               // :427
-      d_c = d_c + wpo[j] * d_o;                                  // :428
-      of[j] = k_diff_sigmoid(d_c * cpv[j], yf[j]);               // :431-432
-      oi[j] = k_diff_sigmoid(d_c * yg[j], yi[j]);                // :435-436
-      og[j] = k_diff_tanh(d_c * yi[j], yg[j]);                   // :439-440
-      oo[j] = d_o;
-      oc[j] = d_c;
-    }
-    float *dp = a.dgifo + row * 4 * C;
-    store4<true>(dp, c0, C, og);
-    store4<true>(dp + C, c0, C, oi);
-    store4<true>(dp + 2 * C, c0, C, of);
-    store4<true>(dp + 3 * C, c0, C, oo);
-    store4<true>(a.dc + row * C, c0, C, oc);
+    for (int w = 1; w < NW; w++) sum += rp[w * NG * 16];
+    const float dm = sum + pv;                                   // :408 with :391 substituted
+    const float dcn = n_on ? dcn_r : 0.f, fn = n_on ? fn_r : 0.f, din = n_on ? din_r : 0.f, dfn = n_on ? dfn_r : 0.f;
+    const float d_h = k_diff_tanh(dm * yo, yh);                  // :411-412
+    const float d_o = k_diff_sigmoid(dm * yh, yo);               // :415-416
+    float d_c = d_h;                                             // :424
+    d_c = d_c + dcn * fn;                                        // :425
+    d_c = d_c + wpi * din;                                       // :426
+    d_c = d_c + wpf * dfn;                                       // :427
+    d_c = d_c + wpo * d_o;                                       // :428
+    const float o_f = k_diff_sigmoid(d_c * cpv, yf);             // :431-432
+    const float o_i = k_diff_sigmoid(d_c * yg, yi);              // :435-436
+    const float o_g = k_diff_tanh(d_c * yi, yg);                 // :439-440
+    float *dp = a.dgifo + row * 4 * C + e_c;
+    dp[0] = o_g; dp[C] = o_i; dp[2 * C] = o_f; dp[3 * C] = d_o;
+    a.dc[row * C + e_c] = d_c;
     if (last) {     // the batched d_r product reads dgifo(T+1) as rows of its operand: keep that block zero (:351) even
-      const float z[4] = {0.f, 0.f, 0.f, 0.f};              // after a longer minibatch has used it
-      float *zp = a.dgifo + rown * 4 * C;
-      store4<true>(zp, c0, C, z); store4<true>(zp + C, c0, C, z); store4<true>(zp + 2 * C, c0, C, z); store4<true>(zp + 3 * C, c0, C, z);
+      float *zp = a.dgifo + rown * 4 * C + e_c;                  // after a longer minibatch has used it
+      zp[0] = 0.f; zp[C] = 0.f; zp[2 * C] = 0.f; zp[3 * C] = 0.f;
     }
   }
 }
