@@ -871,7 +871,26 @@ __global__ __launch_bounds__(NW * 64) void k_dm_v(DmVArgs va) {
   const bool e_on = wave < NT && Geo<SMALL>::owner(lane) && e_s < S && cb < C;
   const size_t row = (size_t)t * S + (e_on ? e_s : 0), rown = row + S, rowp = row - S;
   float yg[4], yi[4], yf[4], yo[4], yh[4], cpv[4], dcn[4], fn[4], din[4], dfn[4], wpi[4], wpf[4], wpo[4];
+  // 4x4x1 geometry: ONE cell per lane on all 64 lanes of wave nt (cell c0 + lane/4, stream lane%4) -- four cells on each
+  // of 16 lanes is four dependent chains of cell math in a row (see k_dmf_v)
+  const int s_cell = c0 + (lane >> 2), s_s = sbase + wave * TS_ + (lane & 3);
+  const bool s_on = SMALL && wave < NT && s_s < S && s_cell < C;
+  const size_t srow = (size_t)t * S + (s_on ? s_s : 0);
+  const int slc = s_on ? s_cell : 0;
+  float sy[13];
   auto epi = [&]() {
+    if constexpr (SMALL) {
+      const bool n_on = s_on && !last;
+      const size_t rn = last ? srow : srow + S;            // clamped: block T+1 is never dereferenced
+      const float *yp = a.gifo + srow * 4 * C + slc;
+      sy[0] = yp[0]; sy[1] = yp[C]; sy[2] = yp[2 * C]; sy[3] = yp[3 * C];
+      sy[4] = a.hh[srow * C + slc]; sy[5] = a.cc[(srow - S) * C + slc];
+      const float d0 = a.dc[rn * C + slc], d1 = a.gifo[rn * 4 * C + 2 * C + slc];
+      const float d2 = a.dgifo[rn * 4 * C + C + slc], d3 = a.dgifo[rn * 4 * C + 2 * C + slc];
+      sy[6] = n_on ? d0 : 0.f; sy[7] = n_on ? d1 : 0.f; sy[8] = n_on ? d2 : 0.f; sy[9] = n_on ? d3 : 0.f;
+      sy[10] = a.pi[slc]; sy[11] = a.pf[slc]; sy[12] = a.po[slc];
+      return;
+    }
     const float *yp = a.gifo + row * 4 * C;
     load4<true>(yp, cb, C, e_on, yg);
     load4<true>(yp + C, cb, C, e_on, yi);
@@ -913,6 +932,30 @@ __global__ __launch_bounds__(NW * 64) void k_dm_v(DmVArgs va) {
   vec_contract<NT, CPW, SMALL, BF>(va.wpk + (size_t)blockIdx.x * nch * (BF ? 64 : 128), nch, NT * TS_, ldsB, lane, wave, acc, bload, bside, epi);
   VEC_COMBINE();
 
+  if constexpr (SMALL) {
+    if (s_on) {
+      // rows 4q..4q+3 of stream j live in red[w][nt][4q + j] (k-groups already combined in-wave): this lane's cell is
+      // component (lane/4)%4 of q = lane/16
+      const float *rp = reinterpret_cast<const float *>(&red[0][wave][((lane >> 4) << 2) | (lane & 3)]) + ((lane >> 2) & 3);
+      float dmv = rp[0];
+#pragma unroll
+      for (int w = 1; w < NW; w++) dmv += rp[(size_t)w * NT * 64 * 4];
+      const float d_h = k_diff_tanh(dmv * sy[3], sy[4]);         // :411-412
+      const float d_o = k_diff_sigmoid(dmv * sy[4], sy[3]);      // :415-416
+      float d_c = d_h;                                           // :424
+      d_c = d_c + sy[6] * sy[7];                                 // :425
+      d_c = d_c + sy[10] * sy[8];                                // :426
+      d_c = d_c + sy[11] * sy[9];                                // :427
+      d_c = d_c + sy[12] * d_o;                                  // :428
+      float *dp = a.dgifo + srow * 4 * C + s_cell;
+      dp[0] = k_diff_tanh(d_c * sy[1], sy[0]);                   // :439-440
+      dp[C] = k_diff_sigmoid(d_c * sy[0], sy[1]);                // :435-436
+      dp[2 * C] = k_diff_sigmoid(d_c * sy[5], sy[2]);            // :431-432
+      dp[3 * C] = d_o;
+      a.dc[srow * C + s_cell] = d_c;
+    }
+    return;
+  }
   if (e_on) {
     const f32x4 v = reduce_tile<NT, SMALL>(red, wave, lane);
     const float dm[4] = {v.x, v.y, v.z, v.w};
