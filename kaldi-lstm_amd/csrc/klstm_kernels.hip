@@ -1225,7 +1225,6 @@ template <int MTW, int KSW, int FS, bool BF>
 __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
   const DmArgs &a = va.g;
   FAT_PROLOGUE();
-  constexpr int Q = MTW * 4;
   const int C = a.C, R = a.R, S = a.S, t = a.t;
   const int c0 = blockIdx.x * MTW * 16;
   const int sbase = blockIdx.y * FST;
@@ -1233,30 +1232,22 @@ __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
 
   reduce_x_slabs(a, sbase, min(S, sbase + FST), blockIdx.x, va.gx);
 
-  // elementwise operands: thread = (stream, cells cb..cb+3), requested before the contraction
-  const int sl_e = threadIdx.x / Q, j_e = threadIdx.x % Q;
-  const int e_s = sbase + sl_e, cb = c0 + 4 * j_e;
-  const bool e_on = sl_e < FST && e_s < S && cb < C;
-  const size_t row = (size_t)t * S + (e_on ? e_s : 0), rown = row + S, rowp = row - S;
-  float yg[4], yi[4], yf[4], yo[4], yh[4], cpv[4], dcn[4], fn[4], din[4], dfn[4], wpi[4], wpf[4], wpo[4];
-  {
-    const float *yp = a.gifo + row * 4 * C;
-    load4<true>(yp, cb, C, e_on, yg);
-    load4<true>(yp + C, cb, C, e_on, yi);
-    load4<true>(yp + 2 * C, cb, C, e_on, yf);
-    load4<true>(yp + 3 * C, cb, C, e_on, yo);
-    load4<true>(a.hh + row * C, cb, C, e_on, yh);
-    load4<true>(a.cc + rowp * C, cb, C, e_on, cpv);
-    const bool n_on = e_on && !last;
-    const size_t rn = last ? row : rown;
-    load4<true>(a.dc + rn * C, cb, C, n_on, dcn);
-    load4<true>(a.gifo + rn * 4 * C + 2 * C, cb, C, n_on, fn);
-    load4<true>(a.dgifo + rn * 4 * C + C, cb, C, n_on, din);
-    load4<true>(a.dgifo + rn * 4 * C + 2 * C, cb, C, n_on, dfn);
-    load4<true>(a.pi, cb, C, e_on, wpi);
-    load4<true>(a.pf, cb, C, e_on, wpf);
-    load4<true>(a.po, cb, C, e_on, wpo);
-  }
+  // elementwise operands, requested before the contraction: thread = (stream, ONE cell) -- 16 streams x 16*MTW cells
+  // = 256*MTW of the 512 threads (a thread that walks four cells runs four dependent chains of cell math in a row)
+  constexpr int NC = MTW * 16;
+  const int sl_e = threadIdx.x / NC, j_e = threadIdx.x % NC;
+  const int e_s = sbase + sl_e, e_c = c0 + j_e;
+  const bool e_on = sl_e < FST && e_s < S && e_c < C;
+  const int lc = e_on ? e_c : 0;
+  const size_t row = (size_t)t * S + (e_on ? e_s : 0);
+  const bool n_on = e_on && !last;
+  const size_t rn = last ? row : row + S;                // clamped: block T+1 is never dereferenced
+  const float *yp = a.gifo + row * 4 * C + lc;
+  const float yg = yp[0], yi = yp[C], yf = yp[2 * C], yo = yp[3 * C];
+  const float yh = a.hh[row * C + lc], cpv = a.cc[(row - S) * C + lc];
+  const float dcn_r = a.dc[rn * C + lc], fn_r = a.gifo[rn * 4 * C + 2 * C + lc];
+  const float din_r = a.dgifo[rn * 4 * C + C + lc], dfn_r = a.dgifo[rn * 4 * C + 2 * C + lc];
+  const float wpi = a.pi[lc], wpf = a.pf[lc], wpo = a.po[lc];
 
   const int nch = (R + KCH - 1) / KCH;
   const int ctile = min((int)blockIdx.x * MTW + mt, (C + 15) / 16 - 1);
@@ -1283,30 +1274,21 @@ __global__ __launch_bounds__(NW * 64) void k_dm_f(DmVArgs va) {
   fat_combine<MTW, KSW, false>(acc, red, rt, lane, mt, ksp);
 
   if (e_on) {
-    const float4 v = *reinterpret_cast<const float4 *>(rt + sl_e * RTS + 4 * j_e);
-    const float dm[4] = {v.x, v.y, v.z, v.w};
-    float og[4], oi[4], of[4], oo[4], oc[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float d_h = k_diff_tanh(dm[j] * yo[j], yh[j]);       // :411-412
-      const float d_o = k_diff_sigmoid(dm[j] * yh[j], yo[j]);    // :415-416
-      float d_c = d_h;                                           // :424
-      d_c = d_c + dcn[j] * fn[j];                                // :425
-      d_c = d_c + wpi[j] * din[j];                               // :426
-      d_c = d_c + wpf[j] * dfn[j];                               // :427
-      d_c = d_c + wpo[j] * d_o;                                  // :428
-      of[j] = k_diff_sigmoid(d_c * cpv[j], yf[j]);               // :431-432
-      oi[j] = k_diff_sigmoid(d_c * yg[j], yi[j]);                // :435-436
-      og[j] = k_diff_tanh(d_c * yi[j], yg[j]);                   // :439-440
-      oo[j] = d_o;
-      oc[j] = d_c;
-    }
-    float *dp = a.dgifo + row * 4 * C;
-    store4<true>(dp, cb, C, og);
-    store4<true>(dp + C, cb, C, oi);
-    store4<true>(dp + 2 * C, cb, C, of);
-    store4<true>(dp + 3 * C, cb, C, oo);
-    store4<true>(a.dc + row * C, cb, C, oc);
+    const float dm = rt[sl_e * RTS + j_e];
+    const float dcn = n_on ? dcn_r : 0.f, fn = n_on ? fn_r : 0.f, din = n_on ? din_r : 0.f, dfn = n_on ? dfn_r : 0.f;
+    const float d_h = k_diff_tanh(dm * yo, yh);                  // :411-412
+    const float d_o = k_diff_sigmoid(dm * yh, yo);               // :415-416
+    float d_c = d_h;                                             // :424
+    d_c = d_c + dcn * fn;                                        // :425
+    d_c = d_c + wpi * din;                                       // :426
+    d_c = d_c + wpf * dfn;                                       // :427
+    d_c = d_c + wpo * d_o;                                       // :428
+    float *dp = a.dgifo + row * 4 * C + e_c;
+    dp[0] = k_diff_tanh(d_c * yi, yg);                           // :439-440
+    dp[C] = k_diff_sigmoid(d_c * yg, yi);                        // :435-436
+    dp[2 * C] = k_diff_sigmoid(d_c * cpv, yf);                   // :431-432
+    dp[3 * C] = d_o;
+    a.dc[row * C + e_c] = d_c;
   }
 }
 
