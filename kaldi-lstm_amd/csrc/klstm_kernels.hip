@@ -2365,8 +2365,9 @@ int g_fat_fine = -1;            // many-stream kernels with half-size row tiles:
 // 64: 755 / 710, 128: 1056 / 1102
 static inline bool fat_fine(int S) { return g_fat_fine >= 1 || (g_fat_fine < 0 && S <= 64); }
 int g_small_nt2 = -1;         // -1 auto, 0 never, 1 always
-int g_small_max = 12;           // largest NumStream served by the 4x4x1_16b geometry (4 streams per workgroup, grid.y = S/4);
-                                // measured at 40/800/512: S=8 406 vs 471 us, S=12 473 vs 491, S=16 522 vs 515 (16x16x4 wins)
+int g_small_max = 16;           // largest NumStream served by the 4x4x1_16b geometry (4 streams per workgroup, grid.y = S/4);
+                                // measured at 40/800/512 (us per minibatch, 4x4x1 vs 16x16x4 tiles): S=8 325 vs 452, S=12 394 vs 460,
+                                // S=16 442 vs 474
 static inline VecCfg pick_vec(int S, int nch, bool gates = false) {
   VecCfg c;
   const int need = cdiv(nch, NW);
