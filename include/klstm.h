@@ -209,7 +209,7 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
  *                  thread) or issue plain stream launches (no fixed cost per graph launch)
  *   "fold"    -1/0/1  folded recurrence W_rm = W_gifo_r * W_r_m: one kernel per step and direction instead of two
  *                  (DESIGN.md 3a); -1 = auto (NumStream <= 8 and >= 12 frames per stream), 1 = whenever NumStream <=
- *                  12 and I, C, R are multiples of 8.  Same results up to fp32 summation order.
+ *                  16 and I, C, R are multiples of 8.  Same results up to fp32 summation order.
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.
  *   "fuse_x"  -1/0/1  x(t) W_gifo_x^T inside the step kernel (auto: NumStream <= 16) or as one batched product (:246)
