@@ -4,13 +4,20 @@
 
 A "step" is one BPTT minibatch: Reset (at utterance starts) -> Propagate -> Backpropagate ->
 Update over T=20 frames x S streams (bd-nnet-train-lstm-streams.cc:209-228), on synthetic
-1000-frame utterances that are already resident in HBM.  N=1 runs BASELINE.json configs[1]
-(NumStream=4).  N>1 shards independent streams over ranks (S per GPU fixed -> weak scaling) with
-ONE all-reduce of the gradient blob per minibatch (torch.distributed nccl = RCCL).
+1000-frame utterances that are already resident in HBM.
+  N = 1 : BASELINE.json configs[1] (NumStream = 4 on one GPU).
+  N > 1 : BASELINE.json configs[2]'s partitioning: 8 streams per GPU (64 streams on 8 GPUs), independent utterance
+          streams sharded over ranks (weak scaling) with ONE all-reduce of the 8.73 MB gradient blob per minibatch (RCCL).
+Timing: after W warm-up steps, exactly K steps are timed between barrier + synchronize fences (`first_k_steps`); because
+K = 20 steps are only ~5 ms of GPU time, the same K-step block is then repeated back to back until at least
+--min-seconds (default 1 s) of timed region have accumulated, and `value` / `ms_per_step` are taken over that whole
+region (`timed`).  Max over ranks.  A second run with ragged utterance lengths (900-1100 frames, new utterances enter
+at minibatch boundaries, padded frames masked) exercises the mask / Reset path (`ragged`).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -24,9 +31,17 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 I_DIM, C_DIM, R_DIM, T_BPTT, UTT_LEN = 40, 800, 512, 20, 1000
+TARGETS_DELAY = 5                                      # train_lstm_streams.sh:7
 LR, MOMENTUM, PARAM_SCALE = 1e-5, 0.9, 0.01          # train_lstm_streams.sh:3-4, nnet.proto:3
-FLOPS_PER_FRAME = 6 * (4 * C_DIM * I_DIM + 4 * C_DIM * R_DIM + R_DIM * C_DIM)   # 13 056 000
+N_PARAMS = 4 * C_DIM * I_DIM + 4 * C_DIM * R_DIM + 7 * C_DIM + R_DIM * C_DIM            # 2 181 600
+# algorithmic FLOPs per frame = 6 * (4C*I + 4C*R + R*C) (fwd + data-grad + weight-grad of the three products)
+FLOPS_PER_FRAME = 6 * (4 * C_DIM * I_DIM + 4 * C_DIM * R_DIM + R_DIM * C_DIM)           # 13 056 000
+# algorithmic HBM bytes per frame (activations) and per minibatch (weights resident on-chip within a chunk)
+ACT_BYTES_PER_FRAME = 4 * (2 * (7 * C_DIM + R_DIM) + 2 * 4 * C_DIM + 2 * R_DIM + 3 * I_DIM)   # 79 072
+WEIGHT_BYTES_PER_MINIBATCH = 5 * N_PARAMS * 4                                            # 43 632 000
 PEAK_F32_MFMA_TF = 157.3                              # MI355X_MICROARCH.md: f32-input MFMA
+PEAK_HBM_TBS = 8.0                                     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BOUNDARY_US = 1.45                                     # MI355X_MICROARCH.md price list: dependent kernel boundary
 
 
 def make_inputs(S, seed, device):
@@ -39,69 +54,112 @@ def make_inputs(S, seed, device):
     return feats.to(device), odiff.to(device)
 
 
-PEAK_HBM_TBS = 8.0                                     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+def make_ragged_schedule(S, seed, device, n_utts_per_stream=3):
+    """Utterances of 900..1100 frames through the reference's multi-stream batcher (bd-nnet-train-lstm-streams.cc:146-206):
+    a stream takes its next utterance at the first minibatch boundary after the previous one ended, the tail of the last
+    minibatch of an utterance is padded with its last frame and masked (mask 0 -> out_diff rows are zero), Reset flags mark
+    new utterances.  Everything is staged in HBM up front; returns (feats, odiff, flags, valid_frames_per_minibatch)."""
+    import kaldi_lstm_amd as k
+    rng = np.random.RandomState(seed)
+    utts = []
+    for u in range(n_utts_per_stream * S):
+        ln = int(rng.randint(900, 1101))
+        utts.append((rng.randn(ln, I_DIM).astype(np.float32), np.zeros(ln, np.int32)))
+    b = k.MultiStreamBatcher(utts, S, T_BPTT, TARGETS_DELAY)
+    feats, odiffs, flags, valid = [], [], [], []
+    while True:
+        nb = b.next()
+        if nb is None:
+            break
+        feat, _tg, mask, fl = nb
+        od = (0.1 * rng.randn(T_BPTT * S, R_DIM)).astype(np.float32) * mask[:, None]
+        feats.append(feat); odiffs.append(od); flags.append(np.asarray(fl, np.int32)); valid.append(int(mask.sum()))
+    return (torch.from_numpy(np.stack(feats)).to(device), torch.from_numpy(np.stack(odiffs)).to(device), flags, valid)
 
 
-def kernel_flops(name, S):
-    """FLOPs of one launch (contraction only).  The folded step kernels contract over the cell axis through
-    W_rm = W_gifo_r W_r_m: more FLOPs per step than the reference's two products, one launch instead of two."""
+# ---- per-launch figures of the step kernels ------------------------------------------------------------------------
+def kernel_alg_flops(name, S):
+    """ALGORITHMIC FLOPs of the frames one launch advances: the reference's own products for S frames of that direction
+    (...streams.h:246,:275,:312 forward; :391,:408 backward), NOT what a folded kernel executes (W_rm = W_gifo_r W_r_m makes
+    the folded kernels contract over the cell axis: more executed FLOPs, fewer launches)."""
     C, R, I = C_DIM, R_DIM, I_DIM
     return {"k_gates_step": 2.0 * S * 4 * C * (R + I), "k_proj_step": 2.0 * S * R * C,
             "k_dr_step": 2.0 * S * 4 * C * (R + I), "k_dm_step": 2.0 * S * R * C,
-            "k_gates_fold": 2.0 * S * 4 * C * (C + I), "k_dmf_step": 2.0 * S * C * 4 * C}[name]
+            "k_gates_fold": 2.0 * S * (4 * C * (R + I) + R * C), "k_dmf_step": 2.0 * S * (4 * C * R + R * C),
+            "k_fwd_persist": 2.0 * S * (4 * C * (R + I) + R * C), "k_bwd_persist": 2.0 * S * (4 * C * R + R * C)}[name]
 
 
-def kernel_bytes(name, S):
-    """Algorithmic HBM bytes of one launch: the weight operand has to be streamed once per step (nothing
-    on-chip survives a kernel boundary) plus the activation rows read and written."""
+def kernel_exec_flops(name, S):
+    """FLOPs the launch actually executes."""
+    C, R, I = C_DIM, R_DIM, I_DIM
+    return {"k_gates_fold": 2.0 * S * 4 * C * (C + I), "k_dmf_step": 2.0 * S * C * 4 * C}.get(name, kernel_alg_flops(name, S))
+
+
+def kernel_alg_bytes(name, S, T):
+    """ALGORITHMIC HBM bytes of one launch per SURVEY 8(d): the activation rows the reference's math reads/writes for the S
+    frames this launch advances, plus this direction's weights amortised over the T launches of a minibatch (8(d) counts
+    each weight tensor once per direction per minibatch: it assumes they stay on-chip within a chunk)."""
+    C, R, I = C_DIM, R_DIM, I_DIM
+    fwd_act = S * (I + (7 * C + R) + R)                      # x in; G,I,F,O,C,H,M,R out; out rows
+    bwd_act = S * ((7 * C + R) + R + 2 * 4 * C + 2 * C + R)  # fwd slab in; out_diff; dgifo(t+1) in + dgifo(t) out; dc in/out; d_r
+    w_fwd = (4 * C * (I + R) + 7 * C + R * C) / T
+    w_bwd = (4 * C * R + 3 * C + R * C) / T
+    return 4.0 * {"k_gates_step": fwd_act + w_fwd, "k_proj_step": S * (C + 2 * R) + R * C / T,
+                  "k_dr_step": S * (4 * C + R) + 4 * C * R / T, "k_dm_step": bwd_act + R * C / T,
+                  "k_gates_fold": fwd_act + w_fwd, "k_dmf_step": bwd_act + w_bwd,
+                  "k_fwd_persist": fwd_act + w_fwd, "k_bwd_persist": bwd_act + w_bwd}[name]
+
+
+def kernel_streamed_bytes(name, S):
+    """Bytes this launch HAS to move in the multi-launch design: its whole weight operand (nothing on-chip survives a kernel
+    boundary) plus the activation rows read and written."""
     C, R, I = C_DIM, R_DIM, I_DIM
     w = {"k_gates_step": 4 * C * (R + I), "k_proj_step": R * C, "k_dr_step": (R + I) * 4 * C, "k_dm_step": C * R,
-         "k_gates_fold": 4 * C * (C + I), "k_dmf_step": C * 4 * C}[name]
-    act = {"k_gates_step": S * (R + I + C) + 7 * C + S * 7 * C,              # r, x, c(t-1), bias+peepholes | gifo, c, h, m
-           "k_proj_step": S * C + 2 * S * R,                                 # m | r, out
-           "k_dr_step": S * 4 * C + 4 * S * (R + I),                         # dgifo(t+1) | 4 split-K slabs
-           "k_dm_step": S * R * 5 + S * C * 10 + 3 * C + S * R + S * C * 5,  # out_diff + slabs, 10 cell operands | d_r, dgifo, dc
-           "k_gates_fold": S * (C + I + C) + 7 * C + S * 7 * C,              # m(t-1), x, c(t-1), bias+peepholes | gifo, c, h, m
-           "k_dmf_step": S * 4 * C + S * C * 11 + 3 * C + S * C * 5          # dgifo(t+1), P + 10 cell operands | dgifo, dc
-           }[name]
+         "k_gates_fold": 4 * C * (C + I), "k_dmf_step": C * 4 * C}.get(name)
+    if w is None:
+        return None
+    act = {"k_gates_step": S * (R + I + C) + 7 * C + S * 7 * C, "k_proj_step": S * C + 2 * S * R,
+           "k_dr_step": S * 4 * C + 4 * S * (R + I), "k_dm_step": S * R * 5 + S * C * 10 + 3 * C + S * R + S * C * 5,
+           "k_gates_fold": S * (C + I + C) + 7 * C + S * 7 * C, "k_dmf_step": S * 4 * C + S * C * 11 + 3 * C + S * C * 5}[name]
     return 4.0 * (w + act)
 
 
-def pmc_traffic(kernel_tag):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json), or None."""
-    import glob
+ROCPROF_TAG = {"k_gates_step": "k_gates_v", "k_dr_step": "k_dr_v", "k_gates_fold": "k_gates_v", "k_dmf_step": "k_dmf_v",
+               "k_proj_step": "k_proj_v", "k_dm_step": "k_dm_v", "k_fwd_persist": "k_fwd_persist", "k_bwd_persist": "k_bwd_persist"}
+
+
+def pmc_profile():
+    """The committed rocprofv3 PMC summary (profiles/rNN_pmc_traffic.json, produced by tools/profile.sh on the GPU box in
+    SEPARATE passes -- counters cannot be collected inside a timed run), or None.  STATIC: not measured by this process."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
-        kern = json.load(open(files[-1]))["kernels"]
-        for name, v in kern.items():
-            if name.startswith(kernel_tag):
-                return v["hbm_bytes_per_launch"]
+        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
-    return None
+        return None, None
 
 
 def init_params(seed=7):
     """U[-ParamScale, +ParamScale] parameters from a fixed-seed host RNG (InitMatParam/InitVecParam semantics,
     ...streams.h:41-53), GetParams order; identical on every rank."""
     rng = np.random.RandomState(seed)
-    n = 4 * C_DIM * I_DIM + 4 * C_DIM * R_DIM + 7 * C_DIM + R_DIM * C_DIM
-    return ((rng.rand(n) - 0.5) * 2 * PARAM_SCALE).astype(np.float32)
+    return ((rng.rand(N_PARAMS) - 0.5) * 2 * PARAM_SCALE).astype(np.float32)
 
 
 def cpu_baseline(S, budget_s):
-    """The oracle (reference op sequence, un-fused) timed on this host on a bounded sample of the same workload:
-    1 thread (Kaldi nnet1 is single-threaded outside BLAS) = `value`, and with the GEMMs threaded over all host cores
-    (what a multi-threaded BLAS under Kaldi would give) = `value_threaded`.  The ONLY place bench.py touches oracle/."""
-    from oracle.oracle import Oracle
+    """The oracle (reference op sequence, un-fused, one GEMM per reference AddMatMat) timed on this host on a bounded sample
+    of the same workload.  The reference's CPU path calls cblas_sgemm (kaldi-matrix.cc:160-175): `value` = GEMMs through
+    OpenBLAS cblas_sgemm on ONE thread (Kaldi nnet1 is single-threaded outside BLAS), `value_threaded` = the same with the
+    BLAS on all physical cores, `value_plain_loops` = the oracle's own triple loops (what the parity tests run).
+    The ONLY place bench.py touches oracle/."""
+    from oracle.oracle import Oracle, use_openblas
     rng = np.random.RandomState(0)
     x = rng.randn(T_BPTT * S, I_DIM).astype(np.float32)
     od = (0.1 * rng.randn(T_BPTT * S, R_DIM)).astype(np.float32)
 
-    def timed(threads, budget):
-        o = Oracle(I_DIM, C_DIM, R_DIM, S, np.float32, threads=threads)
+    def timed(budget):
+        o = Oracle(I_DIM, C_DIM, R_DIM, S, np.float32, threads=1)
         o.set_params(init_params())
         o.propagate(x); o.backpropagate(x, od, MOMENTUM); o.update(LR)      # warm-up
         n, t0 = 0, time.perf_counter()
@@ -113,21 +171,40 @@ def cpu_baseline(S, budget_s):
                 return n, dt
 
     cpu_model = "unknown CPU"
+    phys = set()
     try:
+        pid = cid = None
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
+            if line.startswith("model name") and cpu_model == "unknown CPU":
                 cpu_model = line.split(":", 1)[1].strip()
-                break
+            if line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            if line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+                phys.add((pid, cid))
     except OSError:
         pass
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    nthr = min(ncores, 16)      # the products are GEMV-sized (M = NumStream): more threads only add fork/join cost
-    n1, dt1 = timed(1, budget_s)
-    na, dta = timed(nthr, max(2.0, budget_s / 3))
-    return {"value": n1 * T_BPTT * S / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
-            "value_threaded": na * T_BPTT * S / dta, "cores_threaded": nthr, "host_cores": ncores,
-            "sample": f"{n1} minibatches of {T_BPTT}x{S} frames ({dt1:.1f} s) on 1 thread, {na} ({dta:.1f} s) on "
-                      f"{nthr} OpenMP threads ({cpu_model}, {ncores} logical cores); oracle/lstmp_oracle.c fp32, un-fused reference op order"}
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncores = min(len(phys) or logical, logical)
+    nthr = min(ncores, 64)                      # OpenBLAS build limit (MAX_THREADS = 64)
+    res = {"unit": "frames/s", "kind": "port", "host_logical_cores": logical, "host_physical_cores": ncores}
+    n0, dt0 = timed(max(2.0, budget_s / 4))
+    res["value_plain_loops"] = n0 * T_BPTT * S / dt0
+    blas = use_openblas(1)
+    if blas is None:                            # no OpenBLAS found: the plain loops are all there is
+        res.update({"value": res["value_plain_loops"], "cores": 1, "blas": "none (oracle's own loops)"})
+        n1, dt1, na, dta = n0, dt0, 0, 0.0
+    else:
+        n1, dt1 = timed(budget_s)
+        res.update({"value": n1 * T_BPTT * S / dt1, "cores": 1, "blas": blas})
+        use_openblas(nthr)
+        na, dta = timed(max(2.0, budget_s / 3))
+        res.update({"value_threaded": na * T_BPTT * S / dta, "cores_threaded": nthr})
+        use_openblas(0)
+    res["sample"] = (f"{n1} minibatches of {T_BPTT}x{S} frames ({dt1:.1f} s) with cblas_sgemm on 1 thread, {na} ({dta:.1f} s) on {nthr} "
+                     f"BLAS threads, {n0} ({dt0:.1f} s) with the oracle's own loops; {cpu_model}, {ncores} physical / {logical} logical "
+                     f"cores; oracle/lstmp_oracle.c fp32, un-fused reference op order")
+    return res
 
 
 def main():
@@ -135,12 +212,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--streams-per-gpu", type=int, default=4)
+    ap.add_argument("--streams-per-gpu", type=int, default=0,
+                    help="default: 4 on one GPU (BASELINE.json configs[1]), 8 per GPU on N > 1 (configs[2]: 64 streams on 8 GPUs)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="minimum length of the timed region (whole K-step blocks)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the ragged-length run and the 8-streams-per-GPU reference point")
     ap.add_argument("--launch", choices=("auto", "graph", "eager"), default="auto",
                     help="engine option 'graph': hipGraph replay per call (robust against a busy host thread) or plain "
-                         "stream launches (no ~6 us fixed cost per graph); auto = time both during the warm-up, keep the faster")
+                         "stream launches (no fixed cost per graph launch); auto = time both before the warm-up, keep the faster")
+    ap.add_argument("--option", action="append", default=[], help="engine option key=value (A/B experiments), repeatable")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,21 +239,9 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     import kaldi_lstm_amd as k
-    S = args.streams_per_gpu
+    S = args.streams_per_gpu or (4 if world == 1 else 8)
     stream = torch.cuda.Stream()
-    eng = k.Engine(I_DIM, C_DIM, R_DIM, S, device=local_rank, stream=stream)
-    eng.set_params(init_params())   # identical on all ranks
-    feats, odiff = make_inputs(S, 1234 + rank, "cuda")
-    nchunk = feats.shape[0]
-    out = torch.empty(T_BPTT * S, R_DIM, device="cuda")
-    in_diff = torch.empty(T_BPTT * S, I_DIM, device="cuda")
     ones = np.ones(S, np.int32)
-    dp = k.DataParallelLstm(eng)          # N>1: one all-reduce (sum, fp32) of the 8.73 MB gradient blob per minibatch
-    torch.cuda.synchronize()
-
-    def step(i):
-        c = i % nchunk                      # new utterances on every stream (lock-step) every 50 chunks
-        dp.train_step(feats[c], out, odiff[c], in_diff, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -180,106 +249,209 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def make_engine(S_):
+        e = k.Engine(I_DIM, C_DIM, R_DIM, S_, device=local_rank, stream=stream)
+        e.set_params(init_params())   # identical on all ranks
+        for kv in args.option:
+            key, val = kv.split("=")
+            e.set_option(key, int(val))
+        return e
+
+    eng = make_engine(S)
+    feats, odiff = make_inputs(S, 1234 + rank, "cuda")
+    nchunk = feats.shape[0]
+    out = torch.empty(T_BPTT * S, R_DIM, device="cuda")
+    in_diff = torch.empty(T_BPTT * S, I_DIM, device="cuda")
+    dp = k.DataParallelLstm(eng)          # N>1: one all-reduce (sum, fp32) of the 8.73 MB gradient blob per minibatch
+    torch.cuda.synchronize()
+
+    def step(i):
+        c = i % nchunk                      # new utterances on every stream (lock-step) every 50 chunks
+        dp.train_step(feats[c], out, odiff[c], in_diff, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
+
+    def timed_block(fn, i0, n):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(i0, i0 + n):
+            fn(i)
+        fence()
+        return max_over_ranks(time.perf_counter() - t0)
+
     with torch.cuda.stream(stream):
+        # ---- launch mode A/B (untimed, independent of --warmup): 4 + 16 steps per mode
         launch = args.launch
-        if launch == "auto" and args.warmup < 20:
-            launch = "graph"
-        if launch == "auto":                 # inside the untimed warm-up: half the steps per mode, keep the faster
-            half, tm = args.warmup // 2, []
+        ab = None
+        if launch == "auto":
+            tm = []
             for mode in (1, 0):
                 eng.set_option("graph", mode)
                 for i in range(4):
                     step(i)
-                fence()
-                t0 = time.perf_counter()
-                for i in range(half):
-                    step(i)
-                fence()
-                tm.append(time.perf_counter() - t0)
-            tt = torch.tensor(tm, device="cuda", dtype=torch.float64)
-            if world > 1:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # same decision on every rank
-            launch = "graph" if float(tt[0]) <= float(tt[1]) else "eager"
+                tm.append(timed_block(step, 4, 16))
+            launch = "graph" if tm[0] <= tm[1] else "eager"
+            ab = {"graph_ms_per_step": tm[0] / 16 * 1e3, "eager_ms_per_step": tm[1] / 16 * 1e3}
         eng.set_option("graph", 1 if launch == "graph" else 0)
-        for i in range(args.warmup if args.launch != "auto" or args.warmup < 20 else 8):
+        # ---- warm-up, then exactly K steps, then whole K-step blocks until --min-seconds of timed region
+        for i in range(args.warmup):
             step(i)
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + args.steps):
-            step(i)
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
+        K = args.steps
+        dt_first = timed_block(step, args.warmup, K)
+        blocks = max(0, int(np.ceil((args.min_seconds - dt_first) / max(dt_first, 1e-9))))
+        dt_total, nsteps_total = dt_first, K
+        if blocks:
+            dt_total += timed_block(step, args.warmup + K, blocks * K)
+            nsteps_total += blocks * K
+
+        # ---- ragged utterance lengths (900..1100): mask / Reset on the timed path
+        ragged = None
+        if not args.no_extras:
+            rf, rod, rflags, rvalid = make_ragged_schedule(S, 4321 + rank, "cuda")
+            nrag = rf.shape[0]
+
+            def rstep(i):
+                c = i % nrag
+                fl = rflags[c] if c else ones           # wrap-around: every stream starts over
+                dp.train_step(rf[c], out, rod[c], in_diff, MOMENTUM, LR, reset_flags=fl if fl.any() else None)
+            for i in range(8):
+                rstep(i)
+            reps = max(1, int(np.ceil(min(args.min_seconds, 0.5) / max(dt_first / K * nrag, 1e-9))))
+            dtr = timed_block(rstep, 0, reps * nrag)
+            ragged = {"value": reps * sum(rvalid) * world / dtr, "unit": "valid frames/s", "ms_per_step": dtr / (reps * nrag) * 1e3,
+                      "minibatches": reps * nrag, "valid_frame_fraction": sum(rvalid) / (nrag * T_BPTT * S),
+                      "utterance_frames": "uniform 900..1100", "resets_per_pass": int(sum(int(f.sum()) for f in rflags))}
+            del rf, rod
 
         # ---- roofline leg: per-kernel device time from HIP start/stop events on the engine stream
         NPROF = 10
+        base = args.warmup + nsteps_total
         eng.set_option("profile", 1)
         for i in range(3):                   # untimed pass: creates the event pool
-            step(args.warmup + args.steps + i)
+            step(base + i)
         eng.profile_query("k_gates_step")
         eng.set_option("profile", 1)         # clears the accumulators, keeps the pool
         for i in range(NPROF):
-            step(args.warmup + args.steps + 3 + i)
+            step(base + 3 + i)
         kern = {}
         for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj",
                      "k_gates_fold", "k_gemm_rbatch", "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step",
-                     "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx",
+                     "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx", "k_fwd_persist", "k_bwd_persist",
                      "k_grads", "k_update_repack", "k_pack", "k_pack_fwd", "k_pack_bwd", "k_apply_momentum"):
             tot, n = eng.profile_query(name)
             if n:
                 kern[name] = {"avg_us": tot / n, "launches_per_step": n / NPROF, "us_per_step": tot / NPROF}
         eng.set_option("profile", 0)
 
-    frames = args.steps * T_BPTT * S * world
-    value = frames / dt
-    res = None
+        # ---- 8 streams per GPU on this one GPU: the denominator of a 1 -> 8 GPU efficiency (configs[2] runs 8 per GPU)
+        s8 = None
+        if world == 1 and not args.no_extras and S != 8:
+            e8 = make_engine(8)
+            e8.set_option("graph", 1 if launch == "graph" else 0)
+            f8, o8 = make_inputs(8, 99, "cuda")
+            out8 = torch.empty(T_BPTT * 8, R_DIM, device="cuda"); id8 = torch.empty(T_BPTT * 8, I_DIM, device="cuda")
+            ones8 = np.ones(8, np.int32)
+
+            def step8(i):
+                c = i % nchunk
+                if c == 0:
+                    e8.reset(ones8)
+                e8.propagate(f8[c], out8); e8.backpropagate(f8[c], o8[c], id8, MOMENTUM, 0); e8.update(LR)
+            for i in range(10):
+                step8(i)
+            n8 = 200
+            dt8 = timed_block(step8, 10, n8)
+            s8 = {"value": n8 * T_BPTT * 8 / dt8, "unit": "frames/s", "ms_per_step": dt8 / n8 * 1e3, "streams": 8, "steps": n8}
+            e8.close()
+
+    frames_per_step = T_BPTT * S * world
+    value = nsteps_total * frames_per_step / dt_total
+    ms_per_step = dt_total / nsteps_total * 1e3
     if rank == 0:
-        # dominant kernel = the step kernel that carries the most algorithmic FLOPs per minibatch
-        # (k_gates_step forward, k_dr_step backward: 2*S*4C*R each); of those, the slower one.
-        step_kernels = ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_gates_fold", "k_dmf_step")
+        step_kernels = ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_gates_fold", "k_dmf_step",
+                        "k_fwd_persist", "k_bwd_persist")
         for n in step_kernels:
             if n in kern:
-                kern[n]["tflops"] = kernel_flops(n, S) / (kern[n]["avg_us"] * 1e-6) / 1e12
-                kern[n]["gbs"] = kernel_bytes(n, S) / (kern[n]["avg_us"] * 1e-6) / 1e9
-        folded = "k_dmf_step" in kern
-        # dominant kernel = the step kernel with the most device time per minibatch (folded chain: k_gates_fold forward,
-        # k_dmf_step backward; reference-shaped chain: k_gates_step / k_dr_step, which carry the FLOPs)
-        cand = ("k_gates_fold", "k_dmf_step") if folded else ("k_gates_step", "k_dr_step")
-        dom = max((n for n in kern if n in cand), key=lambda n: kern[n]["us_per_step"])
-        # roofline side: arithmetic intensity of a step kernel is ~S/2 FLOP/B (weights are re-streamed every step),
-        # the ridge is 157.3 TF / 8 TB/s ~ 20 FLOP/B  ->  HBM-bound below S ~ 40, MFMA-bound above
-        intensity = kernel_flops(dom, S) / kernel_bytes(dom, S)
-        hbm_bound = intensity < PEAK_F32_MFMA_TF / PEAK_HBM_TBS
-        tflops = kernel_flops(dom, S) / (kern[dom]["avg_us"] * 1e-6) / 1e12
-        gbs = kernel_bytes(dom, S) / (kern[dom]["avg_us"] * 1e-6) / 1e9
-        tag = {"k_gates_step": "k_gates_v", "k_dr_step": "k_dr_v", "k_gates_fold": "k_gates_v", "k_dmf_step": "k_dmf_v"}[dom]
+                us = kern[n]["avg_us"] * 1e-6
+                if n.endswith("_persist"):             # one launch advances T-1 (forward) / T (backward) steps
+                    us = us / (T_BPTT - 1 if n == "k_fwd_persist" else T_BPTT)
+                    kern[n]["us_per_recurrence_step"] = us * 1e6
+                kern[n]["alg_tflops"] = kernel_alg_flops(n, S) / us / 1e12
+                kern[n]["alg_gbs"] = kernel_alg_bytes(n, S, T_BPTT) / us / 1e9
+        folded = "k_dmf_step" in kern or "k_bwd_persist" in kern
+        # dominant kernel = the step kernel with the most device time per minibatch
+        dom = max((n for n in kern if n in step_kernels), key=lambda n: kern[n]["us_per_step"])
+        per_step_us = kern[dom].get("us_per_recurrence_step", kern[dom]["avg_us"])
+        a_bytes, a_flops = kernel_alg_bytes(dom, S, T_BPTT), kernel_alg_flops(dom, S)
+        gbs = a_bytes / (per_step_us * 1e-6) / 1e9
+        tflops = a_flops / (per_step_us * 1e-6) / 1e12
+        # which roofline: algorithmic intensity of the whole path (8(d): ~165 FLOP/B with weights resident) is far above the
+        # ridge, but a step at S streams is a chain of dependent exchanges; the kernel's own intensity decides the label
+        hbm_bound = (a_flops / a_bytes) < PEAK_F32_MFMA_TF / PEAK_HBM_TBS
+        pmc, pmc_file = pmc_profile()
+        traffic = traffic_ratio = mfma_busy = None
+        alg_bytes_mb = ACT_BYTES_PER_FRAME * T_BPTT * S + WEIGHT_BYTES_PER_MINIBATCH
+        if pmc and pmc.get("streams_per_gpu", 4) == S and pmc.get("chain", "") == ("persistent" if dom.endswith("_persist") else "launches"):
+            for name, v in pmc["kernels"].items():
+                if name.startswith(ROCPROF_TAG[dom]):
+                    traffic = v["hbm_bytes_per_launch"]
+                    mfma_busy = v.get("mfma_busy_frac")
+            if pmc.get("hbm_bytes_per_minibatch"):
+                traffic_ratio = pmc["hbm_bytes_per_minibatch"] / alg_bytes_mb
+        roof = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
+                "achieved": gbs if hbm_bound else tflops, "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else PEAK_F32_MFMA_TF,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": gbs / (PEAK_HBM_TBS * 1e3) if hbm_bound else tflops / PEAK_F32_MFMA_TF,
+                "traffic": traffic, "traffic_source": (pmc_file + " (static: separate rocprofv3 --pmc passes, not this run)") if traffic else None,
+                "avg_us": kern[dom]["avg_us"], "us_per_recurrence_step": per_step_us,
+                "alg_bytes_per_launch": a_bytes, "alg_flops_per_launch": a_flops,
+                "mfma_tflops": tflops, "mfma_frac": tflops / PEAK_F32_MFMA_TF, "hbm_gbs": gbs, "hbm_frac": gbs / (PEAK_HBM_TBS * 1e3),
+                "mfma_busy_frac_pmc": mfma_busy,
+                # SURVEY 8(d) whole-path figures on ms_per_step (weights resident within a chunk)
+                "algorithmic": {"flops_per_minibatch": FLOPS_PER_FRAME * T_BPTT * S, "bytes_per_minibatch": alg_bytes_mb,
+                                "mfma_frac": FLOPS_PER_FRAME * T_BPTT * S / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TF,
+                                "hbm_frac": alg_bytes_mb / (ms_per_step * 1e-3) / 1e12 / PEAK_HBM_TBS},
+                "traffic_ratio": traffic_ratio,
+                # 8(d): us per recurrence step against the 2-boundary floor of the reference-shaped chain
+                "sync_floor": {"us_per_step_and_direction": per_step_us, "two_boundary_floor_us": 2 * BOUNDARY_US}}
+        sb = kernel_streamed_bytes(dom, S)
+        if sb:                                  # what a launch-per-step design must stream (its whole weight operand per launch)
+            roof["streamed"] = {"bytes_per_launch": sb, "gbs": sb / (per_step_us * 1e-6) / 1e9,
+                                "frac": sb / (per_step_us * 1e-6) / 1e9 / (PEAK_HBM_TBS * 1e3),
+                                "exec_flops_per_launch": kernel_exec_flops(dom, S)}
+        chain_us = sum(v["us_per_step"] for n, v in kern.items() if n in step_kernels)
         res = {
             "metric": "frames/sec fwd+BPTT, 40in/800cell/512proj LSTM at 1/2/4/8 MI355X",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "google/ LstmProjectedStreams 40->cell800/proj512, NumStream=%d per GPU, "
-                                   "T_bptt=20, 1000-frame synthetic utterances, fwd+BPTT+update "
-                                   "(BASELINE.json configs[1])" % S,
+            "config": {"workload": "google/ LstmProjectedStreams 40->cell800/proj512, NumStream=%d per GPU (%d in total), "
+                                   "T_bptt=20, 1000-frame synthetic utterances, fwd+BPTT+update (BASELINE.json %s)"
+                                   % (S, S * world, "configs[1]" if world == 1 and S == 4 else
+                                      "configs[2]: 64 streams = 8 per GPU x 8 GPUs" if S == 8 else "custom stream count"),
                        "streams_per_gpu": S, "total_streams": S * world, "bptt": T_BPTT,
-                       "frames_per_step": T_BPTT * S * world, "launch": launch,
-                       "recurrence": "folded (W_rm = W_gifo_r W_r_m, one kernel per step and direction)" if folded
-                                     else "reference-shaped (gates + projection, d_r + d_m kernels per step)",
+                       "frames_per_step": frames_per_step, "launch": launch, "launch_ab": ab,
+                       "recurrence": ("persistent weights-resident chain" if "k_bwd_persist" in kern or "k_fwd_persist" in kern else
+                                      "folded (W_rm = W_gifo_r W_r_m, one kernel per step and direction)" if folded
+                                      else "reference-shaped (gates + projection, d_r + d_m kernels per step)"),
                        "parallelism": "dp%d over streams, 1 all-reduce/minibatch" % world if world > 1 else "single GPU"},
-            "roofline": ({"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
-                          "frac": gbs / (PEAK_HBM_TBS * 1e3)} if hbm_bound else
-                         {"bound": "mfma", "kernel": dom, "achieved": tflops, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                          "frac": tflops / PEAK_F32_MFMA_TF}),
+            "timed": {"steps": nsteps_total, "seconds": dt_total},
+            "first_k_steps": {"steps": K, "seconds": dt_first, "ms_per_step": dt_first / K * 1e3,
+                              "value": K * frames_per_step / dt_first},
+            "roofline": roof,
             "whole_path_tflops": value * FLOPS_PER_FRAME / 1e12 / world,
+            "chain_us_per_step": chain_us, "non_chain_us_per_step": sum(v["us_per_step"] for v in kern.values()) - chain_us,
             "kernels": kern,
         }
-        res["roofline"].update({"traffic": pmc_traffic(tag) if S == 4 else None, "avg_us": kern[dom]["avg_us"],
-                                "bytes_per_launch": kernel_bytes(dom, S), "flops_per_launch": kernel_flops(dom, S),
-                                "flop_per_byte": intensity, "mfma_tflops": tflops,
-                                "mfma_frac": tflops / PEAK_F32_MFMA_TF})
+        if ragged:
+            res["ragged"] = ragged
+        if s8:
+            res["s8_per_gpu"] = s8
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(S, args.cpu_seconds)
         print(json.dumps(res))

@@ -25,21 +25,20 @@ def lib_path():
 
 
 def load_library():
-    """dlopen the in-tree libklstm.so.  If it has not been built yet it is compiled in place with hipcc (gfx950);
+    """dlopen the in-tree libklstm.so.  If it has not been built yet, or its sources changed since, it is compiled in place with hipcc (gfx950);
     there is no other implementation to fall back to -- without the HIP library every call raises."""
     global _LIB
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.exists(path):
-        try:
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("klstm_build", os.path.join(_HERE, "build.py"))
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
-            mod.build()
-        except Exception as exc:       # noqa: BLE001
-            raise KlstmError(-1, f"{path} missing and could not be built with hipcc: {exc}") from exc
+    try:                               # no-op unless the sources changed since the library was built (content hash)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("klstm_build", os.path.join(_HERE, "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    except Exception as exc:       # noqa: BLE001
+        raise KlstmError(-1, f"{path} missing or stale and could not be built with hipcc: {exc}") from exc
     lib = ctypes.CDLL(path)
     P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
     lib.klstm_last_error.restype = ctypes.c_char_p

@@ -9,11 +9,24 @@ HDRS = ["csrc/klstm_kernels.h", "../include/klstm.h"]
 LIB = os.path.join(HERE, "libklstm.so")
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_hash():
+    """Content hash of everything the library is built from (mtimes do not survive the copy to the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SRCS + HDRS + ["build.py"]:
+        with open(os.path.join(HERE, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SRCS + HDRS + ["build.py"])
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -25,6 +38,8 @@ def build(force=False, verbose=False):
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as fh:
+        fh.write(source_hash() + "\n")
     return LIB
 
 

@@ -136,18 +136,8 @@ static klstm_status ensure_planes(klstm_engine *e, int T) {
   HIPCHK(hipMalloc(&e->dr, nb * e->R * sizeof(float)));
   HIPCHK(hipMalloc(&e->dr_part, (size_t)e->ks * e->S * e->R * sizeof(float)));
   HIPCHK(hipMalloc(&e->dx_part, (size_t)e->ks * e->S * e->I * sizeof(float)));
-  {                                   // folded path: P plane and the split-K workspace of its two batched products
-    HIPCHK(hipMalloc(&e->Pm, (size_t)T * e->S * e->C * sizeof(float)));
-    int kl = 0;
-    const size_t M = (size_t)T * e->S;
-    const size_t need[4] = {bwd_tail_ws_floats(d),                                                 // d_r + in_diff
-                            0,
-                            (size_t)gemm_splitk_plan((int)M, e->R, e->C, &kl) * M * e->R,          // r
-                            (size_t)gemm_splitk_plan((int)M, e->C, e->R, &kl) * M * e->C};         // P
-    e->ws_floats = 0;
-    for (size_t n : need) if (n > e->ws_floats) e->ws_floats = n;
-    HIPCHK(hipMalloc(&e->ws, e->ws_floats * sizeof(float)));
-  }
+  HIPCHK(hipMalloc(&e->Pm, (size_t)T * e->S * e->C * sizeof(float)));      // folded path: P = out_diff W_r_m plane
+  e->ws_floats = 0;                                                        // split-K workspace: sized per call (ensure_ws)
   // kSetZero semantics of the reference slabs (...streams.h:230, :352)
   HIPCHK(hipMemsetAsync(e->gifo, 0, nb * 4 * e->C * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->cc, 0, nb * e->C * sizeof(float), e->stream));
@@ -158,6 +148,32 @@ static klstm_status ensure_planes(klstm_engine *e, int T) {
   HIPCHK(hipMemsetAsync(e->dc, 0, nb * e->C * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->dr, 0, nb * e->R * sizeof(float), e->stream));
   e->T_alloc = T;
+  return KLSTM_OK;
+}
+
+// Split-K workspace of the folded path's batched products (r, P, d_r + in_diff).  gemm_splitk_plan() takes MORE K slices
+// when M = T*S is smaller, so ks*M*N is not monotonic in T: the need is computed for the T of THIS call, never inferred
+// from T_alloc.
+static size_t ws_need(const klstm_engine *e, int T) {
+  const Dims d{e->I, e->C, e->R, e->S, T};
+  int kl = 0;
+  const size_t M = (size_t)T * e->S;
+  size_t need = bwd_tail_ws_floats(d);                                                               // d_r + in_diff
+  const size_t nr = (size_t)gemm_splitk_plan((int)M, e->R, e->C, &kl) * M * e->R;                    // r
+  const size_t np = (size_t)gemm_splitk_plan((int)M, e->C, e->R, &kl) * M * e->C;                    // P
+  if (nr > need) need = nr;
+  if (np > need) need = np;
+  return need;
+}
+static klstm_status ensure_ws(klstm_engine *e, int T) {
+  const size_t need = ws_need(e, T);
+  if (need <= e->ws_floats && e->ws) return KLSTM_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  drop_graphs(e);                     // captured launches hold the old address
+  if (e->ws) (void)hipFree(e->ws);
+  e->ws = nullptr; e->ws_floats = 0;
+  HIPCHK(hipMalloc(&e->ws, need * sizeof(float)));
+  e->ws_floats = need;
   return KLSTM_OK;
 }
 
@@ -498,7 +514,7 @@ static klstm_status run_graphed(klstm_engine *e, const klstm_engine::Key &key, F
   if (it == e->graphs.end()) {
     // graphs bake the caller's pointers; a trainer that cycles through a pool of minibatch buffers needs one
     // graph per buffer (bench.py: 50 feature chunks x {fwd, bwd}).  Bounded so a pathological caller cannot leak.
-    if (e->graphs.size() >= 4096) drop_graphs(e);
+    if (e->graphs.size() >= 4096) { HIPCHK(hipStreamSynchronize(e->stream)); drop_graphs(e); }   // launched execs may still run
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     klstm_status st = seq();
@@ -532,6 +548,7 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
   e->fwd_folded = fold_wanted(e, T);
+  if (e->fwd_folded && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_fold(e)) != KLSTM_OK) return st;     // outside the graph: only after an Update
   if (!e->fwd_folded && (st = ensure_packs(e)) != KLSTM_OK) return st;
   klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, e->fwd_folded ? -2 : -1);
@@ -935,6 +952,7 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
     if (!e->pk[0] || e->use_bf16) return fail(KLSTM_ERR_SHAPE, "folded path not available for this engine");
     klstm_status fs = ensure_fold(e);
     if (fs != KLSTM_OK) return fs;
+    if ((fs = ensure_ws(e, T)) != KLSTM_OK) return fs;
   }
   const FwdPtrs fp = fwd_ptrs(e);
   const BwdPtrs bp = bwd_ptrs(e);

@@ -84,10 +84,29 @@ static inline REAL k_tanh(REAL x) {
  * the innermost loop is unit-stride (gcc -O3 vectorises it); summation order over k is
  * ascending, as in a reference (non-blocked) sgemm. */
 
+/* Optional BLAS back end for the timed CPU baseline: the reference's CPU path calls cblas_sgemm for every AddMatMat
+ * (google/matrix/kaldi-matrix.cc:160-175, cblas_Xgemm).  No CBLAS headers exist in this image; bench.py hands in the
+ * address of the ILP64 cblas_sgemm of the OpenBLAS that ships inside numpy (oracle/oracle.py: use_openblas()).  Process-wide;
+ * fp32 build only; NULL = the plain loops below (the parity tests always use the plain loops: fixed summation order). */
+typedef void (*cblas_sgemm64_fn)(int order, int transA, int transB, long M, long N, long K, float alpha, const float *A,
+                                 long lda, const float *B, long ldb, float beta, float *C, long ldc);
+static cblas_sgemm64_fn g_sgemm = 0;
+void lstmp_oracle_set_sgemm(void *fn) { g_sgemm = (cblas_sgemm64_fn)fn; }
+int lstmp_oracle_has_sgemm(void) { return g_sgemm != 0 && sizeof(REAL) == 4; }
+enum { CblasRowMajor_ = 101, CblasNoTrans_ = 111, CblasTrans_ = 112 };
+static inline int blas_gemm(int ta, int tb, int M, int N, int K, const REAL *A, int lda, const REAL *B, int ldb, REAL beta,
+                            REAL *Cm, int ldc) {
+  if (!g_sgemm || sizeof(REAL) != 4) return 0;
+  g_sgemm(CblasRowMajor_, ta ? CblasTrans_ : CblasNoTrans_, tb ? CblasTrans_ : CblasNoTrans_, M, N, K, 1.0f, (const float *)A, lda,
+          (const float *)B, ldb, (float)beta, (float *)Cm, ldc);
+  return 1;
+}
+
 /* C[MxN] = A[MxK] * B[NxK]^T + beta*C   (kNoTrans,kTrans) -- forward products */
 static void gemm_nt(int M, int N, int K, const REAL *A, int lda, const REAL *B, int ldb,
                     REAL beta, REAL *Cm, int ldc, int nthreads) {
   (void)nthreads;
+  if (blas_gemm(0, 1, M, N, K, A, lda, B, ldb, beta, Cm, ldc)) return;
 #pragma omp parallel for if (nthreads > 1) num_threads(nthreads) schedule(static)
   for (int n = 0; n < N; n++) {
     const REAL *b = B + (size_t)n * ldb;
@@ -109,6 +128,7 @@ static void gemm_nt(int M, int N, int K, const REAL *A, int lda, const REAL *B, 
 static void gemm_nn(int M, int N, int K, const REAL *A, int lda, const REAL *B, int ldb,
                     REAL beta, REAL *Cm, int ldc, int nthreads) {
   (void)nthreads;
+  if (blas_gemm(0, 0, M, N, K, A, lda, B, ldb, beta, Cm, ldc)) return;
   for (int m = 0; m < M; m++) {
     REAL *c = Cm + (size_t)m * ldc;
     if (beta == (REAL)0) { for (int n = 0; n < N; n++) c[n] = 0; }
@@ -133,6 +153,7 @@ static void gemm_nn(int M, int N, int K, const REAL *A, int lda, const REAL *B, 
 static void gemm_tn(int M, int N, int K, const REAL *A, int lda, const REAL *B, int ldb,
                     REAL beta, REAL *Cm, int ldc, int nthreads) {
   (void)nthreads;
+  if (blas_gemm(1, 0, M, N, K, A, lda, B, ldb, beta, Cm, ldc)) return;
 #pragma omp parallel for if (nthreads > 1) num_threads(nthreads) schedule(static)
   for (int m = 0; m < M; m++) {
     REAL *c = Cm + (size_t)m * ldc;

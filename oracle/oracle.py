@@ -58,6 +58,39 @@ def _lib(dtype):
     return lib
 
 
+def use_openblas(threads):
+    """Route every GEMM of the fp32 oracle through cblas_sgemm of the OpenBLAS bundled with numpy (ILP64 build, symbol
+    suffix 64_) on `threads` threads -- what a Kaldi CPU build linked against OpenBLAS executes (kaldi-matrix.cc:160-175).
+    threads = 0 switches back to the plain loops.  Returns a description string, or None when the library is not found.
+    Used by bench.py's cpu_baseline only; the parity tests keep the plain loops (fixed summation order)."""
+    import glob
+    lib = _lib(np.float32)
+    lib.lstmp_oracle_set_sgemm.argtypes = [ctypes.c_void_p]
+    if not threads:
+        lib.lstmp_oracle_set_sgemm(None)
+        return "plain loops"
+    cands = glob.glob(os.path.join(os.path.dirname(np.__file__), "..", "numpy.libs", "libscipy_openblas*.so*"))
+    for path in cands:
+        try:
+            ob = ctypes.CDLL(path)
+            for sfx in ("64_", ""):
+                try:
+                    fn = getattr(ob, "scipy_cblas_sgemm" + sfx)
+                    setn = getattr(ob, "scipy_openblas_set_num_threads" + sfx)
+                except AttributeError:
+                    continue
+                if sfx != "64_":
+                    continue                       # the oracle's hook is declared for the ILP64 interface only
+                setn.argtypes = [ctypes.c_int]
+                setn(int(threads))
+                lib.lstmp_oracle_set_sgemm(ctypes.cast(fn, ctypes.c_void_p))
+                _LIBS["openblas"] = ob             # keep the handle alive
+                return f"OpenBLAS cblas_sgemm ({os.path.basename(path)}, {threads} threads)"
+        except OSError:
+            continue
+    return None
+
+
 def param_sizes(I, C, R):
     """Flat blob layout = GetParams order (reference ...streams.h:162-189)."""
     return [("w_gifo_x", (4 * C, I)), ("w_gifo_r", (4 * C, R)), ("bias", (4 * C,)),

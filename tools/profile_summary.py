@@ -1,11 +1,16 @@
 """Collect the rocprofv3 outputs of tools/profile.sh into gpurun_out/prof_<tag>/summary/ (files named as they are
-committed under profiles/): kernel stats CSV, the two PMC CSVs, and <tag>_pmc_traffic.json with HBM bytes per launch
-= (2*FETCH_SIZE + WRITE_SIZE) * 1024  (MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE
-reports half of wide coalesced reads)."""
+committed under profiles/): kernel stats CSV, the PMC CSVs, and <tag>_pmc_traffic.json with
+  * HBM bytes per launch per kernel = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are
+    in KB; on gfx950 FETCH_SIZE reports half of wide coalesced reads),
+  * hbm_bytes_per_minibatch = sum over ALL dispatches of the run / number of minibatches (= launches of k_grads: exactly
+    one per minibatch) -- bench.py divides it by SURVEY 8(d)'s algorithmic bytes for `roofline.traffic_ratio`,
+  * mfma_busy_frac per kernel = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs) (the gfx94x MfmaUtil
+    formula; ROCm 7.2 has no gfx950 derived-counter section)."""
 import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
+cmd = sys.argv[3] if len(sys.argv) > 3 else ""
 dst = os.path.join(out, "summary")
 os.makedirs(dst, exist_ok=True)
 
@@ -15,6 +20,11 @@ def find(sub, pat):
     return hits[0] if hits else None
 
 
+def clean(name):
+    name = re.sub(r"^void ", "", name).replace("klstm::", "")
+    return re.sub(r"\(.*\)$", "", name)
+
+
 ks = find("trace", "*kernel_stats.csv")
 if ks:
     shutil.copy(ks, os.path.join(dst, f"{tag}_rocprofv3_kernel_stats.csv"))
@@ -22,25 +32,36 @@ ds = find("trace", "*domain_stats.csv")
 if ds:
     shutil.copy(ds, os.path.join(dst, f"{tag}_rocprofv3_domain_stats.csv"))
 agg = defaultdict(lambda: defaultdict(list))
-for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+for sub, ctrs in (("pmc_fetch", ("FETCH_SIZE",)), ("pmc_write", ("WRITE_SIZE",)),
+                  ("pmc_mfma", ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))):
     f = find(sub, "*counter_collection.csv")
     if not f:
         continue
-    shutil.copy(f, os.path.join(dst, f"{tag}_pmc_{ctr}_counter_collection.csv"))
+    shutil.copy(f, os.path.join(dst, f"{tag}_{sub}_counter_collection.csv"))
     for row in csv.DictReader(open(f)):
-        if row["Counter_Name"] == ctr:
-            name = re.sub(r"^void ", "", row["Kernel_Name"]).replace("klstm::", "")
-            name = re.sub(r"\(.*\)$", "", name)
-            agg[name][ctr].append(float(row["Counter_Value"]))
+        if row["Counter_Name"] in ctrs:
+            agg[clean(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
 kern = {}
+total_bytes = 0.0
 for name, c in agg.items():
-    fe = sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"]))
-    wr = sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"]))
+    nf, nw = max(1, len(c["FETCH_SIZE"])), max(1, len(c["WRITE_SIZE"]))
+    fe, wr = sum(c["FETCH_SIZE"]) / nf, sum(c["WRITE_SIZE"]) / nw
     kern[name] = {"fetch_kb_raw": fe, "write_kb_raw": wr, "hbm_bytes_per_launch": (2 * fe + wr) * 1024,
                   "launches": len(c["FETCH_SIZE"])}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile.sh) on "
-                     "`python bench.py --steps 20 --warmup 5 --no-cpu-baseline --launch graph`, S=4, T=20, 40/800/512",
-           "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE reports 1/2 of wide "
-                         "coalesced reads; WRITE_SIZE uncalibrated)",
-           "kernels": kern}, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    total_bytes += (2 * sum(c["FETCH_SIZE"]) + sum(c["WRITE_SIZE"])) * 1024      # both passes run the same dispatches
+    if c["SQ_VALU_MFMA_BUSY_CYCLES"] and c["GRBM_GUI_ACTIVE"]:
+        kern[name]["mfma_busy_frac"] = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(c["GRBM_GUI_ACTIVE"]) * 256 * 4)
+        kern[name]["sq_busy_cycles_per_launch"] = sum(c["SQ_BUSY_CYCLES"]) / max(1, len(c["SQ_BUSY_CYCLES"]))
+nmb = kern.get("k_grads", {}).get("launches", 0)
+m = re.search(r"--streams-per-gpu[ =](\d+)", cmd)
+doc = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; separate "
+                 "runs, tools/profile.sh) on `" + cmd + "`, T=20, 40/800/512",
+       "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads; "
+                     "WRITE_SIZE uncalibrated)",
+       "streams_per_gpu": int(m.group(1)) if m else 4,
+       "chain": "persistent" if any(n.startswith("k_fwd_persist") or n.startswith("k_bwd_persist") for n in kern) else "launches",
+       "minibatches": nmb, "hbm_bytes_per_minibatch": total_bytes / nmb if nmb else None,
+       "kernels": kern}
+json.dump(doc, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print("summary in", dst, ":", sorted(os.listdir(dst)))
+print("hbm bytes per minibatch:", doc["hbm_bytes_per_minibatch"])
