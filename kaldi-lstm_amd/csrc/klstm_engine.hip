@@ -72,6 +72,11 @@ struct klstm_engine {
   bool fold_dirty = true;  // W_rm / its packed copies are older than the parameters
   int pk_stale = 0;        // unfolded operand arrays (bits 1..3) not refreshed by the last Update because the folded path is in use
   bool fwd_folded = false; // the last propagate ran the folded chain (its backpropagate follows suit)
+  int use_persist = -1;    // weights-resident persistent chain (klstm_persist.hip): -1 auto, 0 off, 1 on (whenever the shape allows)
+  bool fwd_persist = false; // the last propagate ran steps 2..T inside one persistent launch (its backpropagate follows suit)
+  bool persist_dirty = false;   // a persistent launch ran since the status words were last read back
+  unsigned long long *gran[2] = {nullptr, nullptr};   // granule slots of the forward / backward chain
+  unsigned *pctrl = nullptr;    // 2 x 4 words: {epoch, finished workgroups, status, pad} per direction
   float *pk_fold[2] = {nullptr, nullptr};   // packed [W_rm | W_x] (gates order) and W_rm^T (4-row geometry)
   float *Pm = nullptr;     // out_diff * W_r_m for all frames [(T_alloc) S x C]
   float *ws = nullptr;     // split-K workspace of the batched d_r / in_diff products
@@ -203,6 +208,43 @@ static bool fold_wanted(const klstm_engine *e, int T) {
   // (measured at 40/800/512, T = 20, fwd+bwd+update: 1 stream 361 -> 296 us, 4: 377 -> 311, 8: 406 -> 396, 12: 472 -> 522)
   return e->use_fold == 1 ? T >= 2 : (T >= 12 && e->S <= 8);
 }
+static bool use_fused_x(const klstm_engine *e);
+// persistent chain: needs the folded operands, the x term inside the step, at most 4 streams; auto = on from 3 frames
+// per stream (the forward launch covers steps 2..T)
+static bool persist_wanted(const klstm_engine *e, int T) {
+  if (e->use_persist == 0 || e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || !use_fused_x(e)) return false;
+  if (T < 3 || !persist_supported(Dims{e->I, e->C, e->R, e->S, T})) return false;
+  return e->use_persist == 1 ? true : T >= 8;
+}
+static klstm_status ensure_persist(klstm_engine *e) {
+  if (e->pctrl) return KLSTM_OK;
+  const size_t gb = persist_gran_bytes(Dims{e->I, e->C, e->R, e->S, 0});
+  for (int i = 0; i < 2; i++) {
+    HIPCHK(hipMalloc(&e->gran[i], gb));
+    HIPCHK(hipMemsetAsync(e->gran[i], 0, gb, e->stream));
+  }
+  HIPCHK(hipMalloc(&e->pctrl, 8 * sizeof(unsigned)));
+  HIPCHK(hipMemsetAsync(e->pctrl, 0, 8 * sizeof(unsigned), e->stream));
+  return KLSTM_OK;
+}
+// After a host synchronisation: did a bounded spin of a persistent launch expire?  (Only possible when its workgroups
+// were not co-resident, e.g. another process holds most of the chip.)  The engine then stops using that path.
+static klstm_status check_persist(klstm_engine *e) {
+  if (!e->persist_dirty || !e->pctrl) return KLSTM_OK;
+  e->persist_dirty = false;
+  unsigned w[8];
+  HIPCHK(hipMemcpy(w, e->pctrl, sizeof(w), hipMemcpyDeviceToHost));
+  if (w[2] == 0 && w[6] == 0) return KLSTM_OK;
+  const unsigned z[8] = {w[0], 0, 0, 0, w[4], 0, 0, 0};
+  HIPCHK(hipMemcpy(e->pctrl, z, sizeof(z), hipMemcpyHostToDevice));
+  e->use_persist = 0;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  drop_graphs(e);
+  return fail(KLSTM_ERR_HIP, "persistent recurrence chain timed out (forward step %u, backward step %u): its workgroups were not "
+              "co-resident; results of that minibatch are invalid, the engine falls back to one launch per step",
+              w[2] & 0x7fffffffu, w[6] & 0x7fffffffu);
+}
+
 static klstm_status ensure_packs(klstm_engine *e) {
   if (!e->pk_stale || !e->pk[0]) { e->pk_stale = 0; return KLSTM_OK; }
   const Dims d{e->I, e->C, e->R, e->S, 0};
@@ -314,6 +356,8 @@ void klstm_destroy(klstm_engine *e) {
                  e->pk_fold[0], e->pk_fold[1]};
   for (float *p : ps) if (p) (void)hipFree(p);
   if (e->flags_dev) (void)hipFree(e->flags_dev);
+  for (auto *g : e->gran) if (g) (void)hipFree(g);
+  if (e->pctrl) (void)hipFree(e->pctrl);
   for (float *p : e->stage) if (p) (void)hipFree(p);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -350,7 +394,7 @@ static klstm_status blob_d2h(klstm_engine *e, float *dst, const float *src) {
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMemcpyAsync(dst, src, (size_t)e->nparams * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  return KLSTM_OK;
+  return check_persist(e);
 }
 
 klstm_status klstm_set_params_host(klstm_engine *e, const float *flat) {
@@ -456,8 +500,13 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
     // step 1 closes over the CARRIED r (set by Reset / the previous minibatch, possibly under older weights): unfolded
     // gates kernel, r(0) mirrored into time block 0; steps 2..T close over m(t-1) through W_rm; r(1..T) in one GEMM
     HIPCHK(launch_gates_step(d, p, 1, fx, in, in_stride, st, probe(e, "k_gates_step")));
-    for (int t = 2; t <= T; t++)
-      HIPCHK(launch_gates_step(d, p, t, fx, in, in_stride, st, probe(e, "k_gates_fold"), true));
+    if (e->fwd_persist) {
+      HIPCHK(launch_fwd_persist(d, p, in, in_stride, e->gran[0], e->pctrl, st, probe(e, "k_fwd_persist")));
+      e->persist_dirty = true;
+    } else {
+      for (int t = 2; t <= T; t++)
+        HIPCHK(launch_gates_step(d, p, t, fx, in, in_stride, st, probe(e, "k_gates_fold"), true));
+    }
     HIPCHK(launch_rbatch(d, p, out, out_stride, e->ws, st, probe(e, "k_gemm_rbatch"), probe(e, "k_reduce_rbatch")));
     return KLSTM_OK;
   }
@@ -483,7 +532,12 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     if (ks > 1) HIPCHK(launch_gemm_splitk(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, e->ws, ks, kl,
                                           st, nullptr, 0, probe(e, "k_gemm_P"), probe(e, "k_reduce_P")));
     else HIPCHK(launch_gemm(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
-    for (int t = T; t >= 1; t--) HIPCHK(launch_dmf_step(d, p, t, e->Pm, st, probe(e, "k_dmf_step")));
+    if (e->fwd_persist) {
+      HIPCHK(launch_bwd_persist(d, p, e->Pm, e->gran[1], e->pctrl + 4, st, probe(e, "k_bwd_persist")));
+      e->persist_dirty = true;
+    } else {
+      for (int t = T; t >= 1; t--) HIPCHK(launch_dmf_step(d, p, t, e->Pm, st, probe(e, "k_dmf_step")));
+    }
     HIPCHK(launch_bwd_tail(d, e->dgifo, wr, wx, out_diff, od_stride, e->dr, in_diff, id_stride, e->ws, st,
                            probe(e, "k_gemm_tail"), probe(e, "k_reduce_tail")));
     const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
@@ -547,11 +601,13 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   const int T = rows / e->S;
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
-  e->fwd_folded = fold_wanted(e, T);
+  e->fwd_persist = persist_wanted(e, T);
+  e->fwd_folded = e->fwd_persist || fold_wanted(e, T);
+  if (e->fwd_persist && (st = ensure_persist(e)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_fold(e)) != KLSTM_OK) return st;     // outside the graph: only after an Update
   if (!e->fwd_folded && (st = ensure_packs(e)) != KLSTM_OK) return st;
-  klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, e->fwd_folded ? -2 : -1);
+  klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, e->fwd_persist ? -3 : e->fwd_folded ? -2 : -1);
   st = run_graphed(e, key, [&]() { return seq_forward(e, in, in_stride, out, out_stride, T); });
   if (st != KLSTM_OK) return st;
   e->T_fwd = T;
@@ -583,7 +639,7 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
   const int T = e->T_fwd;
   if (e->fwd_folded) { klstm_status fs = ensure_fold(e); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
-                        flags | (e->fwd_folded ? 256 : 0));
+                        flags | (e->fwd_folded ? 256 : 0) | (e->fwd_persist ? 512 : 0));
   klstm_status st = run_graphed(e, key, [&]() {
     return seq_backward(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, T, momentum, flags);
   });
@@ -689,7 +745,7 @@ klstm_status klstm_synchronize(klstm_engine *e) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
-  return KLSTM_OK;
+  return check_persist(e);
 }
 
 klstm_status klstm_get_activations_host(klstm_engine *e, int which, float *dst) {
@@ -775,6 +831,14 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
     e->use_fold = value;
+    return KLSTM_OK;
+  }
+  if (!strcmp(key, "persist") || !strcmp(key, "persist_tpw") || !strcmp(key, "persist_waves")) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    if (!strcmp(key, "persist")) e->use_persist = value;
+    else if (!strcmp(key, "persist_tpw")) set_persist_tpw(value);         // process-wide tuning knobs (A-B experiments)
+    else set_persist_waves(value);
     return KLSTM_OK;
   }
   if (!strcmp(key, "fuse_x")) {

@@ -131,6 +131,20 @@ hipError_t launch_axpy(float *y, const float *x, float a, long n, hipStream_t st
 hipError_t launch_sgd_momentum(float *param, float *corr, const float *grad, float mmt, float lr, long n, hipStream_t st);
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {});
 
+// Weights-resident persistent chain (klstm_persist.hip; NumStream <= 4, folded recurrence, x term fused): ONE launch runs
+// forward steps 2..T (step 1 stays with launch_gates_step: it closes over the carried r) / backward steps T..1 with the
+// packed fold operands held in registers and the per-step all-to-all done inside the launch through data-tagged granules.
+//   gran: persist_gran_bytes(d) of device memory, zero-filled once;  ctrl: 3 words {epoch, finished workgroups, status},
+//   zero-filled once (one pair per direction).  status != 0 after the launch: a bounded spin expired (0x80000000 | step).
+bool persist_supported(const Dims &d);
+size_t persist_gran_bytes(const Dims &d);
+hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, int in_stride, unsigned long long *gran,
+                              unsigned *ctrl, hipStream_t st, LaunchProbe pr = {});
+hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, unsigned long long *gran, unsigned *ctrl,
+                              hipStream_t st, LaunchProbe pr = {});
+void set_persist_tpw(int v);    // A-B knob: tiles (of 4 cells) per workgroup, 0 = automatic
+void set_persist_waves(int v);  // A-B knob: waves per workgroup (8 or 16), 0 = automatic
+
 int get_small_max();
 void set_fat_fine(int v);       // A-B knob: half-size row tiles in the many-stream kernels (-1 auto, 0, 1)
 void set_small_nt2(int v);     // A-B knob: two stream groups per workgroup at 5..small_max streams

@@ -26,53 +26,14 @@
 //   fixed order through LDS (deterministic), and the fused LSTM cell math runs on the summed tile
 //   in registers.  D lane l holds stream l&15, rows 4*(l>>4)+{0..3}.
 #include "klstm_kernels.h"
+#include "klstm_math.h"
 
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace klstm {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-// bf16 operand mode (engine option "bf16"): weights packed as bf16, activations rounded to bf16 (RNE) when
-// they are staged into LDS, fp32 accumulate; masters, planes and gradients stay fp32.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint2 pack_bf16x4(const float4 &v) {
-  const bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-  return __builtin_bit_cast(uint2, h);
-}
-
-constexpr int NW = 8;        // waves per workgroup in the step kernels (K split)
-constexpr int KCH = 32;      // K chunk one wave consumes per MFMA group (4 k-groups x 8)
-constexpr int KSMAX = 4;     // max split-K slabs of k_dr_step
-
-static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-
-// ---------------------------------------------------------------------------------------------
-// scalar math: the overflow-safe forms Kaldi's CPU path uses, no FMA contraction so that the
-// elementwise results track the CPU formulation to the last bit where possible.
-// ---------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
-// sigmoid / tanh on the hardware transcendental units (v_exp_f32, v_rcp_f32: ~1 ulp each).  The
-// reference CPU forms (overflow-safe split, expf, IEEE divide) cost a ~500-cycle dependent chain on
-// the 16 lanes that own a tile's cell math; IEEE inf arithmetic makes the single-branch forms below
-// saturate correctly (exp2(+big) = inf -> rcp = 0), and the deviation is <= 3e-7 absolute.
-__device__ __forceinline__ float k_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
-}
-__device__ __forceinline__ float k_tanh(float x) {
-  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
-}
-// DiffSigmoid / DiffTanh with the reference's double literal (kaldi-matrix.cc:2562-2593)
-__device__ __forceinline__ float k_diff_sigmoid(float d, float y) {
-  return (float)((double)(d * y) * (1.0 - (double)y));
-}
-__device__ __forceinline__ float k_diff_tanh(float d, float y) {
-  return (float)((double)d * (1.0 - (double)(y * y)));
-}
 
 // ---- operand fetch helpers -----------------------------------------------------------------------
 // VEC = true : rows are 16-byte aligned and every contraction length is a multiple of 8.  The load is

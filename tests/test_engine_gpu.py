@@ -31,7 +31,7 @@ def make_engine(I, C, R, S, params):
 
 
 def run_chunks(I, C, R, S, T, nchunks, scale, momentum, lr, seed=0, want_in_diff=True, od_scale=1.0, fuse_x=-1,
-               vector=1, fat=1, fold=-1):
+               vector=1, fat=1, fold=-1, persist=-1, waves=0, tpw=0):
     """Runs nchunks x (Propagate, Backpropagate, Update) on both sides; returns per-chunk records."""
     rng = np.random.RandomState(seed)
     p = make_params(I, C, R, scale=scale, seed=seed + 1)
@@ -42,6 +42,9 @@ def run_chunks(I, C, R, S, T, nchunks, scale, momentum, lr, seed=0, want_in_diff
     e.set_option("vector", vector)
     e.set_option("fat", fat)
     e.set_option("fold", fold)
+    e.set_option("persist", persist)
+    e.set_option("persist_waves", waves)
+    e.set_option("persist_tpw", tpw)
     recs = []
     for ck in range(nchunks):
         x = rng.randn(T * S, I).astype(np.float32)
@@ -845,6 +848,68 @@ def test_full_size_decreasing_T_split_k_workspace(S, Ts):
         check_blob(e.get_corr(), o.get_corr(), 10 * tol, C, R, f"T={T}: corr")
         assert np.array_equal(e.get_params(), p)         # nothing scribbled over the parameter blob
     e.close()
+
+
+@pytest.mark.parametrize("waves,tpw", [(16, 0), (8, 0), (16, 1), (8, 4)])
+@pytest.mark.parametrize("I,C,R,S,T,want_in_diff", [
+    (40, 64, 32, 4, 6, True),        # 16 tiles
+    (40, 64, 32, 3, 5, True),        # ragged stream group: granule slots of the absent stream are never written
+    (8, 16, 8, 1, 9, False),         # one stream, 4 tiles, no in_diff
+    (72, 136, 40, 2, 7, True),       # 4C = 544: last 128-chunk of the backward contraction partially filled
+    (40, 800, 512, 4, 20, True),     # BASELINE.json configs[1]
+])
+def test_persistent_chain(I, C, R, S, T, want_in_diff, waves, tpw):
+    """Option "persist": steps 2..T of the forward recurrence and T..1 of BPTT run inside ONE launch per direction with the
+    folded operands resident in registers and the per-step all-to-all of m(t-1) / d_m(t+1) through data-tagged granules
+    (klstm_persist.hip).  Same algebra as the launch-per-step folded chain (fp32 summation order differs: the K split over
+    the waves of a tile is different) -> same tolerances against the oracle, over 3 chained minibatches; every geometry
+    (8 / 16 waves per workgroup, 1 / 2 / 4 tiles per workgroup)."""
+    if tpw and (C // 4) % tpw:
+        pytest.skip("tile count not divisible")
+    recs = run_chunks(I, C, R, S, T, nchunks=3, scale=0.3 if C < 200 else 0.01, momentum=0.9, lr=1e-3 if C < 200 else 1e-5,
+                      want_in_diff=want_in_diff, od_scale=1.0 if C < 200 else 0.1, persist=1, waves=waves, tpw=tpw)
+    check(recs, tol_act=3e-5, tol_grad=3e-4 if C > 200 else 1e-4, C=C, S=S, T=T)
+
+
+def test_persistent_chain_replay_state_bridge_and_whole_utterance():
+    """(a) hipGraph replay of the persistent launches equals plain launches bit for bit over several minibatches (the
+    granule tags come from a device-resident epoch, so a replay with frozen kernel arguments still sees fresh tags);
+    (b) two engines fed the same data give bit-identical results (the in-launch exchange is deterministic: fixed
+    summation order, no atomics on data); (c) a 1000-frame utterance in ONE call (standard/ LstmProjected, S = 1: 999
+    in-launch exchanges) against the oracle and against the launch-per-step chain."""
+    I, C, R, S, T = 40, 64, 32, 4, 10
+    p = make_params(I, C, R, scale=0.1, seed=4)
+    rng = np.random.RandomState(4)
+    x = dev(rng.randn(T * S, I)); od = dev(rng.randn(T * S, R))
+    res = []
+    for graph in (1, 0, 0):
+        e = make_engine(I, C, R, S, p)
+        e.set_option("persist", 1); e.set_option("graph", graph)
+        out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+        for _ in range(4):
+            e.propagate(x, out); e.backpropagate(x, od, idf, momentum=0.5); e.update(1e-3)
+        e.synchronize()
+        res.append((out.cpu().numpy(), idf.cpu().numpy(), e.get_corr(), e.get_params()))
+        e.close()
+    for other in res[1:]:
+        for g, h in zip(res[0], other):
+            assert np.array_equal(g, h)
+    I, C, R, S, T = 40, 800, 512, 1, 1000
+    p = make_params(I, C, R, scale=0.01, seed=61)
+    rng = np.random.RandomState(62)
+    x = rng.randn(T, I).astype(np.float32); od = (0.1 * rng.randn(T, R)).astype(np.float32)
+    o = Oracle(I, C, R, S, np.float32); o.set_params(p)
+    out_o = o.propagate(x); id_o = o.backpropagate(x, od, momentum=0.0)
+    for persist in (1, 0):
+        e = make_engine(I, C, R, S, p); e.set_option("persist", persist)
+        e.reset([1])
+        xd, odd = dev(x), dev(od); outd = torch.empty(T, R, device="cuda"); idd = torch.empty(T, I, device="cuda")
+        torch.cuda.synchronize()
+        e.propagate(xd, outd); e.backpropagate(xd, odd, idd, momentum=0.0); e.synchronize()
+        assert relerr(outd.cpu().numpy(), out_o) <= 2e-4
+        assert relerr(idd.cpu().numpy(), id_o) <= 2e-3
+        check_blob(e.get_corr(), o.get_corr(), 2e-3, C, R, f"persist={persist}: corr")
+        e.close()
 
 
 def test_folded_recurrence_state_bridge_reset_replay_and_deferred_momentum():
