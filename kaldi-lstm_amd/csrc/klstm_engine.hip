@@ -72,8 +72,10 @@ struct klstm_engine {
   bool fold_dirty = true;  // W_rm / its packed copies are older than the parameters
   int pk_stale = 0;        // unfolded operand arrays (bits 1..3) not refreshed by the last Update because the folded path is in use
   bool fwd_folded = false; // the last propagate ran the folded chain (its backpropagate follows suit)
-  int use_persist = -1;    // weights-resident persistent chain (klstm_persist.hip): -1 auto, 0 off, 1 on (whenever the shape allows)
-  bool fwd_persist = false; // the last propagate ran steps 2..T inside one persistent launch (its backpropagate follows suit)
+  int use_persist = -1;    // weights-resident persistent chain (klstm_persist.hip): -1 auto (forward, from 8 frames per stream), 0 off,
+                           // 1 forward whenever the shape allows, 2 forward and backward
+  bool fwd_persist = false; // the last propagate ran steps 2..T inside one persistent launch
+  bool bwd_persist = false; // ... and its backpropagate runs steps T..1 inside one persistent launch
   bool persist_dirty = false;   // a persistent launch ran since the status words were last read back
   unsigned long long *gran[2] = {nullptr, nullptr};   // granule slots of the forward / backward chain
   unsigned *pctrl = nullptr;    // 2 x 4 words: {epoch, finished workgroups, status, pad} per direction
@@ -214,7 +216,7 @@ static bool use_fused_x(const klstm_engine *e);
 static bool persist_wanted(const klstm_engine *e, int T) {
   if (e->use_persist == 0 || e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || !use_fused_x(e)) return false;
   if (T < 3 || !persist_supported(Dims{e->I, e->C, e->R, e->S, T})) return false;
-  return e->use_persist == 1 ? true : T >= 8;
+  return e->use_persist >= 1 ? true : T >= 8;
 }
 static klstm_status ensure_persist(klstm_engine *e) {
   if (e->pctrl) return KLSTM_OK;
@@ -532,7 +534,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     if (ks > 1) HIPCHK(launch_gemm_splitk(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, e->ws, ks, kl,
                                           st, nullptr, 0, probe(e, "k_gemm_P"), probe(e, "k_reduce_P")));
     else HIPCHK(launch_gemm(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
-    if (e->fwd_persist) {
+    if (e->bwd_persist) {
       HIPCHK(launch_bwd_persist(d, p, e->Pm, e->gran[1], e->pctrl + 4, st, probe(e, "k_bwd_persist")));
       e->persist_dirty = true;
     } else {
@@ -602,6 +604,9 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
   e->fwd_persist = persist_wanted(e, T);
+  // backward: measured at 40/800/512 the replicated elementwise BPTT of the persistent form (every workgroup recomputes
+  // dgifo of the whole layer, ~0.9 us per step) eats what the resident weights save: on request only
+  e->bwd_persist = e->fwd_persist && e->use_persist == 2;
   e->fwd_folded = e->fwd_persist || fold_wanted(e, T);
   if (e->fwd_persist && (st = ensure_persist(e)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
@@ -639,7 +644,7 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
   const int T = e->T_fwd;
   if (e->fwd_folded) { klstm_status fs = ensure_fold(e); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
-                        flags | (e->fwd_folded ? 256 : 0) | (e->fwd_persist ? 512 : 0));
+                        flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0));
   klstm_status st = run_graphed(e, key, [&]() {
     return seq_backward(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, T, momentum, flags);
   });
@@ -833,11 +838,14 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     e->use_fold = value;
     return KLSTM_OK;
   }
-  if (!strcmp(key, "persist") || !strcmp(key, "persist_tpw") || !strcmp(key, "persist_waves")) {
+  if (!strcmp(key, "persist") || !strcmp(key, "persist_tpw") || !strcmp(key, "persist_waves") || !strcmp(key, "persist_nap0") ||
+      !strcmp(key, "persist_nap")) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
     if (!strcmp(key, "persist")) e->use_persist = value;
     else if (!strcmp(key, "persist_tpw")) set_persist_tpw(value);         // process-wide tuning knobs (A-B experiments)
+    else if (!strcmp(key, "persist_nap0")) set_persist_nap(value, -2);
+    else if (!strcmp(key, "persist_nap")) set_persist_nap(-2, value);
     else set_persist_waves(value);
     return KLSTM_OK;
   }

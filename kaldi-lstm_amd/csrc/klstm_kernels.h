@@ -143,7 +143,8 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, unsigned long long *gran, unsigned *ctrl,
                               hipStream_t st, LaunchProbe pr = {});
 void set_persist_tpw(int v);    // A-B knob: tiles (of 4 cells) per workgroup, 0 = automatic
-void set_persist_waves(int v);  // A-B knob: waves per workgroup (8 or 16), 0 = automatic
+void set_persist_waves(int v);  // A-B knob: waves per workgroup (8, 12 or 16), 0 = automatic
+void set_persist_nap(int nap0, int nap);   // A-B knobs: sweeper sleep before the first pass (x256 clocks) / between passes (x64); -1 = default, -2 = keep
 
 int get_small_max();
 void set_fat_fine(int v);       // A-B knob: half-size row tiles in the many-stream kernels (-1 auto, 0, 1)

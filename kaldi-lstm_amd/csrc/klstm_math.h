@@ -50,4 +50,19 @@ __device__ __forceinline__ float k_diff_tanh(float d, float y) {
 }
 
 
+// The same two derivatives in fp32 with ONE rounding:  d*y*(1 - y) = p - p*y  with p = fl(d*y), and  d*(1 - y*y) = d - d*t
+// with t = fl(y*y), each as a single fused multiply-add (contraction is off in this file, so the FMA is explicit).  The
+// reference rounds the double product to double and then to float; that double rounding differs from the single
+// rounding here only when the exact value lies within 2^-53 (relative) of a float rounding boundary, ~2^-29 of all
+// inputs, by one ulp.  Used where the derivative is REPLICATED (persistent backward chain: every workgroup recomputes the
+// whole layer's dgifo, and the fp64 conversions and multiplies of the forms above were 2-3 us per step there).
+__device__ __forceinline__ float k_diff_sigmoid_fma(float d, float y) {
+  const float p = d * y;
+  return __builtin_fmaf(-p, y, p);
+}
+__device__ __forceinline__ float k_diff_tanh_fma(float d, float y) {
+  const float t = y * y;
+  return __builtin_fmaf(-d, t, d);
+}
+
 }  // namespace klstm

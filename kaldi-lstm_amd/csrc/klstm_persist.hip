@@ -17,9 +17,13 @@
 //     somebody still sweeps it.
 //   * tags = epoch + t with a device-resident epoch that the last workgroup to finish advances by T + 2: no per-call
 //     memset, and a hipGraph replay (frozen kernel arguments) still sees fresh tags.
-//   * every spin is bounded (wall clock, ~50 ms): on expiry the workgroup records the step in status[0] and leaves; the
-//     engine reports it at the next synchronising call.  All workgroups must be co-resident: grid <= 128 workgroups of
-//     512 threads on 256 CUs.
+//   * every spin is bounded (wall clock, ~50 ms): on expiry the workgroup records the step in ctrl[2] and leaves; the
+//     engine reports it at the next synchronising call.  All workgroups must be co-resident: grid <= 200 workgroups,
+//     one per CU.
+//   * wave roles: the first wave of every tile OWNS the tile's cell math, its granule stores and its plane stores and
+//     does NOT sweep (loads return in order behind a wave's own stores: a sweeping wave with write-through stores in
+//     flight would wait for their acknowledgement first); all other waves sweep, one cell per thread.
+//   * barriers wait for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): nothing global is ordered by them.
 // Backward: only d_m travels.  dgifo(t+1) -- the 4C-wide operand of the contraction -- is recomputed by EVERY workgroup
 // for all cells from d_m(t+1), its own replica of the d_c / d_i / d_f carry and the forward planes (L2-resident, requested
 // before the sweep): S x C granules per step instead of S x 4C, and the replicas are bit-identical (same instruction
@@ -39,7 +43,6 @@ namespace klstm {
 #pragma clang fp contract(off)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int PCMAX = 1024;            // largest cell dim: cells per thread in the sweep / elementwise passes = PCMAX / threads
 constexpr long long SPIN_LIMIT = 5000000;   // wall_clock64 ticks (100 MHz): 50 ms
 
 struct PersistFwdArgs {
@@ -52,7 +55,20 @@ struct PersistFwdArgs {
   float *c_save;                  // prev_c [S x C]
   unsigned long long *gran;       // [2][C*4] granules, cell-major (4 stream slots per cell)
   unsigned *ctrl;                 // [0] epoch, [1] finished workgroups, [2] status (0 = ok)
+  int nap0, nap;                  // sweepers sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
+#ifdef KLSTM_PERSIST_TIMING
+  long long *dbg;                 // per workgroup: shader-clock sums of the phases of a step (tools/persist_anatomy.hip)
+#endif
 };
+#ifdef KLSTM_PERSIST_TIMING
+#define PT_DECL() long long pt_prev = clock64(), pt_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PT_MARK(i) do { const long long pt_now = clock64(); pt_acc[i] += pt_now - pt_prev; pt_prev = pt_now; } while (0)
+#define PT_FLUSH(base) do { if (lane == 0) for (int i_ = 0; i_ < 6; i_++) a.dbg[((size_t)blockIdx.x * 16 + wave) * 6 + i_] = pt_acc[i_]; } while (0)
+#else
+#define PT_DECL() do {} while (0)
+#define PT_MARK(i) do {} while (0)
+#define PT_FLUSH(base) do {} while (0)
+#endif
 
 struct PersistBwdArgs {
   int C, S, T;
@@ -64,40 +80,75 @@ struct PersistBwdArgs {
   const float *P;                 // out_diff * W_r_m [T*S x C]
   unsigned long long *gran;
   unsigned *ctrl;
+  int nap0, nap;
+#ifdef KLSTM_PERSIST_TIMING
+  long long *dbg;
+#endif
 };
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t gran_rsrc(const unsigned long long *p, int n) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long *>(p), 0, n * 8, 0x00020000);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
 __device__ __forceinline__ void publish(unsigned long long *slot, int idx, unsigned tag, float v) {
-  __hip_atomic_store(slot + idx, ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+  __hip_atomic_store(slot + idx, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);                     // one 8-byte sc1 store: tag and value cannot tear
 }
+// Sum over the 16 k-groups of the 4-row geometry (lanes with equal lane & 3): two DPP row shifts inside each row of 16 lanes
+// (lanes 12..15 then hold their row's sums), two bpermute rounds across the four rows.  The totals of streams 0..3 end
+// up in lanes 12..15 (of every row): those are the epilogue lanes.
+__device__ __forceinline__ f32x4 kgroup_sum(f32x4 v) {
+  // (scalar copies: __builtin_bit_cast applied directly to a vector-element expression reads element 0)
+  float c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    c[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[e]), 0x114, 0xf, 0xf, true));   // row_shr:4: lane i += lane i-4
+    c[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[e]), 0x118, 0xf, 0xf, true));   // row_shr:8: lanes 12..15 = row sums
+  }
+#pragma unroll
+  for (int m = 16; m < 64; m <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) c[e] += __shfl_xor(c[e], m);
+  }
+  return f32x4{c[0], c[1], c[2], c[3]};
+}
+
+// workgroup barrier that orders LDS traffic only
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Sweep the 4 granules of each of this thread's cells until every tag of a live stream equals `tag`; returns false on
-// timeout.  Two 16-byte sc1 loads per cell, all in flight before the first check.
+// timeout.  Two 16-byte sc1 loads per cell, all in flight before the first check; branch-free inside a pass (threads
+// without a cell sweep cell 0 and ignore it).
+// A polling wave competes with the cell / owner waves of its own CU for the vector-memory queue (their plane and granule
+// stores queue behind its loads: measured 1.2-2.8 us for a 7-store epilogue next to unthrottled pollers), so a sweeper
+// sleeps through the part of the step in which nothing can have arrived (nap0) and briefly between passes (nap).
 template <int PCELL>
 __device__ __forceinline__ bool sweep_cells(const unsigned long long *slot, int C, int S, unsigned tag, const int (&cell)[PCELL],
-                                            float (&v)[PCELL][4], long long t_start) {
-  const __amdgpu_buffer_rsrc_t rs = gran_rsrc(slot, C * 4);
+                                            float (&v)[PCELL][4], long long t_start, int nap0, int nap) {
+  const __amdgpu_buffer_rsrc_t rs = buf_rsrc(slot, C * 32);
+  for (int i = 0; i < nap0; i++) __builtin_amdgcn_s_sleep(4);
   for (unsigned spins = 0;; spins++) {
     u32x4 q[PCELL][2];
 #pragma unroll
-    for (int j = 0; j < PCELL; j++)
-      if (cell[j] < C) {
-        q[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, cell[j] * 32, 0, 16);        // aux 16 = sc1
-        q[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, cell[j] * 32 + 16, 0, 16);
-      }
+    for (int j = 0; j < PCELL; j++) {
+      const int cl = cell[j] < C ? cell[j] : 0;
+      q[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, cl * 32, 0, 16);               // aux 16 = sc1
+      q[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, cl * 32 + 16, 0, 16);
+    }
     bool ok = true;
 #pragma unroll
-    for (int j = 0; j < PCELL; j++)
-      if (cell[j] < C) {
-        ok &= q[j][0].y == tag && (S < 2 || q[j][0].w == tag) && (S < 3 || q[j][1].y == tag) && (S < 4 || q[j][1].w == tag);
-        v[j][0] = __builtin_bit_cast(float, q[j][0].x); v[j][1] = __builtin_bit_cast(float, q[j][0].z);
-        v[j][2] = __builtin_bit_cast(float, q[j][1].x); v[j][3] = __builtin_bit_cast(float, q[j][1].z);
-      }
+    for (int j = 0; j < PCELL; j++) {
+      // (rvalue copies first: __builtin_bit_cast applied directly to a vector-element expression read element 0 for .z)
+      const unsigned u0 = q[j][0].x, t0 = q[j][0].y, u1 = q[j][0].z, t1 = q[j][0].w;
+      const unsigned u2 = q[j][1].x, t2 = q[j][1].y, u3 = q[j][1].z, t3 = q[j][1].w;
+      ok &= ((t0 == tag) & ((S < 2) | (t1 == tag)) & ((S < 3) | (t2 == tag)) & ((S < 4) | (t3 == tag))) | (cell[j] >= C);
+      v[j][0] = __uint_as_float(u0); v[j][1] = __uint_as_float(u1); v[j][2] = __uint_as_float(u2); v[j][3] = __uint_as_float(u3);
+    }
     if (ok) return true;
     if ((spins & 31) == 31 && wall_clock64() - t_start > SPIN_LIMIT) return false;
+    for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -115,300 +166,345 @@ __device__ __forceinline__ void finish(unsigned *ctrl, unsigned epoch, int T) {
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// forward: steps 2..T (step 1 closes over the carried r under possibly older weights and stays with k_gates_v)
+// forward: steps 2..T (step 1 closes over the carried r under possibly older weights and stays with k_gates_v).
+// Wave roles: the first 4*TPW waves are CELL waves -- wave w owns cell (w & 3) of tile (w >> 2) of the workgroup: its four
+// gate rows over the whole K = [m | x] in the 4-row geometry (16 k-groups x 4 rows per MFMA), so the contraction of a
+// cell needs no cross-wave combine: in-wave butterfly, cell math on lanes 0..3 (one per stream), granule + plane stores,
+// all in that wave.  ONE workgroup barrier per step (slab ready).  The remaining waves sweep, one cell per thread.
+// The weights come from the 16-row packed operand of the launch-per-step kernels, gathered once at kernel start.
 // -------------------------------------------------------------------------------------------------------------------
-template <int TPW, int MAXC, int PNW>
+template <int TPW, int MAXC, int PNW, int PCELL>
 __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
-  constexpr int WPT = PNW / TPW;                     // waves per tile (K split)
-  constexpr int PNT = PNW * 64, PCELL = PCMAX / PNT;
+  constexpr int PNT = PNW * 64, NCW = 4 * TPW, NSW = (PNW - NCW) * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C, S = a.S, T = a.T, I = a.I, nch = a.nch;
-  const int LDB = nch * KCH + 16;                    // ds_read_b128 of the B operand conflict-free (klstm_kernels.hip VGeo)
+  const int n128 = (nch * KCH + 127) / 128;          // 128-wide chunks over the padded K of the packed operand (<= MAXC)
+  constexpr int LDB = MAXC * 128 + 16;               // (LDB mod 64 == 16: the 16-lane groups of ds_read_b128 hit 16 distinct slots)
   float *ldsB = lds;                                 // [4][LDB]: row s = [ m(t-1)[s][0..C) | pad | x(t)[s][0..I) | pad ]
-  f32x4 *red = reinterpret_cast<f32x4 *>(lds + 4 * LDB);      // [PNW][16]
-  unsigned *abortf = reinterpret_cast<unsigned *>(red + PNW * 16);
+  unsigned *abortf = reinterpret_cast<unsigned *>(lds + 4 * LDB);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tl = wave / WPT, kw = wave % WPT;
-  const int tile = blockIdx.x * TPW + tl;
-  const int bs = lane & 3, kg = lane >> 4, q = (lane >> 2) & 3;
   const long long t_start = wall_clock64();
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-  // ---- resident weights: this wave's chunks of its tile ----
-  float4 a0[MAXC], a1[MAXC];
-#pragma unroll
-  for (int i = 0; i < MAXC; i++) {
-    const int ch = kw + i * WPT;
-    const float4 *ap = a.wpk + ((size_t)tile * nch + (ch < nch ? ch : 0)) * 128 + lane;
-    a0[i] = ap[0]; a1[i] = ap[64];
-  }
-  // ---- owner lanes: wave kw == 0 of a tile, lanes 0..15 = (cell 4*tile + q, stream bs) ----
-  const int e_cell = tile * 4 + q;
-  const bool e_on = kw == 0 && lane < 16 && bs < S && e_cell < C;
-  const int lc = e_on ? e_cell : 0, ls = e_on ? bs : 0;
-  float pre[4];
-#pragma unroll
-  for (int g = 0; g < 4; g++) pre[g] = a.bias[g * C + lc];
-  const float wpi = a.pi[lc], wpf = a.pf[lc], wpo = a.po[lc];
-  float cp = a.cc[((size_t)1 * S + ls) * C + lc];                    // c(1), written by the step-1 kernel
-  // ---- this thread's cells in the sweep ----
-  int cell[PCELL];
-#pragma unroll
-  for (int j = 0; j < PCELL; j++) cell[j] = tid + j * PNT;
   // zero the B slab once: pad columns and rows of absent streams stay zero for the whole launch
   for (int i = tid; i < 4 * LDB; i += PNT) ldsB[i] = 0.f;
   if (tid == 0) *abortf = 0u;
   __syncthreads();
+  PT_DECL();
 
-  const int nx4 = I / 4;                             // float4 per x row
-  for (int t = 2; t <= T; t++) {
-    // x(t): requested before the sweep, stored after it
-    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool x_on = tid < S * nx4;
-    const int xs = x_on ? tid / nx4 : 0, xk = x_on ? (tid % nx4) * 4 : 0;
-    if (x_on) xv = *reinterpret_cast<const float4 *>(a.x + ((size_t)(t - 1) * S + xs) * a.x_stride + xk);
-    // m(t-1) of every cell
-    float mv[PCELL][4];
-    if (t == 2) {
+  // The two roles run SEPARATE loops with the same barrier sequence (one lds_barrier per step, an abort check behind it):
+  // inside one loop body the register allocator keeps the resident weights of the cell waves AND the sweep state of the
+  // sweepers alive in every wave.
+  if (wave < NCW) {
+    // =========================== cell wave: cell (wave & 3) of tile (wave >> 2) ===========================
+    const int tile = blockIdx.x * TPW + (wave >> 2), cw = wave & 3;
+    const int kg = lane >> 2, bj = lane & 3;
+    // resident weights: rows (cell, gate = lane & 3), k = 128*chunk + 64*h + 4*kg + e.  In the packed operand
+    // (klstm_kernels.hip k_pack: pk[tile][chunk32][h32][lane32][4], row = lane32 & 15, k = 32*chunk32 + 8*(lane32 >> 4) +
+    // 4*h32 + e) that float4 sits at chunk32 = k/32, lane32 = ((k%32)/8)*16 + row, h32 = (k%8)/4
+    float4 a0[MAXC], a1[MAXC];
 #pragma unroll
-      for (int j = 0; j < PCELL; j++)
+    for (int i = 0; i < MAXC; i++) {
+      float4 w[2];
 #pragma unroll
-        for (int s = 0; s < 4; s++) mv[j][s] = (cell[j] < C && s < S) ? a.mm[((size_t)1 * S + s) * C + cell[j]] : 0.f;
-    } else {
-      if (!sweep_cells(a.gran + (size_t)((t - 1) & 1) * C * 4, C, S, epoch + (unsigned)(t - 1), cell, mv, t_start)) {
+      for (int h = 0; h < 2; h++) {
+        const int k0 = 128 * i + 64 * h + 4 * kg;
+        const int c32 = k0 >> 5, l32 = ((k0 & 31) >> 3) * 16 + 4 * cw + bj, h32 = (k0 & 7) >> 2;
+        const bool on = tile * 4 < C && i < n128 && c32 < nch;
+        const float4 *ap = a.wpk + (((size_t)(on ? tile : 0) * nch + (on ? c32 : 0)) * 2 + h32) * 64 + l32;
+        w[h] = *ap;
+        if (!on) w[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      a0[i] = w[0]; a1[i] = w[1];
+    }
+    // epilogue lanes: lanes 12..15 = streams 0..3 of the cell (where kgroup_sum leaves the totals)
+    const int e_cell = tile * 4 + cw, es = lane & 3;
+    const bool e_on = (lane >> 2) == 3 && es < S && e_cell < C;
+    const int lc = e_cell < C ? e_cell : 0, ls = e_on ? es : 0;
+    const float pre0 = a.bias[lc], pre1 = a.bias[C + lc], pre2 = a.bias[2 * C + lc], pre3 = a.bias[3 * C + lc];
+    const float wpi = a.pi[lc], wpf = a.pf[lc], wpo = a.po[lc];
+    float cp = a.cc[((size_t)1 * S + ls) * C + lc];                  // c(1), written by the step-1 kernel
+    for (int t = 2; t <= T; t++) {
+      PT_MARK(5);
+      lds_barrier();                                 // slab of step t ready
+      PT_MARK(1);
+      if (*abortf) break;                            // (plain LDS read: the asm barrier's memory clobber forces the reload; a volatile
+                                                     //  read through the generic pointer became a FLAT load behind vmcnt(0))
+      // gates of this wave's cell: contraction over [m(t-1) | x(t)] with the resident rows.  Exactly MAXC chunks, no
+      // branch: chunks beyond the operand have zero weights and read zero slab columns, so every LDS read of the step
+      // is issued before the first MFMA.
+      float4 b0[MAXC], b1[MAXC];
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        const float *bp = ldsB + bj * LDB + i * 128 + kg * 4;
+        b0[i] = *reinterpret_cast<const float4 *>(bp); b1[i] = *reinterpret_cast<const float4 *>(bp + 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);             // (otherwise the scheduler sinks every read next to its MFMAs: 14 LDS round trips in a row)
+      f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
+        const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
+      }
+      const f32x4 v = kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));   // the 16 k-groups of a (gate, stream) pair
+      PT_MARK(2);                                    // contraction + k-group sum
+      if (e_on) {
+        const size_t e_row = (size_t)t * S + es;
+        float ag = v.x + pre0;
+        float ai = v.y + pre1;
+        float af = v.z + pre2;
+        float ao = v.w + pre3;
+        ai += wpi * cp;                              // :278
+        af += wpf * cp;                              // :281
+        const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
+        float c = gg * gi;                           // :291
+        c = c + cp * gf;                             // :294
+        c = c < -50.f ? -50.f : c;                   // :296
+        c = c > 50.f ? 50.f : c;                     // :297
+        const float h = k_tanh(c);                   // :300
+        ao += wpo * c;                               // :303
+        const float go = k_sigmoid(ao);              // :306
+        const float m = h * go;                      // :309
+        if (t < T) publish(a.gran + (size_t)(t & 1) * C * 4, e_cell * 4 + es, epoch + (unsigned)t, m);
+        float *gp = a.gifo + e_row * 4 * C + e_cell;
+        gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
+        a.cc[e_row * C + e_cell] = c;
+        a.hh[e_row * C + e_cell] = h;
+        a.mm[e_row * C + e_cell] = m;
+        if (t == T) a.c_save[(size_t)es * C + e_cell] = c;       // :331 (c columns)
+        cp = c;
+      }
+      PT_MARK(4);                                    // cell math + stores
+    }
+  } else {
+    // =========================== sweeper: m(t-1) of every cell and x(t) into the slab ===========================
+    const int sidx = (wave - NCW) * 64 + lane;       // rank among the sweeping threads
+    int cell[PCELL];
+#pragma unroll
+    for (int j = 0; j < PCELL; j++) cell[j] = sidx + j * NSW;
+    const int nx4 = I / 4;                           // float4 per x row; the first sweeper wave also stages x(t)
+    const bool x_on = sidx < S * nx4;
+    const int xs = x_on ? sidx / nx4 : 0, xk = x_on ? (sidx % nx4) * 4 : 0;
+    for (int t = 2; t <= T; t++) {
+      PT_MARK(5);
+      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x_on) xv = *reinterpret_cast<const float4 *>(a.x + ((size_t)(t - 1) * S + xs) * a.x_stride + xk);
+      float mv[PCELL][4];
+      if (t == 2) {
+#pragma unroll
+        for (int j = 0; j < PCELL; j++)
+#pragma unroll
+          for (int s = 0; s < 4; s++) mv[j][s] = (cell[j] < C && s < S) ? a.mm[((size_t)1 * S + s) * C + cell[j]] : 0.f;
+      } else if (!sweep_cells(a.gran + (size_t)((t - 1) & 1) * C * 4, C, S, epoch + (unsigned)(t - 1), cell, mv, t_start, a.nap0, a.nap)) {
         *abortf = 1u;
         if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
       }
-    }
+      // (the slab is free: the sweep only completes once every cell wave of THIS workgroup has published step t-1,
+      //  i.e. has finished reading the previous slab)
 #pragma unroll
-    for (int j = 0; j < PCELL; j++)
-      if (cell[j] < C) {
+      for (int j = 0; j < PCELL; j++)
+        if (cell[j] < C) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) if (s < S) ldsB[s * LDB + cell[j]] = mv[j][s];
-      }
-    if (x_on) *reinterpret_cast<float4 *>(ldsB + xs * LDB + a.nchm * KCH + xk) = xv;
-    __syncthreads();
-    if (*reinterpret_cast<volatile unsigned *>(abortf)) break;
-    // ---- contraction over [m(t-1) | x(t)] with the resident weights ----
-    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < MAXC; i++) {
-      const int ch = kw + i * WPT;
-      if (ch < nch) {
-        const float *bp = ldsB + bs * LDB + ch * KCH + kg * 8;
-        const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(bp + 4);
-        const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
-        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j + 1], bv[j + 1], acc1, 0, 0, 0);
+          for (int s = 0; s < 4; s++) if (s < S) ldsB[s * LDB + cell[j]] = mv[j][s];
         }
-      }
-    }
-    f32x4 v = acc0 + acc1;
-#pragma unroll
-    for (int m = 16; m < 64; m <<= 1) {              // the 4 k-groups of a (row, stream) pair sit 16 lanes apart
-      v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
-    }
-    if (lane < 16) red[wave * 16 + lane] = v;
-    __syncthreads();
-    if (e_on) {
-      f32x4 s4 = red[(tl * WPT) * 16 + lane];
-#pragma unroll
-      for (int w = 1; w < WPT; w++) s4 += red[(tl * WPT + w) * 16 + lane];
-      const size_t e_row = (size_t)t * S + bs;
-      float ag = s4.x + pre[0];
-      float ai = s4.y + pre[1];
-      float af = s4.z + pre[2];
-      float ao = s4.w + pre[3];
-      ai += wpi * cp;                                // :278
-      af += wpf * cp;                                // :281
-      const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
-      float c = gg * gi;                             // :291
-      c = c + cp * gf;                               // :294
-      c = c < -50.f ? -50.f : c;                     // :296
-      c = c > 50.f ? 50.f : c;                       // :297
-      const float h = k_tanh(c);                     // :300
-      ao += wpo * c;                                 // :303
-      const float go = k_sigmoid(ao);                // :306
-      const float m = h * go;                        // :309
-      if (t < T) publish(a.gran + (size_t)(t & 1) * C * 4, e_cell * 4 + bs, epoch + (unsigned)t, m);
-      float *gp = a.gifo + e_row * 4 * C + e_cell;
-      gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
-      a.cc[e_row * C + e_cell] = c;
-      a.hh[e_row * C + e_cell] = h;
-      a.mm[e_row * C + e_cell] = m;
-      if (t == T) a.c_save[(size_t)bs * C + e_cell] = c;       // :331 (c columns)
-      cp = c;
+      if (x_on) *reinterpret_cast<float4 *>(ldsB + xs * LDB + a.nchm * KCH + xk) = xv;
+      PT_MARK(0);                                    // sweep + slab store
+      lds_barrier();
+      PT_MARK(1);
+      if (*abortf) break;
     }
   }
+  PT_FLUSH(0);
   finish(a.ctrl, epoch, T);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// backward: steps T..1
+// backward: steps T..1.  Iteration t: every sweeping thread receives d_m(t) of its cell (all streams), recomputes
+// dgifo(t) (:411-440) from it and its replica of the carry, and stores it into the operand slab; the 4 K waves of a tile
+// (one per SIMD) contract their quarter of K = 4C with the resident W_rm^T rows, the tile's first K wave combines the four
+// partial tiles, adds P(t-1) and publishes d_m(t-1).  The sweeping thread of a cell that belongs to this workgroup also
+// writes that cell's dgifo / dc rows (plain stores, acknowledged long before its next sweep starts).  Two workgroup
+// barriers per step (slab ready, partial tiles ready); the sweepers wait at the second one instead of polling the fabric
+// while the K waves work.
 // -------------------------------------------------------------------------------------------------------------------
-template <int TPW, int MAXC, int PNW>
+struct BpttCarry { float dcn, din, dfn, fn; };
+// one (cell, stream) pair of frame t; returns d(g,i,f,o) and updates the carry
+__device__ __forceinline__ float4 bptt_cell(float dm, float yg, float yi, float yf, float yo, float yh, float cpv, float wpi,
+                                            float wpf, float wpo, BpttCarry &k, float &d_c_out) {
+  const float d_h = k_diff_tanh_fma(dm * yo, yh);    // :411-412   (single-rounding fp32 forms, see klstm_math.h)
+  const float d_o = k_diff_sigmoid_fma(dm * yh, yo); // :415-416
+  float d_c = d_h;                                   // :424
+  d_c = d_c + k.dcn * k.fn;                          // :425
+  d_c = d_c + wpi * k.din;                           // :426
+  d_c = d_c + wpf * k.dfn;                           // :427
+  d_c = d_c + wpo * d_o;                             // :428
+  const float o_f = k_diff_sigmoid_fma(d_c * cpv, yf);   // :431-432
+  const float o_i = k_diff_sigmoid_fma(d_c * yg, yi);    // :435-436
+  const float o_g = k_diff_tanh_fma(d_c * yi, yg);       // :439-440
+  k.dcn = d_c; k.din = o_i; k.dfn = o_f; k.fn = yf;  // f(t) is the f(t+1) of the next iteration
+  d_c_out = d_c;
+  return make_float4(o_g, o_i, o_f, d_o);
+}
+
+template <int TPW, int MAXC, int PNW, int PCELL>
 __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
-  constexpr int WPT = PNW / TPW;
-  constexpr int PNT = PNW * 64, PCELL = PCMAX / PNT;
+  constexpr int PNT = PNW * 64, NKW = 4 * TPW, NSW = (PNW - NKW) * 64;
+  constexpr int LDD = 4 * MAXC * 128 + 16;           // (LDD mod 64 == 16: the 16-lane groups of ds_read_b128 hit 16 distinct slots)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C, S = a.S, T = a.T, nch = a.nch, K = 4 * a.C;
-  const int LDD = nch * 128 + 16;                    // (LDD mod 64 == 16: the 16-lane groups of ds_read_b128 hit 16 distinct slots)
-  float *ldsD = lds;                                 // [4][LDD]: dgifo(t+1) rows, natural g|i|f|o order
-  f32x4 *red = reinterpret_cast<f32x4 *>(lds + 4 * LDD);      // [PNW][4]
-  unsigned *abortf = reinterpret_cast<unsigned *>(red + PNW * 4);
+  float *ldsD = lds;                                 // [4][LDD]: dgifo(t) rows, natural g|i|f|o order; columns >= 4C stay zero
+  f32x4 *red = reinterpret_cast<f32x4 *>(lds + 4 * LDD);      // [NKW][4]
+  unsigned *abortf = reinterpret_cast<unsigned *>(red + NKW * 4);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tl = wave / WPT, kw = wave % WPT;
-  const int tile = blockIdx.x * TPW + tl;
-  const int kg = lane >> 2, bj = lane & 3;
   const long long t_start = wall_clock64();
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-  float4 a0[MAXC], a1[MAXC];
-#pragma unroll
-  for (int i = 0; i < MAXC; i++) {
-    const int ch = kw + i * WPT;
-    const float4 *ap = a.wpk + ((size_t)tile * nch + (ch < nch ? ch : 0)) * 128 + lane;
-    a0[i] = ap[0]; a1[i] = ap[64];
-  }
-  // owner lanes of the d_m epilogue: wave kw == 0 of a tile, lanes 0..15 = (cell 4*tile + lane/4, stream lane%4)
-  const int e_i = (lane >> 2) & 3, e_j = lane & 3;
-  const int e_cell = tile * 4 + e_i;
-  const bool e_on = kw == 0 && lane < 16 && e_j < S && e_cell < C;
-  // this thread's cells in the elementwise pass (all cells, every workgroup); `mine`: this workgroup writes their planes
-  int cell[PCELL];
-  bool mine[PCELL];
-  float wpi[PCELL], wpf[PCELL], wpo[PCELL];
-  float dcn[PCELL][4], din[PCELL][4], dfn[PCELL][4];
-#pragma unroll
-  for (int j = 0; j < PCELL; j++) {
-    cell[j] = tid + j * PNT;
-    const int lc = cell[j] < C ? cell[j] : 0;
-    mine[j] = cell[j] < C && (cell[j] >> 2) / TPW == (int)blockIdx.x;
-    wpi[j] = a.pi[lc]; wpf[j] = a.pf[lc]; wpo[j] = a.po[lc];
-#pragma unroll
-    for (int s = 0; s < 4; s++) { dcn[j][s] = 0.f; din[j][s] = 0.f; dfn[j][s] = 0.f; }
-    if (mine[j]) {                                   // the batched d_r product reads dgifo(T+1) as operand rows: keep them zero (:351)
-      for (int s = 0; s < S; s++) {
-        float *zp = a.dgifo + ((size_t)(T + 1) * S + s) * K + cell[j];
-        zp[0] = 0.f; zp[C] = 0.f; zp[2 * C] = 0.f; zp[3 * C] = 0.f;
-      }
-    }
-  }
   for (int i = tid; i < 4 * LDD; i += PNT) ldsD[i] = 0.f;
   if (tid == 0) *abortf = 0u;
   __syncthreads();
 
-  // forward planes through buffer descriptors: one 32-bit lane offset per (cell, stream), the frame / gate part of the
-  // address in the scalar offset (64-bit per-load addresses cost two VGPRs each and pushed this kernel into scratch)
-  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gifo), 0, (T + 2) * S * K * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.hh), 0, (T + 2) * S * C * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.cc), 0, (T + 2) * S * C * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.P), 0, T * S * C * 4, 0x00020000);
-  int offg[PCELL][4], offc[PCELL][4];
-  float fn[PCELL][4];                                // f(t+1) = the yf this thread loaded one iteration earlier
-#pragma unroll
-  for (int j = 0; j < PCELL; j++)
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const bool on = cell[j] < C && s < S;
-      offg[j][s] = on ? (s * K + cell[j]) * 4 : 0;
-      offc[j][s] = on ? (s * C + cell[j]) * 4 : 0;
-      fn[j][s] = 0.f;
-    }
-
-  for (int t = T; t >= 1; t--) {
-    // forward planes of frame t for all cells: requested before the sweep (L2-resident, every workgroup reads the same rows)
-    float yg[PCELL][4], yi[PCELL][4], yf[PCELL][4], yo[PCELL][4], yh[PCELL][4], cpv[PCELL][4], dm[PCELL][4];
-    const int sg = t * S * K * 4, sc = t * S * C * 4;
-#pragma unroll
-    for (int j = 0; j < PCELL; j++)
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        yg[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, offg[j][s], sg, 0));
-        yi[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, offg[j][s], sg + C * 4, 0));
-        yf[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, offg[j][s], sg + 2 * C * 4, 0));
-        yo[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, offg[j][s], sg + 3 * C * 4, 0));
-        yh[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_h, offc[j][s], sc, 0));
-        cpv[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_c, offc[j][s], sc - S * C * 4, 0));
-        if (t == T) dm[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_p, offc[j][s], (T - 1) * S * C * 4, 0));   // d_m(T) = P(T): dgifo(T+1) = 0
-      }
-    if (t < T) {
-      if (!sweep_cells(a.gran + (size_t)(t & 1) * C * 4, C, S, epoch + (unsigned)t, cell, dm, t_start)) {
-        *abortf = 1u;
-        if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
-      }
-    }
-    // elementwise BPTT of frame t for all cells (:411-440), replicated in every workgroup
-#pragma unroll
-    for (int j = 0; j < PCELL; j++)
-      if (cell[j] < C) {
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-          if (s < S) {
-            const float d_h = k_diff_tanh(dm[j][s] * yo[j][s], yh[j][s]);        // :411-412
-            const float d_o = k_diff_sigmoid(dm[j][s] * yh[j][s], yo[j][s]);     // :415-416
-            float d_c = d_h;                                                     // :424
-            d_c = d_c + dcn[j][s] * fn[j][s];                                    // :425
-            d_c = d_c + wpi[j] * din[j][s];                                      // :426
-            d_c = d_c + wpf[j] * dfn[j][s];                                      // :427
-            d_c = d_c + wpo[j] * d_o;                                            // :428
-            const float o_f = k_diff_sigmoid(d_c * cpv[j][s], yf[j][s]);         // :431-432
-            const float o_i = k_diff_sigmoid(d_c * yg[j][s], yi[j][s]);          // :435-436
-            const float o_g = k_diff_tanh(d_c * yi[j][s], yg[j][s]);             // :439-440
-            dcn[j][s] = d_c; din[j][s] = o_i; dfn[j][s] = o_f; fn[j][s] = yf[j][s];
-            if (t > 1) {
-              float *lp = ldsD + s * LDD + cell[j];
-              lp[0] = o_g; lp[C] = o_i; lp[2 * C] = o_f; lp[3 * C] = d_o;
-            }
-            if (mine[j]) {
-              const size_t row = (size_t)t * S + s;
-              float *dp = a.dgifo + row * K + cell[j];
-              dp[0] = o_g; dp[C] = o_i; dp[2 * C] = o_f; dp[3 * C] = d_o;
-              a.dc[row * C + cell[j]] = d_c;
-            }
-          }
-      }
-    if (t == 1) break;
-    __syncthreads();
-    if (*reinterpret_cast<volatile unsigned *>(abortf)) break;
-    // ---- d_m(t-1) rows of this tile: contraction of dgifo(t) over K = 4C with the resident W_rm^T rows ----
-    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  // separate loops per role, same barrier sequence (two lds_barriers per step, the abort check behind the first): see k_fwd_persist
+  if (wave < NKW) {
+    // =========================== K wave: quarter (wave & 3) of K for tile (wave >> 2) ===========================
+    const int tl = wave >> 2, kw = wave & 3;
+    const int tile = blockIdx.x * TPW + tl;
+    const bool owner_wave = kw == 0;
+    const int kg = lane >> 2, bj = lane & 3;
+    float4 a0[MAXC], a1[MAXC];                       // resident weights: chunks kw, kw+4, ... of the tile's 4 rows (zero beyond the operand)
 #pragma unroll
     for (int i = 0; i < MAXC; i++) {
-      const int ch = kw + i * WPT;
-      if (ch < nch) {
-        const float *bp = ldsD + bj * LDD + ch * 128 + kg * 4;
-        const float4 b0 = *reinterpret_cast<const float4 *>(bp), b1 = *reinterpret_cast<const float4 *>(bp + 64);
-        const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
-        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const int ch = kw + 4 * i;
+      const bool on = ch < nch && tile * 4 < C;
+      const float4 *ap = a.wpk + ((size_t)(on ? tile : 0) * nch + (on ? ch : 0)) * 128 + lane;
+      a0[i] = ap[0]; a1[i] = ap[64];
+      if (!on) { a0[i] = make_float4(0.f, 0.f, 0.f, 0.f); a1[i] = a0[i]; }
+    }
+    // epilogue lanes of the owner wave: lanes 0..15 = (cell 4*tile + lane/4, stream lane%4) receive d_m(t-1) of that pair
+    const int e_i = (lane >> 2) & 3, e_j = lane & 3;
+    const int e_cell = tile * 4 + e_i;
+    const bool e_on = owner_wave && lane < 16 && e_j < S && e_cell < C;
+    const __amdgpu_buffer_rsrc_t rs_p = buf_rsrc(a.P, T * S * C * 4);
+    const int e_offc = e_on ? (e_j * C + e_cell) * 4 : 0;
+    PT_DECL();
+    for (int t = T; t > 1; t--) {
+      PT_MARK(5);
+      // P(t-1) for the epilogue: requested now, consumed after the contraction (frame t-1 is row block t-2 of P)
+      const float pnext = owner_wave ? buf_f32(rs_p, e_offc, (t - 2) * S * C * 4) : 0.f;
+      lds_barrier();                                 // slab dgifo(t) ready
+      PT_MARK(1);
+      if (*abortf) break;
+      float4 b0[MAXC], b1[MAXC];
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j + 1], bv[j + 1], acc1, 0, 0, 0);
+      for (int i = 0; i < MAXC; i++) {
+        const float *bp = ldsD + bj * LDD + (kw + 4 * i) * 128 + kg * 4;
+        b0[i] = *reinterpret_cast<const float4 *>(bp); b1[i] = *reinterpret_cast<const float4 *>(bp + 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);             // every LDS read of the step in flight before the first MFMA
+      f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
+        const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
+      }
+      const f32x4 v = kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      if ((lane >> 2) == 3) red[wave * 4 + (lane & 3)] = v;   // lanes 12..15: streams 0..3, components = the tile's 4 cells
+      PT_MARK(2);
+      lds_barrier();                                 // partial tiles ready
+      PT_MARK(3);
+      if (owner_wave) {
+        // row (cell) e_i of stream e_j: component e_i of red[4*tl + w][e_j], the four K quarters in fixed order
+        const float *rp = reinterpret_cast<const float *>(red) + ((tl * 4) * 4 + e_j) * 4 + e_i;
+        const float sum = ((rp[0] + rp[16]) + rp[32]) + rp[48];
+        const float dmv = sum + pnext;               // :408 with :391 substituted: d_m(t-1) = contraction + P(t-1)
+        if (e_on) publish(a.gran + (size_t)((t - 1) & 1) * C * 4, e_cell * 4 + e_j, epoch + (unsigned)(t - 1), dmv);
+      }
+      PT_MARK(4);
+    }
+    PT_FLUSH(0);
+  } else {
+    // =========================== sweeper: d_m(t) of every cell -> dgifo(t) into the slab ===========================
+    // forward planes through buffer descriptors: the lane offset is cell*4 bytes, frame / stream / gate go into the scalar
+    // offset (64-bit per-load addresses cost two VGPRs each and pushed this kernel into scratch)
+    const __amdgpu_buffer_rsrc_t rs_g = buf_rsrc(a.gifo, (T + 2) * S * K * 4), rs_h = buf_rsrc(a.hh, (T + 2) * S * C * 4);
+    const __amdgpu_buffer_rsrc_t rs_c = buf_rsrc(a.cc, (T + 2) * S * C * 4), rs_p = buf_rsrc(a.P, T * S * C * 4);
+    int cell[PCELL];
+    bool mine[PCELL];                                // the cell belongs to this workgroup's tiles: this thread writes its plane rows
+    float wpi[PCELL], wpf[PCELL], wpo[PCELL];
+    int voff[PCELL];
+    BpttCarry kk[PCELL][4];
+#pragma unroll
+    for (int j = 0; j < PCELL; j++) {
+      cell[j] = (wave - NKW) * 64 + lane + j * NSW;
+      const int lc = cell[j] < C ? cell[j] : 0;
+      mine[j] = cell[j] < C && (cell[j] >> 2) / TPW == (int)blockIdx.x;
+      wpi[j] = a.pi[lc]; wpf[j] = a.pf[lc]; wpo[j] = a.po[lc];
+      voff[j] = lc * 4;
+#pragma unroll
+      for (int s = 0; s < 4; s++) kk[j][s] = BpttCarry{0.f, 0.f, 0.f, 0.f};
+      if (mine[j]) {                                 // the batched d_r product reads dgifo(T+1) as operand rows: keep them zero (:351)
+        for (int s = 0; s < S; s++) {
+          float *zp = a.dgifo + ((size_t)(T + 1) * S + s) * K + cell[j];
+          zp[0] = 0.f; zp[C] = 0.f; zp[2 * C] = 0.f; zp[3 * C] = 0.f;
         }
       }
     }
-    f32x4 v = acc0 + acc1;
+    PT_DECL();
+    for (int t = T; t >= 1; t--) {
+      PT_MARK(5);
+      const int sg = t * S * K * 4, sc = t * S * C * 4;
+      // planes of frame t for this thread's cells: requested before the sweep (L2-resident; every workgroup reads the same rows)
+      float yg[PCELL][4], yi[PCELL][4], yf[PCELL][4], yo[PCELL][4], yh[PCELL][4], cpv[PCELL][4], dm[PCELL][4];
 #pragma unroll
-    for (int m = 4; m < 64; m <<= 1) {               // the 16 k-groups of a (row, stream) pair: lanes with equal lane&3
-      v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
-    }
-    if (lane < 4) red[wave * 4 + lane] = v;
-    __syncthreads();
-    if (e_on) {
-      // row (cell) e_i of stream e_j: component e_i of red[w][e_j]
-      const float *rp = reinterpret_cast<const float *>(red) + ((tl * WPT) * 4 + e_j) * 4 + e_i;
-      float sum = rp[0];
+      for (int j = 0; j < PCELL; j++)
 #pragma unroll
-      for (int w = 1; w < WPT; w++) sum += rp[w * 16];
-      const float dmv = sum + a.P[((size_t)(t - 2) * S + e_j) * C + e_cell];     // frame t-1 is row block t-2 of P  (:408 with :391)
-      publish(a.gran + (size_t)((t - 1) & 1) * C * 4, e_cell * 4 + e_j, epoch + (unsigned)(t - 1), dmv);
+        for (int s = 0; s < 4; s++) {
+          const int ss = s < S ? s : 0;              // absent streams re-read stream 0 (their results are never stored)
+          const int og = sg + ss * K * 4, oc = sc + ss * C * 4;
+          yg[j][s] = buf_f32(rs_g, voff[j], og); yi[j][s] = buf_f32(rs_g, voff[j], og + C * 4);
+          yf[j][s] = buf_f32(rs_g, voff[j], og + 2 * C * 4); yo[j][s] = buf_f32(rs_g, voff[j], og + 3 * C * 4);
+          yh[j][s] = buf_f32(rs_h, voff[j], oc); cpv[j][s] = buf_f32(rs_c, voff[j], oc - S * C * 4);
+          if (t == T) dm[j][s] = buf_f32(rs_p, voff[j], ((T - 1) * S + ss) * C * 4);          // d_m(T) = P(T): dgifo(T+1) = 0
+        }
+      if (t < T && !sweep_cells(a.gran + (size_t)(t & 1) * C * 4, C, S, epoch + (unsigned)t, cell, dm, t_start, a.nap0, a.nap)) {
+        *abortf = 1u;
+        if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+      }
+      PT_MARK(0);                                    // plane loads + sweep
+      // elementwise BPTT of frame t (:411-440), replicated in every workgroup
+#pragma unroll
+      for (int j = 0; j < PCELL; j++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          float d_c;
+          const float4 dg = bptt_cell(dm[j][s], yg[j][s], yi[j][s], yf[j][s], yo[j][s], yh[j][s], cpv[j][s], wpi[j], wpf[j], wpo[j],
+                                      kk[j][s], d_c);
+          if (cell[j] < C && s < S) {
+            if (t > 1) {                             // B operand of the contraction
+              float *lp = ldsD + s * LDD + cell[j];
+              lp[0] = dg.x; lp[C] = dg.y; lp[2 * C] = dg.z; lp[3 * C] = dg.w;
+            }
+            if (mine[j]) {                           // own cells: rows of the dgifo / dc planes (gradient products, d_r, in_diff)
+              const size_t row = (size_t)t * S + s;
+              float *dp = a.dgifo + row * K + cell[j];
+              dp[0] = dg.x; dp[C] = dg.y; dp[2 * C] = dg.z; dp[3 * C] = dg.w;
+              a.dc[row * C + cell[j]] = d_c;
+            }
+          }
+        }
+      PT_MARK(2);                                    // elementwise + slab / plane stores
+      if (t == 1) break;
+      lds_barrier();                                 // slab ready
+      PT_MARK(1);
+      if (*abortf) break;
+      lds_barrier();                                 // (partial tiles ready: nothing to do here but keep the count; the K waves
+                                                     //  contract meanwhile, and polling the fabric now would only slow them down)
+      PT_MARK(3);
     }
+    PT_FLUSH(0);
   }
   finish(a.ctrl, epoch, T);
 }
@@ -420,28 +516,44 @@ static inline int pcdiv(int a, int b) { return (a + b - 1) / b; }
 
 static int g_persist_tpw = 0;       // A-B knobs: tiles per workgroup / waves per workgroup (0 = automatic)
 static int g_persist_waves = 0;
+static int g_persist_nap0 = -1, g_persist_nap = -1;   // -1: defaults below
+void set_persist_nap(int nap0, int nap) { if (nap0 >= -1) g_persist_nap0 = nap0; if (nap >= -1) g_persist_nap = nap; }
 void set_persist_tpw(int v) { g_persist_tpw = v; }
 void set_persist_waves(int v) { g_persist_waves = v; }
 
-// Geometry: waves per workgroup (8 or 16), tiles (of 4 cells) per workgroup, chunk slots per wave.  Fewer, fatter
-// workgroups mean fewer sweepers per exchange (less fabric contention); a wave must hold its chunks in registers.
-struct PGeo { int waves, tpw, maxc; };
-static PGeo pick_geo(int C, int nch) {
-  const int waves = g_persist_waves ? g_persist_waves : 16;
-  const int prefer[3] = {g_persist_tpw ? g_persist_tpw : 2, 4, 1};
+// Geometry.  Fewer, fatter workgroups mean fewer sweepers per exchange (less fabric contention).
+//   forward : 4 cell waves per tile (one per cell, whole K in registers: maxc = 128-wide chunks), the rest sweep
+//   backward: waves/tpw waves per tile split K (maxc = chunks per wave), one of them owns the tile, the rest sweep
+struct PGeo { int waves, tpw, maxc, pcell; };
+static PGeo pick_geo_fwd(int C, int nch) {
+  const int waves = (g_persist_waves == 8 || g_persist_waves == 16) ? g_persist_waves : 12;   // measured at 40/800/512: 12 waves, 1 tile
+  const int prefer[3] = {g_persist_tpw ? g_persist_tpw : 1, 1, 2};
+  const int n128 = pcdiv(nch * KCH, 128);
   for (int tpw : prefer) {
-    if (tpw > waves || (C / 4) % tpw != 0 || C / 4 / tpw > 200) continue;
-    const int mc = pcdiv(nch, waves / tpw);
-    if (mc > 8) continue;
-    return PGeo{waves, tpw, mc <= 4 ? 4 : 8};
+    if ((tpw != 1 && tpw != 2) || 4 * tpw >= waves || (C / 4) % tpw != 0 || C / 4 / tpw > 200 || n128 > 12) continue;
+    const int pc = pcdiv(C, (waves - 4 * tpw) * 64);
+    if (pc > 4) continue;
+    return PGeo{waves, tpw, n128 <= 7 ? 7 : n128 <= 9 ? 9 : 12, pc};
   }
-  return PGeo{0, 0, 0};
+  return PGeo{0, 0, 0, 0};
+}
+static PGeo pick_geo(int C, int nch) {              // backward: 4 K waves per tile, chunk slots per K wave
+  const int waves = (g_persist_waves == 8 || g_persist_waves == 16) ? g_persist_waves : 12;
+  const int prefer[3] = {g_persist_tpw ? g_persist_tpw : 1, 1, 2};
+  const int mc = pcdiv(nch, 4);
+  for (int tpw : prefer) {
+    if ((tpw != 1 && tpw != 2) || 4 * tpw >= waves || (C / 4) % tpw != 0 || C / 4 / tpw > 200 || mc > 9) continue;
+    const int pc = pcdiv(C, (waves - 4 * tpw) * 64);
+    if (pc > 4) continue;
+    return PGeo{waves, tpw, mc <= 7 ? 7 : 9, pc};
+  }
+  return PGeo{0, 0, 0, 0};
 }
 
 bool persist_supported(const Dims &d) {
-  if (d.S > 4 || d.C % 8 != 0 || d.I % 8 != 0 || d.C > PCMAX || d.S * (d.I / 4) > 512) return false;
+  if (d.S > 4 || d.C % 8 != 0 || d.I % 8 != 0 || d.S * (d.I / 4) > 64) return false;
   const int nf = pcdiv(d.C, KCH) + pcdiv(d.I, KCH), nb = pcdiv(4 * d.C, 128);
-  return pick_geo(d.C, nf).tpw > 0 && pick_geo(d.C, nb).tpw > 0;
+  return pick_geo_fwd(d.C, nf).tpw > 0 && pick_geo(d.C, nb).tpw > 0;
 }
 size_t persist_gran_bytes(const Dims &d) { return (size_t)2 * d.C * 4 * sizeof(unsigned long long); }
 
@@ -453,21 +565,26 @@ static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t
   else hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), shm, st, a);
   return hipGetLastError();
 }
-#define PDISPATCH(KERN, g, grid, shm, st, pr, a)                                                              \
-  do {                                                                                                        \
-    if (g.waves == 8 && g.tpw == 1 && g.maxc == 4) return plaunch(KERN<1, 4, 8>, grid, 512, shm, st, pr, a);   \
-    if (g.waves == 8 && g.tpw == 1 && g.maxc == 8) return plaunch(KERN<1, 8, 8>, grid, 512, shm, st, pr, a);   \
-    if (g.waves == 8 && g.tpw == 2 && g.maxc == 4) return plaunch(KERN<2, 4, 8>, grid, 512, shm, st, pr, a);   \
-    if (g.waves == 8 && g.tpw == 2 && g.maxc == 8) return plaunch(KERN<2, 8, 8>, grid, 512, shm, st, pr, a);   \
-    if (g.waves == 8 && g.tpw == 4 && g.maxc == 4) return plaunch(KERN<4, 4, 8>, grid, 512, shm, st, pr, a);   \
-    if (g.waves == 8 && g.tpw == 4 && g.maxc == 8) return plaunch(KERN<4, 8, 8>, grid, 512, shm, st, pr, a);   \
-    if (g.waves == 16 && g.tpw == 1 && g.maxc == 4) return plaunch(KERN<1, 4, 16>, grid, 1024, shm, st, pr, a); \
-    if (g.waves == 16 && g.tpw == 1 && g.maxc == 8) return plaunch(KERN<1, 8, 16>, grid, 1024, shm, st, pr, a); \
-    if (g.waves == 16 && g.tpw == 2 && g.maxc == 4) return plaunch(KERN<2, 4, 16>, grid, 1024, shm, st, pr, a); \
-    if (g.waves == 16 && g.tpw == 2 && g.maxc == 8) return plaunch(KERN<2, 8, 16>, grid, 1024, shm, st, pr, a); \
-    if (g.waves == 16 && g.tpw == 4 && g.maxc == 4) return plaunch(KERN<4, 4, 16>, grid, 1024, shm, st, pr, a); \
-    if (g.waves == 16 && g.tpw == 4 && g.maxc == 8) return plaunch(KERN<4, 8, 16>, grid, 1024, shm, st, pr, a); \
-    return hipErrorInvalidValue;                                                                              \
+#define PD5(KERN, TP, MC, W)                                                                                    \
+  if (g.waves == W && g.tpw == TP && g.maxc == MC) {                                                            \
+    if (g.pcell == 1) return plaunch(KERN<TP, MC, W, 1>, grid, W * 64, shm, st, pr, a);                         \
+    if (g.pcell == 2) return plaunch(KERN<TP, MC, W, 2>, grid, W * 64, shm, st, pr, a);                         \
+    if (g.pcell == 3) return plaunch(KERN<TP, MC, W, 3>, grid, W * 64, shm, st, pr, a);                         \
+    return plaunch(KERN<TP, MC, W, 4>, grid, W * 64, shm, st, pr, a);                                           \
+  }
+#define PDISPATCH_FWD(KERN)                                                                                     \
+  do {                                                                                                          \
+    PD5(KERN, 1, 7, 8) PD5(KERN, 1, 9, 8) PD5(KERN, 1, 12, 8)                                                   \
+    PD5(KERN, 1, 7, 12) PD5(KERN, 1, 9, 12) PD5(KERN, 1, 12, 12) PD5(KERN, 2, 7, 12) PD5(KERN, 2, 9, 12) PD5(KERN, 2, 12, 12) \
+    PD5(KERN, 1, 7, 16) PD5(KERN, 1, 9, 16) PD5(KERN, 1, 12, 16) PD5(KERN, 2, 7, 16) PD5(KERN, 2, 9, 16) PD5(KERN, 2, 12, 16) \
+    return hipErrorInvalidValue;                                                                                \
+  } while (0)
+#define PDISPATCH_BWD(KERN)                                                                                     \
+  do {                                                                                                          \
+    PD5(KERN, 1, 7, 8) PD5(KERN, 1, 9, 8)                                                                       \
+    PD5(KERN, 1, 7, 12) PD5(KERN, 1, 9, 12) PD5(KERN, 2, 7, 12) PD5(KERN, 2, 9, 12)                             \
+    PD5(KERN, 1, 7, 16) PD5(KERN, 1, 9, 16) PD5(KERN, 2, 7, 16) PD5(KERN, 2, 9, 16)                             \
+    return hipErrorInvalidValue;                                                                                \
   } while (0)
 
 hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, int in_stride, unsigned long long *gran,
@@ -478,11 +595,12 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
   a.wpk = p.pk_fold; a.bias = p.bias; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm;
   a.x = in; a.x_stride = in_stride; a.c_save = p.prev_c; a.gran = gran; a.ctrl = ctrl;
-  const PGeo g = pick_geo(d.C, a.nch);
+  a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 9; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // measured: tools/persist_anatomy
+  const PGeo g = pick_geo_fwd(d.C, a.nch);
   if (!g.tpw || !p.pk_fold || (reinterpret_cast<uintptr_t>(in) & 15) || in_stride % 4 != 0) return hipErrorInvalidValue;
-  const size_t shm = (size_t)(4 * (a.nch * KCH + 16) + g.waves * 16 * 4 + 4) * sizeof(float);
+  const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4) * sizeof(float);
   const int grid = d.C / 4 / g.tpw;
-  PDISPATCH(k_fwd_persist, g, grid, shm, st, pr, a);
+  PDISPATCH_FWD(k_fwd_persist);
 }
 
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, unsigned long long *gran, unsigned *ctrl,
@@ -492,11 +610,12 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, u
   a.nch = pcdiv(4 * d.C, 128);
   a.wpk = p.pk_fold; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.gran = gran; a.ctrl = ctrl;
+  a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 0; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // (the second barrier already keeps the sweepers off the fabric)
   const PGeo g = pick_geo(d.C, a.nch);
   if (!g.tpw || !p.pk_fold) return hipErrorInvalidValue;
-  const size_t shm = (size_t)(4 * (a.nch * 128 + 16) + g.waves * 4 * 4 + 4) * sizeof(float);
+  const size_t shm = (size_t)(4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4) * sizeof(float);
   const int grid = d.C / 4 / g.tpw;
-  PDISPATCH(k_bwd_persist, g, grid, shm, st, pr, a);
+  PDISPATCH_BWD(k_bwd_persist);
 }
 
 }  // namespace klstm

@@ -850,7 +850,7 @@ def test_full_size_decreasing_T_split_k_workspace(S, Ts):
     e.close()
 
 
-@pytest.mark.parametrize("waves,tpw", [(16, 0), (8, 0), (16, 1), (8, 4)])
+@pytest.mark.parametrize("waves,tpw", [(0, 0), (12, 2), (8, 1), (16, 1)])
 @pytest.mark.parametrize("I,C,R,S,T,want_in_diff", [
     (40, 64, 32, 4, 6, True),        # 16 tiles
     (40, 64, 32, 3, 5, True),        # ragged stream group: granule slots of the absent stream are never written
@@ -862,12 +862,13 @@ def test_persistent_chain(I, C, R, S, T, want_in_diff, waves, tpw):
     """Option "persist": steps 2..T of the forward recurrence and T..1 of BPTT run inside ONE launch per direction with the
     folded operands resident in registers and the per-step all-to-all of m(t-1) / d_m(t+1) through data-tagged granules
     (klstm_persist.hip).  Same algebra as the launch-per-step folded chain (fp32 summation order differs: the K split over
-    the waves of a tile is different) -> same tolerances against the oracle, over 3 chained minibatches; every geometry
-    (8 / 16 waves per workgroup, 1 / 2 / 4 tiles per workgroup)."""
+    the waves of a tile is different; the replicated BPTT derivative terms use the single-rounding fp32 forms of
+    klstm_math.h) -> same tolerances against the oracle, over 3 chained minibatches; several geometries (8 / 12 / 16 waves
+    per workgroup, 1 / 2 tiles per workgroup).  persist = 2: forward AND backward in the persistent form."""
     if tpw and (C // 4) % tpw:
         pytest.skip("tile count not divisible")
     recs = run_chunks(I, C, R, S, T, nchunks=3, scale=0.3 if C < 200 else 0.01, momentum=0.9, lr=1e-3 if C < 200 else 1e-5,
-                      want_in_diff=want_in_diff, od_scale=1.0 if C < 200 else 0.1, persist=1, waves=waves, tpw=tpw)
+                      want_in_diff=want_in_diff, od_scale=1.0 if C < 200 else 0.1, persist=2, waves=waves, tpw=tpw)
     check(recs, tol_act=3e-5, tol_grad=3e-4 if C > 200 else 1e-4, C=C, S=S, T=T)
 
 
@@ -884,7 +885,7 @@ def test_persistent_chain_replay_state_bridge_and_whole_utterance():
     res = []
     for graph in (1, 0, 0):
         e = make_engine(I, C, R, S, p)
-        e.set_option("persist", 1); e.set_option("graph", graph)
+        e.set_option("persist", 2); e.set_option("graph", graph)
         out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
         for _ in range(4):
             e.propagate(x, out); e.backpropagate(x, od, idf, momentum=0.5); e.update(1e-3)
@@ -900,7 +901,7 @@ def test_persistent_chain_replay_state_bridge_and_whole_utterance():
     x = rng.randn(T, I).astype(np.float32); od = (0.1 * rng.randn(T, R)).astype(np.float32)
     o = Oracle(I, C, R, S, np.float32); o.set_params(p)
     out_o = o.propagate(x); id_o = o.backpropagate(x, od, momentum=0.0)
-    for persist in (1, 0):
+    for persist in (2, 1, 0):
         e = make_engine(I, C, R, S, p); e.set_option("persist", persist)
         e.reset([1])
         xd, odd = dev(x), dev(od); outd = torch.empty(T, R, device="cuda"); idd = torch.empty(T, I, device="cuda")

@@ -1,0 +1,110 @@
+// tools/persist_anatomy.hip -- where does a step of the persistent forward chain spend its time?  Builds the product
+// kernel (klstm_persist.hip) with KLSTM_PERSIST_TIMING: every wave sums shader-clock intervals per phase
+// (sweep, barrier 1, contraction, barrier 2, owner epilogue, loop head) over the T-1 steps.  Random weights (timing only).
+#define KLSTM_PERSIST_TIMING
+#include "../kaldi-lstm_amd/csrc/klstm_persist.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("ERR %s line %d: %s\n", #x, __LINE__, hipGetErrorString(e_)); exit(1);} } while (0)
+using namespace klstm;
+
+int main(int argc, char **argv) {
+  const int C = 800, I = 40, S = argc > 1 ? atoi(argv[1]) : 4, T = 200;
+  hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  const int nchm = (C + 31) / 32, nch = nchm + (I + 31) / 32;
+  const size_t npk = (size_t)(C / 4) * nch * 128;
+  float4 *wpk; CK(hipMalloc(&wpk, npk * 16));
+  std::vector<float> h(npk * 4);
+  for (auto &v : h) v = (rand() / (float)RAND_MAX - 0.5f) * 0.02f;
+  CK(hipMemcpy(wpk, h.data(), npk * 16, hipMemcpyHostToDevice));
+  auto dalloc = [&](size_t n) { float *p; CK(hipMalloc(&p, n * 4)); CK(hipMemset(p, 0, n * 4)); return p; };
+  float *vecs = dalloc(7 * C), *gifo = dalloc((size_t)(T + 2) * S * 4 * C), *cc = dalloc((size_t)(T + 2) * S * C),
+        *hh = dalloc((size_t)(T + 2) * S * C), *mm = dalloc((size_t)(T + 2) * S * C), *x = dalloc((size_t)T * S * I), *cs = dalloc(S * C);
+  unsigned long long *gran; CK(hipMalloc(&gran, 2 * C * 4 * 8)); CK(hipMemset(gran, 0, 2 * C * 4 * 8));
+  unsigned *ctrl; CK(hipMalloc(&ctrl, 32)); CK(hipMemset(ctrl, 0, 32));
+  long long *dbg; CK(hipMalloc(&dbg, 256 * 16 * 6 * 8)); CK(hipMemset(dbg, 0, 256 * 16 * 6 * 8));
+  for (int waves : {12}) for (int tpw : {1}) for (int nap0 : {8, 9, 10}) for (int nap : {0}) {
+    if (4 * tpw >= waves) continue;
+    set_persist_waves(waves); set_persist_tpw(tpw);
+    PersistFwdArgs a;
+    a.C = C; a.I = I; a.S = S; a.T = T; a.nchm = nchm; a.nch = nch; a.wpk = wpk;
+    a.bias = vecs; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
+    a.gifo = gifo; a.cc = cc; a.hh = hh; a.mm = mm; a.x = x; a.x_stride = I; a.c_save = cs; a.gran = gran; a.ctrl = ctrl; a.dbg = dbg; a.nap0 = nap0; a.nap = nap;
+    const PGeo g = pick_geo_fwd(C, nch);
+    const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4) * sizeof(float);
+    const int grid = C / 4 / g.tpw;
+    LaunchProbe pr;
+    auto go = [&]() -> hipError_t { PDISPATCH_FWD(k_fwd_persist); };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int rep = 0; rep < 4; rep++) {
+      CK(hipEventRecord(e0, st)); CK(go()); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
+    }
+    std::vector<long long> d(256 * 16 * 6); CK(hipMemcpy(d.data(), dbg, d.size() * 8, hipMemcpyDeviceToHost));
+    unsigned stw[4]; CK(hipMemcpy(stw, ctrl, 16, hipMemcpyDeviceToHost));
+    const double us_step = best * 1e3 / (T - 1);
+    // shader clock -> us: total cycles of a wave / kernel time
+    auto row = [&](int wg, int w) { return &d[((size_t)wg * 16 + w) * 6]; };
+    long long tot = 0; for (int i = 0; i < 6; i++) tot += row(0, 0)[i];
+    const double cyc_per_us = tot / (best * 1e3);
+    printf("S=%d waves=%d tpw=%d grid=%d maxc=%d pcell=%d nap0=%d nap=%d: %.3f us/step (status %x), ~%.0f MHz shader clock\n", S, g.waves, g.tpw, grid, g.maxc, g.pcell, nap0, nap, us_step, stw[2], cyc_per_us);
+    const char *nm[6] = {"sweep+slab", "barrier1", "contract", "barrier2", "epilogue", "loophead"};
+    for (int w : {0}) {
+      printf("   wg0 wave %2d (%s):", w, w < 4 * g.tpw ? "cell   " : "sweeper");
+      for (int i = 0; i < 6; i++) printf(" %s %.2f", nm[i], row(0, w)[i] / cyc_per_us / (T - 1));
+      printf("  us/step\n");
+    }
+    // mean over workgroups of the sweeper wave 1
+    double m[6] = {0, 0, 0, 0, 0, 0};
+    for (int wg = 0; wg < grid; wg++) for (int i = 0; i < 6; i++) m[i] += row(wg, 4 * g.tpw)[i] / cyc_per_us / (T - 1) / grid;
+    printf("   mean over workgroups, first sweeper wave:");
+    for (int i = 0; i < 6; i++) printf(" %s %.2f", nm[i], m[i]);
+    printf("\n");
+  }
+  // ---------------- backward ----------------
+  {
+    const int nchb = (4 * C + 127) / 128;
+    const size_t npb = (size_t)(C / 4) * nchb * 128;
+    float4 *wpb; CK(hipMalloc(&wpb, npb * 16));
+    std::vector<float> hb(npb * 4);
+    for (auto &v : hb) v = (rand() / (float)RAND_MAX - 0.5f) * 0.02f;
+    CK(hipMemcpy(wpb, hb.data(), npb * 16, hipMemcpyHostToDevice));
+    float *dgifo = dalloc((size_t)(T + 2) * S * 4 * C), *dc = dalloc((size_t)(T + 2) * S * C), *P = dalloc((size_t)T * S * C);
+    CK(hipMemset(gran, 0, 2 * C * 4 * 8)); CK(hipMemset(ctrl, 0, 32));
+    for (int waves : {12, 8}) for (int nap0 : {0, 2, 4, 6, 8}) {
+      set_persist_waves(waves); set_persist_tpw(1);
+      PersistBwdArgs a;
+      a.C = C; a.S = S; a.T = T; a.nch = nchb; a.wpk = wpb; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
+      a.gifo = gifo; a.cc = cc; a.hh = hh; a.dgifo = dgifo; a.dc = dc; a.P = P; a.gran = gran; a.ctrl = ctrl; a.nap0 = nap0; a.nap = 0; a.dbg = dbg;
+      const PGeo g = pick_geo(C, nchb);
+      const size_t shm = (size_t)(4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4) * sizeof(float);
+      const int grid = C / 4 / g.tpw;
+      LaunchProbe pr;
+      auto go = [&]() -> hipError_t { PDISPATCH_BWD(k_bwd_persist); };
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      float best = 1e9;
+      for (int rep = 0; rep < 4; rep++) {
+        CK(hipEventRecord(e0, st)); CK(go()); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
+      }
+      std::vector<long long> d(256 * 16 * 6); CK(hipMemcpy(d.data(), dbg, d.size() * 8, hipMemcpyDeviceToHost));
+      unsigned stw[4]; CK(hipMemcpy(stw, ctrl, 16, hipMemcpyDeviceToHost));
+      auto row = [&](int wg, int w) { return &d[((size_t)wg * 16 + w) * 6]; };
+      long long tot = 0; for (int i = 0; i < 6; i++) tot += row(0, 4)[i];
+      const double cyc_per_us = tot / (best * 1e3);
+      printf("BWD S=%d waves=%d tpw=%d grid=%d maxc=%d pcell=%d nap0=%d: %.3f us/step (status %x)\n", S, g.waves, g.tpw, grid, g.maxc, g.pcell, nap0, best * 1e3 / (T - 1), stw[2]);
+      const char *nk[6] = {"-", "wait-slab", "contract", "barrier2", "epilogue", "loophead"};
+      const char *ns[6] = {"loads+sweep", "barrier1", "elementwise", "barrier2", "-", "loophead"};
+      printf("   K wave 0 :");
+      for (int i = 1; i < 6; i++) printf(" %s %.2f", nk[i], row(0, 0)[i] / cyc_per_us / (T - 1));
+      double m[6] = {0, 0, 0, 0, 0, 0};
+      for (int wg = 0; wg < grid; wg++) for (int i = 0; i < 6; i++) m[i] += row(wg, 4)[i] / cyc_per_us / (T - 1) / grid;
+      printf("\n   sweeper (mean over workgroups, wave 4):");
+      for (int i : {0, 2, 1, 3, 5}) printf(" %s %.2f", ns[i], m[i]);
+      printf("\n");
+    }
+  }
+  return 0;
+}
