@@ -211,8 +211,8 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
  *                  (DESIGN.md 3a); -1 = auto (NumStream <= 8 and >= 12 frames per stream), 1 = whenever NumStream <=
  *                  16 and I, C, R are multiples of 8.  Same results up to fp32 summation order.
  *   "persist" -1/0/1/2  weights-resident persistent chain for NumStream <= 4: ONE launch runs forward
- *                  steps 2..T (1, and auto from 8 frames per stream) / also BPTT steps T..1 (2) with the folded operands held in
- *                  registers and the per-step all-to-all done inside the launch.  Same results up to fp32 summation order.
+ *                  steps 2..T (1) / and BPTT steps T..1 (2; auto = 2 from 8 frames per stream) with the folded operands held
+ *                  in registers and the per-step all-to-all done inside the launch.  Same results up to fp32 summation order.
  *                  "persist_waves", "persist_tpw", "persist_nap0", "persist_nap": its geometry / polling knobs (A-B experiments)
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.

@@ -14,6 +14,7 @@
 //   google/feature_transform.nnet.txt).
 #pragma once
 #include <cctype>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -88,187 +89,170 @@ template <class T> inline void ReadBasicType(std::istream &is, bool binary, T *t
   if (is.fail()) KLSTM_ERR("Read failure in ReadBasicType, file position is " << is.tellg());
 }
 
-// ---- matrix ------------------------------------------------------------------------------------
+// ---- matrices and vectors ------------------------------------------------------------------------
+// On-disk forms (the format, not the code, is what has to match Kaldi):
+//   binary matrix  "FM " int32 rows int32 cols, then rows*cols floats without row padding   ("DM " = doubles)
+//   binary vector  "FV " int32 dim, then dim floats                                        ("DV " = doubles)
+//   text matrix    " [" then per row "\n  v v v " and a closing "]\n"; an empty one is " [ ]\n"
+//   text vector    " [ v v v ]\n"
+// The text reader is a two-stage tokenizer of its own: (1) pull the bracketed body out of the stream as one string,
+// (2) cut it into rows at '\n' / ';' and convert each blank-separated field with strtod (which already understands
+// inf / infinity / nan in any case and maps out-of-range literals such as 1e+50 to +-inf after the float cast).
+namespace detail {
+
+[[noreturn]] inline void ReadFailure(const char *what, std::istream &is, std::streamoff start, const std::string &why) {
+  KLSTM_ERR("cannot read " << what << " (" << why << "); the object started at stream offset " << start
+            << ", the stream is now at " << is.tellg());
+}
+
+// Consumes "[ ... ]" plus the line end behind it and returns what stood between the brackets.  "[]" gives an empty body.
+inline std::string TakeBracketedBody(std::istream &is, const char *what, std::streamoff start) {
+  is >> std::ws;
+  if (is.peek() != '[') {
+    std::string got;
+    is >> got;
+    ReadFailure(what, is, start, got.empty() ? "the stream ended where '[' should be" : "found '" + got + "' where '[' should be");
+  }
+  is.get();
+  std::string body;
+  if (!std::getline(is, body, ']')) ReadFailure(what, is, start, "no closing ']' before the end of the stream");
+  if (is.eof()) ReadFailure(what, is, start, "no closing ']' before the end of the stream");
+  if (is.peek() == '\r') is.get();                   // the writer ends the object with a newline; eat one "\n" or "\r\n"
+  if (is.peek() == '\n') is.get();
+  return body;
+}
+
+// Converts the blank-separated fields of [p, end) and appends them to *out.
+inline void ParseFields(const char *p, const char *end, std::vector<BaseFloat> *out, const char *what, std::istream &is,
+                        std::streamoff start) {
+  while (p < end) {
+    if (isspace((unsigned char)*p)) { ++p; continue; }
+    const char *q = p;
+    while (q < end && !isspace((unsigned char)*q)) ++q;
+    const std::string field(p, q);
+    char *stop = nullptr;
+    const double v = strtod(field.c_str(), &stop);
+    if (stop == field.c_str() || *stop != '\0') ReadFailure(what, is, start, "'" + field + "' is not a number");
+    out->push_back((BaseFloat)v);
+    p = q;
+  }
+}
+
+template <class Disk>
+inline void ReadRaw(std::istream &is, size_t n, BaseFloat *dst) {
+  if (n == 0) return;
+  if (sizeof(Disk) == sizeof(BaseFloat)) { is.read(reinterpret_cast<char *>(dst), sizeof(BaseFloat) * n); return; }
+  std::vector<Disk> tmp(n);
+  is.read(reinterpret_cast<char *>(tmp.data()), sizeof(Disk) * n);
+  for (size_t i = 0; i < n; i++) dst[i] = (BaseFloat)tmp[i];
+}
+
+}  // namespace detail
+
 inline void WriteMatrix(std::ostream &os, bool binary, const BaseFloat *data, int32 rows, int32 cols, int32 stride) {
-  if (!os.good()) KLSTM_ERR("Failed to write matrix to stream: stream not good");
   if (binary) {
     WriteToken(os, binary, "FM");
     WriteBasicType(os, binary, rows);
     WriteBasicType(os, binary, cols);
-    if (stride == cols) os.write(reinterpret_cast<const char *>(data), sizeof(BaseFloat) * (size_t)rows * cols);
-    else for (int32 i = 0; i < rows; i++) os.write(reinterpret_cast<const char *>(data + (size_t)i * stride), sizeof(BaseFloat) * cols);
-    if (!os.good()) KLSTM_ERR("Failed to write matrix to stream");
+    for (int32 r = 0; r < rows && cols > 0; r++)     // row by row: the file carries no row padding
+      os.write(reinterpret_cast<const char *>(data + (size_t)r * stride), sizeof(BaseFloat) * (size_t)cols);
+  } else if (cols == 0) {
+    os << " [ ]\n";
   } else {
-    if (cols == 0) { os << " [ ]\n"; return; }
-    os << " [";
-    for (int32 i = 0; i < rows; i++) {
-      os << "\n  ";
-      for (int32 j = 0; j < cols; j++) os << data[(size_t)i * stride + j] << " ";
+    std::ostringstream text;                         // assembled first: one write, and os keeps its own float formatting
+    text.copyfmt(os);
+    text << " [";
+    for (int32 r = 0; r < rows; r++) {
+      text << "\n  ";
+      const BaseFloat *row = data + (size_t)r * stride;
+      for (int32 c = 0; c < cols; c++) text << row[c] << ' ';
     }
-    os << "]\n";
+    text << "]\n";
+    os << text.str();
   }
-}
-
-inline bool ParseTextNumber(std::istream &is, BaseFloat *out, std::string *err) {
-  // a number, or inf / nan in any case (kaldi-matrix.cc:1366-1392)
-  const int i = is.peek();
-  if ((i >= '0' && i <= '9') || i == '-' || i == '+' || i == '.') {
-    // operator>> into float fails on overflow-to-inf tokens such as "1e+50"; go through double
-    double d;
-    is >> d;
-    if (is.fail()) { *err = "Stream failure/EOF while reading matrix data."; return false; }
-    *out = (BaseFloat)d;
-    return true;
-  }
-  std::string str;
-  is >> str;
-  std::string low;
-  for (char c : str) low.push_back((char)tolower(c));
-  if (low == "inf" || low == "infinity") { *out = std::numeric_limits<BaseFloat>::infinity(); return true; }
-  if (low == "-inf" || low == "-infinity") { *out = -std::numeric_limits<BaseFloat>::infinity(); return true; }
-  if (low == "nan") { *out = std::numeric_limits<BaseFloat>::quiet_NaN(); return true; }
-  *err = "Expecting numeric matrix data, got " + str;
-  return false;
+  if (!os.good()) KLSTM_ERR("matrix of " << rows << " x " << cols << " could not be written: the output stream reports an error");
 }
 
 inline void ReadMatrix(std::istream &is, bool binary, std::vector<BaseFloat> *data, int32 *rows, int32 *cols) {
-  std::ostringstream specific_error;
-  const std::streamoff pos_at_start = is.tellg();
+  const std::streamoff start = is.tellg();
   if (binary) {
-    const int peekval = Peek(is, binary);
-    if (peekval == 'C') KLSTM_ERR("Failed to read matrix from stream: CompressedMatrix (CM) is not supported by this reader");
-    std::string token;
-    ReadToken(is, binary, &token);
-    if (token != "FM" && token != "DM") {
-      specific_error << ": Expected token FM, got " << token;
-      goto bad;
-    }
-    {
-      int32 r, c;
-      ReadBasicType(is, binary, &r);
-      ReadBasicType(is, binary, &c);
-      if (r < 0 || c < 0) { specific_error << ": negative dimensions"; goto bad; }
-      data->resize((size_t)r * c);
-      if (token == "FM") {
-        if (r * c != 0) is.read(reinterpret_cast<char *>(data->data()), sizeof(BaseFloat) * (size_t)r * c);
-      } else {   // DM: double on disk, converted (kaldi-matrix.cc:1276-1283)
-        std::vector<double> tmp((size_t)r * c);
-        if (r * c != 0) is.read(reinterpret_cast<char *>(tmp.data()), sizeof(double) * (size_t)r * c);
-        for (size_t i = 0; i < tmp.size(); i++) (*data)[i] = (BaseFloat)tmp[i];
-      }
-      if (is.fail()) goto bad;
-      *rows = r; *cols = c;
-      return;
-    }
-  } else {
-    std::string str;
-    is >> str;
-    if (is.fail()) { specific_error << ": Expected \"[\", got EOF"; goto bad; }
-    if (str == "[]") { data->clear(); *rows = 0; *cols = 0; return; }
-    if (str != "[") { specific_error << ": Expected \"[\", got \"" << str << '"'; goto bad; }
-    std::vector<std::vector<BaseFloat> > rowsv;
-    std::vector<BaseFloat> cur;
-    while (1) {
-      const int i = is.peek();
-      if (i == -1) { specific_error << "Got EOF while reading matrix data"; goto bad; }
-      if ((char)i == ']') {
-        is.get();
-        const int j = is.peek();
-        if ((char)j == '\r') { is.get(); is.get(); }
-        else if ((char)j == '\n') { is.get(); }
-        if (!cur.empty()) rowsv.push_back(cur);
-        if (rowsv.empty()) { data->clear(); *rows = 0; *cols = 0; return; }
-        const size_t nc = rowsv[0].size();
-        data->resize(rowsv.size() * nc);
-        for (size_t r = 0; r < rowsv.size(); r++) {
-          if (rowsv[r].size() != nc) {
-            specific_error << "Matrix has inconsistent #cols: " << nc << " vs." << rowsv[r].size() << " (processing row" << r << ")";
-            goto bad;
-          }
-          memcpy(data->data() + r * nc, rowsv[r].data(), nc * sizeof(BaseFloat));
-        }
-        *rows = (int32)rowsv.size(); *cols = (int32)nc;
-        return;
-      } else if ((char)i == '\n' || (char)i == ';') {
-        is.get();
-        if (!cur.empty()) { rowsv.push_back(cur); cur.clear(); }
-      } else if (isspace(i)) {
-        is.get();
-      } else {
-        BaseFloat v;
-        std::string err;
-        if (!ParseTextNumber(is, &v, &err)) { specific_error << err; goto bad; }
-        cur.push_back(v);
-      }
-    }
+    if (Peek(is, binary) == 'C') detail::ReadFailure("matrix", is, start, "compressed matrices (CM) are not supported");
+    std::string kind;
+    ReadToken(is, binary, &kind);
+    if (kind != "FM" && kind != "DM") detail::ReadFailure("matrix", is, start, "type marker '" + kind + "' instead of FM / DM");
+    int32 r = 0, c = 0;
+    ReadBasicType(is, binary, &r);
+    ReadBasicType(is, binary, &c);
+    if (r < 0 || c < 0) detail::ReadFailure("matrix", is, start, "negative size");
+    data->resize((size_t)r * c);
+    if (kind == "FM") detail::ReadRaw<float>(is, data->size(), data->data());
+    else detail::ReadRaw<double>(is, data->size(), data->data());
+    if (is.fail()) detail::ReadFailure("matrix", is, start, "the stream ended inside the payload");
+    *rows = r; *cols = c;
+    return;
   }
-bad:
-  KLSTM_ERR("Failed to read matrix from stream.  " << specific_error.str() << " File position at start is "
-            << pos_at_start << ", currently " << is.tellg());
+  const std::string body = detail::TakeBracketedBody(is, "matrix", start);
+  data->clear();
+  int32 nrows = 0, ncols = 0;
+  size_t a = 0;
+  while (a <= body.size()) {                         // one row per '\n' / ';' separated piece; blank pieces are not rows
+    size_t b = body.find_first_of("\n;", a);
+    if (b == std::string::npos) b = body.size();
+    const size_t before = data->size();
+    detail::ParseFields(body.data() + a, body.data() + b, data, "matrix", is, start);
+    const int32 got = (int32)(data->size() - before);
+    if (got > 0) {
+      if (nrows == 0) ncols = got;
+      else if (got != ncols) {
+        std::ostringstream why;
+        why << "row " << nrows << " has " << got << " entries, the rows before it have " << ncols;
+        detail::ReadFailure("matrix", is, start, why.str());
+      }
+      nrows++;
+    }
+    a = b + 1;
+  }
+  *rows = nrows; *cols = ncols;
 }
 
-// ---- vector ([UPSTREAM-unvendored] kaldi-vector.cc Write/Read) -----------------------------------
+// ---- vector ([UPSTREAM-unvendored] kaldi-vector.cc Write/Read: same framing with FV / DV and a single text row) ----
 inline void WriteVector(std::ostream &os, bool binary, const BaseFloat *data, int32 dim) {
-  if (!os.good()) KLSTM_ERR("Failed to write vector to stream: stream not good");
   if (binary) {
     WriteToken(os, binary, "FV");
     WriteBasicType(os, binary, dim);
-    os.write(reinterpret_cast<const char *>(data), sizeof(BaseFloat) * (size_t)dim);
+    if (dim > 0) os.write(reinterpret_cast<const char *>(data), sizeof(BaseFloat) * (size_t)dim);
   } else {
     os << " [ ";
-    for (int32 i = 0; i < dim; i++) os << data[i] << " ";
+    for (int32 i = 0; i < dim; i++) os << data[i] << ' ';
     os << "]\n";
   }
-  if (!os.good()) KLSTM_ERR("Failed to write vector to stream");
+  if (!os.good()) KLSTM_ERR("vector of " << dim << " elements could not be written: the output stream reports an error");
 }
 
 inline void ReadVector(std::istream &is, bool binary, std::vector<BaseFloat> *data) {
-  std::ostringstream specific_error;
-  const std::streamoff pos_at_start = is.tellg();
+  const std::streamoff start = is.tellg();
   if (binary) {
-    std::string token;
-    ReadToken(is, binary, &token);
-    if (token != "FV" && token != "DV") { specific_error << ": Expected token FV, got " << token; goto bad; }
-    int32 dim;
+    std::string kind;
+    ReadToken(is, binary, &kind);
+    if (kind != "FV" && kind != "DV") detail::ReadFailure("vector", is, start, "type marker '" + kind + "' instead of FV / DV");
+    int32 dim = 0;
     ReadBasicType(is, binary, &dim);
-    if (dim < 0) { specific_error << ": negative dimension"; goto bad; }
+    if (dim < 0) detail::ReadFailure("vector", is, start, "negative size");
     data->resize(dim);
-    if (token == "FV") { if (dim) is.read(reinterpret_cast<char *>(data->data()), sizeof(BaseFloat) * (size_t)dim); }
-    else {
-      std::vector<double> tmp(dim);
-      if (dim) is.read(reinterpret_cast<char *>(tmp.data()), sizeof(double) * (size_t)dim);
-      for (int32 i = 0; i < dim; i++) (*data)[i] = (BaseFloat)tmp[i];
-    }
-    if (is.fail()) { specific_error << ": Error reading vector data (binary mode); truncated stream?"; goto bad; }
+    if (kind == "FV") detail::ReadRaw<float>(is, data->size(), data->data());
+    else detail::ReadRaw<double>(is, data->size(), data->data());
+    if (is.fail()) detail::ReadFailure("vector", is, start, "the stream ended inside the payload");
     return;
-  } else {
-    std::string s;
-    is >> s;
-    if (is.fail()) { specific_error << "EOF while trying to read vector."; goto bad; }
-    if (s == "[]") { data->clear(); return; }
-    if (s != "[") { specific_error << "Expected \"[\" but got " << s; goto bad; }
-    data->clear();
-    while (1) {
-      const int i = is.peek();
-      if (i == -1) { specific_error << "EOF while reading vector data."; goto bad; }
-      if ((char)i == ']') {
-        is.get();
-        const int j = is.peek();
-        if ((char)j == '\r') { is.get(); is.get(); }
-        else if ((char)j == '\n') { is.get(); }
-        return;
-      }
-      if ((char)i == '\n' || (char)i == ';') { specific_error << "Newline found while reading vector (maybe it's a matrix?)"; goto bad; }
-      if (isspace(i)) { is.get(); continue; }
-      BaseFloat v;
-      std::string err;
-      if (!ParseTextNumber(is, &v, &err)) { specific_error << err; goto bad; }
-      data->push_back(v);
-    }
   }
-bad:
-  KLSTM_ERR("Failed to read vector from stream.  " << specific_error.str() << " File position at start is "
-            << pos_at_start << ", currently " << is.tellg());
+  const std::string body = detail::TakeBracketedBody(is, "vector", start);
+  if (body.find_first_of("\n;") != std::string::npos) {
+    // a row separator inside the brackets: allowed only as trailing blank space (a matrix was probably meant)
+    const size_t sep = body.find_first_of("\n;");
+    if (body.find_first_not_of(" \t\r\n;", sep) != std::string::npos)
+      detail::ReadFailure("vector", is, start, "more than one row between the brackets: this looks like a matrix");
+  }
+  data->clear();
+  detail::ParseFields(body.data(), body.data() + body.size(), data, "vector", is, start);
 }
 
 // Kaldi files written through Output(..., binary=true, write_header=true) start with "\0B";

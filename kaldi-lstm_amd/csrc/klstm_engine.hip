@@ -72,8 +72,8 @@ struct klstm_engine {
   bool fold_dirty = true;  // W_rm / its packed copies are older than the parameters
   int pk_stale = 0;        // unfolded operand arrays (bits 1..3) not refreshed by the last Update because the folded path is in use
   bool fwd_folded = false; // the last propagate ran the folded chain (its backpropagate follows suit)
-  int use_persist = -1;    // weights-resident persistent chain (klstm_persist.hip): -1 auto (forward, from 8 frames per stream), 0 off,
-                           // 1 forward whenever the shape allows, 2 forward and backward
+  int use_persist = -1;    // weights-resident persistent chain (klstm_persist.hip): -1 auto (both directions, from 8 frames per
+                           // stream), 0 off, 1 forward only, 2 forward and backward whenever the shape allows
   bool fwd_persist = false; // the last propagate ran steps 2..T inside one persistent launch
   bool bwd_persist = false; // ... and its backpropagate runs steps T..1 inside one persistent launch
   bool persist_dirty = false;   // a persistent launch ran since the status words were last read back
@@ -604,9 +604,9 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
   e->fwd_persist = persist_wanted(e, T);
-  // backward: measured at 40/800/512 the replicated elementwise BPTT of the persistent form (every workgroup recomputes
-  // dgifo of the whole layer, ~0.9 us per step) eats what the resident weights save: on request only
-  e->bwd_persist = e->fwd_persist && e->use_persist == 2;
+  // backward: the replicated elementwise BPTT of the persistent form (every workgroup recomputes dgifo of the whole
+  // layer, ~0.9 us per step) eats most of what the resident weights save: 3.85 vs 4.0 us per step at 40/800/512
+  e->bwd_persist = e->fwd_persist && e->use_persist != 1;
   e->fwd_folded = e->fwd_persist || fold_wanted(e, T);
   if (e->fwd_persist && (st = ensure_persist(e)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_ws(e, T)) != KLSTM_OK) return st;

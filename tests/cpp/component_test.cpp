@@ -105,6 +105,21 @@ int main(int argc, char **argv) {
         all.insert(all.end(), v.begin(), v.end());
       }
       write_raw(argv[3], all.data(), all.size());
+    } else if (mode == "read_matrices") {
+      // read_matrices <file with matrices back to back (text, or binary behind a \0B header)> <out_raw>: prints "rows cols" per
+      // matrix until the stream is exhausted, dumps all elements
+      std::ifstream f(argv[2], std::ios::binary);
+      const bool binary = InitKaldiInputStream(f);
+      std::vector<float> all;
+      while (true) {
+        if (!binary) f >> std::ws;
+        if (f.peek() == EOF) break;
+        std::vector<BaseFloat> m; int32 r = 0, c = 0;
+        ReadMatrix(f, binary, &m, &r, &c);
+        std::cout << r << " " << c << "\n";
+        all.insert(all.end(), m.begin(), m.end());
+      }
+      write_raw(argv[3], all.data(), all.size());
     } else if (mode == "bad_proto") {
       LstmProjectedStreams c(5, 4);
       std::istringstream proto("<CellDim> 7 <Bogus> 3");

@@ -100,7 +100,7 @@ def test_truncated_and_malformed_models_raise(tmp_path):
     ref = kaldi_fmt.binary_model(make_params(I, C, R, seed=6), I, C, R, S)
     (tmp_path / "trunc.nnet").write_bytes(ref[:len(ref) - 10])
     r = run("dump_params", tmp_path / "trunc.nnet", tmp_path / "p.raw", ok=False)
-    assert r.returncode == 3 and "Failed to read matrix" in r.stdout
+    assert r.returncode == 3 and "cannot read matrix" in r.stdout and "ended inside the payload" in r.stdout
     (tmp_path / "bad.nnet").write_bytes(ref.replace(b"<CellDim>", b"<CellDum>"))
     r = run("dump_params", tmp_path / "bad.nnet", tmp_path / "p.raw", ok=False)
     assert r.returncode == 3 and 'Expected token "<CellDim>"' in r.stdout
@@ -109,6 +109,42 @@ def test_truncated_and_malformed_models_raise(tmp_path):
     (tmp_path / "dims.nnet").write_bytes(wrong)
     r = run("dump_params", tmp_path / "dims.nnet", tmp_path / "p.raw", ok=False)
     assert r.returncode == 3 and "expected" in r.stdout
+
+
+def test_text_and_binary_matrix_reader_edge_cases(tmp_path):
+    """The matrix reader of include/klstm_kaldi_io.hpp against the on-disk forms kaldi-matrix.cc:1172-1212 / :1243-1406 define:
+    rows split at newlines or ';', blank rows ignored, "[]" and "[ ]" = empty, inf / nan / infinity in any case, literals
+    beyond the float range become +-inf, one line end ("\n" or "\r\n") behind the closing bracket is consumed (objects
+    follow each other back to back), DM (double) payloads are converted; ragged rows, non-numbers and truncated objects raise."""
+    import struct
+    txt = (" [\n  1 2 3 \n  4 5 6 ]\n"            # the writer's own layout
+           "[ 7 8 ; 9 10 ;\n ]\r\n"                # ';' rows, an empty trailing row, CRLF
+           " []\n [ ]\n"                           # two empty matrices
+           "[ inf -INF NaN 1e+50 -1e+50 Infinity ]\n"
+           "[ -0.5 ]")                              # no newline at the very end
+    (tmp_path / "m.txt").write_text(txt)
+    r = run("read_matrices", tmp_path / "m.txt", tmp_path / "m.raw")
+    assert r.stdout.split("\n")[:6] == ["2 3", "2 2", "0 0", "0 0", "1 6", "1 1"]
+    v = raw(tmp_path / "m.raw")
+    assert np.array_equal(v[:10], np.arange(1, 11, dtype=np.float32))
+    assert v[10] == np.inf and v[11] == -np.inf and np.isnan(v[12]) and v[13] == np.inf and v[14] == -np.inf and v[15] == np.inf
+    assert v[16] == -0.5 and v.size == 17
+    a = np.arange(6, dtype=np.float32).reshape(2, 3) / 7
+    b = np.arange(4, dtype=np.float64).reshape(1, 4) / 3
+    blob = (b"\0B" + b"FM " + b"\x04" + struct.pack("<i", 2) + b"\x04" + struct.pack("<i", 3) + a.tobytes() +
+            b"DM " + b"\x04" + struct.pack("<i", 1) + b"\x04" + struct.pack("<i", 4) + b.tobytes())
+    (tmp_path / "m.bin").write_bytes(blob)
+    r = run("read_matrices", tmp_path / "m.bin", tmp_path / "b.raw")
+    assert r.stdout.split("\n")[:2] == ["2 3", "1 4"]
+    assert np.array_equal(raw(tmp_path / "b.raw"), np.concatenate([a.ravel(), b.astype(np.float32).ravel()]))
+    for bad, msg in (("[ 1 2 ; 3 ]", "row 1 has 1 entries"), ("[ 1 two ]", "'two' is not a number"), ("[ 1 2", "no closing ']'"),
+                     ("1 2 ]", "where '[' should be")):
+        (tmp_path / "bad.txt").write_text(bad)
+        r = run("read_matrices", tmp_path / "bad.txt", tmp_path / "x.raw", ok=False)
+        assert r.returncode == 3 and "cannot read matrix" in r.stdout and msg in r.stdout, (bad, r.stdout)
+    (tmp_path / "bad.bin").write_bytes(blob[:len(blob) - 5])
+    r = run("read_matrices", tmp_path / "bad.bin", tmp_path / "x.raw", ok=False)
+    assert r.returncode == 3 and "ended inside the payload" in r.stdout
 
 
 def _relerr(a, b):
