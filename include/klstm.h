@@ -138,6 +138,22 @@ klstm_status klstm_backpropagate_host(klstm_engine *e, const float *in_host, int
  * 0 if it is plain host memory, <0 on error: lets an adapter pick the right pair of calls once per matrix. */
 int klstm_pointer_on_device(const klstm_engine *e, const void *p);
 
+/* Data parallelism over utterance streams: every rank runs klstm_backpropagate(.., KLSTM_BPTT_DEFER_MOMENTUM),
+ * then ONE in-place fp32 sum over the ranks of the gradient blob, then klstm_apply_momentum + klstm_update on every rank.
+ *   klstm_allreduce_grads   ncclAllReduce(sum, fp32) of this engine's gradient blob (also a blob bound with
+ *                           klstm_bind_grad_blob) over the ranks of `rccl_comm` (an ncclComm_t), enqueued on the engine's stream
+ *   klstm_allreduce_buffer  the same for any device buffer of n floats, e.g. the fused blob of a stacked net, on hip_stream
+ *   klstm_comm_*            thin pass-throughs to ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy for callers without RCCL
+ *                           headers: rank 0 obtains the 128-byte id and hands it to the other ranks by its own means (file,
+ *                           MPI, the launcher's store), every rank then calls klstm_comm_init_rank (collective).
+ * RCCL is resolved in the running process at the first of these calls (no link-time dependency of libklstm.so). */
+#define KLSTM_COMM_ID_BYTES 128
+klstm_status klstm_comm_get_unique_id(void *id128);
+klstm_status klstm_comm_init_rank(int device, int nranks, int rank, const void *id128, void **comm);
+klstm_status klstm_comm_destroy(void *comm);
+klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm);
+klstm_status klstm_allreduce_buffer(float *buf_dev, size_t n, void *rccl_comm, void *hip_stream);
+
 /* DP mode only, after the all-reduce of klstm_grad_blob():  corr = momentum*corr + grad. */
 klstm_status klstm_apply_momentum(klstm_engine *e, float momentum);
 

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "klstm.h"
@@ -67,16 +68,20 @@ class LstmProjectedStreams {
  public:
   LstmProjectedStreams(int32 input_dim, int32 output_dim)          // ...streams.h:27-33
       : input_dim_(input_dim), output_dim_(output_dim), ncell_(0), nrecur_(output_dim), nstream_(0),
-        device_(0), stream_(nullptr), eng_(nullptr), host_fresh_(true), corr_pending_(false) {}
+        device_(0), stream_(nullptr), eng_(nullptr), host_fresh_(true), corr_pending_(false), dp_comm_(nullptr) {}
   virtual ~LstmProjectedStreams() { if (eng_) klstm_destroy(eng_); }
   LstmProjectedStreams(const LstmProjectedStreams &o)               // Copy() copy-constructs every buffer (:38)
       : input_dim_(o.input_dim_), output_dim_(o.output_dim_), ncell_(o.ncell_), nrecur_(o.nrecur_),
         nstream_(o.nstream_), opts_(o.opts_), device_(o.device_), stream_(o.stream_), eng_(nullptr),
-        host_fresh_(true), corr_pending_(false) {
+        host_fresh_(true), corr_pending_(false), options_(o.options_), dp_comm_(o.dp_comm_) {
     o.PullParams();
     params_ = o.params_;
     corr_ = o.HostCorr();
     corr_pending_ = !corr_.empty();
+    if (o.eng_) {                                     // prev_nnet_state_ is copy-constructed too (:38): the carried c / r
+      state_c_.resize((size_t)nstream_ * ncell_); state_r_.resize((size_t)nstream_ * nrecur_);
+      Check(klstm_get_state_host(o.eng_, state_c_.data(), state_r_.data()));
+    } else { state_c_ = o.state_c_; state_r_ = o.state_r_; }
   }
   LstmProjectedStreams &operator=(const LstmProjectedStreams &) = delete;
   virtual LstmProjectedStreams *Copy() const { return new LstmProjectedStreams(*this); }
@@ -209,11 +214,11 @@ class LstmProjectedStreams {
     if (in.NumRows() > 0 && klstm_pointer_on_device(eng_, in.Data()) == 0)
       Check(klstm_backpropagate_host(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
                                      in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
-                                     opts_.momentum, KLSTM_BPTT_DEFAULT));
+                                     opts_.momentum, dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : KLSTM_BPTT_DEFAULT));
     else
       Check(klstm_backpropagate(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
                                 in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
-                                opts_.momentum, KLSTM_BPTT_DEFAULT));
+                                opts_.momentum, dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : KLSTM_BPTT_DEFAULT));
     host_fresh_ = host_fresh_ && true;
   }
 
@@ -221,6 +226,10 @@ class LstmProjectedStreams {
   virtual void Update(const MatrixView &input, const MatrixView &diff) {
     (void)input; (void)diff;
     EnsureEngine();
+    if (dp_comm_) {                                   // sum of the ranks' gradients, then corr = momentum*corr + sum (:465-487 per rank)
+      Check(klstm_allreduce_grads(eng_, dp_comm_));
+      Check(klstm_apply_momentum(eng_, opts_.momentum));
+    }
     Check(klstm_update(eng_, opts_.learn_rate, ClipGrad()));
     host_fresh_ = false;
   }
@@ -229,7 +238,17 @@ class LstmProjectedStreams {
   int32 NumStream() const { return nstream_; }
   klstm_engine *Engine() { EnsureEngine(); return eng_; }
   // Engine tuning knobs without a reference counterpart ("fold", "bf16", "graph", ...; include/klstm.h klstm_set_option)
-  void SetEngineOption(const char *key, int value) { EnsureEngine(); Check(klstm_set_option(eng_, key, value)); }
+  void SetEngineOption(const char *key, int value) {
+    EnsureEngine();
+    Check(klstm_set_option(eng_, key, value));
+    options_.push_back(std::make_pair(std::string(key), value));   // re-applied when Copy() / a re-created engine needs them
+  }
+  // Data-parallel training over utterance streams (no counterpart in the reference, which is single-GPU): with an
+  // RCCL communicator set, BackpropagateFnc leaves the pure LOCAL gradient in the blob and Update first sums it over the
+  // ranks (klstm_allreduce_grads: one in-place fp32 all-reduce on the engine's stream), then applies momentum and the step.
+  // Every rank holds the same parameters and momentum buffers and feeds its own streams.  comm = an ncclComm_t (or the
+  // handle klstm_comm_init_rank returned); nullptr switches back to single-GPU training.
+  void SetDataParallel(void *rccl_comm) { dp_comm_ = rccl_comm; }
 
  protected:
   virtual bool HasStreams() const { return true; }       // <NumStream> is serialised (:136-137)
@@ -251,6 +270,10 @@ class LstmProjectedStreams {
     if ((int32)params_.size() == NumParams()) Check(klstm_set_params_host(eng_, params_.data()));
     if (corr_pending_ && (int32)corr_.size() == NumParams()) Check(klstm_set_corr_host(eng_, corr_.data()));
     corr_pending_ = false;
+    if (state_c_.size() == (size_t)nstream_ * ncell_ && state_r_.size() == (size_t)nstream_ * nrecur_)
+      Check(klstm_set_state_host(eng_, state_c_.data(), state_r_.data()));          // carried over by Copy()
+    state_c_.clear(); state_r_.clear();
+    for (const auto &kv : options_) Check(klstm_set_option(eng_, kv.first.c_str(), kv.second));
   }
   void PullParams() const {
     if (eng_ && !host_fresh_) {
@@ -303,6 +326,9 @@ class LstmProjectedStreams {
   mutable bool host_fresh_;                 // params_ == device parameters
   std::vector<BaseFloat> corr_;             // only to carry *_corr_ across Copy()
   bool corr_pending_;
+  std::vector<BaseFloat> state_c_, state_r_;        // only to carry prev_nnet_state_ (c, r columns) across Copy()
+  std::vector<std::pair<std::string, int> > options_;   // engine options set through SetEngineOption
+  void *dp_comm_;                           // RCCL communicator of data-parallel training, or nullptr
 };
 
 // standard/nnet/nnet-lstm-projected.h: one utterance per call, no state bridge (:228-231, :314-315 are

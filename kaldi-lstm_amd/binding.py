@@ -82,6 +82,11 @@ def load_library():
     lib.klstm_affine_gradient.argtypes = [P, I, P, I, I, I, I, P, P, P]
     lib.klstm_sgd_momentum_update.argtypes = [P, P, P, ctypes.c_long, F, F, P]
     lib.klstm_xent_eval_masked.argtypes = [P, I, I, I, P, P, P, I, P, P, P]
+    lib.klstm_comm_get_unique_id.argtypes = [P]
+    lib.klstm_comm_init_rank.argtypes = [I, I, I, P, ctypes.POINTER(P)]
+    lib.klstm_comm_destroy.argtypes = [P]
+    lib.klstm_allreduce_grads.argtypes = [P, P]
+    lib.klstm_allreduce_buffer.argtypes = [P, ctypes.c_size_t, P, P]
     _LIB = lib
     return lib
 
@@ -165,6 +170,23 @@ class Engine:
                                       "data": (self.grad_blob_ptr(), False), "version": 2}
         return torch.as_tensor(b, device="cuda")
 
+    def param_blob_tensor(self):
+        """Zero-copy torch view of the device parameter blob (read it; write through set_params_device)."""
+        import torch
+
+        class _Blob:
+            pass
+        b = _Blob()
+        b.__cuda_array_interface__ = {"shape": (self.num_params,), "typestr": "<f4",
+                                      "data": (int(self.lib.klstm_param_blob(self.h)), False), "version": 2}
+        return torch.as_tensor(b, device="cuda")
+
+    def set_params_device(self, t):
+        """Load parameters from a contiguous CUDA float32 tensor (device-to-device, stream-ordered)."""
+        assert t.is_cuda and t.is_contiguous() and t.numel() == self.num_params
+        self._keep.append(t)
+        self._chk(self.lib.klstm_set_params_device(self.h, t.data_ptr()))
+
     # ---- Reset (reference :212-220) ----
     def reset(self, flags):
         f = np.ascontiguousarray(flags, dtype=np.int32)
@@ -224,6 +246,10 @@ class Engine:
         self._chk(self.lib.klstm_bind_grad_blob(self.h, t.data_ptr()))
         self._bound = t
 
+    def allreduce_grads(self, comm):
+        """In-place fp32 sum of the gradient blob over the ranks of `comm` (a RcclComm), on the engine's stream."""
+        self._chk(self.lib.klstm_allreduce_grads(self.h, comm.handle))
+
     def apply_momentum(self, momentum):
         self._chk(self.lib.klstm_apply_momentum(self.h, float(momentum)))
 
@@ -246,6 +272,43 @@ class Engine:
         tot, n = ctypes.c_double(), ctypes.c_long()
         self._chk(self.lib.klstm_profile_query(self.h, kernel.encode(), ctypes.byref(tot), ctypes.byref(n)))
         return tot.value, n.value
+
+
+class RcclComm:
+    """An RCCL communicator created through the C-ABI (klstm_comm_*): the data-path collective of data-parallel training
+    is issued by libklstm.so itself (klstm_allreduce_grads / klstm_allreduce_buffer), not by the launcher.
+    `exchange(id_bytes_or_None) -> id_bytes` hands rank 0's 128-byte id to every rank (e.g. a torch.distributed / MPI
+    broadcast, or a file); with nranks == 1 no exchange is needed."""
+
+    def __init__(self, nranks, rank, device=0, exchange=None):
+        self.lib = load_library()
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _chk(self.lib.klstm_comm_get_unique_id(buf))
+        if nranks > 1:
+            raw = exchange(buf.raw if rank == 0 else None)
+            buf = ctypes.create_string_buffer(bytes(raw), 128)
+        h = ctypes.c_void_p()
+        _chk(self.lib.klstm_comm_init_rank(int(device), int(nranks), int(rank), buf, ctypes.byref(h)))
+        self.handle, self.nranks, self.rank = h, nranks, rank
+
+    def allreduce(self, t, stream=None):
+        """In-place fp32 sum of a contiguous CUDA float32 tensor over the ranks (torch's current stream by default)."""
+        import torch
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+        sp = ctypes.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        _chk(self.lib.klstm_allreduce_buffer(t.data_ptr(), t.numel(), self.handle, sp))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.klstm_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def time_shift(x, out, shift, stream=None):

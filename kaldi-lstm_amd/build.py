@@ -34,9 +34,10 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-result", "-o", LIB] + [os.path.join(HERE, s) for s in SRCS]
+           "-Wall", "-Wno-unused-result", "-I/opt/rocm/include", "-o", LIB] + [os.path.join(HERE, s) for s in SRCS]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    cmd += ["-ldl"]
     subprocess.check_call(cmd)
     with open(STAMP, "w") as fh:
         fh.write(source_hash() + "\n")

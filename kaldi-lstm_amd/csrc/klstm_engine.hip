@@ -18,6 +18,9 @@
 #include <tuple>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library is resolved at run time (see the RCCL section below)
+
 #include "../../include/klstm.h"
 #include "klstm_kernels.h"
 
@@ -1006,6 +1009,99 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
   if (rows > 0) HIPCHK(launch_xent(net_out, rows, cols, stride, targets_dev, mask_dev, diff, diff_stride, row_xent_dev,
                                    row_correct_dev, (hipStream_t)hip_stream));
   return KLSTM_OK;
+}
+
+// ---- RCCL (data-parallel training over utterance streams: ONE sum-all-reduce of the gradient blob per minibatch) ----
+// libklstm.so has no link-time dependency on RCCL: the entry points are looked up in the process when the first DP call
+// arrives -- first among the symbols already loaded (a host framework may have brought its own librccl, e.g. PyTorch's
+// bundled one; two copies of RCCL in one process must not be mixed), then by dlopen("librccl.so.1").
+}  // extern "C"
+namespace {
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+  std::string why;
+};
+RcclApi &rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void *h = nullptr;
+    auto sym = [&](const char *name) -> void * {
+      void *p = dlsym(RTLD_DEFAULT, name);
+      if (!p) {
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) p = dlsym(h, name);
+      }
+      return p;
+    };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce;
+    if (!api.ok) api.why = std::string("RCCL entry points not found (") + (dlerror() ? dlerror() : "librccl.so.1 not loadable") + ")";
+  });
+  return api;
+}
+klstm_status rccl_fail(const char *what, ncclResult_t r) {
+  RcclApi &a = rccl();
+  return fail(KLSTM_ERR_HIP, "%s failed: %s", what, a.GetErrorString ? a.GetErrorString(r) : "RCCL error");
+}
+}  // namespace
+extern "C" {
+
+klstm_status klstm_comm_get_unique_id(void *id128) {
+  if (!id128) return fail(KLSTM_ERR_ARG, "klstm_comm_get_unique_id: null argument");
+  RcclApi &a = rccl();
+  if (!a.ok) return fail(KLSTM_ERR_HIP, "%s", a.why.c_str());
+  ncclUniqueId id;
+  const ncclResult_t r = a.GetUniqueId(&id);
+  if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
+  static_assert(sizeof(id) == KLSTM_COMM_ID_BYTES, "ncclUniqueId size");
+  memcpy(id128, &id, sizeof(id));
+  return KLSTM_OK;
+}
+klstm_status klstm_comm_init_rank(int device, int nranks, int rank, const void *id128, void **comm) {
+  if (!id128 || !comm || nranks <= 0 || rank < 0 || rank >= nranks) return fail(KLSTM_ERR_ARG, "klstm_comm_init_rank: bad argument");
+  RcclApi &a = rccl();
+  if (!a.ok) return fail(KLSTM_ERR_HIP, "%s", a.why.c_str());
+  HIPCHK(hipSetDevice(device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t c = nullptr;
+  const ncclResult_t r = a.CommInitRank(&c, nranks, id, rank);
+  if (r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
+  *comm = c;
+  return KLSTM_OK;
+}
+klstm_status klstm_comm_destroy(void *comm) {
+  if (!comm) return KLSTM_OK;
+  RcclApi &a = rccl();
+  if (!a.ok) return fail(KLSTM_ERR_HIP, "%s", a.why.c_str());
+  const ncclResult_t r = a.CommDestroy(static_cast<ncclComm_t>(comm));
+  return r == ncclSuccess ? KLSTM_OK : rccl_fail("ncclCommDestroy", r);
+}
+klstm_status klstm_allreduce_buffer(float *buf_dev, size_t n, void *rccl_comm, void *hip_stream) {
+  if (!buf_dev || !rccl_comm) return fail(KLSTM_ERR_ARG, "klstm_allreduce_buffer: null argument");
+  if (n == 0) return KLSTM_OK;
+  RcclApi &a = rccl();
+  if (!a.ok) return fail(KLSTM_ERR_HIP, "%s", a.why.c_str());
+  const ncclResult_t r = a.AllReduce(buf_dev, buf_dev, n, ncclFloat32, ncclSum, static_cast<ncclComm_t>(rccl_comm),
+                                     static_cast<hipStream_t>(hip_stream));
+  return r == ncclSuccess ? KLSTM_OK : rccl_fail("ncclAllReduce", r);
+}
+klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm) {
+  if (!e) return fail(KLSTM_ERR_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }     // a pending corr += grads must see the LOCAL sums
+  return klstm_allreduce_buffer(e->grads, (size_t)e->nparams, rccl_comm, e->stream);   // in place, on the engine's stream: no event hops
 }
 
 // Diagnostic: cost of one kernel inside a dependent chain.  Captures `n` back-to-back launches of

@@ -16,6 +16,24 @@ equals the single-GPU S_total run up to fp32 summation order.  Gradients are sum
 import torch
 
 
+def native_comm(dist, group=None, device=None):
+    """RCCL communicator created through the C-ABI of libklstm.so (klstm_comm_*), its 128-byte id handed from rank 0 to
+    the other ranks over the already initialised torch.distributed group (launcher plumbing only: the gradient all-reduce
+    itself is then issued by klstm_allreduce_grads / klstm_allreduce_buffer on the engine's stream).  None when the
+    process group is not on GPUs (gloo CPU tests keep torch.distributed's all_reduce)."""
+    import torch
+    from .binding import RcclComm
+    if not dist.is_initialized() or dist.get_backend(group) != "nccl":
+        return None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def exchange(raw):
+        t = torch.tensor(list(raw) if raw is not None else [0] * 128, dtype=torch.uint8, device="cuda")
+        dist.broadcast(t, src=0, group=group)
+        return bytes(t.cpu().tolist())
+    return RcclComm(world, rank, device=torch.cuda.current_device() if device is None else device, exchange=exchange)
+
+
 def shard_time_major(mat, num_stream_total, rank, world):
     """Rows of a time-major minibatch matrix [T*S_total, D] that belong to this rank's streams,
     as a contiguous time-major [T*S_local, D] tensor/array."""
@@ -41,16 +59,21 @@ class DataParallelLstm:
         # force_collective: take the all-reduce code path even with one rank (tests)
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self._blob = None
+        # on GPUs the collective is libklstm.so's own (klstm_allreduce_grads: RCCL, in place, on the engine's stream)
+        self.comm = native_comm(dist, group) if self.collective and hasattr(engine, "allreduce_grads") else None
 
     def broadcast_params(self, src=0):
-        """Make every replica start from rank `src`'s parameters."""
+        """Make every replica start from rank `src`'s parameters (device to device on GPUs)."""
         if self.world == 1:
             return
+        if self.dist.get_backend(self.group) == "nccl" and hasattr(self.engine, "param_blob_tensor"):
+            p = self.engine.param_blob_tensor().clone()
+            self.dist.broadcast(p, src=src, group=self.group)
+            self.engine.set_params_device(p)
+            return
         p = torch.from_numpy(self.engine.get_params())
-        if self.dist.get_backend(self.group) == "nccl":
-            p = p.cuda()
         self.dist.broadcast(p, src=src, group=self.group)
-        self.engine.set_params(p.cpu().numpy())
+        self.engine.set_params(p.numpy())
 
     def train_step(self, x, out, out_diff, in_diff, momentum, learn_rate, reset_flags=None):
         e = self.engine
@@ -61,9 +84,12 @@ class DataParallelLstm:
             e.backpropagate(x, out_diff, in_diff, momentum, 0)
         else:
             e.backpropagate(x, out_diff, in_diff, momentum, self.DEFER_MOMENTUM)
-            if self._blob is None:
-                self._blob = e.grad_blob_tensor()
-            self.dist.all_reduce(self._blob, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.comm is not None:
+                e.allreduce_grads(self.comm)
+            else:
+                if self._blob is None:
+                    self._blob = e.grad_blob_tensor()
+                self.dist.all_reduce(self._blob, op=self.dist.ReduceOp.SUM, group=self.group)
             e.apply_momentum(momentum)
         e.update(learn_rate)
 
@@ -180,6 +206,8 @@ class DataParallelNnet:
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         pad4 = lambda n: (n + 3) // 4 * 4                  # every slice starts 16-byte aligned (float4 stores)
         self.blob = alloc(sum(pad4(l.num_params) for l in layers))
+        # device layers: the all-reduce is libklstm.so's klstm_allreduce_buffer (RCCL) on the layers' stream
+        self.comm = native_comm(dist, group) if self.collective and self.blob.is_cuda and not overlap else None
         off = 0
         self.slices = []
         for l in layers:
@@ -201,7 +229,10 @@ class DataParallelNnet:
             if self.collective and self.overlap:
                 pending.append(self.dist.all_reduce(self.slices[i], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
         if self.collective and not self.overlap:
-            self.dist.all_reduce(self.blob, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.comm is not None:
+                self.comm.allreduce(self.blob)
+            else:
+                self.dist.all_reduce(self.blob, op=self.dist.ReduceOp.SUM, group=self.group)
         for w in pending:
             w.wait()
         for l in self.layers:

@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <unistd.h>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -190,6 +191,22 @@ int main(int argc, char **argv) {
       const std::string prefix = argv[9];
       c->SetTrainOptions(opts);
       if (const char *f = getenv("KLSTM_TEST_FOLD")) c->SetEngineOption("fold", atoi(f));   // folded recurrence forced on/off
+      void *comm = nullptr;
+      if (const char *dp = getenv("KLSTM_TEST_DP")) {      // "nranks:rank:idfile" -- data-parallel step through the C-ABI's RCCL calls
+        int nranks = 1, rank = 0; char idfile[512] = "";
+        sscanf(dp, "%d:%d:%511s", &nranks, &rank, idfile);
+        char id[KLSTM_COMM_ID_BYTES];
+        if (rank == 0) {
+          if (klstm_comm_get_unique_id(id) != KLSTM_OK) KLSTM_ERR("klstm_comm_get_unique_id: " << klstm_last_error());
+          if (nranks > 1) { std::ofstream g(std::string(idfile) + ".tmp", std::ios::binary); g.write(id, sizeof(id)); g.close(); rename((std::string(idfile) + ".tmp").c_str(), idfile); }
+        } else {
+          for (int tries = 0; tries < 600; tries++) { std::ifstream g(idfile, std::ios::binary); if (g.read(id, sizeof(id))) break; usleep(100000); }
+        }
+        if (klstm_comm_init_rank(0, nranks, rank, id, &comm) != KLSTM_OK) KLSTM_ERR("klstm_comm_init_rank: " << klstm_last_error());
+        c->SetDataParallel(comm);
+        std::cout << "DP " << nranks << " ranks, rank " << rank << "\n";
+      }
+
       const int I = c->InputDim(), R = c->OutputDim();
       // pitched device matrices, like CuMatrix (cu-matrix.cc:67-73): stride > cols
       const int xs = I + 4, os = R + 8, ds = R + 4, is = I + 12;
@@ -221,6 +238,9 @@ int main(int argc, char **argv) {
           g << c->InfoGradient() << "\n";
         }
         c->Update(in, out_diff);
+        // Copy() after the first minibatch: parameters, momentum buffers, carried c / r state and engine options must
+        // all carry over (the reference copy-constructs every member, ...streams.h:38)
+        if (getenv("KLSTM_TEST_COPY") && step == 0) c.reset(c->Copy());
       }
       write_raw(prefix + ".out", hout.data(), hout.size());
       write_raw(prefix + ".in_diff", hid.data(), hid.size());
@@ -231,6 +251,7 @@ int main(int argc, char **argv) {
       InitKaldiOutputStream(f, true);
       c->Write(f, true);
       std::cout << "OK\n" << c->Info() << "\n";
+      if (comm) klstm_comm_destroy(comm);
     } else {
       std::cerr << "usage: component_test init_write|dump_params|convert|bad_proto|run_gpu|run_gpu_host ...\n";
       return 2;

@@ -154,7 +154,9 @@ def _relerr(a, b):
 @pytest.mark.gpu
 @pytest.mark.parametrize("marker,S,mode", [("<LstmProjectedStreams>", 4, "run_gpu"), ("<LstmProjected>", 1, "run_gpu"),
                                            ("<LstmProjectedStreams>", 4, "run_gpu_host"),
-                                           ("<LstmProjectedStreams>", 4, "run_gpu_fold"), ("<LstmProjected>", 1, "run_gpu_fold")])
+                                           ("<LstmProjectedStreams>", 4, "run_gpu_fold"), ("<LstmProjected>", 1, "run_gpu_fold"),
+                                           ("<LstmProjectedStreams>", 4, "run_gpu_dp"),      # C++ data-parallel step over RCCL (1 rank)
+                                           ("<LstmProjectedStreams>", 4, "run_gpu_copy")])   # Copy() after the first minibatch
 def test_component_train_steps_gpu(tmp_path, marker, S, mode, monkeypatch):
     """Reset -> (PropagateFnc, BackpropagateFnc, Update) x3 through the C++ mirror, pitched device
     matrices (run_gpu_host: pitched HOST matrices, staged by the adapter); <LstmProjected> = standard/
@@ -168,6 +170,13 @@ def test_component_train_steps_gpu(tmp_path, marker, S, mode, monkeypatch):
     x.tofile(tmp_path / "x.raw"); od.tofile(tmp_path / "od.raw")
     lr, mmt, nsteps = 1e-4, 0.9, 3
     if mode == "run_gpu_fold":                 # SetEngineOption("fold", 1): the folded chain behind the same Component calls
+        monkeypatch.setenv("KLSTM_TEST_FOLD", "1")
+        mode = "run_gpu"
+    if mode == "run_gpu_dp":                   # SetDataParallel(comm): deferred momentum -> klstm_allreduce_grads -> momentum -> update,
+        monkeypatch.setenv("KLSTM_TEST_DP", "1:0:%s" % (tmp_path / "rccl.id"))     # all issued by the C++ mirror through the C-ABI
+        mode = "run_gpu"
+    if mode == "run_gpu_copy":                 # the rest of the run happens on a Copy(): state, momentum, options carried over
+        monkeypatch.setenv("KLSTM_TEST_COPY", "1")
         monkeypatch.setenv("KLSTM_TEST_FOLD", "1")
         mode = "run_gpu"
     run(mode, tmp_path / "m.nnet", tmp_path / "x.raw", tmp_path / "od.raw", T * S, lr, mmt, nsteps, tmp_path / "res")
