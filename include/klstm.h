@@ -220,6 +220,18 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
                                     const float *mask_dev, float *diff, int diff_stride, float *row_xent_dev,
                                     float *row_correct_dev, void *hip_stream);
 
+/* Xent::EvalMasked for GENERAL posteriors (google/nnet/nnet-loss.cc:76-142): frame r carries the entries
+ * post_pdf/post_weight[post_offsets[r] .. post_offsets[r+1]) (CSR, device arrays; repeated pdfs of a frame add up like the
+ * reference's `tgt(t, pdf) += weight`, :86-96).  diff = (net_out - target) * mask; per row: cross entropy -mask*sum t*log(y),
+ * target entropy -mask*sum t*log(t + 1e-20), and 1 if mask == 1 and the arg-maxima of net_out and of the target row agree
+ * (lowest index on ties, zeros of the dense target row included).  The dense rows x cols target matrix of the reference
+ * (5.3 MB per minibatch at 80 x 16624, built on the host and copied) never exists.  pdf range checks are the caller's
+ * (the reference raises on the host while it builds the matrix, :89-92). */
+klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int cols, int stride, const int *post_offsets_dev,
+                                         const int *post_pdf_dev, const float *post_weight_dev, const float *mask_dev, float *diff,
+                                         int diff_stride, float *row_xent_dev, float *row_entropy_dev, float *row_correct_dev,
+                                         void *hip_stream);
+
 /* Engine knobs (not part of the reference interface).  Keys:
  *   "graph"   0/1  replay the per-call launch sequence from a hipGraph (default 1: robust against a busy host
  *                  thread) or issue plain stream launches (no fixed cost per graph launch)

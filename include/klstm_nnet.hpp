@@ -343,11 +343,61 @@ class Nnet {                                  // google/nnet/nnet-nnet.h:36-150
   NnetTrainOptions opts_;
 };
 
+// Kaldi's Posterior (hmm/posterior.h [UPSTREAM-unvendored]; used as such in nnet-loss.cc:78): per frame a list of (pdf-id, weight)
+typedef std::vector<std::vector<std::pair<int32, BaseFloat> > > Posterior;
+
 // Xent with the overlay's EvalMasked (google/nnet/nnet-loss.h:33-80, nnet-loss.cc:76-164, Report :293-307).
 class Xent {
  public:
-  Xent() : frames_(0), correct_(0), loss_(0), entropy_(0), tgt_(nullptr), mask_(nullptr), rx_(nullptr), rc_(nullptr), cap_(0) {}
-  ~Xent() { klstm_free(tgt_); klstm_free(mask_); klstm_free(rx_); klstm_free(rc_); }
+  Xent() : frames_(0), correct_(0), loss_(0), entropy_(0), tgt_(nullptr), mask_(nullptr), rx_(nullptr), rc_(nullptr), cap_(0),
+           poff_(nullptr), ppdf_(nullptr), pw_(nullptr), re_(nullptr), pcap_(0), ecap_(0) {}
+  ~Xent() { klstm_free(tgt_); klstm_free(mask_); klstm_free(rx_); klstm_free(rc_); klstm_free(poff_); klstm_free(ppdf_); klstm_free(pw_); klstm_free(re_); }
+  // EvalMasked with the reference's signature (nnet-loss.cc:76-79): general posteriors.  The (pdf, weight) lists go to the
+  // device as CSR arrays (a few KB) instead of the reference's dense num_frames x num_pdf host matrix (:85-97).
+  void EvalMasked(const std::vector<BaseFloat> &frame_mask, const DeviceMatrix &net_out, const Posterior &post, DeviceMatrix *diff) {
+    const int32 n = net_out.NumRows(), d = net_out.NumCols();
+    KLSTM_ASSERT(n == (int32)post.size() && n == (int32)frame_mask.size());              // :82
+    std::vector<int32> off(1, 0), pdf;
+    std::vector<BaseFloat> w;
+    for (int32 t = 0; t < n; t++) {
+      for (size_t i = 0; i < post[t].size(); i++) {
+        const int32 id = post[t][i].first;
+        if (id >= d || id < 0) KLSTM_ERR("Posterior pdf-id out of NN-output dimension, please check number of pdfs by 'hmm-info'." << " nn-outputs : " << d << ", posterior pdf-id : " << id);   // :89-92
+        pdf.push_back(id); w.push_back(post[t][i].second);
+      }
+      off.push_back((int32)pdf.size());
+    }
+    void *p;
+    if ((size_t)n > pcap_) {
+      klstm_free(poff_); klstm_free(mask_); klstm_free(rx_); klstm_free(rc_); klstm_free(re_); klstm_free(tgt_);
+      KCheck(klstm_malloc(&p, (size_t)(n + 1) * 4)); poff_ = (int32 *)p;
+      KCheck(klstm_malloc(&p, (size_t)n * 4)); mask_ = (BaseFloat *)p;
+      KCheck(klstm_malloc(&p, (size_t)n * 4)); rx_ = (BaseFloat *)p;
+      KCheck(klstm_malloc(&p, (size_t)n * 4)); rc_ = (BaseFloat *)p;
+      KCheck(klstm_malloc(&p, (size_t)n * 4)); re_ = (BaseFloat *)p;
+      KCheck(klstm_malloc(&p, (size_t)n * 4)); tgt_ = (int32 *)p;
+      pcap_ = n; cap_ = n;
+    }
+    if (pdf.size() + 1 > ecap_) {
+      klstm_free(ppdf_); klstm_free(pw_);
+      ecap_ = pdf.size() + 1;
+      KCheck(klstm_malloc(&p, ecap_ * 4)); ppdf_ = (int32 *)p;
+      KCheck(klstm_malloc(&p, ecap_ * 4)); pw_ = (BaseFloat *)p;
+    }
+    KCheck(klstm_memcpy_h2d(poff_, off.data(), off.size() * 4, nullptr));
+    if (!pdf.empty()) { KCheck(klstm_memcpy_h2d(ppdf_, pdf.data(), pdf.size() * 4, nullptr)); KCheck(klstm_memcpy_h2d(pw_, w.data(), w.size() * 4, nullptr)); }
+    KCheck(klstm_memcpy_h2d(mask_, frame_mask.data(), (size_t)n * 4, nullptr));
+    diff->Resize(n, d, false);                                                            // :103
+    MatrixView y = net_out.View(), dv = diff->View();
+    KCheck(klstm_xent_eval_masked_post(y.Data(), n, d, y.Stride(), poff_, ppdf_, pw_, mask_, dv.Data(), dv.Stride(), rx_, re_, rc_, nullptr));
+    std::vector<BaseFloat> rx(n), rc(n), re(n);
+    KCheck(klstm_memcpy_d2h(rx.data(), rx_, (size_t)n * 4, nullptr));
+    KCheck(klstm_memcpy_d2h(rc.data(), rc_, (size_t)n * 4, nullptr));
+    KCheck(klstm_memcpy_d2h(re.data(), re_, (size_t)n * 4, nullptr));
+    double xe = 0, ent = 0; int32 correct = 0, valid = 0;
+    for (int32 i = 0; i < n; i++) { xe += rx[i]; ent += re[i]; correct += (rc[i] == 1.f); valid += (frame_mask[i] == 1.f); }
+    loss_ += xe; entropy_ += ent; correct_ += correct; frames_ += valid;                  // :138-142
+  }
   // frame_mask: 1 valid / 0 padded per row; target: pdf-id per row (one-hot posterior)
   void EvalMasked(const std::vector<BaseFloat> &frame_mask, const DeviceMatrix &net_out, const std::vector<int32> &target,
                   DeviceMatrix *diff) {
@@ -389,6 +439,8 @@ class Xent {
   double frames_, correct_, loss_, entropy_;
   int32 *tgt_; BaseFloat *mask_, *rx_, *rc_;
   size_t cap_;
+  int32 *poff_, *ppdf_; BaseFloat *pw_, *re_;      // CSR posterior and per-row target entropy of the general EvalMasked
+  size_t pcap_, ecap_;
 };
 
 struct TrainLstmStreamsOptions {              // bd-nnet-train-lstm-streams.cc:27-71 (the options that matter)

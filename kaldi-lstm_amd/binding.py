@@ -82,6 +82,7 @@ def load_library():
     lib.klstm_affine_gradient.argtypes = [P, I, P, I, I, I, I, P, P, P]
     lib.klstm_sgd_momentum_update.argtypes = [P, P, P, ctypes.c_long, F, F, P]
     lib.klstm_xent_eval_masked.argtypes = [P, I, I, I, P, P, P, I, P, P, P]
+    lib.klstm_xent_eval_masked_post.argtypes = [P, I, I, I, P, P, P, P, P, I, P, P, P, P]
     lib.klstm_comm_get_unique_id.argtypes = [P]
     lib.klstm_comm_init_rank.argtypes = [I, I, I, P, ctypes.POINTER(P)]
     lib.klstm_comm_destroy.argtypes = [P]
@@ -385,3 +386,32 @@ def xent_eval_masked(net_out, target, mask, diff, stream=None):
     else:
         torch.cuda.synchronize()
     return float(rx.double().sum().item()), int(rc.sum().item()), int(mask.sum().item())
+
+
+def xent_eval_masked_post(net_out, post, mask, diff, stream=None):
+    """Xent::EvalMasked for general posteriors: post = one list of (pdf, weight) pairs per frame.  Returns
+    (cross_entropy_sum, target_entropy_sum, correct, valid_frames); fills diff = (net_out - target) * mask."""
+    import torch
+    lib = load_library()
+    rows, cols = net_out.shape
+    assert len(post) == rows and mask.dtype == torch.float32
+    off, pdf, w = [0], [], []
+    for fr in post:
+        for p_, w_ in fr:
+            if not 0 <= p_ < cols:              # nnet-loss.cc:89-92 raises while it builds the dense matrix
+                raise KlstmError(-1, f"Posterior pdf-id out of NN-output dimension: nn-outputs {cols}, posterior pdf-id {p_}")
+            pdf.append(int(p_)); w.append(float(w_))
+        off.append(len(pdf))
+    dev = net_out.device
+    off_d = torch.tensor(off, dtype=torch.int32, device=dev)
+    pdf_d = torch.tensor(pdf or [0], dtype=torch.int32, device=dev)
+    w_d = torch.tensor(w or [0.0], dtype=torch.float32, device=dev)
+    rx = torch.empty(rows, device=dev); re_ = torch.empty(rows, device=dev); rc = torch.empty(rows, device=dev)
+    _chk(lib.klstm_xent_eval_masked_post(net_out.data_ptr(), rows, cols, net_out.stride(0), off_d.data_ptr(), pdf_d.data_ptr(),
+                                         w_d.data_ptr(), mask.data_ptr(), diff.data_ptr(), diff.stride(0), rx.data_ptr(),
+                                         re_.data_ptr(), rc.data_ptr(), _sp(stream)))
+    if stream is not None:
+        stream.synchronize()
+    else:
+        torch.cuda.synchronize()
+    return float(rx.double().sum().item()), float(re_.double().sum().item()), int(rc.sum().item()), int((mask == 1).sum().item())

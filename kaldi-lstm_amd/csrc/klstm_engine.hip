@@ -1011,6 +1011,17 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
   return KLSTM_OK;
 }
 
+klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int cols, int stride, const int *post_offsets_dev,
+                                         const int *post_pdf_dev, const float *post_weight_dev, const float *mask_dev, float *diff,
+                                         int diff_stride, float *row_xent_dev, float *row_entropy_dev, float *row_correct_dev,
+                                         void *hip_stream) {
+  if (!net_out || !post_offsets_dev || !mask_dev || !diff || !row_xent_dev || !row_entropy_dev || !row_correct_dev)
+    return fail(KLSTM_ERR_ARG, "klstm_xent_eval_masked_post: null argument");
+  if (rows > 0) HIPCHK(launch_xent_post(net_out, rows, cols, stride, post_offsets_dev, post_pdf_dev, post_weight_dev, mask_dev, diff,
+                                        diff_stride, row_xent_dev, row_entropy_dev, row_correct_dev, (hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+
 // ---- RCCL (data-parallel training over utterance streams: ONE sum-all-reduce of the gradient blob per minibatch) ----
 // libklstm.so has no link-time dependency on RCCL: the entry points are looked up in the process when the first DP call
 // arrives -- first among the symbols already loaded (a host framework may have brought its own librccl, e.g. PyTorch's

@@ -2109,6 +2109,78 @@ __global__ void k_time_shift(const float *__restrict__ in, int rows, int cols, i
   }
 }
 
+// Xent::EvalMasked for GENERAL posteriors (google/nnet/nnet-loss.cc:76-142): frame r carries the (pdf, weight) entries
+// post_pdf/post_w[post_off[r] .. post_off[r+1]); the reference scatters them into a dense zero matrix (`tgt(t, pdf) += w`,
+// so repeated pdfs add up, :86-96) and then works on dense rows.  Here the dense target never exists: one workgroup per
+// row writes diff = y*mask, then the first occurrence of every pdf fixes its column to (y - t)*mask (:102-107) and
+// contributes -mask*t*log(y) (:122-128) and -mask*t*log(t + 1e-20) (:130-136); the target's arg-max (:113) is found among
+// the entries and the implicit zeros with FindRowMaxId's lowest-index tie break.
+__global__ __launch_bounds__(256) void k_xent_post_rows(const float *__restrict__ y, int cols, int stride, const int *__restrict__ post_off,
+                                                        const int *__restrict__ post_pdf, const float *__restrict__ post_w,
+                                                        const float *__restrict__ mask, float *__restrict__ diff, int diff_stride,
+                                                        float *__restrict__ row_xent, float *__restrict__ row_ent,
+                                                        float *__restrict__ row_correct) {
+  __shared__ float smv[4];
+  __shared__ int smi[4];
+  __shared__ float s_xe[256], s_en[256], s_acc[256];
+  __shared__ int s_first[256];
+  const int row = blockIdx.x;
+  const float *yp = y + (size_t)row * stride;
+  float *dp = diff + (size_t)row * diff_stride;
+  const float m = mask[row];
+  const int e0 = post_off[row], n = post_off[row + 1] - e0;
+  float best = -3.4e38f; int bi = 0x7fffffff;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float v = yp[c];
+    dp[c] = v * m;                                   // (y - 0) * mask; columns with a target are redone below
+    if (v > best) { best = v; bi = c; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {                 // arg-max of the network output, lowest index on ties
+    const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { smv[wave] = best; smi[wave] = bi; }
+  __syncthreads();                                   // also orders the dense diff pass before the per-entry fix-up
+  float xe = 0.f, en = 0.f;
+  for (int e = threadIdx.x; e < n; e += 256) {       // (rows with more than 256 entries: the tail is handled by the loops below)
+    const int pdf = post_pdf[e0 + e];
+    float acc = 0.f; bool first = true;
+    for (int k = 0; k < n; k++)
+      if (post_pdf[e0 + k] == pdf) { acc += post_w[e0 + k]; if (k < e) first = false; }   // same order of additions as the scatter
+    if (e < 256) { s_acc[e] = acc; s_first[e] = first ? pdf : -1; }
+    if (first) {
+      const float v = yp[pdf];
+      dp[pdf] = (v - acc) * m;                       // :102-107
+      xe -= (logf(v) * acc) * m;                     // :122-128
+      en -= (logf(acc + 1e-20f) * acc) * m;          // :130-136
+    }
+  }
+  s_xe[threadIdx.x] = xe; s_en[threadIdx.x] = en;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) if (smv[w] > best || (smv[w] == best && smi[w] < bi)) { best = smv[w]; bi = smi[w]; }
+    float sx = 0.f, se = 0.f;
+    for (int t = 0; t < 256; t++) { sx += s_xe[t]; se += s_en[t]; }
+    // arg-max of the (virtual) dense target row
+    const int ne = n < 256 ? n : 256;
+    float tb = -3.4e38f; int ti = 0x7fffffff, distinct = 0;
+    for (int e = 0; e < ne; e++)
+      if (s_first[e] >= 0) { distinct++; if (s_acc[e] > tb || (s_acc[e] == tb && s_first[e] < ti)) { tb = s_acc[e]; ti = s_first[e]; } }
+    if (distinct < cols && tb <= 0.f) {              // an implicit zero is (one of) the maxima: lowest index whose value is 0
+      int z = 0;
+      for (bool again = true; again;) {
+        again = false;
+        for (int e = 0; e < ne; e++) if (s_first[e] == z && s_acc[e] != 0.f) { z++; again = true; break; }
+      }
+      if (tb < 0.f || z < ti) ti = z;
+    }
+    row_xent[row] = sx; row_ent[row] = se;
+    row_correct[row] = (m == 1.f && bi == ti) ? 1.f : 0.f;
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // output tail of the nnet: Softmax rows, Xent::EvalMasked, and the small vector ops of
 // AffineTransform::Update.  One 256-thread workgroup per frame row, lane-contiguous column sweeps.
@@ -2834,6 +2906,13 @@ hipError_t launch_xent(const float *y, int rows, int cols, int stride, const int
                     aligned16(y) && aligned16(diff);
   if (wide) KLAUNCH(k_xent_rows_v, dim3(rows), dim3(1024), st, pr, y, cols, stride, target, mask, diff, diff_stride, row_xent, row_correct);
   KLAUNCH(k_xent_rows, dim3(rows), dim3(256), st, pr, y, cols, stride, target, mask, diff, diff_stride, row_xent, row_correct);
+}
+hipError_t launch_xent_post(const float *y, int rows, int cols, int stride, const int *post_off, const int *post_pdf, const float *post_w,
+                            const float *mask, float *diff, int diff_stride, float *row_xent, float *row_ent, float *row_correct,
+                            hipStream_t st) {
+  LaunchProbe pr;
+  KLAUNCH(k_xent_post_rows, dim3(rows), dim3(256), st, pr, y, cols, stride, post_off, post_pdf, post_w, mask, diff, diff_stride, row_xent,
+          row_ent, row_correct);
 }
 hipError_t launch_col_sum(const float *src, int rows, int cols, int stride, float beta, float *dst, hipStream_t st) {
   LaunchProbe pr;

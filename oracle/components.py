@@ -115,3 +115,22 @@ def xent_eval_masked(net_out, target, frame_mask):
     cross_entropy = float(-np.sum(np.log(net_out) * t * frame_mask[:, None]))           # :122-128
     entropy = float(-np.sum(np.log(t + 1e-20) * t * frame_mask[:, None]))               # :130-136
     return diff, cross_entropy, entropy, correct, int(frame_mask.sum())
+
+
+def xent_eval_masked_post(net_out, post, frame_mask):
+    """Xent::EvalMasked, /root/reference/google/nnet/nnet-loss.cc:76-142, for GENERAL posteriors: post[t] = list of
+    (pdf, weight).  Dense restatement, statement by statement.  Returns diff, cross_entropy, entropy, correct, valid_frames."""
+    n, d = net_out.shape
+    assert n == len(post)                                    # :82
+    t = np.zeros((n, d), net_out.dtype)                      # :85 zero-filled
+    for fr in range(n):                                      # :86-96
+        for pdf, w in post[fr]:
+            if pdf >= d:
+                raise ValueError("Posterior pdf-id out of NN-output dimension")
+            t[fr, pdf] += net_out.dtype.type(w)
+    diff = (net_out - t) * frame_mask[:, None]               # :102-107
+    correct = int(np.sum((frame_mask == 1) & (net_out.argmax(1) == t.argmax(1))))      # :109-120 (FindRowMaxId: first maximum)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cross_entropy = float(-np.sum(np.log(net_out) * t * frame_mask[:, None], dtype=np.float64))          # :122-128
+        entropy = float(-np.sum(np.log(t + net_out.dtype.type(1e-20)) * t * frame_mask[:, None], dtype=np.float64))   # :130-136
+    return diff, cross_entropy, entropy, correct, int(frame_mask.sum())

@@ -470,6 +470,47 @@ def test_affine_softmax_xent_tail(N, K, M):
     assert np.all(diff.cpu().numpy()[mask == 0] == 0.0)         # masked frames give exactly zero diff (:107)
 
 
+@pytest.mark.parametrize("N,M", [(12, 37), (80, 4203), (24, 16624)])
+def test_xent_eval_masked_general_posteriors(N, M):
+    """Xent::EvalMasked with the reference's Posterior argument (nnet-loss.cc:76-142): several weighted pdfs per frame,
+    repeated pdfs (they add up, :95), empty frames, frames whose weights do not sum to one, masked frames; against the
+    dense statement-by-statement restatement.  diff: 2e-6 of its maximum (same two operations per element); cross entropy
+    and target entropy 1e-5 relative (fp32 row sums); frame counts exact, including the arg-max tie rules (an empty frame's
+    target arg-max is index 0)."""
+    import kaldi_lstm_amd as k
+    from oracle import components as oc
+    rng = np.random.RandomState(N + M)
+    a = rng.randn(N, M).astype(np.float32)
+    y = oc.softmax(a)
+    y[3, :] = 1.0 / M; y[3, 0] = 2.0 / M                   # frame 3: network arg-max is index 0 ...
+    mask = (rng.rand(N) > 0.25).astype(np.float32); mask[3] = 1.0
+    post = []
+    for t in range(N):
+        n = rng.randint(1, 5)
+        pdfs = rng.randint(0, M, n)
+        w = rng.rand(n).astype(np.float32); w /= w.sum()
+        post.append([(int(p), float(x)) for p, x in zip(pdfs, w)])
+    post[1] = [(5, 0.25), (7, 0.5), (5, 0.25)]             # repeated pdf: 0.5 vs 0.5 -> arg-max tie, lowest index wins
+    post[2] = [(M - 1, 0.3)]                               # does not sum to one
+    post[3] = []                                           # ... and an empty frame's target arg-max is index 0 too: "correct"
+    yd = dev(y); diff = torch.empty(N, M, device="cuda"); md = dev(mask)
+    torch.cuda.synchronize()
+    xe, ent, correct, valid = k.xent_eval_masked_post(yd, post, md, diff)
+    diff_o, xe_o, ent_o, correct_o, valid_o = oc.xent_eval_masked_post(y, post, mask)
+    assert relerr(diff.cpu().numpy(), diff_o) <= 2e-6
+    assert abs(xe - xe_o) <= 1e-5 * abs(xe_o) and abs(ent - ent_o) <= 1e-5 * max(abs(ent_o), 1e-3)
+    assert (correct, valid) == (correct_o, valid_o)
+    assert np.all(diff.cpu().numpy()[mask == 0] == 0.0)
+    # one-hot posteriors reproduce the one-hot entry point
+    tg = rng.randint(0, M, N).astype(np.int32)
+    d2 = torch.empty(N, M, device="cuda")
+    xe1, c1, v1 = k.xent_eval_masked(yd, torch.from_numpy(tg).cuda(), md, d2)
+    xe2, ent2, c2, v2 = k.xent_eval_masked_post(yd, [[(int(t), 1.0)] for t in tg], md, diff)
+    assert torch.equal(d2, diff) and abs(xe1 - xe2) <= 1e-6 * abs(xe1) and abs(ent2) <= 1e-12 and (c1, v1) == (c2, v2)
+    with pytest.raises(k.KlstmError):
+        k.xent_eval_masked_post(yd, [[(M, 1.0)]] * N, md, diff)           # pdf-id out of range (:89-92)
+
+
 @pytest.mark.parametrize("I,C,R,S", [
     (512, 800, 512, 4),      # BASELINE.json configs[3] second layer (40->512->512, cell 800), 32 streams over 8 GPUs = 4 per GPU
     (512, 1024, 512, 32),    # configs[4] inner layers (cell 1024 / proj 512), 256 streams over 8 GPUs = 32 per GPU

@@ -185,3 +185,23 @@ def test_momentum_and_update():
     o.update(1e-3, clip_grad=50.0)
     c = o.get_corr()
     assert c.max() <= 50.0 and c.min() >= -50.0
+
+
+def test_eval_masked_posterior_restatement():
+    """oracle/components.py: the general-posterior restatement of Xent::EvalMasked (nnet-loss.cc:76-142) reduces to the
+    one-hot one, repeated pdfs add up (:95), the target entropy of a soft posterior is -sum t log t, and an empty frame has
+    target arg-max 0 (FindRowMaxId on an all-zero row)."""
+    from oracle import components as oc
+    rng = np.random.RandomState(0)
+    y = oc.softmax(rng.randn(6, 11).astype(np.float32))
+    tg = rng.randint(0, 11, 6); m = (rng.rand(6) > 0.3).astype(np.float32)
+    a = oc.xent_eval_masked(y, tg, m)
+    b = oc.xent_eval_masked_post(y, [[(int(t), 1.0)] for t in tg], m)
+    assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    post = [[(2, 0.25), (4, 0.5), (2, 0.25)]] + [[] for _ in range(5)]
+    m1 = np.ones(6, np.float32)
+    d, xe, ent, correct, valid = oc.xent_eval_masked_post(y, post, m1)
+    assert np.isclose(d[0, 2], y[0, 2] - 0.5) and np.isclose(d[0, 4], y[0, 4] - 0.5)
+    assert np.isclose(ent, -2 * 0.5 * np.log(0.5), rtol=1e-6)
+    assert np.isclose(xe, -0.5 * (np.log(y[0, 2]) + np.log(y[0, 4])), rtol=1e-6)
+    assert correct == int(y[0].argmax() == 2) + int(sum(y[r].argmax() == 0 for r in range(1, 6))) and valid == 6
