@@ -4,8 +4,11 @@ committed under profiles/): kernel stats CSV, the PMC CSVs, and <tag>_pmc_traffi
     in KB; on gfx950 FETCH_SIZE reports half of wide coalesced reads),
   * hbm_bytes_per_minibatch = sum over ALL dispatches of the run / number of minibatches (= launches of k_grads: exactly
     one per minibatch) -- bench.py divides it by SURVEY 8(d)'s algorithmic bytes for `roofline.traffic_ratio`,
-  * mfma_busy_frac per kernel = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs) (the gfx94x MfmaUtil
-    formula; ROCm 7.2 has no gfx950 derived-counter section)."""
+  * mfma_busy_frac per kernel = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs): the gfx94x MfmaUtil formula
+    reduce(SQ_VALU_MFMA_BUSY_CYCLES,sum) / (reduce(GRBM_GUI_ACTIVE,max) * SIMD_NUM) (counter_defs.yaml; ROCm 7.2 has no gfx950
+    derived-counter section).  rocprofv3's CSV carries the SUM of GRBM_GUI_ACTIVE over its 8 XCC instances, which are all
+    active for the whole dispatch, so max = sum/8.  Cross-check: the fold product's 2.62 GFLOP are 1.28 M 16x16x4 MFMAs of
+    32 cycles = 41 M busy cycles, the counter reads 42.6 M."""
 import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
@@ -50,7 +53,7 @@ for name, c in agg.items():
                   "launches": len(c["FETCH_SIZE"])}
     total_bytes += (2 * sum(c["FETCH_SIZE"]) + sum(c["WRITE_SIZE"])) * 1024      # both passes run the same dispatches
     if c["SQ_VALU_MFMA_BUSY_CYCLES"] and c["GRBM_GUI_ACTIVE"]:
-        kern[name]["mfma_busy_frac"] = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(c["GRBM_GUI_ACTIVE"]) * 256 * 4)
+        kern[name]["mfma_busy_frac"] = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(c["GRBM_GUI_ACTIVE"]) / 8 * 1024)
         kern[name]["sq_busy_cycles_per_launch"] = sum(c["SQ_BUSY_CYCLES"]) / max(1, len(c["SQ_BUSY_CYCLES"]))
 nmb = kern.get("k_grads", {}).get("launches", 0)
 m = re.search(r"--streams-per-gpu[ =](\d+)", cmd)
