@@ -214,7 +214,7 @@ static bool fold_wanted(const klstm_engine *e, int T) {
   return e->use_fold == 1 ? T >= 2 : (T >= 12 && e->S <= 8);
 }
 static bool use_fused_x(const klstm_engine *e);
-// persistent chain: needs the folded operands, the x term inside the step, at most 8 streams; auto = on from 8 frames
+// persistent chain: needs the folded operands, the x term inside the step, at most 4 streams; auto = on from 3 frames
 // per stream (the forward launch covers steps 2..T)
 static bool persist_wanted(const klstm_engine *e, int T) {
   if (e->use_persist == 0 || e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || !use_fused_x(e)) return false;
@@ -842,12 +842,11 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     return KLSTM_OK;
   }
   if (!strcmp(key, "persist") || !strcmp(key, "persist_tpw") || !strcmp(key, "persist_waves") || !strcmp(key, "persist_nap0") ||
-      !strcmp(key, "persist_nap") || !strcmp(key, "persist_ng")) {
+      !strcmp(key, "persist_nap")) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
     if (!strcmp(key, "persist")) e->use_persist = value;
     else if (!strcmp(key, "persist_tpw")) set_persist_tpw(value);         // process-wide tuning knobs (A-B experiments)
-    else if (!strcmp(key, "persist_ng")) set_persist_ng(value);
     else if (!strcmp(key, "persist_nap0")) set_persist_nap(value, -2);
     else if (!strcmp(key, "persist_nap")) set_persist_nap(-2, value);
     else set_persist_waves(value);

@@ -134,7 +134,7 @@ hipError_t launch_axpy(float *y, const float *x, float a, long n, hipStream_t st
 hipError_t launch_sgd_momentum(float *param, float *corr, const float *grad, float mmt, float lr, long n, hipStream_t st);
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {});
 
-// Weights-resident persistent chain (klstm_persist.hip; NumStream <= 8, folded recurrence, x term fused): ONE launch runs
+// Weights-resident persistent chain (klstm_persist.hip; NumStream <= 4, folded recurrence, x term fused): ONE launch runs
 // forward steps 2..T (step 1 stays with launch_gates_step: it closes over the carried r) / backward steps T..1 with the
 // packed fold operands held in registers and the per-step all-to-all done inside the launch through data-tagged granules.
 //   gran: persist_gran_bytes(d) of device memory, zero-filled once;  ctrl: 3 words {epoch, finished workgroups, status},
@@ -146,7 +146,6 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, unsigned long long *gran, unsigned *ctrl,
                               hipStream_t st, LaunchProbe pr = {});
 void set_persist_tpw(int v);    // A-B knob: tiles (of 4 cells) per workgroup, 0 = automatic
-void set_persist_ng(int v);     // A-B knob: stream groups of the persistent chain (1 or 2), 0 = automatic
 void set_persist_waves(int v);  // A-B knob: waves per workgroup (8, 12 or 16), 0 = automatic
 void set_persist_nap(int nap0, int nap);   // A-B knobs: sweeper sleep before the first pass (x256 clocks) / between passes (x64); -1 = default, -2 = keep
 

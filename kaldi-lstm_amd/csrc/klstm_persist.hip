@@ -29,13 +29,6 @@
 // before the sweep): S x C granules per step instead of S x 4C, and the replicas are bit-identical (same instruction
 // sequence on the same inputs).  The owner of a cell writes its dgifo / dc rows for the gradient products.
 //
-// Stream groups (NG = 1 or 2): the streams of a minibatch are independent, so two groups of up to 4 streams run as a
-// software pipeline -- half-step (t, g) sweeps what group g published a whole half-step earlier while the other group
-// computes: the exchange latency of one group hides behind the work of the other.  NumStream 5..8 always runs two groups
-// (a full step of 8 streams costs what 4 streams cost); the backward chain splits 4 streams 2 + 2 as well (its replicated
-// elementwise pass halves per half-step and overlaps the other group's contraction).  Each group has its own granule
-// slots and its own operand slab.
-//
 // Geometry = the 4x4x1_16b forms of klstm_kernels.hip (same packed operands, written by the fold product):
 //   forward : tile = 4 cells x 4 gates (16 rows), chunk = 32 k, lane l feeds A row l&15 / k-group l>>4, B stream l&3
 //   backward: tile = 4 cells (4 rows), chunk = 128 k, block b = k-group, A lane 4b+i = row i, B lane 4b+j = stream j
@@ -180,29 +173,28 @@ __device__ __forceinline__ void finish(unsigned *ctrl, unsigned epoch, int T) {
 // all in that wave.  ONE workgroup barrier per step (slab ready).  The remaining waves sweep, one cell per thread.
 // The weights come from the 16-row packed operand of the launch-per-step kernels, gathered once at kernel start.
 // -------------------------------------------------------------------------------------------------------------------
-template <int TPW, int MAXC, int PNW, int PCELL, int NG>
+template <int TPW, int MAXC, int PNW, int PCELL>
 __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
   constexpr int PNT = PNW * 64, NCW = 4 * TPW, NSW = (PNW - NCW) * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C, S = a.S, T = a.T, I = a.I, nch = a.nch;
-  const int SG = (S + NG - 1) / NG;                  // streams per group (<= 4)
   const int n128 = (nch * KCH + 127) / 128;          // 128-wide chunks over the padded K of the packed operand (<= MAXC)
   constexpr int LDB = MAXC * 128 + 16;               // (LDB mod 64 == 16: the 16-lane groups of ds_read_b128 hit 16 distinct slots)
-  float *ldsB = lds;                                 // [NG][4][LDB]: row s = [ m(t-1)[s][0..C) | pad | x(t)[s][0..I) | pad ]
-  unsigned *abortf = reinterpret_cast<unsigned *>(lds + NG * 4 * LDB);
+  float *ldsB = lds;                                 // [4][LDB]: row s = [ m(t-1)[s][0..C) | pad | x(t)[s][0..I) | pad ]
+  unsigned *abortf = reinterpret_cast<unsigned *>(lds + 4 * LDB);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long t_start = wall_clock64();
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // zero the B slabs once: pad columns and rows of absent streams stay zero for the whole launch
-  for (int i = tid; i < NG * 4 * LDB; i += PNT) ldsB[i] = 0.f;
+  // zero the B slab once: pad columns and rows of absent streams stay zero for the whole launch
+  for (int i = tid; i < 4 * LDB; i += PNT) ldsB[i] = 0.f;
   if (tid == 0) *abortf = 0u;
   __syncthreads();
   PT_DECL();
 
-  // The two roles run SEPARATE loops with the same barrier sequence (one lds_barrier per half-step, an abort check behind
-  // it): inside one loop body the register allocator keeps the resident weights of the cell waves AND the sweep state of
-  // the sweepers alive in every wave.
+  // The two roles run SEPARATE loops with the same barrier sequence (one lds_barrier per step, an abort check behind it):
+  // inside one loop body the register allocator keeps the resident weights of the cell waves AND the sweep state of the
+  // sweepers alive in every wave.
   if (wave < NCW) {
     // =========================== cell wave: cell (wave & 3) of tile (wave >> 2) ===========================
     const int tile = blockIdx.x * TPW + (wave >> 2), cw = wave & 3;
@@ -225,75 +217,66 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       }
       a0[i] = w[0]; a1[i] = w[1];
     }
-    // epilogue lanes: lanes 12..15 = streams 0..3 of the group (where kgroup_sum leaves the totals)
+    // epilogue lanes: lanes 12..15 = streams 0..3 of the cell (where kgroup_sum leaves the totals)
     const int e_cell = tile * 4 + cw, es = lane & 3;
-    const bool e_lane = (lane >> 2) == 3 && e_cell < C;
-    const int lc = e_cell < C ? e_cell : 0;
+    const bool e_on = (lane >> 2) == 3 && es < S && e_cell < C;
+    const int lc = e_cell < C ? e_cell : 0, ls = e_on ? es : 0;
     const float pre0 = a.bias[lc], pre1 = a.bias[C + lc], pre2 = a.bias[2 * C + lc], pre3 = a.bias[3 * C + lc];
     const float wpi = a.pi[lc], wpf = a.pf[lc], wpo = a.po[lc];
-    float cp[NG];
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-      const int sg = g * SG + es;                    // global stream of this lane in group g
-      cp[g] = a.cc[((size_t)1 * S + ((e_lane && es < SG && sg < S) ? sg : 0)) * C + lc];   // c(1), written by the step-1 kernel
-    }
+    float cp = a.cc[((size_t)1 * S + ls) * C + lc];                  // c(1), written by the step-1 kernel
     for (int t = 2; t <= T; t++) {
-#pragma unroll
-      for (int g = 0; g < NG; g++) {
-        PT_MARK(5);
-        lds_barrier();                               // slab of half-step (t, g) ready
-        PT_MARK(1);
-        if (*abortf) goto done;                      // (plain LDS read: the asm barrier's memory clobber forces the reload; a volatile
+      PT_MARK(5);
+      lds_barrier();                                 // slab of step t ready
+      PT_MARK(1);
+      if (*abortf) break;                            // (plain LDS read: the asm barrier's memory clobber forces the reload; a volatile
                                                      //  read through the generic pointer became a FLAT load behind vmcnt(0))
-        // gates of this wave's cell: contraction over [m(t-1) | x(t)] with the resident rows.  Exactly MAXC chunks, no
-        // branch: chunks beyond the operand have zero weights and read zero slab columns, so every LDS read of the step
-        // is issued before the first MFMA.
-        float4 b0[MAXC], b1[MAXC];
+      // gates of this wave's cell: contraction over [m(t-1) | x(t)] with the resident rows.  Exactly MAXC chunks, no
+      // branch: chunks beyond the operand have zero weights and read zero slab columns, so every LDS read of the step
+      // is issued before the first MFMA.
+      float4 b0[MAXC], b1[MAXC];
 #pragma unroll
-        for (int i = 0; i < MAXC; i++) {
-          const float *bp = ldsB + (g * 4 + bj) * LDB + i * 128 + kg * 4;
-          b0[i] = *reinterpret_cast<const float4 *>(bp); b1[i] = *reinterpret_cast<const float4 *>(bp + 64);
-        }
-        __builtin_amdgcn_sched_barrier(0);           // (otherwise the scheduler sinks every read next to its MFMAs: 14 LDS round trips in a row)
-        f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-        for (int i = 0; i < MAXC; i++) {
-          const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
-          const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
-#pragma unroll
-          for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
-        }
-        const f32x4 v = kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));   // the 16 k-groups of a (gate, stream) pair
-        PT_MARK(2);                                  // contraction + k-group sum
-        const int sgl = g * SG + es;                 // global stream
-        if (e_lane && es < SG && sgl < S) {
-          const size_t e_row = (size_t)t * S + sgl;
-          float ag = v.x + pre0;
-          float ai = v.y + pre1;
-          float af = v.z + pre2;
-          float ao = v.w + pre3;
-          ai += wpi * cp[g];                         // :278
-          af += wpf * cp[g];                         // :281
-          const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
-          float c = gg * gi;                         // :291
-          c = c + cp[g] * gf;                        // :294
-          c = c < -50.f ? -50.f : c;                 // :296
-          c = c > 50.f ? 50.f : c;                   // :297
-          const float h = k_tanh(c);                 // :300
-          ao += wpo * c;                             // :303
-          const float go = k_sigmoid(ao);            // :306
-          const float m = h * go;                    // :309
-          if (t < T) publish(a.gran + (size_t)(g * 2 + (t & 1)) * C * 4, e_cell * 4 + es, epoch + (unsigned)t, m);
-          float *gp = a.gifo + e_row * 4 * C + e_cell;
-          gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
-          a.cc[e_row * C + e_cell] = c;
-          a.hh[e_row * C + e_cell] = h;
-          a.mm[e_row * C + e_cell] = m;
-          if (t == T) a.c_save[(size_t)sgl * C + e_cell] = c;    // :331 (c columns)
-          cp[g] = c;
-        }
-        PT_MARK(4);                                  // cell math + stores
+      for (int i = 0; i < MAXC; i++) {
+        const float *bp = ldsB + bj * LDB + i * 128 + kg * 4;
+        b0[i] = *reinterpret_cast<const float4 *>(bp); b1[i] = *reinterpret_cast<const float4 *>(bp + 64);
       }
+      __builtin_amdgcn_sched_barrier(0);             // (otherwise the scheduler sinks every read next to its MFMAs: 14 LDS round trips in a row)
+      f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
+        const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
+      }
+      const f32x4 v = kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));   // the 16 k-groups of a (gate, stream) pair
+      PT_MARK(2);                                    // contraction + k-group sum
+      if (e_on) {
+        const size_t e_row = (size_t)t * S + es;
+        float ag = v.x + pre0;
+        float ai = v.y + pre1;
+        float af = v.z + pre2;
+        float ao = v.w + pre3;
+        ai += wpi * cp;                              // :278
+        af += wpf * cp;                              // :281
+        const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
+        float c = gg * gi;                           // :291
+        c = c + cp * gf;                             // :294
+        c = c < -50.f ? -50.f : c;                   // :296
+        c = c > 50.f ? 50.f : c;                     // :297
+        const float h = k_tanh(c);                   // :300
+        ao += wpo * c;                               // :303
+        const float go = k_sigmoid(ao);              // :306
+        const float m = h * go;                      // :309
+        if (t < T) publish(a.gran + (size_t)(t & 1) * C * 4, e_cell * 4 + es, epoch + (unsigned)t, m);
+        float *gp = a.gifo + e_row * 4 * C + e_cell;
+        gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
+        a.cc[e_row * C + e_cell] = c;
+        a.hh[e_row * C + e_cell] = h;
+        a.mm[e_row * C + e_cell] = m;
+        if (t == T) a.c_save[(size_t)es * C + e_cell] = c;       // :331 (c columns)
+        cp = c;
+      }
+      PT_MARK(4);                                    // cell math + stores
     }
   } else {
     // =========================== sweeper: m(t-1) of every cell and x(t) into the slab ===========================
@@ -302,43 +285,37 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
 #pragma unroll
     for (int j = 0; j < PCELL; j++) cell[j] = sidx + j * NSW;
     const int nx4 = I / 4;                           // float4 per x row; the first sweeper wave also stages x(t)
+    const bool x_on = sidx < S * nx4;
+    const int xs = x_on ? sidx / nx4 : 0, xk = x_on ? (sidx % nx4) * 4 : 0;
     for (int t = 2; t <= T; t++) {
-#pragma unroll
-      for (int g = 0; g < NG; g++) {
-        PT_MARK(5);
-        const int s0 = g * SG, ns = (S - s0) < SG ? (S - s0) : SG;       // this group's streams
-        const bool x_on = sidx < ns * nx4;
-        const int xs = x_on ? sidx / nx4 : 0, xk = x_on ? (sidx % nx4) * 4 : 0;
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (x_on) xv = *reinterpret_cast<const float4 *>(a.x + ((size_t)(t - 1) * S + s0 + xs) * a.x_stride + xk);
-        float mv[PCELL][4];
-        if (t == 2) {
-#pragma unroll
-          for (int j = 0; j < PCELL; j++)
-#pragma unroll
-            for (int s = 0; s < 4; s++) mv[j][s] = (cell[j] < C && s < ns) ? a.mm[((size_t)1 * S + s0 + s) * C + cell[j]] : 0.f;
-        } else if (!sweep_cells(a.gran + (size_t)(g * 2 + ((t - 1) & 1)) * C * 4, C, ns, epoch + (unsigned)(t - 1), cell, mv, t_start,
-                                NG == 1 ? a.nap0 : 0, a.nap)) {
-          *abortf = 1u;
-          if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
-        }
-        // (the slab is free: the sweep only completes once every cell wave of THIS workgroup has published (t-1, g),
-        //  i.e. has finished reading the previous contents of slab g)
+      PT_MARK(5);
+      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x_on) xv = *reinterpret_cast<const float4 *>(a.x + ((size_t)(t - 1) * S + xs) * a.x_stride + xk);
+      float mv[PCELL][4];
+      if (t == 2) {
 #pragma unroll
         for (int j = 0; j < PCELL; j++)
-          if (cell[j] < C) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) if (s < ns) ldsB[(g * 4 + s) * LDB + cell[j]] = mv[j][s];
-          }
-        if (x_on) *reinterpret_cast<float4 *>(ldsB + (g * 4 + xs) * LDB + a.nchm * KCH + xk) = xv;
-        PT_MARK(0);                                  // sweep + slab store
-        lds_barrier();
-        PT_MARK(1);
-        if (*abortf) goto done;
+          for (int s = 0; s < 4; s++) mv[j][s] = (cell[j] < C && s < S) ? a.mm[((size_t)1 * S + s) * C + cell[j]] : 0.f;
+      } else if (!sweep_cells(a.gran + (size_t)((t - 1) & 1) * C * 4, C, S, epoch + (unsigned)(t - 1), cell, mv, t_start, a.nap0, a.nap)) {
+        *abortf = 1u;
+        if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
       }
+      // (the slab is free: the sweep only completes once every cell wave of THIS workgroup has published step t-1,
+      //  i.e. has finished reading the previous slab)
+#pragma unroll
+      for (int j = 0; j < PCELL; j++)
+        if (cell[j] < C) {
+#pragma unroll
+          for (int s = 0; s < 4; s++) if (s < S) ldsB[s * LDB + cell[j]] = mv[j][s];
+        }
+      if (x_on) *reinterpret_cast<float4 *>(ldsB + xs * LDB + a.nchm * KCH + xk) = xv;
+      PT_MARK(0);                                    // sweep + slab store
+      lds_barrier();
+      PT_MARK(1);
+      if (*abortf) break;
     }
   }
-done:
   PT_FLUSH(0);
   finish(a.ctrl, epoch, T);
 }
@@ -371,26 +348,24 @@ __device__ __forceinline__ float4 bptt_cell(float dm, float yg, float yi, float 
   return make_float4(o_g, o_i, o_f, d_o);
 }
 
-template <int TPW, int MAXC, int PNW, int PCELL, int NG>
+template <int TPW, int MAXC, int PNW, int PCELL>
 __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
   constexpr int PNT = PNW * 64, NKW = 4 * TPW, NSW = (PNW - NKW) * 64;
   constexpr int LDD = 4 * MAXC * 128 + 16;           // (LDD mod 64 == 16: the 16-lane groups of ds_read_b128 hit 16 distinct slots)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C, S = a.S, T = a.T, nch = a.nch, K = 4 * a.C;
-  const int SG = (S + NG - 1) / NG;                  // streams per group (<= 4)
-  float *ldsD = lds;                                 // [NG][4][LDD]: dgifo(t) rows of a group, natural g|i|f|o order; columns >= 4C stay zero
-  f32x4 *red = reinterpret_cast<f32x4 *>(lds + NG * 4 * LDD);      // [NKW][4]
+  float *ldsD = lds;                                 // [4][LDD]: dgifo(t) rows, natural g|i|f|o order; columns >= 4C stay zero
+  f32x4 *red = reinterpret_cast<f32x4 *>(lds + 4 * LDD);      // [NKW][4]
   unsigned *abortf = reinterpret_cast<unsigned *>(red + NKW * 4);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long t_start = wall_clock64();
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int i = tid; i < NG * 4 * LDD; i += PNT) ldsD[i] = 0.f;
+  for (int i = tid; i < 4 * LDD; i += PNT) ldsD[i] = 0.f;
   if (tid == 0) *abortf = 0u;
   __syncthreads();
-  PT_DECL();
 
-  // separate loops per role, same barrier sequence (two lds_barriers per half-step, the abort check behind the first): see k_fwd_persist
+  // separate loops per role, same barrier sequence (two lds_barriers per step, the abort check behind the first): see k_fwd_persist
   if (wave < NKW) {
     // =========================== K wave: quarter (wave & 3) of K for tile (wave >> 2) ===========================
     const int tl = wave >> 2, kw = wave & 3;
@@ -406,52 +381,50 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
       a0[i] = ap[0]; a1[i] = ap[64];
       if (!on) { a0[i] = make_float4(0.f, 0.f, 0.f, 0.f); a1[i] = a0[i]; }
     }
-    // epilogue lanes of the owner wave: lanes 0..15 = (cell 4*tile + lane/4, stream lane%4 of the group) receive d_m(t-1) of that pair
+    // epilogue lanes of the owner wave: lanes 0..15 = (cell 4*tile + lane/4, stream lane%4) receive d_m(t-1) of that pair
     const int e_i = (lane >> 2) & 3, e_j = lane & 3;
     const int e_cell = tile * 4 + e_i;
-    const bool e_lane = owner_wave && lane < 16 && e_cell < C;
+    const bool e_on = owner_wave && lane < 16 && e_j < S && e_cell < C;
     const __amdgpu_buffer_rsrc_t rs_p = buf_rsrc(a.P, T * S * C * 4);
+    const int e_offc = e_on ? (e_j * C + e_cell) * 4 : 0;
+    PT_DECL();
     for (int t = T; t > 1; t--) {
+      PT_MARK(5);
+      // P(t-1) for the epilogue: requested now, consumed after the contraction (frame t-1 is row block t-2 of P)
+      const float pnext = owner_wave ? buf_f32(rs_p, e_offc, (t - 2) * S * C * 4) : 0.f;
+      lds_barrier();                                 // slab dgifo(t) ready
+      PT_MARK(1);
+      if (*abortf) break;
+      float4 b0[MAXC], b1[MAXC];
 #pragma unroll
-      for (int g = 0; g < NG; g++) {
-        PT_MARK(5);
-        const int sgl = g * SG + e_j;                // global stream of this epilogue lane
-        const bool e_on = e_lane && e_j < SG && sgl < S;
-        // P(t-1) for the epilogue: requested now, consumed after the contraction (frame t-1 is row block t-2 of P)
-        const float pnext = owner_wave ? buf_f32(rs_p, e_on ? (sgl * C + e_cell) * 4 : 0, (t - 2) * S * C * 4) : 0.f;
-        lds_barrier();                               // slab dgifo(t, g) ready
-        PT_MARK(1);
-        if (*abortf) goto done;
-        float4 b0[MAXC], b1[MAXC];
-#pragma unroll
-        for (int i = 0; i < MAXC; i++) {
-          const float *bp = ldsD + (g * 4 + bj) * LDD + (kw + 4 * i) * 128 + kg * 4;
-          b0[i] = *reinterpret_cast<const float4 *>(bp); b1[i] = *reinterpret_cast<const float4 *>(bp + 64);
-        }
-        __builtin_amdgcn_sched_barrier(0);           // every LDS read of the step in flight before the first MFMA
-        f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-        for (int i = 0; i < MAXC; i++) {
-          const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
-          const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
-#pragma unroll
-          for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
-        }
-        const f32x4 v = kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
-        if ((lane >> 2) == 3) red[wave * 4 + (lane & 3)] = v;   // lanes 12..15: streams 0..3, components = the tile's 4 cells
-        PT_MARK(2);
-        lds_barrier();                               // partial tiles ready
-        PT_MARK(3);
-        if (owner_wave) {
-          // row (cell) e_i of stream e_j: component e_i of red[4*tl + w][e_j], the four K quarters in fixed order
-          const float *rp = reinterpret_cast<const float *>(red) + ((tl * 4) * 4 + e_j) * 4 + e_i;
-          const float sum = ((rp[0] + rp[16]) + rp[32]) + rp[48];
-          const float dmv = sum + pnext;             // :408 with :391 substituted: d_m(t-1) = contraction + P(t-1)
-          if (e_on) publish(a.gran + (size_t)(g * 2 + ((t - 1) & 1)) * C * 4, e_cell * 4 + e_j, epoch + (unsigned)(t - 1), dmv);
-        }
-        PT_MARK(4);
+      for (int i = 0; i < MAXC; i++) {
+        const float *bp = ldsD + bj * LDD + (kw + 4 * i) * 128 + kg * 4;
+        b0[i] = *reinterpret_cast<const float4 *>(bp); b1[i] = *reinterpret_cast<const float4 *>(bp + 64);
       }
+      __builtin_amdgcn_sched_barrier(0);             // every LDS read of the step in flight before the first MFMA
+      f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
+        const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
+      }
+      const f32x4 v = kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      if ((lane >> 2) == 3) red[wave * 4 + (lane & 3)] = v;   // lanes 12..15: streams 0..3, components = the tile's 4 cells
+      PT_MARK(2);
+      lds_barrier();                                 // partial tiles ready
+      PT_MARK(3);
+      if (owner_wave) {
+        // row (cell) e_i of stream e_j: component e_i of red[4*tl + w][e_j], the four K quarters in fixed order
+        const float *rp = reinterpret_cast<const float *>(red) + ((tl * 4) * 4 + e_j) * 4 + e_i;
+        const float sum = ((rp[0] + rp[16]) + rp[32]) + rp[48];
+        const float dmv = sum + pnext;               // :408 with :391 substituted: d_m(t-1) = contraction + P(t-1)
+        if (e_on) publish(a.gran + (size_t)((t - 1) & 1) * C * 4, e_cell * 4 + e_j, epoch + (unsigned)(t - 1), dmv);
+      }
+      PT_MARK(4);
     }
+    PT_FLUSH(0);
   } else {
     // =========================== sweeper: d_m(t) of every cell -> dgifo(t) into the slab ===========================
     // forward planes through buffer descriptors: the lane offset is cell*4 bytes, frame / stream / gate go into the scalar
@@ -462,7 +435,7 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
     bool mine[PCELL];                                // the cell belongs to this workgroup's tiles: this thread writes its plane rows
     float wpi[PCELL], wpf[PCELL], wpo[PCELL];
     int voff[PCELL];
-    BpttCarry kk[NG][PCELL][4];
+    BpttCarry kk[PCELL][4];
 #pragma unroll
     for (int j = 0; j < PCELL; j++) {
       cell[j] = (wave - NKW) * 64 + lane + j * NSW;
@@ -471,9 +444,7 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
       wpi[j] = a.pi[lc]; wpf[j] = a.pf[lc]; wpo[j] = a.po[lc];
       voff[j] = lc * 4;
 #pragma unroll
-      for (int g = 0; g < NG; g++)
-#pragma unroll
-        for (int s = 0; s < 4; s++) kk[g][j][s] = BpttCarry{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < 4; s++) kk[j][s] = BpttCarry{0.f, 0.f, 0.f, 0.f};
       if (mine[j]) {                                 // the batched d_r product reads dgifo(T+1) as operand rows: keep them zero (:351)
         for (int s = 0; s < S; s++) {
           float *zp = a.dgifo + ((size_t)(T + 1) * S + s) * K + cell[j];
@@ -481,64 +452,60 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
         }
       }
     }
+    PT_DECL();
     for (int t = T; t >= 1; t--) {
+      PT_MARK(5);
+      const int sg = t * S * K * 4, sc = t * S * C * 4;
+      // planes of frame t for this thread's cells: requested before the sweep (L2-resident; every workgroup reads the same rows)
+      float yg[PCELL][4], yi[PCELL][4], yf[PCELL][4], yo[PCELL][4], yh[PCELL][4], cpv[PCELL][4], dm[PCELL][4];
 #pragma unroll
-      for (int g = 0; g < NG; g++) {
-        PT_MARK(5);
-        const int s0 = g * SG, ns = (S - s0) < SG ? (S - s0) : SG;       // this group's streams
-        const int sg = (t * S + s0) * K * 4, sc = (t * S + s0) * C * 4;
-        // planes of frame t for this thread's cells: requested before the sweep (L2-resident; every workgroup reads the same rows)
-        float yg[PCELL][4], yi[PCELL][4], yf[PCELL][4], yo[PCELL][4], yh[PCELL][4], cpv[PCELL][4], dm[PCELL][4];
+      for (int j = 0; j < PCELL; j++)
 #pragma unroll
-        for (int j = 0; j < PCELL; j++)
-#pragma unroll
-          for (int s = 0; s < 4; s++) {
-            const int ss = s < ns ? s : 0;           // absent streams re-read stream 0 of the group (their results are never stored)
-            const int og = sg + ss * K * 4, oc = sc + ss * C * 4;
-            yg[j][s] = buf_f32(rs_g, voff[j], og); yi[j][s] = buf_f32(rs_g, voff[j], og + C * 4);
-            yf[j][s] = buf_f32(rs_g, voff[j], og + 2 * C * 4); yo[j][s] = buf_f32(rs_g, voff[j], og + 3 * C * 4);
-            yh[j][s] = buf_f32(rs_h, voff[j], oc); cpv[j][s] = buf_f32(rs_c, voff[j], oc - S * C * 4);
-            if (t == T) dm[j][s] = buf_f32(rs_p, voff[j], ((T - 1) * S + s0 + ss) * C * 4);   // d_m(T) = P(T): dgifo(T+1) = 0
-          }
-        if (t < T && !sweep_cells(a.gran + (size_t)(g * 2 + (t & 1)) * C * 4, C, ns, epoch + (unsigned)t, cell, dm, t_start, a.nap0, a.nap)) {
-          *abortf = 1u;
-          if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+        for (int s = 0; s < 4; s++) {
+          const int ss = s < S ? s : 0;              // absent streams re-read stream 0 (their results are never stored)
+          const int og = sg + ss * K * 4, oc = sc + ss * C * 4;
+          yg[j][s] = buf_f32(rs_g, voff[j], og); yi[j][s] = buf_f32(rs_g, voff[j], og + C * 4);
+          yf[j][s] = buf_f32(rs_g, voff[j], og + 2 * C * 4); yo[j][s] = buf_f32(rs_g, voff[j], og + 3 * C * 4);
+          yh[j][s] = buf_f32(rs_h, voff[j], oc); cpv[j][s] = buf_f32(rs_c, voff[j], oc - S * C * 4);
+          if (t == T) dm[j][s] = buf_f32(rs_p, voff[j], ((T - 1) * S + ss) * C * 4);          // d_m(T) = P(T): dgifo(T+1) = 0
         }
-        PT_MARK(0);                                  // plane loads + sweep
-        // elementwise BPTT of frame t (:411-440), replicated in every workgroup
+      if (t < T && !sweep_cells(a.gran + (size_t)(t & 1) * C * 4, C, S, epoch + (unsigned)t, cell, dm, t_start, a.nap0, a.nap)) {
+        *abortf = 1u;
+        if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+      }
+      PT_MARK(0);                                    // plane loads + sweep
+      // elementwise BPTT of frame t (:411-440), replicated in every workgroup
 #pragma unroll
-        for (int j = 0; j < PCELL; j++)
+      for (int j = 0; j < PCELL; j++)
 #pragma unroll
-          for (int s = 0; s < 4; s++) {
-            float d_c;
-            const float4 dg = bptt_cell(dm[j][s], yg[j][s], yi[j][s], yf[j][s], yo[j][s], yh[j][s], cpv[j][s], wpi[j], wpf[j], wpo[j],
-                                        kk[g][j][s], d_c);
-            if (cell[j] < C && s < ns) {
-              if (t > 1) {                           // B operand of the contraction
-                float *lp = ldsD + (g * 4 + s) * LDD + cell[j];
-                lp[0] = dg.x; lp[C] = dg.y; lp[2 * C] = dg.z; lp[3 * C] = dg.w;
-              }
-              if (mine[j]) {                         // own cells: rows of the dgifo / dc planes (gradient products, d_r, in_diff)
-                const size_t row = (size_t)t * S + s0 + s;
-                float *dp = a.dgifo + row * K + cell[j];
-                dp[0] = dg.x; dp[C] = dg.y; dp[2 * C] = dg.z; dp[3 * C] = dg.w;
-                a.dc[row * C + cell[j]] = d_c;
-              }
+        for (int s = 0; s < 4; s++) {
+          float d_c;
+          const float4 dg = bptt_cell(dm[j][s], yg[j][s], yi[j][s], yf[j][s], yo[j][s], yh[j][s], cpv[j][s], wpi[j], wpf[j], wpo[j],
+                                      kk[j][s], d_c);
+          if (cell[j] < C && s < S) {
+            if (t > 1) {                             // B operand of the contraction
+              float *lp = ldsD + s * LDD + cell[j];
+              lp[0] = dg.x; lp[C] = dg.y; lp[2 * C] = dg.z; lp[3 * C] = dg.w;
+            }
+            if (mine[j]) {                           // own cells: rows of the dgifo / dc planes (gradient products, d_r, in_diff)
+              const size_t row = (size_t)t * S + s;
+              float *dp = a.dgifo + row * K + cell[j];
+              dp[0] = dg.x; dp[C] = dg.y; dp[2 * C] = dg.z; dp[3 * C] = dg.w;
+              a.dc[row * C + cell[j]] = d_c;
             }
           }
-        PT_MARK(2);                                  // elementwise + slab / plane stores
-        if (t == 1) continue;
-        lds_barrier();                               // slab ready
-        PT_MARK(1);
-        if (*abortf) goto done;
-        lds_barrier();                               // (partial tiles ready: nothing to do here but keep the count; the K waves
+        }
+      PT_MARK(2);                                    // elementwise + slab / plane stores
+      if (t == 1) break;
+      lds_barrier();                                 // slab ready
+      PT_MARK(1);
+      if (*abortf) break;
+      lds_barrier();                                 // (partial tiles ready: nothing to do here but keep the count; the K waves
                                                      //  contract meanwhile, and polling the fabric now would only slow them down)
-        PT_MARK(3);
-      }
+      PT_MARK(3);
     }
+    PT_FLUSH(0);
   }
-done:
-  PT_FLUSH(0);
   finish(a.ctrl, epoch, T);
 }
 
@@ -556,72 +523,65 @@ void set_persist_waves(int v) { g_persist_waves = v; }
 
 // Geometry.  Fewer, fatter workgroups mean fewer sweepers per exchange (less fabric contention).
 //   forward : 4 cell waves per tile (one per cell, whole K in registers: maxc = 128-wide chunks), the rest sweep
-//   backward: 4 K waves per tile split K (maxc = chunks per K wave), the first of them owns the tile, the rest sweep
-//   ng      : stream groups (software pipeline): 2 above 4 streams; the backward chain also splits 2..4 streams
-struct PGeo { int waves, tpw, maxc, pcell, ng; };
-static int g_persist_ng = 0;        // A-B knob: force the number of stream groups (0 = automatic)
-void set_persist_ng(int v) { g_persist_ng = v; }
-static PGeo pick_geo_fwd(int C, int nch, int S) {
-  const int waves = g_persist_waves == 16 ? 16 : 12;   // measured at 40/800/512: 12 waves, 1 tile
+//   backward: waves/tpw waves per tile split K (maxc = chunks per wave), one of them owns the tile, the rest sweep
+struct PGeo { int waves, tpw, maxc, pcell; };
+static PGeo pick_geo_fwd(int C, int nch) {
+  const int waves = (g_persist_waves == 8 || g_persist_waves == 16) ? g_persist_waves : 12;   // measured at 40/800/512: 12 waves, 1 tile
   const int prefer[3] = {g_persist_tpw ? g_persist_tpw : 1, 1, 2};
   const int n128 = pcdiv(nch * KCH, 128);
-  const int ng = S > 4 ? 2 : (g_persist_ng == 2 && S >= 2 ? 2 : 1);
   for (int tpw : prefer) {
     if ((tpw != 1 && tpw != 2) || 4 * tpw >= waves || (C / 4) % tpw != 0 || C / 4 / tpw > 200 || n128 > 12) continue;
     const int pc = pcdiv(C, (waves - 4 * tpw) * 64);
     if (pc > 4) continue;
-    return PGeo{waves, tpw, n128 <= 7 ? 7 : n128 <= 9 ? 9 : 12, pc, ng};
+    return PGeo{waves, tpw, n128 <= 7 ? 7 : n128 <= 9 ? 9 : 12, pc};
   }
-  return PGeo{0, 0, 0, 0, 0};
+  return PGeo{0, 0, 0, 0};
 }
-static PGeo pick_geo(int C, int nch, int S) {        // backward
-  const int waves = g_persist_waves == 16 ? 16 : 12;
+static PGeo pick_geo(int C, int nch) {              // backward: 4 K waves per tile, chunk slots per K wave
+  const int waves = (g_persist_waves == 8 || g_persist_waves == 16) ? g_persist_waves : 12;
   const int prefer[3] = {g_persist_tpw ? g_persist_tpw : 1, 1, 2};
   const int mc = pcdiv(nch, 4);
-  const int ng = S > 4 ? 2 : (g_persist_ng == 1 || S < 2 ? 1 : 2);
   for (int tpw : prefer) {
     if ((tpw != 1 && tpw != 2) || 4 * tpw >= waves || (C / 4) % tpw != 0 || C / 4 / tpw > 200 || mc > 9) continue;
     const int pc = pcdiv(C, (waves - 4 * tpw) * 64);
     if (pc > 4) continue;
-    return PGeo{waves, tpw, mc <= 7 ? 7 : 9, pc, ng};
+    return PGeo{waves, tpw, mc <= 7 ? 7 : 9, pc};
   }
-  return PGeo{0, 0, 0, 0, 0};
+  return PGeo{0, 0, 0, 0};
 }
 
 bool persist_supported(const Dims &d) {
-  if (d.S > 8 || d.C % 8 != 0 || d.I % 8 != 0 || 4 * (d.I / 4) > 64) return false;
+  if (d.S > 4 || d.C % 8 != 0 || d.I % 8 != 0 || d.S * (d.I / 4) > 64) return false;
   const int nf = pcdiv(d.C, KCH) + pcdiv(d.I, KCH), nb = pcdiv(4 * d.C, 128);
-  const PGeo gf = pick_geo_fwd(d.C, nf, d.S), gb = pick_geo(d.C, nb, d.S);
-  if (!gf.tpw || !gb.tpw) return false;
-  // dynamic LDS of the backward slabs (the forward ones are smaller)
-  return (size_t)(gb.ng * 4 * (4 * gb.maxc * 128 + 16) + 64) * sizeof(float) <= 160 * 1024;
+  return pick_geo_fwd(d.C, nf).tpw > 0 && pick_geo(d.C, nb).tpw > 0;
 }
-size_t persist_gran_bytes(const Dims &d) { (void)d; return (size_t)2 * 2 * d.C * 4 * sizeof(unsigned long long); }   // [groups][parity][C*4]
+size_t persist_gran_bytes(const Dims &d) { return (size_t)2 * d.C * 4 * sizeof(unsigned long long); }
 
 template <class K, class A>
 static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t st, LaunchProbe pr, const A &a) {
-  if (shm > 64 * 1024)                               // above the default dynamic-LDS limit
+  if (shm > 64 * 1024)                               // above the default dynamic-LDS limit (cell dim 1024 backward)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (pr.start) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), shm, st, pr.start, pr.stop, 0, a);
   else hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), shm, st, a);
   return hipGetLastError();
 }
-#define PD6(KERN, TP, MC, W, G)                                                                                 \
-  if (g.waves == W && g.tpw == TP && g.maxc == MC && g.ng == G) {                                               \
-    if (g.pcell == 1) return plaunch(KERN<TP, MC, W, 1, G>, grid, W * 64, shm, st, pr, a);                      \
-    if (g.pcell == 2) return plaunch(KERN<TP, MC, W, 2, G>, grid, W * 64, shm, st, pr, a);                      \
-    if (g.pcell == 3) return plaunch(KERN<TP, MC, W, 3, G>, grid, W * 64, shm, st, pr, a);                      \
-    return plaunch(KERN<TP, MC, W, 4, G>, grid, W * 64, shm, st, pr, a);                                        \
+#define PD5(KERN, TP, MC, W)                                                                                    \
+  if (g.waves == W && g.tpw == TP && g.maxc == MC) {                                                            \
+    if (g.pcell == 1) return plaunch(KERN<TP, MC, W, 1>, grid, W * 64, shm, st, pr, a);                         \
+    if (g.pcell == 2) return plaunch(KERN<TP, MC, W, 2>, grid, W * 64, shm, st, pr, a);                         \
+    if (g.pcell == 3) return plaunch(KERN<TP, MC, W, 3>, grid, W * 64, shm, st, pr, a);                         \
+    return plaunch(KERN<TP, MC, W, 4>, grid, W * 64, shm, st, pr, a);                                           \
   }
-#define PD5(KERN, TP, MC, W) PD6(KERN, TP, MC, W, 1) PD6(KERN, TP, MC, W, 2)
 #define PDISPATCH_FWD(KERN)                                                                                     \
   do {                                                                                                          \
+    PD5(KERN, 1, 7, 8) PD5(KERN, 1, 9, 8) PD5(KERN, 1, 12, 8)                                                   \
     PD5(KERN, 1, 7, 12) PD5(KERN, 1, 9, 12) PD5(KERN, 1, 12, 12) PD5(KERN, 2, 7, 12) PD5(KERN, 2, 9, 12) PD5(KERN, 2, 12, 12) \
-    PD5(KERN, 1, 7, 16) PD5(KERN, 1, 9, 16) PD5(KERN, 2, 7, 16) PD5(KERN, 2, 9, 16)                             \
+    PD5(KERN, 1, 7, 16) PD5(KERN, 1, 9, 16) PD5(KERN, 1, 12, 16) PD5(KERN, 2, 7, 16) PD5(KERN, 2, 9, 16) PD5(KERN, 2, 12, 16) \
     return hipErrorInvalidValue;                                                                                \
   } while (0)
 #define PDISPATCH_BWD(KERN)                                                                                     \
   do {                                                                                                          \
+    PD5(KERN, 1, 7, 8) PD5(KERN, 1, 9, 8)                                                                       \
     PD5(KERN, 1, 7, 12) PD5(KERN, 1, 9, 12) PD5(KERN, 2, 7, 12) PD5(KERN, 2, 9, 12)                             \
     PD5(KERN, 1, 7, 16) PD5(KERN, 1, 9, 16) PD5(KERN, 2, 7, 16) PD5(KERN, 2, 9, 16)                             \
     return hipErrorInvalidValue;                                                                                \
@@ -636,9 +596,9 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm;
   a.x = in; a.x_stride = in_stride; a.c_save = p.prev_c; a.gran = gran; a.ctrl = ctrl;
   a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 9; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // measured: tools/persist_anatomy
-  const PGeo g = pick_geo_fwd(d.C, a.nch, d.S);
+  const PGeo g = pick_geo_fwd(d.C, a.nch);
   if (!g.tpw || !p.pk_fold || (reinterpret_cast<uintptr_t>(in) & 15) || in_stride % 4 != 0) return hipErrorInvalidValue;
-  const size_t shm = (size_t)(g.ng * 4 * (g.maxc * 128 + 16) + 4) * sizeof(float);
+  const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4) * sizeof(float);
   const int grid = d.C / 4 / g.tpw;
   PDISPATCH_FWD(k_fwd_persist);
 }
@@ -651,9 +611,9 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, u
   a.wpk = p.pk_fold; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.gran = gran; a.ctrl = ctrl;
   a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 0; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // (the second barrier already keeps the sweepers off the fabric)
-  const PGeo g = pick_geo(d.C, a.nch, d.S);
+  const PGeo g = pick_geo(d.C, a.nch);
   if (!g.tpw || !p.pk_fold) return hipErrorInvalidValue;
-  const size_t shm = (size_t)(g.ng * 4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4) * sizeof(float);
+  const size_t shm = (size_t)(4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4) * sizeof(float);
   const int grid = d.C / 4 / g.tpw;
   PDISPATCH_BWD(k_bwd_persist);
 }

@@ -891,16 +891,13 @@ def test_full_size_decreasing_T_split_k_workspace(S, Ts):
     e.close()
 
 
-@pytest.mark.parametrize("waves,tpw", [(0, 0), (12, 2), (16, 1)])
+@pytest.mark.parametrize("waves,tpw", [(0, 0), (12, 2), (8, 1), (16, 1)])
 @pytest.mark.parametrize("I,C,R,S,T,want_in_diff", [
     (40, 64, 32, 4, 6, True),        # 16 tiles
     (40, 64, 32, 3, 5, True),        # ragged stream group: granule slots of the absent stream are never written
     (8, 16, 8, 1, 9, False),         # one stream, 4 tiles, no in_diff
     (72, 136, 40, 2, 7, True),       # 4C = 544: last 128-chunk of the backward contraction partially filled
     (40, 800, 512, 4, 20, True),     # BASELINE.json configs[1]
-    (40, 64, 32, 8, 6, True),        # two stream groups of 4 (software pipeline over the groups)
-    (40, 64, 32, 5, 9, True),        # groups of 3 + 2
-    (40, 800, 512, 8, 20, True),     # BASELINE.json configs[2]: 8 streams per GPU
 ])
 def test_persistent_chain(I, C, R, S, T, want_in_diff, waves, tpw):
     """Option "persist": steps 2..T of the forward recurrence and T..1 of BPTT run inside ONE launch per direction with the

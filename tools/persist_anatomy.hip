@@ -21,19 +21,18 @@ int main(int argc, char **argv) {
   auto dalloc = [&](size_t n) { float *p; CK(hipMalloc(&p, n * 4)); CK(hipMemset(p, 0, n * 4)); return p; };
   float *vecs = dalloc(7 * C), *gifo = dalloc((size_t)(T + 2) * S * 4 * C), *cc = dalloc((size_t)(T + 2) * S * C),
         *hh = dalloc((size_t)(T + 2) * S * C), *mm = dalloc((size_t)(T + 2) * S * C), *x = dalloc((size_t)T * S * I), *cs = dalloc(S * C);
-  unsigned long long *gran; CK(hipMalloc(&gran, 4 * C * 4 * 8)); CK(hipMemset(gran, 0, 4 * C * 4 * 8));
+  unsigned long long *gran; CK(hipMalloc(&gran, 2 * C * 4 * 8)); CK(hipMemset(gran, 0, 2 * C * 4 * 8));
   unsigned *ctrl; CK(hipMalloc(&ctrl, 32)); CK(hipMemset(ctrl, 0, 32));
   long long *dbg; CK(hipMalloc(&dbg, 256 * 16 * 6 * 8)); CK(hipMemset(dbg, 0, 256 * 16 * 6 * 8));
-  for (int waves : {12}) for (int tpw : {1}) for (int ngf : {1, 2}) for (int nap0 : {0, 9}) for (int nap : {0}) {
-    set_persist_ng(ngf);
+  for (int waves : {12}) for (int tpw : {1}) for (int nap0 : {8, 9, 10}) for (int nap : {0}) {
     if (4 * tpw >= waves) continue;
     set_persist_waves(waves); set_persist_tpw(tpw);
     PersistFwdArgs a;
     a.C = C; a.I = I; a.S = S; a.T = T; a.nchm = nchm; a.nch = nch; a.wpk = wpk;
     a.bias = vecs; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
     a.gifo = gifo; a.cc = cc; a.hh = hh; a.mm = mm; a.x = x; a.x_stride = I; a.c_save = cs; a.gran = gran; a.ctrl = ctrl; a.dbg = dbg; a.nap0 = nap0; a.nap = nap;
-    const PGeo g = pick_geo_fwd(C, nch, S);
-    const size_t shm = (size_t)(g.ng * 4 * (g.maxc * 128 + 16) + 4) * sizeof(float);
+    const PGeo g = pick_geo_fwd(C, nch);
+    const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4) * sizeof(float);
     const int grid = C / 4 / g.tpw;
     LaunchProbe pr;
     auto go = [&]() -> hipError_t { PDISPATCH_FWD(k_fwd_persist); };
@@ -50,7 +49,7 @@ int main(int argc, char **argv) {
     auto row = [&](int wg, int w) { return &d[((size_t)wg * 16 + w) * 6]; };
     long long tot = 0; for (int i = 0; i < 6; i++) tot += row(0, 0)[i];
     const double cyc_per_us = tot / (best * 1e3);
-    printf("S=%d waves=%d tpw=%d ng=%d grid=%d maxc=%d pcell=%d nap0=%d nap=%d: %.3f us/step (status %x), ~%.0f MHz shader clock\n", S, g.waves, g.tpw, g.ng, grid, g.maxc, g.pcell, nap0, nap, us_step, stw[2], cyc_per_us);
+    printf("S=%d waves=%d tpw=%d grid=%d maxc=%d pcell=%d nap0=%d nap=%d: %.3f us/step (status %x), ~%.0f MHz shader clock\n", S, g.waves, g.tpw, grid, g.maxc, g.pcell, nap0, nap, us_step, stw[2], cyc_per_us);
     const char *nm[6] = {"sweep+slab", "barrier1", "contract", "barrier2", "epilogue", "loophead"};
     for (int w : {0}) {
       printf("   wg0 wave %2d (%s):", w, w < 4 * g.tpw ? "cell   " : "sweeper");
@@ -73,15 +72,14 @@ int main(int argc, char **argv) {
     for (auto &v : hb) v = (rand() / (float)RAND_MAX - 0.5f) * 0.02f;
     CK(hipMemcpy(wpb, hb.data(), npb * 16, hipMemcpyHostToDevice));
     float *dgifo = dalloc((size_t)(T + 2) * S * 4 * C), *dc = dalloc((size_t)(T + 2) * S * C), *P = dalloc((size_t)T * S * C);
-    CK(hipMemset(gran, 0, 4 * C * 4 * 8)); CK(hipMemset(ctrl, 0, 32));
-    for (int waves : {12}) for (int ngf : {1, 2}) for (int nap0 : {0}) {
-      set_persist_ng(ngf);
+    CK(hipMemset(gran, 0, 2 * C * 4 * 8)); CK(hipMemset(ctrl, 0, 32));
+    for (int waves : {12, 8}) for (int nap0 : {0, 2, 4, 6, 8}) {
       set_persist_waves(waves); set_persist_tpw(1);
       PersistBwdArgs a;
       a.C = C; a.S = S; a.T = T; a.nch = nchb; a.wpk = wpb; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
       a.gifo = gifo; a.cc = cc; a.hh = hh; a.dgifo = dgifo; a.dc = dc; a.P = P; a.gran = gran; a.ctrl = ctrl; a.nap0 = nap0; a.nap = 0; a.dbg = dbg;
-      const PGeo g = pick_geo(C, nchb, S);
-      const size_t shm = (size_t)(g.ng * 4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4) * sizeof(float);
+      const PGeo g = pick_geo(C, nchb);
+      const size_t shm = (size_t)(4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4) * sizeof(float);
       const int grid = C / 4 / g.tpw;
       LaunchProbe pr;
       auto go = [&]() -> hipError_t { PDISPATCH_BWD(k_bwd_persist); };
@@ -96,7 +94,7 @@ int main(int argc, char **argv) {
       auto row = [&](int wg, int w) { return &d[((size_t)wg * 16 + w) * 6]; };
       long long tot = 0; for (int i = 0; i < 6; i++) tot += row(0, 4)[i];
       const double cyc_per_us = tot / (best * 1e3);
-      printf("BWD S=%d waves=%d tpw=%d ng=%d grid=%d maxc=%d pcell=%d nap0=%d: %.3f us/step (status %x)\n", S, g.waves, g.tpw, g.ng, grid, g.maxc, g.pcell, nap0, best * 1e3 / (T - 1), stw[2]);
+      printf("BWD S=%d waves=%d tpw=%d grid=%d maxc=%d pcell=%d nap0=%d: %.3f us/step (status %x)\n", S, g.waves, g.tpw, grid, g.maxc, g.pcell, nap0, best * 1e3 / (T - 1), stw[2]);
       const char *nk[6] = {"-", "wait-slab", "contract", "barrier2", "epilogue", "loophead"};
       const char *ns[6] = {"loads+sweep", "barrier1", "elementwise", "barrier2", "-", "loophead"};
       printf("   K wave 0 :");
