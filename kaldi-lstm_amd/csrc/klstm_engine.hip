@@ -257,7 +257,9 @@ static klstm_status ensure_packs(klstm_engine *e) {
   e->pk_stale = 0;
   return KLSTM_OK;
 }
-static klstm_status ensure_fold(klstm_engine *e) {
+// need_x: the x chunks of the packed gates operand are read too (launch-per-step folded chain; the persistent kernel
+// takes W_gifo_x from the natural matrix)
+static klstm_status ensure_fold(klstm_engine *e, bool need_x) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
   if (!e->pk_fold[0]) {
     long nf[2];
@@ -268,10 +270,11 @@ static klstm_status ensure_fold(klstm_engine *e) {
     }
     e->fold_dirty = true;
   }
-  if (!e->fold_dirty) return KLSTM_OK;
-  HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, !e->foldx_fresh, e->stream, probe(e, "k_fold"),
-                     e->foldx_fresh ? LaunchProbe() : probe(e, "k_pack_foldx")));
-  e->foldx_fresh = true;
+  const bool pack_x = need_x && !e->foldx_fresh;
+  if (!e->fold_dirty && !pack_x) return KLSTM_OK;
+  HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, pack_x, e->stream, probe(e, "k_fold"),
+                     pack_x ? probe(e, "k_pack_foldx") : LaunchProbe()));
+  if (pack_x) e->foldx_fresh = true;
   e->fold_dirty = false;
   return KLSTM_OK;
 }
@@ -504,11 +507,11 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
   if (e->fwd_folded) {
     // step 1 closes over the CARRIED r (set by Reset / the previous minibatch, possibly under older weights): unfolded
     // gates kernel, r(0) mirrored into time block 0; steps 2..T close over m(t-1) through W_rm; r(1..T) in one GEMM
-    HIPCHK(launch_gates_step(d, p, 1, fx, in, in_stride, st, probe(e, "k_gates_step")));
-    if (e->fwd_persist) {
+    if (e->fwd_persist) {                         // (all T steps in the one launch, step 1 on the natural matrices)
       HIPCHK(launch_fwd_persist(d, p, in, in_stride, e->gran[0], e->pctrl, st, probe(e, "k_fwd_persist")));
       e->persist_dirty = true;
     } else {
+      HIPCHK(launch_gates_step(d, p, 1, fx, in, in_stride, st, probe(e, "k_gates_step")));
       for (int t = 2; t <= T; t++)
         HIPCHK(launch_gates_step(d, p, t, fx, in, in_stride, st, probe(e, "k_gates_fold"), true));
     }
@@ -613,8 +616,13 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   e->fwd_folded = e->fwd_persist || fold_wanted(e, T);
   if (e->fwd_persist && (st = ensure_persist(e)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
-  if (e->fwd_folded && (st = ensure_fold(e)) != KLSTM_OK) return st;     // outside the graph: only after an Update
+  if (e->fwd_folded && (st = ensure_fold(e, !e->fwd_persist)) != KLSTM_OK) return st;     // outside the graph: only after an Update
   if (!e->fwd_folded && (st = ensure_packs(e)) != KLSTM_OK) return st;
+  if (e->fwd_folded && !e->fwd_persist && (e->pk_stale & 1) && e->pk[0]) {   // step 1 of the launch-per-step folded chain
+    const Dims d0{e->I, e->C, e->R, e->S, 0};
+    HIPCHK(launch_pack(d0, e->params, e->wrT, e->wmT, e->wxT, e->pk, 1, e->use_bf16, e->stream, probe(e, "k_pack")));
+    e->pk_stale &= ~1;
+  }
   klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, e->fwd_persist ? -3 : e->fwd_folded ? -2 : -1);
   st = run_graphed(e, key, [&]() { return seq_forward(e, in, in_stride, out, out_stride, T); });
   if (st != KLSTM_OK) return st;
@@ -645,7 +653,7 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
     return KLSTM_OK;
   }
   const int T = e->T_fwd;
-  if (e->fwd_folded) { klstm_status fs = ensure_fold(e); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
+  if (e->fwd_folded) { klstm_status fs = ensure_fold(e, !e->fwd_persist); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
                         flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0));
   klstm_status st = run_graphed(e, key, [&]() {
@@ -740,9 +748,10 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
   // (Packing the BPTT operands on a second stream, overlapped with the next forward pass, was measured to cost
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
   // while the folded chain is in use only the step-1 gates operand (array 0) is read; the others are refreshed on demand
-  const int mask = e->fwd_folded ? 1 : 15;
-  float *foldx = (e->fwd_folded && !e->use_bf16) ? e->pk_fold[0] : nullptr;
-  if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, mask, e->use_bf16, e->stream, probe(e, "k_pack"), foldx));
+  // (and with the persistent forward kernel none at all: it reads the natural matrices)
+  const int mask = e->fwd_persist ? 0 : e->fwd_folded ? 1 : 15;
+  float *foldx = (e->fwd_folded && !e->fwd_persist && !e->use_bf16) ? e->pk_fold[0] : nullptr;
+  if (e->pk[0] && (mask || foldx)) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, mask, e->use_bf16, e->stream, probe(e, "k_pack"), foldx));
   e->pk_stale = 15 & ~mask;
   e->fold_dirty = true;
   e->foldx_fresh = foldx != nullptr;
@@ -1129,7 +1138,7 @@ klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *
   const std::string w0(what);
   if (w0 == "gates_fold" || w0 == "dmf" || w0 == "fold" || w0 == "fold_gemm" || w0 == "rbatch" || w0 == "bwd_tail") {
     if (!e->pk[0] || e->use_bf16) return fail(KLSTM_ERR_SHAPE, "folded path not available for this engine");
-    klstm_status fs = ensure_fold(e);
+    klstm_status fs = ensure_fold(e, true);
     if (fs != KLSTM_OK) return fs;
     if ((fs = ensure_ws(e, T)) != KLSTM_OK) return fs;
   }

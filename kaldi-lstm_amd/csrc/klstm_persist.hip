@@ -46,13 +46,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr long long SPIN_LIMIT = 5000000;   // wall_clock64 ticks (100 MHz): 50 ms
 
 struct PersistFwdArgs {
-  int C, I, S, T;
+  int C, I, R, S, T;
   int nchm, nch;                  // 32-wide chunks over C (the m part) and in total (m + x)
-  const float4 *wpk;              // packed [W_rm | W_x], gates order: [C/4 tiles][nch][2][64]
+  const float4 *wpk;              // packed W_rm (the m chunks of the folded gates operand): [C/4 tiles][nch][2][64]
+  const float *wr, *wx;           // natural W_gifo_r [4C x R], W_gifo_x [4C x I] (step 1, and the x chunks of every step)
   const float *bias, *pi, *pf, *po;
-  float *gifo, *cc, *hh, *mm;     // activation planes, time-major row blocks of S
+  float *gifo, *cc, *hh, *mm, *rr; // activation planes, time-major row blocks of S
   const float *x; int x_stride;   // input rows [T*S x I]
-  float *c_save;                  // prev_c [S x C]
+  float *prev_c;                  // carried c [S x C]: read at step 1 (:231), written at step T (:331)
+  const float *prev_r;            // carried r [S x R]: read at step 1
   unsigned long long *gran;       // [2][C*4] granules, cell-major (4 stream slots per cell)
   unsigned *ctrl;                 // [0] epoch, [1] finished workgroups, [2] status (0 = ok)
   int nap0, nap;                  // sweepers sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
@@ -173,21 +175,52 @@ __device__ __forceinline__ void finish(unsigned *ctrl, unsigned epoch, int T) {
 // all in that wave.  ONE workgroup barrier per step (slab ready).  The remaining waves sweep, one cell per thread.
 // The weights come from the 16-row packed operand of the launch-per-step kernels, gathered once at kernel start.
 // -------------------------------------------------------------------------------------------------------------------
+// One contraction of a cell wave: NCHUNK 128-wide chunks of resident rows (a0/a1) against slab row `bj` (stride LD).
+// Exactly NCHUNK chunks, no branch: chunks beyond the operand have zero weights and read zero slab columns, so every LDS
+// read of the step is issued before the first MFMA.  Returns the gate pre-activations g,i,f,o of (cell, stream lane&3) in
+// lanes 12..15.
+template <int NCHUNK>
+__device__ __forceinline__ f32x4 cell_contract(const float4 (&a0)[NCHUNK], const float4 (&a1)[NCHUNK], const float *slab_row, int kg) {
+  float4 b0[NCHUNK], b1[NCHUNK];
+#pragma unroll
+  for (int i = 0; i < NCHUNK; i++) {
+    const float *bp = slab_row + i * 128 + kg * 4;
+    b0[i] = *reinterpret_cast<const float4 *>(bp); b1[i] = *reinterpret_cast<const float4 *>(bp + 64);
+  }
+  __builtin_amdgcn_sched_barrier(0);                 // (otherwise the scheduler sinks every read next to its MFMAs: one LDS round trip per chunk)
+  f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for (int i = 0; i < NCHUNK; i++) {
+    const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
+    const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
+  }
+  return kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));   // the 16 k-groups of a (gate, stream) pair
+}
+
+// 128-wide chunks of the UNFOLDED step-1 operand [r(0) | pad | x(1)] (K = RP + I, RP = R rounded up to 32) that go with
+// MAXC chunks of the folded one (R <= C: a projection)
+constexpr int persist_maxu(int maxc) { return maxc == 7 ? 5 : maxc; }
+
 template <int TPW, int MAXC, int PNW, int PCELL>
 __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
-  constexpr int PNT = PNW * 64, NCW = 4 * TPW, NSW = (PNW - NCW) * 64;
+  constexpr int PNT = PNW * 64, NCW = 4 * TPW, NSW = (PNW - NCW) * 64, MAXU = persist_maxu(MAXC);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int C = a.C, S = a.S, T = a.T, I = a.I, nch = a.nch;
-  const int n128 = (nch * KCH + 127) / 128;          // 128-wide chunks over the padded K of the packed operand (<= MAXC)
+  const int C = a.C, S = a.S, T = a.T, I = a.I, R = a.R, nch = a.nch;
+  const int RP = (R + KCH - 1) / KCH * KCH;          // x columns of the step-1 slab start here (the layout of the packed gates operand)
+  const int XP = a.nchm * KCH;                       // ... and here in the folded slab
   constexpr int LDB = MAXC * 128 + 16;               // (LDB mod 64 == 16: the 16-lane groups of ds_read_b128 hit 16 distinct slots)
+  constexpr int LDU = MAXU * 128 + 16;
   float *ldsB = lds;                                 // [4][LDB]: row s = [ m(t-1)[s][0..C) | pad | x(t)[s][0..I) | pad ]
-  unsigned *abortf = reinterpret_cast<unsigned *>(lds + 4 * LDB);
+  float *ldsU = lds + 4 * LDB;                       // [4][LDU]: row s = [ r(0)[s][0..R) | pad | x(1)[s][0..I) | pad ]   (step 1 only)
+  unsigned *abortf = reinterpret_cast<unsigned *>(ldsU + 4 * LDU);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long t_start = wall_clock64();
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // zero the B slab once: pad columns and rows of absent streams stay zero for the whole launch
-  for (int i = tid; i < 4 * LDB; i += PNT) ldsB[i] = 0.f;
+  // zero both slabs once: pad columns and rows of absent streams stay zero for the whole launch
+  for (int i = tid; i < 4 * (LDB + LDU); i += PNT) lds[i] = 0.f;
   if (tid == 0) *abortf = 0u;
   __syncthreads();
   PT_DECL();
@@ -199,87 +232,99 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
     // =========================== cell wave: cell (wave & 3) of tile (wave >> 2) ===========================
     const int tile = blockIdx.x * TPW + (wave >> 2), cw = wave & 3;
     const int kg = lane >> 2, bj = lane & 3;
-    // resident weights: rows (cell, gate = lane & 3), k = 128*chunk + 64*h + 4*kg + e.  In the packed operand
-    // (klstm_kernels.hip k_pack: pk[tile][chunk32][h32][lane32][4], row = lane32 & 15, k = 32*chunk32 + 8*(lane32 >> 4) +
-    // 4*h32 + e) that float4 sits at chunk32 = k/32, lane32 = ((k%32)/8)*16 + row, h32 = (k%8)/4
-    float4 a0[MAXC], a1[MAXC];
-#pragma unroll
-    for (int i = 0; i < MAXC; i++) {
-      float4 w[2];
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int k0 = 128 * i + 64 * h + 4 * kg;
-        const int c32 = k0 >> 5, l32 = ((k0 & 31) >> 3) * 16 + 4 * cw + bj, h32 = (k0 & 7) >> 2;
-        const bool on = tile * 4 < C && i < n128 && c32 < nch;
-        const float4 *ap = a.wpk + (((size_t)(on ? tile : 0) * nch + (on ? c32 : 0)) * 2 + h32) * 64 + l32;
-        w[h] = *ap;
-        if (!on) w[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      a0[i] = w[0]; a1[i] = w[1];
-    }
-    // epilogue lanes: lanes 12..15 = streams 0..3 of the cell (where kgroup_sum leaves the totals)
     const int e_cell = tile * 4 + cw, es = lane & 3;
+    const int lc = e_cell < C ? e_cell : 0;
+    const size_t wrow = (size_t)bj * C + lc;         // this lane's weight row: gate bj of the cell (rows of the 4C axis are g,i,f,o blocks)
+    // epilogue lanes: lanes 12..15 = streams 0..3 of the cell (where kgroup_sum leaves the totals)
     const bool e_on = (lane >> 2) == 3 && es < S && e_cell < C;
-    const int lc = e_cell < C ? e_cell : 0, ls = e_on ? es : 0;
+    const int ls = e_on ? es : 0;
     const float pre0 = a.bias[lc], pre1 = a.bias[C + lc], pre2 = a.bias[2 * C + lc], pre3 = a.bias[3 * C + lc];
     const float wpi = a.pi[lc], wpf = a.pf[lc], wpo = a.po[lc];
-    float cp = a.cc[((size_t)1 * S + ls) * C + lc];                  // c(1), written by the step-1 kernel
+    float cp = a.prev_c[(size_t)ls * C + lc];                        // carried c(0) (:231)
+    if (e_on) a.cc[(size_t)es * C + e_cell] = cp;                    // time block 0 of the c plane: BPTT reads it (:231)
+    auto cell_math = [&](int t, const f32x4 &v) {
+      if (!e_on) return;
+      const size_t e_row = (size_t)t * S + es;
+      float ag = v.x + pre0;
+      float ai = v.y + pre1;
+      float af = v.z + pre2;
+      float ao = v.w + pre3;
+      ai += wpi * cp;                              // :278
+      af += wpf * cp;                              // :281
+      const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
+      float c = gg * gi;                           // :291
+      c = c + cp * gf;                             // :294
+      c = c < -50.f ? -50.f : c;                   // :296
+      c = c > 50.f ? 50.f : c;                     // :297
+      const float h = k_tanh(c);                   // :300
+      ao += wpo * c;                               // :303
+      const float go = k_sigmoid(ao);              // :306
+      const float m = h * go;                      // :309
+      if (t < T) publish(a.gran + (size_t)(t & 1) * C * 4, e_cell * 4 + es, epoch + (unsigned)t, m);
+      float *gp = a.gifo + e_row * 4 * C + e_cell;
+      gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
+      a.cc[e_row * C + e_cell] = c;
+      a.hh[e_row * C + e_cell] = h;
+      a.mm[e_row * C + e_cell] = m;
+      if (t == T) a.prev_c[(size_t)es * C + e_cell] = c;         // :331 (c columns)
+      cp = c;
+    };
+      // ---- step 1 closes over the CARRIED r (:275; set by Reset / the previous minibatch, possibly under older weights):
+      // unfolded rows [W_gifo_r | W_gifo_x] straight from the natural matrices, dead after step 1
+      float4 u0[MAXU], u1[MAXU];
+#pragma unroll
+      for (int i = 0; i < MAXU; i++) {
+        float4 w[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int k0 = 128 * i + 64 * h + 4 * kg;
+          const bool in_r = e_cell < C && k0 < R, in_x = e_cell < C && k0 >= RP && k0 - RP < I;
+          const float *ap = in_x ? a.wx + wrow * I + (k0 - RP) : a.wr + wrow * R + (in_r ? k0 : 0);
+          w[h] = *reinterpret_cast<const float4 *>(ap);
+          if (!in_r && !in_x) w[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        u0[i] = w[0]; u1[i] = w[1];
+      }
+      // (requested now, behind the step-1 rows: they arrive while step 1 computes and travels)
+      // ---- steps 2..T: resident folded rows [W_rm | W_x], k = 128*chunk + 64*h + 4*kg + e.  W_rm from the packed operand the
+      // fold product writes (klstm_kernels.hip: pk[tile][chunk32][h32][lane32][4], row = lane32 & 15,
+      // k = 32*chunk32 + 8*(lane32 >> 4) + 4*h32 + e), W_x from the natural W_gifo_x.
+      float4 a0[MAXC], a1[MAXC];
+#pragma unroll
+      for (int i = 0; i < MAXC; i++) {
+        float4 w[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int k0 = 128 * i + 64 * h + 4 * kg;
+          const int c32 = k0 >> 5, l32 = ((k0 & 31) >> 3) * 16 + 4 * cw + bj, h32 = (k0 & 7) >> 2;
+          const bool in_m = e_cell < C && c32 < a.nchm, in_x = e_cell < C && k0 >= XP && k0 - XP < I;
+          const float4 *ap = in_x ? reinterpret_cast<const float4 *>(a.wx + wrow * I + (k0 - XP))
+                                  : a.wpk + (((size_t)(in_m ? tile : 0) * nch + (in_m ? c32 : 0)) * 2 + h32) * 64 + l32;
+          w[h] = *ap;
+          if (!in_m && !in_x) w[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        a0[i] = w[0]; a1[i] = w[1];
+      }
+      PT_MARK(5);
+      lds_barrier();                                 // slab of step 1 ready
+      PT_MARK(1);
+      const f32x4 v = cell_contract<MAXU>(u0, u1, ldsU + bj * LDU, kg);
+      PT_MARK(2);
+      cell_math(1, v);
+      PT_MARK(4);
     for (int t = 2; t <= T; t++) {
       PT_MARK(5);
       lds_barrier();                                 // slab of step t ready
       PT_MARK(1);
       if (*abortf) break;                            // (plain LDS read: the asm barrier's memory clobber forces the reload; a volatile
                                                      //  read through the generic pointer became a FLAT load behind vmcnt(0))
-      // gates of this wave's cell: contraction over [m(t-1) | x(t)] with the resident rows.  Exactly MAXC chunks, no
-      // branch: chunks beyond the operand have zero weights and read zero slab columns, so every LDS read of the step
-      // is issued before the first MFMA.
-      float4 b0[MAXC], b1[MAXC];
-#pragma unroll
-      for (int i = 0; i < MAXC; i++) {
-        const float *bp = ldsB + bj * LDB + i * 128 + kg * 4;
-        b0[i] = *reinterpret_cast<const float4 *>(bp); b1[i] = *reinterpret_cast<const float4 *>(bp + 64);
-      }
-      __builtin_amdgcn_sched_barrier(0);             // (otherwise the scheduler sinks every read next to its MFMAs: 14 LDS round trips in a row)
-      f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-      for (int i = 0; i < MAXC; i++) {
-        const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
-        const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
-      }
-      const f32x4 v = kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));   // the 16 k-groups of a (gate, stream) pair
+      const f32x4 v = cell_contract<MAXC>(a0, a1, ldsB + bj * LDB, kg);
       PT_MARK(2);                                    // contraction + k-group sum
-      if (e_on) {
-        const size_t e_row = (size_t)t * S + es;
-        float ag = v.x + pre0;
-        float ai = v.y + pre1;
-        float af = v.z + pre2;
-        float ao = v.w + pre3;
-        ai += wpi * cp;                              // :278
-        af += wpf * cp;                              // :281
-        const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
-        float c = gg * gi;                           // :291
-        c = c + cp * gf;                             // :294
-        c = c < -50.f ? -50.f : c;                   // :296
-        c = c > 50.f ? 50.f : c;                     // :297
-        const float h = k_tanh(c);                   // :300
-        ao += wpo * c;                               // :303
-        const float go = k_sigmoid(ao);              // :306
-        const float m = h * go;                      // :309
-        if (t < T) publish(a.gran + (size_t)(t & 1) * C * 4, e_cell * 4 + es, epoch + (unsigned)t, m);
-        float *gp = a.gifo + e_row * 4 * C + e_cell;
-        gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
-        a.cc[e_row * C + e_cell] = c;
-        a.hh[e_row * C + e_cell] = h;
-        a.mm[e_row * C + e_cell] = m;
-        if (t == T) a.c_save[(size_t)es * C + e_cell] = c;       // :331 (c columns)
-        cp = c;
-      }
+      cell_math(t, v);
       PT_MARK(4);                                    // cell math + stores
     }
   } else {
-    // =========================== sweeper: m(t-1) of every cell and x(t) into the slab ===========================
+    // =========================== sweeper: the B operand of every step into the slab ===========================
     const int sidx = (wave - NCW) * 64 + lane;       // rank among the sweeping threads
     int cell[PCELL];
 #pragma unroll
@@ -287,29 +332,35 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
     const int nx4 = I / 4;                           // float4 per x row; the first sweeper wave also stages x(t)
     const bool x_on = sidx < S * nx4;
     const int xs = x_on ? sidx / nx4 : 0, xk = x_on ? (sidx % nx4) * 4 : 0;
-    for (int t = 2; t <= T; t++) {
+    for (int t = 1; t <= T; t++) {
       PT_MARK(5);
       float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (x_on) xv = *reinterpret_cast<const float4 *>(a.x + ((size_t)(t - 1) * S + xs) * a.x_stride + xk);
-      float mv[PCELL][4];
-      if (t == 2) {
+      if (t == 1) {
+        // step 1: the carried r(0) (:231, :275) into the unfolded slab, and into time block 0 of the r plane (BPTT reads it)
+        for (int i = sidx; i < S * (R / 4); i += NSW) {
+          const int s = i / (R / 4), k = (i % (R / 4)) * 4;
+          const float4 rv = *reinterpret_cast<const float4 *>(a.prev_r + (size_t)s * R + k);
+          *reinterpret_cast<float4 *>(ldsU + s * LDU + k) = rv;
+          if (blockIdx.x == 0) *reinterpret_cast<float4 *>(a.rr + (size_t)s * R + k) = rv;
+        }
+        if (x_on) *reinterpret_cast<float4 *>(ldsU + xs * LDU + RP + xk) = xv;
+      } else {
+        float mv[PCELL][4];                          // m(t-1) of every cell
+        if (!sweep_cells(a.gran + (size_t)((t - 1) & 1) * C * 4, C, S, epoch + (unsigned)(t - 1), cell, mv, t_start, a.nap0, a.nap)) {
+          *abortf = 1u;
+          if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+        }
+        // (the slab is free: the sweep only completes once every cell wave of THIS workgroup has published step t-1,
+        //  i.e. has finished reading the previous slab)
 #pragma unroll
         for (int j = 0; j < PCELL; j++)
+          if (cell[j] < C) {
 #pragma unroll
-          for (int s = 0; s < 4; s++) mv[j][s] = (cell[j] < C && s < S) ? a.mm[((size_t)1 * S + s) * C + cell[j]] : 0.f;
-      } else if (!sweep_cells(a.gran + (size_t)((t - 1) & 1) * C * 4, C, S, epoch + (unsigned)(t - 1), cell, mv, t_start, a.nap0, a.nap)) {
-        *abortf = 1u;
-        if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+            for (int s = 0; s < 4; s++) if (s < S) ldsB[s * LDB + cell[j]] = mv[j][s];
+          }
+        if (x_on) *reinterpret_cast<float4 *>(ldsB + xs * LDB + XP + xk) = xv;
       }
-      // (the slab is free: the sweep only completes once every cell wave of THIS workgroup has published step t-1,
-      //  i.e. has finished reading the previous slab)
-#pragma unroll
-      for (int j = 0; j < PCELL; j++)
-        if (cell[j] < C) {
-#pragma unroll
-          for (int s = 0; s < 4; s++) if (s < S) ldsB[s * LDB + cell[j]] = mv[j][s];
-        }
-      if (x_on) *reinterpret_cast<float4 *>(ldsB + xs * LDB + a.nchm * KCH + xk) = xv;
       PT_MARK(0);                                    // sweep + slab store
       lds_barrier();
       PT_MARK(1);
@@ -525,7 +576,7 @@ void set_persist_waves(int v) { g_persist_waves = v; }
 //   forward : 4 cell waves per tile (one per cell, whole K in registers: maxc = 128-wide chunks), the rest sweep
 //   backward: waves/tpw waves per tile split K (maxc = chunks per wave), one of them owns the tile, the rest sweep
 struct PGeo { int waves, tpw, maxc, pcell; };
-static PGeo pick_geo_fwd(int C, int nch) {
+static PGeo pick_geo_fwd(int C, int nch, int ku = 0) {   // ku: width of the step-1 operand [r | x]
   const int waves = (g_persist_waves == 8 || g_persist_waves == 16) ? g_persist_waves : 12;   // measured at 40/800/512: 12 waves, 1 tile
   const int prefer[3] = {g_persist_tpw ? g_persist_tpw : 1, 1, 2};
   const int n128 = pcdiv(nch * KCH, 128);
@@ -533,7 +584,9 @@ static PGeo pick_geo_fwd(int C, int nch) {
     if ((tpw != 1 && tpw != 2) || 4 * tpw >= waves || (C / 4) % tpw != 0 || C / 4 / tpw > 200 || n128 > 12) continue;
     const int pc = pcdiv(C, (waves - 4 * tpw) * 64);
     if (pc > 4) continue;
-    return PGeo{waves, tpw, n128 <= 7 ? 7 : n128 <= 9 ? 9 : 12, pc};
+    const int maxc = n128 <= 7 ? 7 : n128 <= 9 ? 9 : 12;
+    if (pcdiv(ku, 128) > persist_maxu(maxc)) continue;
+    return PGeo{waves, tpw, maxc, pc};
   }
   return PGeo{0, 0, 0, 0};
 }
@@ -551,9 +604,9 @@ static PGeo pick_geo(int C, int nch) {              // backward: 4 K waves per t
 }
 
 bool persist_supported(const Dims &d) {
-  if (d.S > 4 || d.C % 8 != 0 || d.I % 8 != 0 || d.S * (d.I / 4) > 64) return false;
+  if (d.S > 4 || d.C % 8 != 0 || d.I % 8 != 0 || d.R % 4 != 0 || d.S * (d.I / 4) > 64) return false;
   const int nf = pcdiv(d.C, KCH) + pcdiv(d.I, KCH), nb = pcdiv(4 * d.C, 128);
-  return pick_geo_fwd(d.C, nf).tpw > 0 && pick_geo(d.C, nb).tpw > 0;
+  return pick_geo_fwd(d.C, nf, pcdiv(d.R, KCH) * KCH + d.I).tpw > 0 && pick_geo(d.C, nb).tpw > 0;
 }
 size_t persist_gran_bytes(const Dims &d) { return (size_t)2 * d.C * 4 * sizeof(unsigned long long); }
 
@@ -590,15 +643,15 @@ static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t
 hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, int in_stride, unsigned long long *gran,
                               unsigned *ctrl, hipStream_t st, LaunchProbe pr) {
   PersistFwdArgs a;
-  a.C = d.C; a.I = d.I; a.S = d.S; a.T = d.T;
+  a.C = d.C; a.I = d.I; a.R = d.R; a.S = d.S; a.T = d.T;
   a.nchm = pcdiv(d.C, KCH); a.nch = a.nchm + pcdiv(d.I, KCH);
-  a.wpk = p.pk_fold; a.bias = p.bias; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
-  a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm;
-  a.x = in; a.x_stride = in_stride; a.c_save = p.prev_c; a.gran = gran; a.ctrl = ctrl;
+  a.wpk = p.pk_fold; a.wr = p.wr; a.wx = p.wx; a.bias = p.bias; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
+  a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm; a.rr = p.rr;
+  a.x = in; a.x_stride = in_stride; a.prev_c = p.prev_c; a.prev_r = p.prev_r; a.gran = gran; a.ctrl = ctrl;
   a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 9; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // measured: tools/persist_anatomy
-  const PGeo g = pick_geo_fwd(d.C, a.nch);
+  const PGeo g = pick_geo_fwd(d.C, a.nch, pcdiv(d.R, KCH) * KCH + d.I);
   if (!g.tpw || !p.pk_fold || (reinterpret_cast<uintptr_t>(in) & 15) || in_stride % 4 != 0) return hipErrorInvalidValue;
-  const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4) * sizeof(float);
+  const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4 * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);
   const int grid = d.C / 4 / g.tpw;
   PDISPATCH_FWD(k_fwd_persist);
 }

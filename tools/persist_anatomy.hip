@@ -10,7 +10,7 @@
 using namespace klstm;
 
 int main(int argc, char **argv) {
-  const int C = 800, I = 40, S = argc > 1 ? atoi(argv[1]) : 4, T = 200;
+  const int C = 800, I = 40, R = 512, S = argc > 1 ? atoi(argv[1]) : 4, T = 200;
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   const int nchm = (C + 31) / 32, nch = nchm + (I + 31) / 32;
   const size_t npk = (size_t)(C / 4) * nch * 128;
@@ -20,7 +20,8 @@ int main(int argc, char **argv) {
   CK(hipMemcpy(wpk, h.data(), npk * 16, hipMemcpyHostToDevice));
   auto dalloc = [&](size_t n) { float *p; CK(hipMalloc(&p, n * 4)); CK(hipMemset(p, 0, n * 4)); return p; };
   float *vecs = dalloc(7 * C), *gifo = dalloc((size_t)(T + 2) * S * 4 * C), *cc = dalloc((size_t)(T + 2) * S * C),
-        *hh = dalloc((size_t)(T + 2) * S * C), *mm = dalloc((size_t)(T + 2) * S * C), *x = dalloc((size_t)T * S * I), *cs = dalloc(S * C);
+        *hh = dalloc((size_t)(T + 2) * S * C), *mm = dalloc((size_t)(T + 2) * S * C), *x = dalloc((size_t)T * S * I), *cs = dalloc(S * C),
+        *wr = dalloc((size_t)4 * C * R), *wx = dalloc((size_t)4 * C * I), *pr0 = dalloc(S * R), *rr = dalloc((size_t)(T + 2) * S * R);
   unsigned long long *gran; CK(hipMalloc(&gran, 2 * C * 4 * 8)); CK(hipMemset(gran, 0, 2 * C * 4 * 8));
   unsigned *ctrl; CK(hipMalloc(&ctrl, 32)); CK(hipMemset(ctrl, 0, 32));
   long long *dbg; CK(hipMalloc(&dbg, 256 * 16 * 6 * 8)); CK(hipMemset(dbg, 0, 256 * 16 * 6 * 8));
@@ -28,11 +29,11 @@ int main(int argc, char **argv) {
     if (4 * tpw >= waves) continue;
     set_persist_waves(waves); set_persist_tpw(tpw);
     PersistFwdArgs a;
-    a.C = C; a.I = I; a.S = S; a.T = T; a.nchm = nchm; a.nch = nch; a.wpk = wpk;
+    a.C = C; a.I = I; a.R = R; a.S = S; a.T = T; a.nchm = nchm; a.nch = nch; a.wpk = wpk; a.wr = wr; a.wx = wx; a.prev_r = pr0; a.rr = rr;
     a.bias = vecs; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
-    a.gifo = gifo; a.cc = cc; a.hh = hh; a.mm = mm; a.x = x; a.x_stride = I; a.c_save = cs; a.gran = gran; a.ctrl = ctrl; a.dbg = dbg; a.nap0 = nap0; a.nap = nap;
-    const PGeo g = pick_geo_fwd(C, nch);
-    const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4) * sizeof(float);
+    a.gifo = gifo; a.cc = cc; a.hh = hh; a.mm = mm; a.x = x; a.x_stride = I; a.prev_c = cs; a.gran = gran; a.ctrl = ctrl; a.dbg = dbg; a.nap0 = nap0; a.nap = nap;
+    const PGeo g = pick_geo_fwd(C, nch, (R + 31) / 32 * 32 + I);
+    const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4 * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);
     const int grid = C / 4 / g.tpw;
     LaunchProbe pr;
     auto go = [&]() -> hipError_t { PDISPATCH_FWD(k_fwd_persist); };

@@ -33,7 +33,8 @@ for S in (1, 2, 4):
                 e.profile_query("k_grads"); e.set_option("profile", 1)
                 for _ in range(10): step()
                 kern = {}
-                for name in ("k_gates_fold", "k_dmf_step", "k_fwd_persist", "k_bwd_persist"):
+                for name in ("k_gates_step", "k_gates_fold", "k_dmf_step", "k_fwd_persist", "k_bwd_persist", "k_gemm_rbatch", "k_reduce_rbatch", "k_gemm_P", "k_reduce_P",
+                             "k_gemm_tail", "k_reduce_tail", "k_grads", "k_update_repack", "k_pack", "k_fold", "k_pack_foldx"):
                     tot, n = e.profile_query(name)
                     if n: kern[name] = round(tot / 10, 1)
                 e.set_option("profile", 0)
