@@ -535,13 +535,15 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     const int M = T * d.S;
     // P = out_diff W_r_m for all frames; chain of T folded steps; then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r
     // (:391, feeds the W_r_m gradient :486) and in_diff = dgifo W_gifo_x (:457) as split-K products
+    const bool p_inside = e->bwd_persist && persist_p_in_kernel(d) && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
     int kl = 0;
     int ks = gemm_splitk_plan(M, d.C, d.R, &kl);
-    if (ks > 1) HIPCHK(launch_gemm_splitk(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, e->ws, ks, kl,
+    if (p_inside) {}                              // (the persistent kernel contracts its own columns of P while its weights load)
+    else if (ks > 1) HIPCHK(launch_gemm_splitk(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, e->ws, ks, kl,
                                           st, nullptr, 0, probe(e, "k_gemm_P"), probe(e, "k_reduce_P")));
     else HIPCHK(launch_gemm(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
     if (e->bwd_persist) {
-      HIPCHK(launch_bwd_persist(d, p, e->Pm, e->gran[1], e->pctrl + 4, st, probe(e, "k_bwd_persist")));
+      HIPCHK(launch_bwd_persist(d, p, e->Pm, out_diff, od_stride, e->gran[1], e->pctrl + 4, st, probe(e, "k_bwd_persist")));
       e->persist_dirty = true;
     } else {
       for (int t = T; t >= 1; t--) HIPCHK(launch_dmf_step(d, p, t, e->Pm, st, probe(e, "k_dmf_step")));

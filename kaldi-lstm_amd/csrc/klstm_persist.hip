@@ -73,7 +73,10 @@ struct PersistFwdArgs {
 #endif
 
 struct PersistBwdArgs {
-  int C, S, T;
+  int C, R, S, T;
+  int pin;                        // 1: P = out_diff W_r_m is computed here (own columns, kept in LDS); 0: read from P
+  const float *od; int od_stride; // out_diff rows [T*S x R]
+  const float *wmT;               // W_r_m^T [C x R]
   int nch;                        // 128-wide chunks over 4C
   const float4 *wpk;              // packed W_rm^T, 4-row geometry: [C/4 tiles][nch][2][64]
   const float *pi, *pf, *po;
@@ -401,13 +404,15 @@ __device__ __forceinline__ float4 bptt_cell(float dm, float yg, float yi, float 
 
 template <int TPW, int MAXC, int PNW, int PCELL>
 __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
-  constexpr int PNT = PNW * 64, NKW = 4 * TPW, NSW = (PNW - NKW) * 64;
+  constexpr int PNT = PNW * 64, NKW = 4 * TPW, NSW = (PNW - NKW - 1) * 64;   // K waves, one P wave, sweepers
   constexpr int LDD = 4 * MAXC * 128 + 16;           // (LDD mod 64 == 16: the 16-lane groups of ds_read_b128 hit 16 distinct slots)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C, S = a.S, T = a.T, nch = a.nch, K = 4 * a.C;
   float *ldsD = lds;                                 // [4][LDD]: dgifo(t) rows, natural g|i|f|o order; columns >= 4C stay zero
   f32x4 *red = reinterpret_cast<f32x4 *>(lds + 4 * LDD);      // [NKW][4]
   unsigned *abortf = reinterpret_cast<unsigned *>(red + NKW * 4);
+  constexpr int PLW = 4 * TPW;                       // own cells
+  float *ldsP = reinterpret_cast<float *>(abortf + 4);        // [T*S][PLW]: own columns of P = out_diff W_r_m (pin)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long t_start = wall_clock64();
@@ -438,11 +443,17 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
     const bool e_on = owner_wave && lane < 16 && e_j < S && e_cell < C;
     const __amdgpu_buffer_rsrc_t rs_p = buf_rsrc(a.P, T * S * C * 4);
     const int e_offc = e_on ? (e_j * C + e_cell) * 4 : 0;
+    const float *e_pl = ldsP + (e_j < S ? e_j : 0) * PLW + tl * 4 + e_i;      // this lane's column of the LDS copy of P
     PT_DECL();
+    if (a.pin) {
+      lds_barrier();                                 // P of frames T, T-1 ready (P wave)
+      // d_m(T) = P(T) (dgifo(T+1) = 0, :351) travels like every other step
+      if (e_on) publish(a.gran + (size_t)(T & 1) * C * 4, e_cell * 4 + e_j, epoch + (unsigned)T, e_pl[(size_t)(T - 1) * S * PLW]);
+    }
     for (int t = T; t > 1; t--) {
       PT_MARK(5);
       // P(t-1) for the epilogue: requested now, consumed after the contraction (frame t-1 is row block t-2 of P)
-      const float pnext = owner_wave ? buf_f32(rs_p, e_offc, (t - 2) * S * C * 4) : 0.f;
+      const float pnext = !owner_wave ? 0.f : a.pin ? e_pl[(size_t)(t - 2) * S * PLW] : buf_f32(rs_p, e_offc, (t - 2) * S * C * 4);
       lds_barrier();                                 // slab dgifo(t) ready
       PT_MARK(1);
       if (*abortf) break;
@@ -476,6 +487,61 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
       PT_MARK(4);
     }
     PT_FLUSH(0);
+  } else if (wave == NKW) {
+    // =========================== P wave: own columns of P = out_diff W_r_m (:391's second term through :408) ===========================
+    // Same 4-row geometry as the contraction: A = rows of W_r_m^T (the tile's 4 cells, resident: R <= 512 = 4 chunks),
+    // B = 4 rows of out_diff per batch; lanes 12..15 end up with P[row 4b + (lane & 3)][cells 0..3].  Frames T and T-1
+    // before the first barrier, then one frame ahead of the owner's epilogue, entirely inside the time this wave would
+    // otherwise spend waiting at the barriers.  (pin == 0: the wave only keeps the barrier count.)
+    const int kg = lane >> 2, bj = lane & 3, R = a.R, rows = T * S;
+    float4 w0[TPW][4], w1[TPW][4];
+#pragma unroll
+    for (int tl = 0; tl < TPW; tl++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int k = 128 * i + 4 * kg, pc = ((int)blockIdx.x * TPW + tl) * 4 + bj;
+        const bool on = a.pin && pc < C;
+        w0[tl][i] = on && k < R ? *reinterpret_cast<const float4 *>(a.wmT + (size_t)pc * R + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        w1[tl][i] = on && k + 64 < R ? *reinterpret_cast<const float4 *>(a.wmT + (size_t)pc * R + k + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    int next = (rows + 3) / 4 - 1;                   // batches in descending row order
+    auto p_batches = [&](int row_lo) {               // every batch that holds a row >= row_lo
+      while (next >= 0 && 4 * next + 3 >= row_lo) {
+        const int row = 4 * next + bj;
+        const float *op = a.od + (size_t)(row < rows ? row : 0) * a.od_stride + 4 * kg;
+        float4 b0[4], b1[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = 128 * i + 4 * kg;
+          b0[i] = row < rows && k < R ? *reinterpret_cast<const float4 *>(op + 128 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+          b1[i] = row < rows && k + 64 < R ? *reinterpret_cast<const float4 *>(op + 128 * i + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int tl = 0; tl < TPW; tl++) {
+          f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float av[8] = {w0[tl][i].x, w0[tl][i].y, w0[tl][i].z, w0[tl][i].w, w1[tl][i].x, w1[tl][i].y, w1[tl][i].z, w1[tl][i].w};
+            const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
+          }
+          const f32x4 v = kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+          if (kg == 3 && row < rows) *reinterpret_cast<float4 *>(ldsP + (size_t)row * PLW + tl * 4) = make_float4(v.x, v.y, v.z, v.w);
+        }
+        next--;
+      }
+    };
+    if (a.pin) {
+      p_batches((T - 2) * S);
+      lds_barrier();
+    }
+    for (int t = T; t > 1; t--) {
+      if (a.pin) p_batches((t - 3) * S);             // frame t-2, read by the owner at step t-1
+      lds_barrier();
+      if (*abortf) break;
+      lds_barrier();
+    }
   } else {
     // =========================== sweeper: d_m(t) of every cell -> dgifo(t) into the slab ===========================
     // forward planes through buffer descriptors: the lane offset is cell*4 bytes, frame / stream / gate go into the scalar
@@ -489,7 +555,7 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
     BpttCarry kk[PCELL][4];
 #pragma unroll
     for (int j = 0; j < PCELL; j++) {
-      cell[j] = (wave - NKW) * 64 + lane + j * NSW;
+      cell[j] = (wave - NKW - 1) * 64 + lane + j * NSW;
       const int lc = cell[j] < C ? cell[j] : 0;
       mine[j] = cell[j] < C && (cell[j] >> 2) / TPW == (int)blockIdx.x;
       wpi[j] = a.pi[lc]; wpf[j] = a.pf[lc]; wpo[j] = a.po[lc];
@@ -503,6 +569,7 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
         }
       }
     }
+    if (a.pin) lds_barrier();                       // (P of the last two frames ready: the P wave)
     PT_DECL();
     for (int t = T; t >= 1; t--) {
       PT_MARK(5);
@@ -518,9 +585,9 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
           yg[j][s] = buf_f32(rs_g, voff[j], og); yi[j][s] = buf_f32(rs_g, voff[j], og + C * 4);
           yf[j][s] = buf_f32(rs_g, voff[j], og + 2 * C * 4); yo[j][s] = buf_f32(rs_g, voff[j], og + 3 * C * 4);
           yh[j][s] = buf_f32(rs_h, voff[j], oc); cpv[j][s] = buf_f32(rs_c, voff[j], oc - S * C * 4);
-          if (t == T) dm[j][s] = buf_f32(rs_p, voff[j], ((T - 1) * S + ss) * C * 4);          // d_m(T) = P(T): dgifo(T+1) = 0
+          if (t == T && !a.pin) dm[j][s] = buf_f32(rs_p, voff[j], ((T - 1) * S + ss) * C * 4);   // d_m(T) = P(T): dgifo(T+1) = 0
         }
-      if (t < T && !sweep_cells(a.gran + (size_t)(t & 1) * C * 4, C, S, epoch + (unsigned)t, cell, dm, t_start, a.nap0, a.nap)) {
+      if ((t < T || a.pin) && !sweep_cells(a.gran + (size_t)(t & 1) * C * 4, C, S, epoch + (unsigned)t, cell, dm, t_start, a.nap0, a.nap)) {
         *abortf = 1u;
         if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
       }
@@ -596,7 +663,8 @@ static PGeo pick_geo(int C, int nch) {              // backward: 4 K waves per t
   const int mc = pcdiv(nch, 4);
   for (int tpw : prefer) {
     if ((tpw != 1 && tpw != 2) || 4 * tpw >= waves || (C / 4) % tpw != 0 || C / 4 / tpw > 200 || mc > 9) continue;
-    const int pc = pcdiv(C, (waves - 4 * tpw) * 64);
+    if (4 * tpw + 1 >= waves) continue;
+    const int pc = pcdiv(C, (waves - 4 * tpw - 1) * 64);     // (one wave contracts P)
     if (pc > 4) continue;
     return PGeo{waves, tpw, mc <= 7 ? 7 : 9, pc};
   }
@@ -656,17 +724,26 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
   PDISPATCH_FWD(k_fwd_persist);
 }
 
-hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, unsigned long long *gran, unsigned *ctrl,
-                              hipStream_t st, LaunchProbe pr) {
+// P = out_diff W_r_m inside the backward launch: own columns in LDS (T*S rows x 4*tpw cells), rows of W_r_m^T in registers
+bool persist_p_in_kernel(const Dims &d) {
+  const PGeo g = pick_geo(d.C, pcdiv(4 * d.C, 128));
+  return g.tpw > 0 && d.R <= 512 && d.R % 4 == 0 && (size_t)d.T * d.S * 4 * g.tpw * sizeof(float) <= 32 * 1024;
+}
+
+hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, const float *out_diff, int od_stride,
+                              unsigned long long *gran, unsigned *ctrl, hipStream_t st, LaunchProbe pr) {
   PersistBwdArgs a;
-  a.C = d.C; a.S = d.S; a.T = d.T;
+  a.C = d.C; a.R = d.R; a.S = d.S; a.T = d.T;
+  a.pin = persist_p_in_kernel(d) && out_diff && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
+  if (!a.pin && !P) return hipErrorInvalidValue;
+  a.od = out_diff; a.od_stride = od_stride; a.wmT = p.wmT;
   a.nch = pcdiv(4 * d.C, 128);
   a.wpk = p.pk_fold; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.gran = gran; a.ctrl = ctrl;
   a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 0; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // (the second barrier already keeps the sweepers off the fabric)
   const PGeo g = pick_geo(d.C, a.nch);
   if (!g.tpw || !p.pk_fold) return hipErrorInvalidValue;
-  const size_t shm = (size_t)(4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4) * sizeof(float);
+  const size_t shm = (size_t)(4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4 + (a.pin ? d.T * d.S * 4 * g.tpw : 0)) * sizeof(float);
   const int grid = d.C / 4 / g.tpw;
   PDISPATCH_BWD(k_bwd_persist);
 }
