@@ -508,8 +508,9 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
     // step 1 closes over the CARRIED r (set by Reset / the previous minibatch, possibly under older weights): unfolded
     // gates kernel, r(0) mirrored into time block 0; steps 2..T close over m(t-1) through W_rm; r(1..T) in one GEMM
     if (e->fwd_persist) {                         // (all T steps in the one launch, step 1 on the natural matrices)
-      HIPCHK(launch_fwd_persist(d, p, in, in_stride, e->gran[0], e->pctrl, st, probe(e, "k_fwd_persist")));
+      HIPCHK(launch_fwd_persist(d, p, in, in_stride, out, out_stride, e->gran[0], e->pctrl, st, probe(e, "k_fwd_persist")));
       e->persist_dirty = true;
+      if (persist_r_in_kernel(d)) return KLSTM_OK;  // (r(1..T), the output rows and the carried r come out of the same launch)
     } else {
       HIPCHK(launch_gates_step(d, p, 1, fx, in, in_stride, st, probe(e, "k_gates_step")));
       for (int t = 2; t <= T; t++)

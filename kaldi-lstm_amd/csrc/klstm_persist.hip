@@ -50,11 +50,14 @@ struct PersistFwdArgs {
   int nchm, nch;                  // 32-wide chunks over C (the m part) and in total (m + x)
   const float4 *wpk;              // packed W_rm (the m chunks of the folded gates operand): [C/4 tiles][nch][2][64]
   const float *wr, *wx;           // natural W_gifo_r [4C x R], W_gifo_x [4C x I] (step 1, and the x chunks of every step)
+  const float *wm;                // natural W_r_m [R x C] (rin)
+  int rin;                        // 1: r(t) = W_r_m m(t) (:312) is contracted here too (rr plane, out rows, prev_r); 0: by the caller
+  float *out; int out_stride;     // output rows [T*S x R] (:328) (rin)
   const float *bias, *pi, *pf, *po;
   float *gifo, *cc, *hh, *mm, *rr; // activation planes, time-major row blocks of S
   const float *x; int x_stride;   // input rows [T*S x I]
   float *prev_c;                  // carried c [S x C]: read at step 1 (:231), written at step T (:331)
-  const float *prev_r;            // carried r [S x R]: read at step 1
+  float *prev_r;                  // carried r [S x R]: read at step 1, written with r(T) (:331) (rin)
   unsigned long long *gran;       // [2][C*4] granules, cell-major (4 stream slots per cell)
   unsigned *ctrl;                 // [0] epoch, [1] finished workgroups, [2] status (0 = ok)
   int nap0, nap;                  // sweepers sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
@@ -183,7 +186,8 @@ __device__ __forceinline__ void finish(unsigned *ctrl, unsigned epoch, int T) {
 // read of the step is issued before the first MFMA.  Returns the gate pre-activations g,i,f,o of (cell, stream lane&3) in
 // lanes 12..15.
 template <int NCHUNK>
-__device__ __forceinline__ f32x4 cell_contract(const float4 (&a0)[NCHUNK], const float4 (&a1)[NCHUNK], const float *slab_row, int kg) {
+__device__ __forceinline__ f32x4 cell_contract(const float4 (&a0)[NCHUNK], const float4 (&a1)[NCHUNK], const float *slab_row, int kg,
+                                               int *read_flag = nullptr, int flag_value = 0) {
   float4 b0[NCHUNK], b1[NCHUNK];
 #pragma unroll
   for (int i = 0; i < NCHUNK; i++) {
@@ -191,6 +195,10 @@ __device__ __forceinline__ f32x4 cell_contract(const float4 (&a0)[NCHUNK], const
     b0[i] = *reinterpret_cast<const float4 *>(bp); b1[i] = *reinterpret_cast<const float4 *>(bp + 64);
   }
   __builtin_amdgcn_sched_barrier(0);                 // (otherwise the scheduler sinks every read next to its MFMAs: one LDS round trip per chunk)
+  if (read_flag) {                                   // tell the slab's writers that this wave holds its copy
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __hip_atomic_store(read_flag, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
   for (int i = 0; i < NCHUNK; i++) {
@@ -199,7 +207,7 @@ __device__ __forceinline__ f32x4 cell_contract(const float4 (&a0)[NCHUNK], const
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
   }
-  return kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));   // the 16 k-groups of a (gate, stream) pair
+  return kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));   // the 16 k-groups of a (row, stream) pair
 }
 
 // 128-wide chunks of the UNFOLDED step-1 operand [r(0) | pad | x(1)] (K = RP + I, RP = R rounded up to 32) that go with
@@ -208,7 +216,7 @@ constexpr int persist_maxu(int maxc) { return maxc == 7 ? 5 : maxc; }
 
 template <int TPW, int MAXC, int PNW, int PCELL>
 __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
-  constexpr int PNT = PNW * 64, NCW = 4 * TPW, NSW = (PNW - NCW) * 64, MAXU = persist_maxu(MAXC);
+  constexpr int PNT = PNW * 64, NCW = 4 * TPW, NSW = (PNW - NCW - 1) * 64, MAXU = persist_maxu(MAXC);   // cell waves, one projection wave, sweepers
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C, S = a.S, T = a.T, I = a.I, R = a.R, nch = a.nch;
   const int RP = (R + KCH - 1) / KCH * KCH;          // x columns of the step-1 slab start here (the layout of the packed gates operand)
@@ -218,17 +226,19 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
   float *ldsB = lds;                                 // [4][LDB]: row s = [ m(t-1)[s][0..C) | pad | x(t)[s][0..I) | pad ]
   float *ldsU = lds + 4 * LDB;                       // [4][LDU]: row s = [ r(0)[s][0..R) | pad | x(1)[s][0..I) | pad ]   (step 1 only)
   unsigned *abortf = reinterpret_cast<unsigned *>(ldsU + 4 * LDU);
+  int *projf = reinterpret_cast<int *>(abortf + 1);  // last step whose slab the projection wave has read
+  const bool proj_on = a.rin && (int)blockIdx.x * 4 < R;   // this workgroup contracts rows 4*blockIdx .. +3 of W_r_m
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long t_start = wall_clock64();
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // zero both slabs once: pad columns and rows of absent streams stay zero for the whole launch
   for (int i = tid; i < 4 * (LDB + LDU); i += PNT) lds[i] = 0.f;
-  if (tid == 0) *abortf = 0u;
+  if (tid == 0) { *abortf = 0u; *projf = 0; }
   __syncthreads();
   PT_DECL();
 
-  // The two roles run SEPARATE loops with the same barrier sequence (one lds_barrier per step, an abort check behind it):
+  // The roles run SEPARATE loops with the same barrier sequence (one lds_barrier per step, an abort check behind it):
   // inside one loop body the register allocator keeps the resident weights of the cell waves AND the sweep state of the
   // sweepers alive in every wave.
   if (wave < NCW) {
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       ao += wpo * c;                               // :303
       const float go = k_sigmoid(ao);              // :306
       const float m = h * go;                      // :309
-      if (t < T) publish(a.gran + (size_t)(t & 1) * C * 4, e_cell * 4 + es, epoch + (unsigned)t, m);
+      if (t < T || a.rin) publish(a.gran + (size_t)(t & 1) * C * 4, e_cell * 4 + es, epoch + (unsigned)t, m);   // (m(T): for r(T) only)
       float *gp = a.gifo + e_row * 4 * C + e_cell;
       gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
       a.cc[e_row * C + e_cell] = c;
@@ -315,30 +325,61 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       PT_MARK(2);
       cell_math(1, v);
       PT_MARK(4);
+    bool dead = false;
     for (int t = 2; t <= T; t++) {
       PT_MARK(5);
       lds_barrier();                                 // slab of step t ready
       PT_MARK(1);
-      if (*abortf) break;                            // (plain LDS read: the asm barrier's memory clobber forces the reload; a volatile
+      if (*abortf) { dead = true; break; }           // (plain LDS read: the asm barrier's memory clobber forces the reload; a volatile
                                                      //  read through the generic pointer became a FLAT load behind vmcnt(0))
       const f32x4 v = cell_contract<MAXC>(a0, a1, ldsB + bj * LDB, kg);
       PT_MARK(2);                                    // contraction + k-group sum
       cell_math(t, v);
       PT_MARK(4);                                    // cell math + stores
     }
+    if (a.rin && !dead) lds_barrier();               // (slab of m(T) for the projection wave)
+  } else if (wave == NCW) {
+    // =========================== projection wave: r(t-1) = W_r_m m(t-1) (:312) from the slab of step t ===========================
+    // Rows 4*blockIdx .. +3 of W_r_m resident (same 4-row geometry, K = C), the first R/4 workgroups; everything it does
+    // sits off the critical path (the cell waves read the same slab at the same time).  Writes the r plane, the output rows
+    // (:328) and, for frame T, the carried r (:331).  rin == 0 / other workgroups: keeps the barrier count only.
+    const int kg = lane >> 2, bj = lane & 3;
+    const int prow = (int)blockIdx.x * 4 + bj;
+    float4 a0[MAXC], a1[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; i++) {
+      const int k = 128 * i + 4 * kg;
+      a0[i] = proj_on && k < C ? *reinterpret_cast<const float4 *>(a.wm + (size_t)prow * C + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      a1[i] = proj_on && k + 64 < C ? *reinterpret_cast<const float4 *>(a.wm + (size_t)prow * C + k + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    lds_barrier();                                   // step 1
+    for (int t = 2; t <= T + (a.rin ? 1 : 0); t++) {
+      lds_barrier();
+      if (*abortf) break;
+      if (!proj_on) continue;
+      // (columns >= C of the slab row hold x(t) and pad: their weights are zero)
+      const f32x4 v = cell_contract<MAXC>(a0, a1, ldsB + bj * LDB, kg, projf, t);
+      if (kg == 3 && bj < S) {                       // lanes 12..15: stream bj, components = rows 4*blockIdx .. +3
+        const int f = t - 1, g4 = (int)blockIdx.x * 4;
+        *reinterpret_cast<float4 *>(a.rr + ((size_t)f * S + bj) * R + g4) = make_float4(v.x, v.y, v.z, v.w);
+        float *op = a.out + ((size_t)(f - 1) * S + bj) * a.out_stride + g4;
+        op[0] = v.x; op[1] = v.y; op[2] = v.z; op[3] = v.w;
+        if (f == T) *reinterpret_cast<float4 *>(a.prev_r + (size_t)bj * R + g4) = make_float4(v.x, v.y, v.z, v.w);
+      }
+    }
   } else {
     // =========================== sweeper: the B operand of every step into the slab ===========================
-    const int sidx = (wave - NCW) * 64 + lane;       // rank among the sweeping threads
+    const int sidx = (wave - NCW - 1) * 64 + lane;   // rank among the sweeping threads
     int cell[PCELL];
 #pragma unroll
     for (int j = 0; j < PCELL; j++) cell[j] = sidx + j * NSW;
     const int nx4 = I / 4;                           // float4 per x row; the first sweeper wave also stages x(t)
     const bool x_on = sidx < S * nx4;
     const int xs = x_on ? sidx / nx4 : 0, xk = x_on ? (sidx % nx4) * 4 : 0;
-    for (int t = 1; t <= T; t++) {
+    for (int t = 1; t <= T + (a.rin ? 1 : 0); t++) {  // (rin: one more slab, m(T), for r(T))
       PT_MARK(5);
       float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (x_on) xv = *reinterpret_cast<const float4 *>(a.x + ((size_t)(t - 1) * S + xs) * a.x_stride + xk);
+      if (x_on && t <= T) xv = *reinterpret_cast<const float4 *>(a.x + ((size_t)(t - 1) * S + xs) * a.x_stride + xk);
       if (t == 1) {
         // step 1: the carried r(0) (:231, :275) into the unfolded slab, and into time block 0 of the r plane (BPTT reads it)
         for (int i = sidx; i < S * (R / 4); i += NSW) {
@@ -355,7 +396,9 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
           if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
         }
         // (the slab is free: the sweep only completes once every cell wave of THIS workgroup has published step t-1,
-        //  i.e. has finished reading the previous slab)
+        //  i.e. has finished reading the previous slab; the projection wave says so itself)
+        if (proj_on && t > 2)
+          while (__hip_atomic_load(projf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t - 1) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int j = 0; j < PCELL; j++)
           if (cell[j] < C) {
@@ -649,7 +692,8 @@ static PGeo pick_geo_fwd(int C, int nch, int ku = 0) {   // ku: width of the ste
   const int n128 = pcdiv(nch * KCH, 128);
   for (int tpw : prefer) {
     if ((tpw != 1 && tpw != 2) || 4 * tpw >= waves || (C / 4) % tpw != 0 || C / 4 / tpw > 200 || n128 > 12) continue;
-    const int pc = pcdiv(C, (waves - 4 * tpw) * 64);
+    if (4 * tpw + 1 >= waves) continue;
+    const int pc = pcdiv(C, (waves - 4 * tpw - 1) * 64);     // (one wave projects)
     if (pc > 4) continue;
     const int maxc = n128 <= 7 ? 7 : n128 <= 9 ? 9 : 12;
     if (pcdiv(ku, 128) > persist_maxu(maxc)) continue;
@@ -708,18 +752,25 @@ static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t
     return hipErrorInvalidValue;                                                                                \
   } while (0)
 
-hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, int in_stride, unsigned long long *gran,
-                              unsigned *ctrl, hipStream_t st, LaunchProbe pr) {
+// r(t) = W_r_m m(t) inside the forward launch: 4 rows of W_r_m per workgroup on its projection wave
+bool persist_r_in_kernel(const Dims &d) {
+  const PGeo g = pick_geo_fwd(d.C, pcdiv(d.C, KCH) + pcdiv(d.I, KCH), pcdiv(d.R, KCH) * KCH + d.I);
+  return g.tpw > 0 && d.R % 4 == 0 && d.R / 4 <= d.C / 4 / g.tpw;
+}
+
+hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, int in_stride, float *out, int out_stride,
+                              unsigned long long *gran, unsigned *ctrl, hipStream_t st, LaunchProbe pr) {
   PersistFwdArgs a;
   a.C = d.C; a.I = d.I; a.R = d.R; a.S = d.S; a.T = d.T;
   a.nchm = pcdiv(d.C, KCH); a.nch = a.nchm + pcdiv(d.I, KCH);
-  a.wpk = p.pk_fold; a.wr = p.wr; a.wx = p.wx; a.bias = p.bias; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
+  a.wpk = p.pk_fold; a.wr = p.wr; a.wx = p.wx; a.wm = p.wm; a.bias = p.bias; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm; a.rr = p.rr;
   a.x = in; a.x_stride = in_stride; a.prev_c = p.prev_c; a.prev_r = p.prev_r; a.gran = gran; a.ctrl = ctrl;
+  a.rin = out && persist_r_in_kernel(d); a.out = out; a.out_stride = out_stride;
   a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 9; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // measured: tools/persist_anatomy
   const PGeo g = pick_geo_fwd(d.C, a.nch, pcdiv(d.R, KCH) * KCH + d.I);
   if (!g.tpw || !p.pk_fold || (reinterpret_cast<uintptr_t>(in) & 15) || in_stride % 4 != 0) return hipErrorInvalidValue;
-  const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4 * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);
+  const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4 * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);   // (+ abort flag, projection flag)
   const int grid = d.C / 4 / g.tpw;
   PDISPATCH_FWD(k_fwd_persist);
 }

@@ -29,7 +29,7 @@ int main(int argc, char **argv) {
     if (4 * tpw >= waves) continue;
     set_persist_waves(waves); set_persist_tpw(tpw);
     PersistFwdArgs a;
-    a.C = C; a.I = I; a.R = R; a.S = S; a.T = T; a.nchm = nchm; a.nch = nch; a.wpk = wpk; a.wr = wr; a.wx = wx; a.prev_r = pr0; a.rr = rr;
+    a.C = C; a.I = I; a.R = R; a.S = S; a.T = T; a.nchm = nchm; a.nch = nch; a.wpk = wpk; a.wr = wr; a.wx = wx; a.prev_r = pr0; a.rr = rr; a.wm = nullptr; a.rin = 0; a.out = nullptr; a.out_stride = 0;
     a.bias = vecs; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
     a.gifo = gifo; a.cc = cc; a.hh = hh; a.mm = mm; a.x = x; a.x_stride = I; a.prev_c = cs; a.gran = gran; a.ctrl = ctrl; a.dbg = dbg; a.nap0 = nap0; a.nap = nap;
     const PGeo g = pick_geo_fwd(C, nch, (R + 31) / 32 * 32 + I);
