@@ -864,6 +864,12 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else set_persist_waves(value);
     return KLSTM_OK;
   }
+  if (!strcmp(key, "fold_direct")) {             // 0: the fold product on the generic 64x64-tile kernel (A-B; process-wide)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    set_fold_direct(value);
+    e->fold_dirty = true;
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "fuse_x")) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);

@@ -1,0 +1,250 @@
+// kaldi-lstm_amd/csrc/klstm_fold.hip -- the fold product W_rm = W_gifo_r W_r_m (4C x C over K = R, fp32 MFMA), once per Update.
+//
+// The recurrence of ...streams.h substitutes r(t-1) = W_r_m m(t-1) (:312) into the gates pre-activation (:275):
+// W_gifo_r r(t-1) = (W_gifo_r W_r_m) m(t-1).  This product is the largest single piece of work outside the chain
+// (2.6 GFLOP at 800/512: 16.7 us at the fp32 MFMA peak), and the generic 64x64-tile kernel (klstm_kernels.hip k_gemm)
+// loses a third of it to tile quantisation alone: 650 tiles over 256 CUs = 3 tiles on the slowest CU against 2.54 on
+// average, on top of a single-buffered LDS pipeline (tools/fold_probe.hip: 4.0 us per 64-wide K tile against 3.1 us for
+// three tiles' MFMAs).
+//
+// Here the tile is shaped to the chip instead: one WAVE owns 32 x 16*NI outputs (2 x NI blocks of v_mfma_f32_16x16x4_f32),
+// a workgroup is 2 x 2 waves, and NI is picked so that the grid is a whole number of rounds of 256 workgroups
+// (800/512: NI = 5 -> 50 x 5 = 250 workgroups of 64 x 160, ONE wave per SIMD, 10 blocks each -- 97.7 % balance).
+// No LDS in the K loop and no barrier anywhere: both operands are k-contiguous in memory (A = rows of W_gifo_r,
+// B = rows of W_r_m^T), so lane (i16, kg) loads the 32 bytes at k = 32c + 8kg of ITS row and feeds MFMA steps e = 0..7 with
+// the eight components -- the same k bijection for A and B, every k exactly once.  The four k-groups of a row together
+// consume one whole 128-byte line per chunk: with 16-byte pieces (chunks of 16 k) every line was fetched by two different
+// chunks, the 57 KB in flight per CU do not survive in a 32 KB L1, and the kernel ran at the L2's pace (35 us).
+// 2*(2 + NI) loads per 8*2*NI MFMAs, one between every two groups of NI MFMAs; a register ring of FD chunks keeps >= 2
+// chunks (5k MFMA cycles) of loads in flight; the two waves that share rows / columns meet in the CU's L1.
+// Measured (tools/fold_probe.hip, 800/512): K loop 24.1 us = 42.5 cycles per MFMA against 33.0 with the refills removed
+// and 32.0 in a bare MFMA loop (tools/mfma_peak.hip: 140 TFLOP/s at 2.22 GHz on random data) -- every 1 KB load
+// instruction costs ~57 cycles of the SIMD's MFMA issue wherever it is placed, wherever its data comes from (re-reading
+// chunk 0 out of L1: 42.0), with one or two waves per SIMD, with the K walk rotated per workgroup against L2 channel
+// hot spots.  Whole launch 33.8 us against 38.6 us for the tiled kernel.
+// Epilogue: rows are read in gates-packed order (logical row 4*cell + gate <- stored row gate*C + cell) and the tile goes
+// straight into the two packed operands of the folded chain (through a wave-private LDS transpose, no workgroup barrier):
+//   pk1  [W_rm | W_x] gates operand   [C/4 tiles][nch1 chunks of 32][2][64] float4, float4 = 4 consecutive k of one row
+//   pk2  W_rm^T, 4-row geometry        [C/4 tiles][nch2 chunks of 128][2][64] float4, float4 = 4 consecutive cells of one gate
+// (layouts: klstm_kernels.hip k_gates_v / k_dmf_v; klstm_persist.hip reads the same arrays).
+#include "klstm_kernels.h"
+#include "klstm_math.h"
+
+#include <hip/hip_ext.h>
+
+namespace klstm {
+
+#pragma clang fp contract(off)
+
+struct FoldArgs {
+  int C, R;
+  const float *wr;     // W_gifo_r [4C x R], rows in g,i,f,o blocks of C
+  const float *wmT;    // W_r_m^T  [C x R]
+  float4 *pk1; int nch1;
+  float4 *pk2; int nch2;
+  int nbn;             // workgroups along N
+  int nwg;
+#ifdef KLSTM_FOLD_TIMING
+  int kscale;          // 1; 0 = every refill re-reads chunk 0 (timing experiment: same instruction stream, no new lines)
+  long long *dbg;      // per workgroup: shader clocks / wall ticks of the K loop and of the whole kernel (tools/fold_probe.hip)
+#endif
+};
+
+constexpr int FD = 4;          // chunks of 32 k in the register ring (R % (32*FD) == 0: the K loop has no conditional loads --
+                               // with them hipcc drains the whole ring, s_waitcnt vmcnt(0), at the top of every iteration)
+
+template <int NI>
+__global__ __launch_bounds__(256) void k_fold_direct(FoldArgs a) {
+  constexpr int MI = 2, WN = 16 * NI, NWAVE = 4;       // wave tile 32 x WN, 2 x 2 waves
+  constexpr int FLD = 16 * MI + 4;                     // LDS row stride of the epilogue transpose (floats): 16-byte aligned rows + pad
+  __shared__ __attribute__((aligned(16))) float Cs[NWAVE][WN * FLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int C = a.C, R = a.R, nchunk = R / 32;
+  // XCD-aware order (workgroup w lands on XCD w % 8): XCD x gets a contiguous m-major range, i.e. a few row panels of A
+  // and all of B in its own L2
+  const int cpx = (a.nwg + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * cpx + (int)(blockIdx.x >> 3);
+  if (b >= a.nwg) return;
+#ifdef KLSTM_FOLD_TIMING
+  const long long t_c0 = clock64(), t_w0 = wall_clock64();
+#endif
+  const int m0 = (b / a.nbn) * 64 + (wave >> 1) * 32, n0 = (b % a.nbn) * (2 * WN) + (wave & 1) * WN;
+
+  const float *ap[MI], *bp[NI];
+  bool aok[MI], bok[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    const int x = m0 + 16 * mi + i16;                  // logical row 4*cell + gate
+    aok[mi] = (x >> 2) < C;
+    ap[mi] = a.wr + (size_t)(aok[mi] ? (x & 3) * C + (x >> 2) : 0) * R + 8 * kg;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) {
+    const int n = n0 + 16 * ni + i16;
+    bok[ni] = n < C;
+    bp[ni] = a.wmT + (size_t)(bok[ni] ? n : 0) * R + 8 * kg;
+  }
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = (f32x4){0, 0, 0, 0};
+
+  float4 ra[FD][MI][2], rb[FD][NI][2];
+  auto load = [&](int d, int c) {
+    const int co = 32 * c;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+      ra[d][mi][0] = *reinterpret_cast<const float4 *>(ap[mi] + co);
+      ra[d][mi][1] = *reinterpret_cast<const float4 *>(ap[mi] + co + 4);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+      rb[d][ni][0] = *reinterpret_cast<const float4 *>(bp[ni] + co);
+      rb[d][ni][1] = *reinterpret_cast<const float4 *>(bp[ni] + co + 4);
+    }
+  };
+  // One stage = the 8*2*NI MFMAs of the chunk in ring slot d, with the 2*(2+NI) loads that refill slot dl (the chunk
+  // consumed by the PREVIOUS stage) spread between them, one load per NI MFMAs.  A wave issues in order and this kernel
+  // runs one wave per SIMD: 14 loads in a burst hold the issue port for ~800 cycles per chunk while the MFMA pipe drains
+  // (measured: 41.8 cycles per MFMA instead of 32); one load between two groups of MFMAs disappears in their shadow.
+  auto stage = [&](int d, int dl, int cl, bool refill) {
+    float av[MI][8], bv[NI][8];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        av[mi][4 * h] = ra[d][mi][h].x; av[mi][4 * h + 1] = ra[d][mi][h].y; av[mi][4 * h + 2] = ra[d][mi][h].z; av[mi][4 * h + 3] = ra[d][mi][h].w;
+      }
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        bv[ni][4 * h] = rb[d][ni][h].x; bv[ni][4 * h + 1] = rb[d][ni][h].y; bv[ni][4 * h + 2] = rb[d][ni][h].z; bv[ni][4 * h + 3] = rb[d][ni][h].w;
+      }
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) acc[mi][ni] = MFMA16(av[mi][e], bv[ni][e], acc[mi][ni]);
+        // the 2 * (MI + NI) refill loads, spread evenly over the 8 * MI groups of NI MFMAs
+        constexpr int NLOAD = 2 * (MI + NI), NSLOT = 8 * MI;
+        const int slot = e * MI + mi;
+#pragma unroll
+        for (int l = slot * NLOAD / NSLOT; l < (slot + 1) * NLOAD / NSLOT; l++) {
+          if (!refill) break;
+          const int row = l >> 1, h = l & 1;
+#ifdef KLSTM_FOLD_TIMING
+          const int co = 32 * cl * (a.kscale != 0);        // (0: every refill re-reads chunk 0, timing experiment)
+#else
+          const int co = 32 * cl;
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+          if (row < MI) ra[dl][row][h] = *reinterpret_cast<const float4 *>(ap[row] + co + 4 * h);
+          else rb[dl][row - MI][h] = *reinterpret_cast<const float4 *>(bp[row - MI] + co + 4 * h);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+  };
+#ifdef KLSTM_FOLD_TIMING
+  const long long t_c1 = clock64(), t_w1 = wall_clock64();
+#endif
+#pragma unroll
+  for (int d = 0; d < FD - 1; d++) load(d, d);
+  // chunk c lives in slot c % FD; stage c refills slot (c - 1) % FD with chunk c + FD - 1
+  stage(0, FD - 1, FD - 1, true);
+  int c0 = 1;
+  for (; c0 + 2 * FD - 1 <= nchunk; c0 += FD) {        // stages c0 .. c0+FD-1, all of them with a refill (chunk <= nchunk - 1)
+#pragma unroll
+    for (int j = 0; j < FD; j++) stage((1 + j) % FD, j % FD, c0 + j + FD - 1, true);
+  }
+  // the last FD - 1 stages (R % (32*FD) == 0: c0 == nchunk - FD + 1 here): nothing left to request
+#pragma unroll
+  for (int j = 0; j < FD - 1; j++) stage((1 + j) % FD, 0, 0, false);
+#ifdef KLSTM_FOLD_TIMING
+  const long long t_c2 = clock64(), t_w2 = wall_clock64();
+#endif
+
+  // ---- epilogue: wave-private transpose through LDS.  acc[mi][ni] of lane (i16, kg) = rows 16mi + 4kg + (0..3) at
+  // column 16ni + i16; Cs[column][row] makes that one 16-byte store.  Rows / columns past the operand were fed row 0 /
+  // column 0 of the inputs and are simply not written out.
+  float *cs = Cs[wave];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+      *reinterpret_cast<float4 *>(cs + (16 * ni + i16) * FLD + 16 * mi + 4 * kg) =
+          make_float4(acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (same wave reads it back: program order on the LDS queue is enough, the
+                                                       //  wait only keeps the compiler from hoisting the reads)
+  const int cell0 = m0 >> 2;
+  // gates operand: piece = (16-row tile tl, column quad nq, row i): 16 consecutive float4 (256 B) per (tl, nq)
+#pragma unroll
+  for (int it = 0; it < MI * NI; it++) {
+    const int tl = it / NI, nq = (it % NI) * 4 + kg, i = i16;
+    const int nl = 4 * nq, n = n0 + nl, cell = cell0 + tl * 4 + (i >> 2);
+    const float *cp = cs + nl * FLD + tl * 16 + i;
+    const float4 v = make_float4(cp[0], cp[FLD], cp[2 * FLD], cp[3 * FLD]);
+    if (cell < C && n < C)
+      a.pk1[(((size_t)(cell >> 2) * a.nch1 + (n >> 5)) * 2 + ((n & 7) >> 2)) * 64 + ((n & 31) >> 3) * 16 + i] = v;
+  }
+  // d_m operand: piece = (column quad ct, gate, cell quad kq, cq = column % 4): 4 cells of one gate at one column
+#pragma unroll
+  for (int it = 0; it < 2 * NI; it++) {
+    const int cq = lane & 3, kq = (lane >> 2) & 1, gate = (lane >> 3) & 3, ct = it * 2 + (lane >> 5);
+    const int c = n0 + ct * 4 + cq, cell = cell0 + kq * 4;
+    const float *cp = cs + (ct * 4 + cq) * FLD + kq * 16 + gate;
+    const float4 v = make_float4(cp[0], cp[4], cp[8], cp[12]);
+    const int k = gate * C + cell;
+    if (c < C && cell < C)
+      a.pk2[(((size_t)(c >> 2) * a.nch2 + (k >> 7)) * 2 + ((k >> 6) & 1)) * 64 + ((k & 63) >> 2) * 4 + cq] = v;
+  }
+#ifdef KLSTM_FOLD_TIMING
+  if (tid == 0) {
+    long long *q = a.dbg + (size_t)blockIdx.x * 8;
+    q[0] = t_c2 - t_c1; q[1] = t_w2 - t_w1; q[2] = clock64() - t_c0; q[3] = wall_clock64() - t_w0; q[4] = t_w0;
+  }
+#endif
+}
+
+#ifdef KLSTM_FOLD_TIMING
+static long long *g_fold_dbg = nullptr;
+static int g_fold_kscale = 1;
+#endif
+static int g_fold_direct = 1;
+void set_fold_direct(int v) { g_fold_direct = v; }
+
+bool fold_direct_supported(const Dims &d) { return g_fold_direct != 0 && d.C % 4 == 0 && d.R % (32 * FD) == 0; }
+
+hipError_t launch_fold_direct(const Dims &d, const float *wr, const float *wmT, float *pk_fold[2], int nch1, int nch2,
+                              hipStream_t st, LaunchProbe pr) {
+  FoldArgs a;
+  a.C = d.C; a.R = d.R; a.wr = wr; a.wmT = wmT;
+  a.pk1 = reinterpret_cast<float4 *>(pk_fold[0]); a.nch1 = nch1;
+  a.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); a.nch2 = nch2;
+#ifdef KLSTM_FOLD_TIMING
+  a.dbg = g_fold_dbg; a.kscale = g_fold_kscale;
+#endif
+  const int nbm = (4 * d.C + 63) / 64;
+  // columns per workgroup: the choice with the fewest rounds of 256 workgroups x blocks per wave
+  int best = 0, best_cost = 0;
+  for (int ni : {5, 4}) {
+    const int nbn = (d.C + 32 * ni - 1) / (32 * ni), cost = ((nbm * nbn + 255) / 256) * ni;
+    if (!best || cost < best_cost) { best = ni; best_cost = cost; }
+  }
+  a.nbn = (d.C + 32 * best - 1) / (32 * best);
+  a.nwg = nbm * a.nbn;
+  const dim3 grid((a.nwg + 7) / 8 * 8), block(256);
+  if (best == 5) {
+    if (pr.start) hipExtLaunchKernelGGL(k_fold_direct<5>, grid, block, 0, st, pr.start, pr.stop, 0, a);
+    else hipLaunchKernelGGL(k_fold_direct<5>, grid, block, 0, st, a);
+  } else {
+    if (pr.start) hipExtLaunchKernelGGL(k_fold_direct<4>, grid, block, 0, st, pr.start, pr.stop, 0, a);
+    else hipLaunchKernelGGL(k_fold_direct<4>, grid, block, 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace klstm

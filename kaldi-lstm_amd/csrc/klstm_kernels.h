@@ -51,6 +51,11 @@ hipError_t launch_gates_step(const Dims &d, const FwdPtrs &p, int t, bool fuse_x
 //   launch_gates_step(..., fold = true)   a(t) = W_x x(t) + b + W_rm m(t-1), t >= 2
 //   launch_rbatch   r(1..T) = m(1..T) W_r_m^T -> rr rows, out rows, prev_r
 //   launch_dmf_step d_m(t) = P(t) + dgifo(t+1) W_rm with P = out_diff W_r_m, then the elementwise BPTT (:411-440)
+// the fold product on wave-owned 32 x 80 (or 64) tiles without LDS staging (klstm_fold.hip); launch_fold uses it when supported
+bool fold_direct_supported(const Dims &d);
+void set_fold_direct(int v);
+hipError_t launch_fold_direct(const Dims &d, const float *wr, const float *wmT, float *pk_fold[2], int nch1, int nch2,
+                              hipStream_t st, LaunchProbe pr = {});
 hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
                        hipStream_t st, LaunchProbe pr = {}, LaunchProbe pr2 = {});
                        // pk_fold zero-filled once by the caller; pack_x = false: launch_pack(.., foldx) already wrote the W_x chunks

@@ -2696,7 +2696,10 @@ hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT,
   g.pk1 = reinterpret_cast<float4 *>(pk_fold[0]); g.nch1 = cdiv(d.C, KCH) + cdiv(d.I, KCH);
   g.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); g.nch2 = cdiv(4 * d.C, KCH4);
   const dim3 grid(cdiv(cdiv(d.C, GT) * cdiv(4 * d.C, GT), 8) * 8), block(256);
-  auto first = [&]() -> hipError_t { KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g); };
+  auto first = [&]() -> hipError_t {
+    if (fold_direct_supported(d)) return launch_fold_direct(d, param_blob + o_wr, wmT, pk_fold, g.nch1, g.nch2, st, pr);   // klstm_fold.hip
+    KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
+  };
   hipError_t err = first();
   if (err != hipSuccess || !pack_x) return err;
   const long nx = (long)cdiv(d.C, 4) * cdiv(d.I, KCH) * 128;
