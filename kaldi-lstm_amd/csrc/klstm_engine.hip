@@ -77,7 +77,8 @@ struct klstm_engine {
   bool fwd_folded = false; // the last propagate ran the folded chain (its backpropagate follows suit)
   int use_persist = -1;    // weights-resident persistent chain (klstm_persist.hip): -1 auto (both directions, from 8 frames per
                            // stream), 0 off, 1 forward only, 2 forward and backward whenever the shape allows
-  bool fwd_persist = false; // the last propagate ran steps 2..T inside one persistent launch
+  bool fwd_persist = false; // the last propagate ran inside one persistent launch
+  int persist_tail = 1;     // option "persist_tail": d_r / in_diff inside the persistent backward launch (0: batched products after it)
   bool bwd_persist = false; // ... and its backpropagate runs steps T..1 inside one persistent launch
   bool persist_dirty = false;   // a persistent launch ran since the status words were last read back
   unsigned long long *gran[2] = {nullptr, nullptr};   // granule slots of the forward / backward chain
@@ -536,6 +537,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     const int M = T * d.S;
     // P = out_diff W_r_m for all frames; chain of T folded steps; then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r
     // (:391, feeds the W_r_m gradient :486) and in_diff = dgifo W_gifo_x (:457) as split-K products
+    bool tail_inside = false;
     const bool p_inside = e->bwd_persist && persist_p_in_kernel(d) && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
     int kl = 0;
     int ks = gemm_splitk_plan(M, d.C, d.R, &kl);
@@ -544,13 +546,16 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
                                           st, nullptr, 0, probe(e, "k_gemm_P"), probe(e, "k_reduce_P")));
     else HIPCHK(launch_gemm(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
     if (e->bwd_persist) {
-      HIPCHK(launch_bwd_persist(d, p, e->Pm, out_diff, od_stride, e->gran[1], e->pctrl + 4, st, probe(e, "k_bwd_persist")));
+      tail_inside = p_inside && e->persist_tail != 0 && persist_tail_in_kernel(d, in_diff != nullptr);
+      HIPCHK(launch_bwd_persist(d, p, e->Pm, out_diff, od_stride, in_diff, id_stride, tail_inside, e->gran[1], e->pctrl + 4, st,
+                                probe(e, "k_bwd_persist")));
       e->persist_dirty = true;
     } else {
       for (int t = T; t >= 1; t--) HIPCHK(launch_dmf_step(d, p, t, e->Pm, st, probe(e, "k_dmf_step")));
     }
-    HIPCHK(launch_bwd_tail(d, e->dgifo, wr, wx, out_diff, od_stride, e->dr, in_diff, id_stride, e->ws, st,
-                           probe(e, "k_gemm_tail"), probe(e, "k_reduce_tail")));
+    if (!tail_inside)
+      HIPCHK(launch_bwd_tail(d, e->dgifo, wr, wx, out_diff, od_stride, e->dr, in_diff, id_stride, e->ws, st,
+                             probe(e, "k_gemm_tail"), probe(e, "k_reduce_tail")));
     const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
     HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, defer ? 0.f : mmt, defer ? e->grads : e->corr, st,
                         probe(e, "k_grads")));
@@ -862,6 +867,12 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else if (!strcmp(key, "persist_nap0")) set_persist_nap(value, -2);
     else if (!strcmp(key, "persist_nap")) set_persist_nap(-2, value);
     else set_persist_waves(value);
+    return KLSTM_OK;
+  }
+  if (!strcmp(key, "persist_tail")) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    e->persist_tail = value;
     return KLSTM_OK;
   }
   if (!strcmp(key, "fold_direct")) {             // 0: the fold product on the generic 64x64-tile kernel (A-B; process-wide)

@@ -150,8 +150,10 @@ bool persist_r_in_kernel(const Dims &d);   // r(t) = W_r_m m(t), the output rows
 hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, int in_stride, float *out, int out_stride,
                               unsigned long long *gran, unsigned *ctrl, hipStream_t st, LaunchProbe pr = {});
 bool persist_p_in_kernel(const Dims &d);   // P = out_diff W_r_m computed inside the backward launch (then P may be null)
+bool persist_tail_in_kernel(const Dims &d, bool want_in_diff);   // d_r / in_diff contracted inside the backward launch
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, const float *out_diff, int od_stride,
-                              unsigned long long *gran, unsigned *ctrl, hipStream_t st, LaunchProbe pr = {});
+                              float *in_diff, int id_stride, bool tail_inside, unsigned long long *gran, unsigned *ctrl,
+                              hipStream_t st, LaunchProbe pr = {});
 void set_persist_tpw(int v);    // A-B knob: tiles (of 4 cells) per workgroup, 0 = automatic
 void set_persist_waves(int v);  // A-B knob: waves per workgroup (8, 12 or 16), 0 = automatic
 void set_persist_nap(int nap0, int nap);   // A-B knobs: sweeper sleep before the first pass (x256 clocks) / between passes (x64); -1 = default, -2 = keep

@@ -80,6 +80,11 @@ struct PersistBwdArgs {
   int pin;                        // 1: P = out_diff W_r_m is computed here (own columns, kept in LDS); 0: read from P
   const float *od; int od_stride; // out_diff rows [T*S x R]
   const float *wmT;               // W_r_m^T [C x R]
+  int din, I;                     // din: d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r (:391) and in_diff = dgifo W_gifo_x (:457) are
+                                  //      contracted here too, 4 columns per workgroup (bit 1: in_diff wanted)
+  const float *wrT, *wxT;         // W_gifo_r^T [R x 4C], W_gifo_x^T [I x 4C]
+  float *dr;                      // d_r plane [(T+2)*S x R], time-major row blocks
+  float *in_diff; int id_stride;  // [T*S x I]
   int nch;                        // 128-wide chunks over 4C
   const float4 *wpk;              // packed W_rm^T, 4-row geometry: [C/4 tiles][nch][2][64]
   const float *pi, *pf, *po;
@@ -452,17 +457,31 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C, S = a.S, T = a.T, nch = a.nch, K = 4 * a.C;
   float *ldsD = lds;                                 // [4][LDD]: dgifo(t) rows, natural g|i|f|o order; columns >= 4C stay zero
-  f32x4 *red = reinterpret_cast<f32x4 *>(lds + 4 * LDD);      // [NKW][4]
+  const int wslab = a.din ? 4 * LDD : 0;
+  float *ldsW = lds + 4 * LDD;                       // [4][LDD] (din): 4 rows of W_gifo_r^T / W_gifo_x^T, same column order
+  f32x4 *red = reinterpret_cast<f32x4 *>(lds + 4 * LDD + wslab);      // [NKW][4]
   unsigned *abortf = reinterpret_cast<unsigned *>(red + NKW * 4);
   constexpr int PLW = 4 * TPW;                       // own cells
+  int *dflag = reinterpret_cast<int *>(abortf + 1);  // lowest step whose slab the d_r contraction has read (counts down)
   float *ldsP = reinterpret_cast<float *>(abortf + 4);        // [T*S][PLW]: own columns of P = out_diff W_r_m (pin)
+  // the d_r / in_diff columns of this workgroup: 4 rows of W_gifo_r^T (workgroups 0 .. R/4-1), then of W_gifo_x^T
+  const int ngr = a.R / 4, ngx = (a.din & 2) ? a.I / 4 : 0;
+  const bool d_on = a.din && (int)blockIdx.x < ngr + ngx, d_isr = (int)blockIdx.x < ngr;
+  const int dcol = d_isr ? (int)blockIdx.x * 4 : ((int)blockIdx.x - ngr) * 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long t_start = wall_clock64();
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int i = tid; i < 4 * LDD; i += PNT) ldsD[i] = 0.f;
-  if (tid == 0) *abortf = 0u;
+  for (int i = tid; i < 4 * LDD + wslab; i += PNT) ldsD[i] = 0.f;
+  if (tid == 0) { *abortf = 0u; *dflag = T + 2; }
   __syncthreads();
+  if (d_on) {
+    const float *src = (d_isr ? a.wrT : a.wxT) + (size_t)dcol * K;
+    for (int i = tid; i < K; i += PNT) {             // K/4 float4 per row, 4 rows
+      const int row = i / (K / 4), k4 = i % (K / 4);
+      *reinterpret_cast<float4 *>(ldsW + row * LDD + 4 * k4) = *reinterpret_cast<const float4 *>(src + (size_t)row * K + 4 * k4);
+    }
+  }                                                  // (visible to the P wave behind the first barrier below)
 
   // separate loops per role, same barrier sequence (two lds_barriers per step, the abort check behind the first): see k_fwd_persist
   if (wave < NKW) {
@@ -493,13 +512,14 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
       // d_m(T) = P(T) (dgifo(T+1) = 0, :351) travels like every other step
       if (e_on) publish(a.gran + (size_t)(T & 1) * C * 4, e_cell * 4 + e_j, epoch + (unsigned)T, e_pl[(size_t)(T - 1) * S * PLW]);
     }
+    bool dead = false;
     for (int t = T; t > 1; t--) {
       PT_MARK(5);
       // P(t-1) for the epilogue: requested now, consumed after the contraction (frame t-1 is row block t-2 of P)
       const float pnext = !owner_wave ? 0.f : a.pin ? e_pl[(size_t)(t - 2) * S * PLW] : buf_f32(rs_p, e_offc, (t - 2) * S * C * 4);
       lds_barrier();                                 // slab dgifo(t) ready
       PT_MARK(1);
-      if (*abortf) break;
+      if (*abortf) { dead = true; break; }
       float4 b0[MAXC], b1[MAXC];
 #pragma unroll
       for (int i = 0; i < MAXC; i++) {
@@ -529,24 +549,15 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
       }
       PT_MARK(4);
     }
+    if (a.din && !dead) lds_barrier();               // (slab dgifo(1): in_diff of frame 1 only)
     PT_FLUSH(0);
   } else if (wave == NKW) {
     // =========================== P wave: own columns of P = out_diff W_r_m (:391's second term through :408) ===========================
-    // Same 4-row geometry as the contraction: A = rows of W_r_m^T (the tile's 4 cells, resident: R <= 512 = 4 chunks),
+    // Same 4-row geometry as the contraction: A = rows of W_r_m^T (the tile's 4 cells; R <= 512 = 4 chunks),
     // B = 4 rows of out_diff per batch; lanes 12..15 end up with P[row 4b + (lane & 3)][cells 0..3].  Frames T and T-1
     // before the first barrier, then one frame ahead of the owner's epilogue, entirely inside the time this wave would
     // otherwise spend waiting at the barriers.  (pin == 0: the wave only keeps the barrier count.)
     const int kg = lane >> 2, bj = lane & 3, R = a.R, rows = T * S;
-    float4 w0[TPW][4], w1[TPW][4];
-#pragma unroll
-    for (int tl = 0; tl < TPW; tl++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int k = 128 * i + 4 * kg, pc = ((int)blockIdx.x * TPW + tl) * 4 + bj;
-        const bool on = a.pin && pc < C;
-        w0[tl][i] = on && k < R ? *reinterpret_cast<const float4 *>(a.wmT + (size_t)pc * R + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        w1[tl][i] = on && k + 64 < R ? *reinterpret_cast<const float4 *>(a.wmT + (size_t)pc * R + k + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
     int next = (rows + 3) / 4 - 1;                   // batches in descending row order
     auto p_batches = [&](int row_lo) {               // every batch that holds a row >= row_lo
       while (next >= 0 && 4 * next + 3 >= row_lo) {
@@ -561,10 +572,18 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
         }
 #pragma unroll
         for (int tl = 0; tl < TPW; tl++) {
+          // (rows of W_r_m^T re-read per batch, L1/L2 hits: resident they would push the d_r ring below into scratch)
+          float4 w0[4], w1[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int k = 128 * i + 4 * kg, pc = ((int)blockIdx.x * TPW + tl) * 4 + bj;
+            w0[i] = pc < C && k < R ? *reinterpret_cast<const float4 *>(a.wmT + (size_t)pc * R + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w1[i] = pc < C && k + 64 < R ? *reinterpret_cast<const float4 *>(a.wmT + (size_t)pc * R + k + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
           f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            const float av[8] = {w0[tl][i].x, w0[tl][i].y, w0[tl][i].z, w0[tl][i].w, w1[tl][i].x, w1[tl][i].y, w1[tl][i].z, w1[tl][i].w};
+            const float av[8] = {w0[i].x, w0[i].y, w0[i].z, w0[i].w, w1[i].x, w1[i].y, w1[i].z, w1[i].w};
             const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
@@ -579,11 +598,64 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
       p_batches((T - 2) * S);
       lds_barrier();
     }
-    for (int t = T; t > 1; t--) {
-      if (a.pin) p_batches((t - 3) * S);             // frame t-2, read by the owner at step t-1
-      lds_barrier();
+    // d_r(T) = out_diff(T): dgifo(T+1) = 0 (:351, :391)
+    if (d_on && d_isr && kg == 3 && bj < S)
+      *reinterpret_cast<float4 *>(a.dr + ((size_t)T * S + bj) * R + dcol) =
+          *reinterpret_cast<const float4 *>(a.od + ((size_t)(T - 1) * S + bj) * a.od_stride + dcol);
+    const int nchw = (K + 127) / 128;
+    for (int t = T; t >= (a.din ? 1 : 2); t--) {
+      if (a.pin && t > 1) p_batches((t - 3) * S);    // frame t-2, read by the owner at step t-1
+      lds_barrier();                                 // slab dgifo(t) ready
       if (*abortf) break;
-      lds_barrier();
+      if (t > 1) lds_barrier();
+      // dgifo(t) against this workgroup's 4 rows of W_gifo_r^T: d_r(t-1) = out_diff(t-1) + dgifo(t) W_gifo_r (:391);
+      // against 4 rows of W_gifo_x^T: in_diff(t) (:457).  Both operands in LDS, behind the second barrier: the K waves
+      // are done with the slab, the sweepers are out on the fabric, and they ask dflag before they overwrite it.
+      if (d_on && (t > 1 || !d_isr)) {
+        // groups of 2 chunks, double-buffered: the next group's 8 LDS reads in flight under the current group's 16 MFMAs (a rolled
+        // read -> MFMA loop pays one LDS round trip per chunk: 2.2 us per step, and the sweepers then wait for dflag)
+        f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        const float *ap = ldsW + bj * LDD + kg * 4, *bp = ldsD + bj * LDD + kg * 4;
+        float4 qa[2][2][2], qb[2][2][2];
+        auto dload = [&](int u, int g) {
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            qa[u][c][0] = *reinterpret_cast<const float4 *>(ap + (2 * g + c) * 128); qa[u][c][1] = *reinterpret_cast<const float4 *>(ap + (2 * g + c) * 128 + 64);
+            qb[u][c][0] = *reinterpret_cast<const float4 *>(bp + (2 * g + c) * 128); qb[u][c][1] = *reinterpret_cast<const float4 *>(bp + (2 * g + c) * 128 + 64);
+          }
+        };
+        auto dmul = [&](int u) {
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            const float av[8] = {qa[u][c][0].x, qa[u][c][0].y, qa[u][c][0].z, qa[u][c][0].w, qa[u][c][1].x, qa[u][c][1].y, qa[u][c][1].z, qa[u][c][1].w};
+            const float bv[8] = {qb[u][c][0].x, qb[u][c][0].y, qb[u][c][0].z, qb[u][c][0].w, qb[u][c][1].x, qb[u][c][1].y, qb[u][c][1].z, qb[u][c][1].w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], bv[j], acc[j & 3], 0, 0, 0);
+          }
+        };
+        const int ngrp = (nchw + 1) / 2;             // (a chunk past the operand reads zero columns of both slabs: 4*MAXC chunks exist)
+        dload(0, 0);
+        for (int g = 0; g < ngrp; g += 2) {
+          if (g + 1 < ngrp) dload(1, g + 1);
+          dmul(0);
+          if (g + 2 < ngrp) dload(0, g + 2);
+          if (g + 1 < ngrp) dmul(1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(dflag, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const f32x4 v = kgroup_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        if (kg == 3 && bj < S) {                     // lanes 12..15: stream bj, components = columns dcol .. +3
+          if (d_isr) {
+            const float4 o = *reinterpret_cast<const float4 *>(a.od + ((size_t)(t - 2) * S + bj) * a.od_stride + dcol);
+            *reinterpret_cast<float4 *>(a.dr + ((size_t)(t - 1) * S + bj) * R + dcol) = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+          } else {
+            float *ip = a.in_diff + ((size_t)(t - 1) * S + bj) * a.id_stride + dcol;
+            ip[0] = v.x; ip[1] = v.y; ip[2] = v.z; ip[3] = v.w;
+          }
+        }
+      } else if (d_on) {
+        __hip_atomic_store(dflag, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
   } else {
     // =========================== sweeper: d_m(t) of every cell -> dgifo(t) into the slab ===========================
@@ -635,6 +707,8 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
         if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
       }
       PT_MARK(0);                                    // plane loads + sweep
+      if (d_on && t < T)                             // the d_r contraction still reads the slab of step t+1?
+        while (__hip_atomic_load(dflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > t + 1) __builtin_amdgcn_s_sleep(1);
       // elementwise BPTT of frame t (:411-440), replicated in every workgroup
 #pragma unroll
       for (int j = 0; j < PCELL; j++)
@@ -644,7 +718,7 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
           const float4 dg = bptt_cell(dm[j][s], yg[j][s], yi[j][s], yf[j][s], yo[j][s], yh[j][s], cpv[j][s], wpi[j], wpf[j], wpo[j],
                                       kk[j][s], d_c);
           if (cell[j] < C && s < S) {
-            if (t > 1) {                             // B operand of the contraction
+            if (t > 1 || a.din) {                    // B operand of the contraction (t == 1: of in_diff(1) only)
               float *lp = ldsD + s * LDD + cell[j];
               lp[0] = dg.x; lp[C] = dg.y; lp[2 * C] = dg.z; lp[3 * C] = dg.w;
             }
@@ -657,10 +731,10 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
           }
         }
       PT_MARK(2);                                    // elementwise + slab / plane stores
-      if (t == 1) break;
+      if (t == 1 && !a.din) break;
       lds_barrier();                                 // slab ready
       PT_MARK(1);
-      if (*abortf) break;
+      if (*abortf || t == 1) break;
       lds_barrier();                                 // (partial tiles ready: nothing to do here but keep the count; the K waves
                                                      //  contract meanwhile, and polling the fabric now would only slow them down)
       PT_MARK(3);
@@ -781,20 +855,32 @@ bool persist_p_in_kernel(const Dims &d) {
   return g.tpw > 0 && d.R <= 512 && d.R % 4 == 0 && (size_t)d.T * d.S * 4 * g.tpw * sizeof(float) <= 32 * 1024;
 }
 
+// d_r and in_diff inside the backward launch: 4 columns per workgroup on its P wave, operand rows in LDS
+bool persist_tail_in_kernel(const Dims &d, bool want_in_diff) {
+  const PGeo g = pick_geo(d.C, pcdiv(4 * d.C, 128));
+  if (!g.tpw || d.R % 4 != 0 || d.I % 4 != 0 || d.C % 4 != 0) return false;
+  const size_t lds = (size_t)(8 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 16 + 4 + (persist_p_in_kernel(d) ? d.T * d.S * 4 * g.tpw : 0)) * sizeof(float);
+  return d.R / 4 + (want_in_diff ? d.I / 4 : 0) <= d.C / 4 / g.tpw && lds <= 160 * 1024;
+}
+
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, const float *out_diff, int od_stride,
-                              unsigned long long *gran, unsigned *ctrl, hipStream_t st, LaunchProbe pr) {
+                              float *in_diff, int id_stride, bool tail_inside, unsigned long long *gran, unsigned *ctrl,
+                              hipStream_t st, LaunchProbe pr) {
   PersistBwdArgs a;
   a.C = d.C; a.R = d.R; a.S = d.S; a.T = d.T;
   a.pin = persist_p_in_kernel(d) && out_diff && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
   if (!a.pin && !P) return hipErrorInvalidValue;
   a.od = out_diff; a.od_stride = od_stride; a.wmT = p.wmT;
+  a.din = tail_inside ? (in_diff ? 3 : 1) : 0; a.I = d.I; a.wrT = p.wrT; a.wxT = p.wxT; a.dr = p.dr; a.in_diff = in_diff; a.id_stride = id_stride;
+  if (a.din && (!persist_tail_in_kernel(d, in_diff != nullptr) || !out_diff || (reinterpret_cast<uintptr_t>(out_diff) & 15) || od_stride % 4 != 0))
+    return hipErrorInvalidValue;
   a.nch = pcdiv(4 * d.C, 128);
   a.wpk = p.pk_fold; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.gran = gran; a.ctrl = ctrl;
   a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 0; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // (the second barrier already keeps the sweepers off the fabric)
   const PGeo g = pick_geo(d.C, a.nch);
   if (!g.tpw || !p.pk_fold) return hipErrorInvalidValue;
-  const size_t shm = (size_t)(4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4 + (a.pin ? d.T * d.S * 4 * g.tpw : 0)) * sizeof(float);
+  const size_t shm = (size_t)((a.din ? 8 : 4) * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4 + (a.pin ? d.T * d.S * 4 * g.tpw : 0)) * sizeof(float);
   const int grid = d.C / 4 / g.tpw;
   PDISPATCH_BWD(k_bwd_persist);
 }
