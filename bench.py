@@ -86,7 +86,8 @@ def kernel_alg_flops(name, S):
     return {"k_gates_step": 2.0 * S * 4 * C * (R + I), "k_proj_step": 2.0 * S * R * C,
             "k_dr_step": 2.0 * S * 4 * C * (R + I), "k_dm_step": 2.0 * S * R * C,
             "k_gates_fold": 2.0 * S * (4 * C * (R + I) + R * C), "k_dmf_step": 2.0 * S * (4 * C * R + R * C),
-            "k_fwd_persist": 2.0 * S * (4 * C * (R + I) + R * C), "k_bwd_persist": 2.0 * S * (4 * C * R + R * C)}[name]
+            "k_fwd_persist": 2.0 * S * (4 * C * (R + I) + R * C),      # :246 + :275 + :312, all T frames in the launch
+            "k_bwd_persist": 2.0 * S * (4 * C * (R + I) + R * C)}[name]  # :391 + :408 + :457 (d_r, d_m, in_diff)
 
 
 def kernel_exec_flops(name, S):
@@ -378,8 +379,8 @@ def main():
         for n in step_kernels:
             if n in kern:
                 us = kern[n]["avg_us"] * 1e-6
-                if n.endswith("_persist"):             # one launch advances T-1 (forward) / T (backward) steps
-                    us = us / (T_BPTT - 1 if n == "k_fwd_persist" else T_BPTT)
+                if n.endswith("_persist"):             # one launch advances all T frames of its direction
+                    us = us / T_BPTT
                     kern[n]["us_per_recurrence_step"] = us * 1e6
                 kern[n]["alg_tflops"] = kernel_alg_flops(n, S) / us / 1e12
                 kern[n]["alg_gbs"] = kernel_alg_bytes(n, S, T_BPTT) / us / 1e9
