@@ -59,7 +59,7 @@ int main(int argc, char **argv) {
     }
     // mean over workgroups of the sweeper wave 1
     double m[6] = {0, 0, 0, 0, 0, 0};
-    for (int wg = 0; wg < grid; wg++) for (int i = 0; i < 6; i++) m[i] += row(wg, 4 * g.tpw)[i] / cyc_per_us / (T - 1) / grid;
+    for (int wg = 0; wg < grid; wg++) for (int i = 0; i < 6; i++) m[i] += row(wg, 4 * g.tpw + 1)[i] / cyc_per_us / (T - 1) / grid;
     printf("   mean over workgroups, first sweeper wave:");
     for (int i = 0; i < 6; i++) printf(" %s %.2f", nm[i], m[i]);
     printf("\n");
@@ -74,7 +74,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(wpb, hb.data(), npb * 16, hipMemcpyHostToDevice));
     float *dgifo = dalloc((size_t)(T + 2) * S * 4 * C), *dc = dalloc((size_t)(T + 2) * S * C), *P = dalloc((size_t)T * S * C);
     CK(hipMemset(gran, 0, 2 * C * 4 * 8)); CK(hipMemset(ctrl, 0, 32));
-    for (int waves : {12, 8}) for (int nap0 : {0, 2, 4, 6, 8}) {
+    for (int waves : {12, 16}) for (int nap0 : {0, 2, 4, 6, 8}) {
       set_persist_waves(waves); set_persist_tpw(1);
       PersistBwdArgs a;
       a.C = C; a.R = R; a.S = S; a.T = T; a.pin = 0; a.din = 0; a.I = I; a.wrT = nullptr; a.wxT = nullptr; a.dr = nullptr; a.in_diff = nullptr; a.id_stride = 0; a.od = nullptr; a.od_stride = 0; a.wmT = nullptr; a.nch = nchb; a.wpk = wpb; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
@@ -93,7 +93,7 @@ int main(int argc, char **argv) {
       std::vector<long long> d(256 * 16 * 6); CK(hipMemcpy(d.data(), dbg, d.size() * 8, hipMemcpyDeviceToHost));
       unsigned stw[4]; CK(hipMemcpy(stw, ctrl, 16, hipMemcpyDeviceToHost));
       auto row = [&](int wg, int w) { return &d[((size_t)wg * 16 + w) * 6]; };
-      long long tot = 0; for (int i = 0; i < 6; i++) tot += row(0, 4)[i];
+      long long tot = 0; for (int i = 0; i < 6; i++) tot += row(0, 5)[i];
       const double cyc_per_us = tot / (best * 1e3);
       printf("BWD S=%d waves=%d tpw=%d grid=%d maxc=%d pcell=%d nap0=%d: %.3f us/step (status %x)\n", S, g.waves, g.tpw, grid, g.maxc, g.pcell, nap0, best * 1e3 / (T - 1), stw[2]);
       const char *nk[6] = {"-", "wait-slab", "contract", "barrier2", "epilogue", "loophead"};
@@ -101,8 +101,8 @@ int main(int argc, char **argv) {
       printf("   K wave 0 :");
       for (int i = 1; i < 6; i++) printf(" %s %.2f", nk[i], row(0, 0)[i] / cyc_per_us / (T - 1));
       double m[6] = {0, 0, 0, 0, 0, 0};
-      for (int wg = 0; wg < grid; wg++) for (int i = 0; i < 6; i++) m[i] += row(wg, 4)[i] / cyc_per_us / (T - 1) / grid;
-      printf("\n   sweeper (mean over workgroups, wave 4):");
+      for (int wg = 0; wg < grid; wg++) for (int i = 0; i < 6; i++) m[i] += row(wg, 5)[i] / cyc_per_us / (T - 1) / grid;
+      printf("\n   sweeper (mean over workgroups, wave 5):");
       for (int i : {0, 2, 1, 3, 5}) printf(" %s %.2f", ns[i], m[i]);
       printf("\n");
     }
