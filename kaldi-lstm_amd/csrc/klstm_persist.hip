@@ -432,6 +432,32 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
 // while the K waves work.
 // -------------------------------------------------------------------------------------------------------------------
 struct BpttCarry { float dcn, din, dfn, fn; };
+// The elementwise BPTT of a (cell, stream) pair (:411-440) is linear in d_m(t): everything else -- the forward planes of
+// frame t, the carry of frame t+1 -- is known BEFORE d_m(t) has crossed the fabric.  The sweepers fold it into six
+// coefficients while they would otherwise nap in front of the first poll, and spend 5 operations per pair once d_m is in:
+//   d_h = d_m*[yo(1-yh^2)]   d_o = d_m*[yh*yo(1-yo)]   d_c = d_m*k1 + pre,  k1 = ah + wpo*ao,  pre = dcn*fn + wpi*din + wpf*dfn
+//   d_f = d_c*[cpv*yf(1-yf)] d_i = d_c*[yg*yi(1-yi)]   d_g = d_c*[yi(1-yg^2)]
+// (same algebra as :411-440, products associated differently: a few ulp, identical in every workgroup)
+struct BpttCoef { float k1, ao, pre, bf, bi, bg; };
+__device__ __forceinline__ BpttCoef bptt_coef(float yg, float yi, float yf, float yo, float yh, float cpv, float wpi, float wpf,
+                                              float wpo, const BpttCarry &k) {
+  BpttCoef c;
+  const float ah = __builtin_fmaf(-yo, yh * yh, yo);                 // :411-412
+  c.ao = yh * __builtin_fmaf(-yo, yo, yo);                          // :415-416
+  c.k1 = __builtin_fmaf(wpo, c.ao, ah);                             // :424, :428
+  c.pre = __builtin_fmaf(wpf, k.dfn, __builtin_fmaf(wpi, k.din, k.dcn * k.fn));   // :425-427
+  c.bf = cpv * __builtin_fmaf(-yf, yf, yf);                         // :431-432
+  c.bi = yg * __builtin_fmaf(-yi, yi, yi);                          // :435-436
+  c.bg = __builtin_fmaf(-yi, yg * yg, yi);                          // :439-440
+  return c;
+}
+__device__ __forceinline__ float4 bptt_apply(float dm, const BpttCoef &c, float yf, BpttCarry &k, float &d_c_out) {
+  const float d_c = __builtin_fmaf(dm, c.k1, c.pre);
+  const float d_o = dm * c.ao, o_g = d_c * c.bg, o_i = d_c * c.bi, o_f = d_c * c.bf;
+  k.dcn = d_c; k.din = o_i; k.dfn = o_f; k.fn = yf;                  // f(t) is the f(t+1) of the next iteration
+  d_c_out = d_c;
+  return make_float4(o_g, o_i, o_f, d_o);
+}
 // one (cell, stream) pair of frame t; returns d(g,i,f,o) and updates the carry
 __device__ __forceinline__ float4 bptt_cell(float dm, float yg, float yi, float yf, float yo, float yh, float cpv, float wpi,
                                             float wpf, float wpo, BpttCarry &k, float &d_c_out) {
@@ -702,6 +728,16 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
           yh[j][s] = buf_f32(rs_h, voff[j], oc); cpv[j][s] = buf_f32(rs_c, voff[j], oc - S * C * 4);
           if (t == T && !a.pin) dm[j][s] = buf_f32(rs_p, voff[j], ((T - 1) * S + ss) * C * 4);   // d_m(T) = P(T): dgifo(T+1) = 0
         }
+      // coefficient pass: waits for the plane loads, which is the nap in front of the first poll
+      BpttCoef cf[PCELL][4];
+      float yfk[PCELL][4];
+#pragma unroll
+      for (int j = 0; j < PCELL; j++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          cf[j][s] = bptt_coef(yg[j][s], yi[j][s], yf[j][s], yo[j][s], yh[j][s], cpv[j][s], wpi[j], wpf[j], wpo[j], kk[j][s]);
+          yfk[j][s] = yf[j][s];
+        }
       if ((t < T || a.pin) && !sweep_cells(a.gran + (size_t)(t & 1) * C * 4, C, S, epoch + (unsigned)t, cell, dm, t_start, a.nap0, a.nap)) {
         *abortf = 1u;
         if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
@@ -715,8 +751,7 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; s++) {
           float d_c;
-          const float4 dg = bptt_cell(dm[j][s], yg[j][s], yi[j][s], yf[j][s], yo[j][s], yh[j][s], cpv[j][s], wpi[j], wpf[j], wpo[j],
-                                      kk[j][s], d_c);
+          const float4 dg = bptt_apply(dm[j][s], cf[j][s], yfk[j][s], kk[j][s], d_c);
           if (cell[j] < C && s < S) {
             if (t > 1 || a.din) {                    // B operand of the contraction (t == 1: of in_diff(1) only)
               float *lp = ldsD + s * LDD + cell[j];
