@@ -220,7 +220,10 @@ static bool use_fused_x(const klstm_engine *e);
 static bool persist_wanted(const klstm_engine *e, int T) {
   if (e->use_persist == 0 || e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || !use_fused_x(e)) return false;
   if (T < 3 || !persist_supported(Dims{e->I, e->C, e->R, e->S, T})) return false;
-  return e->use_persist >= 1 ? true : T >= 8;
+  // auto: 1..4 streams from 8 frames on.  5..8 streams (two groups against the same resident rows, forward launch only)
+  // are available with persist = 1 but bring nothing: the exchange takes twice as long with twice the granules, 4.2 us per
+  // step inside the launch against 4.2 for the launch-per-step kernel (tools/persist_anatomy 8, tools/persist_timing.py)
+  return e->use_persist >= 1 ? true : (T >= 8 && e->S <= 4);
 }
 static klstm_status ensure_persist(klstm_engine *e) {
   if (e->pctrl) return KLSTM_OK;
@@ -618,9 +621,7 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
   e->fwd_persist = persist_wanted(e, T);
-  // backward: the replicated elementwise BPTT of the persistent form (every workgroup recomputes dgifo of the whole
-  // layer, ~0.9 us per step) eats most of what the resident weights save: 3.85 vs 4.0 us per step at 40/800/512
-  e->bwd_persist = e->fwd_persist && e->use_persist != 1;
+  e->bwd_persist = e->fwd_persist && e->use_persist != 1 && persist_bwd_supported(Dims{e->I, e->C, e->R, e->S, T});
   e->fwd_folded = e->fwd_persist || fold_wanted(e, T);
   if (e->fwd_persist && (st = ensure_persist(e)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_ws(e, T)) != KLSTM_OK) return st;

@@ -105,6 +105,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *p, int by
 __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
+__device__ __forceinline__ void buf_store_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+}
 __device__ __forceinline__ void publish(unsigned long long *slot, int idx, unsigned tag, float v) {
   __hip_atomic_store(slot + idx, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);                     // one 8-byte sc1 store: tag and value cannot tear
@@ -137,27 +140,32 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // A polling wave competes with the cell / owner waves of its own CU for the vector-memory queue (their plane and granule
 // stores queue behind its loads: measured 1.2-2.8 us for a 7-store epilogue next to unthrottled pollers), so a sweeper
 // sleeps through the part of the step in which nothing can have arrived (nap0) and briefly between passes (nap).
-template <int PCELL>
+template <int PCELL, int NG = 1>
 __device__ __forceinline__ bool sweep_cells(const unsigned long long *slot, int C, int S, unsigned tag, const int (&cell)[PCELL],
-                                            float (&v)[PCELL][4], long long t_start, int nap0, int nap) {
-  const __amdgpu_buffer_rsrc_t rs = buf_rsrc(slot, C * 32);
+                                            float (&v)[PCELL][4 * NG], long long t_start, int nap0, int nap) {
+  // NG groups of 4 stream slots per cell: 32*NG bytes, 2*NG loads
+  const __amdgpu_buffer_rsrc_t rs = buf_rsrc(slot, C * 32 * NG);
   for (int i = 0; i < nap0; i++) __builtin_amdgcn_s_sleep(4);
   for (unsigned spins = 0;; spins++) {
-    u32x4 q[PCELL][2];
+    u32x4 q[PCELL][2 * NG];
 #pragma unroll
     for (int j = 0; j < PCELL; j++) {
       const int cl = cell[j] < C ? cell[j] : 0;
-      q[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, cl * 32, 0, 16);               // aux 16 = sc1
-      q[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, cl * 32 + 16, 0, 16);
+#pragma unroll
+      for (int h = 0; h < 2 * NG; h++) q[j][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, cl * 32 * NG + 16 * h, 0, 16);   // aux 16 = sc1
     }
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < PCELL; j++) {
-      // (rvalue copies first: __builtin_bit_cast applied directly to a vector-element expression read element 0 for .z)
-      const unsigned u0 = q[j][0].x, t0 = q[j][0].y, u1 = q[j][0].z, t1 = q[j][0].w;
-      const unsigned u2 = q[j][1].x, t2 = q[j][1].y, u3 = q[j][1].z, t3 = q[j][1].w;
-      ok &= ((t0 == tag) & ((S < 2) | (t1 == tag)) & ((S < 3) | (t2 == tag)) & ((S < 4) | (t3 == tag))) | (cell[j] >= C);
-      v[j][0] = __uint_as_float(u0); v[j][1] = __uint_as_float(u1); v[j][2] = __uint_as_float(u2); v[j][3] = __uint_as_float(u3);
+      bool okc = true;
+#pragma unroll
+      for (int h = 0; h < 2 * NG; h++) {
+        // (rvalue copies first: __builtin_bit_cast applied directly to a vector-element expression read element 0 for .z)
+        const unsigned u0 = q[j][h].x, t0 = q[j][h].y, u1 = q[j][h].z, t1 = q[j][h].w;
+        okc &= ((S < 2 * h + 1) | (t0 == tag)) & ((S < 2 * h + 2) | (t1 == tag));
+        v[j][2 * h] = __uint_as_float(u0); v[j][2 * h + 1] = __uint_as_float(u1);
+      }
+      ok &= okc | (cell[j] >= C);
     }
     if (ok) return true;
     if ((spins & 31) == 31 && wall_clock64() - t_start > SPIN_LIMIT) return false;
@@ -219,18 +227,20 @@ __device__ __forceinline__ f32x4 cell_contract(const float4 (&a0)[NCHUNK], const
 // MAXC chunks of the folded one (R <= C: a projection)
 constexpr int persist_maxu(int maxc) { return maxc == 7 ? 5 : maxc; }
 
-template <int TPW, int MAXC, int PNW, int PCELL>
+// NG: groups of 4 streams (NumStream <= 4*NG); the weights stay where they are, every step contracts them NG times
+template <int TPW, int MAXC, int PNW, int PCELL, int NG>
 __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
   constexpr int PNT = PNW * 64, NCW = 4 * TPW, NSW = (PNW - NCW - 1) * 64, MAXU = persist_maxu(MAXC);   // cell waves, one projection wave, sweepers
+  constexpr int SS = 4 * NG;                         // stream slots per cell (slab rows, granules)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = a.C, S = a.S, T = a.T, I = a.I, R = a.R, nch = a.nch;
   const int RP = (R + KCH - 1) / KCH * KCH;          // x columns of the step-1 slab start here (the layout of the packed gates operand)
   const int XP = a.nchm * KCH;                       // ... and here in the folded slab
   constexpr int LDB = MAXC * 128 + 16;               // (LDB mod 64 == 16: the 16-lane groups of ds_read_b128 hit 16 distinct slots)
   constexpr int LDU = MAXU * 128 + 16;
-  float *ldsB = lds;                                 // [4][LDB]: row s = [ m(t-1)[s][0..C) | pad | x(t)[s][0..I) | pad ]
-  float *ldsU = lds + 4 * LDB;                       // [4][LDU]: row s = [ r(0)[s][0..R) | pad | x(1)[s][0..I) | pad ]   (step 1 only)
-  unsigned *abortf = reinterpret_cast<unsigned *>(ldsU + 4 * LDU);
+  float *ldsB = lds;                                 // [SS][LDB]: row s = [ m(t-1)[s][0..C) | pad | x(t)[s][0..I) | pad ]
+  float *ldsU = lds + SS * LDB;                      // [SS][LDU]: row s = [ r(0)[s][0..R) | pad | x(1)[s][0..I) | pad ]   (step 1 only)
+  unsigned *abortf = reinterpret_cast<unsigned *>(ldsU + SS * LDU);
   int *projf = reinterpret_cast<int *>(abortf + 1);  // last step whose slab the projection wave has read
   const bool proj_on = a.rin && (int)blockIdx.x * 4 < R;   // this workgroup contracts rows 4*blockIdx .. +3 of W_r_m
   const int tid = threadIdx.x, lane = tid & 63;
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
   const long long t_start = wall_clock64();
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // zero both slabs once: pad columns and rows of absent streams stay zero for the whole launch
-  for (int i = tid; i < 4 * (LDB + LDU); i += PNT) lds[i] = 0.f;
+  for (int i = tid; i < SS * (LDB + LDU); i += PNT) lds[i] = 0.f;
   if (tid == 0) { *abortf = 0u; *projf = 0; }
   __syncthreads();
   PT_DECL();
@@ -254,15 +264,24 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
     const int lc = e_cell < C ? e_cell : 0;
     const size_t wrow = (size_t)bj * C + lc;         // this lane's weight row: gate bj of the cell (rows of the 4C axis are g,i,f,o blocks)
     // epilogue lanes: lanes 12..15 = streams 0..3 of the cell (where kgroup_sum leaves the totals)
-    const bool e_on = (lane >> 2) == 3 && es < S && e_cell < C;
-    const int ls = e_on ? es : 0;
     const float pre0 = a.bias[lc], pre1 = a.bias[C + lc], pre2 = a.bias[2 * C + lc], pre3 = a.bias[3 * C + lc];
     const float wpi = a.pi[lc], wpf = a.pf[lc], wpo = a.po[lc];
-    float cp = a.prev_c[(size_t)ls * C + lc];                        // carried c(0) (:231)
-    if (e_on) a.cc[(size_t)es * C + e_cell] = cp;                    // time block 0 of the c plane: BPTT reads it (:231)
-    auto cell_math = [&](int t, const f32x4 &v) {
-      if (!e_on) return;
-      const size_t e_row = (size_t)t * S + es;
+    // plane stores through buffer descriptors: one 32-bit lane offset per group and plane shape, frame in the scalar offset
+    // (64-bit per-store addresses pushed the two-group kernel into scratch)
+    const __amdgpu_buffer_rsrc_t rs_g = buf_rsrc(a.gifo, (T + 2) * S * 4 * C * 4), rs_c = buf_rsrc(a.cc, (T + 2) * S * C * 4);
+    const __amdgpu_buffer_rsrc_t rs_h = buf_rsrc(a.hh, (T + 2) * S * C * 4), rs_m = buf_rsrc(a.mm, (T + 2) * S * C * 4);
+    bool e_ong[NG];
+    float cpg[NG];                                   // c(t-1) of (cell, stream 4g + es)
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      e_ong[g] = (lane >> 2) == 3 && 4 * g + es < S && e_cell < C;
+      cpg[g] = a.prev_c[(size_t)(e_ong[g] ? 4 * g + es : 0) * C + lc];            // carried c(0) (:231)
+      if (e_ong[g]) a.cc[(size_t)(4 * g + es) * C + e_cell] = cpg[g];              // time block 0 of the c plane: BPTT reads it (:231)
+    }
+    auto cell_math = [&](int t, int g, const f32x4 &v) {
+      if (!e_ong[g]) return;
+      const int es_g = 4 * g + es;                   // the stream
+      float &cp = cpg[g];
       float ag = v.x + pre0;
       float ai = v.y + pre1;
       float af = v.z + pre2;
@@ -278,13 +297,14 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       ao += wpo * c;                               // :303
       const float go = k_sigmoid(ao);              // :306
       const float m = h * go;                      // :309
-      if (t < T || a.rin) publish(a.gran + (size_t)(t & 1) * C * 4, e_cell * 4 + es, epoch + (unsigned)t, m);   // (m(T): for r(T) only)
-      float *gp = a.gifo + e_row * 4 * C + e_cell;
-      gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
-      a.cc[e_row * C + e_cell] = c;
-      a.hh[e_row * C + e_cell] = h;
-      a.mm[e_row * C + e_cell] = m;
-      if (t == T) a.prev_c[(size_t)es * C + e_cell] = c;         // :331 (c columns)
+      if (t < T || a.rin) publish(a.gran + (size_t)(t & 1) * C * SS, e_cell * SS + es_g, epoch + (unsigned)t, m);   // (m(T): for r(T) only)
+      const int vg = (es_g * 4 * C + e_cell) * 4, vc = (es_g * C + e_cell) * 4, sg = t * S * 4 * C * 4, sc = t * S * C * 4;
+      buf_store_f32(rs_g, vg, sg, gg); buf_store_f32(rs_g, vg, sg + C * 4, gi);
+      buf_store_f32(rs_g, vg, sg + 2 * C * 4, gf); buf_store_f32(rs_g, vg, sg + 3 * C * 4, go);
+      buf_store_f32(rs_c, vc, sc, c);
+      buf_store_f32(rs_h, vc, sc, h);
+      buf_store_f32(rs_m, vc, sc, m);
+      if (t == T) a.prev_c[(size_t)es_g * C + e_cell] = c;       // :331 (c columns)
       cp = c;
     };
       // ---- step 1 closes over the CARRIED r (:275; set by Reset / the previous minibatch, possibly under older weights):
@@ -303,32 +323,43 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
         }
         u0[i] = w[0]; u1[i] = w[1];
       }
-      // (requested now, behind the step-1 rows: they arrive while step 1 computes and travels)
-      // ---- steps 2..T: resident folded rows [W_rm | W_x], k = 128*chunk + 64*h + 4*kg + e.  W_rm from the packed operand the
-      // fold product writes (klstm_kernels.hip: pk[tile][chunk32][h32][lane32][4], row = lane32 & 15,
-      // k = 32*chunk32 + 8*(lane32 >> 4) + 4*h32 + e), W_x from the natural W_gifo_x.
       float4 a0[MAXC], a1[MAXC];
+      auto load_folded = [&]() {
+        // ---- steps 2..T: resident folded rows [W_rm | W_x], k = 128*chunk + 64*h + 4*kg + e.  W_rm from the packed operand the
+        // fold product writes (klstm_kernels.hip: pk[tile][chunk32][h32][lane32][4], row = lane32 & 15,
+        // k = 32*chunk32 + 8*(lane32 >> 4) + 4*h32 + e), W_x from the natural W_gifo_x.
 #pragma unroll
-      for (int i = 0; i < MAXC; i++) {
-        float4 w[2];
+        for (int i = 0; i < MAXC; i++) {
+          float4 w[2];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int k0 = 128 * i + 64 * h + 4 * kg;
-          const int c32 = k0 >> 5, l32 = ((k0 & 31) >> 3) * 16 + 4 * cw + bj, h32 = (k0 & 7) >> 2;
-          const bool in_m = e_cell < C && c32 < a.nchm, in_x = e_cell < C && k0 >= XP && k0 - XP < I;
-          const float4 *ap = in_x ? reinterpret_cast<const float4 *>(a.wx + wrow * I + (k0 - XP))
-                                  : a.wpk + (((size_t)(in_m ? tile : 0) * nch + (in_m ? c32 : 0)) * 2 + h32) * 64 + l32;
-          w[h] = *ap;
-          if (!in_m && !in_x) w[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int h = 0; h < 2; h++) {
+            const int k0 = 128 * i + 64 * h + 4 * kg;
+            const int c32 = k0 >> 5, l32 = ((k0 & 31) >> 3) * 16 + 4 * cw + bj, h32 = (k0 & 7) >> 2;
+            const bool in_m = e_cell < C && c32 < a.nchm, in_x = e_cell < C && k0 >= XP && k0 - XP < I;
+            const float4 *ap = in_x ? reinterpret_cast<const float4 *>(a.wx + wrow * I + (k0 - XP))
+                                    : a.wpk + (((size_t)(in_m ? tile : 0) * nch + (in_m ? c32 : 0)) * 2 + h32) * 64 + l32;
+            w[h] = *ap;
+            if (!in_m && !in_x) w[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          a0[i] = w[0]; a1[i] = w[1];
         }
-        a0[i] = w[0]; a1[i] = w[1];
-      }
+      };
+      // one group: requested now, behind the step-1 rows (they arrive while step 1 computes and travels); two groups: both
+      // row sets at once do not fit the 168 registers of a 12-wave workgroup, requested once the step-1 rows are dead
+      if (NG == 1) load_folded();
       PT_MARK(5);
       lds_barrier();                                 // slab of step 1 ready
       PT_MARK(1);
-      const f32x4 v = cell_contract<MAXU>(u0, u1, ldsU + bj * LDU, kg);
+      f32x4 v1[NG];
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        if (g) __builtin_amdgcn_sched_barrier(0);
+        v1[g] = cell_contract<MAXU>(u0, u1, ldsU + (4 * g + bj) * LDU, kg);
+      }
       PT_MARK(2);
-      cell_math(1, v);
+      if (NG > 1) load_folded();
+#pragma unroll
+      for (int g = 0; g < NG; g++) cell_math(1, g, v1[g]);
       PT_MARK(4);
     bool dead = false;
     for (int t = 2; t <= T; t++) {
@@ -337,9 +368,15 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       PT_MARK(1);
       if (*abortf) { dead = true; break; }           // (plain LDS read: the asm barrier's memory clobber forces the reload; a volatile
                                                      //  read through the generic pointer became a FLAT load behind vmcnt(0))
-      const f32x4 v = cell_contract<MAXC>(a0, a1, ldsB + bj * LDB, kg);
-      PT_MARK(2);                                    // contraction + k-group sum
-      cell_math(t, v);
+      f32x4 vt[NG];
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        if (g) __builtin_amdgcn_sched_barrier(0);    // (one group's 56 operand registers at a time)
+        vt[g] = cell_contract<MAXC>(a0, a1, ldsB + (4 * g + bj) * LDB, kg);
+      }
+      PT_MARK(2);                                    // contractions + k-group sums
+#pragma unroll
+      for (int g = 0; g < NG; g++) cell_math(t, g, vt[g]);   // (back to back: the groups' dependent exp/rcp chains interleave)
       PT_MARK(4);                                    // cell math + stores
     }
     if (a.rin && !dead) lds_barrier();               // (slab of m(T) for the projection wave)
@@ -363,13 +400,18 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       if (*abortf) break;
       if (!proj_on) continue;
       // (columns >= C of the slab row hold x(t) and pad: their weights are zero)
-      const f32x4 v = cell_contract<MAXC>(a0, a1, ldsB + bj * LDB, kg, projf, t);
-      if (kg == 3 && bj < S) {                       // lanes 12..15: stream bj, components = rows 4*blockIdx .. +3
-        const int f = t - 1, g4 = (int)blockIdx.x * 4;
-        *reinterpret_cast<float4 *>(a.rr + ((size_t)f * S + bj) * R + g4) = make_float4(v.x, v.y, v.z, v.w);
-        float *op = a.out + ((size_t)(f - 1) * S + bj) * a.out_stride + g4;
-        op[0] = v.x; op[1] = v.y; op[2] = v.z; op[3] = v.w;
-        if (f == T) *reinterpret_cast<float4 *>(a.prev_r + (size_t)bj * R + g4) = make_float4(v.x, v.y, v.z, v.w);
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        if (g) __builtin_amdgcn_sched_barrier(0);
+        const f32x4 v = cell_contract<MAXC>(a0, a1, ldsB + (4 * g + bj) * LDB, kg, g == NG - 1 ? projf : nullptr, t);
+        const int ps = 4 * g + bj;
+        if (kg == 3 && ps < S) {                     // lanes 12..15: stream ps, components = rows 4*blockIdx .. +3
+          const int f = t - 1, g4 = (int)blockIdx.x * 4;
+          *reinterpret_cast<float4 *>(a.rr + ((size_t)f * S + ps) * R + g4) = make_float4(v.x, v.y, v.z, v.w);
+          float *op = a.out + ((size_t)(f - 1) * S + ps) * a.out_stride + g4;
+          op[0] = v.x; op[1] = v.y; op[2] = v.z; op[3] = v.w;
+          if (f == T) *reinterpret_cast<float4 *>(a.prev_r + (size_t)ps * R + g4) = make_float4(v.x, v.y, v.z, v.w);
+        }
       }
     }
   } else {
@@ -395,8 +437,8 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
         }
         if (x_on) *reinterpret_cast<float4 *>(ldsU + xs * LDU + RP + xk) = xv;
       } else {
-        float mv[PCELL][4];                          // m(t-1) of every cell
-        if (!sweep_cells(a.gran + (size_t)((t - 1) & 1) * C * 4, C, S, epoch + (unsigned)(t - 1), cell, mv, t_start, a.nap0, a.nap)) {
+        float mv[PCELL][SS];                         // m(t-1) of every cell
+        if (!sweep_cells<PCELL, NG>(a.gran + (size_t)((t - 1) & 1) * C * SS, C, S, epoch + (unsigned)(t - 1), cell, mv, t_start, a.nap0, a.nap)) {
           *abortf = 1u;
           if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
         }
@@ -408,7 +450,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
         for (int j = 0; j < PCELL; j++)
           if (cell[j] < C) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) if (s < S) ldsB[s * LDB + cell[j]] = mv[j][s];
+            for (int s = 0; s < SS; s++) if (s < S) ldsB[s * LDB + cell[j]] = mv[j][s];
           }
         if (x_on) *reinterpret_cast<float4 *>(ldsB + xs * LDB + XP + xk) = xv;
       }
@@ -824,12 +866,16 @@ static PGeo pick_geo(int C, int nch) {              // backward: 4 K waves per t
   return PGeo{0, 0, 0, 0};
 }
 
+// forward: up to 8 streams (two groups of 4 against the same resident rows); backward: up to 4
 bool persist_supported(const Dims &d) {
-  if (d.S > 4 || d.C % 8 != 0 || d.I % 8 != 0 || d.R % 4 != 0 || d.S * (d.I / 4) > 64) return false;
+  if (d.S > 8 || d.C % 8 != 0 || d.I % 8 != 0 || d.R % 4 != 0 || d.S * (d.I / 4) > 192) return false;
   const int nf = pcdiv(d.C, KCH) + pcdiv(d.I, KCH), nb = pcdiv(4 * d.C, 128);
-  return pick_geo_fwd(d.C, nf, pcdiv(d.R, KCH) * KCH + d.I).tpw > 0 && pick_geo(d.C, nb).tpw > 0;
+  const PGeo gf = pick_geo_fwd(d.C, nf, pcdiv(d.R, KCH) * KCH + d.I);
+  if (d.S > 4 && gf.waves != 12) return false;
+  return gf.tpw > 0 && pick_geo(d.C, nb).tpw > 0;
 }
-size_t persist_gran_bytes(const Dims &d) { return (size_t)2 * d.C * 4 * sizeof(unsigned long long); }
+bool persist_bwd_supported(const Dims &d) { return d.S <= 4 && persist_supported(d); }
+size_t persist_gran_bytes(const Dims &d) { return (size_t)2 * d.C * 8 * sizeof(unsigned long long); }   // (up to 8 stream slots per cell)
 
 template <class K, class A>
 static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t st, LaunchProbe pr, const A &a) {
@@ -846,11 +892,20 @@ static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t
     if (g.pcell == 3) return plaunch(KERN<TP, MC, W, 3>, grid, W * 64, shm, st, pr, a);                         \
     return plaunch(KERN<TP, MC, W, 4>, grid, W * 64, shm, st, pr, a);                                           \
   }
+// forward: the same with the stream-group count; two groups (5..8 streams) only in the 12-wave geometries
+#define PF5(KERN, TP, MC, W, NG_)                                                                               \
+  if (g.waves == W && g.tpw == TP && g.maxc == MC && ng == NG_) {                                               \
+    if (g.pcell == 1) return plaunch(KERN<TP, MC, W, 1, NG_>, grid, W * 64, shm, st, pr, a);                    \
+    if (g.pcell == 2) return plaunch(KERN<TP, MC, W, 2, NG_>, grid, W * 64, shm, st, pr, a);                    \
+    if (g.pcell == 3) return plaunch(KERN<TP, MC, W, 3, NG_>, grid, W * 64, shm, st, pr, a);                    \
+    return plaunch(KERN<TP, MC, W, 4, NG_>, grid, W * 64, shm, st, pr, a);                                      \
+  }
 #define PDISPATCH_FWD(KERN)                                                                                     \
   do {                                                                                                          \
-    PD5(KERN, 1, 7, 8) PD5(KERN, 1, 9, 8) PD5(KERN, 1, 12, 8)                                                   \
-    PD5(KERN, 1, 7, 12) PD5(KERN, 1, 9, 12) PD5(KERN, 1, 12, 12) PD5(KERN, 2, 7, 12) PD5(KERN, 2, 9, 12) PD5(KERN, 2, 12, 12) \
-    PD5(KERN, 1, 7, 16) PD5(KERN, 1, 9, 16) PD5(KERN, 1, 12, 16) PD5(KERN, 2, 7, 16) PD5(KERN, 2, 9, 16) PD5(KERN, 2, 12, 16) \
+    PF5(KERN, 1, 7, 8, 1) PF5(KERN, 1, 9, 8, 1) PF5(KERN, 1, 12, 8, 1)                                          \
+    PF5(KERN, 1, 7, 12, 1) PF5(KERN, 1, 9, 12, 1) PF5(KERN, 1, 12, 12, 1) PF5(KERN, 2, 7, 12, 1) PF5(KERN, 2, 9, 12, 1) PF5(KERN, 2, 12, 12, 1) \
+    PF5(KERN, 1, 7, 16, 1) PF5(KERN, 1, 9, 16, 1) PF5(KERN, 1, 12, 16, 1) PF5(KERN, 2, 7, 16, 1) PF5(KERN, 2, 9, 16, 1) PF5(KERN, 2, 12, 16, 1) \
+    PF5(KERN, 1, 7, 12, 2) PF5(KERN, 1, 9, 12, 2) PF5(KERN, 1, 12, 12, 2) PF5(KERN, 2, 7, 12, 2) PF5(KERN, 2, 9, 12, 2) PF5(KERN, 2, 12, 12, 2) \
     return hipErrorInvalidValue;                                                                                \
   } while (0)
 #define PDISPATCH_BWD(KERN)                                                                                     \
@@ -876,10 +931,11 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm; a.rr = p.rr;
   a.x = in; a.x_stride = in_stride; a.prev_c = p.prev_c; a.prev_r = p.prev_r; a.gran = gran; a.ctrl = ctrl;
   a.rin = out && persist_r_in_kernel(d); a.out = out; a.out_stride = out_stride;
-  a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 9; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // measured: tools/persist_anatomy
+  a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : d.S > 4 ? 14 : 9; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // measured: tools/persist_anatomy
   const PGeo g = pick_geo_fwd(d.C, a.nch, pcdiv(d.R, KCH) * KCH + d.I);
   if (!g.tpw || !p.pk_fold || (reinterpret_cast<uintptr_t>(in) & 15) || in_stride % 4 != 0) return hipErrorInvalidValue;
-  const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4 * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);   // (+ abort flag, projection flag)
+  const int ng = d.S > 4 ? 2 : 1;
+  const size_t shm = (size_t)(4 * ng * (g.maxc * 128 + 16) + 4 * ng * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);   // (+ abort flag, projection flag)
   const int grid = d.C / 4 / g.tpw;
   PDISPATCH_FWD(k_fwd_persist);
 }

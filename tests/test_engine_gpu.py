@@ -898,6 +898,9 @@ def test_full_size_decreasing_T_split_k_workspace(S, Ts):
     (8, 16, 8, 1, 9, False),         # one stream, 4 tiles, no in_diff
     (72, 136, 40, 2, 7, True),       # 4C = 544: last 128-chunk of the backward contraction partially filled
     (40, 800, 512, 4, 20, True),     # BASELINE.json configs[1]
+    (40, 64, 32, 8, 6, True),        # two stream groups against the same resident rows (forward launch; backward per step)
+    (40, 800, 512, 6, 20, True),     # ragged second group
+    (40, 800, 512, 8, 20, True),     # BASELINE.json configs[2]: 8 streams per GPU
 ])
 def test_persistent_chain(I, C, R, S, T, want_in_diff, waves, tpw):
     """Option "persist": steps 2..T of the forward recurrence and T..1 of BPTT run inside ONE launch per direction with the

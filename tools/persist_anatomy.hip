@@ -22,10 +22,10 @@ int main(int argc, char **argv) {
   float *vecs = dalloc(7 * C), *gifo = dalloc((size_t)(T + 2) * S * 4 * C), *cc = dalloc((size_t)(T + 2) * S * C),
         *hh = dalloc((size_t)(T + 2) * S * C), *mm = dalloc((size_t)(T + 2) * S * C), *x = dalloc((size_t)T * S * I), *cs = dalloc(S * C),
         *wr = dalloc((size_t)4 * C * R), *wx = dalloc((size_t)4 * C * I), *pr0 = dalloc(S * R), *rr = dalloc((size_t)(T + 2) * S * R);
-  unsigned long long *gran; CK(hipMalloc(&gran, 2 * C * 4 * 8)); CK(hipMemset(gran, 0, 2 * C * 4 * 8));
+  unsigned long long *gran; CK(hipMalloc(&gran, 2 * C * 8 * 8)); CK(hipMemset(gran, 0, 2 * C * 8 * 8));
   unsigned *ctrl; CK(hipMalloc(&ctrl, 32)); CK(hipMemset(ctrl, 0, 32));
   long long *dbg; CK(hipMalloc(&dbg, 256 * 16 * 6 * 8)); CK(hipMemset(dbg, 0, 256 * 16 * 6 * 8));
-  for (int waves : {12}) for (int tpw : {1}) for (int nap0 : {8, 9, 10}) for (int nap : {0}) {
+  for (int waves : {12}) for (int tpw : {1}) for (int nap0 : {8, 9, 10, 11, 12, 13, 14, 15, 16}) for (int nap : {0}) {
     if (4 * tpw >= waves) continue;
     set_persist_waves(waves); set_persist_tpw(tpw);
     PersistFwdArgs a;
@@ -33,9 +33,10 @@ int main(int argc, char **argv) {
     a.bias = vecs; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
     a.gifo = gifo; a.cc = cc; a.hh = hh; a.mm = mm; a.x = x; a.x_stride = I; a.prev_c = cs; a.gran = gran; a.ctrl = ctrl; a.dbg = dbg; a.nap0 = nap0; a.nap = nap;
     const PGeo g = pick_geo_fwd(C, nch, (R + 31) / 32 * 32 + I);
-    const size_t shm = (size_t)(4 * (g.maxc * 128 + 16) + 4 * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);
+    const size_t shm = (size_t)((S > 4 ? 8 : 4) * (g.maxc * 128 + 16) + (S > 4 ? 8 : 4) * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);
     const int grid = C / 4 / g.tpw;
     LaunchProbe pr;
+    const int ng = S > 4 ? 2 : 1;
     auto go = [&]() -> hipError_t { PDISPATCH_FWD(k_fwd_persist); };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9;
@@ -65,7 +66,7 @@ int main(int argc, char **argv) {
     printf("\n");
   }
   // ---------------- backward ----------------
-  {
+  if (S <= 4) {
     const int nchb = (4 * C + 127) / 128;
     const size_t npb = (size_t)(C / 4) * nchb * 128;
     float4 *wpb; CK(hipMalloc(&wpb, npb * 16));
@@ -73,7 +74,7 @@ int main(int argc, char **argv) {
     for (auto &v : hb) v = (rand() / (float)RAND_MAX - 0.5f) * 0.02f;
     CK(hipMemcpy(wpb, hb.data(), npb * 16, hipMemcpyHostToDevice));
     float *dgifo = dalloc((size_t)(T + 2) * S * 4 * C), *dc = dalloc((size_t)(T + 2) * S * C), *P = dalloc((size_t)T * S * C);
-    CK(hipMemset(gran, 0, 2 * C * 4 * 8)); CK(hipMemset(ctrl, 0, 32));
+    CK(hipMemset(gran, 0, 2 * C * 8 * 8)); CK(hipMemset(ctrl, 0, 32));
     for (int waves : {12, 16}) for (int nap0 : {0, 2, 4, 6, 8}) {
       set_persist_waves(waves); set_persist_tpw(1);
       PersistBwdArgs a;

@@ -8,7 +8,7 @@ import kaldi_lstm_amd as k
 
 I, C, R, T = 40, 800, 512, 20
 rows = []
-for S in (1, 2, 4):
+for S in (1, 2, 4, 8):
     for persist, waves, tpw in ((0, 0, 0), (1, 0, 0), (2, 0, 0)):
         stream = torch.cuda.Stream()
         e = k.Engine(I, C, R, S, stream=stream)
