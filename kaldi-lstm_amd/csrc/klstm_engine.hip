@@ -876,6 +876,10 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     e->persist_tail = value;
     return KLSTM_OK;
   }
+  if (!strcmp(key, "direct_nt_shape")) {         // value = 10*NI + waves (A-B; process-wide)
+    set_direct_nt_shape(value / 10, value % 10);
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "fold_direct")) {             // 0: the fold product on the generic 64x64-tile kernel (A-B; process-wide)
     HIPCHK(hipStreamSynchronize(e->stream));
     set_fold_direct(value);
@@ -960,6 +964,10 @@ klstm_status klstm_stream_synchronize(void *hip_stream) {
 klstm_status klstm_affine_propagate(const float *in, int rows, int in_dim, int in_stride, const float *W,
                                     const float *bias, float *out, int out_dim, int out_stride, void *hip_stream) {
   if (!in || !W || !out) return fail(KLSTM_ERR_ARG, "klstm_affine_propagate: null argument");
+  if (direct_nt_supported(rows, out_dim, in_dim, in, in_stride, W, in_dim)) {     // few frames, wide layer: the output tail
+    HIPCHK(launch_direct_nt(rows, out_dim, in_dim, in, in_stride, W, in_dim, out, out_stride, bias, (hipStream_t)hip_stream));
+    return KLSTM_OK;
+  }
   HIPCHK(launch_gemm(false, true, rows, out_dim, in_dim, in, in_stride, W, in_dim, 0.f, out, out_stride, bias,
                      (hipStream_t)hip_stream));
   return KLSTM_OK;

@@ -53,44 +53,11 @@ struct FoldArgs {
 constexpr int FD = 4;          // chunks of 32 k in the register ring (R % (32*FD) == 0: the K loop has no conditional loads --
                                // with them hipcc drains the whole ring, s_waitcnt vmcnt(0), at the top of every iteration)
 
-template <int NI>
-__global__ __launch_bounds__(256) void k_fold_direct(FoldArgs a) {
-  constexpr int MI = 2, WN = 16 * NI, NWAVE = 4;       // wave tile 32 x WN, 2 x 2 waves
-  constexpr int FLD = 16 * MI + 4;                     // LDS row stride of the epilogue transpose (floats): 16-byte aligned rows + pad
-  __shared__ __attribute__((aligned(16))) float Cs[NWAVE][WN * FLD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i16 = lane & 15, kg = lane >> 4;
-  const int C = a.C, R = a.R, nchunk = R / 32;
-  // XCD-aware order (workgroup w lands on XCD w % 8): XCD x gets a contiguous m-major range, i.e. a few row panels of A
-  // and all of B in its own L2
-  const int cpx = (a.nwg + 7) >> 3;
-  const int b = (int)(blockIdx.x & 7) * cpx + (int)(blockIdx.x >> 3);
-  if (b >= a.nwg) return;
-#ifdef KLSTM_FOLD_TIMING
-  const long long t_c0 = clock64(), t_w0 = wall_clock64();
-#endif
-  const int m0 = (b / a.nbn) * 64 + (wave >> 1) * 32, n0 = (b % a.nbn) * (2 * WN) + (wave & 1) * WN;
-
-  const float *ap[MI], *bp[NI];
-  bool aok[MI], bok[NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; mi++) {
-    const int x = m0 + 16 * mi + i16;                  // logical row 4*cell + gate
-    aok[mi] = (x >> 2) < C;
-    ap[mi] = a.wr + (size_t)(aok[mi] ? (x & 3) * C + (x >> 2) : 0) * R + 8 * kg;
-  }
-#pragma unroll
-  for (int ni = 0; ni < NI; ni++) {
-    const int n = n0 + 16 * ni + i16;
-    bok[ni] = n < C;
-    bp[ni] = a.wmT + (size_t)(bok[ni] ? n : 0) * R + 8 * kg;
-  }
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = (f32x4){0, 0, 0, 0};
-
+// The K loop shared by the direct kernels: lane (i16, kg) holds the row pointers ap[mi] / bp[ni] (already advanced by 8*kg);
+// K = 32 * nchunk, nchunk a multiple of FD.  acc[mi][ni] += A rows x B rows over all of K.
+template <int MI, int NI>
+__device__ __forceinline__ void direct_kloop(const float *const (&ap)[MI], const float *const (&bp)[NI], int nchunk,
+                                             f32x4 (&acc)[MI][NI], int kscale = 1) {
   float4 ra[FD][MI][2], rb[FD][NI][2];
   auto load = [&](int d, int c) {
     const int co = 32 * c;
@@ -136,11 +103,7 @@ __global__ __launch_bounds__(256) void k_fold_direct(FoldArgs a) {
         for (int l = slot * NLOAD / NSLOT; l < (slot + 1) * NLOAD / NSLOT; l++) {
           if (!refill) break;
           const int row = l >> 1, h = l & 1;
-#ifdef KLSTM_FOLD_TIMING
-          const int co = 32 * cl * (a.kscale != 0);        // (0: every refill re-reads chunk 0, timing experiment)
-#else
-          const int co = 32 * cl;
-#endif
+          const int co = 32 * cl * kscale;                 // (kscale 0: every refill re-reads chunk 0, timing experiment)
           __builtin_amdgcn_sched_barrier(0);
           if (row < MI) ra[dl][row][h] = *reinterpret_cast<const float4 *>(ap[row] + co + 4 * h);
           else rb[dl][row - MI][h] = *reinterpret_cast<const float4 *>(bp[row - MI] + co + 4 * h);
@@ -148,9 +111,6 @@ __global__ __launch_bounds__(256) void k_fold_direct(FoldArgs a) {
         }
       }
   };
-#ifdef KLSTM_FOLD_TIMING
-  const long long t_c1 = clock64(), t_w1 = wall_clock64();
-#endif
 #pragma unroll
   for (int d = 0; d < FD - 1; d++) load(d, d);
   // chunk c lives in slot c % FD; stage c refills slot (c - 1) % FD with chunk c + FD - 1
@@ -163,6 +123,52 @@ __global__ __launch_bounds__(256) void k_fold_direct(FoldArgs a) {
   // the last FD - 1 stages (R % (32*FD) == 0: c0 == nchunk - FD + 1 here): nothing left to request
 #pragma unroll
   for (int j = 0; j < FD - 1; j++) stage((1 + j) % FD, 0, 0, false);
+}
+
+template <int NI>
+__global__ __launch_bounds__(256) void k_fold_direct(FoldArgs a) {
+  constexpr int MI = 2, WN = 16 * NI, NWAVE = 4;       // wave tile 32 x WN, 2 x 2 waves
+  constexpr int FLD = 16 * MI + 4;                     // LDS row stride of the epilogue transpose (floats): 16-byte aligned rows + pad
+  __shared__ __attribute__((aligned(16))) float Cs[NWAVE][WN * FLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int C = a.C, R = a.R, nchunk = R / 32;
+  // XCD-aware order (workgroup w lands on XCD w % 8): XCD x gets a contiguous m-major range, i.e. a few row panels of A
+  // and all of B in its own L2
+  const int cpx = (a.nwg + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * cpx + (int)(blockIdx.x >> 3);
+  if (b >= a.nwg) return;
+#ifdef KLSTM_FOLD_TIMING
+  const long long t_c0 = clock64(), t_w0 = wall_clock64();
+#endif
+  const int m0 = (b / a.nbn) * 64 + (wave >> 1) * 32, n0 = (b % a.nbn) * (2 * WN) + (wave & 1) * WN;
+
+  const float *ap[MI], *bp[NI];
+  bool aok[MI], bok[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    const int x = m0 + 16 * mi + i16;                  // logical row 4*cell + gate
+    aok[mi] = (x >> 2) < C;
+    ap[mi] = a.wr + (size_t)(aok[mi] ? (x & 3) * C + (x >> 2) : 0) * R + 8 * kg;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) {
+    const int n = n0 + 16 * ni + i16;
+    bok[ni] = n < C;
+    bp[ni] = a.wmT + (size_t)(bok[ni] ? n : 0) * R + 8 * kg;
+  }
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = (f32x4){0, 0, 0, 0};
+
+#ifdef KLSTM_FOLD_TIMING
+  const long long t_c1 = clock64(), t_w1 = wall_clock64();
+  direct_kloop<MI, NI>(ap, bp, nchunk, acc, a.kscale != 0);
+#else
+  direct_kloop<MI, NI>(ap, bp, nchunk, acc);
+#endif
 #ifdef KLSTM_FOLD_TIMING
   const long long t_c2 = clock64(), t_w2 = wall_clock64();
 #endif
@@ -209,6 +215,63 @@ __global__ __launch_bounds__(256) void k_fold_direct(FoldArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// C[M x N] = A[M x K] B[N x K]^T + bias for FEW rows and MANY columns (AffineTransform::PropagateFnc of the output layer:
+// 80 x 16624 over K = 512, nnet.proto:4): the same register-direct K loop, one wave = all M rows (MI = M/16 blocks) x 16
+// (NI) columns, one-wave workgroups: every wave streams its rows of B exactly once; the M rows of A are re-read by every wave
+// (160 KB each, out of L2: that traffic, 83 MB at NI = 2, is what bounds the kernel -- wider waves leave SIMDs idle, narrower
+// ones double it; sharing A through LDS between the waves of a workgroup is the next step).  The 64x64-tile kernel spends
+// half of its second row tile on padding at M = 80: 37.9 us against 29.5 us here.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DirectNtArgs {
+  int M, N, K;
+  const float *A; int lda;
+  const float *B; int ldb;
+  float *Cm; int ldc;
+  const float *bias;
+};
+
+template <int MI, int NI>
+__global__ __launch_bounds__(256) void k_direct_nt(DirectNtArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int n0 = ((int)blockIdx.x * (int)(blockDim.x >> 6) + wave) * 16 * NI;
+  if (n0 >= a.N) return;
+  const float *ap[MI], *bp[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    const int m = 16 * mi + i16;
+    ap[mi] = a.A + (size_t)(m < a.M ? m : 0) * a.lda + 8 * kg;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) {
+    const int n = n0 + 16 * ni + i16;
+    bp[ni] = a.B + (size_t)(n < a.N ? n : 0) * a.ldb + 8 * kg;
+  }
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = (f32x4){0, 0, 0, 0};
+  direct_kloop<MI, NI>(ap, bp, a.K / 32, acc);
+  // lane (i16, kg): rows 16mi + 4kg + (0..3) at column n0 + 16ni + i16: 16 lanes = 64 contiguous bytes per row
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) {
+    const int n = n0 + 16 * ni + i16;
+    if (n >= a.N) continue;
+    const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+      const float e[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = 16 * mi + 4 * kg + r;
+        if (m < a.M) a.Cm[(size_t)m * a.ldc + n] = e[r] + bv;
+      }
+    }
+  }
+}
+
 #ifdef KLSTM_FOLD_TIMING
 static long long *g_fold_dbg = nullptr;
 static int g_fold_kscale = 1;
@@ -244,6 +307,34 @@ hipError_t launch_fold_direct(const Dims &d, const float *wr, const float *wmT, 
     if (pr.start) hipExtLaunchKernelGGL(k_fold_direct<4>, grid, block, 0, st, pr.start, pr.stop, 0, a);
     else hipLaunchKernelGGL(k_fold_direct<4>, grid, block, 0, st, a);
   }
+  return hipGetLastError();
+}
+
+static int g_nt_ni = 2, g_nt_waves = 1;   // measured at 80 x 16624 x 512 (tools/nt_sweep.py): 29.5 us; 1x1 36.7, 2x2 34.0, 4x1 49.4; tiled kernel 37.9
+void set_direct_nt_shape(int ni, int waves) { g_nt_ni = ni == 1 || ni == 2 ? ni : 4; g_nt_waves = waves >= 1 && waves <= 4 ? waves : 2; }
+
+bool direct_nt_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb) {
+  return g_fold_direct != 0 && M >= 1 && M <= 80 && N >= 64 && K % (32 * FD) == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+         (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+}
+
+hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
+                            const float *bias, hipStream_t st) {
+  DirectNtArgs a{M, N, K, A, lda, B, ldb, Cm, ldc, bias};
+  // columns per wave (16*NI) and waves per workgroup: experiment knobs (g_nt_ni, g_nt_waves)
+  const int ni = g_nt_ni, nw = g_nt_waves;
+  const dim3 grid((N + 16 * ni * nw - 1) / (16 * ni * nw)), block(64 * nw);
+#define NT_CASE(MI_)                                                                                   \
+  case MI_:                                                                                            \
+    if (ni == 1) hipLaunchKernelGGL((k_direct_nt<MI_, 1>), grid, block, 0, st, a);                      \
+    else if (ni == 2) hipLaunchKernelGGL((k_direct_nt<MI_, 2>), grid, block, 0, st, a);                 \
+    else hipLaunchKernelGGL((k_direct_nt<MI_, 4>), grid, block, 0, st, a);                              \
+    break;
+  switch ((M + 15) / 16) {
+    NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5)
+    default: return hipErrorInvalidValue;
+  }
+#undef NT_CASE
   return hipGetLastError();
 }
 

@@ -56,6 +56,11 @@ bool fold_direct_supported(const Dims &d);
 void set_fold_direct(int v);
 hipError_t launch_fold_direct(const Dims &d, const float *wr, const float *wmT, float *pk_fold[2], int nch1, int nch2,
                               hipStream_t st, LaunchProbe pr = {});
+// C = A B^T + bias for up to 80 rows and many columns, operands straight into MFMA registers (klstm_fold.hip)
+void set_direct_nt_shape(int ni, int waves);
+bool direct_nt_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb);
+hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
+                            const float *bias, hipStream_t st);
 hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
                        hipStream_t st, LaunchProbe pr = {}, LaunchProbe pr2 = {});
                        // pk_fold zero-filled once by the caller; pack_x = false: launch_pack(.., foldx) already wrote the W_x chunks
