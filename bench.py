@@ -343,7 +343,7 @@ def main():
         for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj",
                      "k_gates_fold", "k_gemm_rbatch", "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step",
                      "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx", "k_fwd_persist", "k_bwd_persist",
-                     "k_grads", "k_update_repack", "k_pack", "k_pack_fwd", "k_pack_bwd", "k_apply_momentum"):
+                     "k_grads", "k_grads_update", "k_update_repack", "k_pack", "k_pack_fwd", "k_pack_bwd", "k_apply_momentum"):
             tot, n = eng.profile_query(name)
             if n:
                 kern[name] = {"avg_us": tot / n, "launches_per_step": n / NPROF, "us_per_step": tot / NPROF}
@@ -362,7 +362,7 @@ def main():
                 c = i % nchunk
                 if c == 0:
                     e8.reset(ones8)
-                e8.propagate(f8[c], out8); e8.backpropagate(f8[c], o8[c], id8, MOMENTUM, 0); e8.update(LR)
+                e8.propagate(f8[c], out8); e8.backpropagate(f8[c], o8[c], id8, MOMENTUM, 2); e8.update(LR)
             for i in range(10):
                 step8(i)
             n8 = 200

@@ -56,6 +56,15 @@ typedef enum {
  * klstm_apply_momentum().  (The reference folds momentum into the gradient GEMM's beta,
  * ...streams.h:465-487, which would multiply momentum by the number of ranks.) */
 #define KLSTM_BPTT_DEFER_MOMENTUM 1
+/* "klstm_update follows immediately, with the input rows unchanged": Kaldi's Component::Backpropagate runs
+ * BackpropagateFnc and then Update on the same (input, out_diff) pair, so the gradient products (:468-487) may wait for
+ * the learning rate and run as ONE pass together with the Update (:504-512): corr = momentum*corr + grad, theta -= lr*corr,
+ * transposed copies refreshed -- one launch and 16 MB of HBM traffic less per minibatch.  Results are identical.  The
+ * engine keeps the `in` pointer until then: any other call that observes or changes gradients, momentum buffers,
+ * parameters or activations in between (get_corr, set_params, propagate, ...) first runs the gradient products the
+ * ordinary way, so only a caller that overwrites the rows of `in` before klstm_update breaks the contract.
+ * Ignored together with KLSTM_BPTT_DEFER_MOMENTUM. */
+#define KLSTM_BPTT_FUSE_UPDATE    2
 
 /* Message of the calling thread's most recent failing call ("" if none). */
 const char *klstm_last_error(void);

@@ -214,11 +214,11 @@ class LstmProjectedStreams {
     if (in.NumRows() > 0 && klstm_pointer_on_device(eng_, in.Data()) == 0)
       Check(klstm_backpropagate_host(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
                                      in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
-                                     opts_.momentum, dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : KLSTM_BPTT_DEFAULT));
+                                     opts_.momentum, dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : KLSTM_BPTT_FUSE_UPDATE));
     else
       Check(klstm_backpropagate(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
                                 in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
-                                opts_.momentum, dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : KLSTM_BPTT_DEFAULT));
+                                opts_.momentum, dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : KLSTM_BPTT_FUSE_UPDATE));
     host_fresh_ = host_fresh_ && true;
   }
 

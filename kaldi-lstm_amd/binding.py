@@ -96,6 +96,10 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+BPTT_DEFER_MOMENTUM = 1
+BPTT_FUSE_UPDATE = 2      # klstm.h: "klstm_update follows immediately, input rows unchanged"
+
+
 class Engine:
     """One LstmProjectedStreams layer on one MI355X."""
 

@@ -67,6 +67,9 @@ struct klstm_engine {
   int T_bwd = -1;
   bool use_graph = true;
   bool mmt_pending = false;   // DP: corr = mmt*corr + grads is folded into the next Update
+  // KLSTM_BPTT_FUSE_UPDATE: the gradient products of the last backpropagate wait for klstm_update (or for anything that looks)
+  bool grads_pending = false;
+  const float *gp_in = nullptr; int gp_in_stride = 0, gp_T = 0; float gp_mmt = 0.f; bool gp_bf16 = false;
   float mmt_value = 0.f;
   bool use_vector = true;
   bool use_fat = true;
@@ -188,7 +191,17 @@ static klstm_status ensure_ws(klstm_engine *e, int T) {
   return KLSTM_OK;
 }
 
+// gradient products deferred by KLSTM_BPTT_FUSE_UPDATE, the ordinary way (somebody looks before the Update arrives)
+static klstm_status flush_grads(klstm_engine *e) {
+  if (!e->grads_pending) return KLSTM_OK;
+  e->grads_pending = false;
+  const Dims d{e->I, e->C, e->R, e->S, e->gp_T};
+  HIPCHK(launch_grads(d, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
+                      probe(e, "k_grads"), e->gp_bf16));
+  return KLSTM_OK;
+}
 static klstm_status flush_momentum(klstm_engine *e) {
+  { klstm_status gs = flush_grads(e); if (gs != KLSTM_OK) return gs; }
   if (!e->mmt_pending) return KLSTM_OK;
   e->mmt_pending = false;
   HIPCHK(launch_apply_momentum(e->corr, e->grads, e->mmt_value, e->nparams, e->stream, probe(e, "k_apply_momentum")));
@@ -426,10 +439,11 @@ klstm_status klstm_get_corr_host(klstm_engine *e, float *flat) {
   return blob_d2h(e, flat, e ? e->corr : nullptr);
 }
 klstm_status klstm_set_corr_host(klstm_engine *e, const float *flat) {
-  if (e) e->mmt_pending = false;
+  if (e) { e->mmt_pending = false; e->grads_pending = false; }    // (whatever was on its way into corr is replaced)
   return blob_h2d(e, e ? e->corr : nullptr, flat);
 }
 klstm_status klstm_get_grads_host(klstm_engine *e, float *flat) { return blob_d2h(e, flat, e ? e->grads : nullptr); }
+/* (klstm_set_params_* leave deferred gradient products pending: they do not read the parameters) */
 
 klstm_status klstm_reset(klstm_engine *e, const int *flags, int n) {
   if (!e || !flags) return fail(KLSTM_ERR_ARG, "klstm_reset: null argument");
@@ -530,6 +544,11 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
   return KLSTM_OK;
 }
 
+// May klstm_backpropagate leave the gradient products to the following klstm_update?
+static bool grads_fusable(const klstm_engine *e, int T, int flags, bool bf16_path) {
+  return (flags & KLSTM_BPTT_FUSE_UPDATE) && !(flags & KLSTM_BPTT_DEFER_MOMENTUM) && e->R % 4 == 0 && e->C % 4 == 0 && e->I % 4 == 0 &&
+         !grads_bf16_tiles(Dims{e->I, e->C, e->R, e->S, T}, bf16_path);
+}
 static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride, const float *out_diff,
                                  int od_stride, float *in_diff, int id_stride, int T, float mmt, int flags) {
   const Dims d{e->I, e->C, e->R, e->S, T};
@@ -560,6 +579,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
       HIPCHK(launch_bwd_tail(d, e->dgifo, wr, wx, out_diff, od_stride, e->dr, in_diff, id_stride, e->ws, st,
                              probe(e, "k_gemm_tail"), probe(e, "k_reduce_tail")));
     const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
+    if (grads_fusable(e, T, flags, false)) return KLSTM_OK;      // (klstm_update runs them together with the Update)
     HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, defer ? 0.f : mmt, defer ? e->grads : e->corr, st,
                         probe(e, "k_grads")));
     return KLSTM_OK;
@@ -575,6 +595,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
   const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
   float *dst = defer ? e->grads : e->corr;
   const float beta = defer ? 0.f : mmt;
+  if (grads_fusable(e, T, flags, e->use_bf16)) return KLSTM_OK;
   HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, beta, dst, st,
                       probe(e, "k_grads"), e->use_bf16));                                     // :468-487
   return KLSTM_OK;
@@ -616,6 +637,7 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
     return KLSTM_OK;
   }
   HIPCHK(hipSetDevice(e->device));
+  { klstm_status gs = flush_grads(e); if (gs != KLSTM_OK) return gs; }   // (deferred gradient products read the planes of the last minibatch)
   if (in_stride < e->I || out_stride < e->R) return fail(KLSTM_ERR_ARG, "klstm_propagate: stride smaller than row width");
   const int T = rows / e->S;
   klstm_status st = ensure_planes(e, T);
@@ -670,6 +692,10 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
   });
   if (st != KLSTM_OK) return st;
   e->T_bwd = T;
+  if (grads_fusable(e, T, flags, e->fwd_folded ? false : e->use_bf16)) {
+    e->grads_pending = true;
+    e->gp_in = in; e->gp_in_stride = in_stride; e->gp_T = T; e->gp_mmt = momentum; e->gp_bf16 = e->fwd_folded ? false : e->use_bf16;
+  }
   return KLSTM_OK;
 }
 
@@ -717,6 +743,7 @@ klstm_status klstm_backpropagate_host(klstm_engine *e, const float *in, int in_s
                                       int out_diff_stride, float *in_diff, int in_diff_stride, int rows,
                                       float momentum, int flags) {
   if (!e || ((!in || !out_diff) && rows != 0)) return fail(KLSTM_ERR_ARG, "klstm_backpropagate_host: null argument");
+  flags &= ~KLSTM_BPTT_FUSE_UPDATE;                 // (the staged copy of `in` does not outlive this call's contract)
   if (rows <= 0 || e->T_fwd < 0 || rows != e->T_fwd * e->S)
     return klstm_backpropagate(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, rows, momentum, flags);
   if (in_stride < e->I || out_diff_stride < e->R || (in_diff && in_diff_stride < e->I))
@@ -750,10 +777,19 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
   HIPCHK(hipSetDevice(e->device));
   const Dims d{e->I, e->C, e->R, e->S, 0};
   // theta -= lr * corr, and the transposed copies the BPTT kernels read are refreshed in the same pass
-  const float *fold_grad = e->mmt_pending ? e->grads : nullptr;
-  e->mmt_pending = false;
-  HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
-                              e->wxT, e->stream, probe(e, "k_update_repack")));
+  if (e->grads_pending) {
+    // KLSTM_BPTT_FUSE_UPDATE: gradient products, momentum, Update and the transposed copies in one pass
+    e->grads_pending = false;
+    const Dims dg{e->I, e->C, e->R, e->S, e->gp_T};
+    const GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
+    HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
+                        probe(e, "k_grads_update"), false, &u));
+  } else {
+    const float *fold_grad = e->mmt_pending ? e->grads : nullptr;
+    e->mmt_pending = false;
+    HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
+                                e->wxT, e->stream, probe(e, "k_update_repack")));
+  }
   // (Packing the BPTT operands on a second stream, overlapped with the next forward pass, was measured to cost
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
   // while the folded chain is in use only the step-1 gates operand (array 0) is read; the others are refreshed on demand

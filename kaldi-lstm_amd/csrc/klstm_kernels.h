@@ -105,9 +105,14 @@ hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, con
 // All seven gradient accumulations (...streams.h:468-487) in ONE launch: three A^T*B products
 // (w_gifo_x, w_gifo_r, w_r_m) plus the bias / peephole column sums.  dst = beta*dst + grad, dst is a
 // blob in GetParams order.
+// upd: fold the Update (:504-512) into the same pass -- dst_blob must then be the momentum blob: dst = beta*dst + grad,
+// clipped if clip > 0, params -= lr*dst, and the three transposed copies are written from the updated parameters (the C % 4,
+// R % 4 row quads of a tile: shapes with C, R multiples of 4).  fp32 tiles only (launch fails for the bf16 tile path).
+struct GradsUpdate { float *params; float lr, clip; float *wrT, *wmT, *wxT; };
+bool grads_bf16_tiles(const Dims &d, bool bf16);      // would launch_grads take the bf16 tile path?
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,
-                        hipStream_t st, LaunchProbe pr = {}, bool bf16 = false);   // bf16: operands rounded to bf16, 16x16x32 MFMA, fp32 accumulate
+                        hipStream_t st, LaunchProbe pr = {}, bool bf16 = false, const GradsUpdate *upd = nullptr);   // bf16: operands rounded to bf16, 16x16x32 MFMA, fp32 accumulate
 
 // Update (:504-512) + refresh of the transposed weight copies in ONE launch.
 //   grad != nullptr : corr = mmt*corr + grad first (DP mode, after the all-reduce)

@@ -1502,6 +1502,9 @@ struct GemmJob {
   int gperm;
   float4 *pk1; int nch1;  // [W_rm | W_x] gates array: [C/4 tiles][nch1 chunks of 32][2][64]
   float4 *pk2; int nch2;  // W_rm^T 4-row array:       [C/4 tiles][nch2 chunks of 128][2][64]
+  // gradient product with the Update folded in (launch_grads with a GradsUpdate): Cm is the momentum buffer,
+  // Cm = beta*Cm + A*B (:468-487), clipped if clip > 0, then P -= lr*Cm (:504-512); Ct then receives the UPDATED P
+  float *P; float lr, clip;
 };
 
 // One operand tile = GT x GK elements = 2 x (8 floats per thread).  Operand stored [X x K] (TA=false: 8 consecutive k
@@ -1605,7 +1608,7 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
   // beta != 0 (momentum folded into the gradient products, :468-487): the old C tile is requested now so that its
   // HBM latency hides under the K loop instead of sitting in front of the stores
   float cold[2][2][4];
-  if (g.beta != 0.f) {
+  if (g.beta != 0.f && !g.P) {
 #pragma unroll
     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
@@ -1667,6 +1670,58 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
     }
     __syncthreads();
   }
+  if (g.P) {
+    // Gradient product with momentum and Update folded in (launch_grads + GradsUpdate; N, ldc, ldct multiples of 4, 16-byte
+    // aligned blobs).  Everything that touches HBM moves as 16-byte pieces, 256 contiguous bytes per tile row: the tile goes
+    // through LDS (the K loop ended with a barrier, As is free), then  corr = beta*corr + grad (:468-487), clip,
+    // theta -= lr*corr (:504-512)  on float4 rows, then the transposed copy of the updated parameters.
+    float *Cs = As;                                    // 64 x GLX floats <= GLDS
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+      for (int ni = 0; ni < 2; ni++) {
+        const float e[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) Cs[(wr * 32 + mi * 16 + 4 * kg + r) * GLX + wc * 32 + ni * 16 + i16] = e[r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int p = tid + 256 * u, ml = p >> 4, nq = (p & 15) * 4;
+      const int m = m0 + ml, n = n0 + nq;
+      if (m < g.M && n + 4 <= g.N) {
+        float *cs = Cs + ml * GLX + nq;
+        const float4 a = *reinterpret_cast<const float4 *>(cs);
+        float4 *cp = reinterpret_cast<float4 *>(g.Cm + (size_t)m * g.ldc + n), *pp = reinterpret_cast<float4 *>(g.P + (size_t)m * g.ldc + n);
+        float4 pv = *pp;
+        float c[4] = {a.x, a.y, a.z, a.w};
+        if (g.beta != 0.f) {
+          const float4 o = *cp;
+          c[0] = g.beta * o.x + c[0]; c[1] = g.beta * o.y + c[1]; c[2] = g.beta * o.z + c[2]; c[3] = g.beta * o.w + c[3];
+        }
+        if (g.clip > 0.f) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) { c[q] = c[q] < -g.clip ? -g.clip : c[q]; c[q] = c[q] > g.clip ? g.clip : c[q]; }
+        }
+        pv.x = pv.x + (-g.lr) * c[0]; pv.y = pv.y + (-g.lr) * c[1]; pv.z = pv.z + (-g.lr) * c[2]; pv.w = pv.w + (-g.lr) * c[3];
+        *cp = make_float4(c[0], c[1], c[2], c[3]);
+        *pp = pv;
+        *reinterpret_cast<float4 *>(cs) = pv;
+      }
+    }
+    if (!g.Ct) return;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int p = tid + 256 * u, nl = p >> 4, mq = (p & 15) * 4;
+      const int n = n0 + nl, m = m0 + mq;
+      if (n < g.N && m + 4 <= g.M) {
+        const float *cs = Cs + mq * GLX + nl;
+        *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(cs[0], cs[GLX], cs[2 * GLX], cs[3 * GLX]);
+      }
+    }
+    return;
+  }
   if (g.pk1) {
     // tile rows are in gates-packed order: row r = 4*(cell - cell0) + gate, cell0 = m0/4 (a multiple of 16); columns are
     // the k axis of the folded gates operand and the row (cell) axis of the folded d_m operand.  Stage the tile in LDS,
@@ -1727,7 +1782,7 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
         if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = val;
         if (g.C3 && m >= g.tail0) g.C3[(size_t)(m - g.tail0) * g.N + n] = val;
       }
-      if (g.Ct) {               // beta == 0 and no bias on this path (launch_fold)
+      if (g.Ct) {               // transposed copy of the raw product (beta == 0, no bias)
         const int m = m0 + wr * 32 + mi * 16 + 4 * kg;
         if (m + 4 <= g.M) *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(e[0], e[1], e[2], e[3]);
       }
@@ -1856,6 +1911,8 @@ struct GradsArgs {
   const float *dgifo, *cc;
   float beta;
   float *g_bias, *g_pi, *g_pf, *g_po;
+  float *p_bias, *p_pi, *p_pf, *p_po;   // parameters to update in the same pass (null: gradient only)
+  float lr, clip;
 };
 
 // bias / peephole column sums of k_grads: block vb covers 64 columns of the 4C gate axis with 4 row groups
@@ -1893,9 +1950,23 @@ __device__ __forceinline__ void grads_column_sums(const GradsArgs &a, int vb, fl
   if (ty == 0 && col < 4 * C) {
     for (int w = 1; w < 4; w++) { sb += rb[w][tx]; sp += rp[w][tx]; }
     const int gate = col / C, cell = col - gate * C;
-    a.g_bias[col] = (a.beta != 0.f ? a.beta * a.g_bias[col] : 0.f) + sb;
+    auto fold_update = [&](float c, float *pp) {       // :504-512 for one vector element
+      if (a.clip > 0.f) { c = c < -a.clip ? -a.clip : c; c = c > a.clip ? a.clip : c; }
+      float pv = *pp;
+      pv = pv + (-a.lr) * c;
+      *pp = pv;
+      return c;
+    };
+    float cb = (a.beta != 0.f ? a.beta * a.g_bias[col] : 0.f) + sb;
+    if (a.p_bias) cb = fold_update(cb, a.p_bias + col);
+    a.g_bias[col] = cb;
     float *gp = gate == 1 ? a.g_pi : gate == 2 ? a.g_pf : gate == 3 ? a.g_po : nullptr;
-    if (gp) gp[cell] = (a.beta != 0.f ? a.beta * gp[cell] : 0.f) + sp;
+    float *pq = gate == 1 ? a.p_pi : gate == 2 ? a.p_pf : gate == 3 ? a.p_po : nullptr;
+    if (gp) {
+      float cp = (a.beta != 0.f ? a.beta * gp[cell] : 0.f) + sp;
+      if (pq) cp = fold_update(cp, pq + cell);
+      gp[cell] = cp;
+    }
   }
 }
 
@@ -2762,6 +2833,7 @@ static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const flo
   g.Cm = Cm; g.ldc = ldc; g.bias = bias;
   g.Ct = nullptr; g.ldct = 0; g.C2 = nullptr; g.ldc2 = 0; g.C3 = nullptr; g.tail0 = 0;
   g.gperm = 0; g.pk1 = nullptr; g.nch1 = 0; g.pk2 = nullptr; g.nch2 = 0;
+  g.P = nullptr; g.lr = 0.f; g.clip = 0.f;
   // branch-free 8-wide fetches need aligned rows and a contiguous extent that is a multiple of 8
   g.vecA = aligned16(A) && lda % 4 == 0 && (transA ? M : K) % 8 == 0;
   g.vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K : N) % 8 == 0;
@@ -2838,9 +2910,11 @@ hipError_t launch_bwd_tail(const Dims &d, const float *dgifo, const float *wr, c
   KLAUNCH(k_splitk_reduce2, dim3(nbr1 + nbr2), dim3(256), st, pr2, r1, r2, nbr1);
 }
 
+bool grads_bf16_tiles(const Dims &d, bool bf16) { return bf16 && d.T * d.S >= GRADS_BF16_MIN_ROWS; }
+
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst,
-                        hipStream_t st, LaunchProbe pr, bool bf16) {
+                        hipStream_t st, LaunchProbe pr, bool bf16, const GradsUpdate *upd) {
   const int S = d.S, C = d.C, R = d.R, I = d.I, TS = d.T * d.S;
   const long o_wx = 0, o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_pi = o_b + 4 * C,
              o_pf = o_pi + C, o_po = o_pf + C, o_wm = o_po + C;
@@ -2854,11 +2928,23 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
   a.nb2 = a.nb1 + cdiv(R, GT) * cdiv(C, GT);
   a.C = C; a.S = S; a.T = d.T; a.dgifo = dgifo; a.cc = cc; a.beta = beta;
   a.g_bias = dst + o_b; a.g_pi = dst + o_pi; a.g_pf = dst + o_pf; a.g_po = dst + o_po;
+  a.p_bias = a.p_pi = a.p_pf = a.p_po = nullptr; a.lr = 0.f; a.clip = 0.f;
+  if (upd) {                                          // Update folded into the same pass (fp32 tiles only)
+    float *pb = upd->params;
+    a.wx.P = pb + o_wx; a.wr.P = pb + o_wr; a.wm.P = pb + o_wm;
+    a.wx.lr = a.wr.lr = a.wm.lr = a.lr = upd->lr;
+    a.wx.clip = a.wr.clip = a.wm.clip = a.clip = upd->clip;
+    a.wx.Ct = upd->wxT; a.wx.ldct = 4 * C;           // [I x 4C]
+    a.wr.Ct = upd->wrT; a.wr.ldct = 4 * C;           // [R x 4C]
+    a.wm.Ct = upd->wmT; a.wm.ldct = R;               // [C x R]
+    a.p_bias = pb + o_b; a.p_pi = pb + o_pi; a.p_pf = pb + o_pf; a.p_po = pb + o_po;
+  }
   a.nvec = cdiv(4 * C, 64);
   // below ~256 frames per minibatch the products are write-bound and the 64x64 fp32 tiles are faster (80 frames: 13.4 vs
   // 16.5 us); from there on the bf16 tiles win (640 frames at 512/1024/512: 99 -> 55 us)
   const bool bf_ok = bf16 && TS >= GRADS_BF16_MIN_ROWS && aligned16(dgifo) && aligned16(dr) && aligned16(in) && aligned16(rr) && aligned16(mm) &&
                      in_stride % 4 == 0 && C % 4 == 0 && R % 4 == 0 && I % 4 == 0;
+  if (bf_ok && upd) return hipErrorInvalidValue;
   if (bf_ok) {                                        // 128x128 tiles on the bf16 pipe
     a.nb0 = cdiv(4 * C, BT) * cdiv(I, BT);
     a.nb1 = a.nb0 + cdiv(4 * C, BT) * cdiv(R, BT);

@@ -49,6 +49,7 @@ class DataParallelLstm:
     grad_blob_tensor(), apply_momentum, update (kaldi_lstm_amd.Engine provides exactly these)."""
 
     DEFER_MOMENTUM = 1
+    FUSE_UPDATE = 2       # klstm.h: the Update follows immediately (it does, two lines below)
 
     def __init__(self, engine, group=None, force_collective=False):
         import torch.distributed as dist
@@ -81,7 +82,7 @@ class DataParallelLstm:
             e.reset(reset_flags)
         e.propagate(x, out)
         if not self.collective:
-            e.backpropagate(x, out_diff, in_diff, momentum, 0)
+            e.backpropagate(x, out_diff, in_diff, momentum, self.FUSE_UPDATE)
         else:
             e.backpropagate(x, out_diff, in_diff, momentum, self.DEFER_MOMENTUM)
             if self.comm is not None:

@@ -1111,3 +1111,43 @@ def test_config_c1_whole_utterance_forward():
         cs, rs = e.get_state(); st = o.get_state()
         assert relerr(cs, st[:, 4 * C:5 * C]) <= 2e-4 and relerr(rs, st[:, 7 * C:]) <= 2e-4
         e.close()
+
+
+@pytest.mark.parametrize("I,C,R,S,T,persist,clip", [
+    (40, 64, 32, 4, 6, -1, 0.0),
+    (40, 64, 32, 4, 6, 0, 0.0),           # launch-per-step chains
+    (72, 136, 40, 2, 7, -1, 0.05),        # partial tiles, gradient clipping inside the fused pass
+    (40, 800, 512, 4, 20, -1, 0.0),       # BASELINE.json configs[1]
+])
+def test_backpropagate_fuse_update_flag(I, C, R, S, T, persist, clip):
+    """KLSTM_BPTT_FUSE_UPDATE: the gradient products wait for klstm_update and run as one pass with it (:468-487 + :504-512
+    + the transposed copies).  Bit-identical to the two-kernel path over chained minibatches -- parameters, momentum
+    buffers, outputs of the following forward pass (which reads the refreshed transposed / folded copies) -- and a call that
+    looks at the momentum buffers between the two (get_corr) gets the finished gradient."""
+    p = make_params(I, C, R, scale=0.3 if C < 200 else 0.01, seed=11)
+    rng = np.random.RandomState(12)
+    xs = [dev(rng.randn(T * S, I)) for _ in range(3)]
+    ods = [dev(0.3 * rng.randn(T * S, R)) for _ in range(3)]
+    res = []
+    for mode in ("plain", "fused", "fused+peek"):
+        e = make_engine(I, C, R, S, p)
+        e.set_option("persist", persist)
+        out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+        outs, peeks = [], []
+        for x, od in zip(xs, ods):
+            e.propagate(x, out)
+            outs.append(out.cpu().numpy().copy())
+            e.backpropagate(x, od, idf, momentum=0.9, flags=0 if mode == "plain" else 2)
+            if mode == "fused+peek":
+                peeks.append(e.get_corr())
+            e.update(1e-3 if C < 200 else 1e-5, clip)
+        e.synchronize()
+        res.append((outs, idf.cpu().numpy(), e.get_corr(), e.get_params(), peeks))
+        e.close()
+    for other in res[1:]:
+        for a, b in zip(res[0][0], other[0]):
+            assert np.array_equal(a, b)
+        for a, b in zip(res[0][1:4], other[1:4]):
+            assert np.array_equal(a, b)
+    if clip == 0.0:       # (without clipping the momentum buffer after the Update is what get_corr saw before it)
+        assert np.array_equal(res[2][4][-1], res[0][2])

@@ -19,7 +19,7 @@ for S in (1, 2, 4, 8):
         out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
         with torch.cuda.stream(stream):
             def step():
-                e.propagate(x, out); e.backpropagate(x, od, ind, 0.9); e.update(1e-5)
+                e.propagate(x, out); e.backpropagate(x, od, ind, 0.9, 2); e.update(1e-5)
             try:
                 for _ in range(10): step()
                 e.synchronize()
@@ -30,11 +30,11 @@ for S in (1, 2, 4, 8):
                 us = (time.perf_counter() - t0) / N * 1e6
                 e.set_option("profile", 1)
                 for _ in range(3): step()
-                e.profile_query("k_grads"); e.set_option("profile", 1)
+                e.profile_query("k_grads_update"); e.profile_query("k_grads"); e.set_option("profile", 1)
                 for _ in range(10): step()
                 kern = {}
                 for name in ("k_gates_step", "k_gates_fold", "k_dmf_step", "k_fwd_persist", "k_bwd_persist", "k_gemm_rbatch", "k_reduce_rbatch", "k_gemm_P", "k_reduce_P",
-                             "k_gemm_tail", "k_reduce_tail", "k_grads", "k_update_repack", "k_pack", "k_fold", "k_pack_foldx"):
+                             "k_gemm_tail", "k_reduce_tail", "k_grads", "k_grads_update", "k_update_repack", "k_pack", "k_fold", "k_pack_foldx"):
                     tot, n = e.profile_query(name)
                     if n: kern[name] = round(tot / 10, 1)
                 e.set_option("profile", 0)
