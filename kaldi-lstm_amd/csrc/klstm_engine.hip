@@ -1048,9 +1048,14 @@ klstm_status klstm_affine_update(const float *in, int in_stride, const float *ou
                                  float lr_bias, float momentum, void *hip_stream) {
   if (!in || !out_diff || !W || !bias || !W_corr || !bias_corr) return fail(KLSTM_ERR_ARG, "klstm_affine_update: null argument");
   hipStream_t st = (hipStream_t)hip_stream;
-  HIPCHK(launch_gemm(true, false, out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, momentum, W_corr, in_dim, nullptr, st));
+  if (in_dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(W_corr)) & 15) == 0) {
+    // gradient product, momentum and Update of the weight matrix in one pass (no second trip over the 3 x 34 MB)
+    HIPCHK(launch_gemm_tn_update(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, momentum, W_corr, W, in_dim, lr, st));
+  } else {
+    HIPCHK(launch_gemm(true, false, out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, momentum, W_corr, in_dim, nullptr, st));
+    HIPCHK(launch_axpy(W, W_corr, -lr, (long)out_dim * in_dim, st));
+  }
   HIPCHK(launch_col_sum(out_diff, rows, out_dim, od_stride, momentum, bias_corr, st));
-  HIPCHK(launch_axpy(W, W_corr, -lr, (long)out_dim * in_dim, st));
   HIPCHK(launch_axpy(bias, bias_corr, -lr_bias, out_dim, st));
   return KLSTM_OK;
 }
@@ -1058,7 +1063,10 @@ klstm_status klstm_affine_gradient(const float *in, int in_stride, const float *
                                    int out_dim, float *W_grad, float *bias_grad, void *hip_stream) {
   if (!in || !out_diff || !W_grad || !bias_grad) return fail(KLSTM_ERR_ARG, "klstm_affine_gradient: null argument");
   hipStream_t st = (hipStream_t)hip_stream;
-  HIPCHK(launch_gemm(true, false, out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, 0.f, W_grad, in_dim, nullptr, st));
+  if (in_dim % 4 == 0 && (reinterpret_cast<uintptr_t>(W_grad) & 15) == 0)
+    HIPCHK(launch_gemm_tn_coal(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, 0.f, W_grad, in_dim, st));
+  else
+    HIPCHK(launch_gemm(true, false, out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, 0.f, W_grad, in_dim, nullptr, st));
   HIPCHK(launch_col_sum(out_diff, rows, out_dim, od_stride, 0.f, bias_grad, st));
   return KLSTM_OK;
 }

@@ -56,6 +56,11 @@ bool fold_direct_supported(const Dims &d);
 void set_fold_direct(int v);
 hipError_t launch_fold_direct(const Dims &d, const float *wr, const float *wmT, float *pk_fold[2], int nch1, int nch2,
                               hipStream_t st, LaunchProbe pr = {});
+// Cm = beta*Cm + A^T B and P -= lr*Cm in one pass (N, ldc % 4 == 0, 16-byte aligned Cm and P)
+hipError_t launch_gemm_tn_update(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm,
+                                 float *P, int ldc, float lr, hipStream_t st, LaunchProbe pr = {});
+hipError_t launch_gemm_tn_coal(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm,
+                               int ldc, hipStream_t st, LaunchProbe pr = {});
 // C = A B^T + bias for up to 80 rows and many columns, operands straight into MFMA registers (klstm_fold.hip)
 void set_direct_nt_shape(int ni, int waves);
 bool direct_nt_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb);

@@ -1505,6 +1505,7 @@ struct GemmJob {
   // gradient product with the Update folded in (launch_grads with a GradsUpdate): Cm is the momentum buffer,
   // Cm = beta*Cm + A*B (:468-487), clipped if clip > 0, then P -= lr*Cm (:504-512); Ct then receives the UPDATED P
   float *P; float lr, clip;
+  int coal;               // 1: Cm = beta*Cm + A*B through the same coalesced 16-byte epilogue without P (N, ldc % 4 == 0, aligned, no bias)
 };
 
 // One operand tile = GT x GK elements = 2 x (8 floats per thread).  Operand stored [X x K] (TA=false: 8 consecutive k
@@ -1608,7 +1609,7 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
   // beta != 0 (momentum folded into the gradient products, :468-487): the old C tile is requested now so that its
   // HBM latency hides under the K loop instead of sitting in front of the stores
   float cold[2][2][4];
-  if (g.beta != 0.f && !g.P) {
+  if (g.beta != 0.f && !g.P && !g.coal) {
 #pragma unroll
     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
@@ -1670,8 +1671,8 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
     }
     __syncthreads();
   }
-  if (g.P) {
-    // Gradient product with momentum and Update folded in (launch_grads + GradsUpdate; N, ldc, ldct multiples of 4, 16-byte
+  if (g.P || g.coal) {
+    // Gradient product with momentum and (P != null) Update folded in (launch_grads + GradsUpdate; N, ldc, ldct multiples of 4, 16-byte
     // aligned blobs).  Everything that touches HBM moves as 16-byte pieces, 256 contiguous bytes per tile row: the tile goes
     // through LDS (the K loop ended with a barrier, As is free), then  corr = beta*corr + grad (:468-487), clip,
     // theta -= lr*corr (:504-512)  on float4 rows, then the transposed copy of the updated parameters.
@@ -1692,8 +1693,10 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
       if (m < g.M && n + 4 <= g.N) {
         float *cs = Cs + ml * GLX + nq;
         const float4 a = *reinterpret_cast<const float4 *>(cs);
-        float4 *cp = reinterpret_cast<float4 *>(g.Cm + (size_t)m * g.ldc + n), *pp = reinterpret_cast<float4 *>(g.P + (size_t)m * g.ldc + n);
-        float4 pv = *pp;
+        float4 *cp = reinterpret_cast<float4 *>(g.Cm + (size_t)m * g.ldc + n);
+        float4 *pp = reinterpret_cast<float4 *>((g.P ? g.P : g.Cm) + (size_t)m * g.ldc + n);
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.P) pv = *pp;
         float c[4] = {a.x, a.y, a.z, a.w};
         if (g.beta != 0.f) {
           const float4 o = *cp;
@@ -1703,13 +1706,15 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
 #pragma unroll
           for (int q = 0; q < 4; q++) { c[q] = c[q] < -g.clip ? -g.clip : c[q]; c[q] = c[q] > g.clip ? g.clip : c[q]; }
         }
-        pv.x = pv.x + (-g.lr) * c[0]; pv.y = pv.y + (-g.lr) * c[1]; pv.z = pv.z + (-g.lr) * c[2]; pv.w = pv.w + (-g.lr) * c[3];
         *cp = make_float4(c[0], c[1], c[2], c[3]);
-        *pp = pv;
-        *reinterpret_cast<float4 *>(cs) = pv;
+        if (g.P) {
+          pv.x = pv.x + (-g.lr) * c[0]; pv.y = pv.y + (-g.lr) * c[1]; pv.z = pv.z + (-g.lr) * c[2]; pv.w = pv.w + (-g.lr) * c[3];
+          *pp = pv;
+          *reinterpret_cast<float4 *>(cs) = pv;
+        }
       }
     }
-    if (!g.Ct) return;
+    if (!g.Ct || !g.P) return;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -2833,7 +2838,7 @@ static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const flo
   g.Cm = Cm; g.ldc = ldc; g.bias = bias;
   g.Ct = nullptr; g.ldct = 0; g.C2 = nullptr; g.ldc2 = 0; g.C3 = nullptr; g.tail0 = 0;
   g.gperm = 0; g.pk1 = nullptr; g.nch1 = 0; g.pk2 = nullptr; g.nch2 = 0;
-  g.P = nullptr; g.lr = 0.f; g.clip = 0.f;
+  g.P = nullptr; g.lr = 0.f; g.clip = 0.f; g.coal = 0;
   // branch-free 8-wide fetches need aligned rows and a contiguous extent that is a multiple of 8
   g.vecA = aligned16(A) && lda % 4 == 0 && (transA ? M : K) % 8 == 0;
   g.vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K : N) % 8 == 0;
@@ -2849,6 +2854,26 @@ hipError_t launch_gemm(bool transA, bool transB, int M, int N, int K, const floa
   if (transA && !transB) KLAUNCH((k_gemm<true, false>), grid, block, st, pr, g);
   if (!transA && transB) KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
   KLAUNCH((k_gemm<false, false>), grid, block, st, pr, g);
+}
+
+// Cm = beta*Cm + A^T B (gradient of a weight matrix, K = frames), then P -= lr*Cm in the same pass (GemmJob::P):
+// AffineTransform::Update with the momentum folded into the product like ...streams.h:468-487.  N, ldc multiples of 4,
+// 16-byte aligned Cm / P.
+hipError_t launch_gemm_tn_update(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm,
+                                 float *P, int ldc, float lr, hipStream_t st, LaunchProbe pr) {
+  GemmJob g = make_job(true, false, M, N, K, A, lda, B, ldb, beta, Cm, ldc, nullptr);
+  g.P = P; g.lr = lr; g.clip = 0.f;
+  const dim3 grid(cdiv(cdiv(N, GT) * cdiv(M, GT), 8) * 8), block(256);
+  KLAUNCH((k_gemm<true, false>), grid, block, st, pr, g);
+}
+
+// Cm = beta*Cm + A^T B through the coalesced epilogue (N, ldc % 4 == 0, 16-byte aligned Cm)
+hipError_t launch_gemm_tn_coal(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm,
+                               int ldc, hipStream_t st, LaunchProbe pr) {
+  GemmJob g = make_job(true, false, M, N, K, A, lda, B, ldb, beta, Cm, ldc, nullptr);
+  g.coal = 1;
+  const dim3 grid(cdiv(cdiv(N, GT) * cdiv(M, GT), 8) * 8), block(256);
+  KLAUNCH((k_gemm<true, false>), grid, block, st, pr, g);
 }
 
 // Split-K plan: worth it when the output tiles cover less than half the chip and K is long.
@@ -2939,6 +2964,7 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
     a.wm.Ct = upd->wmT; a.wm.ldct = R;               // [C x R]
     a.p_bias = pb + o_b; a.p_pi = pb + o_pi; a.p_pf = pb + o_pf; a.p_po = pb + o_po;
   }
+  if (!upd && aligned16(dst) && C % 4 == 0 && R % 4 == 0 && I % 4 == 0) a.wx.coal = a.wr.coal = a.wm.coal = 1;
   a.nvec = cdiv(4 * C, 64);
   // below ~256 frames per minibatch the products are write-bound and the 64x64 fp32 tiles are faster (80 frames: 13.4 vs
   // 16.5 us); from there on the bf16 tiles win (640 frames at 512/1024/512: 99 -> 55 us)
