@@ -531,7 +531,8 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
   unsigned *abortf = reinterpret_cast<unsigned *>(red + NKW * 4);
   constexpr int PLW = 4 * TPW;                       // own cells
   int *dflag = reinterpret_cast<int *>(abortf + 1);  // lowest step whose slab the d_r contraction has read (counts down)
-  float *ldsP = reinterpret_cast<float *>(abortf + 4);        // [T*S][PLW]: own columns of P = out_diff W_r_m (pin)
+  float *ldsDC = reinterpret_cast<float *>(abortf + 4);       // [4][PLW]: d_c(t) of the own cells (sweeper -> P wave -> dc plane)
+  float *ldsP = ldsDC + 4 * 4 * TPW;                          // [T*S][PLW]: own columns of P = out_diff W_r_m (pin)
   // the d_r / in_diff columns of this workgroup: 4 rows of W_gifo_r^T (workgroups 0 .. R/4-1), then of W_gifo_x^T
   const int ngr = a.R / 4, ngx = (a.din & 2) ? a.I / 4 : 0;
   const bool d_on = a.din && (int)blockIdx.x < ngr + ngx, d_isr = (int)blockIdx.x < ngr;
@@ -675,6 +676,16 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
       if (a.pin && t > 1) p_batches((t - 3) * S);    // frame t-2, read by the owner at step t-1
       lds_barrier();                                 // slab dgifo(t) ready
       if (*abortf) break;
+      // rows of the dgifo / dc planes of this workgroup's cells, out of the slab (lane = stream, gate, cell)
+#pragma unroll
+      for (int tl = 0; tl < TPW; tl++) {
+        const int os = lane >> 4, og = (lane >> 2) & 3, oc = ((int)blockIdx.x * TPW + tl) * 4 + (lane & 3);
+        if (os < S && oc < C) a.dgifo[((size_t)t * S + os) * K + og * C + oc] = ldsD[os * LDD + og * C + oc];
+        if (lane < 16) {
+          const int ds = lane >> 2;
+          if (ds < S && oc < C) a.dc[((size_t)t * S + ds) * C + oc] = ldsDC[ds * (4 * TPW) + tl * 4 + (lane & 3)];
+        }
+      }
       if (t > 1) lds_barrier();
       // dgifo(t) against this workgroup's 4 rows of W_gifo_r^T: d_r(t-1) = out_diff(t-1) + dgifo(t) W_gifo_r (:391);
       // against 4 rows of W_gifo_x^T: in_diff(t) (:457).  Both operands in LDS, behind the second barrier: the K waves
@@ -788,27 +799,36 @@ __global__ __launch_bounds__(PNW * 64) void k_bwd_persist(PersistBwdArgs a) {
       if (d_on && t < T)                             // the d_r contraction still reads the slab of step t+1?
         while (__hip_atomic_load(dflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > t + 1) __builtin_amdgcn_s_sleep(1);
       // elementwise BPTT of frame t (:411-440), replicated in every workgroup
+      float4 dgk[PCELL][4];
+      float dck[PCELL][4];
 #pragma unroll
       for (int j = 0; j < PCELL; j++)
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-          float d_c;
-          const float4 dg = bptt_apply(dm[j][s], cf[j][s], yfk[j][s], kk[j][s], d_c);
-          if (cell[j] < C && s < S) {
-            if (t > 1 || a.din) {                    // B operand of the contraction (t == 1: of in_diff(1) only)
-              float *lp = ldsD + s * LDD + cell[j];
-              lp[0] = dg.x; lp[C] = dg.y; lp[2 * C] = dg.z; lp[3 * C] = dg.w;
-            }
-            if (mine[j]) {                           // own cells: rows of the dgifo / dc planes (gradient products, d_r, in_diff)
-              const size_t row = (size_t)t * S + s;
-              float *dp = a.dgifo + row * K + cell[j];
-              dp[0] = dg.x; dp[C] = dg.y; dp[2 * C] = dg.z; dp[3 * C] = dg.w;
-              a.dc[row * C + cell[j]] = d_c;
-            }
+          dgk[j][s] = bptt_apply(dm[j][s], cf[j][s], yfk[j][s], kk[j][s], dck[j][s]);
+          if (cell[j] < C && s < S && (t > 1 || a.din)) {   // B operand of the contraction (t == 1: of in_diff(1) only)
+            float *lp = ldsD + s * LDD + cell[j];
+            lp[0] = dgk[j][s].x; lp[C] = dgk[j][s].y; lp[2 * C] = dgk[j][s].z; lp[3 * C] = dgk[j][s].w;
+            if (mine[j]) ldsDC[s * (4 * TPW) + cell[j] - (int)blockIdx.x * 4 * TPW] = dck[j][s];
           }
         }
-      PT_MARK(2);                                    // elementwise + slab / plane stores
-      if (t == 1 && !a.din) break;
+      // own cells: rows of the dgifo / dc planes (gradient products).  The P wave copies them out of the slab behind the
+      // barrier (as sweeper stores in front of it, the one wave per workgroup that owns cells held everybody up: 0.9 ->
+      // 0.56 us for this phase); only the last frame without an in_diff step has no barrier and does it here
+      auto own_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < PCELL; j++)
+#pragma unroll
+          for (int s = 0; s < 4; s++)
+            if (mine[j] && s < S) {
+              const size_t row = (size_t)t * S + s;
+              float *dp = a.dgifo + row * K + cell[j];
+              dp[0] = dgk[j][s].x; dp[C] = dgk[j][s].y; dp[2 * C] = dgk[j][s].z; dp[3 * C] = dgk[j][s].w;
+              a.dc[row * C + cell[j]] = dck[j][s];
+            }
+      };
+      PT_MARK(2);                                    // elementwise + slab stores
+      if (t == 1 && !a.din) { own_rows(); break; }
       lds_barrier();                                 // slab ready
       PT_MARK(1);
       if (*abortf || t == 1) break;
@@ -950,7 +970,7 @@ bool persist_p_in_kernel(const Dims &d) {
 bool persist_tail_in_kernel(const Dims &d, bool want_in_diff) {
   const PGeo g = pick_geo(d.C, pcdiv(4 * d.C, 128));
   if (!g.tpw || d.R % 4 != 0 || d.I % 4 != 0 || d.C % 4 != 0) return false;
-  const size_t lds = (size_t)(8 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 16 + 4 + (persist_p_in_kernel(d) ? d.T * d.S * 4 * g.tpw : 0)) * sizeof(float);
+  const size_t lds = (size_t)(8 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 16 + 4 + 16 * g.tpw + (persist_p_in_kernel(d) ? d.T * d.S * 4 * g.tpw : 0)) * sizeof(float);
   return d.R / 4 + (want_in_diff ? d.I / 4 : 0) <= d.C / 4 / g.tpw && lds <= 160 * 1024;
 }
 
@@ -971,7 +991,7 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
   a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 0; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // (the second barrier already keeps the sweepers off the fabric)
   const PGeo g = pick_geo(d.C, a.nch);
   if (!g.tpw || !p.pk_fold) return hipErrorInvalidValue;
-  const size_t shm = (size_t)((a.din ? 8 : 4) * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4 + (a.pin ? d.T * d.S * 4 * g.tpw : 0)) * sizeof(float);
+  const size_t shm = (size_t)((a.din ? 8 : 4) * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4 + 16 * g.tpw + (a.pin ? d.T * d.S * 4 * g.tpw : 0)) * sizeof(float);
   const int grid = d.C / 4 / g.tpw;
   PDISPATCH_BWD(k_bwd_persist);
 }

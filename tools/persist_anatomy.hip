@@ -81,7 +81,7 @@ int main(int argc, char **argv) {
       a.C = C; a.R = R; a.S = S; a.T = T; a.pin = 0; a.din = 0; a.I = I; a.wrT = nullptr; a.wxT = nullptr; a.dr = nullptr; a.in_diff = nullptr; a.id_stride = 0; a.od = nullptr; a.od_stride = 0; a.wmT = nullptr; a.nch = nchb; a.wpk = wpb; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
       a.gifo = gifo; a.cc = cc; a.hh = hh; a.dgifo = dgifo; a.dc = dc; a.P = P; a.gran = gran; a.ctrl = ctrl; a.nap0 = nap0; a.nap = 0; a.dbg = dbg;
       const PGeo g = pick_geo(C, nchb);
-      const size_t shm = (size_t)(4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4) * sizeof(float);
+      const size_t shm = (size_t)(4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4 + 16 * g.tpw) * sizeof(float);
       const int grid = C / 4 / g.tpw;
       LaunchProbe pr;
       auto go = [&]() -> hipError_t { PDISPATCH_BWD(k_bwd_persist); };
