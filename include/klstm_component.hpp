@@ -199,8 +199,11 @@ class LstmProjectedStreams {
     KLSTM_ASSERT(in.NumRows() % nstream_ == 0);                   // :225
     KLSTM_ASSERT(in.NumCols() == input_dim_ && out->NumCols() == output_dim_ && out->NumRows() == in.NumRows());
     EnsureEngine();
-    // a CuMatrix holds host memory when Kaldi runs with the GPU disabled (cu-matrix.h:479-481): staged, same device path
-    if (in.NumRows() > 0 && klstm_pointer_on_device(eng_, in.Data()) == 0)
+    // a CuMatrix holds host memory when Kaldi runs with the GPU disabled (cu-matrix.h:479-481): staged, same device path.
+    // All matrices of a call live on the same side in Kaldi; a mixed call would hand a host pointer to a kernel.
+    const int in_dev = in.NumRows() > 0 ? klstm_pointer_on_device(eng_, in.Data()) : 1;
+    KLSTM_ASSERT(in.NumRows() == 0 || klstm_pointer_on_device(eng_, out->Data()) == in_dev);
+    if (in_dev == 0)
       Check(klstm_propagate_host(eng_, in.Data(), in.NumRows(), in.Stride(), out->Data(), out->Stride()));
     else
       Check(klstm_propagate(eng_, in.Data(), in.NumRows(), in.Stride(), out->Data(), out->Stride()));
@@ -211,7 +214,10 @@ class LstmProjectedStreams {
                                 MatrixView *in_diff) {
     (void)out;
     EnsureEngine();
-    if (in.NumRows() > 0 && klstm_pointer_on_device(eng_, in.Data()) == 0)
+    const int in_dev = in.NumRows() > 0 ? klstm_pointer_on_device(eng_, in.Data()) : 1;
+    KLSTM_ASSERT(in.NumRows() == 0 || (klstm_pointer_on_device(eng_, out_diff.Data()) == in_dev &&
+                                       (!in_diff || klstm_pointer_on_device(eng_, in_diff->Data()) == in_dev)));
+    if (in_dev == 0)
       Check(klstm_backpropagate_host(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
                                      in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
                                      opts_.momentum, dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : KLSTM_BPTT_FUSE_UPDATE));

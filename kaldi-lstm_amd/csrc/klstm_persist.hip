@@ -1,4 +1,5 @@
-// kaldi-lstm_amd/csrc/klstm_persist.hip -- weights-RESIDENT recurrence chain for NumStream <= 4 (engine option "persist").
+// kaldi-lstm_amd/csrc/klstm_persist.hip -- weights-RESIDENT recurrence chain (engine option "persist"): forward for up to 8
+// streams, backward for up to 4; the default chain from 1 to 4 streams.
 //
 // The launch-per-step chain (klstm_kernels.hip) re-fetches its whole weight operand (~10.5 MB at 40/800/512) in every one
 // of the 2T step kernels because nothing on-chip survives a kernel boundary: 12x the algorithmic HBM traffic of a
@@ -20,19 +21,23 @@
 //   * every spin is bounded (wall clock, ~50 ms): on expiry the workgroup records the step in ctrl[2] and leaves; the
 //     engine reports it at the next synchronising call.  All workgroups must be co-resident: grid <= 200 workgroups,
 //     one per CU.
-//   * wave roles: the first wave of every tile OWNS the tile's cell math, its granule stores and its plane stores and
-//     does NOT sweep (loads return in order behind a wave's own stores: a sweeping wave with write-through stores in
-//     flight would wait for their acknowledgement first); all other waves sweep, one cell per thread.
+//   * wave roles: the waves that own cell math, granule stores and plane stores do NOT sweep (loads return in order behind
+//     a wave's own stores: a sweeping wave with write-through stores in flight would wait for their acknowledgement
+//     first); one wave per workgroup carries the products that hang off the chain (r = W_r_m m forward; P, d_r, in_diff
+//     and the own plane rows backward); all other waves sweep, PCELL cells per thread.
 //   * barriers wait for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): nothing global is ordered by them.
 // Backward: only d_m travels.  dgifo(t+1) -- the 4C-wide operand of the contraction -- is recomputed by EVERY workgroup
 // for all cells from d_m(t+1), its own replica of the d_c / d_i / d_f carry and the forward planes (L2-resident, requested
 // before the sweep): S x C granules per step instead of S x 4C, and the replicas are bit-identical (same instruction
-// sequence on the same inputs).  The owner of a cell writes its dgifo / dc rows for the gradient products.
+// sequence on the same inputs).  The workgroup that owns a cell writes its dgifo / dc rows for the gradient products.
+// Step 1 of the forward pass closes over the CARRIED r (possibly produced under older weights) and is contracted against
+// the natural [W_gifo_r | W_gifo_x] rows inside the same launch.
 //
-// Geometry = the 4x4x1_16b forms of klstm_kernels.hip (same packed operands, written by the fold product):
-//   forward : tile = 4 cells x 4 gates (16 rows), chunk = 32 k, lane l feeds A row l&15 / k-group l>>4, B stream l&3
-//   backward: tile = 4 cells (4 rows), chunk = 128 k, block b = k-group, A lane 4b+i = row i, B lane 4b+j = stream j
-// A workgroup owns TPW tiles; its 8 waves are split TPW ways, the waves of a tile split K.
+// Geometry = the 4-row form of v_mfma_f32_4x4x1_16b (16 blocks = 16 k-groups of one 4 rows x 4 streams tile, chunk = 128 k,
+// A lane 4b+i = row i, B lane 4b+j = stream j), on the packed operands the fold product writes:
+//   forward : a cell wave holds the 4 gate rows of ONE cell over the whole K = [m | x] (gathered from the 16-row gates operand)
+//   backward: 4 K waves per tile of 4 cells, each a quarter of K = 4C of the W_rm^T operand
+// A workgroup owns TPW tiles (1 by default: 200 workgroups of 12 waves at C = 800).
 #include "klstm_kernels.h"
 #include "klstm_math.h"
 
@@ -187,12 +192,12 @@ __device__ __forceinline__ void finish(unsigned *ctrl, unsigned epoch, int T) {
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// forward: steps 2..T (step 1 closes over the carried r under possibly older weights and stays with k_gates_v).
+// forward: steps 1..T (+ one more exchange for r(T) when the projection runs here).
 // Wave roles: the first 4*TPW waves are CELL waves -- wave w owns cell (w & 3) of tile (w >> 2) of the workgroup: its four
 // gate rows over the whole K = [m | x] in the 4-row geometry (16 k-groups x 4 rows per MFMA), so the contraction of a
-// cell needs no cross-wave combine: in-wave butterfly, cell math on lanes 0..3 (one per stream), granule + plane stores,
-// all in that wave.  ONE workgroup barrier per step (slab ready).  The remaining waves sweep, one cell per thread.
-// The weights come from the 16-row packed operand of the launch-per-step kernels, gathered once at kernel start.
+// cell needs no cross-wave combine: in-wave butterfly, cell math on lanes 12..15 (one per stream), granule + plane stores,
+// all in that wave.  ONE workgroup barrier per step (slab ready).  Wave 4*TPW projects, the remaining waves sweep.
+// The folded rows come from the 16-row packed gates operand, gathered once behind step 1.
 // -------------------------------------------------------------------------------------------------------------------
 // One contraction of a cell wave: NCHUNK 128-wide chunks of resident rows (a0/a1) against slab row `bj` (stride LD).
 // Exactly NCHUNK chunks, no branch: chunks beyond the operand have zero weights and read zero slab columns, so every LDS

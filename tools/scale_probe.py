@@ -17,7 +17,7 @@ def run(S, T, n=50, small_max=None, bf16=0, dims=None):
     x = torch.randn(T * S, I, device="cuda"); od = 0.1 * torch.randn(T * S, R, device="cuda")
     out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
     torch.cuda.synchronize()
-    def fbu(): e.propagate(x, out); e.backpropagate(x, od, ind, 0.9); e.update(1e-5)
+    def fbu(): e.propagate(x, out); e.backpropagate(x, od, ind, 0.9, 2); e.update(1e-5)   # (flags 2: the Update follows, klstm.h)
     t0 = time.perf_counter(); fbu(); e.synchronize(); first = time.perf_counter() - t0
     for _ in range(3): fbu()
     e.synchronize(); t0 = time.perf_counter()
@@ -38,6 +38,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "bf16":
     for b in (0, 1):                                  # BASELINE.json configs[4] inner layer, 32 streams per GPU
         print("c5 layer 512->1024/512 bf16=%d " % b, end=""); run(32, 20, bf16=b, dims=(512, 1024, 512))
     sys.exit(0)
-for S in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+for S in (1, 2, 4, 8, 12, 16, 32, 64, 128, 256):
     run(S, 20)
 run(1, 1000, n=5)
