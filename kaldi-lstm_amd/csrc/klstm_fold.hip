@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256) void k_fold_direct(FoldArgs a) {
 // 80 x 16624 over K = 512, nnet.proto:4): the same register-direct K loop, one wave = all M rows (MI = M/16 blocks) x 16
 // (NI) columns, one-wave workgroups: every wave streams its rows of B exactly once; the M rows of A are re-read by every wave
 // (160 KB each, out of L2: that traffic, 83 MB at NI = 2, is what bounds the kernel -- wider waves leave SIMDs idle, narrower
-// ones double it; sharing A through LDS between the waves of a workgroup is the next step).  The 64x64-tile kernel spends
+// ones double it.  Sharing A through LDS between the 4 waves of a workgroup, one barrier per 32-k chunk, was measured at
+// 48 us with one chunk of prefetch lead: at 40 MFMAs per chunk and wave the loads need >= 4 chunks in flight, which the
+// register ring of the direct form has and a 3-slot LDS ring does not).  The 64x64-tile kernel spends
 // half of its second row tile on padding at M = 80: 37.9 us against 29.5 us here.
 // ---------------------------------------------------------------------------------------------------------------------
 struct DirectNtArgs {
@@ -310,7 +312,7 @@ hipError_t launch_fold_direct(const Dims &d, const float *wr, const float *wmT, 
   return hipGetLastError();
 }
 
-static int g_nt_ni = 2, g_nt_waves = 1;   // measured at 80 x 16624 x 512 (tools/nt_sweep.py): 29.5 us; 1x1 36.7, 2x2 34.0, 4x1 49.4; tiled kernel 37.9
+static int g_nt_ni = 2, g_nt_waves = 1;   //    // measured at 80 x 16624 x 512 (tools/nt_sweep.py): 29.5 us; 1x1 36.7, 2x2 34.0, 4x1 49.4; tiled kernel 37.9
 void set_direct_nt_shape(int ni, int waves) { g_nt_ni = ni == 1 || ni == 2 ? ni : 4; g_nt_waves = waves >= 1 && waves <= 4 ? waves : 2; }
 
 bool direct_nt_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb) {
