@@ -440,6 +440,9 @@ def main():
                        "recurrence": ("persistent weights-resident chain" if "k_bwd_persist" in kern or "k_fwd_persist" in kern else
                                       "folded (W_rm = W_gifo_r W_r_m, one kernel per step and direction)" if folded
                                       else "reference-shaped (gates + projection, d_r + d_m kernels per step)"),
+                       "update": ("gradient products + momentum + Update as one pass (klstm_backpropagate with KLSTM_BPTT_FUSE_UPDATE: the "
+                                  "Update follows immediately, as in Kaldi's Component::Backpropagate)" if "k_grads_update" in kern else
+                                  "gradient products, all-reduce, momentum + Update" if world > 1 else "gradient products, then Update"),
                        "parallelism": "dp%d over streams, 1 all-reduce/minibatch" % world if world > 1 else "single GPU"},
             "timed": {"steps": nsteps_total, "seconds": dt_total},
             "first_k_steps": {"steps": K, "seconds": dt_first, "ms_per_step": dt_first / K * 1e3,
