@@ -901,6 +901,10 @@ def test_full_size_decreasing_T_split_k_workspace(S, Ts):
     (40, 64, 32, 8, 6, True),        # two stream groups against the same resident rows (forward launch; backward per step)
     (40, 800, 512, 6, 20, True),     # ragged second group
     (40, 800, 512, 8, 20, True),     # BASELINE.json configs[2]: 8 streams per GPU
+    (512, 1024, 512, 4, 6, True),    # configs[4]'s inner layer shape: 9 chunks per K wave, 150 KB of LDS backward, wide input
+    (40, 64, 32, 4, 600, True),      # T*S = 2400 rows: P does not fit the LDS budget -> batched P product, the rest in-kernel
+    (40, 256, 192, 2, 9, True),      # R/4 + I/4 = 58 column groups on 64 workgroups
+    (40, 800, 640, 4, 5, False),     # step-1 operand wider than the forward geometry takes -> launch-per-step chain, same answers
 ])
 def test_persistent_chain(I, C, R, S, T, want_in_diff, waves, tpw):
     """Option "persist": steps 2..T of the forward recurrence and T..1 of BPTT run inside ONE launch per direction with the
