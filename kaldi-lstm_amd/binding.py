@@ -285,14 +285,24 @@ class RcclComm:
     `exchange(id_bytes_or_None) -> id_bytes` hands rank 0's 128-byte id to every rank (e.g. a torch.distributed / MPI
     broadcast, or a file); with nranks == 1 no exchange is needed."""
 
-    def __init__(self, nranks, rank, device=0, exchange=None):
-        self.lib = load_library()
+    @staticmethod
+    def unique_id():
+        """128-byte id for a new communicator (call on one rank, hand the bytes to all)."""
         buf = ctypes.create_string_buffer(128)
-        if rank == 0:
-            _chk(self.lib.klstm_comm_get_unique_id(buf))
-        if nranks > 1:
-            raw = exchange(buf.raw if rank == 0 else None)
-            buf = ctypes.create_string_buffer(bytes(raw), 128)
+        _chk(load_library().klstm_comm_get_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, nranks, rank, device=0, exchange=None, uid=None):
+        self.lib = load_library()
+        if uid is not None:
+            buf = ctypes.create_string_buffer(bytes(uid), 128)
+        else:
+            buf = ctypes.create_string_buffer(128)
+            if rank == 0:
+                _chk(self.lib.klstm_comm_get_unique_id(buf))
+            if nranks > 1:
+                raw = exchange(buf.raw if rank == 0 else None)
+                buf = ctypes.create_string_buffer(bytes(raw), 128)
         h = ctypes.c_void_p()
         _chk(self.lib.klstm_comm_init_rank(int(device), int(nranks), int(rank), buf, ctypes.byref(h)))
         self.handle, self.nranks, self.rank = h, nranks, rank

@@ -21,17 +21,40 @@ def native_comm(dist, group=None, device=None):
     the other ranks over the already initialised torch.distributed group (launcher plumbing only: the gradient all-reduce
     itself is then issued by klstm_allreduce_grads / klstm_allreduce_buffer on the engine's stream).  None when the
     process group is not on GPUs (gloo CPU tests keep torch.distributed's all_reduce)."""
+    import sys
     import torch
     from .binding import RcclComm
     if not dist.is_initialized() or dist.get_backend(group) != "nccl":
         return None
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-
-    def exchange(raw):
-        t = torch.tensor(list(raw) if raw is not None else [0] * 128, dtype=torch.uint8, device="cuda")
-        dist.broadcast(t, src=0, group=group)
-        return bytes(t.cpu().tolist())
-    return RcclComm(world, rank, device=torch.cuda.current_device() if device is None else device, exchange=exchange)
+    dev = torch.cuda.current_device() if device is None else device
+    # Every rank takes the same decision: rank 0's id (or its failure to make one) is broadcast, and after the collective
+    # communicator creation the ranks agree on whether ALL of them succeeded; otherwise everybody falls back to
+    # torch.distributed's all_reduce (a rank that raised on its own would leave the others waiting in a collective).
+    msg = torch.zeros(129, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        try:
+            msg[1:] = torch.tensor(list(RcclComm.unique_id()), dtype=torch.uint8)
+            msg[0] = 1
+        except Exception as ex:
+            print("kaldi_lstm_amd.dp: no RCCL unique id (%s)" % ex, file=sys.stderr)
+    dist.broadcast(msg, src=0, group=group)
+    host = msg.cpu().tolist()
+    comm = None
+    if host[0] == 1:
+        try:
+            comm = RcclComm(world, rank, device=dev, uid=bytes(host[1:]))
+        except Exception as ex:
+            print("kaldi_lstm_amd.dp: rank %d could not join the library-owned RCCL communicator (%s)" % (rank, ex), file=sys.stderr)
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        if comm is not None:
+            comm.close()
+        if rank == 0:
+            print("kaldi_lstm_amd.dp: the all-reduce goes through torch.distributed instead of klstm_allreduce_*", file=sys.stderr)
+        return None
+    return comm
 
 
 def shard_time_major(mat, num_stream_total, rank, world):
