@@ -233,10 +233,11 @@ static bool use_fused_x(const klstm_engine *e);
 static bool persist_wanted(const klstm_engine *e, int T) {
   if (e->use_persist == 0 || e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || !use_fused_x(e)) return false;
   if (T < 3 || !persist_supported(Dims{e->I, e->C, e->R, e->S, T})) return false;
-  // auto: 1..4 streams from 8 frames on.  5..8 streams (two groups against the same resident rows, forward launch only)
-  // are available with persist = 1 but bring nothing: the exchange takes twice as long with twice the granules, 4.2 us per
-  // step inside the launch against 4.2 for the launch-per-step kernel (tools/persist_anatomy 8, tools/persist_timing.py)
-  return e->use_persist >= 1 ? true : (T >= 8 && e->S <= 4);
+  // auto: from 8 frames on.  1..4 streams: both directions.  5..8 streams: the forward launch only (two groups against the
+  // same resident rows) -- the exchange takes twice as long with twice the granules, 4.2 us per step inside the launch
+  // against 4.2 for the launch-per-step kernel, but the step-1 kernel, the batched projection pair and the per-Update
+  // packing go away: 296-303 vs 306-309 us per minibatch at 8 streams (tools/persist_timing.py, tools/stream_breakdown.py)
+  return e->use_persist >= 1 ? true : T >= 8;
 }
 static klstm_status ensure_persist(klstm_engine *e) {
   if (e->pctrl) return KLSTM_OK;

@@ -956,7 +956,7 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm; a.rr = p.rr;
   a.x = in; a.x_stride = in_stride; a.prev_c = p.prev_c; a.prev_r = p.prev_r; a.gran = gran; a.ctrl = ctrl;
   a.rin = out && persist_r_in_kernel(d); a.out = out; a.out_stride = out_stride;
-  a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : d.S > 4 ? 14 : 9; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // measured: tools/persist_anatomy
+  a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : d.S > 4 ? 17 : 9; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // measured: tools/persist_anatomy, tools/nap_sweep.py
   const PGeo g = pick_geo_fwd(d.C, a.nch, pcdiv(d.R, KCH) * KCH + d.I);
   if (!g.tpw || !p.pk_fold || (reinterpret_cast<uintptr_t>(in) & 15) || in_stride % 4 != 0) return hipErrorInvalidValue;
   const int ng = d.S > 4 ? 2 : 1;
