@@ -907,6 +907,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else set_persist_waves(value);
     return KLSTM_OK;
   }
+  if (!strcmp(key, "persist_nap0_bwd")) { set_persist_nap0_bwd(value); return KLSTM_OK; }
   if (!strcmp(key, "persist_tail")) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);

@@ -161,6 +161,7 @@ hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long
 //   zero-filled once (one pair per direction).  status != 0 after the launch: a bounded spin expired (0x80000000 | step).
 bool persist_supported(const Dims &d);
 size_t persist_gran_bytes(const Dims &d);
+void set_persist_nap0_bwd(int v);
 bool persist_bwd_supported(const Dims &d);   // the backward persistent kernel (NumStream <= 4; the forward one takes 8)
 bool persist_r_in_kernel(const Dims &d);   // r(t) = W_r_m m(t), the output rows and prev_r written by the forward launch (pass out)
 hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, int in_stride, float *out, int out_stride,

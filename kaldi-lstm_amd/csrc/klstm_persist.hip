@@ -854,6 +854,8 @@ static inline int pcdiv(int a, int b) { return (a + b - 1) / b; }
 static int g_persist_tpw = 0;       // A-B knobs: tiles per workgroup / waves per workgroup (0 = automatic)
 static int g_persist_waves = 0;
 static int g_persist_nap0 = -1, g_persist_nap = -1;   // -1: defaults below
+static int g_persist_nap0_bwd = -1;                   // backward launch separately (-1: follows g_persist_nap0)
+void set_persist_nap0_bwd(int v) { g_persist_nap0_bwd = v; }
 void set_persist_nap(int nap0, int nap) { if (nap0 >= -1) g_persist_nap0 = nap0; if (nap >= -1) g_persist_nap = nap; }
 void set_persist_tpw(int v) { g_persist_tpw = v; }
 void set_persist_waves(int v) { g_persist_waves = v; }
@@ -993,7 +995,8 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
   a.nch = pcdiv(4 * d.C, 128);
   a.wpk = p.pk_fold; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.gran = gran; a.ctrl = ctrl;
-  a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : 0; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // (the second barrier already keeps the sweepers off the fabric)
+  a.nap0 = g_persist_nap0_bwd >= 0 ? g_persist_nap0_bwd : g_persist_nap0 >= 0 ? g_persist_nap0 : 0;     // (the second barrier already keeps the sweepers off the fabric)
+  a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;
   const PGeo g = pick_geo(d.C, a.nch);
   if (!g.tpw || !p.pk_fold) return hipErrorInvalidValue;
   const size_t shm = (size_t)((a.din ? 8 : 4) * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4 + 16 * g.tpw + (a.pin ? d.T * d.S * 4 * g.tpw : 0)) * sizeof(float);

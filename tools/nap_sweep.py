@@ -4,12 +4,13 @@ import numpy as np, torch
 import kaldi_lstm_amd as k
 I, C, R, T = 40, 800, 512, 20
 S = int(sys.argv[1])
+BWD = int(os.environ.get("NAP0_BWD", "0"))      # backward launch's nap0 (0 = its default)
 stream = torch.cuda.Stream()
 for nap0 in [int(v) for v in sys.argv[2:]]:
     e = k.Engine(I, C, R, S, stream=stream)
     rng = np.random.RandomState(7)
     e.set_params(((rng.rand(e.num_params) - 0.5) * 0.02).astype(np.float32))
-    e.set_option("graph", 0); e.set_option("persist_nap0", nap0)
+    e.set_option("graph", 0); e.set_option("persist_nap0_bwd", BWD); e.set_option("persist_nap0", nap0)
     x = torch.randn(T * S, I, device="cuda"); od = 0.1 * torch.randn(T * S, R, device="cuda")
     out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
     with torch.cuda.stream(stream):
