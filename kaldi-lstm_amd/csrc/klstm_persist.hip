@@ -247,6 +247,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
   float *ldsU = lds + SS * LDB;                      // [SS][LDU]: row s = [ r(0)[s][0..R) | pad | x(1)[s][0..I) | pad ]   (step 1 only)
   unsigned *abortf = reinterpret_cast<unsigned *>(ldsU + SS * LDU);
   int *projf = reinterpret_cast<int *>(abortf + 1);  // last step whose slab the projection wave has read
+  int *pubcnt = reinterpret_cast<int *>(abortf + 2); // publishes issued by this workgroup's cell waves so far (one count per wave and step)
   const bool proj_on = a.rin && (int)blockIdx.x * 4 < R;   // this workgroup contracts rows 4*blockIdx .. +3 of W_r_m
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // zero both slabs once: pad columns and rows of absent streams stay zero for the whole launch
   for (int i = tid; i < SS * (LDB + LDU); i += PNT) lds[i] = 0.f;
-  if (tid == 0) { *abortf = 0u; *projf = 0; }
+  if (tid == 0) { *abortf = 0u; *projf = 0; *pubcnt = 0; }
   __syncthreads();
   PT_DECL();
 
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       if (NG > 1) load_folded();
 #pragma unroll
       for (int g = 0; g < NG; g++) cell_math(1, g, v1[g]);
+      if (lane == 0) __hip_atomic_fetch_add(pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // publishes of this step issued
       PT_MARK(4);
     bool dead = false;
     for (int t = 2; t <= T; t++) {
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       PT_MARK(2);                                    // contractions + k-group sums
 #pragma unroll
       for (int g = 0; g < NG; g++) cell_math(t, g, vt[g]);   // (back to back: the groups' dependent exp/rcp chains interleave)
+      if (lane == 0) __hip_atomic_fetch_add(pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // publishes of this step issued
       PT_MARK(4);                                    // cell math + stores
     }
     if (a.rin && !dead) lds_barrier();               // (slab of m(T) for the projection wave)
@@ -443,6 +446,11 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
         if (x_on) *reinterpret_cast<float4 *>(ldsU + xs * LDU + RP + xk) = xv;
       } else {
         float mv[PCELL][SS];                         // m(t-1) of every cell
+        // Polling starts once this workgroup's OWN cell waves have issued their publishes of step t-1 (the others are about
+        // as far): sweeper loads already in the CU's vector-memory queue hold the publishes back, and with them the whole
+        // exchange.  A fixed sleep tuned to the cell waves' epilogue did the same job (nap0 = 9: 2.35 us per step, 2.7 at
+        // 7 or 12; twice that for two stream groups); the event needs no tuning: 2.16-2.24 us for nap0 = 0..3.
+        while (__hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NCW * (t - 1)) __builtin_amdgcn_s_sleep(1);
         if (!sweep_cells<PCELL, NG>(a.gran + (size_t)((t - 1) & 1) * C * SS, C, S, epoch + (unsigned)(t - 1), cell, mv, t_start, a.nap0, a.nap)) {
           *abortf = 1u;
           if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
@@ -958,7 +966,7 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm; a.rr = p.rr;
   a.x = in; a.x_stride = in_stride; a.prev_c = p.prev_c; a.prev_r = p.prev_r; a.gran = gran; a.ctrl = ctrl;
   a.rin = out && persist_r_in_kernel(d); a.out = out; a.out_stride = out_stride;
-  a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : d.S > 4 ? 17 : 9; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // measured: tools/persist_anatomy, tools/nap_sweep.py
+  a.nap0 = g_persist_nap0 >= 0 ? g_persist_nap0 : d.S > 4 ? 4 : 2; a.nap = g_persist_nap >= 0 ? g_persist_nap : 0;     // (behind the publish flag; measured: tools/persist_anatomy, tools/nap_sweep.py)
   const PGeo g = pick_geo_fwd(d.C, a.nch, pcdiv(d.R, KCH) * KCH + d.I);
   if (!g.tpw || !p.pk_fold || (reinterpret_cast<uintptr_t>(in) & 15) || in_stride % 4 != 0) return hipErrorInvalidValue;
   const int ng = d.S > 4 ? 2 : 1;

@@ -25,7 +25,7 @@ int main(int argc, char **argv) {
   unsigned long long *gran; CK(hipMalloc(&gran, 2 * C * 8 * 8)); CK(hipMemset(gran, 0, 2 * C * 8 * 8));
   unsigned *ctrl; CK(hipMalloc(&ctrl, 32)); CK(hipMemset(ctrl, 0, 32));
   long long *dbg; CK(hipMalloc(&dbg, 256 * 16 * 6 * 8)); CK(hipMemset(dbg, 0, 256 * 16 * 6 * 8));
-  for (int waves : {12}) for (int tpw : {1}) for (int nap0 : {8, 9, 10, 11, 12, 13, 14, 15, 16}) for (int nap : {0}) {
+  for (int waves : {12}) for (int tpw : {1}) for (int nap0 : {0, 1, 2, 3, 4, 5, 6, 8}) for (int nap : {0}) {
     if (4 * tpw >= waves) continue;
     set_persist_waves(waves); set_persist_tpw(tpw);
     PersistFwdArgs a;
