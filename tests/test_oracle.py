@@ -205,3 +205,50 @@ def test_eval_masked_posterior_restatement():
     assert np.isclose(ent, -2 * 0.5 * np.log(0.5), rtol=1e-6)
     assert np.isclose(xe, -0.5 * (np.log(y[0, 2]) + np.log(y[0, 4])), rtol=1e-6)
     assert correct == int(y[0].argmax() == 2) + int(sum(y[r].argmax() == 0 for r in range(1, 6))) and valid == 6
+
+
+def test_against_torch_nn_lstm_with_projection():
+    """An INDEPENDENT implementation of the same cell: torch.nn.LSTM(proj_size=R) is the LSTMP of Sak et al. without
+    peepholes -- c' = f*c + i*g, h = o*tanh(c'), r = W_hr h -- with gate rows ordered i,f,g,o and two bias vectors.  With the
+    three peephole vectors at zero and activations far from the +-50 cell clip the reference layer (...streams.h:222-332,
+    :334-499) computes exactly that; streams are the batch dimension, a fresh engine starts from zero state like
+    torch's default (h0, c0).  Forward outputs, the carried state, the input gradient and all weight gradients agree in
+    fp64.  (Not a pin of the peephole / clip / multi-stream-reset semantics: those have no counterpart in torch.)"""
+    import torch
+    I, C, R, S, T = 5, 12, 7, 3, 9
+    rng = np.random.RandomState(5)
+    p = make_params(I, C, R, scale=0.5, seed=9, dtype=np.float64)
+    blob = split_blob(p, I, C, R)
+    for name in ("peephole_i_c", "peephole_f_c", "peephole_o_c"):
+        blob[name][:] = 0.0                       # (views into p)
+    x = rng.randn(T * S, I)
+    od = rng.randn(T * S, R)
+
+    o = Oracle(I, C, R, S, np.float64)
+    o.set_params(p)
+    out = o.propagate(x)
+    in_diff = o.backpropagate(x, od, momentum=0.0)
+    g = split_blob(o.get_corr(), I, C, R)
+    st = o.get_state()
+
+    lstm = torch.nn.LSTM(input_size=I, hidden_size=C, num_layers=1, bias=True, batch_first=False, proj_size=R).double()
+    perm = np.concatenate([np.arange(C, 2 * C), np.arange(2 * C, 3 * C), np.arange(0, C), np.arange(3 * C, 4 * C)])   # torch rows i,f,g,o <- ours g,i,f,o
+    with torch.no_grad():
+        lstm.weight_ih_l0.copy_(torch.from_numpy(blob["w_gifo_x"][perm]))
+        lstm.weight_hh_l0.copy_(torch.from_numpy(blob["w_gifo_r"][perm]))
+        lstm.bias_ih_l0.copy_(torch.from_numpy(blob["bias"][perm]))
+        lstm.bias_hh_l0.zero_()
+        lstm.weight_hr_l0.copy_(torch.from_numpy(blob["w_r_m"]))
+    xt = torch.from_numpy(x.reshape(T, S, I)).clone().requires_grad_(True)      # time-major rows t*S + s = (seq, batch)
+    yt, (hT, cT) = lstm(xt)
+    (yt * torch.from_numpy(od.reshape(T, S, R))).sum().backward()
+
+    np.testing.assert_allclose(out, yt.detach().numpy().reshape(T * S, R), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(st[:, 4 * C:5 * C], cT[0].detach().numpy(), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(st[:, 7 * C:], hT[0].detach().numpy(), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(in_diff, xt.grad.numpy().reshape(T * S, I), rtol=1e-9, atol=1e-11)
+    inv = np.argsort(perm)
+    np.testing.assert_allclose(g["w_gifo_x"], lstm.weight_ih_l0.grad.numpy()[inv], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(g["w_gifo_r"], lstm.weight_hh_l0.grad.numpy()[inv], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(g["bias"], lstm.bias_ih_l0.grad.numpy()[inv], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(g["w_r_m"], lstm.weight_hr_l0.grad.numpy(), rtol=1e-9, atol=1e-11)
