@@ -12,7 +12,9 @@
  * not vendored (writing stand-ins for them is not a reference build).  This restatement
  * is therefore pinned only by construction (op-for-op against the cited lines) and by
  * the independent checks in tests/test_oracle.py (fp64 autograd of the forward
- * equations, finite differences, stream/chunk invariants).
+ * equations, finite differences, stream/chunk invariants, and -- for the peephole-free
+ * case -- agreement with an independent LSTMP implementation, torch.nn.LSTM with
+ * proj_size, on outputs, state and every gradient to 1e-11 in fp64).
  *
  * What it follows (all paths relative to /root/reference):
  *   google/nnet/bd-nnet-lstm-projected-streams.h
