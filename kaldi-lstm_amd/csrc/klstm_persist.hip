@@ -450,7 +450,10 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
         // as far): sweeper loads already in the CU's vector-memory queue hold the publishes back, and with them the whole
         // exchange.  A fixed sleep tuned to the cell waves' epilogue did the same job (nap0 = 9: 2.35 us per step, 2.7 at
         // 7 or 12; twice that for two stream groups); the event needs no tuning: 2.16-2.24 us for nap0 = 0..3.
-        while (__hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NCW * (t - 1)) __builtin_amdgcn_s_sleep(1);
+        for (unsigned spins = 0; __hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NCW * (t - 1); spins++) {
+          __builtin_amdgcn_s_sleep(1);
+          if ((spins & 1023) == 1023 && wall_clock64() - t_start > SPIN_LIMIT) break;   // (bounded like every other spin: the sweep below then times out and reports)
+        }
         if (!sweep_cells<PCELL, NG>(a.gran + (size_t)((t - 1) & 1) * C * SS, C, S, epoch + (unsigned)(t - 1), cell, mv, t_start, a.nap0, a.nap)) {
           *abortf = 1u;
           if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
