@@ -65,7 +65,7 @@ struct klstm_engine {
   int ks = 1;
   int T_fwd = -1;     // T of the last propagate (-1: none yet)
   int T_bwd = -1;
-  bool use_graph = true;
+  int use_graph = 1;        // option "graph": 0 plain launches, 1 a hipGraph per call unless the call is one or two launches, 2 always
   bool mmt_pending = false;   // DP: corr = mmt*corr + grads is folded into the next Update
   // KLSTM_BPTT_FUSE_UPDATE: the gradient products of the last backpropagate wait for klstm_update (or for anything that looks)
   bool grads_pending = false;
@@ -603,8 +603,10 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
 }
 
 template <class F>
-static klstm_status run_graphed(klstm_engine *e, const klstm_engine::Key &key, F &&seq) {
-  if (!e->use_graph || e->profile) return seq();
+static klstm_status run_graphed(klstm_engine *e, const klstm_engine::Key &key, F &&seq, bool short_seq = false) {
+  // short_seq: the call is one or two launches (persistent chain): a graph launch costs more than they do (bench A-B at
+  // 40/800/512, 4 streams: 196 us per minibatch with a graph per call, 188 with plain launches); option "graph" = 2 forces it
+  if (!e->use_graph || e->profile || (short_seq && e->use_graph != 2)) return seq();
   auto it = e->graphs.find(key);
   if (it == e->graphs.end()) {
     // graphs bake the caller's pointers; a trainer that cycles through a pool of minibatch buffers needs one
@@ -656,7 +658,8 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
     e->pk_stale &= ~1;
   }
   klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, e->fwd_persist ? -3 : e->fwd_folded ? -2 : -1);
-  st = run_graphed(e, key, [&]() { return seq_forward(e, in, in_stride, out, out_stride, T); });
+  st = run_graphed(e, key, [&]() { return seq_forward(e, in, in_stride, out, out_stride, T); },
+                   e->fwd_persist && persist_r_in_kernel(Dims{e->I, e->C, e->R, e->S, T}));
   if (st != KLSTM_OK) return st;
   e->T_fwd = T;
   e->T_bwd = -1;
@@ -688,9 +691,12 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
   if (e->fwd_folded) { klstm_status fs = ensure_fold(e, !e->fwd_persist); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
                         flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0));
+  // (one or two launches: the persistent kernel with P and the tail inside, plus at most the gradient products)
+  const bool bwd_short = e->bwd_persist && persist_p_in_kernel(Dims{e->I, e->C, e->R, e->S, T}) &&
+                         persist_tail_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, in_diff != nullptr) && e->persist_tail != 0;
   klstm_status st = run_graphed(e, key, [&]() {
     return seq_backward(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, T, momentum, flags);
-  });
+  }, bwd_short);
   if (st != KLSTM_OK) return st;
   e->T_bwd = T;
   if (grads_fusable(e, T, flags, e->fwd_folded ? false : e->use_bf16)) {
@@ -850,7 +856,7 @@ klstm_status klstm_get_activations_host(klstm_engine *e, int which, float *dst) 
 
 klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
   if (!e || !key) return fail(KLSTM_ERR_ARG, "null argument");
-  if (!strcmp(key, "graph")) { e->use_graph = value != 0; return KLSTM_OK; }
+  if (!strcmp(key, "graph")) { e->use_graph = value < 0 ? 0 : value > 2 ? 2 : value; return KLSTM_OK; }
   if (!strcmp(key, "vector")) {          // 0: force the generic kernels (testing)
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);

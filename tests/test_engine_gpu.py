@@ -931,7 +931,7 @@ def test_persistent_chain_replay_state_bridge_and_whole_utterance():
     rng = np.random.RandomState(4)
     x = dev(rng.randn(T * S, I)); od = dev(rng.randn(T * S, R))
     res = []
-    for graph in (1, 0, 0):
+    for graph in (2, 0, 1):                      # 2: a hipGraph per call even for the one-launch calls; 1: the default (plain launches here)
         e = make_engine(I, C, R, S, p)
         e.set_option("persist", 2); e.set_option("graph", graph)
         out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
