@@ -242,9 +242,11 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
                                          void *hip_stream);
 
 /* Engine knobs (not part of the reference interface).  Keys:
- *   "graph"   0/1/2  replay the per-call launch sequence from a hipGraph (robust against a busy host thread) or issue
- *                  plain stream launches (no fixed cost per graph launch).  Default 1: a graph per call unless the call
- *                  is one or two launches anyway (persistent chain); 2: always; 0: never
+ *   "graph"   0/1/2  issue plain stream launches (default 0: measured equal or faster at every stream count while the host
+ *                  thread keeps ahead, and indifferent to callers that hand in fresh buffers every minibatch) or replay the
+ *                  per-call launch sequence from a hipGraph keyed on the caller's pointers (a busy host thread: 40-80
+ *                  launches per call on the launch-per-step chains).  1: a graph per call unless the call is one or
+ *                  two launches anyway (persistent chain); 2: always
  *   "fold"    -1/0/1  folded recurrence W_rm = W_gifo_r * W_r_m: one kernel per step and direction instead of two
  *                  (DESIGN.md 3a); -1 = auto (NumStream <= 8 and >= 12 frames per stream), 1 = whenever NumStream <=
  *                  16 and I, C, R are multiples of 8.  Same results up to fp32 summation order.

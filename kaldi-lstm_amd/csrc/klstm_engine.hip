@@ -65,7 +65,7 @@ struct klstm_engine {
   int ks = 1;
   int T_fwd = -1;     // T of the last propagate (-1: none yet)
   int T_bwd = -1;
-  int use_graph = 1;        // option "graph": 0 plain launches, 1 a hipGraph per call unless the call is one or two launches, 2 always
+  int use_graph = 0;        // option "graph": 0 plain launches (default), 1 a hipGraph per call unless the call is one or two launches, 2 always
   bool mmt_pending = false;   // DP: corr = mmt*corr + grads is folded into the next Update
   // KLSTM_BPTT_FUSE_UPDATE: the gradient products of the last backpropagate wait for klstm_update (or for anything that looks)
   bool grads_pending = false;

@@ -24,8 +24,13 @@ def dev(a):
 
 
 def make_engine(I, C, R, S, params):
+    """Engines of this file replay their launch-per-step calls from hipGraphs (option "graph" = 1; the product default is
+    plain launches, which the tools, bench.py, the component tests and every test that sets the option itself run):
+    KLSTM_TEST_GRAPH=0 runs the whole file on plain launches."""
+    import os
     import kaldi_lstm_amd as k
     e = k.Engine(I, C, R, S)
+    e.set_option("graph", int(os.environ.get("KLSTM_TEST_GRAPH", "1")))
     e.set_params(params)
     return e
 

@@ -3,8 +3,9 @@ sys.path.insert(0, "/root/repo")
 import torch
 import kaldi_lstm_amd as k
 import numpy as np
-I, C, R, T, S = 40, 800, 512, 20, 4
-for graph in (1, 0, 1, 0):
+I, C, R, T = 40, 800, 512, 20
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+for graph in (2, 0, 2, 0):
     e = k.Engine(I, C, R, S)
     e.set_option("graph", graph)
     rng = np.random.RandomState(7)
@@ -16,5 +17,5 @@ for graph in (1, 0, 1, 0):
     e.synchronize(); t0 = time.perf_counter()
     for _ in range(200): fbu()
     e.synchronize(); dt = (time.perf_counter() - t0) / 200
-    print("graph=%d: %.1f us/minibatch" % (graph, dt * 1e6))
+    print("S=%d graph=%d: %.1f us/minibatch" % (S, graph, dt * 1e6))
     e.close()
