@@ -269,11 +269,6 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value);
 klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *total_us,
                                  long *launches);
 
-/* Diagnostic: wall time per launch (microseconds) of the named step kernel(s) ("gates", "proj",
- * "gates+proj", "dr", "dm", "dr+dm", "grads", "update") inside a dependent chain of n launches replayed
- * from a hipGraph.  Needs a preceding klstm_propagate; clobbers the activation planes. */
-klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *us_per_launch);
-
 #ifdef __cplusplus
 }
 #endif

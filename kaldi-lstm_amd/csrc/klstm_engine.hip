@@ -1205,83 +1205,4 @@ klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm) {
   return klstm_allreduce_buffer(e->grads, (size_t)e->nparams, rccl_comm, e->stream);   // in place, on the engine's stream: no event hops
 }
 
-// Diagnostic: cost of one kernel inside a dependent chain.  Captures `n` back-to-back launches of
-// the named step kernel(s) (t cycles 1..T of the last propagate) into a hipGraph, replays it 5
-// times and returns the best wall time per launch in microseconds (HIP events on the engine
-// stream).  Leaves the activation planes in an undefined state.
-klstm_status klstm_debug_chain(klstm_engine *e, const char *what, int n, float *us_per_launch) {
-  if (!e || !what || !us_per_launch || n <= 0) return fail(KLSTM_ERR_ARG, "bad argument");
-  if (e->T_fwd < 0) return fail(KLSTM_ERR_STATE, "klstm_debug_chain: run a propagate first");
-  HIPCHK(hipSetDevice(e->device));
-  const int T = e->T_fwd;
-  const Dims d{e->I, e->C, e->R, e->S, T};
-  { klstm_status ps = ensure_packs(e); if (ps != KLSTM_OK) return ps; }
-  const std::string w0(what);
-  if (w0 == "gates_fold" || w0 == "dmf" || w0 == "fold" || w0 == "fold_gemm" || w0 == "rbatch" || w0 == "bwd_tail") {
-    if (!e->pk[0] || e->use_bf16) return fail(KLSTM_ERR_SHAPE, "folded path not available for this engine");
-    klstm_status fs = ensure_fold(e, true);
-    if (fs != KLSTM_OK) return fs;
-    if ((fs = ensure_ws(e, T)) != KLSTM_OK) return fs;
-  }
-  const FwdPtrs fp = fwd_ptrs(e);
-  const BwdPtrs bp = bwd_ptrs(e);
-  float *scratch_out = nullptr, *xin = nullptr, *xdiff = nullptr;
-  HIPCHK(hipMalloc(&scratch_out, (size_t)T * e->S * e->R * sizeof(float)));
-  HIPCHK(hipMalloc(&xin, (size_t)T * e->S * e->I * sizeof(float)));
-  HIPCHK(hipMalloc(&xdiff, (size_t)T * e->S * e->I * sizeof(float)));
-  HIPCHK(hipMemsetAsync(xin, 0, (size_t)T * e->S * e->I * sizeof(float), e->stream));
-  const bool fx = use_fused_x(e);
-  hipStream_t st = e->stream;
-  const std::string w(what);
-  auto seq = [&]() -> klstm_status {
-    for (int i = 0; i < n; i++) {
-      const int t = 1 + (i % T);
-      if (w == "gates_fold") HIPCHK(launch_gates_step(d, fp, t < 2 ? 2 : t, fx, xin, e->I, st, LaunchProbe(), true));
-      else if (w == "dmf") HIPCHK(launch_dmf_step(d, bp, t < T ? t : 1, e->Pm, st));
-      else if (w == "fold" || w == "fold_gemm") HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, true, st));
-      else if (w == "rbatch") HIPCHK(launch_rbatch(d, fp, scratch_out, e->R, e->ws, st));
-      else if (w == "bwd_tail") HIPCHK(launch_bwd_tail(d, e->dgifo, e->params + e->o_wr(), e->params + e->o_wx(), scratch_out, e->R,
-                                                       e->dr, xdiff, e->I, e->ws, st));
-      else if (w == "gates") HIPCHK(launch_gates_step(d, fp, t, fx, xin, e->I, st));
-      else if (w == "proj") HIPCHK(launch_proj_step(d, fp, t, scratch_out, e->R, st));
-      else if (w == "gates+proj") { if (i & 1) HIPCHK(launch_proj_step(d, fp, t, scratch_out, e->R, st)); else HIPCHK(launch_gates_step(d, fp, t, fx, xin, e->I, st)); }
-      else if (w == "dr") HIPCHK(launch_dr_step(d, bp, t < T ? t : 1, xdiff, e->I, st));
-      else if (w == "dm") HIPCHK(launch_dm_step(d, bp, t, scratch_out, e->R, xdiff, e->I, st));
-      else if (w == "dr+dm") { if (i & 1) HIPCHK(launch_dm_step(d, bp, t, scratch_out, e->R, xdiff, e->I, st)); else HIPCHK(launch_dr_step(d, bp, t < T ? t : 1, xdiff, e->I, st)); }
-      else if (w == "grads") HIPCHK(launch_grads(d, e->dgifo, e->dr, xin, e->I, e->rr, e->mm, e->cc, 0.9f, e->corr, st, LaunchProbe(), e->use_bf16));
-      else if (w == "update") HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, st));
-      else if (w == "pack") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, st));
-      else if (w == "pack_fwd") HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 3, e->use_bf16, st));
-      else return fail(KLSTM_ERR_ARG, "klstm_debug_chain: unknown kernel '%s'", what);
-    }
-    return KLSTM_OK;
-  };
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  HIPCHK(hipMemsetAsync(scratch_out, 0, (size_t)T * e->S * e->R * sizeof(float), st));
-  HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-  klstm_status rc = seq();
-  hipError_t er = hipStreamEndCapture(st, &graph);
-  if (rc != KLSTM_OK) return rc;
-  if (er != hipSuccess) return fail(KLSTM_ERR_HIP, "EndCapture: %s", hipGetErrorString(er));
-  HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  float best = 1e30f;
-  for (int rep = 0; rep < 6; rep++) {
-    HIPCHK(hipEventRecord(e0, st));
-    HIPCHK(hipGraphLaunch(exec, st));
-    HIPCHK(hipEventRecord(e1, st));
-    HIPCHK(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    if (rep > 0 && ms < best) best = ms;
-  }
-  *us_per_launch = best * 1e3f / n;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
-  (void)hipFree(scratch_out); (void)hipFree(xin); (void)hipFree(xdiff);
-  return KLSTM_OK;
-}
-
 }  // extern "C"
