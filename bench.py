@@ -408,7 +408,11 @@ def main():
                 "achieved": gbs if hbm_bound else tflops, "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else PEAK_F32_MFMA_TF,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": gbs / (PEAK_HBM_TBS * 1e3) if hbm_bound else tflops / PEAK_F32_MFMA_TF,
-                "traffic": traffic, "traffic_source": (pmc_file + " (static: separate rocprofv3 --pmc passes, not this run)") if traffic else None,
+                "traffic": traffic,
+                "traffic_source": ((pmc_file + " (static: separate rocprofv3 --pmc passes, not this run)") if traffic else
+                                   "none: the committed PMC passes (profiles/) are for %s streams per GPU on the %s chain, this run is %d streams on %s"
+                                   % (pmc.get("streams_per_gpu") if pmc else "?", pmc.get("chain") if pmc else "?", S,
+                                      "the persistent chain" if dom.endswith("_persist") else "launch-per-step kernels")),
                 "avg_us": kern[dom]["avg_us"], "us_per_recurrence_step": per_step_us,
                 "alg_bytes_per_launch": a_bytes, "alg_flops_per_launch": a_flops,
                 "mfma_tflops": tflops, "mfma_frac": tflops / PEAK_F32_MFMA_TF, "hbm_gbs": gbs, "hbm_frac": gbs / (PEAK_HBM_TBS * 1e3),
