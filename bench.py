@@ -129,16 +129,17 @@ ROCPROF_TAG = {"k_gates_step": "k_gates_v", "k_dr_step": "k_dr_v", "k_gates_fold
                "k_proj_step": "k_proj_v", "k_dm_step": "k_dm_v", "k_fwd_persist": "k_fwd_persist", "k_bwd_persist": "k_bwd_persist"}
 
 
-def pmc_profile():
+def pmc_profile(S=4):
     """The committed rocprofv3 PMC summary (profiles/rNN_pmc_traffic.json, produced by tools/profile.sh on the GPU box in
     SEPARATE passes -- counters cannot be collected inside a timed run), or None.  STATIC: not measured by this process."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
+    docs = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):      # latest round last
+        try:
+            docs.append((json.load(open(f)), os.path.relpath(f, ROOT)))
+        except Exception:
+            pass
+    same = [d for d in docs if d[0].get("streams_per_gpu", 4) == S]
+    return same[-1] if same else docs[-1] if docs else (None, None)
 
 
 def init_params(seed=7):
@@ -394,7 +395,7 @@ def main():
         # which roofline: algorithmic intensity of the whole path (8(d): ~165 FLOP/B with weights resident) is far above the
         # ridge, but a step at S streams is a chain of dependent exchanges; the kernel's own intensity decides the label
         hbm_bound = (a_flops / a_bytes) < PEAK_F32_MFMA_TF / PEAK_HBM_TBS
-        pmc, pmc_file = pmc_profile()
+        pmc, pmc_file = pmc_profile(S)
         traffic = traffic_ratio = mfma_busy = None
         alg_bytes_mb = ACT_BYTES_PER_FRAME * T_BPTT * S + WEIGHT_BYTES_PER_MINIBATCH
         if pmc and pmc.get("streams_per_gpu", 4) == S and pmc.get("chain", "") == ("persistent" if dom.endswith("_persist") else "launches"):

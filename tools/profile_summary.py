@@ -62,7 +62,7 @@ doc = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA
        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads; "
                      "WRITE_SIZE uncalibrated)",
        "streams_per_gpu": int(m.group(1)) if m else 4,
-       "chain": "persistent" if any(n.startswith("k_fwd_persist") or n.startswith("k_bwd_persist") for n in kern) else "launches",
+       "chain": "persistent" if any(n.startswith("k_bwd_persist") for n in kern) else "launches",   # (which kind of kernel runs BPTT, the dominant chain)
        "minibatches": nmb, "hbm_bytes_per_minibatch": total_bytes / nmb if nmb else None,
        "kernels": kern}
 json.dump(doc, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
