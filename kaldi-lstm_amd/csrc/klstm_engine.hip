@@ -300,7 +300,7 @@ static klstm_status ensure_fold(klstm_engine *e, bool need_x) {
 extern "C" {
 
 const char *klstm_last_error(void) { return g_err.c_str(); }
-const char *klstm_version(void) { return "klstm 0.1 gfx950 (f32 MFMA 16x16x4)"; }
+const char *klstm_version(void) { return "klstm 0.2 gfx950 (f32 MFMA, persistent weights-resident chain)"; }
 
 klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_stream, int device,
                           void *hip_stream, klstm_engine **out) {
