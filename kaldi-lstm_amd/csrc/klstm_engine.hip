@@ -81,6 +81,8 @@ struct klstm_engine {
   int use_persist = -1;    // weights-resident persistent chain (klstm_persist.hip): -1 auto (both directions, from 8 frames per
                            // stream), 0 off, 1 forward only, 2 forward and backward whenever the shape allows
   bool fwd_persist = false; // the last propagate ran inside one persistent launch
+  PersistOpts popt;         // per-engine knobs of the persistent kernels (options persist_waves, persist_tpw, persist_nap*, ...)
+  int ncu = 0;              // compute units of the device: every workgroup of a persistent launch needs one of its own
   int persist_tail = 1;     // option "persist_tail": d_r / in_diff inside the persistent backward launch (0: batched products after it)
   bool bwd_persist = false; // ... and its backpropagate runs steps T..1 inside one persistent launch
   bool persist_dirty = false;   // a persistent launch ran since the status words were last read back
@@ -230,9 +232,15 @@ static bool fold_wanted(const klstm_engine *e, int T) {
 static bool use_fused_x(const klstm_engine *e);
 // persistent chain: needs the folded operands, the x term inside the step, at most 4 streams; auto = on from 3 frames
 // per stream (the forward launch covers steps 2..T)
+static bool persist_bwd_wanted(const klstm_engine *e, int T) {
+  const Dims d{e->I, e->C, e->R, e->S, T};
+  return e->use_persist != 1 && persist_bwd_supported(d, e->popt) && persist_bwd_grid(d) <= e->ncu;
+}
 static bool persist_wanted(const klstm_engine *e, int T) {
   if (e->use_persist == 0 || e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || !use_fused_x(e)) return false;
-  if (T < 3 || !persist_supported(Dims{e->I, e->C, e->R, e->S, T})) return false;
+  const Dims d{e->I, e->C, e->R, e->S, T};
+  if (T < 3 || !persist_supported(d, e->popt)) return false;
+  if (persist_fwd_grid(d, e->popt) > e->ncu) return false;      // (its workgroups could not all be resident at once)
   // auto: from 8 frames on.  1..4 streams: both directions.  5..8 streams: the forward launch only (two groups against the
   // same resident rows) -- the exchange takes twice as long with twice the granules, 4.2 us per step inside the launch
   // against 4.2 for the launch-per-step kernel, but the step-1 kernel, the batched projection pair and the per-Update
@@ -319,6 +327,7 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
     return fail(KLSTM_ERR_NOGPU, "klstm_create: device %d is %s, kernels are built for gfx950 only", device, prop.gcnArchName);
   HIPCHK(hipSetDevice(device));
   klstm_engine *e = new klstm_engine();
+  e->ncu = prop.multiProcessorCount;
   e->I = input_dim; e->C = cell_dim; e->R = recur_dim; e->S = num_stream; e->device = device;
   e->nparams = e->o_wm() + (long)e->R * e->C;
   if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
@@ -527,9 +536,9 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
     // step 1 closes over the CARRIED r (set by Reset / the previous minibatch, possibly under older weights): unfolded
     // gates kernel, r(0) mirrored into time block 0; steps 2..T close over m(t-1) through W_rm; r(1..T) in one GEMM
     if (e->fwd_persist) {                         // (all T steps in the one launch, step 1 on the natural matrices)
-      HIPCHK(launch_fwd_persist(d, p, in, in_stride, out, out_stride, e->gran[0], e->pctrl, st, probe(e, "k_fwd_persist")));
+      HIPCHK(launch_fwd_persist(d, p, in, in_stride, out, out_stride, e->gran[0], e->pctrl, e->popt, st, probe(e, "k_fwd_persist")));
       e->persist_dirty = true;
-      if (persist_r_in_kernel(d)) return KLSTM_OK;  // (r(1..T), the output rows and the carried r come out of the same launch)
+      if (persist_r_in_kernel(d, e->popt)) return KLSTM_OK;  // (r(1..T), the output rows and the carried r come out of the same launch)
     } else {
       HIPCHK(launch_gates_step(d, p, 1, fx, in, in_stride, st, probe(e, "k_gates_step")));
       for (int t = 2; t <= T; t++)
@@ -561,7 +570,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     // P = out_diff W_r_m for all frames; chain of T folded steps; then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r
     // (:391, feeds the W_r_m gradient :486) and in_diff = dgifo W_gifo_x (:457) as split-K products
     bool tail_inside = false;
-    const bool p_inside = e->bwd_persist && persist_p_in_kernel(d) && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
+    const bool p_inside = e->bwd_persist && persist_p_in_kernel(d, e->popt) && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
     int kl = 0;
     int ks = gemm_splitk_plan(M, d.C, d.R, &kl);
     if (p_inside) {}                              // (the persistent kernel contracts its own columns of P while its weights load)
@@ -569,8 +578,8 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
                                           st, nullptr, 0, probe(e, "k_gemm_P"), probe(e, "k_reduce_P")));
     else HIPCHK(launch_gemm(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
     if (e->bwd_persist) {
-      tail_inside = p_inside && e->persist_tail != 0 && persist_tail_in_kernel(d, in_diff != nullptr);
-      HIPCHK(launch_bwd_persist(d, p, e->Pm, out_diff, od_stride, in_diff, id_stride, tail_inside, e->gran[1], e->pctrl + 4, st,
+      tail_inside = e->persist_tail != 0 && persist_tail_in_kernel(d, in_diff != nullptr, e->popt);
+      HIPCHK(launch_bwd_persist(d, p, e->Pm, out_diff, od_stride, in_diff, id_stride, tail_inside, e->gran[1], e->pctrl + 4, e->popt, st,
                                 probe(e, "k_bwd_persist")));
       e->persist_dirty = true;
     } else {
@@ -646,7 +655,7 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
   e->fwd_persist = persist_wanted(e, T);
-  e->bwd_persist = e->fwd_persist && e->use_persist != 1 && persist_bwd_supported(Dims{e->I, e->C, e->R, e->S, T});
+  e->bwd_persist = e->fwd_persist && persist_bwd_wanted(e, T);
   e->fwd_folded = e->fwd_persist || fold_wanted(e, T);
   if (e->fwd_persist && (st = ensure_persist(e)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
@@ -659,7 +668,7 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   }
   klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, e->fwd_persist ? -3 : e->fwd_folded ? -2 : -1);
   st = run_graphed(e, key, [&]() { return seq_forward(e, in, in_stride, out, out_stride, T); },
-                   e->fwd_persist && persist_r_in_kernel(Dims{e->I, e->C, e->R, e->S, T}));
+                   e->fwd_persist && persist_r_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, e->popt));
   if (st != KLSTM_OK) return st;
   e->T_fwd = T;
   e->T_bwd = -1;
@@ -692,8 +701,8 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
                         flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0));
   // (one or two launches: the persistent kernel with P and the tail inside, plus at most the gradient products)
-  const bool bwd_short = e->bwd_persist && persist_p_in_kernel(Dims{e->I, e->C, e->R, e->S, T}) &&
-                         persist_tail_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, in_diff != nullptr) && e->persist_tail != 0;
+  const bool bwd_short = e->bwd_persist && persist_p_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, e->popt) &&
+                         persist_tail_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, in_diff != nullptr, e->popt) && e->persist_tail != 0;
   klstm_status st = run_graphed(e, key, [&]() {
     return seq_backward(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, T, momentum, flags);
   }, bwd_short);
@@ -902,18 +911,25 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     e->use_fold = value;
     return KLSTM_OK;
   }
-  if (!strcmp(key, "persist") || !strcmp(key, "persist_tpw") || !strcmp(key, "persist_waves") || !strcmp(key, "persist_nap0") ||
-      !strcmp(key, "persist_nap")) {
+  if (!strncmp(key, "persist", 7) && strcmp(key, "persist_tail")) {
+    // "persist": -1 auto, 0 off, 1 forward launch only, 2 both directions whenever the shape allows.  The rest are knobs of
+    // THIS engine's persistent launches (kernel arguments and geometry): A-B experiments and tests.
     HIPCHK(hipStreamSynchronize(e->stream));
-    drop_graphs(e);
+    drop_graphs(e);                                 // captured launches bake geometry and kernel arguments
     if (!strcmp(key, "persist")) e->use_persist = value;
-    else if (!strcmp(key, "persist_tpw")) set_persist_tpw(value);         // process-wide tuning knobs (A-B experiments)
-    else if (!strcmp(key, "persist_nap0")) set_persist_nap(value, -2);
-    else if (!strcmp(key, "persist_nap")) set_persist_nap(-2, value);
-    else set_persist_waves(value);
+    else if (!strcmp(key, "persist_tpw")) e->popt.tpw = value;
+    else if (!strcmp(key, "persist_waves")) { e->popt.waves = value; e->popt.bwd_waves = value; }
+    else if (!strcmp(key, "persist_bwd_waves")) e->popt.bwd_waves = value;
+    else if (!strcmp(key, "persist_nap0")) e->popt.nap0 = value;
+    else if (!strcmp(key, "persist_nap")) e->popt.nap = value;
+    else if (!strcmp(key, "persist_nap0_bwd")) e->popt.nap0_bwd = value;
+    else if (!strcmp(key, "persist_spin_us")) e->popt.spin_limit = (long long)value * 100;      // wall clock: 100 MHz
+    else if (!strcmp(key, "persist_test_stall_fwd")) e->popt.test_stall_fwd = value;            // test hooks: force the timeout path
+    else if (!strcmp(key, "persist_test_stall_bwd")) e->popt.test_stall_bwd = value;
+    else if (!strcmp(key, "persist_ncu")) e->ncu = value;                                       // test hook: pretend the device has this many CUs
+    else return fail(KLSTM_ERR_ARG, "klstm_set_option: unknown key '%s'", key);
     return KLSTM_OK;
   }
-  if (!strcmp(key, "persist_nap0_bwd")) { set_persist_nap0_bwd(value); return KLSTM_OK; }
   if (!strcmp(key, "persist_tail")) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);

@@ -154,26 +154,35 @@ hipError_t launch_axpy(float *y, const float *x, float a, long n, hipStream_t st
 hipError_t launch_sgd_momentum(float *param, float *corr, const float *grad, float mmt, float lr, long n, hipStream_t st);
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {});
 
-// Weights-resident persistent chain (klstm_persist.hip; NumStream <= 4, folded recurrence, x term fused): ONE launch runs
-// forward steps 2..T (step 1 stays with launch_gates_step: it closes over the carried r) / backward steps T..1 with the
-// packed fold operands held in registers and the per-step all-to-all done inside the launch through data-tagged granules.
-//   gran: persist_gran_bytes(d) of device memory, zero-filled once;  ctrl: 3 words {epoch, finished workgroups, status},
-//   zero-filled once (one pair per direction).  status != 0 after the launch: a bounded spin expired (0x80000000 | step).
-bool persist_supported(const Dims &d);
+// Weights-resident persistent chain (klstm_persist.hip forward, klstm_persist_bwd.hip backward; NumStream <= 8, folded
+// recurrence, x term fused): ONE launch per direction runs all T steps with the packed fold operands held in registers and
+// the per-step all-to-all done inside the launch through data-tagged granules.
+//   gran: persist_gran_bytes(d) of device memory per direction, zero-filled once;  ctrl: 4 words per direction {epoch,
+//   finished workgroups, status, pad}, zero-filled once.  status != 0 after the launch: a bounded wait expired
+//   (0x80000000 | step) and the results of that launch are invalid.
+// Per-engine knobs (A-B experiments and tests; 0 / -1 = defaults):
+struct PersistOpts {
+  int waves = 0, tpw = 0;         // forward: waves per workgroup (8, 12, 16), tiles of 4 cells per workgroup (1, 2)
+  int nap0 = -1, nap = -1;        // sweepers sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
+  int nap0_bwd = -1;              // the same for the backward launch
+  int bwd_waves = 0;              // backward: 12 or 16 waves per workgroup
+  long long spin_limit = 0;       // wall-clock ticks (100 MHz) a single in-kernel wait may take (0 = 50 ms)
+  int test_stall_fwd = 0, test_stall_bwd = 0;   // test hook: workgroup 0 withholds its publish of this step -> timeout path
+  long long *dbg = nullptr;       // tools/persist_anatomy (KLSTM_PERSIST_TIMING builds only)
+};
+bool persist_supported(const Dims &d, const PersistOpts &o);       // forward
+bool persist_bwd_supported(const Dims &d, const PersistOpts &o);   // backward
+int persist_fwd_grid(const Dims &d, const PersistOpts &o);         // workgroups that must be co-resident (one per CU)
+int persist_bwd_grid(const Dims &d);
 size_t persist_gran_bytes(const Dims &d);
-void set_persist_nap0_bwd(int v);
-bool persist_bwd_supported(const Dims &d);   // the backward persistent kernel (NumStream <= 4; the forward one takes 8)
-bool persist_r_in_kernel(const Dims &d);   // r(t) = W_r_m m(t), the output rows and prev_r written by the forward launch (pass out)
+bool persist_r_in_kernel(const Dims &d, const PersistOpts &o);   // r(t) = W_r_m m(t), the output rows and prev_r written by the forward launch (pass out)
 hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, int in_stride, float *out, int out_stride,
-                              unsigned long long *gran, unsigned *ctrl, hipStream_t st, LaunchProbe pr = {});
-bool persist_p_in_kernel(const Dims &d);   // P = out_diff W_r_m computed inside the backward launch (then P may be null)
-bool persist_tail_in_kernel(const Dims &d, bool want_in_diff);   // d_r / in_diff contracted inside the backward launch
+                              unsigned long long *gran, unsigned *ctrl, const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});
+bool persist_p_in_kernel(const Dims &d, const PersistOpts &o);   // P = out_diff W_r_m computed inside the backward launch (then P may be null)
+bool persist_tail_in_kernel(const Dims &d, bool want_in_diff, const PersistOpts &o);   // d_r / in_diff contracted inside the backward launch
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, const float *out_diff, int od_stride,
                               float *in_diff, int id_stride, bool tail_inside, unsigned long long *gran, unsigned *ctrl,
-                              hipStream_t st, LaunchProbe pr = {});
-void set_persist_tpw(int v);    // A-B knob: tiles (of 4 cells) per workgroup, 0 = automatic
-void set_persist_waves(int v);  // A-B knob: waves per workgroup (8, 12 or 16), 0 = automatic
-void set_persist_nap(int nap0, int nap);   // A-B knobs: sweeper sleep before the first pass (x256 clocks) / between passes (x64); -1 = default, -2 = keep
+                              const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});
 
 int get_small_max();
 void set_fat_fine(int v);       // A-B knob: half-size row tiles in the many-stream kernels (-1 auto, 0, 1)

@@ -1,0 +1,550 @@
+// kaldi-lstm_amd/csrc/klstm_persist_bwd.hip -- weights-RESIDENT truncated-BPTT chain (engine option "persist"), 1..8 streams:
+// ONE launch runs steps T..1 of the folded recurrence
+//     d_m(t-1) = P(t-1) + dgifo(t) W_rm,   P = out_diff W_r_m          (...streams.h:391 substituted into :408)
+//     dgifo(t) = elementwise BPTT of d_m(t), the carry of frame t+1 and the forward planes of frame t   (:411-440)
+// with the per-step all-to-all of d_m (S x C floats) inside the launch: data-tagged 8-byte granules {tag, fp32}, one sc1
+// store per (cell, stream) by the lane that owns it, swept with 16-byte sc1 loads until every tag matches (the transport of
+// klstm_persist.hip; cdna_hip_programming.md Guideline 16 recipe R2).
+//
+// What changed against the round-2 kernel (sweepers -> LDS slab -> barrier -> 4 K waves -> barrier -> owner; 3.4-3.6 us per
+// step, MI355X, 40/800/512, 4 streams): the waves that RECEIVE d_m(t) are the waves that contract it.  A sweep-and-contract
+// (SC) wave owns a fixed set of cells; its lanes hold W_rm^T[own output cell i][k = (gate, cell)] for those cells in MFMA
+// A-operand order, so what the sweep delivers goes through the elementwise pass in registers and straight into
+// v_mfma_f32_4x4x1_16b as the B operand: no operand slab, no workgroup barrier, no idle contraction waves while the others
+// sweep.  The cross-wave part of the contraction (every SC wave holds a slice of K) is a 16-byte partial per wave and
+// stream in LDS plus an LDS counter; the OWNER wave adds the partials in fixed order, adds P(t-1) and publishes d_m(t-1).
+//   per 32-cell "slot" of an SC wave, lane = (cell lane & 31, stream pair h = lane >> 5):
+//     sweep     one 16-byte sc1 load = the granules of (cell, streams 2h, 2h+1)
+//     planes    g, i, f, o, h of frame t and c of frame t-1 for the lane's two (cell, stream) pairs, requested before the
+//               sweep (L2 hits; every workgroup reads the same rows; 128 contiguous bytes per half wave and instruction),
+//               folded into six coefficients per pair while d_m flies
+//     apply     d_c = d_m k1 + carry; d(g,i,f) = d_c (bg,bi,bf); d_o = d_m ao; carry' = d_c q       (5 operations per pair)
+//     transpose the 8 dgifo values through a wave-private LDS tile into B-operand order (k-group lane >> 2, stream lane & 3)
+//     contract  4 MFMAs per 16 cells (one per gate): A = resident weights, B = dgifo, 16 cells per MFMA
+//   d_r(t-1) = out_diff(t-1) + dgifo(t) W_gifo_r (:391) and in_diff(t) = dgifo(t) W_gifo_x (:457) are four more output columns
+//   per workgroup for the same B operand: their weights sit in LDS (read after the d_m partial has been signalled, off the
+//   chain), partials go to a second LDS array and the P wave finishes them.
+// Only d_m travels; dgifo is recomputed by every workgroup (replicas are bit-identical: same instruction sequence on the
+// same inputs).  Shipping dgifo instead (each workgroup computing only its own cells) would quadruple the swept bytes
+// (S x 4C values, 68-77 KB per workgroup and pass even in 16-byte {tag, 3 x fp32} granules) for no shorter chain: after the
+// sweep a replicated pair costs five multiply-adds.
+// 5..8 streams: the two groups of 4 run their chains one after the other inside the launch, against the same resident
+// weights (the exchange is latency bound at 4 streams and bandwidth bound at 8: two streams groups pipelined against each
+// other measured slower than in sequence, DESIGN.md 3c "dead ends"); each group has its own granule slots.
+// Wave roles: wave 0 = owner (combine, publish, dgifo / dc plane rows of the own cells), wave 1 = P wave (own columns of
+// P = out_diff W_r_m ahead of the chain; finishes d_r / in_diff), waves 2.. = SC waves.  Nothing global is ordered by
+// anything but the granule tags; every wait is bounded (per wait, wall clock).
+#include "klstm_kernels.h"
+#include "klstm_math.h"
+#include "klstm_persist_dev.h"
+
+#include <hip/hip_ext.h>
+
+namespace klstm {
+
+#pragma clang fp contract(off)
+
+struct PersistBwd2Args {
+  int C, R, S, T, I;
+  int pin;                        // 1: P = out_diff W_r_m is computed here (own columns, kept in LDS); 0: read from P
+  int din;                        // bit 0: d_r(1..T) contracted here, bit 1: in_diff too (4 columns per workgroup)
+  const float *od; int od_stride; // out_diff rows [T*S x R]
+  const float *wmT;               // W_r_m^T [C x R]
+  const float *wrT, *wxT;         // W_gifo_r^T [R x 4C], W_gifo_x^T [I x 4C]
+  float *dr;                      // d_r plane [(T+2)*S x R], time-major row blocks
+  float *in_diff; int id_stride;  // [T*S x I]
+  int nch;                        // 128-wide chunks over 4C
+  const float *wpk;               // packed W_rm^T, 4-row geometry: [C/4 tiles][nch][2][64] float4
+  const float *pi, *pf, *po;
+  const float *gifo, *cc, *hh;
+  float *dgifo, *dc;
+  const float *P;                 // out_diff * W_r_m [T*S x C] (pin == 0)
+  unsigned long long *gran;       // [stream groups][2][C*4] granules, cell-major (4 stream slots per cell)
+  unsigned *ctrl;                 // [0] epoch, [1] finished workgroups, [2] status (0 = ok)
+  int nap0, nap;                  // SC waves sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
+  long long spin_limit;           // wall-clock ticks (100 MHz) a single wait may take
+  int test_stall;                 // test hook: workgroup 0 does not publish d_m(test_stall) (0: never)
+#ifdef KLSTM_PERSIST_TIMING
+  long long *dbg;
+#endif
+};
+
+// The elementwise BPTT of a (cell, stream) pair (:411-440) is linear in d_m(t); everything else is known before d_m(t) has
+// crossed the fabric.  Six coefficients per pair from the forward planes of frame t:
+//   d_h = d_m [yo(1-yh^2)]   d_o = d_m [yh yo(1-yo)]   d_c = d_m k1 + carry,  k1 = yo(1-yh^2) + wpo ao       (:411-428)
+//   d_f = d_c [c(t-1) yf(1-yf)]   d_i = d_c [yg yi(1-yi)]   d_g = d_c [yi(1-yg^2)]                            (:431-440)
+//   carry(t-1) = d_c(t) f(t) + d_i(t) wpi + d_f(t) wpf = d_c(t) q(t),  q = yf + wpi bi + wpf bf               (:425-427 of frame t-1)
+// (same algebra as the reference, products associated differently: a few ulp; identical in every workgroup)
+struct Bptt2Coef { float k1, ao, q, bg, bi, bf; };
+__device__ __forceinline__ Bptt2Coef bptt2_coef(float yg, float yi, float yf, float yo, float yh, float cpv, float wpi, float wpf,
+                                                float wpo) {
+  Bptt2Coef c;
+  const float ah = __builtin_fmaf(-yo, yh * yh, yo);
+  c.ao = yh * __builtin_fmaf(-yo, yo, yo);
+  c.k1 = __builtin_fmaf(wpo, c.ao, ah);
+  c.bf = cpv * __builtin_fmaf(-yf, yf, yf);
+  c.bi = yg * __builtin_fmaf(-yi, yi, yi);
+  c.bg = __builtin_fmaf(-yi, yg * yg, yi);
+  c.q = __builtin_fmaf(wpf, c.bf, __builtin_fmaf(wpi, c.bi, yf));
+  return c;
+}
+// d(g, i, f, o) of frame t; updates the carry
+__device__ __forceinline__ float4 bptt2_apply(float dm, const Bptt2Coef &c, float &carry, float &d_c_out) {
+  const float d_c = __builtin_fmaf(dm, c.k1, carry);
+  carry = d_c * c.q;
+  d_c_out = d_c;
+  return make_float4(d_c * c.bg, d_c * c.bi, d_c * c.bf, dm * c.ao);
+}
+
+__device__ __forceinline__ float dpp_quad(unsigned v, bool odd_pair) {
+  // lane 4b + j reads lane 4b + 2*(j >> 1) (+ 1): quad_perm [0,0,2,2] / [1,1,3,3]
+  return odd_pair ? __int_as_float(__builtin_amdgcn_update_dpp(0, (int)v, 0xF5, 0xf, 0xf, true))
+                  : __int_as_float(__builtin_amdgcn_update_dpp(0, (int)v, 0xA0, 0xf, 0xf, true));
+}
+
+template <int NW, int NU>
+__global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
+  constexpr int NSC = NW - 2, NSLOT = NSC * NU, NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned *abortf = reinterpret_cast<unsigned *>(lds);
+  int *pcnt = reinterpret_cast<int *>(lds) + 1;      // d_m partials written (one count per SC wave and step)
+  int *dcnt = reinterpret_cast<int *>(lds) + 2;      // d_r / in_diff partials written
+  int *dcons = reinterpret_cast<int *>(lds) + 3;     // d steps the P wave has consumed
+  int *pdone = reinterpret_cast<int *>(lds) + 4;     // frames of P in LDS (T per stream group, descending frames)
+  int *pubn = reinterpret_cast<int *>(lds) + 5;      // publishes the owner has issued (T per stream group)
+  int *odone = reinterpret_cast<int *>(lds) + 6;     // stream groups the owner has finished
+  f32x4 *red = reinterpret_cast<f32x4 *>(lds + 16);  // [NSC][4 streams]: components = the 4 own cells
+  f32x4 *red2 = red + NSC * 4;                       // [2][NSC][4 streams]: components = the 4 d_r / in_diff columns
+  float *xtile = reinterpret_cast<float *>(red2 + 2 * NSC * 4);   // [NSC][4 gates][32 cells][4 streams]: natural -> operand order
+  float *wD = xtile + NSC * 512;                         // [NSLOT][2 sets][4 gates][64 lanes]: A operands of the d_r / in_diff columns
+  f32x4 *ldsP = reinterpret_cast<f32x4 *>(wD + NSLOT * 512);     // [T][4 streams] (pin): components = the 4 own cells
+  const int C = a.C, S = a.S, T = a.T, K = 4 * a.C;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ngrp = (S + 3) >> 2;
+  const long long limit = a.spin_limit;
+  const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the d_r / in_diff columns of this workgroup: 4 rows of W_gifo_r^T (workgroups 0 .. R/4-1), then of W_gifo_x^T
+  const int ngr = a.R / 4, ngx = (a.din & 2) ? a.I / 4 : 0;
+  const bool d_on = a.din && (int)blockIdx.x < ngr + ngx, d_isr = (int)blockIdx.x < ngr;
+  const int dcol = d_isr ? (int)blockIdx.x * 4 : ((int)blockIdx.x - ngr) * 4;
+  if (tid < 16) reinterpret_cast<int *>(lds)[tid] = 0;
+  if (d_on) {
+    const float *src = (d_isr ? a.wrT : a.wxT) + (size_t)dcol * K;
+    for (int i = tid; i < NSLOT * 512; i += NT) {
+      const int ln = i & 63, e = (i >> 6) & 3, p = (i >> 8) & 1, sl = i >> 9;
+      const int cell = 32 * sl + 16 * p + (ln >> 2);
+      wD[i] = cell < C ? src[(size_t)(ln & 3) * K + e * C + cell] : 0.f;
+    }
+  }
+  __syncthreads();
+  PT_DECL();
+
+  if (wave == 0) {
+    // =========================== owner: combine, publish, own plane rows ===========================
+    // lanes 0..15 = (own cell oi = lane >> 2, stream oj = lane & 3)
+    const int oi = (lane >> 2) & 3, oj = lane & 3;
+    const int ocell = (int)blockIdx.x * 4 + oi;
+    const float wpi = a.pi[ocell], wpf = a.pf[ocell], wpo = a.po[ocell];
+    const float *redf = reinterpret_cast<const float *>(red);
+    int np = 0;
+    bool dead = false;
+    for (int g = 0; g < ngrp && !dead; g++) {
+      const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
+      const bool on = lane < 16 && oj < Sg;
+      const int srow = 4 * g + (oj < Sg ? oj : 0);
+      unsigned long long *gr = a.gran + (size_t)g * 2 * C * 4;
+      const unsigned tag0 = epoch + (unsigned)(g * (T + 2));
+      if (on) {                                      // the batched d_r product (tail outside) reads dgifo(T+1) as operand rows: zero (:351)
+        float *zp = a.dgifo + ((size_t)(T + 1) * S + srow) * K + ocell;
+        zp[0] = 0.f; zp[C] = 0.f; zp[2 * C] = 0.f; zp[3 * C] = 0.f;
+      }
+      // d_m(T) = P(T): dgifo(T+1) = 0 (:351, :391) -- travels like every other step
+      float dmv;
+      if (a.pin) {
+        if (!lds_wait_ge(pdone, g * T + 1, abortf, limit)) { dead = true; break; }
+        dmv = reinterpret_cast<const float *>(&ldsP[(T - 1) * 4 + oj])[oi];
+      } else {
+        dmv = a.P[((size_t)(T - 1) * S + srow) * C + ocell];
+      }
+      if (on && !(a.test_stall == T && blockIdx.x == 0)) publish(gr + (size_t)(T & 1) * C * 4, ocell * 4 + oj, tag0 + (unsigned)T, dmv);
+      __hip_atomic_store(pubn, g * T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      float carry = 0.f;
+      float yg, yi, yf, yo, yh, cpv;
+      auto load_planes = [&](int t) {                // the own pair's planes of frame t: consumed one publish later
+        const float *gp = a.gifo + ((size_t)t * S + srow) * K + ocell;
+        yg = gp[0]; yi = gp[C]; yf = gp[2 * C]; yo = gp[3 * C];
+        yh = a.hh[((size_t)t * S + srow) * C + ocell];
+        cpv = a.cc[((size_t)(t - 1) * S + srow) * C + ocell];
+      };
+      auto own_rows = [&](int t, float dm) {         // dgifo / dc rows of the own cells (the gradient products read them)
+        const Bptt2Coef cf = bptt2_coef(yg, yi, yf, yo, yh, cpv, wpi, wpf, wpo);
+        float dcv;
+        const float4 d = bptt2_apply(dm, cf, carry, dcv);
+        if (on) {
+          float *dp = a.dgifo + ((size_t)t * S + srow) * K + ocell;
+          dp[0] = d.x; dp[C] = d.y; dp[2 * C] = d.z; dp[3 * C] = d.w;
+          a.dc[((size_t)t * S + srow) * C + ocell] = dcv;
+        }
+      };
+      load_planes(T);
+      for (int t = T; t >= 2; t--) {
+        PT_MARK(5);
+        float pnext = 0.f;
+        if (!a.pin) pnext = a.P[((size_t)(t - 2) * S + srow) * C + ocell];
+        ++np;
+        if (!lds_wait_ge(pcnt, NSC * np, abortf, limit)) { dead = true; break; }
+        PT_MARK(0);                                  // waiting for the partials of step t
+        float part[NSC];
+#pragma unroll
+        for (int w = 0; w < NSC; w++) part[w] = redf[(w * 4 + oj) * 4 + oi];
+        if (a.pin) {
+          if (!lds_wait_ge(pdone, g * T + (T - t + 2), abortf, limit)) { dead = true; break; }
+          pnext = reinterpret_cast<const float *>(&ldsP[(t - 2) * 4 + oj])[oi];
+        }
+        float sum = part[0];
+#pragma unroll
+        for (int w = 1; w < NSC; w++) sum += part[w];  // fixed order
+        const float dmn = sum + pnext;               // :408 with :391 substituted: d_m(t-1) = contraction + P(t-1)
+        if (on && !(a.test_stall == t - 1 && blockIdx.x == 0))
+          publish(gr + (size_t)((t - 1) & 1) * C * 4, ocell * 4 + oj, tag0 + (unsigned)(t - 1), dmn);
+        __hip_atomic_store(pubn, g * T + (T - t + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PT_MARK(1);                                  // combine + publish
+        own_rows(t, dmv);
+        dmv = dmn;
+        load_planes(t - 1);
+        PT_MARK(2);
+      }
+      if (dead) break;
+      own_rows(1, dmv);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __hip_atomic_store(odone, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    PT_FLUSH(0);
+  } else if (wave == 1) {
+    // =========================== P wave: own columns of P = out_diff W_r_m; finishes d_r / in_diff ===========================
+    // 4-row geometry: A = rows of W_r_m^T (the 4 own cells; R <= 512 = 4 chunks, resident), B = the 4 stream rows of out_diff
+    // of one frame; lanes 12..15 end up with P[frame][stream lane & 3][cells 0..3].  Runs ahead of the chain.
+    const int kg = lane >> 2, bj = lane & 3, R = a.R;
+    float4 w0[4], w1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int k = 128 * i + 4 * kg, pc = (int)blockIdx.x * 4 + bj;
+      w0[i] = a.pin && k < R ? *reinterpret_cast<const float4 *>(a.wmT + (size_t)pc * R + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      w1[i] = a.pin && k + 64 < R ? *reinterpret_cast<const float4 *>(a.wmT + (size_t)pc * R + k + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float *red2f = reinterpret_cast<const float *>(red2);
+    const int fi = (lane >> 2) & 3, fj = lane & 3;   // finishing lanes 0..15 = (column fi, stream fj)
+    int nd = 0;
+    bool dead = false;
+    for (int g = 0; g < ngrp && !dead; g++) {
+      const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
+      if (g > 0 && a.pin && !lds_wait_ge(odone, g, abortf, limit)) break;   // (the P rows of the previous group are still being read)
+      int nextf = T - 1;                             // next frame of P (descending)
+      auto p_until = [&](int flo) {
+        while (nextf >= flo && nextf >= 0) {
+          const int f = nextf;
+          const bool rv = bj < Sg;
+          const float *op = a.od + ((size_t)f * S + 4 * g + (rv ? bj : 0)) * a.od_stride + 4 * kg;
+          float4 b0[4], b1[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int k = 128 * i + 4 * kg;
+            b0[i] = rv && k < R ? *reinterpret_cast<const float4 *>(op + 128 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b1[i] = rv && k + 64 < R ? *reinterpret_cast<const float4 *>(op + 128 * i + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float av[8] = {w0[i].x, w0[i].y, w0[i].z, w0[i].w, w1[i].x, w1[i].y, w1[i].z, w1[i].w};
+            const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) acc[jj & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[jj], bv[jj], acc[jj & 3], 0, 0, 0);
+          }
+          const f32x4 v = kgroup_sum_pl((acc[0] + acc[1]) + (acc[2] + acc[3]));
+          if (lane >= 12 && lane < 16) ldsP[f * 4 + bj] = v;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __hip_atomic_store(pdone, g * T + (T - f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          nextf--;
+        }
+      };
+      // d_r(T) = out_diff(T): dgifo(T+1) = 0 (:351, :391)
+      if (d_on && d_isr && lane < 16 && fj < Sg)
+        a.dr[((size_t)T * S + 4 * g + fj) * R + dcol + fi] = a.od[((size_t)(T - 1) * S + 4 * g + fj) * a.od_stride + dcol + fi];
+      if (a.pin) p_until(T - 2);
+      if (d_on) {
+        for (int t = T; t >= (d_isr ? 2 : 1); t--) {
+          if (a.pin) p_until(t - 3);                 // one frame ahead of the owner
+          float odv = 0.f;
+          if (d_isr && lane < 16 && fj < Sg) odv = a.od[((size_t)(t - 2) * S + 4 * g + fj) * a.od_stride + dcol + fi];
+          ++nd;
+          if (!lds_wait_ge(dcnt, NSC * nd, abortf, limit)) { dead = true; break; }
+          float part[NSC];
+#pragma unroll
+          for (int w = 0; w < NSC; w++) part[w] = red2f[(((nd & 1) * NSC + w) * 4 + fj) * 4 + fi];
+          float sum = part[0];
+#pragma unroll
+          for (int w = 1; w < NSC; w++) sum += part[w];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __hip_atomic_store(dcons, nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (lane < 16 && fj < Sg) {
+            if (d_isr) a.dr[((size_t)(t - 1) * S + 4 * g + fj) * R + dcol + fi] = odv + sum;          // :391
+            else a.in_diff[((size_t)(t - 1) * S + 4 * g + fj) * a.id_stride + dcol + fi] = sum;       // :457
+          }
+        }
+      }
+      if (a.pin && !dead) p_until(0);
+    }
+  } else {
+    // =========================== sweep-and-contract waves ===========================
+    // Two lane layouts per 32-cell slot.  NATURAL (sweep, planes, elementwise): lane = (cell c32 = lane & 31, stream pair
+    // h = lane >> 5: streams 2h, 2h+1) -- every plane load instruction reads two 128-byte row segments (lanes of a quad on
+    // four different rows cost 1.8-3.0 us of plane loads per step here, and the slowest workgroup sets everybody's pace).
+    // OPERAND (contraction): lane = (k-group b = lane >> 2, stream j = lane & 3).  dgifo goes from one to the other through a
+    // wave-private 2 KB LDS tile [gate][cell][stream] (in-order DS queue of ONE wave: no barrier, no counter).
+    const int w = wave - 2, b = lane >> 2, j = lane & 3, c32 = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, nch = a.nch;
+    float *xt = xtile + w * 512;                     // [4 gates][32 cells][4 streams]
+    float wA[NU][2][4];                              // W_rm^T[own cell j][k = e*C + cell] for the wave's cells, A-operand order
+    float wpi[NU], wpf[NU], wpo[NU];
+    int svoff[NU];
+    unsigned cmask = 0;                              // bit u: the lane's cell of slot u exists
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const int sl = u * NSC + w;
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const int cell = 32 * sl + 16 * p + b;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int k = e * C + (cell < C ? cell : 0);
+          // packed operand: float4 [(tile*nch + k/128)*128 + ((k/64)&1)*64 + 4*((k/4)&15) + row], component k & 3
+          const float v = a.wpk[((size_t)((size_t)tile * nch + (k >> 7)) * 128 + ((k >> 6) & 1) * 64 + 4 * ((k >> 2) & 15) + j) * 4 + (k & 3)];
+          wA[u][p][e] = cell < C ? v : 0.f;
+        }
+      }
+      const int cl = 32 * sl + c32;                  // the lane's cell in the natural layout
+      if (cl < C) cmask |= 1u << u;
+      const int clc = cl < C ? cl : 0;
+      svoff[u] = clc * 32 + h * 16;
+      wpi[u] = a.pi[clc]; wpf[u] = a.pf[clc]; wpo[u] = a.po[clc];
+    }
+    // plane addresses: lane part in a VGPR, slot part in the immediate, stream / gate / frame parts in the scalar offset
+    const int voffG = (2 * h * K + 32 * w + c32) * 4, voffC = (2 * h * C + 32 * w + c32) * 4;
+    const __amdgpu_buffer_rsrc_t rs_g = buf_rsrc(a.gifo, (T + 2) * S * K * 4), rs_h = buf_rsrc(a.hh, (T + 2) * S * C * 4);
+    const __amdgpu_buffer_rsrc_t rs_c = buf_rsrc(a.cc, (T + 2) * S * C * 4);
+    int nd = 0;
+    bool dead = false;
+    for (int g = 0; g < ngrp && !dead; g++) {
+      const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
+      const bool need0 = 2 * h < Sg, need1 = 2 * h + 1 < Sg;
+      const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(a.gran + (size_t)g * 2 * C * 4, 2 * C * 32);
+      const unsigned tag0 = epoch + (unsigned)(g * (T + 2));
+      float carry[NU][2];
+#pragma unroll
+      for (int u = 0; u < NU; u++) { carry[u][0] = 0.f; carry[u][1] = 0.f; }
+      const int tlo = (d_on && !d_isr) ? 1 : 2;      // frame 1 is swept only where in_diff(1) is contracted
+      for (int t = T; t >= tlo; t--) {
+        PT_MARK(5);
+        // plane loads go out once the owner's publish of d_m(t) has been ISSUED: loads already in this CU's vector-memory
+        // queue would hold the write-through store back, and with it every other workgroup
+        if (!lds_wait_ge(pubn, g * T + (T - t + 1), abortf, limit)) { dead = true; break; }
+        const int sG = (t * S + 4 * g) * K * 4, sC = (t * S + 4 * g) * C * 4;
+        Bptt2Coef cf[NU][2];
+#pragma unroll
+        for (int u = 0; u < NU; u++)
+#pragma unroll
+          for (int x = 0; x < 2; x++) {                // stream 2h + x (absent streams read a later row or zeros: never used)
+            const int imm = u * NSC * 32 * 4, oG = sG + x * K * 4, oC = sC + x * C * 4;
+            const float yg = buf_f32(rs_g, voffG + imm, oG), yi = buf_f32(rs_g, voffG + imm, oG + C * 4);
+            const float yf = buf_f32(rs_g, voffG + imm, oG + 2 * C * 4), yo = buf_f32(rs_g, voffG + imm, oG + 3 * C * 4);
+            const float yh = buf_f32(rs_h, voffC + imm, oC), cpv = buf_f32(rs_c, voffC + imm, oC - S * C * 4);
+            cf[u][x] = bptt2_coef(yg, yi, yf, yo, yh, cpv, wpi[u], wpf[u], wpo[u]);
+          }
+        PT_MARK(0);                                  // planes + coefficients
+        // ---- sweep d_m(t): until every live tag equals tag0 + t ----
+        for (int i = 0; i < a.nap0; i++) __builtin_amdgcn_s_sleep(4);
+        const unsigned tag = tag0 + (unsigned)t;
+        const int soff = (t & 1) * C * 32;
+        u32x4 q[NU];
+        {
+          const long long t0 = wall_clock64();
+          for (unsigned spins = 0;; spins++) {
+#pragma unroll
+            for (int u = 0; u < NU; u++) q[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_gr, svoff[u], soff, 16);   // aux 16 = sc1
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+              const unsigned t0g = q[u].y, t1g = q[u].w;
+              const bool live = (cmask >> u) & 1u;
+              ok &= !live | (((!need0) | (t0g == tag)) & ((!need1) | (t1g == tag)));
+            }
+            if (__all(ok)) break;
+            if ((spins & 15) == 15) {
+              if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { dead = true; break; }
+              if (wall_clock64() - t0 > limit) {
+                __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+                dead = true;
+                break;
+              }
+            }
+            for (int i = 0; i < a.nap; i++) __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        if (dead) break;
+        PT_MARK(1);                                  // sweep
+        // ---- elementwise BPTT of frame t (:411-440) for the lane's two streams, then into operand order through the tile ----
+        float Bv[NU][2][4];
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+          const unsigned v0 = q[u].x, v1 = q[u].z;
+          const bool live = (cmask >> u) & 1u;       // (absent cells: zero weights, and nothing but zeros may meet them)
+          float dcv;
+          const float4 d0 = bptt2_apply(live ? __uint_as_float(v0) : 0.f, cf[u][0], carry[u][0], dcv);
+          const float4 d1 = bptt2_apply(live ? __uint_as_float(v1) : 0.f, cf[u][1], carry[u][1], dcv);
+          float2 *xw = reinterpret_cast<float2 *>(xt + c32 * 4 + 2 * h);
+          xw[0] = make_float2(d0.x, d1.x); xw[64] = make_float2(d0.y, d1.y);           // gate e at + e*128 floats
+          xw[128] = make_float2(d0.z, d1.z); xw[192] = make_float2(d0.w, d1.w);
+          asm volatile("" ::: "memory");             // (lanes exchange data: the compiler must not move the reads above the writes;
+                                                     //  the hardware runs one wave's DS operations in order)
+#pragma unroll
+          for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Bv[u][p][e] = xt[e * 128 + p * 64 + lane];       // [e][16p + b][j]
+          asm volatile("" ::: "memory");
+        }
+        if (t > 1) {
+          // ---- this wave's slice of dgifo(t) W_rm for the 4 own cells ----
+          f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+          for (int u = 0; u < NU; u++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+              acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[u][p][0], Bv[u][p][0], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[u][p][1], Bv[u][p][1], acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[u][p][2], Bv[u][p][2], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[u][p][3], Bv[u][p][3], acc1, 0, 0, 0);
+            }
+          const f32x4 v = kgroup_sum_pl(acc0 + acc1);
+          if (lane >= 12 && lane < 16) red[w * 4 + (lane & 3)] = v;   // stream lane & 3, components = the 4 own cells
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(pcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        PT_MARK(2);                                  // elementwise + contraction + partial
+        if (d_on && (t > 1 || !d_isr)) {
+          // ---- the same dgifo(t) against 4 rows of W_gifo_r^T / W_gifo_x^T (LDS): d_r(t-1) (:391) / in_diff(t) (:457) ----
+          ++nd;
+          if (nd > 2 && !lds_wait_ge(dcons, nd - 2, abortf, limit)) { dead = true; break; }   // (this parity's partials have been read)
+          float wd[NU][2][4];
+#pragma unroll
+          for (int u = 0; u < NU; u++)
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+              for (int e = 0; e < 4; e++) wd[u][p][e] = wD[(((u * NSC + w) * 2 + p) * 4 + e) * 64 + lane];
+          f32x4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+#pragma unroll
+          for (int u = 0; u < NU; u++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+              d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[u][p][0], Bv[u][p][0], d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[u][p][1], Bv[u][p][1], d1, 0, 0, 0);
+              d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[u][p][2], Bv[u][p][2], d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[u][p][3], Bv[u][p][3], d1, 0, 0, 0);
+            }
+          const f32x4 v = kgroup_sum_pl(d0 + d1);
+          if (lane >= 12 && lane < 16) red2[((nd & 1) * NSC + w) * 4 + (lane & 3)] = v;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(dcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        PT_MARK(3);                                  // d_r / in_diff slice
+      }
+    }
+    PT_FLUSH(0);
+  }
+  __syncthreads();
+  if (tid == 0 && *abortf) atomicMax(&a.ctrl[2], 0x80000000u | 0x7fffu);   // (a bounded LDS wait expired or a sweep timed out)
+  finish(a.ctrl, epoch, ngrp * (T + 2));
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// launcher
+// -------------------------------------------------------------------------------------------------------------------
+static inline int pcdiv2(int a, int b) { return (a + b - 1) / b; }
+
+// Geometry: waves per workgroup and 32-cell slots per SC wave.  16 waves (128 registers each): up to 3 slots (C <= 1344);
+// 12 waves: 3 slots (C <= 960).
+struct PGeo2 { int nw, nu; };
+static PGeo2 pick_geo_bwd2(const Dims &d, const PersistOpts &o) {
+  const int slots = pcdiv2(d.C, 32);
+  const int order[2] = {o.bwd_waves == 12 ? 12 : 16, o.bwd_waves == 12 ? 16 : 12};
+  for (int nw : order) {
+    const int nu = pcdiv2(slots, nw - 2);
+    if (nw == 16 && nu <= 3) return PGeo2{16, nu <= 2 ? 2 : 3};
+    if (nw == 12 && nu <= 3) return PGeo2{12, 3};
+  }
+  return PGeo2{0, 0};
+}
+static size_t bwd2_lds_bytes(const PGeo2 &g, int T, bool pin) {
+  const int nsc = g.nw - 2, nslot = nsc * g.nu;
+  return (size_t)(16 + nsc * 16 + 2 * nsc * 16 + nsc * 512 + nslot * 512 + (pin ? T * 16 : 0)) * sizeof(float);
+}
+
+bool persist_bwd_supported(const Dims &d, const PersistOpts &o) {
+  if (d.S > 8 || d.C % 8 != 0 || d.R % 4 != 0 || d.C / 4 > 256) return false;
+  return pick_geo_bwd2(d, o).nw != 0;
+}
+int persist_bwd_grid(const Dims &d) { return d.C / 4; }
+// P = out_diff W_r_m inside the backward launch: own columns in LDS (T frames x 4 streams x 4 cells), rows of W_r_m^T in registers
+bool persist_p_in_kernel(const Dims &d, const PersistOpts &o) {
+  const PGeo2 g = pick_geo_bwd2(d, o);
+  return g.nw != 0 && d.R <= 512 && d.R % 4 == 0 && bwd2_lds_bytes(g, d.T, true) <= 152 * 1024;
+}
+// d_r and in_diff inside the backward launch: 4 columns per workgroup
+bool persist_tail_in_kernel(const Dims &d, bool want_in_diff, const PersistOpts &o) {
+  const PGeo2 g = pick_geo_bwd2(d, o);
+  if (!g.nw || d.R % 4 != 0 || d.I % 4 != 0 || d.C % 4 != 0) return false;
+  return d.R / 4 + (want_in_diff ? d.I / 4 : 0) <= d.C / 4;
+}
+
+template <class Kn>
+static hipError_t plaunch2(Kn kern, int grid, int threads, size_t shm, hipStream_t st, LaunchProbe pr, const PersistBwd2Args &a) {
+  if (shm > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (pr.start) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), shm, st, pr.start, pr.stop, 0, a);
+  else hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), shm, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, const float *out_diff, int od_stride,
+                              float *in_diff, int id_stride, bool tail_inside, unsigned long long *gran, unsigned *ctrl,
+                              const PersistOpts &o, hipStream_t st, LaunchProbe pr) {
+  PersistBwd2Args a;
+  a.C = d.C; a.R = d.R; a.S = d.S; a.T = d.T; a.I = d.I;
+  a.pin = persist_p_in_kernel(d, o) && out_diff && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
+  if (!a.pin && !P) return hipErrorInvalidValue;
+  a.od = out_diff; a.od_stride = od_stride; a.wmT = p.wmT;
+  a.din = tail_inside ? (in_diff ? 3 : 1) : 0; a.wrT = p.wrT; a.wxT = p.wxT; a.dr = p.dr; a.in_diff = in_diff; a.id_stride = id_stride;
+  if (a.din && (!persist_tail_in_kernel(d, in_diff != nullptr, o) || !out_diff)) return hipErrorInvalidValue;
+  a.nch = pcdiv2(4 * d.C, 128);
+  a.wpk = reinterpret_cast<const float *>(p.pk_fold); a.pi = p.pi; a.pf = p.pf; a.po = p.po;
+  a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.gran = gran; a.ctrl = ctrl;
+  a.nap0 = o.nap0_bwd >= 0 ? o.nap0_bwd : 0;
+  a.nap = o.nap >= 0 ? o.nap : 0;
+  a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;
+  a.test_stall = o.test_stall_bwd;
+#ifdef KLSTM_PERSIST_TIMING
+  a.dbg = o.dbg;
+#endif
+  const PGeo2 g = pick_geo_bwd2(d, o);
+  if (!g.nw || !p.pk_fold || d.S > 8) return hipErrorInvalidValue;
+  const size_t shm = bwd2_lds_bytes(g, d.T, a.pin != 0);
+  const int grid = persist_bwd_grid(d);
+  if (g.nw == 16 && g.nu == 2) return plaunch2(k_bwd_persist2<16, 2>, grid, 1024, shm, st, pr, a);
+  if (g.nw == 16 && g.nu == 3) return plaunch2(k_bwd_persist2<16, 3>, grid, 1024, shm, st, pr, a);
+  if (g.nw == 12 && g.nu == 3) return plaunch2(k_bwd_persist2<12, 3>, grid, 768, shm, st, pr, a);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace klstm

@@ -1,0 +1,116 @@
+// kaldi-lstm_amd/csrc/klstm_persist_dev.h -- device helpers shared by the two persistent (weights-resident) chain kernels,
+// klstm_persist.hip (forward) and klstm_persist_bwd.hip (backward): the granule transport, buffer-descriptor plane I/O,
+// the k-group sums of the 4-row MFMA geometry, bounded waits and the end-of-launch epoch hand-over.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "klstm_math.h"
+
+namespace klstm {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr long long SPIN_LIMIT_DEFAULT = 5000000;   // wall_clock64 ticks (100 MHz): 50 ms per wait
+
+#ifdef KLSTM_PERSIST_TIMING
+#define PT_DECL() long long pt_prev = clock64(), pt_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PT_MARK(i) do { const long long pt_now = clock64(); pt_acc[i] += pt_now - pt_prev; pt_prev = pt_now; } while (0)
+#define PT_FLUSH(base) do { if (lane == 0) for (int i_ = 0; i_ < 6; i_++) a.dbg[((size_t)blockIdx.x * 16 + wave) * 6 + i_] = pt_acc[i_]; } while (0)
+#else
+#define PT_DECL() do {} while (0)
+#define PT_MARK(i) do {} while (0)
+#define PT_FLUSH(base) do {} while (0)
+#endif
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+}
+__device__ __forceinline__ void publish(unsigned long long *slot, int idx, unsigned tag, float v) {
+  __hip_atomic_store(slot + idx, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);                     // one 8-byte sc1 store: tag and value cannot tear
+}
+
+// Sum over the 16 k-groups of the 4-row geometry (lanes with equal lane & 3): two DPP row shifts inside each row of 16 lanes
+// (lanes 12..15 then hold their row's sums), then the four rows.  The totals of streams 0..3 end up in lanes 12..15 (of
+// every row): those are the epilogue lanes.
+//   kgroup_sum    : rows combined by two ds_bpermute rounds (an LDS round trip each)
+//   kgroup_sum_pl : rows combined by v_permlane16_swap / v_permlane32_swap (gfx950; register-only): with x = y = c,
+//                   permlane16_swap leaves x = [c.r0, c.r0, c.r2, c.r2], y = [c.r1, c.r1, c.r3, c.r3] (odd rows of x swapped with
+//                   even rows of y), permlane32_swap x = [s.lo, s.lo], y = [s.hi, s.hi]
+// Both are fixed instruction sequences: deterministic, identical in every wave (the two orders differ in the last bits).
+__device__ __forceinline__ f32x4 kgroup_sum(f32x4 v) {
+  // (scalar copies: __builtin_bit_cast applied directly to a vector-element expression reads element 0)
+  float c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    c[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[e]), 0x114, 0xf, 0xf, true));   // row_shr:4: lane i += lane i-4
+    c[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[e]), 0x118, 0xf, 0xf, true));   // row_shr:8: lanes 12..15 = row sums
+  }
+#pragma unroll
+  for (int m = 16; m < 64; m <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) c[e] += __shfl_xor(c[e], m);
+  }
+  return f32x4{c[0], c[1], c[2], c[3]};
+}
+__device__ __forceinline__ f32x4 kgroup_sum_pl(f32x4 v) {
+  float c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    c[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[e]), 0x114, 0xf, 0xf, true));
+    c[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[e]), 0x118, 0xf, 0xf, true));
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const unsigned u = __float_as_uint(c[e]);
+    const u32x2 r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float s = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);           // rows 0,1: r0 + r1; rows 2,3: r2 + r3
+    const unsigned us = __float_as_uint(s);
+    const u32x2 r32 = __builtin_amdgcn_permlane32_swap(us, us, false, false);
+    c[e] = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);                    // every row: (r0 + r1) + (r2 + r3)
+  }
+  return f32x4{c[0], c[1], c[2], c[3]};
+}
+
+// workgroup barrier that orders LDS traffic only
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Bounded wait on an LDS counter of this workgroup: until *ctr >= target (returns true), the abort flag is up or
+// `limit` wall-clock ticks have passed since the wait began (returns false; on expiry the abort flag is raised).
+__device__ __forceinline__ bool lds_wait_ge(int *ctr, int target, unsigned *abortf, long long limit) {
+  if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) { asm volatile("" ::: "memory"); return true; }
+  const long long t0 = wall_clock64();
+  for (unsigned spins = 1;; spins++) {
+    __builtin_amdgcn_s_sleep(1);
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) break;
+    if ((spins & 15) == 0) {
+      if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+      if ((spins & 1023) == 0 && wall_clock64() - t0 > limit) {
+        __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return false;
+      }
+    }
+  }
+  asm volatile("" ::: "memory");                     // (the reads that follow are not hoisted above the poll)
+  return true;
+}
+
+// end of launch: the last workgroup to arrive advances the epoch for the next call (a later launch cannot start before
+// every workgroup of this one has exited, so nobody reads ctrl[0] concurrently)
+__device__ __forceinline__ void finish(unsigned *ctrl, unsigned epoch, int ntags) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = atomicAdd(&ctrl[1], 1u);
+    if (old == gridDim.x - 1) {
+      __hip_atomic_store(&ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctrl[0], epoch + (unsigned)ntags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace klstm

@@ -1,8 +1,9 @@
-// tools/persist_anatomy.hip -- where does a step of the persistent forward chain spend its time?  Builds the product
+// tools/persist_anatomy.hip -- where does a step of the persistent chains (forward, backward) spend its time?  Builds the product
 // kernel (klstm_persist.hip) with KLSTM_PERSIST_TIMING: every wave sums shader-clock intervals per phase
 // (sweep, barrier 1, contraction, barrier 2, owner epilogue, loop head) over the T-1 steps.  Random weights (timing only).
 #define KLSTM_PERSIST_TIMING
 #include "../kaldi-lstm_amd/csrc/klstm_persist.hip"
+#include "../kaldi-lstm_amd/csrc/klstm_persist_bwd.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -27,12 +28,12 @@ int main(int argc, char **argv) {
   long long *dbg; CK(hipMalloc(&dbg, 256 * 16 * 6 * 8)); CK(hipMemset(dbg, 0, 256 * 16 * 6 * 8));
   for (int waves : {12}) for (int tpw : {1}) for (int nap0 : {0, 1, 2, 3, 4, 5, 6, 8}) for (int nap : {0}) {
     if (4 * tpw >= waves) continue;
-    set_persist_waves(waves); set_persist_tpw(tpw);
+    PersistOpts o; o.waves = waves; o.tpw = tpw;
     PersistFwdArgs a;
     a.C = C; a.I = I; a.R = R; a.S = S; a.T = T; a.nchm = nchm; a.nch = nch; a.wpk = wpk; a.wr = wr; a.wx = wx; a.prev_r = pr0; a.rr = rr; a.wm = nullptr; a.rin = 0; a.out = nullptr; a.out_stride = 0;
     a.bias = vecs; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
-    a.gifo = gifo; a.cc = cc; a.hh = hh; a.mm = mm; a.x = x; a.x_stride = I; a.prev_c = cs; a.gran = gran; a.ctrl = ctrl; a.dbg = dbg; a.nap0 = nap0; a.nap = nap;
-    const PGeo g = pick_geo_fwd(C, nch, (R + 31) / 32 * 32 + I);
+    a.gifo = gifo; a.cc = cc; a.hh = hh; a.mm = mm; a.x = x; a.x_stride = I; a.prev_c = cs; a.gran = gran; a.ctrl = ctrl; a.dbg = dbg; a.nap0 = nap0; a.nap = nap; a.spin_limit = SPIN_LIMIT_DEFAULT; a.test_stall = 0;
+    const PGeo g = pick_geo_fwd(o, C, nch, (R + 31) / 32 * 32 + I);
     const size_t shm = (size_t)((S > 4 ? 8 : 4) * (g.maxc * 128 + 16) + (S > 4 ? 8 : 4) * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);
     const int grid = C / 4 / g.tpw;
     LaunchProbe pr;
@@ -65,46 +66,60 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 6; i++) printf(" %s %.2f", nm[i], m[i]);
     printf("\n");
   }
-  // ---------------- backward ----------------
-  if (S <= 4) {
+  // ---------------- backward (klstm_persist_bwd.hip) ----------------
+  {
     const int nchb = (4 * C + 127) / 128;
     const size_t npb = (size_t)(C / 4) * nchb * 128;
     float4 *wpb; CK(hipMalloc(&wpb, npb * 16));
     std::vector<float> hb(npb * 4);
     for (auto &v : hb) v = (rand() / (float)RAND_MAX - 0.5f) * 0.02f;
     CK(hipMemcpy(wpb, hb.data(), npb * 16, hipMemcpyHostToDevice));
-    float *dgifo = dalloc((size_t)(T + 2) * S * 4 * C), *dc = dalloc((size_t)(T + 2) * S * C), *P = dalloc((size_t)T * S * C);
+    auto rfill = [&](float *p, size_t n, float lo, float hi) {
+      std::vector<float> t(n); for (auto &v : t) v = lo + (hi - lo) * (rand() / (float)RAND_MAX);
+      CK(hipMemcpy(p, t.data(), n * 4, hipMemcpyHostToDevice));
+    };
+    rfill(gifo, (size_t)(T + 2) * S * 4 * C, 0.1f, 0.9f); rfill(hh, (size_t)(T + 2) * S * C, -0.5f, 0.5f); rfill(cc, (size_t)(T + 2) * S * C, -1.f, 1.f);
+    float *dgifo = dalloc((size_t)(T + 2) * S * 4 * C), *dc = dalloc((size_t)(T + 2) * S * C), *P = dalloc((size_t)T * S * C),
+          *dr = dalloc((size_t)(T + 2) * S * R), *od = dalloc((size_t)T * S * R), *idf = dalloc((size_t)T * S * I),
+          *wrT = dalloc((size_t)R * 4 * C), *wxT = dalloc((size_t)I * 4 * C), *wmT = dalloc((size_t)C * R);
+    rfill(od, (size_t)T * S * R, -0.1f, 0.1f); rfill(wrT, (size_t)R * 4 * C, -0.01f, 0.01f); rfill(wxT, (size_t)I * 4 * C, -0.01f, 0.01f);
+    rfill(wmT, (size_t)C * R, -0.01f, 0.01f); rfill(P, (size_t)T * S * C, -0.01f, 0.01f);
     CK(hipMemset(gran, 0, 2 * C * 8 * 8)); CK(hipMemset(ctrl, 0, 32));
-    for (int waves : {12, 16}) for (int nap0 : {0, 2, 4, 6, 8}) {
-      set_persist_waves(waves); set_persist_tpw(1);
-      PersistBwdArgs a;
-      a.C = C; a.R = R; a.S = S; a.T = T; a.pin = 0; a.din = 0; a.I = I; a.wrT = nullptr; a.wxT = nullptr; a.dr = nullptr; a.in_diff = nullptr; a.id_stride = 0; a.od = nullptr; a.od_stride = 0; a.wmT = nullptr; a.nch = nchb; a.wpk = wpb; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
-      a.gifo = gifo; a.cc = cc; a.hh = hh; a.dgifo = dgifo; a.dc = dc; a.P = P; a.gran = gran; a.ctrl = ctrl; a.nap0 = nap0; a.nap = 0; a.dbg = dbg;
-      const PGeo g = pick_geo(C, nchb);
-      const size_t shm = (size_t)(4 * (4 * g.maxc * 128 + 16) + 4 * g.tpw * 4 * 4 + 4 + 16 * g.tpw) * sizeof(float);
-      const int grid = C / 4 / g.tpw;
-      LaunchProbe pr;
-      auto go = [&]() -> hipError_t { PDISPATCH_BWD(k_bwd_persist); };
+    BwdPtrs bp{};
+    bp.wrT = wrT; bp.wmT = wmT; bp.wxT = wxT; bp.pi = vecs + 4 * C; bp.pf = vecs + 5 * C; bp.po = vecs + 6 * C;
+    bp.gifo = gifo; bp.cc = cc; bp.hh = hh; bp.dgifo = dgifo; bp.dc = dc; bp.dr = dr; bp.pk_fold = wpb;
+    const Dims d{I, C, R, S, T};
+    for (int full : {0, 1}) for (int waves : {16, 12}) for (int nap0 : {0, 2, 4}) {
+      PersistOpts o; o.bwd_waves = waves; o.nap0_bwd = nap0; o.dbg = dbg;
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       float best = 1e9;
       for (int rep = 0; rep < 4; rep++) {
-        CK(hipEventRecord(e0, st)); CK(go()); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        CK(hipEventRecord(e0, st));
+        CK(launch_bwd_persist(d, bp, P, full ? od : nullptr, R, full ? idf : nullptr, I, full != 0, gran, ctrl, o, st));
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
       }
-      std::vector<long long> d(256 * 16 * 6); CK(hipMemcpy(d.data(), dbg, d.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<long long> dd(256 * 16 * 6); CK(hipMemcpy(dd.data(), dbg, dd.size() * 8, hipMemcpyDeviceToHost));
       unsigned stw[4]; CK(hipMemcpy(stw, ctrl, 16, hipMemcpyDeviceToHost));
-      auto row = [&](int wg, int w) { return &d[((size_t)wg * 16 + w) * 6]; };
-      long long tot = 0; for (int i = 0; i < 6; i++) tot += row(0, 5)[i];
+      auto row = [&](int wg, int w) { return &dd[((size_t)wg * 16 + w) * 6]; };
+      long long tot = 0; for (int i = 0; i < 6; i++) tot += row(0, 0)[i];
       const double cyc_per_us = tot / (best * 1e3);
-      printf("BWD S=%d waves=%d tpw=%d grid=%d maxc=%d pcell=%d nap0=%d: %.3f us/step (status %x)\n", S, g.waves, g.tpw, grid, g.maxc, g.pcell, nap0, best * 1e3 / (T - 1), stw[2]);
-      const char *nk[6] = {"-", "wait-slab", "contract", "barrier2", "epilogue", "loophead"};
-      const char *ns[6] = {"loads+sweep", "barrier1", "elementwise", "barrier2", "-", "loophead"};
-      printf("   K wave 0 :");
-      for (int i = 1; i < 6; i++) printf(" %s %.2f", nk[i], row(0, 0)[i] / cyc_per_us / (T - 1));
-      double m[6] = {0, 0, 0, 0, 0, 0};
-      for (int wg = 0; wg < grid; wg++) for (int i = 0; i < 6; i++) m[i] += row(wg, 5)[i] / cyc_per_us / (T - 1) / grid;
-      printf("\n   sweeper (mean over workgroups, wave 5):");
-      for (int i : {0, 2, 1, 3, 5}) printf(" %s %.2f", ns[i], m[i]);
+      const int ngrp = (S + 3) / 4, nsteps = ngrp * (T - 1);
+      const PGeo2 g = pick_geo_bwd2(d, o);
+      printf("BWD2 S=%d waves=%d nu=%d %s nap0=%d: %.3f us/step over %d steps (%.1f us per launch, status %x)\n", S, g.nw, g.nu,
+             full ? "P+d_r+in_diff inside" : "bare chain", nap0, best * 1e3 / nsteps, nsteps, best * 1e3, stw[2]);
+      const char *no[6] = {"wait-partials", "combine+publish", "own-rows", "-", "-", "loophead"};
+      const char *ns[6] = {"planes+coef", "sweep", "apply+contract", "d-slice", "-", "wait-pub"};
+      printf("   owner wg0 :");
+      for (int i : {0, 1, 2, 5}) printf(" %s %.2f", no[i], row(0, 0)[i] / cyc_per_us / nsteps);
+      double m[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0};
+      const int grid = C / 4;
+      for (int wg = 0; wg < grid; wg++) for (int i = 0; i < 6; i++) {
+        const double v = row(wg, 3)[i] / cyc_per_us / nsteps;
+        m[i] += v / grid; if (v > mx[i]) mx[i] = v;
+      }
+      printf("\n   SC wave 1 (mean over workgroups | max):");
+      for (int i : {5, 0, 1, 2, 3}) printf(" %s %.2f|%.2f", ns[i], m[i], mx[i]);
       printf("\n");
     }
   }
