@@ -12,9 +12,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr long long SPIN_LIMIT_DEFAULT = 5000000;   // wall_clock64 ticks (100 MHz): 50 ms per wait
 
 #ifdef KLSTM_PERSIST_TIMING
-#define PT_DECL() long long pt_prev = clock64(), pt_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PT_N 10
+#define PT_DECL() long long pt_prev = clock64(), pt_acc[PT_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PT_MARK(i) do { const long long pt_now = clock64(); pt_acc[i] += pt_now - pt_prev; pt_prev = pt_now; } while (0)
-#define PT_FLUSH(base) do { if (lane == 0) for (int i_ = 0; i_ < 6; i_++) a.dbg[((size_t)blockIdx.x * 16 + wave) * 6 + i_] = pt_acc[i_]; } while (0)
+#define PT_FLUSH(base) do { if (lane == 0) for (int i_ = 0; i_ < PT_N; i_++) a.dbg[((size_t)blockIdx.x * 16 + wave) * PT_N + i_] = pt_acc[i_]; } while (0)
 #else
 #define PT_DECL() do {} while (0)
 #define PT_MARK(i) do {} while (0)

@@ -25,7 +25,7 @@ int main(int argc, char **argv) {
         *wr = dalloc((size_t)4 * C * R), *wx = dalloc((size_t)4 * C * I), *pr0 = dalloc(S * R), *rr = dalloc((size_t)(T + 2) * S * R);
   unsigned long long *gran; CK(hipMalloc(&gran, 2 * C * 8 * 8)); CK(hipMemset(gran, 0, 2 * C * 8 * 8));
   unsigned *ctrl; CK(hipMalloc(&ctrl, 32)); CK(hipMemset(ctrl, 0, 32));
-  long long *dbg; CK(hipMalloc(&dbg, 256 * 16 * 6 * 8)); CK(hipMemset(dbg, 0, 256 * 16 * 6 * 8));
+  long long *dbg; CK(hipMalloc(&dbg, 256 * 16 * 10 * 8)); CK(hipMemset(dbg, 0, 256 * 16 * 10 * 8));
   for (int waves : {12}) for (int tpw : {1}) for (int nap0 : {0, 1, 2, 3, 4, 5, 6, 8}) for (int nap : {0}) {
     if (4 * tpw >= waves) continue;
     PersistOpts o; o.waves = waves; o.tpw = tpw;
@@ -45,11 +45,11 @@ int main(int argc, char **argv) {
       CK(hipEventRecord(e0, st)); CK(go()); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
     }
-    std::vector<long long> d(256 * 16 * 6); CK(hipMemcpy(d.data(), dbg, d.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<long long> d(256 * 16 * 10); CK(hipMemcpy(d.data(), dbg, d.size() * 8, hipMemcpyDeviceToHost));
     unsigned stw[4]; CK(hipMemcpy(stw, ctrl, 16, hipMemcpyDeviceToHost));
     const double us_step = best * 1e3 / (T - 1);
     // shader clock -> us: total cycles of a wave / kernel time
-    auto row = [&](int wg, int w) { return &d[((size_t)wg * 16 + w) * 6]; };
+    auto row = [&](int wg, int w) { return &d[((size_t)wg * 16 + w) * 10]; };
     long long tot = 0; for (int i = 0; i < 6; i++) tot += row(0, 0)[i];
     const double cyc_per_us = tot / (best * 1e3);
     printf("S=%d waves=%d tpw=%d grid=%d maxc=%d pcell=%d nap0=%d nap=%d: %.3f us/step (status %x), ~%.0f MHz shader clock\n", S, g.waves, g.tpw, grid, g.maxc, g.pcell, nap0, nap, us_step, stw[2], cyc_per_us);
@@ -89,7 +89,7 @@ int main(int argc, char **argv) {
     bp.wrT = wrT; bp.wmT = wmT; bp.wxT = wxT; bp.pi = vecs + 4 * C; bp.pf = vecs + 5 * C; bp.po = vecs + 6 * C;
     bp.gifo = gifo; bp.cc = cc; bp.hh = hh; bp.dgifo = dgifo; bp.dc = dc; bp.dr = dr; bp.pk_fold = wpb;
     const Dims d{I, C, R, S, T};
-    for (int full : {0, 1}) for (int waves : {16, 12}) for (int nap0 : {0, 2, 4}) {
+    for (int full : {0, 1}) for (int waves : {16}) for (int nap0 : {0, 1, 2}) {
       PersistOpts o; o.bwd_waves = waves; o.nap0_bwd = nap0; o.dbg = dbg;
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       float best = 1e9;
@@ -99,28 +99,33 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
       }
-      std::vector<long long> dd(256 * 16 * 6); CK(hipMemcpy(dd.data(), dbg, dd.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<long long> dd(256 * 16 * 10); CK(hipMemcpy(dd.data(), dbg, dd.size() * 8, hipMemcpyDeviceToHost));
       unsigned stw[4]; CK(hipMemcpy(stw, ctrl, 16, hipMemcpyDeviceToHost));
-      auto row = [&](int wg, int w) { return &dd[((size_t)wg * 16 + w) * 6]; };
-      long long tot = 0; for (int i = 0; i < 6; i++) tot += row(0, 0)[i];
+      auto row = [&](int wg, int w) { return &dd[((size_t)wg * 16 + w) * 10]; };
+      long long tot = 0; for (int i = 0; i < 10; i++) tot += row(0, 0)[i];
       const double cyc_per_us = tot / (best * 1e3);
       const int ngrp = (S + 3) / 4, nsteps = ngrp * (T - 1);
       const PGeo2 g = pick_geo_bwd2(d, o);
       printf("BWD2 S=%d waves=%d nu=%d %s nap0=%d: %.3f us/step over %d steps (%.1f us per launch, status %x)\n", S, g.nw, g.nu,
              full ? "P+d_r+in_diff inside" : "bare chain", nap0, best * 1e3 / nsteps, nsteps, best * 1e3, stw[2]);
       const char *no[6] = {"wait-partials", "combine+publish", "own-rows", "-", "-", "loophead"};
-      const char *ns[6] = {"planes+coef", "sweep", "apply+contract", "d-slice", "-", "wait-pub"};
+      const char *ns[10] = {"wait-pubn", "sweep-wait", "apply+contract", "d-slice", "-", "loophead", "wait-planes", "coefs", "-", "issue"};
       printf("   owner wg0 :");
       for (int i : {0, 1, 2, 5}) printf(" %s %.2f", no[i], row(0, 0)[i] / cyc_per_us / nsteps);
-      double m[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0};
+      double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mx[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       const int grid = C / 4;
-      for (int wg = 0; wg < grid; wg++) for (int i = 0; i < 6; i++) {
+      for (int wg = 0; wg < grid; wg++) for (int i = 0; i < 10; i++) {
         const double v = row(wg, 3)[i] / cyc_per_us / nsteps;
         m[i] += v / grid; if (v > mx[i]) mx[i] = v;
       }
       printf("\n   SC wave 1 (mean over workgroups | max):");
-      for (int i : {5, 0, 1, 2, 3}) printf(" %s %.2f|%.2f", ns[i], m[i], mx[i]);
-      printf("\n");
+      for (int i : {5, 6, 7, 0, 9, 3, 1, 2}) printf(" %s %.2f|%.2f", ns[i], m[i], mx[i]);
+      printf("\n   wg0, per SC wave (columns as above):\n");
+      for (int w = 2; w < g.nw; w++) {
+        printf("     wave %2d:", w);
+        for (int i : {5, 6, 7, 0, 9, 3, 1, 2}) printf(" %.2f", row(0, w)[i] / cyc_per_us / nsteps);
+        printf("\n");
+      }
     }
   }
   return 0;
