@@ -250,10 +250,23 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *   "fold"    -1/0/1  folded recurrence W_rm = W_gifo_r * W_r_m: one kernel per step and direction instead of two
  *                  (DESIGN.md 3a); -1 = auto (NumStream <= 8 and >= 12 frames per stream), 1 = whenever NumStream <=
  *                  16 and I, C, R are multiples of 8.  Same results up to fp32 summation order.
- *   "persist" -1/0/1/2  weights-resident persistent chain for NumStream <= 4: ONE launch runs forward
- *                  steps 2..T (1) / and BPTT steps T..1 (2; auto = 2 from 8 frames per stream) with the folded operands held
- *                  in registers and the per-step all-to-all done inside the launch.  Same results up to fp32 summation order.
- *                  "persist_waves", "persist_tpw", "persist_nap0", "persist_nap": its geometry / polling knobs (A-B experiments)
+ *   "persist" -1/0/1/2  weights-resident persistent chain for NumStream <= 8: ONE launch per direction runs
+ *                  all T steps with the folded operands held in registers and the per-step all-to-all done inside the
+ *                  launch.  0 = off, 1 = forward launch only, 2 = both directions whenever the shape allows, -1 = auto (both
+ *                  directions from 8 frames per stream).  Same results up to fp32 summation order.  Needs one compute unit
+ *                  per workgroup (C/4 backward, C/4 or C/8 forward): an engine on a device (partition) with fewer compute
+ *                  units keeps to one launch per step, and klstm_last_error() says so when the option asked for it.
+ *                  Every in-kernel wait is bounded; a launch that gives up sets a status word that (a) makes the Update
+ *                  kernels of this engine return without touching momentum or parameters, (b) is reported as KLSTM_ERR_HIP
+ *                  by the next call that looks (propagate / backpropagate / update poll a host-mapped copy without a
+ *                  synchronisation; klstm_synchronize and every device-to-host getter read the device words), after which
+ *                  the engine stays on the launch-per-step chain.  Outputs and carried state of that minibatch are invalid.
+ *                  Per-engine knobs (A-B experiments and tests): "persist_waves" (forward and backward geometry: 8, 12, 16),
+ *                  "persist_bwd_waves" (12, 16), "persist_tpw", "persist_nap0", "persist_nap", "persist_nap0_bwd",
+ *                  "persist_spin_us" (bound of a single in-kernel wait, default 50 000), "persist_ncu" (pretend CU count),
+ *                  "persist_test_stall_fwd" / "persist_test_stall_bwd" (workgroup 0 withholds its publish of that step:
+ *                  forces the give-up path)
+ *   "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.
  *   "fuse_x"  -1/0/1  x(t) W_gifo_x^T inside the step kernel (auto: NumStream <= 16) or as one batched product (:246)
@@ -268,6 +281,12 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value);
  * over everything executed since the option was set.  Synchronises the stream. */
 klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *total_us,
                                  long *launches);
+
+/* Test support: occupy `workgroups` compute units of `device` for about `microseconds` (one 1024-thread workgroup with
+ * 96 KB of LDS per unit, spinning on the wall clock) on `hip_stream` (NULL: a private non-blocking stream).  Used by the
+ * uneven-load tests of the persistent chain (MI355X_MICROARCH.md: test every hand-off under uneven load).  where_dev (or
+ * NULL): 2 words per workgroup, filled with the XCC id and the HW_ID register of the compute unit it landed on. */
+klstm_status klstm_debug_occupy(int device, int workgroups, int microseconds, void *hip_stream, unsigned *where_dev);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,7 @@ def load_library():
     lib.klstm_synchronize.argtypes = [P]
     lib.klstm_get_activations_host.argtypes = [P, I, P]
     lib.klstm_set_option.argtypes = [P, ctypes.c_char_p, I]
+    lib.klstm_debug_occupy.argtypes = [I, I, I, P, P]
     lib.klstm_profile_query.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_long)]
     lib.klstm_time_shift.argtypes = [P, I, I, I, P, I, I, P]

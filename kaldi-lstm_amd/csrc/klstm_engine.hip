@@ -36,6 +36,15 @@ static klstm_status fail(klstm_status st, const char *fmt, ...) {
   g_err = buf;
   return st;
 }
+// a remark for klstm_last_error() that is not a failure (why a faster path was not taken)
+static void note(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
 #define HIPCHK(expr)                                                                          \
   do {                                                                                        \
     hipError_t _e = (expr);                                                                   \
@@ -88,6 +97,7 @@ struct klstm_engine {
   bool persist_dirty = false;   // a persistent launch ran since the status words were last read back
   unsigned long long *gran[2] = {nullptr, nullptr};   // granule slots of the forward / backward chain
   unsigned *pctrl = nullptr;    // 2 x 4 words: {epoch, finished workgroups, status, pad} per direction
+  unsigned *pstat_host = nullptr;   // pinned, device-mapped word the persistent kernels set when they give up (polled without a sync)
   float *pk_fold[2] = {nullptr, nullptr};   // packed [W_rm | W_x] (gates order) and W_rm^T (4-row geometry)
   float *Pm = nullptr;     // out_diff * W_r_m for all frames [(T_alloc) S x C]
   float *ws = nullptr;     // split-K workspace of the batched d_r / in_diff products
@@ -199,7 +209,7 @@ static klstm_status flush_grads(klstm_engine *e) {
   e->grads_pending = false;
   const Dims d{e->I, e->C, e->R, e->S, e->gp_T};
   HIPCHK(launch_grads(d, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
-                      probe(e, "k_grads"), e->gp_bf16));
+                      probe(e, "k_grads"), e->gp_bf16, nullptr, e->pctrl));
   return KLSTM_OK;
 }
 static klstm_status flush_momentum(klstm_engine *e) {
@@ -240,7 +250,12 @@ static bool persist_wanted(const klstm_engine *e, int T) {
   if (e->use_persist == 0 || e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || !use_fused_x(e)) return false;
   const Dims d{e->I, e->C, e->R, e->S, T};
   if (T < 3 || !persist_supported(d, e->popt)) return false;
-  if (persist_fwd_grid(d, e->popt) > e->ncu) return false;      // (its workgroups could not all be resident at once)
+  if (persist_fwd_grid(d, e->popt) > e->ncu) {                   // (its workgroups could not all be resident at once)
+    if (e->use_persist >= 1)
+      note("persistent chain not used: it needs %d co-resident workgroups, the device (partition) has %d compute units; "
+           "falling back to one launch per step", persist_fwd_grid(d, e->popt), e->ncu);
+    return false;
+  }
   // auto: from 8 frames on.  1..4 streams: both directions.  5..8 streams: the forward launch only (two groups against the
   // same resident rows) -- the exchange takes twice as long with twice the granules, 4.2 us per step inside the launch
   // against 4.2 for the launch-per-step kernel, but the step-1 kernel, the batched projection pair and the per-Update
@@ -254,8 +269,16 @@ static klstm_status ensure_persist(klstm_engine *e) {
     HIPCHK(hipMalloc(&e->gran[i], gb));
     HIPCHK(hipMemsetAsync(e->gran[i], 0, gb, e->stream));
   }
-  HIPCHK(hipMalloc(&e->pctrl, 8 * sizeof(unsigned)));
-  HIPCHK(hipMemsetAsync(e->pctrl, 0, 8 * sizeof(unsigned), e->stream));
+  HIPCHK(hipMalloc(&e->pctrl, 16 * sizeof(unsigned)));   // (+ 8 diagnostic words: which cells' granules never arrived)
+  HIPCHK(hipMemsetAsync(e->pctrl, 0, 16 * sizeof(unsigned), e->stream));
+  if (hipHostMalloc(reinterpret_cast<void **>(&e->pstat_host), 64, hipHostMallocMapped) == hipSuccess) {
+    *e->pstat_host = 0u;
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, e->pstat_host, 0) == hipSuccess) e->popt.hstat = static_cast<unsigned *>(dp);
+  } else {
+    (void)hipGetLastError();
+    e->pstat_host = nullptr;                       // (no early notice then: the status words are still read at every sync)
+  }
   return KLSTM_OK;
 }
 // After a host synchronisation: did a bounded spin of a persistent launch expire?  (Only possible when its workgroups
@@ -263,17 +286,29 @@ static klstm_status ensure_persist(klstm_engine *e) {
 static klstm_status check_persist(klstm_engine *e) {
   if (!e->persist_dirty || !e->pctrl) return KLSTM_OK;
   e->persist_dirty = false;
-  unsigned w[8];
+  if (e->pstat_host) *e->pstat_host = 0u;
+  unsigned w[16];
   HIPCHK(hipMemcpy(w, e->pctrl, sizeof(w), hipMemcpyDeviceToHost));
   if (w[2] == 0 && w[6] == 0) return KLSTM_OK;
-  const unsigned z[8] = {w[0], 0, 0, 0, w[4], 0, 0, 0};
+  e->grads_pending = false; e->mmt_pending = false;   // (what was queued for the Update belongs to the invalid minibatch)
+  const unsigned z[16] = {w[0], 0, 0, 0, w[4], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   HIPCHK(hipMemcpy(e->pctrl, z, sizeof(z), hipMemcpyHostToDevice));
   e->use_persist = 0;
   HIPCHK(hipStreamSynchronize(e->stream));
   drop_graphs(e);
-  return fail(KLSTM_ERR_HIP, "persistent recurrence chain timed out (forward step %u, backward step %u): its workgroups were not "
-              "co-resident; results of that minibatch are invalid, the engine falls back to one launch per step",
-              w[2] & 0x7fffffffu, w[6] & 0x7fffffffu);
+  return fail(KLSTM_ERR_HIP, "persistent recurrence chain timed out (forward status %x, backward status %x): its workgroups were not "
+              "co-resident; outputs and state of that minibatch are invalid, its Update was NOT applied (the update kernels read "
+              "the status words), the engine falls back to one launch per step [forward: %u (cell, stream-group) sweeps expired, cells %d..%d]",
+              w[2], w[6], w[10], w[10] ? e->C - (int)w[9] : -1, (int)w[8] - 1);
+}
+
+// Early notice without a synchronisation: the kernels set a host-mapped word when they give up.  Called at the head of
+// propagate / backpropagate / update; what it reports belongs to an EARLIER call (launches are asynchronous).
+static klstm_status poll_persist(klstm_engine *e) {
+  if (!e->pstat_host || !*reinterpret_cast<volatile unsigned *>(e->pstat_host)) return KLSTM_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->persist_dirty = true;
+  return check_persist(e);
 }
 
 static klstm_status ensure_packs(klstm_engine *e) {
@@ -393,6 +428,7 @@ void klstm_destroy(klstm_engine *e) {
   if (e->flags_dev) (void)hipFree(e->flags_dev);
   for (auto *g : e->gran) if (g) (void)hipFree(g);
   if (e->pctrl) (void)hipFree(e->pctrl);
+  if (e->pstat_host) (void)hipHostFree(e->pstat_host);
   for (float *p : e->stage) if (p) (void)hipFree(p);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -591,7 +627,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
     if (grads_fusable(e, T, flags, false)) return KLSTM_OK;      // (klstm_update runs them together with the Update)
     HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, defer ? 0.f : mmt, defer ? e->grads : e->corr, st,
-                        probe(e, "k_grads")));
+                        probe(e, "k_grads"), false, nullptr, e->pctrl));
     return KLSTM_OK;
   }
   for (int t = T; t >= 1; t--) {
@@ -607,7 +643,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
   const float beta = defer ? 0.f : mmt;
   if (grads_fusable(e, T, flags, e->use_bf16)) return KLSTM_OK;
   HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, beta, dst, st,
-                      probe(e, "k_grads"), e->use_bf16));                                     // :468-487
+                      probe(e, "k_grads"), e->use_bf16, nullptr, e->pctrl));                  // :468-487
   return KLSTM_OK;
 }
 
@@ -649,6 +685,7 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
     return KLSTM_OK;
   }
   HIPCHK(hipSetDevice(e->device));
+  { klstm_status ps = poll_persist(e); if (ps != KLSTM_OK) return ps; }
   { klstm_status gs = flush_grads(e); if (gs != KLSTM_OK) return gs; }   // (deferred gradient products read the planes of the last minibatch)
   if (in_stride < e->I || out_stride < e->R) return fail(KLSTM_ERR_ARG, "klstm_propagate: stride smaller than row width");
   const int T = rows / e->S;
@@ -685,6 +722,7 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
   if (rows != 0 && (in_stride < e->I || out_diff_stride < e->R || (in_diff && in_diff_stride < e->I)))
     return fail(KLSTM_ERR_ARG, "klstm_backpropagate: stride smaller than row width");
   HIPCHK(hipSetDevice(e->device));
+  { klstm_status ps = poll_persist(e); if (ps != KLSTM_OK) return ps; }
   { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }   // grads is about to be overwritten
   if (rows == 0) {          // T = 0: every gradient GEMM has K = 0 -> corr = momentum*corr (:468-487), grads = 0
     const bool defer0 = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
@@ -791,6 +829,7 @@ klstm_status klstm_apply_momentum(klstm_engine *e, float momentum) {
 klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
+  { klstm_status ps = poll_persist(e); if (ps != KLSTM_OK) return ps; }
   const Dims d{e->I, e->C, e->R, e->S, 0};
   // theta -= lr * corr, and the transposed copies the BPTT kernels read are refreshed in the same pass
   if (e->grads_pending) {
@@ -799,12 +838,12 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
     const Dims dg{e->I, e->C, e->R, e->S, e->gp_T};
     const GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
     HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
-                        probe(e, "k_grads_update"), false, &u));
+                        probe(e, "k_grads_update"), false, &u, e->pctrl));
   } else {
     const float *fold_grad = e->mmt_pending ? e->grads : nullptr;
     e->mmt_pending = false;
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
-                                e->wxT, e->stream, probe(e, "k_update_repack")));
+                                e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl));
   }
   // (Packing the BPTT operands on a second stream, overlapped with the next forward pass, was measured to cost
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
@@ -1222,3 +1261,32 @@ klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm) {
 }
 
 }  // extern "C"
+
+// ---- test support: hold compute units busy (uneven-load tests of the persistent chain) ----
+namespace {
+__global__ __launch_bounds__(1024) void k_occupy(long long ticks, unsigned *where) {
+  extern __shared__ float hog[];                   // 96 KB: nothing else fits next to this workgroup
+  hog[threadIdx.x] = (float)threadIdx.x;
+  if (where && threadIdx.x == 0) {                   // which XCD / SE / CU this workgroup landed on (HW_REG_XCC_ID = 20, HW_REG_HW_ID = 4)
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    where[2 * blockIdx.x] = xcc; where[2 * blockIdx.x + 1] = hwid;
+  }
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (hog[threadIdx.x] < 0.f && where) where[0] = 1u;
+}
+}  // namespace
+
+extern "C" klstm_status klstm_debug_occupy(int device, int workgroups, int microseconds, void *hip_stream, unsigned *where_dev) {
+  if (workgroups <= 0 || microseconds <= 0) return fail(KLSTM_ERR_ARG, "klstm_debug_occupy: bad arguments");
+  HIPCHK(hipSetDevice(device));
+  static hipStream_t own = nullptr;
+  if (!hip_stream && !own) HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : own;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  hipLaunchKernelGGL(k_occupy, dim3(workgroups), dim3(1024), 96 * 1024, st, (long long)microseconds * 100, where_dev);
+  HIPCHK(hipGetLastError());
+  return KLSTM_OK;
+}

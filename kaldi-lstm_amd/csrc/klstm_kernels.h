@@ -117,7 +117,8 @@ struct GradsUpdate { float *params; float lr, clip; float *wrT, *wmT, *wxT; };
 bool grads_bf16_tiles(const Dims &d, bool bf16);      // would launch_grads take the bf16 tile path?
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,
-                        hipStream_t st, LaunchProbe pr = {}, bool bf16 = false, const GradsUpdate *upd = nullptr);   // bf16: operands rounded to bf16, 16x16x32 MFMA, fp32 accumulate
+                        hipStream_t st, LaunchProbe pr = {}, bool bf16 = false, const GradsUpdate *upd = nullptr,
+                        const unsigned *guard = nullptr);   // bf16: operands rounded to bf16, 16x16x32 MFMA, fp32 accumulate
 
 // Update (:504-512) + refresh of the transposed weight copies in ONE launch.
 //   grad != nullptr : corr = mmt*corr + grad first (DP mode, after the all-reduce)
@@ -125,7 +126,9 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
 //   lr == 0 && !grad: pure repack (after klstm_set_params)
 hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_blob, const float *grad_blob,
                                 float mmt, float lr, float clip, float *wrT, float *wmT, float *wxT,
-                                hipStream_t st, LaunchProbe pr = {});
+                                hipStream_t st, LaunchProbe pr = {}, const unsigned *guard = nullptr);
+// guard (both): the two status words of the persistent chain (ctrl[2], ctrl[6]); when either is non-zero the kernels return
+// without touching anything -- a minibatch whose chain gave up must not reach the momentum buffers or the parameters
 
 // Packed weight copies for the vector kernels (shapes with R, I, C multiples of 8):
 //   [0] gates [W_gifo_r | W_gifo_x]   [1] proj W_r_m   [2] dr [W_gifo_r^T ; W_gifo_x^T]   [3] dm W_r_m^T
@@ -168,6 +171,7 @@ struct PersistOpts {
   int bwd_waves = 0;              // backward: 12 or 16 waves per workgroup
   long long spin_limit = 0;       // wall-clock ticks (100 MHz) a single in-kernel wait may take (0 = 50 ms)
   int test_stall_fwd = 0, test_stall_bwd = 0;   // test hook: workgroup 0 withholds its publish of this step -> timeout path
+  unsigned *hstat = nullptr;      // host-mapped status word: set by a launch that gives up (the engine polls it without a sync)
   long long *dbg = nullptr;       // tools/persist_anatomy (KLSTM_PERSIST_TIMING builds only)
 };
 bool persist_supported(const Dims &d, const PersistOpts &o);       // forward

@@ -1910,6 +1910,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce2(ReduceArgs r1, ReduceArg
 //   blocks [nb2, nb3)      bias / peephole column sums (AddRowSumMat, AddDiagMatMat x3)
 // ---------------------------------------------------------------------------------------------
 struct GradsArgs {
+  const unsigned *guard;   // status words of the persistent chain ([2], [6]): non-zero -> the minibatch is invalid, touch nothing
   GemmJob wx, wr, wm;
   int nb0, nb1, nb2, nvec;   // tile-id ranges of the three products, then nvec column-sum blocks
   int C, S, T;
@@ -1976,6 +1977,7 @@ __device__ __forceinline__ void grads_column_sums(const GradsArgs &a, int vb, fl
 }
 
 __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
+  if (a.guard && (a.guard[2] | a.guard[6])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ __attribute__((aligned(16))) float As[GLDS];
   __shared__ __attribute__((aligned(16))) float Bs[GLDS];
   // XCD-aware order: workgroup w lands on XCD w % 8 (observed dispatch rule, speed only); XCD x gets the contiguous
@@ -2096,6 +2098,7 @@ __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int 
 }
 
 __global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
+  if (a.guard && (a.guard[2] | a.guard[6])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ __attribute__((aligned(16))) unsigned As[4 * PLANE];
   __shared__ __attribute__((aligned(16))) unsigned Bs[4 * PLANE];
   const int nbt = a.nb2 + a.nvec;
@@ -2117,6 +2120,7 @@ __global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
 // 32x32 tiles of the three matrices (+ 1024-element chunks of the vector parameters).
 // ---------------------------------------------------------------------------------------------
 struct UpdArgs {
+  const unsigned *guard;   // as in GradsArgs
   float *param, *corr;
   const float *grad;        // DP: corr = mmt*corr + grad first
   float mmt, lr, clip;
@@ -2142,6 +2146,7 @@ __device__ __forceinline__ float upd_elem(const UpdArgs &a, long idx) {
 }
 
 __global__ __launch_bounds__(256) void k_update_repack(UpdArgs a) {
+  if (a.guard && (a.guard[2] | a.guard[6])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ float tile[32][33];
   const int b = blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   if (b >= a.tb_vec) {
@@ -2192,6 +2197,7 @@ __device__ __forceinline__ float4 upd_vec(const UpdArgs &a, long idx) {
 }
 
 __global__ __launch_bounds__(256) void k_update_repack_v(UpdArgs a) {
+  if (a.guard && (a.guard[2] | a.guard[6])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ __attribute__((aligned(16))) float tile[64 * 68];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= a.tb_vec) {
@@ -2998,12 +3004,13 @@ bool grads_bf16_tiles(const Dims &d, bool bf16) { return bf16 && d.T * d.S >= GR
 
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst,
-                        hipStream_t st, LaunchProbe pr, bool bf16, const GradsUpdate *upd) {
+                        hipStream_t st, LaunchProbe pr, bool bf16, const GradsUpdate *upd, const unsigned *guard) {
   const int S = d.S, C = d.C, R = d.R, I = d.I, TS = d.T * d.S;
   const long o_wx = 0, o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_pi = o_b + 4 * C,
              o_pf = o_pi + C, o_po = o_pf + C, o_wm = o_po + C;
   const float *dg1 = dgifo + (size_t)S * 4 * C;                      // DGIFO[1..T]
   GradsArgs a;
+  a.guard = guard;
   a.wx = make_job(true, false, 4 * C, I, TS, dg1, 4 * C, in, in_stride, beta, dst + o_wx, I, nullptr);             // :468
   a.wr = make_job(true, false, 4 * C, R, TS, dg1, 4 * C, rr, R, beta, dst + o_wr, R, nullptr);                      // :471 (YR[0..T-1])
   a.wm = make_job(true, false, R, C, TS, dr + (size_t)S * R, R, mm + (size_t)S * C, C, beta, dst + o_wm, C, nullptr); // :486
@@ -3041,9 +3048,10 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
 
 hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_blob, const float *grad_blob,
                                 float mmt, float lr, float clip, float *wrT, float *wmT, float *wxT,
-                                hipStream_t st, LaunchProbe pr) {
+                                hipStream_t st, LaunchProbe pr, const unsigned *guard) {
   const int C = d.C, R = d.R, I = d.I;
   UpdArgs a;
+  a.guard = guard;
   a.param = param_blob; a.corr = corr_blob; a.grad = grad_blob; a.mmt = mmt; a.lr = lr; a.clip = clip;
   a.touch = (lr != 0.f || grad_blob != nullptr || clip > 0.f) ? 1 : 0;
   const long o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_wm = o_b + 7 * C;

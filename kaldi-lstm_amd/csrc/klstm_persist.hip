@@ -60,6 +60,7 @@ struct PersistFwdArgs {
   int nap0, nap;                  // sweepers sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
   long long spin_limit;           // wall-clock ticks (100 MHz) a single wait may take before the workgroup gives up
   int test_stall;                 // test hook: workgroup 0 stops publishing at this step (0: never) -> every sweep of that step times out
+  unsigned *hstat;                // host-mapped status word (or null): set when a wait expires, read by the engine without a sync
 #ifdef KLSTM_PERSIST_TIMING
   long long *dbg;                 // per workgroup: shader-clock sums of the phases of a step (tools/persist_anatomy.hip)
 #endif
@@ -73,7 +74,7 @@ struct PersistFwdArgs {
 // sleeps through the part of the step in which nothing can have arrived (nap0) and briefly between passes (nap).
 template <int PCELL, int NG = 1>
 __device__ __forceinline__ bool sweep_cells(const unsigned long long *slot, int C, int S, unsigned tag, const int (&cell)[PCELL],
-                                            float (&v)[PCELL][4 * NG], long long limit, int nap0, int nap) {
+                                            float (&v)[PCELL][4 * NG], long long limit, int nap0, int nap, unsigned *dbg = nullptr) {
   // NG groups of 4 stream slots per cell: 32*NG bytes, 2*NG loads
   const __amdgpu_buffer_rsrc_t rs = buf_rsrc(slot, C * 32 * NG);
   for (int i = 0; i < nap0; i++) __builtin_amdgcn_s_sleep(4);
@@ -100,7 +101,21 @@ __device__ __forceinline__ bool sweep_cells(const unsigned long long *slot, int 
       ok &= okc | (cell[j] >= C);
     }
     if (ok) return true;
-    if ((spins & 31) == 31 && wall_clock64() - t0 > limit) return false;
+    if ((spins & 31) == 31 && wall_clock64() - t0 > limit) {
+      if (dbg) {                                     // diagnostics: lowest / highest cell whose granules never arrived, how many
+#pragma unroll
+        for (int j = 0; j < PCELL; j++) {
+          bool okc = true;
+#pragma unroll
+          for (int h = 0; h < 2 * NG; h++) {
+            const unsigned ta = q[j][h].y, tb = q[j][h].w;
+            okc &= ((S < 2 * h + 1) | (ta == tag)) & ((S < 2 * h + 2) | (tb == tag));
+          }
+          if (!okc && cell[j] < C) { atomicMax(&dbg[0], (unsigned)cell[j] + 1u); atomicMax(&dbg[1], (unsigned)(C - cell[j])); atomicAdd(&dbg[2], 1u); }
+        }
+      }
+      return false;
+    }
     for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
   }
 }
@@ -371,9 +386,12 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
             if ((spins & 1023) == 1023 && wall_clock64() - w0 > a.spin_limit) break;   // (bounded like every other spin: the sweep below then times out and reports)
           }
         }
-        if (!sweep_cells<PCELL, NG>(a.gran + (size_t)((t - 1) & 1) * C * SS, C, S, epoch + (unsigned)(t - 1), cell, mv, a.spin_limit, a.nap0, a.nap)) {
+        if (!sweep_cells<PCELL, NG>(a.gran + (size_t)((t - 1) & 1) * C * SS, C, S, epoch + (unsigned)(t - 1), cell, mv, a.spin_limit, a.nap0, a.nap, a.ctrl + 8)) {
           *abortf = 1u;
-          if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+          if (lane == 0) {
+            atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+            if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
         }
         // (the slab is free: the sweep only completes once every cell wave of THIS workgroup has published step t-1,
         //  i.e. has finished reading the previous slab; the projection wave says so itself)
@@ -479,6 +497,7 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
   a.nap0 = o.nap0 >= 0 ? o.nap0 : d.S > 4 ? 4 : 2; a.nap = o.nap >= 0 ? o.nap : 0;     // (behind the publish flag; measured: tools/persist_anatomy, tools/nap_sweep.py)
   a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;
   a.test_stall = o.test_stall_fwd;
+  a.hstat = o.hstat;
 #ifdef KLSTM_PERSIST_TIMING
   a.dbg = o.dbg;
 #endif

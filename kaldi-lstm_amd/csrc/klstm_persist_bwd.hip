@@ -64,6 +64,7 @@ struct PersistBwd2Args {
   int nap0, nap;                  // SC waves sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
   long long spin_limit;           // wall-clock ticks (100 MHz) a single wait may take
   int test_stall;                 // test hook: workgroup 0 does not publish d_m(test_stall) (0: never)
+  unsigned *hstat;                // host-mapped status word (or null): set when a wait expires, read by the engine without a sync
 #ifdef KLSTM_PERSIST_TIMING
   long long *dbg;
 #endif
@@ -464,7 +465,10 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
     PT_FLUSH(0);
   }
   __syncthreads();
-  if (tid == 0 && *abortf) atomicMax(&a.ctrl[2], 0x80000000u | 0x7fffu);   // (a bounded LDS wait expired or a sweep timed out)
+  if (tid == 0 && *abortf) {                         // (a bounded LDS wait expired or a sweep timed out)
+    atomicMax(&a.ctrl[2], 0x80000000u | 0x7fffu);
+    if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   finish(a.ctrl, epoch, ngrp * (T + 2));
 }
 
@@ -534,6 +538,7 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
   a.nap = o.nap >= 0 ? o.nap : 0;
   a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;
   a.test_stall = o.test_stall_bwd;
+  a.hstat = o.hstat;
 #ifdef KLSTM_PERSIST_TIMING
   a.dbg = o.dbg;
 #endif
