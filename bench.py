@@ -14,6 +14,9 @@ K = 20 steps are only ~5 ms of GPU time, the same K-step block is then repeated 
 region (`timed`).  Max over ranks.  A second run with ragged utterance lengths (900-1100 frames, new utterances enter
 at minibatch boundaries, padded frames masked) exercises the mask / Reset path (`ragged`).
 
+`--config` selects the BASELINE.json configuration: c2 (default) = configs[1], the headline; c3 = configs[2]'s per-GPU shard
+(the same layer at 8 streams per GPU, = --streams-per-gpu 8); c1 / c4 / c5 = configs[0] / [3] / [4] (bench_configs.py).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -129,6 +132,21 @@ ROCPROF_TAG = {"k_gates_step": "k_gates_v", "k_dr_step": "k_dr_v", "k_gates_fold
                "k_proj_step": "k_proj_v", "k_dm_step": "k_dm_v", "k_fwd_persist": "k_fwd_persist", "k_bwd_persist": "k_bwd_persist"}
 
 
+def rocprof_avg_us(kernel_tag, S):
+    """Average duration (us) of the kernels whose name contains `kernel_tag` in the latest committed `rocprofv3 --kernel-trace
+    --stats` summary for this stream count (profiles/rNN[sS]_rocprofv3_kernel_stats.csv), or (None, None).  STATIC: not this run."""
+    import csv
+    pat = "r*s%d_rocprofv3_kernel_stats.csv" % S if S != 4 else "r[0-9][0-9]_rocprofv3_kernel_stats.csv"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+    if not files:
+        return None, None
+    tot = calls = 0
+    for row in csv.DictReader(open(files[-1])):
+        if kernel_tag in row["Name"]:
+            tot += float(row["TotalDurationNs"]); calls += int(row["Calls"])
+    return (tot / calls / 1e3, os.path.relpath(files[-1], ROOT)) if calls else (None, None)
+
+
 def pmc_profile(S=4):
     """The committed rocprofv3 PMC summary (profiles/rNN_pmc_traffic.json, produced by tools/profile.sh on the GPU box in
     SEPARATE passes -- counters cannot be collected inside a timed run), or None.  STATIC: not measured by this process."""
@@ -154,7 +172,7 @@ def cpu_baseline(S, budget_s):
     of the same workload.  The reference's CPU path calls cblas_sgemm (kaldi-matrix.cc:160-175): `value` = GEMMs through
     OpenBLAS cblas_sgemm on ONE thread (Kaldi nnet1 is single-threaded outside BLAS), `value_threaded` = the same with the
     BLAS on all physical cores, `value_plain_loops` = the oracle's own triple loops (what the parity tests run).
-    The ONLY place bench.py touches oracle/."""
+    The only place bench.py touches oracle/ (bench_configs.py: the cpu_baseline leg of --config c1 likewise)."""
     from oracle.oracle import Oracle, use_openblas
     rng = np.random.RandomState(0)
     x = rng.randn(T_BPTT * S, I_DIM).astype(np.float32)
@@ -216,7 +234,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--streams-per-gpu", type=int, default=0,
                     help="default: 4 on one GPU (BASELINE.json configs[1]), 8 per GPU on N > 1 (configs[2]: 64 streams on 8 GPUs)")
-    ap.add_argument("--min-seconds", type=float, default=1.0, help="minimum length of the timed region (whole K-step blocks)")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum length of the timed region (whole K-step blocks)")
+    ap.add_argument("--config", choices=("c1", "c2", "c3", "c4", "c5"), default="c2",
+                    help="BASELINE.json configuration: c2 = configs[1] (headline, default); c3 = configs[2]'s per-GPU shard (8 streams "
+                         "per GPU); c1 / c4 / c5 = configs[0] / [3] / [4] on one GPU (bench_configs.py)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the ragged-length run and the 8-streams-per-GPU reference point")
@@ -241,7 +262,13 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     import kaldi_lstm_amd as k
-    S = args.streams_per_gpu or (4 if world == 1 else 8)
+    if args.config in ("c1", "c4", "c5"):
+        if world != 1:
+            sys.exit("bench.py --config %s is a single-GPU (per-GPU shard) line" % args.config)
+        import bench_configs
+        print(json.dumps(bench_configs.RUN[args.config](args, k)))
+        return
+    S = args.streams_per_gpu or (8 if (world > 1 or args.config == "c3") else 4)
     stream = torch.cuda.Stream()
     ones = np.ones(S, np.int32)
 
@@ -271,7 +298,9 @@ def main():
     nchunk = feats.shape[0]
     out = torch.empty(T_BPTT * S, R_DIM, device="cuda")
     in_diff = torch.empty(T_BPTT * S, I_DIM, device="cuda")
-    dp = k.DataParallelLstm(eng)          # N>1: one all-reduce (sum, fp32) of the 8.73 MB gradient blob per minibatch
+    # N>1: one all-reduce (sum, fp32) of the 8.73 MB gradient blob per minibatch, issued by libklstm.so itself (RCCL); a run
+    # on several GPUs that cannot make the library-owned communicator fails instead of silently measuring something else
+    dp = k.DataParallelLstm(eng, require_native=world > 1)
     torch.cuda.synchronize()
 
     def step(i):
@@ -344,7 +373,8 @@ def main():
         for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj",
                      "k_gates_fold", "k_gemm_rbatch", "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step",
                      "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx", "k_fwd_persist", "k_bwd_persist",
-                     "k_grads", "k_grads_update", "k_update_repack", "k_pack", "k_pack_fwd", "k_pack_bwd", "k_apply_momentum"):
+                     "k_grads", "k_grads_update", "k_update_repack", "k_pack", "k_pack_fwd", "k_pack_bwd", "k_apply_momentum",
+                     "rccl_allreduce"):
             tot, n = eng.profile_query(name)
             if n:
                 kern[name] = {"avg_us": tot / n, "launches_per_step": n / NPROF, "us_per_step": tot / NPROF}
@@ -405,7 +435,17 @@ def main():
                     mfma_busy = v.get("mfma_busy_frac")
             if pmc.get("hbm_bytes_per_minibatch"):
                 traffic_ratio = pmc["hbm_bytes_per_minibatch"] / alg_bytes_mb
-        roof = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
+        rp_us, rp_file = rocprof_avg_us(ROCPROF_TAG[dom], S)
+        if rp_us and dom.endswith("_persist"):
+            rp_us /= T_BPTT
+        frac_now = gbs / (PEAK_HBM_TBS * 1e3) if hbm_bound else tflops / PEAK_F32_MFMA_TF
+        roof = {"bound": "hbm" if hbm_bound else "mfma",
+                # neither roof is near: the kernel is a chain of dependent in-launch exchanges (sync_floor below)
+                "limiter": ("latency (in-launch exchange)" if dom.endswith("_persist") else "latency (dependent launches)")
+                           if max(gbs / (PEAK_HBM_TBS * 1e3), tflops / PEAK_F32_MFMA_TF) < 0.1 else ("hbm" if hbm_bound else "mfma"),
+                "frac_rocprof": (frac_now * per_step_us / rp_us) if rp_us else None,
+                "rocprof": {"avg_us_per_step": rp_us, "file": rp_file} if rp_us else None,
+                "kernel": dom,
                 "achieved": gbs if hbm_bound else tflops, "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else PEAK_F32_MFMA_TF,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": gbs / (PEAK_HBM_TBS * 1e3) if hbm_bound else tflops / PEAK_F32_MFMA_TF,
@@ -439,7 +479,8 @@ def main():
             "config": {"workload": "google/ LstmProjectedStreams 40->cell800/proj512, NumStream=%d per GPU (%d in total), "
                                    "T_bptt=20, 1000-frame synthetic utterances, fwd+BPTT+update (BASELINE.json %s)"
                                    % (S, S * world, "configs[1]" if world == 1 and S == 4 else
-                                      "configs[2]: 64 streams = 8 per GPU x 8 GPUs" if S == 8 else "custom stream count"),
+                                      "configs[2]: 64 streams = 8 per GPU x 8 GPUs%s" % ("; this line: one GPU's shard" if world == 1 else "")
+                                      if S == 8 else "custom stream count"),
                        "streams_per_gpu": S, "total_streams": S * world, "bptt": T_BPTT,
                        "frames_per_step": frames_per_step, "launch": launch, "launch_ab": ab,
                        "recurrence": ("persistent weights-resident chain" if "k_bwd_persist" in kern or "k_fwd_persist" in kern else
@@ -448,7 +489,8 @@ def main():
                        "update": ("gradient products + momentum + Update as one pass (klstm_backpropagate with KLSTM_BPTT_FUSE_UPDATE: the "
                                   "Update follows immediately, as in Kaldi's Component::Backpropagate)" if "k_grads_update" in kern else
                                   "gradient products, all-reduce, momentum + Update" if world > 1 else "gradient products, then Update"),
-                       "parallelism": "dp%d over streams, 1 all-reduce/minibatch" % world if world > 1 else "single GPU"},
+                       "parallelism": "dp%d over streams, 1 all-reduce/minibatch" % world if world > 1 else "single GPU",
+                       "collective": dp.collective_name, "ranks_seen": dp.ranks_seen},
             "timed": {"steps": nsteps_total, "seconds": dt_total},
             "first_k_steps": {"steps": K, "seconds": dt_first, "ms_per_step": dt_first / K * 1e3,
                               "value": K * frames_per_step / dt_first},
@@ -457,6 +499,8 @@ def main():
             "chain_us_per_step": chain_us, "non_chain_us_per_step": sum(v["us_per_step"] for v in kern.values()) - chain_us,
             "kernels": kern,
         }
+        if "rccl_allreduce" in kern:                # exposed time of the gradient all-reduce per minibatch (events on the engine's stream)
+            res["allreduce_us"] = kern["rccl_allreduce"]["us_per_step"]
         if ragged:
             res["ragged"] = ragged
         if s8:

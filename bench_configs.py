@@ -1,0 +1,256 @@
+"""bench.py --config c1|c4|c5: the other BASELINE.json configurations as driver-runnable lines (per-GPU shard on ONE GPU).
+
+  c1  BASELINE.json configs[0]: standard/ LstmProjected 40 -> cell 800 / proj 512, ONE 1000-frame utterance through the
+      nnet-forward path (standard/nnet/nnet-lstm-projected.h:222-316).  The reference case is CPU plumbing: `cpu_baseline` is
+      the oracle's forward on this host, `value` the same utterance through the engine (S = 1, whole utterance in one call).
+  c4  configs[3]: 2 stacked LstmProjectedStreams (40 -> 512 -> 512, cell 800) + AffineTransform 16624 + Softmax +
+      Xent::EvalMasked, NumStream 32 over 8 GPUs = 4 streams per GPU (README.md:24-29, nnet.proto:1-6).
+  c5  configs[4]: 3 x LstmProjectedStreams cell 1024 / proj 512 (40 -> 512 -> 512 -> 512), NumStream 256 over 8 GPUs = 32
+      streams per GPU, bf16 operands with fp32 accumulate and fp32 masters (build extension; the reference is fp32 only).
+(c2 = the headline line, c3 = the headline layer at 8 streams per GPU: `bench.py --streams-per-gpu 8`; both live in bench.py.)
+
+Each function returns the dict bench.py prints: metric / value / unit / ms_per_step / dtype / config.workload / roofline
+(whole minibatch: algorithmic FLOPs per SURVEY.md 8(d) over the measured step, against the dense MFMA peak of the dtype)
+/ sections (device time per part, HIP events) / kernels (engine probes where an engine runs them).
+"""
+import time
+
+import numpy as np
+import torch
+
+T_BPTT, LR, MOMENTUM = 20, 1e-5, 0.9
+PEAK_F32_MFMA_TF, PEAK_BF16_MFMA_TF, PEAK_HBM_TBS = 157.3, 2500.0, 8.0
+
+
+def lstm_flops_per_frame(I, C, R):
+    return 6 * (4 * C * I + 4 * C * R + R * C)        # fwd + data-grad + weight-grad of the three products
+
+
+def n_params(I, C, R):
+    return 4 * C * I + 4 * C * R + 7 * C + R * C
+
+
+def init_params(I, C, R, seed, scale=0.01):
+    rng = np.random.RandomState(seed)
+    return ((rng.rand(n_params(I, C, R)) - 0.5) * 2 * scale).astype(np.float32)
+
+
+def _timed(step, warmup, K, min_seconds):
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt_first = time.perf_counter() - t0
+    blocks = max(0, int(np.ceil((min_seconds - dt_first) / max(dt_first, 1e-9))))
+    dt, n = dt_first, K
+    if blocks:
+        t0 = time.perf_counter()
+        for i in range(blocks * K):
+            step(warmup + K + i)
+        torch.cuda.synchronize()
+        dt += time.perf_counter() - t0
+        n += blocks * K
+    return dt, n, dt_first
+
+
+def _engine_kernels(engines, step, base, nprof=10):
+    names = ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj", "k_gates_fold", "k_gemm_rbatch",
+             "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step", "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx",
+             "k_fwd_persist", "k_bwd_persist", "k_grads", "k_grads_update", "k_update_repack", "k_pack", "k_apply_momentum")
+    for e in engines:
+        e.set_option("profile", 1)
+    for i in range(3):
+        step(base + i)
+    for e in engines:
+        e.profile_query("k_grads"); e.set_option("profile", 1)
+    for i in range(nprof):
+        step(base + 3 + i)
+    kern = {}
+    for li, e in enumerate(engines):
+        for nme in names:
+            tot, n = e.profile_query(nme)
+            if n:
+                kern["layer%d.%s" % (li, nme)] = {"avg_us": tot / n, "launches_per_step": n / nprof, "us_per_step": tot / nprof}
+        e.set_option("profile", 0)
+    return kern
+
+
+def _sections(parts, nrep=20):
+    """Device time of named callables (HIP events on torch's current stream), each averaged over nrep calls."""
+    out = {}
+    for name, fn in parts:
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(nrep):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        out[name] = a.elapsed_time(b) * 1e3 / nrep
+    return out
+
+
+def _roof(flops_per_step, ms_per_step, peak_tf, dtype, note):
+    tf = flops_per_step / (ms_per_step * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "whole minibatch (sections / kernels below)", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s",
+            "frac": tf / peak_tf, "traffic": None, "dtype_peak": dtype, "note": note}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def run_c1(args, k):
+    from oracle.oracle import Oracle, use_openblas   # (cpu_baseline leg only: the checker as the CPU reference path)
+    I, C, R, T = 40, 800, 512, 1000
+    p = init_params(I, C, R, 7)
+    rng = np.random.RandomState(1234)
+    x = rng.randn(T, I).astype(np.float32)
+    e = k.Engine(I, C, R, 1)
+    e.set_params(p)
+    xd = torch.from_numpy(x).cuda(); out = torch.empty(T, R, device="cuda")
+    one = np.ones(1, np.int32)
+
+    def step(i):
+        e.reset(one)                                   # standard/ LstmProjected: zero initial state per utterance
+        e.propagate(xd, out)
+    dt, n, dt_first = _timed(step, max(3, args.warmup // 10), max(5, args.steps // 25), args.min_seconds)
+    ms = dt / n * 1e3
+    e.set_option("profile", 1)
+    for i in range(5):
+        step(i)
+    kern = {}
+    for nme in ("k_fwd_persist", "k_fold", "k_gates_step", "k_gates_fold", "k_gemm_rbatch"):
+        tot, cnt = e.profile_query(nme)
+        if cnt:
+            kern[nme] = {"avg_us": tot / cnt, "launches_per_step": cnt / 5}
+    e.close()
+    fwd_flops = 2 * (4 * C * I + 4 * C * R + R * C)
+    res = {"metric": "frames/sec forward (nnet-forward), standard/ LstmProjected 40in/800cell/512proj, one 1000-frame utterance",
+           "value": T / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1, "steps": n, "warmup": max(3, args.warmup // 10), "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "standard/ LstmProjected 40->cell800/proj512, 1 utterance of 1000 frames, forward only, whole utterance in "
+                                  "one call (BASELINE.json configs[0]; the reference case is CPU plumbing: cpu_baseline is the figure it names)",
+                      "streams_per_gpu": 1, "frames_per_step": T},
+           "roofline": _roof(fwd_flops * T, ms, PEAK_F32_MFMA_TF, "f32", "one stream: 999 dependent in-launch exchanges, latency bound"),
+           "kernels": kern}
+    if not args.no_cpu_baseline:
+        blas = use_openblas(1)
+        o = Oracle(I, C, R, 1, np.float32, threads=1); o.set_params(p)
+        o.reset([1]); o.propagate(x)
+        cnt, t0 = 0, time.perf_counter()
+        while True:
+            o.reset([1]); o.propagate(x); cnt += 1
+            dtc = time.perf_counter() - t0
+            if dtc >= args.cpu_seconds and cnt >= 2:
+                break
+        use_openblas(0)
+        res["cpu_baseline"] = {"value": cnt * T / dtc, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "%d utterances of 1000 frames (%.1f s), oracle forward, GEMMs through %s" % (cnt, dtc, blas or "its own loops")}
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def run_c4(args, k):
+    I, C, R, NPDF, S, T = 40, 800, 512, 16624, 4, T_BPTT
+    rng = np.random.RandomState(21)
+    dims_in = [I, R]
+    engines = []
+    for l in range(2):
+        e = k.Engine(dims_in[l], C, R, S)
+        e.set_params(init_params(dims_in[l], C, R, 30 + l))
+        engines.append(e)
+    W = torch.from_numpy(((rng.rand(NPDF, R) - 0.5) * 0.02).astype(np.float32)).cuda()
+    b = torch.zeros(NPDF, device="cuda")
+    layers = [k.LstmDP(e) for e in engines] + [k.AffineDP(W, b, k)]
+    # loss statistics accumulate on the device and are read back once per 50-minibatch utterance round (the reference's
+    # trainer reports every few thousand frames); --option eager_loss=1: read back every minibatch instead
+    lazy = "eager_loss=1" not in args.option
+    net = k.DataParallelNnet(layers, k.SoftmaxXentDP(k, lazy=lazy), alloc=lambda n: torch.zeros(n, device="cuda"))
+    nchunk = 50
+    feats = torch.randn(nchunk, T * S, I, device="cuda")
+    tg = torch.from_numpy(rng.randint(0, NPDF, (nchunk, T * S)).astype(np.int32)).cuda()
+    mask = torch.ones(T * S, device="cuda")
+    ones = [1] * S
+
+    acc = [torch.zeros((), dtype=torch.float64, device="cuda"), torch.zeros((), device="cuda"), torch.zeros((), device="cuda")]
+    seen = []
+
+    def step(i):
+        c = i % nchunk
+        xe, correct, valid = net.train_step(feats[c], tg[c], mask, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
+        if lazy:
+            acc[0] += xe; acc[1] += correct; acc[2] += valid
+            if c == nchunk - 1:
+                seen.append((float(acc[0].item()), int(acc[1].item()), int(acc[2].item())))    # one read-back per utterance round
+    dt, n, dt_first = _timed(step, args.warmup, args.steps, args.min_seconds)
+    ms = dt / n * 1e3
+    kern = _engine_kernels(engines, step, args.warmup + n)
+    # device time of the output tail, part by part
+    x80 = torch.randn(T * S, R, device="cuda"); aff = layers[-1]; loss = net.loss
+    net_out = aff.propagate(x80)
+    diff, _, _, _ = loss.eval(net_out, tg[0], mask)
+    torch.cuda.synchronize()
+    sections = _sections([("affine_propagate", lambda: aff.propagate(x80)),
+                          ("softmax", lambda: k.softmax(net_out, loss._post)),
+                          ("affine_gradient+in_diff", lambda: aff.backpropagate(x80, diff, True)),
+                          ("affine_momentum_update", lambda: aff.apply(MOMENTUM, LR))])
+    for e in engines:
+        e.close()
+    fl = lstm_flops_per_frame(I, C, R) + lstm_flops_per_frame(R, C, R) + 6 * NPDF * R
+    return {"metric": "frames/sec fwd+BPTT+update, 2x LstmProjectedStreams(cell 800, proj 512) + AffineTransform 16624 + Softmax/Xent, per-GPU shard",
+            "value": T * S / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1, "steps": n, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "2 stacked LstmProjectedStreams (40->512->512, cell 800) + AffineTransform 512->16624 + Softmax + Xent::EvalMasked, "
+                                   "NumStream=4 per GPU (the per-GPU shard of BASELINE.json configs[3]: 32 streams on 8 GPUs), T_bptt=20, one fused "
+                                   "57.6 MB gradient blob, loss statistics %s" % ("accumulated on the device, read back every 50 minibatches" if lazy else "read back every minibatch"),
+                       "streams_per_gpu": S, "frames_per_step": T * S},
+            "roofline": _roof(fl * T * S, ms, PEAK_F32_MFMA_TF, "f32", "86.2 MFLOP per frame (SURVEY.md 8(d))"),
+            "sections_us": sections, "kernels": kern}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+class _FixedDiffLoss:
+    """configs[4] names no output layer: out_diff ~ N(0, 1e-2) stands in for it (as in the headline line)."""
+
+    def __init__(self, diff):
+        self.diff = diff
+
+    def eval(self, net_out, targets, mask):
+        return self.diff, 0.0, 0, 0
+
+
+def run_c5(args, k):
+    I, C, R, S, T, NL = 40, 1024, 512, 32, T_BPTT, 3
+    dims_in = [I, R, R]
+    engines = []
+    for l in range(NL):
+        e = k.Engine(dims_in[l], C, R, S)
+        e.set_params(init_params(dims_in[l], C, R, 40 + l, scale=0.02))
+        e.set_option("bf16", 1)
+        engines.append(e)
+    od = 0.1 * torch.randn(T * S, R, device="cuda")
+    net = k.DataParallelNnet([k.LstmDP(e) for e in engines], _FixedDiffLoss(od), alloc=lambda n: torch.zeros(n, device="cuda"))
+    nchunk = 50
+    feats = torch.randn(nchunk, T * S, I, device="cuda")
+    ones = [1] * S
+
+    def step(i):
+        c = i % nchunk
+        net.train_step(feats[c], None, None, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
+    dt, n, dt_first = _timed(step, args.warmup, max(20, args.steps // 5), args.min_seconds)
+    ms = dt / n * 1e3
+    kern = _engine_kernels(engines, step, args.warmup + n)
+    for e in engines:
+        e.close()
+    fl = sum(lstm_flops_per_frame(dims_in[l], C, R) for l in range(NL))
+    return {"metric": "frames/sec fwd+BPTT+update, 3x LstmProjectedStreams cell 1024 / proj 512, bf16, per-GPU shard",
+            "value": T * S / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1, "steps": n, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "3 stacked LstmProjectedStreams cell 1024 / proj 512 (40->512->512->512), NumStream=32 per GPU (the per-GPU shard "
+                                   "of BASELINE.json configs[4]: 256 streams on 8 GPUs), T_bptt=20, bf16 operands / fp32 accumulate / fp32 masters",
+                       "streams_per_gpu": S, "frames_per_step": T * S},
+            "roofline": _roof(fl * T * S, ms, PEAK_BF16_MFMA_TF, "bf16", "73.3 MFLOP per frame (SURVEY.md 8(d)); launch-per-step chain"),
+            "kernels": kern}
+
+
+RUN = {"c1": run_c1, "c4": run_c4, "c5": run_c5}

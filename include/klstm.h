@@ -160,6 +160,7 @@ int klstm_pointer_on_device(const klstm_engine *e, const void *p);
 klstm_status klstm_comm_get_unique_id(void *id128);
 klstm_status klstm_comm_init_rank(int device, int nranks, int rank, const void *id128, void **comm);
 klstm_status klstm_comm_destroy(void *comm);
+klstm_status klstm_comm_count(void *comm, int *nranks);       /* ncclCommCount: how many ranks the communicator really spans */
 klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm);
 klstm_status klstm_allreduce_buffer(float *buf_dev, size_t n, void *rccl_comm, void *hip_stream);
 

@@ -220,13 +220,19 @@ class LstmProjectedStreams {
     if (in_dev == 0)
       Check(klstm_backpropagate_host(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
                                      in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
-                                     opts_.momentum, dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : KLSTM_BPTT_FUSE_UPDATE));
+                                     opts_.momentum, BpttFlags()));
     else
       Check(klstm_backpropagate(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
                                 in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
-                                opts_.momentum, dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : KLSTM_BPTT_FUSE_UPDATE));
+                                opts_.momentum, BpttFlags()));
     host_fresh_ = host_fresh_ && true;
   }
+  // The caller that KNOWS Update follows immediately on the same (input, out_diff) pair -- Kaldi's Component::Backpropagate,
+  // here Nnet::Backpropagate -- says so; the engine may then leave the gradient products to klstm_update and run them in
+  // one pass with the Update (KLSTM_BPTT_FUSE_UPDATE keeps the raw `in` pointer until then).  A bare BackpropagateFnc
+  // (gradient checks, custom adapters) keeps the engine's default: the products run inside the call.
+  void SetUpdateFollows(bool v) { update_follows_ = v; }
+  int BpttFlags() const { return dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : update_follows_ ? KLSTM_BPTT_FUSE_UPDATE : KLSTM_BPTT_DEFAULT; }
 
   // Update, ...streams.h:501-512 (arguments unused there too)
   virtual void Update(const MatrixView &input, const MatrixView &diff) {
@@ -330,6 +336,7 @@ class LstmProjectedStreams {
   klstm_engine *eng_;
   mutable std::vector<BaseFloat> params_;   // host shadow, GetParams order
   mutable bool host_fresh_;                 // params_ == device parameters
+  bool update_follows_ = false;             // set by the caller that runs Update right behind BackpropagateFnc
   std::vector<BaseFloat> corr_;             // only to carry *_corr_ across Copy()
   bool corr_pending_;
   std::vector<BaseFloat> state_c_, state_r_;        // only to carry prev_nnet_state_ (c, r columns) across Copy()

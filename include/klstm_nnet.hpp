@@ -70,6 +70,7 @@ class Layer {
   virtual void PropagateFnc(const MatrixView &in, MatrixView *out) = 0;
   virtual void BackpropagateFnc(const MatrixView &in, const MatrixView &out, const MatrixView &out_diff, MatrixView *in_diff) = 0;
   virtual void Update(const MatrixView &, const MatrixView &) {}
+  virtual void SetUpdateFollows(bool) {}                     // Nnet::Backpropagate: Update comes right behind BackpropagateFnc
   virtual void SetTrainOptions(const NnetTrainOptions &) {}
   virtual void Reset(std::vector<int> &) {}                  // the overlay adds Reset to every Component (nnet-nnet.h:133-137)
   virtual int32 NumParams() const { return 0; }
@@ -96,6 +97,7 @@ class LstmLayer : public Layer {            // LstmProjectedStreams / LstmProjec
   void PropagateFnc(const MatrixView &in, MatrixView *out) override { c_->PropagateFnc(in, out); }
   void BackpropagateFnc(const MatrixView &in, const MatrixView &out, const MatrixView &od, MatrixView *id) override { c_->BackpropagateFnc(in, out, od, id); }
   void Update(const MatrixView &a, const MatrixView &b) override { c_->Update(a, b); }
+  void SetUpdateFollows(bool v) override { c_->SetUpdateFollows(v); }
   void SetTrainOptions(const NnetTrainOptions &o) override { c_->SetTrainOptions(o); }
   void Reset(std::vector<int> &f) override { if (std::string(c_->Marker()) == "<LstmProjectedStreams>") c_->Reset(f); }
   int32 NumParams() const override { return c_->NumParams(); }
@@ -332,8 +334,11 @@ class Nnet {                                  // google/nnet/nnet-nnet.h:36-150
       MatrixView idv, *idp = nullptr;
       if (i > 0) { bprop_[i]->Resize(in.NumRows(), layers_[i]->InputDim(), false); idv = bprop_[i]->View(); idp = &idv; }
       else if (in_diff) { idp = in_diff; }
+      const bool upd = layers_[i]->IsUpdatable();
+      layers_[i]->SetUpdateFollows(upd);
       layers_[i]->BackpropagateFnc(in, out, od, idp);
-      if (layers_[i]->IsUpdatable()) layers_[i]->Update(in, od);
+      if (upd) layers_[i]->Update(in, od);
+      layers_[i]->SetUpdateFollows(false);
     }
   }
  private:

@@ -87,6 +87,7 @@ def load_library():
     lib.klstm_comm_get_unique_id.argtypes = [P]
     lib.klstm_comm_init_rank.argtypes = [I, I, I, P, ctypes.POINTER(P)]
     lib.klstm_comm_destroy.argtypes = [P]
+    lib.klstm_comm_count.argtypes = [P, ctypes.POINTER(I)]
     lib.klstm_allreduce_grads.argtypes = [P, P]
     lib.klstm_allreduce_buffer.argtypes = [P, ctypes.c_size_t, P, P]
     _LIB = lib
@@ -308,6 +309,12 @@ class RcclComm:
         _chk(self.lib.klstm_comm_init_rank(int(device), int(nranks), int(rank), buf, ctypes.byref(h)))
         self.handle, self.nranks, self.rank = h, nranks, rank
 
+    def count(self):
+        """ncclCommCount: the number of ranks this communicator spans."""
+        n = ctypes.c_int(0)
+        _chk(self.lib.klstm_comm_count(self.handle, ctypes.byref(n)))
+        return n.value
+
     def allreduce(self, t, stream=None):
         """In-place fp32 sum of a contiguous CUDA float32 tensor over the ranks (torch's current stream by default)."""
         import torch
@@ -387,15 +394,19 @@ def softmax(x, out, stream=None):
     _chk(lib.klstm_softmax(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), out.stride(0), _sp(stream)))
 
 
-def xent_eval_masked(net_out, target, mask, diff, stream=None):
-    """Returns (cross_entropy_sum, correct, valid_frames); fills diff = (net_out - onehot) * mask."""
+def xent_eval_masked(net_out, target, mask, diff, stream=None, lazy=False, rows_out=None):
+    """Returns (cross_entropy_sum, correct, valid_frames); fills diff = (net_out - onehot) * mask.
+    lazy: no synchronisation -- the three statistics come back as 0-d device tensors (a trainer that reports every N
+    minibatches adds them up on the device and reads them once); rows_out = (row_xent, row_correct) buffers to reuse."""
     import torch
     lib = load_library()
     assert target.dtype == torch.int32 and mask.dtype == torch.float32
     rows = net_out.shape[0]
-    rx = torch.empty(rows, device=net_out.device); rc = torch.empty(rows, device=net_out.device)
+    rx, rc = rows_out if rows_out is not None else (torch.empty(rows, device=net_out.device), torch.empty(rows, device=net_out.device))
     _chk(lib.klstm_xent_eval_masked(net_out.data_ptr(), rows, net_out.shape[1], net_out.stride(0), target.data_ptr(),
                                     mask.data_ptr(), diff.data_ptr(), diff.stride(0), rx.data_ptr(), rc.data_ptr(), _sp(stream)))
+    if lazy:
+        return rx.sum(dtype=torch.float64), rc.sum(), mask.sum()
     if stream is not None:
         stream.synchronize()
     else:

@@ -247,8 +247,9 @@ static bool persist_bwd_wanted(const klstm_engine *e, int T) {
   return e->use_persist != 1 && persist_bwd_supported(d, e->popt) && persist_bwd_grid(d) <= e->ncu;
 }
 static bool persist_wanted(const klstm_engine *e, int T) {
-  if (e->use_persist == 0 || e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || !use_fused_x(e)) return false;
+  if (e->use_persist == 0 || e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0]) return false;
   const Dims d{e->I, e->C, e->R, e->S, T};
+  if (!use_fused_x(e) && !persist_x_batched(d)) return false;   // (x inside the step unless the input is wide: then the batched product feeds the launch)
   if (T < 3 || !persist_supported(d, e->popt)) return false;
   if (persist_fwd_grid(d, e->popt) > e->ncu) {                   // (its workgroups could not all be resident at once)
     if (e->use_persist >= 1)
@@ -298,8 +299,7 @@ static klstm_status check_persist(klstm_engine *e) {
   drop_graphs(e);
   return fail(KLSTM_ERR_HIP, "persistent recurrence chain timed out (forward status %x, backward status %x): its workgroups were not "
               "co-resident; outputs and state of that minibatch are invalid, its Update was NOT applied (the update kernels read "
-              "the status words), the engine falls back to one launch per step [forward: %u (cell, stream-group) sweeps expired, cells %d..%d]",
-              w[2], w[6], w[10], w[10] ? e->C - (int)w[9] : -1, (int)w[8] - 1);
+              "the status words), the engine falls back to one launch per step", w[2], w[6]);
 }
 
 // Early notice without a synchronisation: the kernels set a host-mapped word when they give up.  Called at the head of
@@ -564,7 +564,7 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
   const Dims d{e->I, e->C, e->R, e->S, T};
   const FwdPtrs p = fwd_ptrs(e);
   hipStream_t st = e->stream;
-  const bool fx = use_fused_x(e);
+  const bool fx = use_fused_x(e) && !(e->fwd_persist && persist_x_batched(d));
   if (!fx)   // x -> g,i,f,o for all frames at once + bias (...streams.h:246, :259)
     HIPCHK(launch_gemm(false, true, T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, 0.f,
                        e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias, st, probe(e, "k_gemm_xproj")));
@@ -1177,6 +1177,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
@@ -1199,6 +1200,7 @@ RcclApi &rccl() {
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce;
@@ -1244,6 +1246,13 @@ klstm_status klstm_comm_destroy(void *comm) {
   const ncclResult_t r = a.CommDestroy(static_cast<ncclComm_t>(comm));
   return r == ncclSuccess ? KLSTM_OK : rccl_fail("ncclCommDestroy", r);
 }
+klstm_status klstm_comm_count(void *comm, int *nranks) {
+  if (!comm || !nranks) return fail(KLSTM_ERR_ARG, "klstm_comm_count: null argument");
+  RcclApi &a = rccl();
+  if (!a.ok || !a.CommCount) return fail(KLSTM_ERR_HIP, "%s", a.ok ? "ncclCommCount not found" : a.why.c_str());
+  const ncclResult_t r = a.CommCount(static_cast<ncclComm_t>(comm), nranks);
+  return r == ncclSuccess ? KLSTM_OK : rccl_fail("ncclCommCount", r);
+}
 klstm_status klstm_allreduce_buffer(float *buf_dev, size_t n, void *rccl_comm, void *hip_stream) {
   if (!buf_dev || !rccl_comm) return fail(KLSTM_ERR_ARG, "klstm_allreduce_buffer: null argument");
   if (n == 0) return KLSTM_OK;
@@ -1257,7 +1266,12 @@ klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
   { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }     // a pending corr += grads must see the LOCAL sums
-  return klstm_allreduce_buffer(e->grads, (size_t)e->nparams, rccl_comm, e->stream);   // in place, on the engine's stream: no event hops
+  // option "profile": the exposed time of the collective between two events on the engine's stream ("rccl_allreduce")
+  const LaunchProbe pr = probe(e, "rccl_allreduce");
+  if (pr.start) HIPCHK(hipEventRecord(pr.start, e->stream));
+  const klstm_status st = klstm_allreduce_buffer(e->grads, (size_t)e->nparams, rccl_comm, e->stream);   // in place, on the engine's stream: no event hops
+  if (pr.stop) HIPCHK(hipEventRecord(pr.stop, e->stream));
+  return st;
 }
 
 }  // extern "C"

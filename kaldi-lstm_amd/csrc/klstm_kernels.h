@@ -175,6 +175,7 @@ struct PersistOpts {
   long long *dbg = nullptr;       // tools/persist_anatomy (KLSTM_PERSIST_TIMING builds only)
 };
 bool persist_supported(const Dims &d, const PersistOpts &o);       // forward
+bool persist_x_batched(const Dims &d);   // wide input: the caller runs x W_gifo_x^T + bias as one batched product into the gifo plane first
 bool persist_bwd_supported(const Dims &d, const PersistOpts &o);   // backward
 int persist_fwd_grid(const Dims &d, const PersistOpts &o);         // workgroups that must be co-resident (one per CU)
 int persist_bwd_grid(const Dims &d);

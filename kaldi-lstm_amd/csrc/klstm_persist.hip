@@ -53,6 +53,8 @@ struct PersistFwdArgs {
   const float *bias, *pi, *pf, *po;
   float *gifo, *cc, *hh, *mm, *rr; // activation planes, time-major row blocks of S
   const float *x; int x_stride;   // input rows [T*S x I]
+  const float *xg;                // non-null: x(t) W_gifo_x^T + bias is already in the gifo plane (batched product, :246/:259): wide inputs;
+                                  // the kernel then runs with I = 0 (no x columns in the slabs, no x rows of the operands)
   float *prev_c;                  // carried c [S x C]: read at step 1 (:231), written at step T (:331)
   float *prev_r;                  // carried r [S x R]: read at step 1, written with r(T) (:331) (rin)
   unsigned long long *gran;       // [2][C*4] granules, cell-major (4 stream slots per cell)
@@ -74,7 +76,7 @@ struct PersistFwdArgs {
 // sleeps through the part of the step in which nothing can have arrived (nap0) and briefly between passes (nap).
 template <int PCELL, int NG = 1>
 __device__ __forceinline__ bool sweep_cells(const unsigned long long *slot, int C, int S, unsigned tag, const int (&cell)[PCELL],
-                                            float (&v)[PCELL][4 * NG], long long limit, int nap0, int nap, unsigned *dbg = nullptr) {
+                                            float (&v)[PCELL][4 * NG], long long limit, int nap0, int nap) {
   // NG groups of 4 stream slots per cell: 32*NG bytes, 2*NG loads
   const __amdgpu_buffer_rsrc_t rs = buf_rsrc(slot, C * 32 * NG);
   for (int i = 0; i < nap0; i++) __builtin_amdgcn_s_sleep(4);
@@ -101,21 +103,7 @@ __device__ __forceinline__ bool sweep_cells(const unsigned long long *slot, int 
       ok &= okc | (cell[j] >= C);
     }
     if (ok) return true;
-    if ((spins & 31) == 31 && wall_clock64() - t0 > limit) {
-      if (dbg) {                                     // diagnostics: lowest / highest cell whose granules never arrived, how many
-#pragma unroll
-        for (int j = 0; j < PCELL; j++) {
-          bool okc = true;
-#pragma unroll
-          for (int h = 0; h < 2 * NG; h++) {
-            const unsigned ta = q[j][h].y, tb = q[j][h].w;
-            okc &= ((S < 2 * h + 1) | (ta == tag)) & ((S < 2 * h + 2) | (tb == tag));
-          }
-          if (!okc && cell[j] < C) { atomicMax(&dbg[0], (unsigned)cell[j] + 1u); atomicMax(&dbg[1], (unsigned)(C - cell[j])); atomicAdd(&dbg[2], 1u); }
-        }
-      }
-      return false;
-    }
+    if ((spins & 31) == 31 && wall_clock64() - t0 > limit) return false;
     for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
   }
 }
@@ -162,7 +150,8 @@ __device__ __forceinline__ f32x4 cell_contract(const float4 (&a0)[NCHUNK], const
 constexpr int persist_maxu(int maxc) { return maxc == 7 ? 5 : maxc; }
 
 // NG: groups of 4 streams (NumStream <= 4*NG); the weights stay where they are, every step contracts them NG times
-template <int TPW, int MAXC, int PNW, int PCELL, int NG>
+// XB: the x-projection is the caller's batched product (a.xg); compiled apart so that the default kernels carry nothing of it
+template <int TPW, int MAXC, int PNW, int PCELL, int NG, bool XB = false>
 __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
   constexpr int PNT = PNW * 64, NCW = 4 * TPW, NSW = (PNW - NCW - 1) * 64, MAXU = persist_maxu(MAXC);   // cell waves, one projection wave, sweepers
   constexpr int SS = 4 * NG;                         // stream slots per cell (slab rows, granules)
@@ -198,7 +187,8 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
     const int lc = e_cell < C ? e_cell : 0;
     const size_t wrow = (size_t)bj * C + lc;         // this lane's weight row: gate bj of the cell (rows of the 4C axis are g,i,f,o blocks)
     // epilogue lanes: lanes 12..15 = streams 0..3 of the cell (where kgroup_sum leaves the totals)
-    const float pre0 = a.bias[lc], pre1 = a.bias[C + lc], pre2 = a.bias[2 * C + lc], pre3 = a.bias[3 * C + lc];
+    constexpr bool xb = XB;
+    const float pre0 = xb ? 0.f : a.bias[lc], pre1 = xb ? 0.f : a.bias[C + lc], pre2 = xb ? 0.f : a.bias[2 * C + lc], pre3 = xb ? 0.f : a.bias[3 * C + lc];
     const float wpi = a.pi[lc], wpf = a.pf[lc], wpo = a.po[lc];
     // plane stores through buffer descriptors: one 32-bit lane offset per group and plane shape, frame in the scalar offset
     // (64-bit per-store addresses pushed the two-group kernel into scratch)
@@ -212,14 +202,14 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       cpg[g] = a.prev_c[(size_t)(e_ong[g] ? 4 * g + es : 0) * C + lc];            // carried c(0) (:231)
       if (e_ong[g]) a.cc[(size_t)(4 * g + es) * C + e_cell] = cpg[g];              // time block 0 of the c plane: BPTT reads it (:231)
     }
-    auto cell_math = [&](int t, int g, const f32x4 &v) {
+    auto cell_math = [&](int t, int g, const f32x4 &v, const float4 &xp) {
       if (!e_ong[g]) return;
       const int es_g = 4 * g + es;                   // the stream
       float &cp = cpg[g];
-      float ag = v.x + pre0;
-      float ai = v.y + pre1;
-      float af = v.z + pre2;
-      float ao = v.w + pre3;
+      float ag = v.x + (XB ? xp.x : pre0);           // (XB: x(t) W_x^T + bias as the batched product left it)
+      float ai = v.y + (XB ? xp.y : pre1);
+      float af = v.z + (XB ? xp.z : pre2);
+      float ao = v.w + (XB ? xp.w : pre3);
       ai += wpi * cp;                              // :278
       af += wpf * cp;                              // :281
       const float gi = k_sigmoid(ai), gf = k_sigmoid(af), gg = k_tanh(ag);   // :284-288
@@ -282,6 +272,19 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       // one group: requested now, behind the step-1 rows (they arrive while step 1 computes and travels); two groups: both
       // row sets at once do not fit the 168 registers of a 12-wave workgroup, requested once the step-1 rows are dead
       if (NG == 1) load_folded();
+      // batched x-projection: the four pre-activations of this lane's (cell, stream) of frame t, requested ahead of the barrier
+      auto load_xp = [&](int t, float4 (&xp)[NG]) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+          xp[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (xb && e_ong[g]) {
+            const float *gp = a.xg + ((size_t)t * S + 4 * g + es) * 4 * C + e_cell;
+            xp[g] = make_float4(gp[0], gp[C], gp[2 * C], gp[3 * C]);
+          }
+        }
+      };
+      float4 xp1[NG];
+      load_xp(1, xp1);
       PT_MARK(5);
       lds_barrier();                                 // slab of step 1 ready
       PT_MARK(1);
@@ -294,11 +297,13 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       PT_MARK(2);
       if (NG > 1) load_folded();
 #pragma unroll
-      for (int g = 0; g < NG; g++) cell_math(1, g, v1[g]);
+      for (int g = 0; g < NG; g++) cell_math(1, g, v1[g], xp1[g]);
       if (lane == 0) __hip_atomic_fetch_add(pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // publishes of this step issued
       PT_MARK(4);
     bool dead = false;
     for (int t = 2; t <= T; t++) {
+      float4 xpt[NG];
+      load_xp(t, xpt);
       PT_MARK(5);
       lds_barrier();                                 // slab of step t ready
       PT_MARK(1);
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       }
       PT_MARK(2);                                    // contractions + k-group sums
 #pragma unroll
-      for (int g = 0; g < NG; g++) cell_math(t, g, vt[g]);   // (back to back: the groups' dependent exp/rcp chains interleave)
+      for (int g = 0; g < NG; g++) cell_math(t, g, vt[g], xpt[g]);   // (back to back: the groups' dependent exp/rcp chains interleave)
       if (lane == 0) __hip_atomic_fetch_add(pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // publishes of this step issued
       PT_MARK(4);                                    // cell math + stores
     }
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
             if ((spins & 1023) == 1023 && wall_clock64() - w0 > a.spin_limit) break;   // (bounded like every other spin: the sweep below then times out and reports)
           }
         }
-        if (!sweep_cells<PCELL, NG>(a.gran + (size_t)((t - 1) & 1) * C * SS, C, S, epoch + (unsigned)(t - 1), cell, mv, a.spin_limit, a.nap0, a.nap, a.ctrl + 8)) {
+        if (!sweep_cells<PCELL, NG>(a.gran + (size_t)((t - 1) & 1) * C * SS, C, S, epoch + (unsigned)(t - 1), cell, mv, a.spin_limit, a.nap0, a.nap)) {
           *abortf = 1u;
           if (lane == 0) {
             atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
@@ -440,15 +445,23 @@ static PGeo pick_geo_fwd(const PersistOpts &o, int C, int nch, int ku = 0) {   /
 }
 
 // forward: up to 8 streams (two groups of 4 against the same resident rows)
+// Wide inputs (the 512 -> 800 / 512 inner layers of a stack): the x columns would take the operand past 9 chunks of 128 per
+// cell wave (12 spill) and the x rows past what the sweepers stage; x(t) W_gifo_x^T + bias then stays the batched product
+// of the reference (:246, :259) in front of the launch and the kernel adds it from the gifo plane.
+bool persist_x_batched(const Dims &d) {
+  return pcdiv((pcdiv(d.C, KCH) + pcdiv(d.I, KCH)) * KCH, 128) > 9 || d.S * (d.I / 4) > 192;
+}
 bool persist_supported(const Dims &d, const PersistOpts &o) {
-  if (d.S > 8 || d.C % 8 != 0 || d.I % 8 != 0 || d.R % 4 != 0 || d.S * (d.I / 4) > 192) return false;
-  const int nf = pcdiv(d.C, KCH) + pcdiv(d.I, KCH);
-  const PGeo gf = pick_geo_fwd(o, d.C, nf, pcdiv(d.R, KCH) * KCH + d.I);
-  if (d.S > 4 && gf.waves != 12) return false;
+  if (d.S > 8 || d.C % 8 != 0 || d.I % 8 != 0 || d.R % 4 != 0) return false;
+  const int Ik = persist_x_batched(d) ? 0 : d.I;
+  const int nf = pcdiv(d.C, KCH) + pcdiv(Ik, KCH);
+  const PGeo gf = pick_geo_fwd(o, d.C, nf, pcdiv(d.R, KCH) * KCH + Ik);
+  if ((d.S > 4 || persist_x_batched(d)) && (gf.waves != 12 || (persist_x_batched(d) && gf.maxc > 9))) return false;
   return gf.tpw > 0;
 }
 int persist_fwd_grid(const Dims &d, const PersistOpts &o) {
-  const PGeo g = pick_geo_fwd(o, d.C, pcdiv(d.C, KCH) + pcdiv(d.I, KCH), pcdiv(d.R, KCH) * KCH + d.I);
+  const int Ik = persist_x_batched(d) ? 0 : d.I;
+  const PGeo g = pick_geo_fwd(o, d.C, pcdiv(d.C, KCH) + pcdiv(Ik, KCH), pcdiv(d.R, KCH) * KCH + Ik);
   return g.tpw ? d.C / 4 / g.tpw : 0;
 }
 // forward: [2 parities][C][8 stream slots]; backward: [2 stream groups][2 parities][C][4 stream slots] -- the same size
@@ -470,8 +483,18 @@ static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t
     if (g.pcell == 3) return plaunch(KERN<TP, MC, W, 3, NG_>, grid, W * 64, shm, st, pr, a);                    \
     return plaunch(KERN<TP, MC, W, 4, NG_>, grid, W * 64, shm, st, pr, a);                                      \
   }
+#define PFX(KERN, TP, MC, NG_)                                                                                  \
+  if (xbat && g.waves == 12 && g.tpw == TP && g.maxc == MC && ng == NG_) {                                      \
+    if (g.pcell == 1) return plaunch(KERN<TP, MC, 12, 1, NG_, true>, grid, 768, shm, st, pr, a);                \
+    if (g.pcell == 2) return plaunch(KERN<TP, MC, 12, 2, NG_, true>, grid, 768, shm, st, pr, a);                \
+    if (g.pcell == 3) return plaunch(KERN<TP, MC, 12, 3, NG_, true>, grid, 768, shm, st, pr, a);                \
+    return plaunch(KERN<TP, MC, 12, 4, NG_, true>, grid, 768, shm, st, pr, a);                                  \
+  }
 #define PDISPATCH_FWD(KERN)                                                                                     \
   do {                                                                                                          \
+    PFX(KERN, 1, 7, 1) PFX(KERN, 1, 9, 1) PFX(KERN, 2, 7, 1) PFX(KERN, 2, 9, 1)                                  \
+    PFX(KERN, 1, 7, 2) PFX(KERN, 1, 9, 2) PFX(KERN, 2, 7, 2) PFX(KERN, 2, 9, 2)                                  \
+    if (xbat) return hipErrorInvalidValue;                                                                       \
     PF5(KERN, 1, 7, 8, 1) PF5(KERN, 1, 9, 8, 1) PF5(KERN, 1, 12, 8, 1)                                          \
     PF5(KERN, 1, 7, 12, 1) PF5(KERN, 1, 9, 12, 1) PF5(KERN, 1, 12, 12, 1) PF5(KERN, 2, 7, 12, 1) PF5(KERN, 2, 9, 12, 1) PF5(KERN, 2, 12, 12, 1) \
     PF5(KERN, 1, 7, 16, 1) PF5(KERN, 1, 9, 16, 1) PF5(KERN, 1, 12, 16, 1) PF5(KERN, 2, 7, 16, 1) PF5(KERN, 2, 9, 16, 1) PF5(KERN, 2, 12, 16, 1) \
@@ -481,15 +504,19 @@ static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t
 
 // r(t) = W_r_m m(t) inside the forward launch: 4 rows of W_r_m per workgroup on its projection wave
 bool persist_r_in_kernel(const Dims &d, const PersistOpts &o) {
-  const PGeo g = pick_geo_fwd(o, d.C, pcdiv(d.C, KCH) + pcdiv(d.I, KCH), pcdiv(d.R, KCH) * KCH + d.I);
+  const int Ik = persist_x_batched(d) ? 0 : d.I;
+  const PGeo g = pick_geo_fwd(o, d.C, pcdiv(d.C, KCH) + pcdiv(Ik, KCH), pcdiv(d.R, KCH) * KCH + Ik);
   return g.tpw > 0 && d.R % 4 == 0 && d.R / 4 <= d.C / 4 / g.tpw;
 }
 
 hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, int in_stride, float *out, int out_stride,
                               unsigned long long *gran, unsigned *ctrl, const PersistOpts &o, hipStream_t st, LaunchProbe pr) {
   PersistFwdArgs a;
-  a.C = d.C; a.I = d.I; a.R = d.R; a.S = d.S; a.T = d.T;
-  a.nchm = pcdiv(d.C, KCH); a.nch = a.nchm + pcdiv(d.I, KCH);
+  const bool xbat = persist_x_batched(d);            // (the caller has run the batched x-projection into the gifo plane)
+  a.C = d.C; a.I = xbat ? 0 : d.I; a.R = d.R; a.S = d.S; a.T = d.T;
+  a.xg = xbat ? p.gifo : nullptr;
+  a.nchm = pcdiv(d.C, KCH); a.nch = a.nchm + pcdiv(d.I, KCH);   // (stride of the packed operand: the fold product writes the layer's full row)
+  const int nch_k = a.nchm + pcdiv(a.I, KCH);                      // chunks this launch contracts
   a.wpk = p.pk_fold; a.wr = p.wr; a.wx = p.wx; a.wm = p.wm; a.bias = p.bias; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm; a.rr = p.rr;
   a.x = in; a.x_stride = in_stride; a.prev_c = p.prev_c; a.prev_r = p.prev_r; a.gran = gran; a.ctrl = ctrl;
@@ -501,8 +528,8 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
 #ifdef KLSTM_PERSIST_TIMING
   a.dbg = o.dbg;
 #endif
-  const PGeo g = pick_geo_fwd(o, d.C, a.nch, pcdiv(d.R, KCH) * KCH + d.I);
-  if (!g.tpw || !p.pk_fold || (reinterpret_cast<uintptr_t>(in) & 15) || in_stride % 4 != 0) return hipErrorInvalidValue;
+  const PGeo g = pick_geo_fwd(o, d.C, nch_k, pcdiv(d.R, KCH) * KCH + a.I);
+  if (!g.tpw || !p.pk_fold || (!xbat && ((reinterpret_cast<uintptr_t>(in) & 15) || in_stride % 4 != 0))) return hipErrorInvalidValue;
   const int ng = d.S > 4 ? 2 : 1;
   const size_t shm = (size_t)(4 * ng * (g.maxc * 128 + 16) + 4 * ng * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);   // (+ abort flag, projection flag)
   const int grid = d.C / 4 / g.tpw;

@@ -74,7 +74,9 @@ class DataParallelLstm:
     DEFER_MOMENTUM = 1
     FUSE_UPDATE = 2       # klstm.h: the Update follows immediately (it does, two lines below)
 
-    def __init__(self, engine, group=None, force_collective=False):
+    def __init__(self, engine, group=None, force_collective=False, require_native=False):
+        """require_native: fail instead of falling back to torch.distributed's all_reduce when the library-owned RCCL
+        communicator cannot be made on a GPU process group (bench.py --gpus N: the line must say what it measured)."""
         import torch.distributed as dist
         self.engine = engine
         self.dist = dist
@@ -85,6 +87,15 @@ class DataParallelLstm:
         self._blob = None
         # on GPUs the collective is libklstm.so's own (klstm_allreduce_grads: RCCL, in place, on the engine's stream)
         self.comm = native_comm(dist, group) if self.collective and hasattr(engine, "allreduce_grads") else None
+        on_gpu = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        if self.collective and require_native and on_gpu and self.comm is None:
+            raise RuntimeError("data-parallel run on GPUs without the library-owned RCCL communicator (klstm_comm_init_rank failed on "
+                               "some rank, see stderr): refusing to fall back to torch.distributed.all_reduce silently")
+        # what the gradient all-reduce of train_step goes through, and how many ranks it really spans
+        self.collective_name = ("none (single rank)" if not self.collective else
+                                "klstm_allreduce_grads (RCCL ncclAllReduce, in place, on the engine's stream)" if self.comm is not None else
+                                "torch.distributed.all_reduce (%s)" % (dist.get_backend(group) if dist.is_initialized() else "?"))
+        self.ranks_seen = self.comm.count() if self.comm is not None else self.world
 
     def broadcast_params(self, src=0):
         """Make every replica start from rank `src`'s parameters (device to device on GPUs)."""
@@ -199,17 +210,20 @@ class AffineDP:
 
 
 class SoftmaxXentDP:
-    """Softmax + Xent::EvalMasked (google/nnet/nnet-loss.cc:76-142) on the device ops of the C-ABI."""
+    """Softmax + Xent::EvalMasked (google/nnet/nnet-loss.cc:76-142) on the device ops of the C-ABI.
+    lazy: the statistics stay 0-d device tensors (no host synchronisation per minibatch; the reference's trainer prints
+    them every few thousand frames, bd-nnet-train-lstm-streams.cc:240-257)."""
 
-    def __init__(self, ops):
-        self.ops = ops
-        self._post = self._diff = None
+    def __init__(self, ops, lazy=False):
+        self.ops, self.lazy = ops, lazy
+        self._post = self._diff = self._rows = None
 
     def eval(self, net_out, targets, mask):
         if self._post is None or self._post.shape != net_out.shape:
             self._post, self._diff = torch.empty_like(net_out), torch.empty_like(net_out)
+            self._rows = (torch.empty(net_out.shape[0], device=net_out.device), torch.empty(net_out.shape[0], device=net_out.device))
         self.ops.softmax(net_out, self._post)
-        xe, correct, valid = self.ops.xent_eval_masked(self._post, targets, mask, self._diff)
+        xe, correct, valid = self.ops.xent_eval_masked(self._post, targets, mask, self._diff, lazy=self.lazy, rows_out=self._rows)
         return self._diff, xe, correct, valid
 
 
