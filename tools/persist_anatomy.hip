@@ -38,6 +38,8 @@ int main(int argc, char **argv) {
     const int grid = C / 4 / g.tpw;
     LaunchProbe pr;
     const int ng = S > 4 ? 2 : 1;
+    const bool xbat = false;
+    a.xg = nullptr; a.hstat = nullptr;
     auto go = [&]() -> hipError_t { PDISPATCH_FWD(k_fwd_persist); };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9;
@@ -89,7 +91,7 @@ int main(int argc, char **argv) {
     bp.wrT = wrT; bp.wmT = wmT; bp.wxT = wxT; bp.pi = vecs + 4 * C; bp.pf = vecs + 5 * C; bp.po = vecs + 6 * C;
     bp.gifo = gifo; bp.cc = cc; bp.hh = hh; bp.dgifo = dgifo; bp.dc = dc; bp.dr = dr; bp.pk_fold = wpb;
     const Dims d{I, C, R, S, T};
-    for (int full : {0, 1}) for (int waves : {16}) for (int nap0 : {0, 1, 2}) {
+    for (int full : {0, 1}) for (int waves : {16, 12}) for (int nap0 : {0}) {
       PersistOpts o; o.bwd_waves = waves; o.nap0_bwd = nap0; o.dbg = dbg;
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       float best = 1e9;
@@ -109,7 +111,7 @@ int main(int argc, char **argv) {
       printf("BWD2 S=%d waves=%d nu=%d %s nap0=%d: %.3f us/step over %d steps (%.1f us per launch, status %x)\n", S, g.nw, g.nu,
              full ? "P+d_r+in_diff inside" : "bare chain", nap0, best * 1e3 / nsteps, nsteps, best * 1e3, stw[2]);
       const char *no[6] = {"wait-partials", "combine+publish", "own-rows", "-", "-", "loophead"};
-      const char *ns[10] = {"wait-pubn", "sweep-wait", "apply+contract", "d-slice", "-", "loophead", "wait-planes", "coefs", "-", "issue"};
+      const char *ns[10] = {"planes+coef", "sweep", "apply+contract", "d-slice", "-", "loophead", "-", "-", "-", "-"};
       printf("   owner wg0 :");
       for (int i : {0, 1, 2, 5}) printf(" %s %.2f", no[i], row(0, 0)[i] / cyc_per_us / nsteps);
       double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mx[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -119,11 +121,11 @@ int main(int argc, char **argv) {
         m[i] += v / grid; if (v > mx[i]) mx[i] = v;
       }
       printf("\n   SC wave 1 (mean over workgroups | max):");
-      for (int i : {5, 6, 7, 0, 9, 3, 1, 2}) printf(" %s %.2f|%.2f", ns[i], m[i], mx[i]);
+      for (int i : {5, 0, 1, 2, 3}) printf(" %s %.2f|%.2f", ns[i], m[i], mx[i]);
       printf("\n   wg0, per SC wave (columns as above):\n");
       for (int w = 2; w < g.nw; w++) {
         printf("     wave %2d:", w);
-        for (int i : {5, 6, 7, 0, 9, 3, 1, 2}) printf(" %.2f", row(0, w)[i] / cyc_per_us / nsteps);
+        for (int i : {5, 0, 1, 2, 3}) printf(" %.2f", row(0, w)[i] / cyc_per_us / nsteps);
         printf("\n");
       }
     }
