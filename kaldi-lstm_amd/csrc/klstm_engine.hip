@@ -98,6 +98,7 @@ struct klstm_engine {
   unsigned long long *gran[2] = {nullptr, nullptr};   // granule slots of the forward / backward chain
   unsigned *pctrl = nullptr;    // 2 x 4 words: {epoch, finished workgroups, status, pad} per direction
   unsigned *pstat_host = nullptr;   // pinned, device-mapped word the persistent kernels set when they give up (polled without a sync)
+  void *fold_scratch = nullptr;             // bf16 planes of the two fold operands (klstm_fold3.hip)
   float *pk_fold[2] = {nullptr, nullptr};   // packed [W_rm | W_x] (gates order) and W_rm^T (4-row geometry)
   float *Pm = nullptr;     // out_diff * W_r_m for all frames [(T_alloc) S x C]
   float *ws = nullptr;     // split-K workspace of the batched d_r / in_diff products
@@ -333,8 +334,11 @@ static klstm_status ensure_fold(klstm_engine *e, bool need_x) {
   }
   const bool pack_x = need_x && !e->foldx_fresh;
   if (!e->fold_dirty && !pack_x) return KLSTM_OK;
+  if (!e->fold_scratch && fold_bf16x3_supported(d)) HIPCHK(hipMalloc(&e->fold_scratch, fold_bf16x3_scratch_bytes(d)));
+  const bool f3 = e->fold_scratch && fold_bf16x3_supported(d);
   HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, pack_x, e->stream, probe(e, "k_fold"),
-                     pack_x ? probe(e, "k_pack_foldx") : LaunchProbe()));
+                     pack_x ? probe(e, "k_pack_foldx") : LaunchProbe(), f3 ? e->fold_scratch : nullptr,
+                     f3 ? probe(e, "k_split3") : LaunchProbe()));
   if (pack_x) e->foldx_fresh = true;
   e->fold_dirty = false;
   return KLSTM_OK;
@@ -428,6 +432,7 @@ void klstm_destroy(klstm_engine *e) {
   if (e->flags_dev) (void)hipFree(e->flags_dev);
   for (auto *g : e->gran) if (g) (void)hipFree(g);
   if (e->pctrl) (void)hipFree(e->pctrl);
+  if (e->fold_scratch) (void)hipFree(e->fold_scratch);
   if (e->pstat_host) (void)hipHostFree(e->pstat_host);
   for (float *p : e->stage) if (p) (void)hipFree(p);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -982,6 +987,13 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
   if (!strcmp(key, "fold_direct")) {             // 0: the fold product on the generic 64x64-tile kernel (A-B; process-wide)
     HIPCHK(hipStreamSynchronize(e->stream));
     set_fold_direct(value);
+    e->fold_dirty = true;
+    return KLSTM_OK;
+  }
+  if (!strcmp(key, "fold_bf16x3")) {             // 0: the fold product on the fp32 MFMA (klstm_fold.hip) (A-B; process-wide)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    set_fold_bf16x3(value);
     e->fold_dirty = true;
     return KLSTM_OK;
   }

@@ -1,0 +1,313 @@
+// kaldi-lstm_amd/csrc/klstm_fold3.hip -- the fold product W_rm = W_gifo_r W_r_m on the bf16 matrix cores at fp32 accuracy.
+//
+// klstm_fold.hip runs the product on v_mfma_f32_16x16x4_f32 (256 FLOP/clk/CU): 2.6 GFLOP at 800/512 = 16.7 us at that peak,
+// 32 us measured.  The bf16 MFMA (v_mfma_f32_16x16x32_bf16) is 16x faster per instruction-clock, enough to pay for a
+// three-way split of both operands:
+//     a = a1 + a2 + a3,  a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)      (8 + 8 + 8 = 24 mantissa bits)
+//     a b ~= a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2)                        (terms below 2^-24 |a b| dropped)
+// six bf16 products accumulated in fp32, smallest first: every partial product of two bf16 numbers is EXACT in fp32, so
+// the only roundings are the fp32 accumulations (as in the fp32 MFMA) and the three dropped terms (~3 * 2^-24 relative to
+// |a||b|, the size of one fp32 rounding).  tests/test_engine_gpu.py holds the result to the tolerance of the fp32 kernel.
+//
+//   k_split3        both operands -> three bf16 planes each, once per Update (reads 8 MB, writes 12 MB)
+//   k_fold_bf16x3   128 x 96 tiles (2 x 2 waves of 64 x 48 = 4 x 3 MFMA blocks x 6 products), K in stages of 32:
+//                   one stage = 3 planes x (128 + 96) rows x 64 B = 42 KB, brought in by LDS-DMA
+//                   (global_load_lds_dwordx4: 16 rows x 64 B per wave instruction, no registers), double buffered, ONE
+//                   barrier per stage.  LDS rows are 64 B; the 16-byte k-group of row r sits in slot kg ^ ((-(r >> 2)) & 3)
+//                   (swizzle applied on the SOURCE side of the DMA, whose destination is lane-linear): the ds_read_b128 of
+//                   an MFMA operand (16 rows x 4 k-groups) touches every bank quad once per 16-lane group.
+//                   800/512: 25 x 9 = 225 workgroups, one round of the 256 CUs, 88 % of them busy.
+// Epilogue as in k_fold_direct: rows are read in gates-packed order (logical row 4*cell + gate <- stored row gate*C + cell)
+// and the tile goes straight into the two packed operands of the folded chain (pk1 / pk2, layouts in klstm_fold.hip).
+#include "klstm_kernels.h"
+#include "klstm_math.h"
+
+#include <hip/hip_ext.h>
+
+namespace klstm {
+
+#pragma clang fp contract(off)
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+struct Split3Args {
+  const float *src[2];
+  unsigned short *dst[2];
+  size_t plane[2];       // elements per plane
+  size_t n8[2];          // groups of 8 elements
+};
+
+__global__ __launch_bounds__(256) void k_split3(Split3Args a) {
+  const size_t tot = a.n8[0] + a.n8[1];
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < tot; g += (size_t)gridDim.x * blockDim.x) {
+    const int w = g >= a.n8[0];
+    const size_t i = (w ? g - a.n8[0] : g) * 8;
+    const float4 lo = *reinterpret_cast<const float4 *>(a.src[w] + i), hi = *reinterpret_cast<const float4 *>(a.src[w] + i + 4);
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    u16x8_t h1, h2, h3;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const unsigned short b1 = bf16_rne(v[e]);
+      const float r1 = v[e] - bf16_f32(b1);              // exact
+      const unsigned short b2 = bf16_rne(r1);
+      const float r2 = r1 - bf16_f32(b2);                // exact
+      h1[e] = b1; h2[e] = b2; h3[e] = bf16_rne(r2);
+    }
+    *reinterpret_cast<u16x8_t *>(a.dst[w] + i) = h1;
+    *reinterpret_cast<u16x8_t *>(a.dst[w] + a.plane[w] + i) = h2;
+    *reinterpret_cast<u16x8_t *>(a.dst[w] + 2 * a.plane[w] + i) = h3;
+  }
+}
+
+struct Fold3Args {
+  int C, R;
+  const unsigned short *a3;   // W_gifo_r split: [3][4C x R] bf16, rows in g,i,f,o blocks of C
+  const unsigned short *b3;   // W_r_m^T split:  [3][C x R]
+  size_t a_plane, b_plane;
+  float4 *pk1; int nch1;
+  float4 *pk2; int nch2;
+  int nbn, nwg;
+#ifdef KLSTM_FOLD3_TIMING
+  long long *dbg;             // per workgroup: shader clocks at entry / first operands / end of the K loop / exit (tools/fold3_probe.hip)
+#endif
+};
+
+// LW: four more waves (4..7, one per SIMD) issue all the LDS-DMA requests, the MFMA waves none.
+// NODMA: timing experiment (tools/fold3_probe.hip), stages past the first NBUF - 1 are not requested.
+template <int MI, int NI, int NBUF, bool NODMA = false, bool LW = false>
+__global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
+  constexpr int BM = 32 * MI, BN = 32 * NI, WM = 16 * MI, WN = 16 * NI;
+  constexpr int APL = BM * 64, BPL = BN * 64, STG = 3 * (APL + BPL);   // bytes: one plane tile of A / B, one stage
+  constexpr int NA = 3 * (BM / 16), NQ = NA + 3 * (BN / 16);           // DMA instructions of a stage (1 KB each)
+  constexpr int NJ = (NQ + 3) / 4;                                     // per wave
+  constexpr int FLD = WM + 4;                                          // epilogue transpose: floats per column
+  static_assert(4 * WN * FLD * 4 <= NBUF * STG, "epilogue transpose does not fit the staging buffers");
+  static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * NJ <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int C = a.C, R = a.R, nstage = R / 32;
+  // XCD-aware order (workgroup w lands on XCD w % 8): XCD x gets a contiguous m-major range -- the 9 column tiles of a row
+  // panel of A share one L2, all of B (2.4 MB) is in every L2
+  const int cpx = (a.nwg + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * cpx + (int)(blockIdx.x >> 3);
+  if (b >= a.nwg) return;
+  const int m0w = (b / a.nbn) * BM, n0w = (b % a.nbn) * BN;
+#ifdef KLSTM_FOLD3_TIMING
+  const long long t_c0 = clock64(), t_w0 = wall_clock64();
+#endif
+
+  // ---- DMA sources: instruction q of a stage fills LDS bytes [q KB, q KB + 1 KB) = 16 rows of one plane; lane l brings
+  // the 16 bytes of (row l >> 2, slot l & 3) = k-group slot ^ swizzle(row)
+  const char *src[NJ];
+  int qd[NJ];
+  {
+    const int r16 = lane >> 2, kgs = (lane & 3) ^ ((-(r16 >> 2)) & 3);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      int q = (wave & 3) + 4 * j;
+      if (q > NQ - 1) q = NQ - 1;                                       // (a duplicate of the last one: same bytes, same place)
+      qd[j] = q;
+      if (q < NA) {
+        const int p = q / (BM / 16), x = m0w + (q % (BM / 16)) * 16 + r16;       // logical row 4*cell + gate
+        const size_t row = (x >> 2) < C ? (size_t)(x & 3) * C + (x >> 2) : 0;
+        src[j] = reinterpret_cast<const char *>(a.a3 + p * a.a_plane + row * R + kgs * 8);
+      } else {
+        const int p = (q - NA) / (BN / 16), n = n0w + ((q - NA) % (BN / 16)) * 16 + r16;
+        src[j] = reinterpret_cast<const char *>(a.b3 + p * a.b_plane + (size_t)(n < C ? n : 0) * R + kgs * 8);
+      }
+    }
+  }
+  auto issue = [&](int s, int buf) {
+    char *db = smem + buf * STG;
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + (size_t)s * 64), (lptr_t)(db + qd[j] * 1024), 16, 0, 0);
+  };
+
+  if (LW && wave >= 4) {                                               // loader waves: same barrier sequence as the MFMA waves
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; s++)
+      if (s < nstage) issue(s, s);
+    int ib = NBUF - 1;
+    for (int k = 0; k < nstage; k++) {
+      const int ahead = nstage - 1 - k < NBUF - 2 ? nstage - 1 - k : NBUF - 2;
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NBUF >= 4 ? 2 * NJ : 0) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NBUF >= 3 ? NJ : 0) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (!NODMA && k + NBUF - 1 < nstage) issue(k + NBUF - 1, ib);
+      ib = ib + 1 == NBUF ? 0 : ib + 1;
+    }
+    __syncthreads();                                                   // (the MFMA waves' barrier below)
+  }
+  const bool loader = LW && wave >= 4;
+  const int tw = wave & 3, wr = tw >> 1, wc = tw & 1;                  // loader wave w + 4 shares the epilogue of MFMA wave w
+  const int sw = (kg ^ ((-(i16 >> 2)) & 3)) * 16;
+  const int aoff = (wr * WM + i16) * 64 + sw, boff = 3 * APL + (wc * WN + i16) * 64 + sw;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = (f32x4){0, 0, 0, 0};
+
+  // Stage k lives in buffer k % NBUF and is brought in NBUF - 1 stages ahead.  The operands of a stage are read from LDS
+  // into one of two register sets while the MFMAs of the stage before run on the other (one wave per SIMD: nobody else
+  // would cover the LDS reads -- measured without this, tools/fold3_probe.hip: 20.9 us with the refills removed, 2.7x the
+  // MFMA time).
+  // advance(k): this wave's requests for stage k have landed (those of later stages may still be in flight: vmcnt counts
+  // in order) and its LDS reads of stage k-1 are complete; the barrier makes both true for everyone, so buffer (k-1) % NBUF
+  // can take stage k + NBUF - 1; then the reads of stage k are issued.
+  int rb = 0, ib = NBUF - 1;
+  auto advance = [&](int k, bf16x8_t (&af)[3][MI], bf16x8_t (&bf)[3][NI]) {
+    const int ahead = nstage - 1 - k < NBUF - 2 ? nstage - 1 - k : NBUF - 2;
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NBUF >= 4 ? 2 * NJ : 0) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NBUF >= 3 ? NJ : 0) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!LW && !NODMA && k + NBUF - 1 < nstage) issue(k + NBUF - 1, ib);
+    const char *sb = smem + rb * STG;
+    rb = rb + 1 == NBUF ? 0 : rb + 1;
+    ib = ib + 1 == NBUF ? 0 : ib + 1;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) af[p][mi] = *reinterpret_cast<const bf16x8_t *>(sb + p * APL + aoff + mi * 1024);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) bf[p][ni] = *reinterpret_cast<const bf16x8_t *>(sb + p * BPL + boff + ni * 1024);
+    }
+  };
+  auto multiply = [&](const bf16x8_t (&af)[3][MI], const bf16x8_t (&bf)[3][NI]) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+#pragma unroll
+    for (int t = 0; t < 6; t++)
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[t]][mi], bf[PB[t]][ni], acc[mi][ni], 0, 0, 0);
+  };
+#ifdef KLSTM_FOLD3_TIMING
+  long long t_c1 = 0, t_c2 = 0;
+#endif
+  // ---- epilogue (k_fold_direct's, for WM rows): acc[mi][ni] of lane (i16, kg) = rows 16mi + 4kg + (0..3) at column 16ni + i16
+  const int m0 = m0w + wr * WM, n0 = n0w + wc * WN;
+  float *cs = reinterpret_cast<float *>(smem) + tw * (WN * FLD);
+  if (!loader) {
+    if (!LW) {
+#pragma unroll
+      for (int s = 0; s < NBUF - 1; s++)
+        if (s < nstage) issue(s, s);
+    }
+    bf16x8_t af0[3][MI], bf0[3][NI], af1[3][MI], bf1[3][NI];
+    advance(0, af0, bf0);
+#ifdef KLSTM_FOLD3_TIMING
+    t_c1 = clock64();
+#endif
+    for (int s = 0; s < nstage; s += 2) {
+      if (s + 1 < nstage) advance(s + 1, af1, bf1);
+      multiply(af0, bf0);
+      if (s + 1 < nstage) {
+        if (s + 2 < nstage) advance(s + 2, af0, bf0);
+        multiply(af1, bf1);
+      }
+    }
+#ifdef KLSTM_FOLD3_TIMING
+    t_c2 = clock64();
+#endif
+    __syncthreads();                                                   // the staging buffers become the transpose buffers
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++)
+        *reinterpret_cast<float4 *>(cs + (16 * ni + i16) * FLD + 16 * mi + 4 * kg) =
+            make_float4(acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w);
+  }
+  if (LW) __syncthreads();                                             // with loader waves the two packed operands are written by different waves
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int cell0 = m0 >> 2;
+  // gates operand: piece = (16-row tile tl, column quad nq, row i): 16 consecutive float4 (256 B) per (tl, nq)
+  if (!loader)
+#pragma unroll
+  for (int it = 0; it < MI * NI; it++) {
+    const int tl = it / NI, nq = (it % NI) * 4 + kg, i = i16;
+    const int nl = 4 * nq, n = n0 + nl, cell = cell0 + tl * 4 + (i >> 2);
+    const float *cp = cs + nl * FLD + tl * 16 + i;
+    const float4 v = make_float4(cp[0], cp[FLD], cp[2 * FLD], cp[3 * FLD]);
+    if (cell < C && n < C)
+      a.pk1[(((size_t)(cell >> 2) * a.nch1 + (n >> 5)) * 2 + ((n & 7) >> 2)) * 64 + ((n & 31) >> 3) * 16 + i] = v;
+  }
+  // d_m operand: piece = (column quad ct, gate, cell quad kq, cq = column % 4): 4 cells of one gate at one column
+  constexpr int NKQ = WM / 16, CTS = 4 / NKQ;                         // cell quads of the wave's rows; column quads per pass
+  if (!LW || loader)
+#pragma unroll
+  for (int it = 0; it < WN / 4 / CTS; it++) {
+    const int cq = lane & 3, kq = (lane >> 2) % NKQ, gate = (lane / (4 * NKQ)) & 3, ct = it * CTS + lane / (16 * NKQ);
+    const int c = n0 + ct * 4 + cq, cell = cell0 + kq * 4;
+    const float *cp = cs + (ct * 4 + cq) * FLD + kq * 16 + gate;
+    const float4 v = make_float4(cp[0], cp[4], cp[8], cp[12]);
+    const int k = gate * C + cell;
+    if (c < C && cell < C)
+      a.pk2[(((size_t)(c >> 2) * a.nch2 + (k >> 7)) * 2 + ((k >> 6) & 1)) * 64 + ((k & 63) >> 2) * 4 + cq] = v;
+  }
+#ifdef KLSTM_FOLD3_TIMING
+  if (tid == 0) {
+    long long *q = a.dbg + (size_t)blockIdx.x * 8;
+    q[0] = t_c1 - t_c0; q[1] = t_c2 - t_c1; q[2] = clock64() - t_c2; q[3] = wall_clock64() - t_w0; q[4] = t_w0;
+  }
+#endif
+}
+
+#ifdef KLSTM_FOLD3_TIMING
+static long long *g_fold3_dbg = nullptr;
+#endif
+static int g_fold_bf16x3 = 1;
+void set_fold_bf16x3(int v) { g_fold_bf16x3 = v; }
+bool fold_bf16x3_supported(const Dims &d) { return g_fold_bf16x3 != 0 && d.C % 4 == 0 && d.R % 32 == 0; }
+size_t fold_bf16x3_scratch_bytes(const Dims &d) { return (size_t)3 * 5 * d.C * d.R * sizeof(unsigned short); }
+
+hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
+                              int nch2, hipStream_t st, LaunchProbe pr_split, LaunchProbe pr) {
+  constexpr int MI = 4, NI = 3, NBUF = 3;
+  unsigned short *a3 = static_cast<unsigned short *>(scratch);
+  const size_t apl = (size_t)4 * d.C * d.R, bpl = (size_t)d.C * d.R;
+  unsigned short *b3 = a3 + 3 * apl;
+  Split3Args s;
+  s.src[0] = wr; s.src[1] = wmT; s.dst[0] = a3; s.dst[1] = b3; s.plane[0] = apl; s.plane[1] = bpl;
+  s.n8[0] = apl / 8; s.n8[1] = bpl / 8;
+  const unsigned sgrid = (unsigned)std::min<size_t>((s.n8[0] + s.n8[1] + 255) / 256, 2048);
+  if (pr_split.start) hipExtLaunchKernelGGL(k_split3, dim3(sgrid), dim3(256), 0, st, pr_split.start, pr_split.stop, 0, s);
+  else hipLaunchKernelGGL(k_split3, dim3(sgrid), dim3(256), 0, st, s);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+
+  Fold3Args a;
+#ifdef KLSTM_FOLD3_TIMING
+  a.dbg = g_fold3_dbg;
+#endif
+  a.C = d.C; a.R = d.R; a.a3 = a3; a.b3 = b3; a.a_plane = apl; a.b_plane = bpl;
+  a.pk1 = reinterpret_cast<float4 *>(pk_fold[0]); a.nch1 = nch1;
+  a.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); a.nch2 = nch2;
+  a.nbn = (d.C + 32 * NI - 1) / (32 * NI);
+  a.nwg = ((4 * d.C + 32 * MI - 1) / (32 * MI)) * a.nbn;
+  constexpr int shm = NBUF * 3 * (32 * MI + 32 * NI) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_bf16x3<MI, NI, NBUF, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    if (err != hipSuccess) return err;
+    attr_set = true;
+  }
+  const dim3 grid((a.nwg + 7) / 8 * 8), block(512);
+  if (pr.start) hipExtLaunchKernelGGL((k_fold_bf16x3<MI, NI, NBUF, false, true>), grid, block, shm, st, pr.start, pr.stop, 0, a);
+  else hipLaunchKernelGGL((k_fold_bf16x3<MI, NI, NBUF, false, true>), grid, block, shm, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace klstm

@@ -66,8 +66,15 @@ void set_direct_nt_shape(int ni, int waves);
 bool direct_nt_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb);
 hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
                             const float *bias, hipStream_t st);
+// the same product as six bf16 MFMA products of three-way split operands (fp32 accuracy; klstm_fold3.hip); scratch holds the planes
+bool fold_bf16x3_supported(const Dims &d);
+void set_fold_bf16x3(int v);
+size_t fold_bf16x3_scratch_bytes(const Dims &d);
+hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
+                              int nch2, hipStream_t st, LaunchProbe pr_split = {}, LaunchProbe pr = {});
 hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
-                       hipStream_t st, LaunchProbe pr = {}, LaunchProbe pr2 = {});
+                       hipStream_t st, LaunchProbe pr = {}, LaunchProbe pr2 = {}, void *scratch3 = nullptr, LaunchProbe pr3 = {});
+                       // scratch3 (fold_bf16x3_scratch_bytes) selects the bf16x3 kernel when it supports the shape; pr3 = its split pass
                        // pk_fold zero-filled once by the caller; pack_x = false: launch_pack(.., foldx) already wrote the W_x chunks
 hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_stride, float *ws, hipStream_t st,
                          LaunchProbe pr = {}, LaunchProbe pr2 = {});   // ws: split-K workspace (gemm_splitk_plan(T*S, R, C) slices)

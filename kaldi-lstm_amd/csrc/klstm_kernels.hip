@@ -2830,7 +2830,7 @@ __global__ __launch_bounds__(256) void k_pack_foldx(const float *__restrict__ wx
 // step kernels (NT form on the transposed copy W_r_m^T [C x R]: both operands k-contiguous); then the x chunks.
 // pk_fold[0/1] must have been zero-filled once (padding rows / k tails are never written).
 hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
-                       hipStream_t st, LaunchProbe pr, LaunchProbe pr2) {
+                       hipStream_t st, LaunchProbe pr, LaunchProbe pr2, void *scratch3, LaunchProbe pr3) {
   const long o_wr = (long)4 * d.C * d.I;
   GemmJob g = make_job(false, true, 4 * d.C, d.C, d.R, param_blob + o_wr, d.R, wmT, d.R, 0.f, nullptr, d.C, nullptr);
   g.gperm = d.C;
@@ -2838,6 +2838,8 @@ hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT,
   g.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); g.nch2 = cdiv(4 * d.C, KCH4);
   const dim3 grid(cdiv(cdiv(d.C, GT) * cdiv(4 * d.C, GT), 8) * 8), block(256);
   auto first = [&]() -> hipError_t {
+    if (scratch3 && fold_bf16x3_supported(d))
+      return launch_fold_bf16x3(d, param_blob + o_wr, wmT, scratch3, pk_fold, g.nch1, g.nch2, st, pr3, pr);       // klstm_fold3.hip
     if (fold_direct_supported(d)) return launch_fold_direct(d, param_blob + o_wr, wmT, pk_fold, g.nch1, g.nch2, st, pr);   // klstm_fold.hip
     KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
   };
