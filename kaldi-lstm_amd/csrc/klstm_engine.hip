@@ -99,6 +99,7 @@ struct klstm_engine {
   unsigned *pctrl = nullptr;    // 2 x 4 words: {epoch, finished workgroups, status, pad} per direction
   unsigned *pstat_host = nullptr;   // pinned, device-mapped word the persistent kernels set when they give up (polled without a sync)
   void *fold_scratch = nullptr;             // bf16 planes of the two fold operands (klstm_fold3.hip)
+  bool planes_fresh = false;                // ... and they were written from the current parameters (by the fused Update)
   float *pk_fold[2] = {nullptr, nullptr};   // packed [W_rm | W_x] (gates order) and W_rm^T (4-row geometry)
   float *Pm = nullptr;     // out_diff * W_r_m for all frames [(T_alloc) S x C]
   float *ws = nullptr;     // split-K workspace of the batched d_r / in_diff products
@@ -227,6 +228,7 @@ static klstm_status repack(klstm_engine *e) {
                               probe(e, "k_update_repack")));
   if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream, probe(e, "k_pack")));
   e->fold_dirty = true;
+  e->planes_fresh = false;
   e->foldx_fresh = false;
   e->pk_stale = 0;
   return KLSTM_OK;
@@ -296,6 +298,7 @@ static klstm_status check_persist(klstm_engine *e) {
   const unsigned z[16] = {w[0], 0, 0, 0, w[4], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   HIPCHK(hipMemcpy(e->pctrl, z, sizeof(z), hipMemcpyHostToDevice));
   e->use_persist = 0;
+  e->planes_fresh = false;
   HIPCHK(hipStreamSynchronize(e->stream));
   drop_graphs(e);
   return fail(KLSTM_ERR_HIP, "persistent recurrence chain timed out (forward status %x, backward status %x): its workgroups were not "
@@ -338,7 +341,7 @@ static klstm_status ensure_fold(klstm_engine *e, bool need_x) {
   const bool f3 = e->fold_scratch && fold_bf16x3_supported(d);
   HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, pack_x, e->stream, probe(e, "k_fold"),
                      pack_x ? probe(e, "k_pack_foldx") : LaunchProbe(), f3 ? e->fold_scratch : nullptr,
-                     f3 ? probe(e, "k_split3") : LaunchProbe()));
+                     f3 ? probe(e, "k_split3") : LaunchProbe(), f3 && e->planes_fresh));
   if (pack_x) e->foldx_fresh = true;
   e->fold_dirty = false;
   return KLSTM_OK;
@@ -841,10 +844,13 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
     // KLSTM_BPTT_FUSE_UPDATE: gradient products, momentum, Update and the transposed copies in one pass
     e->grads_pending = false;
     const Dims dg{e->I, e->C, e->R, e->S, e->gp_T};
-    const GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
+    GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
+    e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d);
+    if (e->planes_fresh) fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
     HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
                         probe(e, "k_grads_update"), false, &u, e->pctrl));
   } else {
+    e->planes_fresh = false;
     const float *fold_grad = e->mmt_pending ? e->grads : nullptr;
     e->mmt_pending = false;
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,

@@ -33,12 +33,6 @@ typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-__device__ __forceinline__ unsigned short bf16_rne(float x) {
-  const unsigned u = __float_as_uint(x);
-  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-
 struct Split3Args {
   const float *src[2];
   unsigned short *dst[2];
@@ -56,11 +50,9 @@ __global__ __launch_bounds__(256) void k_split3(Split3Args a) {
     u16x8_t h1, h2, h3;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      const unsigned short b1 = bf16_rne(v[e]);
-      const float r1 = v[e] - bf16_f32(b1);              // exact
-      const unsigned short b2 = bf16_rne(r1);
-      const float r2 = r1 - bf16_f32(b2);                // exact
-      h1[e] = b1; h2[e] = b2; h3[e] = bf16_rne(r2);
+      unsigned short b1, b2, b3;
+      bf16_split3(v[e], b1, b2, b3);
+      h1[e] = b1; h2[e] = b2; h3[e] = b3;
     }
     *reinterpret_cast<u16x8_t *>(a.dst[w] + i) = h1;
     *reinterpret_cast<u16x8_t *>(a.dst[w] + a.plane[w] + i) = h2;
@@ -273,8 +265,14 @@ void set_fold_bf16x3(int v) { g_fold_bf16x3 = v; }
 bool fold_bf16x3_supported(const Dims &d) { return g_fold_bf16x3 != 0 && d.C % 4 == 0 && d.R % 32 == 0; }
 size_t fold_bf16x3_scratch_bytes(const Dims &d) { return (size_t)3 * 5 * d.C * d.R * sizeof(unsigned short); }
 
+void fold_bf16x3_planes(const Dims &d, void *scratch, unsigned short **a3, long *a_plane, unsigned short **b3, long *b_plane) {
+  *a3 = static_cast<unsigned short *>(scratch);
+  *a_plane = (long)4 * d.C * d.R; *b_plane = (long)d.C * d.R;
+  *b3 = *a3 + 3 * *a_plane;
+}
+
 hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
-                              int nch2, hipStream_t st, LaunchProbe pr_split, LaunchProbe pr) {
+                              int nch2, hipStream_t st, LaunchProbe pr_split, LaunchProbe pr, bool planes_fresh) {
   constexpr int MI = 4, NI = 3, NBUF = 3;
   unsigned short *a3 = static_cast<unsigned short *>(scratch);
   const size_t apl = (size_t)4 * d.C * d.R, bpl = (size_t)d.C * d.R;
@@ -283,8 +281,10 @@ hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, 
   s.src[0] = wr; s.src[1] = wmT; s.dst[0] = a3; s.dst[1] = b3; s.plane[0] = apl; s.plane[1] = bpl;
   s.n8[0] = apl / 8; s.n8[1] = bpl / 8;
   const unsigned sgrid = (unsigned)std::min<size_t>((s.n8[0] + s.n8[1] + 255) / 256, 2048);
-  if (pr_split.start) hipExtLaunchKernelGGL(k_split3, dim3(sgrid), dim3(256), 0, st, pr_split.start, pr_split.stop, 0, s);
-  else hipLaunchKernelGGL(k_split3, dim3(sgrid), dim3(256), 0, st, s);
+  if (!planes_fresh) {
+    if (pr_split.start) hipExtLaunchKernelGGL(k_split3, dim3(sgrid), dim3(256), 0, st, pr_split.start, pr_split.stop, 0, s);
+    else hipLaunchKernelGGL(k_split3, dim3(sgrid), dim3(256), 0, st, s);
+  }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
 

@@ -71,9 +71,12 @@ bool fold_bf16x3_supported(const Dims &d);
 void set_fold_bf16x3(int v);
 size_t fold_bf16x3_scratch_bytes(const Dims &d);
 hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
-                              int nch2, hipStream_t st, LaunchProbe pr_split = {}, LaunchProbe pr = {});
+                              int nch2, hipStream_t st, LaunchProbe pr_split = {}, LaunchProbe pr = {}, bool planes_fresh = false);
+                              // planes_fresh: the split pass is skipped (the fused Update wrote the planes: GradsUpdate::a3 / b3)
+void fold_bf16x3_planes(const Dims &d, void *scratch, unsigned short **a3, long *a_plane, unsigned short **b3, long *b_plane);
 hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
-                       hipStream_t st, LaunchProbe pr = {}, LaunchProbe pr2 = {}, void *scratch3 = nullptr, LaunchProbe pr3 = {});
+                       hipStream_t st, LaunchProbe pr = {}, LaunchProbe pr2 = {}, void *scratch3 = nullptr, LaunchProbe pr3 = {},
+                       bool planes_fresh = false);
                        // scratch3 (fold_bf16x3_scratch_bytes) selects the bf16x3 kernel when it supports the shape; pr3 = its split pass
                        // pk_fold zero-filled once by the caller; pack_x = false: launch_pack(.., foldx) already wrote the W_x chunks
 hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_stride, float *ws, hipStream_t st,
@@ -120,7 +123,11 @@ hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, con
 // upd: fold the Update (:504-512) into the same pass -- dst_blob must then be the momentum blob: dst = beta*dst + grad,
 // clipped if clip > 0, params -= lr*dst, and the three transposed copies are written from the updated parameters (the C % 4,
 // R % 4 row quads of a tile: shapes with C, R multiples of 4).  fp32 tiles only (launch fails for the bf16 tile path).
-struct GradsUpdate { float *params; float lr, clip; float *wrT, *wmT, *wxT; };
+struct GradsUpdate {
+  float *params; float lr, clip; float *wrT, *wmT, *wxT;
+  // optional: the bf16 planes of the fold operands (fold_bf16x3_planes) are written from the updated W_gifo_r / W_r_m too
+  unsigned short *a3 = nullptr, *b3 = nullptr; long a_plane = 0, b_plane = 0;
+};
 bool grads_bf16_tiles(const Dims &d, bool bf16);      // would launch_grads take the bf16 tile path?
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,

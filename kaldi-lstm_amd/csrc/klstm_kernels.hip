@@ -1505,6 +1505,7 @@ struct GemmJob {
   // gradient product with the Update folded in (launch_grads with a GradsUpdate): Cm is the momentum buffer,
   // Cm = beta*Cm + A*B (:468-487), clipped if clip > 0, then P -= lr*Cm (:504-512); Ct then receives the UPDATED P
   float *P; float lr, clip;
+  unsigned short *s3; long s3pl; int s3t;   // three bf16 planes of the UPDATED P (s3t = 0: P's layout, ld = ldc; 1: Ct's layout, ld = ldct)
   int coal;               // 1: Cm = beta*Cm + A*B through the same coalesced 16-byte epilogue without P (N, ldc % 4 == 0, aligned, no bias)
 };
 
@@ -1711,6 +1712,10 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
           pv.x = pv.x + (-g.lr) * c[0]; pv.y = pv.y + (-g.lr) * c[1]; pv.z = pv.z + (-g.lr) * c[2]; pv.w = pv.w + (-g.lr) * c[3];
           *pp = pv;
           *reinterpret_cast<float4 *>(cs) = pv;
+          if (g.s3 && !g.s3t) {
+            const float v4[4] = {pv.x, pv.y, pv.z, pv.w};
+            bf16_split3_store4(v4, g.s3 + (size_t)m * g.ldc + n, g.s3pl);
+          }
         }
       }
     }
@@ -1722,7 +1727,9 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
       const int n = n0 + nl, m = m0 + mq;
       if (n < g.N && m + 4 <= g.M) {
         const float *cs = Cs + mq * GLX + nl;
-        *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(cs[0], cs[GLX], cs[2 * GLX], cs[3 * GLX]);
+        const float v4[4] = {cs[0], cs[GLX], cs[2 * GLX], cs[3 * GLX]};
+        *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        if (g.s3 && g.s3t) bf16_split3_store4(v4, g.s3 + (size_t)n * g.ldct + m, g.s3pl);
       }
     }
     return;
@@ -2830,7 +2837,7 @@ __global__ __launch_bounds__(256) void k_pack_foldx(const float *__restrict__ wx
 // step kernels (NT form on the transposed copy W_r_m^T [C x R]: both operands k-contiguous); then the x chunks.
 // pk_fold[0/1] must have been zero-filled once (padding rows / k tails are never written).
 hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
-                       hipStream_t st, LaunchProbe pr, LaunchProbe pr2, void *scratch3, LaunchProbe pr3) {
+                       hipStream_t st, LaunchProbe pr, LaunchProbe pr2, void *scratch3, LaunchProbe pr3, bool planes_fresh) {
   const long o_wr = (long)4 * d.C * d.I;
   GemmJob g = make_job(false, true, 4 * d.C, d.C, d.R, param_blob + o_wr, d.R, wmT, d.R, 0.f, nullptr, d.C, nullptr);
   g.gperm = d.C;
@@ -2839,7 +2846,7 @@ hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT,
   const dim3 grid(cdiv(cdiv(d.C, GT) * cdiv(4 * d.C, GT), 8) * 8), block(256);
   auto first = [&]() -> hipError_t {
     if (scratch3 && fold_bf16x3_supported(d))
-      return launch_fold_bf16x3(d, param_blob + o_wr, wmT, scratch3, pk_fold, g.nch1, g.nch2, st, pr3, pr);       // klstm_fold3.hip
+      return launch_fold_bf16x3(d, param_blob + o_wr, wmT, scratch3, pk_fold, g.nch1, g.nch2, st, pr3, pr, planes_fresh);   // klstm_fold3.hip
     if (fold_direct_supported(d)) return launch_fold_direct(d, param_blob + o_wr, wmT, pk_fold, g.nch1, g.nch2, st, pr);   // klstm_fold.hip
     KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
   };
@@ -2905,7 +2912,7 @@ static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const flo
   g.Cm = Cm; g.ldc = ldc; g.bias = bias;
   g.Ct = nullptr; g.ldct = 0; g.C2 = nullptr; g.ldc2 = 0; g.C3 = nullptr; g.tail0 = 0;
   g.gperm = 0; g.pk1 = nullptr; g.nch1 = 0; g.pk2 = nullptr; g.nch2 = 0;
-  g.P = nullptr; g.lr = 0.f; g.clip = 0.f; g.coal = 0;
+  g.P = nullptr; g.lr = 0.f; g.clip = 0.f; g.coal = 0; g.s3 = nullptr; g.s3pl = 0; g.s3t = 0;
   // branch-free 8-wide fetches need aligned rows and a contiguous extent that is a multiple of 8
   g.vecA = aligned16(A) && lda % 4 == 0 && (transA ? M : K) % 8 == 0;
   g.vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K : N) % 8 == 0;
@@ -3030,6 +3037,8 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
     a.wx.Ct = upd->wxT; a.wx.ldct = 4 * C;           // [I x 4C]
     a.wr.Ct = upd->wrT; a.wr.ldct = 4 * C;           // [R x 4C]
     a.wm.Ct = upd->wmT; a.wm.ldct = R;               // [C x R]
+    if (upd->a3) { a.wr.s3 = upd->a3; a.wr.s3pl = upd->a_plane; a.wr.s3t = 0; }
+    if (upd->b3) { a.wm.s3 = upd->b3; a.wm.s3pl = upd->b_plane; a.wm.s3t = 1; }
     a.p_bias = pb + o_b; a.p_pi = pb + o_pi; a.p_pf = pb + o_pf; a.p_po = pb + o_po;
   }
   if (!upd && aligned16(dst) && C % 4 == 0 && R % 4 == 0 && I % 4 == 0) a.wx.coal = a.wr.coal = a.wm.coal = 1;

@@ -65,4 +65,26 @@ __device__ __forceinline__ float k_diff_tanh_fma(float d, float y) {
   return __builtin_fmaf(-d, t, d);
 }
 
+// Three-way bf16 split of an fp32 number (klstm_fold3.hip): x = h1 + h2 + h3 up to 2^-24 |x|, both residuals exact.
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ void bf16_split3(float x, unsigned short &h1, unsigned short &h2, unsigned short &h3) {
+  h1 = bf16_rne(x);
+  const float r1 = x - bf16_f32(h1);
+  h2 = bf16_rne(r1);
+  h3 = bf16_rne(r1 - bf16_f32(h2));
+}
+// four consecutive elements -> 8 bytes into each of the three planes
+__device__ __forceinline__ void bf16_split3_store4(const float (&v)[4], unsigned short *dst, long plane) {
+  unsigned short h[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) bf16_split3(v[e], h[0][e], h[1][e], h[2][e]);
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    *reinterpret_cast<uint2 *>(dst + q * plane) = make_uint2(h[q][0] | ((unsigned)h[q][1] << 16), h[q][2] | ((unsigned)h[q][3] << 16));
+}
+
 }  // namespace klstm
