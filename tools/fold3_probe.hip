@@ -71,7 +71,8 @@ int main() {
   VAR(4, 3, 3, false);
   VAR(4, 3, 3, true);
   VARL(4, 3, 3, false, true);
-  VARL(4, 3, 2, false, true);
-  VARL(4, 4, 3, false, true);
+  VARL(2, 5, 3, false, true);
+  VARL(2, 5, 2, false, true);
+  VARL(3, 3, 3, false, true);
   return 0;
 }

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Profiling recipe behind profiles/rNN_* (run on the GPU box: gpurun -- 'bash tools/profile.sh r02').
+# Profiling recipe behind profiles/rNN_* (run on the GPU box: gpurun -- 'bash tools/profile.sh r03').
 # Four separate passes of the SAME command (MI355X_MICROARCH.md HBM/rocprofv3 section: counters never share a run
 # with tracing), every pass under `timeout` (a rocprofv3 run that never exits would burn the box's budget):
 #   1. --kernel-trace --stats                                   -> per-kernel average durations
 #   2. --pmc FETCH_SIZE                                         -> HBM/MALL read traffic per launch
 #   3. --pmc WRITE_SIZE                                         -> write traffic per launch
 #   4. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE  -> MFMA pipe utilisation per kernel
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift
 EXTRA="$@"
 OUT=gpurun_out/prof_$TAG
