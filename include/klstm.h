@@ -68,7 +68,7 @@ typedef enum {
 
 /* Message of the calling thread's most recent failing call ("" if none). */
 const char *klstm_last_error(void);
-/* Library / kernel-arch identification string, e.g. "klstm 0.2 gfx950 (...)". */
+/* Library / kernel-arch identification string, e.g. "klstm 0.3 gfx950 (...)". */
 const char *klstm_version(void);
 
 /* Replaces: LstmProjectedStreams(input_dim, output_dim) + <CellDim>/<NumStream> of
@@ -267,6 +267,9 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  "persist_spin_us" (bound of a single in-kernel wait, default 50 000), "persist_ncu" (pretend CU count),
  *                  "persist_test_stall_fwd" / "persist_test_stall_bwd" (workgroup 0 withholds its publish of that step:
  *                  forces the give-up path)
+ *   "fold_bf16x3"  0/1  the fold product W_rm = W_gifo_r * W_r_m as six bf16 MFMA products of three-way split operands
+ *                  (fp32 accuracy: every partial product exact, fp32 accumulation, dropped terms below 2^-24; DESIGN.md 3d;
+ *                  default 1) or on the fp32 MFMA (0; process-wide, A-B experiments).  "fold_direct" 0: the generic tile kernel
  *   "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.

@@ -43,7 +43,7 @@ struct ErrLine {
 
 inline void WriteToken(std::ostream &os, bool /*binary*/, const char *token) {
   os << token << " ";
-  if (os.fail()) KLSTM_ERR("WriteToken: stream failure");
+  if (os.fail()) KLSTM_ERR("model output stream failed while writing token '" << token << "'");
 }
 inline void WriteToken(std::ostream &os, bool binary, const std::string &t) { WriteToken(os, binary, t.c_str()); }
 
@@ -54,14 +54,14 @@ inline int Peek(std::istream &is, bool binary) {
 inline void ReadToken(std::istream &is, bool binary, std::string *str) {
   if (!binary) is >> std::ws;
   is >> *str;
-  if (is.fail()) KLSTM_ERR("ReadToken, failed to read token at file position " << is.tellg());
-  if (!isspace(is.peek())) KLSTM_ERR("ReadToken, expected space after token, saw instead " << (char)is.peek());
-  is.get();  // consume the space
+  if (is.fail()) KLSTM_ERR("model file: no token where one was expected (offset " << is.tellg() << ")");
+  if (!isspace(is.peek())) KLSTM_ERR("model file: token '" << *str << "' is not followed by white space (next byte '" << (char)is.peek() << "')");
+  is.get();  // the separator
 }
 inline void ExpectToken(std::istream &is, bool binary, const char *token) {
   std::string str;
   ReadToken(is, binary, &str);
-  if (str != token) KLSTM_ERR("Expected token \"" << token << "\", got instead \"" << str << "\".");
+  if (str != token) KLSTM_ERR("model file: found token '" << str << "' where '" << token << "' belongs");
 }
 
 template <class T> inline void WriteBasicType(std::ostream &os, bool binary, T t) {
@@ -72,21 +72,21 @@ template <class T> inline void WriteBasicType(std::ostream &os, bool binary, T t
   } else {
     os << t << " ";
   }
-  if (os.fail()) KLSTM_ERR("WriteBasicType: stream failure");
+  if (os.fail()) KLSTM_ERR("model output stream failed while writing a scalar");
 }
 template <class T> inline void ReadBasicType(std::istream &is, bool binary, T *t) {
   if (binary) {
     const int len_c_in = is.get();
-    if (len_c_in == -1) KLSTM_ERR("ReadBasicType: encountered end of stream.");
+    if (len_c_in == -1) KLSTM_ERR("model file ends inside a binary scalar");
     const char len_c = (char)len_c_in;
     if (len_c != (char)sizeof(*t))
-      KLSTM_ERR("ReadBasicType: did not get expected integer type, " << (int)len_c << " vs. " << (int)sizeof(*t)
-                << ".  You can change this code to successfully read it later, if needed.");
+      KLSTM_ERR("model file: binary scalar is stored with " << (int)len_c << " bytes, this field has " << (int)sizeof(*t)
+                << " (a model written with another integer / BaseFloat width?)");
     is.read(reinterpret_cast<char *>(t), sizeof(*t));
   } else {
     is >> *t;
   }
-  if (is.fail()) KLSTM_ERR("Read failure in ReadBasicType, file position is " << is.tellg());
+  if (is.fail()) KLSTM_ERR("model file: unreadable scalar near offset " << is.tellg());
 }
 
 // ---- matrices and vectors ------------------------------------------------------------------------

@@ -350,7 +350,7 @@ static klstm_status ensure_fold(klstm_engine *e, bool need_x) {
 extern "C" {
 
 const char *klstm_last_error(void) { return g_err.c_str(); }
-const char *klstm_version(void) { return "klstm 0.2 gfx950 (f32 MFMA, persistent weights-resident chain)"; }
+const char *klstm_version(void) { return "klstm 0.3 gfx950 (f32 MFMA, persistent weights-resident chain, bf16x3 fold product)"; }
 
 klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_stream, int device,
                           void *hip_stream, klstm_engine **out) {
@@ -987,11 +987,14 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     return KLSTM_OK;
   }
   if (!strcmp(key, "direct_nt_shape")) {         // value = 10*NI + waves (A-B; process-wide)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
     set_direct_nt_shape(value / 10, value % 10);
     return KLSTM_OK;
   }
   if (!strcmp(key, "fold_direct")) {             // 0: the fold product on the generic 64x64-tile kernel (A-B; process-wide)
     HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
     set_fold_direct(value);
     e->fold_dirty = true;
     return KLSTM_OK;

@@ -103,7 +103,7 @@ def test_truncated_and_malformed_models_raise(tmp_path):
     assert r.returncode == 3 and "cannot read matrix" in r.stdout and "ended inside the payload" in r.stdout
     (tmp_path / "bad.nnet").write_bytes(ref.replace(b"<CellDim>", b"<CellDum>"))
     r = run("dump_params", tmp_path / "bad.nnet", tmp_path / "p.raw", ok=False)
-    assert r.returncode == 3 and 'Expected token "<CellDim>"' in r.stdout
+    assert r.returncode == 3 and "found token" in r.stdout and "'<CellDim>' belongs" in r.stdout
     wrong = kaldi_fmt.binary_model(make_params(I, C + 1, R, seed=6), I, C + 1, R, S).replace(
         b"<CellDim> \x04" + bytes([C + 1, 0, 0, 0]), b"<CellDim> \x04" + bytes([C, 0, 0, 0]))
     (tmp_path / "dims.nnet").write_bytes(wrong)

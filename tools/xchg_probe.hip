@@ -144,9 +144,108 @@ static void run(int G, int N, int steps, int sweep_waves, int extra_work, hipStr
   CK(hipFree(gran)); CK(hipFree(tmo)); CK(hipFree(fin)); CK(hipFree(cyc));
 }
 
+
+// 16-byte granules {tag, 3 payload words}: the transport of a bf16 chain (6 bf16 operands behind one 32-bit tag).  NG granules
+// in all, one 16-byte sc1 store each, swept with 16-byte sc1 loads by `sweep_waves` waves.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_xchg16(u32x4 *gran, int NG, int steps, int sweep_waves, unsigned *tmo, unsigned *final_vals,
+                                               unsigned long long *cycles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds[];   // 3*NG payload words + NT/64 partial sums
+  const int tid = threadIdx.x, G = gridDim.x, b = blockIdx.x;
+  const int own0 = (int)((long)NG * b / G), own1 = (int)((long)NG * (b + 1) / G);
+  const int nsweep = sweep_waves * 64, NW = 3 * NG;
+  unsigned sum = 0;
+  if (tid == 0) lds[NW + 32] = 0u;
+  __syncthreads();
+  const long long t_start = wall_clock64();
+  for (int e = 1; e <= steps; e++) {
+    u32x4 *slot = gran + (size_t)(e & 1) * NG;
+    for (int i = own0 + tid; i < own1; i += NT) {
+      u32x4 v = {(unsigned)e, mix(e, 3 * i, sum), mix(e, 3 * i + 1, sum), mix(e, 3 * i + 2, sum)};
+      const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void *)slot, 0, NG * 16, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ws, i * 16, 0, 16);   // one 16-byte sc1 store
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)slot, 0, NG * 16, 0x00020000);
+    if (tid < nsweep) {
+      bool done = false;
+      for (unsigned spins = 0; !done; spins++) {
+        bool ok = true;
+        constexpr int MAXL = 8;
+        u32x4 q[MAXL];
+#pragma unroll
+        for (int l = 0; l < MAXL; l++) {
+          const int i = tid + l * nsweep;
+          if (i < NG) q[l] = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 16);
+        }
+#pragma unroll
+        for (int l = 0; l < MAXL; l++) {
+          const int i = tid + l * nsweep;
+          if (i < NG) { ok &= q[l].x == (unsigned)e; lds[3 * i] = q[l].y; lds[3 * i + 1] = q[l].z; lds[3 * i + 2] = q[l].w; }
+        }
+        done = __all(ok);
+        if (!done && (spins & 63) == 63 && wall_clock64() - t_start > 100000000LL / 20) {
+          if ((tid & 63) == 0) { atomicExch(tmo, 0x80000000u | (unsigned)e); lds[NW + 32] = 1u; }
+          done = true;
+        }
+      }
+    }
+    __syncthreads();
+    if (lds[NW + 32]) return;
+    unsigned part = 0;
+    for (int i = tid; i < NW; i += NT) part += lds[i];
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+    __syncthreads();
+    if ((tid & 63) == 0) lds[NW + (tid >> 6)] = part;
+    __syncthreads();
+    sum = 0;
+    for (int w = 0; w < NT / 64; w++) sum += lds[NW + w];
+    __syncthreads();
+  }
+  if (tid == 0) { final_vals[b] = sum; cycles[b] = (unsigned long long)(wall_clock64() - t_start); }
+}
+
+template <int NT>
+static void run16(int G, int NG, int steps, int sweep_waves, hipStream_t st) {
+  u32x4 *gran; unsigned long long *cyc; unsigned *tmo, *fin;
+  CK(hipMalloc(&gran, (size_t)2 * NG * 16)); CK(hipMalloc(&tmo, 4)); CK(hipMalloc(&fin, G * 4)); CK(hipMalloc(&cyc, G * 8));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e9f; bool ok = true; unsigned tm = 0;
+  const size_t shm = (size_t)(3 * NG + 40) * 4;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xchg16<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  for (int rep = 0; rep < 4; rep++) {
+    CK(hipMemsetAsync(gran, 0, (size_t)2 * NG * 16, st)); CK(hipMemsetAsync(tmo, 0, 4, st));
+    CK(hipEventRecord(e0, st));
+    hipLaunchKernelGGL((k_xchg16<NT>), dim3(G), dim3(NT), shm, st, gran, NG, steps, sweep_waves, tmo, fin, cyc);
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep > 0 && ms < best) best = ms;
+    CK(hipMemcpy(&tm, tmo, 4, hipMemcpyDeviceToHost));
+    if (tm) { ok = false; break; }
+    std::vector<unsigned> f(G); CK(hipMemcpy(f.data(), fin, G * 4, hipMemcpyDeviceToHost));
+    unsigned sum = 0;
+    for (int e = 1; e <= steps; e++) { unsigned s2 = 0; for (int i = 0; i < 3 * NG; i++) s2 += mix(e, i, sum); sum = s2; }
+    for (int b = 0; b < G; b++) if (f[b] != sum) ok = false;
+  }
+  printf("16-byte granules G=%3d NT=%4d NG=%5d (%.1f KB, %d bf16 values) sweepwaves=%2d : %.3f us/step (event, %d steps)  %s%s\n",
+         G, NT, NG, NG * 16 / 1024.0, 6 * NG, sweep_waves, best * 1e3f / steps, steps, ok ? "OK" : "MISMATCH", tm ? " TIMEOUT" : "");
+  fflush(stdout);
+  CK(hipFree(gran)); CK(hipFree(tmo)); CK(hipFree(fin)); CK(hipFree(cyc));
+}
+
 int main(int argc, char **argv) {
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   const int steps = argc > 1 ? atoi(argv[1]) : 200;
+  if (argc > 2 && !strcmp(argv[2], "wide")) {          // the exchange of a 16..32-stream bf16 chain (C = 1024 cells)
+    for (int S : {8, 16, 32}) {
+      const int NG = (1024 * S + 5) / 6;
+      for (int G : {128, 256}) {
+        if (NG <= 8 * 512) run16<512>(G, NG, steps, 8, st);
+        if (NG <= 8 * 1024) run16<1024>(G, NG, steps, 16, st);
+        if (NG <= 8 * 768) run16<768>(G, NG, steps, 12, st);
+      }
+    }
+    return 0;
+  }
   for (int N : {2048, 3200, 6400, 12800}) {
     for (int G : {50, 100, 200, 256}) {
       if (N <= 16 * 256) run<256>(G, N, steps, 4, 0, st);
