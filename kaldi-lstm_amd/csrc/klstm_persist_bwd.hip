@@ -436,7 +436,9 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
         if (d_on && (t > 1 || !d_isr)) {
           // ---- the same dgifo(t) against 4 rows of W_gifo_r^T / W_gifo_x^T (LDS): d_r(t-1) (:391) / in_diff(t) (:457) ----
           ++nd;
-          if (nd > 2 && !lds_wait_ge(dcons, nd - 2, abortf, limit)) { dead = true; break; }   // (this parity's partials have been read)
+          // The P wave counts arrivals in ONE counter: nobody may add to it for step nd before it has passed its check for
+          // step nd - 1 (a fast wave's early arrival would stand in for a slow wave's missing one).  It did so a whole step ago.
+          if (nd > 1 && !lds_wait_ge(dcons, nd - 1, abortf, limit)) { dead = true; break; }
           float wd[NU][2][4];
 #pragma unroll
           for (int u = 0; u < NU; u++)
