@@ -56,6 +56,43 @@ def _timed(step, warmup, K, min_seconds):
     return dt, n, dt_first
 
 
+class _WholeStep:
+    """One train step per call, either issued call by call from Python (eager) or replayed from ONE hipGraph per input chunk
+    (the inputs of chunk c are fixed device buffers, so the graph of chunk c is captured once and replayed every time the chunk
+    comes round): the whole minibatch -- every engine call, the output layer, the loss, the statistics accumulation -- is a
+    single graph launch and the ~30 Python -> C-ABI calls of a step (8-10 us each) disappear from the timeline, which is what
+    a C++ trainer sitting on the same C-ABI would see.  Everything runs on one explicit stream (graphs cannot be captured on
+    the null stream).  Measured on c4: no gain over call-by-call launches on an explicit stream (0.569 vs 0.564 ms) -- the host
+    keeps ahead; what DID cost 0.25 ms per step was issuing everything on the NULL stream (0.817 ms).  Off by default."""
+
+    def __init__(self, raw, stream, nkeys, graphed, after=None):
+        self.raw, self.stream, self.nkeys, self.graphed, self.after = raw, stream, nkeys, graphed, after
+        self.graphs, self.calls = {}, 0
+
+    def __call__(self, i):
+        c = i % self.nkeys
+        with torch.cuda.stream(self.stream):
+            if not self.graphed or self.calls < 3:                 # (the first calls allocate: eager)
+                self.raw(c)
+            else:
+                g = self.graphs.get(c)
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.stream, capture_error_mode="relaxed"):
+                        self.raw(c)
+                    self.graphs[c] = g
+                g.replay()
+            self.calls += 1
+            if self.after is not None:
+                self.after(c)
+
+    def prepare(self):
+        """capture every chunk's graph outside the timed region"""
+        for i in range(self.nkeys + 3):
+            self(i)
+        torch.cuda.synchronize()
+
+
 def _engine_kernels(engines, step, base, nprof=10):
     names = ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj", "k_gates_fold", "k_gemm_rbatch",
              "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step", "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx",
@@ -105,9 +142,11 @@ def run_c1(args, k):
     p = init_params(I, C, R, 7)
     rng = np.random.RandomState(1234)
     x = rng.randn(T, I).astype(np.float32)
-    e = k.Engine(I, C, R, 1)
+    stream = torch.cuda.Stream()                        # (launches on the null stream cost more in the runtime: see run_c4)
+    e = k.Engine(I, C, R, 1, stream=stream)
     e.set_params(p)
     xd = torch.from_numpy(x).cuda(); out = torch.empty(T, R, device="cuda")
+    torch.cuda.synchronize()
     one = np.ones(1, np.int32)
 
     def step(i):
@@ -154,18 +193,20 @@ def run_c4(args, k):
     I, C, R, NPDF, S, T = 40, 800, 512, 16624, 4, T_BPTT
     rng = np.random.RandomState(21)
     dims_in = [I, R]
+    graphed = "whole_step_graph=1" in args.option
+    stream = torch.cuda.Stream()
     engines = []
     for l in range(2):
-        e = k.Engine(dims_in[l], C, R, S)
+        e = k.Engine(dims_in[l], C, R, S, stream=stream)
         e.set_params(init_params(dims_in[l], C, R, 30 + l))
         engines.append(e)
     W = torch.from_numpy(((rng.rand(NPDF, R) - 0.5) * 0.02).astype(np.float32)).cuda()
     b = torch.zeros(NPDF, device="cuda")
-    layers = [k.LstmDP(e) for e in engines] + [k.AffineDP(W, b, k)]
+    layers = [k.LstmDP(e) for e in engines] + [k.AffineDP(W, b, k, stream=stream)]
     # loss statistics accumulate on the device and are read back once per 50-minibatch utterance round (the reference's
     # trainer reports every few thousand frames); --option eager_loss=1: read back every minibatch instead
     lazy = "eager_loss=1" not in args.option
-    net = k.DataParallelNnet(layers, k.SoftmaxXentDP(k, lazy=lazy), alloc=lambda n: torch.zeros(n, device="cuda"))
+    net = k.DataParallelNnet(layers, k.SoftmaxXentDP(k, lazy=lazy, stream=stream), alloc=lambda n: torch.zeros(n, device="cuda"))
     nchunk = 50
     feats = torch.randn(nchunk, T * S, I, device="cuda")
     tg = torch.from_numpy(rng.randint(0, NPDF, (nchunk, T * S)).astype(np.int32)).cuda()
@@ -175,18 +216,30 @@ def run_c4(args, k):
     acc = [torch.zeros((), dtype=torch.float64, device="cuda"), torch.zeros((), device="cuda"), torch.zeros((), device="cuda")]
     seen = []
 
-    def step(i):
-        c = i % nchunk
+    def raw(c):
         xe, correct, valid = net.train_step(feats[c], tg[c], mask, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
         if lazy:
             acc[0] += xe; acc[1] += correct; acc[2] += valid
-            if c == nchunk - 1:
-                seen.append((float(acc[0].item()), int(acc[1].item()), int(acc[2].item())))    # one read-back per utterance round
+
+    def after(c):
+        if lazy and c == nchunk - 1:
+            seen.append((float(acc[0].item()), int(acc[1].item()), int(acc[2].item())))    # one read-back per utterance round
+    torch.cuda.synchronize()
+    step = _WholeStep(raw, stream, nchunk, graphed and lazy, after)
+    step.prepare()
     dt, n, dt_first = _timed(step, args.warmup, args.steps, args.min_seconds)
     ms = dt / n * 1e3
+    ms_eager = None
+    if step.graphed:                                   # the same steps issued call by call from Python, for the record
+        step.graphed = False
+        dte, ne, _ = _timed(step, 10, args.steps, min(1.0, args.min_seconds))
+        ms_eager = dte / ne * 1e3
+    graphed_used = graphed and lazy
     kern = _engine_kernels(engines, step, args.warmup + n)
     # device time of the output tail, part by part
     x80 = torch.randn(T * S, R, device="cuda"); aff = layers[-1]; loss = net.loss
+    torch.cuda.synchronize()
+    aff.stream = loss.stream = None                    # (_sections times on torch's current stream)
     net_out = aff.propagate(x80)
     diff, _, _, _ = loss.eval(net_out, tg[0], mask)
     torch.cuda.synchronize()
@@ -203,7 +256,11 @@ def run_c4(args, k):
             "config": {"workload": "2 stacked LstmProjectedStreams (40->512->512, cell 800) + AffineTransform 512->16624 + Softmax + Xent::EvalMasked, "
                                    "NumStream=4 per GPU (the per-GPU shard of BASELINE.json configs[3]: 32 streams on 8 GPUs), T_bptt=20, one fused "
                                    "57.6 MB gradient blob, loss statistics %s" % ("accumulated on the device, read back every 50 minibatches" if lazy else "read back every minibatch"),
-                       "streams_per_gpu": S, "frames_per_step": T * S},
+                       "streams_per_gpu": S, "frames_per_step": T * S,
+                       "launch": "one hipGraph per minibatch (captured per input chunk)" if graphed_used else
+                                 "call by call from Python on one explicit stream (--option whole_step_graph=1: one hipGraph per minibatch; "
+                                 "measured equal: 0.569 vs 0.564 ms)",
+                       "ms_per_step_call_by_call": ms_eager},
             "roofline": _roof(fl * T * S, ms, PEAK_F32_MFMA_TF, "f32", "86.2 MFLOP per frame (SURVEY.md 8(d))"),
             "sections_us": sections, "kernels": kern}
 
@@ -223,8 +280,9 @@ def run_c5(args, k):
     I, C, R, S, T, NL = 40, 1024, 512, 32, T_BPTT, 3
     dims_in = [I, R, R]
     engines = []
+    stream = torch.cuda.Stream()
     for l in range(NL):
-        e = k.Engine(dims_in[l], C, R, S)
+        e = k.Engine(dims_in[l], C, R, S, stream=stream)
         e.set_params(init_params(dims_in[l], C, R, 40 + l, scale=0.02))
         e.set_option("bf16", 1)
         engines.append(e)
@@ -233,6 +291,8 @@ def run_c5(args, k):
     nchunk = 50
     feats = torch.randn(nchunk, T * S, I, device="cuda")
     ones = [1] * S
+
+    torch.cuda.synchronize()
 
     def step(i):
         c = i % nchunk

@@ -176,8 +176,10 @@ class LstmDP:
 class AffineDP:
     """AffineTransform (W [out, in], bias [out]) on the device ops of the C-ABI (klstm_affine_*)."""
 
-    def __init__(self, W, bias, ops):
-        self.W, self.bias, self.ops = W.contiguous(), bias.contiguous(), ops
+    def __init__(self, W, bias, ops, stream=None):
+        """stream: the torch stream the device ops are issued on (None: the default stream, like an engine created without
+        one); a trainer that replays whole minibatches from one hipGraph gives every layer the same explicit stream."""
+        self.W, self.bias, self.ops, self.stream = W.contiguous(), bias.contiguous(), ops, stream
         self.num_params = W.numel() + bias.numel()
         self.W_corr, self.b_corr = torch.zeros_like(self.W), torch.zeros_like(self.bias)
         self._out = self._ind = None
@@ -192,21 +194,21 @@ class AffineDP:
     def propagate(self, x):
         if self._out is None or self._out.shape[0] != x.shape[0]:
             self._out = torch.empty(x.shape[0], self.W.shape[0], device=x.device)
-        self.ops.affine_propagate(x, self.W, self.bias, self._out)
+        self.ops.affine_propagate(x, self.W, self.bias, self._out, self.stream)
         return self._out
 
     def backpropagate(self, x, out_diff, want_in_diff):
-        self.ops.affine_gradient(x, out_diff, self.gW, self.gb)
+        self.ops.affine_gradient(x, out_diff, self.gW, self.gb, self.stream)
         if not want_in_diff:
             return None
         if self._ind is None or self._ind.shape[0] != x.shape[0]:
             self._ind = torch.empty(x.shape[0], self.W.shape[1], device=x.device)
-        self.ops.affine_backpropagate(out_diff, self.W, self._ind)
+        self.ops.affine_backpropagate(out_diff, self.W, self._ind, self.stream)
         return self._ind
 
     def apply(self, momentum, lr):
-        self.ops.sgd_momentum_update(self.W.view(-1), self.W_corr.view(-1), self.gW.reshape(-1), momentum, lr)
-        self.ops.sgd_momentum_update(self.bias, self.b_corr, self.gb, momentum, lr)
+        self.ops.sgd_momentum_update(self.W.view(-1), self.W_corr.view(-1), self.gW.reshape(-1), momentum, lr, self.stream)
+        self.ops.sgd_momentum_update(self.bias, self.b_corr, self.gb, momentum, lr, self.stream)
 
 
 class SoftmaxXentDP:
@@ -214,16 +216,16 @@ class SoftmaxXentDP:
     lazy: the statistics stay 0-d device tensors (no host synchronisation per minibatch; the reference's trainer prints
     them every few thousand frames, bd-nnet-train-lstm-streams.cc:240-257)."""
 
-    def __init__(self, ops, lazy=False):
-        self.ops, self.lazy = ops, lazy
+    def __init__(self, ops, lazy=False, stream=None):
+        self.ops, self.lazy, self.stream = ops, lazy, stream
         self._post = self._diff = self._rows = None
 
     def eval(self, net_out, targets, mask):
         if self._post is None or self._post.shape != net_out.shape:
             self._post, self._diff = torch.empty_like(net_out), torch.empty_like(net_out)
             self._rows = (torch.empty(net_out.shape[0], device=net_out.device), torch.empty(net_out.shape[0], device=net_out.device))
-        self.ops.softmax(net_out, self._post)
-        xe, correct, valid = self.ops.xent_eval_masked(self._post, targets, mask, self._diff, lazy=self.lazy, rows_out=self._rows)
+        self.ops.softmax(net_out, self._post, self.stream)
+        xe, correct, valid = self.ops.xent_eval_masked(self._post, targets, mask, self._diff, stream=self.stream, lazy=self.lazy, rows_out=self._rows)
         return self._diff, xe, correct, valid
 
 
