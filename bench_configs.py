@@ -206,7 +206,9 @@ def run_c4(args, k):
     # loss statistics accumulate on the device and are read back once per 50-minibatch utterance round (the reference's
     # trainer reports every few thousand frames); --option eager_loss=1: read back every minibatch instead
     lazy = "eager_loss=1" not in args.option
-    net = k.DataParallelNnet(layers, k.SoftmaxXentDP(k, lazy=lazy, stream=stream), alloc=lambda n: torch.zeros(n, device="cuda"))
+    fused = "fuse_single_rank=0" not in args.option
+    net = k.DataParallelNnet(layers, k.SoftmaxXentDP(k, lazy=lazy, stream=stream), alloc=lambda n: torch.zeros(n, device="cuda"),
+                             fuse_single_rank=fused)
     nchunk = 50
     feats = torch.randn(nchunk, T * S, I, device="cuda")
     tg = torch.from_numpy(rng.randint(0, NPDF, (nchunk, T * S)).astype(np.int32)).cuda()
@@ -287,7 +289,8 @@ def run_c5(args, k):
         e.set_option("bf16", 1)
         engines.append(e)
     od = 0.1 * torch.randn(T * S, R, device="cuda")
-    net = k.DataParallelNnet([k.LstmDP(e) for e in engines], _FixedDiffLoss(od), alloc=lambda n: torch.zeros(n, device="cuda"))
+    net = k.DataParallelNnet([k.LstmDP(e) for e in engines], _FixedDiffLoss(od), alloc=lambda n: torch.zeros(n, device="cuda"),
+                             fuse_single_rank="fuse_single_rank=0" not in args.option)
     nchunk = 50
     feats = torch.randn(nchunk, T * S, I, device="cuda")
     ones = [1] * S

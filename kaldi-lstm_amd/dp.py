@@ -162,14 +162,21 @@ class LstmDP:
         self.e.propagate(x, self._out)
         return self._out
 
-    def backpropagate(self, x, out_diff, want_in_diff):
+    def backpropagate(self, x, out_diff, want_in_diff, fused_momentum=None):
+        """fused_momentum (single rank, no collective in between): Kaldi's Component::Backpropagate order -- the gradient
+        products run inside the following update() as ONE pass with momentum and the step (KLSTM_BPTT_FUSE_UPDATE)."""
         if want_in_diff and (self._ind is None or self._ind.shape[0] != x.shape[0]):
             self._ind = torch.empty(x.shape[0], self.e.I, device=x.device)
-        self.e.backpropagate(x, out_diff, self._ind if want_in_diff else None, 0.0, DataParallelLstm.DEFER_MOMENTUM)
+        self._fused = fused_momentum is not None
+        if self._fused:
+            self.e.backpropagate(x, out_diff, self._ind if want_in_diff else None, fused_momentum, DataParallelLstm.FUSE_UPDATE)
+        else:
+            self.e.backpropagate(x, out_diff, self._ind if want_in_diff else None, 0.0, DataParallelLstm.DEFER_MOMENTUM)
         return self._ind if want_in_diff else None
 
     def apply(self, momentum, lr):
-        self.e.apply_momentum(momentum)
+        if not getattr(self, "_fused", False):
+            self.e.apply_momentum(momentum)
         self.e.update(lr)
 
 
@@ -197,8 +204,14 @@ class AffineDP:
         self.ops.affine_propagate(x, self.W, self.bias, self._out, self.stream)
         return self._out
 
-    def backpropagate(self, x, out_diff, want_in_diff):
-        self.ops.affine_gradient(x, out_diff, self.gW, self.gb, self.stream)
+    def backpropagate(self, x, out_diff, want_in_diff, fused_momentum=None):
+        """fused_momentum (single rank): the gradient is not materialised -- apply() runs klstm_affine_update (gradient +
+        momentum + step in one pass over W) on the x / out_diff of this call, which stay valid until then."""
+        self._fused = fused_momentum is not None
+        if self._fused:
+            self._x, self._od = x, out_diff
+        else:
+            self.ops.affine_gradient(x, out_diff, self.gW, self.gb, self.stream)
         if not want_in_diff:
             return None
         if self._ind is None or self._ind.shape[0] != x.shape[0]:
@@ -207,6 +220,9 @@ class AffineDP:
         return self._ind
 
     def apply(self, momentum, lr):
+        if getattr(self, "_fused", False):
+            self.ops.affine_update(self._x, self._od, self.W, self.bias, self.W_corr, self.b_corr, lr, lr, momentum, self.stream)
+            return
         self.ops.sgd_momentum_update(self.W.view(-1), self.W_corr.view(-1), self.gW.reshape(-1), momentum, lr, self.stream)
         self.ops.sgd_momentum_update(self.bias, self.b_corr, self.gb, momentum, lr, self.stream)
 
@@ -234,7 +250,7 @@ class DataParallelNnet:
     gradient blob and the momentum/update step on every rank (bd-nnet-train-lstm-streams.cc:209-228 per rank, on this
     rank's streams).  `alloc(n)` returns the flat blob storage (torch CUDA float32 for the device layers)."""
 
-    def __init__(self, layers, loss, alloc, group=None, force_collective=False, overlap=False):
+    def __init__(self, layers, loss, alloc, group=None, force_collective=False, overlap=False, fuse_single_rank=False):
         """overlap=False: ONE all-reduce of the whole blob after the last Backpropagate (fewest, largest collective).
         overlap=True: one asynchronous all-reduce per layer slice, issued as soon as that layer's gradient exists, so
         the output layer's 34 MB (configs[3]) travel over xGMI while the LSTM layers below still run their BPTT chains;
@@ -244,6 +260,9 @@ class DataParallelNnet:
         self.overlap = overlap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())
+        # single rank, nothing to reduce: layers that can do so run gradient + momentum + step as one pass (what the C++ mirror
+        # does with KLSTM_BPTT_FUSE_UPDATE / klstm_affine_update); the fused gradient blob then stays unused
+        self.fused = fuse_single_rank and not self.collective
         pad4 = lambda n: (n + 3) // 4 * 4                  # every slice starts 16-byte aligned (float4 stores)
         self.blob = alloc(sum(pad4(l.num_params) for l in layers))
         # device layers: the all-reduce is libklstm.so's klstm_allreduce_buffer (RCCL) on the layers' stream
@@ -265,7 +284,10 @@ class DataParallelNnet:
         diff, xent, correct, valid = self.loss.eval(acts[-1], targets, mask)
         pending = []
         for i in range(len(self.layers) - 1, -1, -1):
-            diff = self.layers[i].backpropagate(acts[i], diff, i > 0)     # the first layer's in_diff is never used (:228)
+            if self.fused:
+                diff = self.layers[i].backpropagate(acts[i], diff, i > 0, fused_momentum=momentum)
+            else:
+                diff = self.layers[i].backpropagate(acts[i], diff, i > 0)     # the first layer's in_diff is never used (:228)
             if self.collective and self.overlap:
                 pending.append(self.dist.all_reduce(self.slices[i], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
         if self.collective and not self.overlap:

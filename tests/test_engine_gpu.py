@@ -751,6 +751,45 @@ def test_stacked_net_dp_device_layers_against_cpu_twins(overlap):
                                    tol_param=5e-5, tol_grad=2e-4)
 
 
+def test_stacked_net_fused_single_rank_equals_the_two_pass_path():
+    """DataParallelNnet(fuse_single_rank=True) on one rank: every layer runs gradient + momentum + step as ONE pass
+    (KLSTM_BPTT_FUSE_UPDATE in the LSTM engines, klstm_affine_update in the output layer -- Kaldi's Component::Backpropagate
+    order) instead of gradient -> blob -> momentum -> step.  Same parameters after three minibatches as the two-pass net
+    (the LSTM engines bit-identical; the output layer to fp32 rounding: it adds momentum*corr + grad in another order),
+    and the same loss statistics."""
+    import kaldi_lstm_amd as k
+    from tests import nnet_twins as tw
+    dims = (40, 64, 32, 2, 131)
+    I, C, R, n_lstm, n_out = dims
+    S, T, mmt, lr = 4, 6, 0.9, 1e-3
+    lstm, W, b = tw.make_stack(dims, S, seed=31, dtype=np.float32, scale=0.2)
+    nets, engs = [], []
+    for fused in (False, True):
+        engines = [make_engine(I if l == 0 else R, C, R, S, lstm[l]) for l in range(n_lstm)]
+        layers = [k.LstmDP(e) for e in engines] + [k.AffineDP(dev(W), dev(b), k)]
+        nets.append(k.DataParallelNnet(layers, k.SoftmaxXentDP(k), alloc=lambda n: torch.zeros(n, device="cuda"), fuse_single_rank=fused))
+        engs.append(engines)
+    assert nets[1].fused and not nets[0].fused
+    rng = np.random.RandomState(32)
+    for i in range(3):
+        x = dev(rng.randn(T * S, I).astype(np.float32))
+        tg = torch.from_numpy(rng.randint(0, n_out, T * S).astype(np.int32)).cuda()
+        mk = dev((rng.rand(T * S) > 0.25).astype(np.float32))
+        flags = [1] * S if i == 0 else None
+        st = [n.train_step(x, tg, mk, mmt, lr, reset_flags=flags) for n in nets]
+        assert abs(st[0][0] - st[1][0]) <= 1e-5 * abs(st[0][0]) and st[0][1:] == st[1][1:]
+    torch.cuda.synchronize()
+    for e0, e1 in zip(*engs):
+        check_blob(e1.get_params(), e0.get_params(), 2e-6, C, R, "params fused vs two-pass")
+        check_blob(e1.get_corr(), e0.get_corr(), 2e-6, C, R, "momentum fused vs two-pass")
+    a0, a1 = nets[0].layers[-1], nets[1].layers[-1]
+    assert relerr(a1.W.cpu().numpy(), a0.W.cpu().numpy()) <= 2e-6 and relerr(a1.W_corr.cpu().numpy(), a0.W_corr.cpu().numpy()) <= 2e-6
+    assert relerr(a1.bias.cpu().numpy(), a0.bias.cpu().numpy()) <= 2e-6
+    for es in engs:
+        for e in es:
+            e.close()
+
+
 def test_config_c3_full_size_net_end_to_end():
     """BASELINE.json configs[3] at FULL size as ONE net (google/nnet.proto:1-6, README.md:24-29): LstmProjectedStreams 40 -> 800/512,
     LstmProjectedStreams 512 -> 800/512, AffineTransform 512 -> 16624, Softmax, Xent::EvalMasked; 32 streams over 8 GPUs = 4 per
