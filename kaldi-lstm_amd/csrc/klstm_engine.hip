@@ -243,8 +243,9 @@ static bool fold_wanted(const klstm_engine *e, int T) {
   return e->use_fold == 1 ? T >= 2 : (T >= 12 && e->S <= 8);
 }
 static bool use_fused_x(const klstm_engine *e);
-// persistent chain: needs the folded operands, the x term inside the step, at most 4 streams; auto = on from 3 frames
-// per stream (the forward launch covers steps 2..T)
+// persistent chain: needs the folded operands, up to 8 streams, the x term inside the step or -- wide inputs --
+// from the batched product; one launch per direction covers all T steps; auto = on from 8 frames per stream; one compute
+// unit per workgroup (an engine on a smaller device or partition keeps to one launch per step)
 static bool persist_bwd_wanted(const klstm_engine *e, int T) {
   const Dims d{e->I, e->C, e->R, e->S, T};
   return e->use_persist != 1 && persist_bwd_supported(d, e->popt) && persist_bwd_grid(d) <= e->ncu;
@@ -260,10 +261,9 @@ static bool persist_wanted(const klstm_engine *e, int T) {
            "falling back to one launch per step", persist_fwd_grid(d, e->popt), e->ncu);
     return false;
   }
-  // auto: from 8 frames on.  1..4 streams: both directions.  5..8 streams: the forward launch only (two groups against the
-  // same resident rows) -- the exchange takes twice as long with twice the granules, 4.2 us per step inside the launch
-  // against 4.2 for the launch-per-step kernel, but the step-1 kernel, the batched projection pair and the per-Update
-  // packing go away: 296-303 vs 306-309 us per minibatch at 8 streams (tools/persist_timing.py, tools/stream_breakdown.py)
+  // auto: from 8 frames on, both directions, 1..8 streams (5..8: two groups of 4 against the same resident rows -- together in
+  // the forward launch, one after the other in the backward launch): 272 vs 293 us per minibatch at 8 streams, 166 vs 229 at 4
+  // (tools/persist_timing.py, profiles/r03_persist_timing.txt)
   return e->use_persist >= 1 ? true : T >= 8;
 }
 static klstm_status ensure_persist(klstm_engine *e) {
