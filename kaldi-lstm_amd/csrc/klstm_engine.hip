@@ -573,9 +573,14 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
   const FwdPtrs p = fwd_ptrs(e);
   hipStream_t st = e->stream;
   const bool fx = use_fused_x(e) && !(e->fwd_persist && persist_x_batched(d));
-  if (!fx)   // x -> g,i,f,o for all frames at once + bias (...streams.h:246, :259)
-    HIPCHK(launch_gemm(false, true, T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, 0.f,
-                       e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias, st, probe(e, "k_gemm_xproj")));
+  if (!fx) {  // x -> g,i,f,o for all frames at once + bias (...streams.h:246, :259)
+    if (e->use_bf16 && gemm_bf16_nt_supported(T * d.S, d.I, in, in_stride, p.wx, d.I))   // bf16 mode: operands rounded like the fused form's
+      HIPCHK(launch_gemm_bf16_nt(T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias,
+                                 st, probe(e, "k_gemm_xproj")));
+    else
+      HIPCHK(launch_gemm(false, true, T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, 0.f,
+                         e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias, st, probe(e, "k_gemm_xproj")));
+  }
   if (e->fwd_folded) {
     // step 1 closes over the CARRIED r (set by Reset / the previous minibatch, possibly under older weights): unfolded
     // gates kernel, r(0) mirrored into time block 0; steps 2..T close over m(t-1) through W_rm; r(1..T) in one GEMM

@@ -128,6 +128,10 @@ struct GradsUpdate {
   // optional: the bf16 planes of the fold operands (fold_bf16x3_planes) are written from the updated W_gifo_r / W_r_m too
   unsigned short *a3 = nullptr, *b3 = nullptr; long a_plane = 0, b_plane = 0;
 };
+// C = A B^T + bias on the bf16 pipe (both operands rounded, fp32 accumulate): the batched x-projection of the bf16 operand mode
+bool gemm_bf16_nt_supported(int M, int K, const float *A, int lda, const float *B, int ldb);
+hipError_t launch_gemm_bf16_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
+                               const float *bias, hipStream_t st, LaunchProbe pr = {});
 bool grads_bf16_tiles(const Dims &d, bool bf16);      // would launch_grads take the bf16 tile path?
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,

@@ -1,6 +1,6 @@
 """Numpy emulation of the engine's bf16 operand mode (option "bf16"), test infrastructure only.
 
-Semantics being pinned: in the four per-step contractions (gates :275 [+ :246 when the x term is fused], projection
+Semantics being pinned: in the four per-step contractions (gates :275 [+ :246 when the x term is fused, or batched over >= 256 frames of >= 128 inputs], projection
 :312, d_r/in_diff :391/:457, d_m :408) BOTH operands are rounded to bf16 (round-to-nearest-even) and the products
 are accumulated in fp32; so are the three gradient products (:468, :471, :486) from 256 frames per minibatch on.  Everything else -- elementwise math,
 activation planes, the bias / peephole sums, momentum, Update, the fp32 master weights -- is unchanged fp32.  Products of bf16 values are exact in
@@ -36,9 +36,10 @@ def minibatch(parts, x, od, c0, r0, S, fuse_x, want_in_diff=True):
     g = np.zeros((T + 2, S, C)); i = np.zeros_like(g); f = np.zeros_like(g); o = np.zeros_like(g)
     c = np.zeros_like(g); h = np.zeros_like(g); m = np.zeros_like(g); r = np.zeros((T + 2, S, R))
     c[0], r[0] = c0, r0
+    x_bf16 = fuse_x or (T * S >= GRADS_BF16_MIN_ROWS and I >= 128)   # the batched x-projection runs on the bf16 pipe from 256 frames and 128 inputs on
     for t in range(1, T + 1):
         xt = x[(t - 1) * S:t * S]
-        a = (rb(xt) @ wxb.T if fuse_x else f32(xt @ wx.T)) + b + rb(r[t - 1]) @ wrb.T
+        a = (rb(xt) @ wxb.T if x_bf16 else f32(xt @ wx.T)) + b + rb(r[t - 1]) @ wrb.T
         ag, ai, af, ao = a[:, :C], a[:, C:2 * C], a[:, 2 * C:3 * C], a[:, 3 * C:]
         i[t] = sigmoid(ai + c[t - 1] * pi)
         f[t] = sigmoid(af + c[t - 1] * pf)
