@@ -577,6 +577,9 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
     if (e->use_bf16 && gemm_bf16_nt_supported(T * d.S, d.I, in, in_stride, p.wx, d.I))   // bf16 mode: operands rounded like the fused form's
       HIPCHK(launch_gemm_bf16_nt(T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias,
                                  st, probe(e, "k_gemm_xproj")));
+    else if (direct_nt_supported(T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I))       // few frames, wide input (klstm_fold.hip)
+      HIPCHK(launch_direct_nt(T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias, st,
+                              probe(e, "k_gemm_xproj")));
     else
       HIPCHK(launch_gemm(false, true, T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, 0.f,
                          e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias, st, probe(e, "k_gemm_xproj")));

@@ -312,6 +312,46 @@ hipError_t launch_fold_direct(const Dims &d, const float *wr, const float *wmT, 
   return hipGetLastError();
 }
 
+// The same product for a NARROW result (the batched x-projection of a wide-input layer at few frames: 80 x 3200 over K = 512): one
+// 16-column block per WORKGROUP, its four waves take a quarter of K each (K % 512 == 0) and wave 0 adds the partial tiles in
+// fixed order through LDS -- 200 workgroups x 4 waves instead of 100 one-wave workgroups (16.6 -> ~5 us inside configs[3]).
+template <int MI>
+__global__ __launch_bounds__(256) void k_direct_nt_ks(DirectNtArgs a) {
+  __shared__ __attribute__((aligned(16))) f32x4 part[3][MI][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int n0 = (int)blockIdx.x * 16, kq = a.K / 4;
+  const float *ap[MI], *bp[1];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    const int m = 16 * mi + i16;
+    ap[mi] = a.A + (size_t)(m < a.M ? m : 0) * a.lda + wave * kq + 8 * kg;
+  }
+  const int nb = n0 + i16;
+  bp[0] = a.B + (size_t)(nb < a.N ? nb : 0) * a.ldb + wave * kq + 8 * kg;
+  f32x4 acc[MI][1];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) acc[mi][0] = (f32x4){0, 0, 0, 0};
+  direct_kloop<MI, 1>(ap, bp, kq / 32, acc);
+  if (wave > 0) {
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) part[wave - 1][mi][lane] = acc[mi][0];
+  }
+  __syncthreads();
+  if (wave > 0 || nb >= a.N) return;
+  const float bv = a.bias ? a.bias[nb] : 0.f;
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    const f32x4 v = ((acc[mi][0] + part[0][mi][lane]) + part[1][mi][lane]) + part[2][mi][lane];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int m = 16 * mi + 4 * kg + r;
+      if (m < a.M) a.Cm[(size_t)m * a.ldc + nb] = e[r] + bv;
+    }
+  }
+}
+
 static int g_nt_ni = 2, g_nt_waves = 1;   //    // measured at 80 x 16624 x 512 (tools/nt_sweep.py): 29.5 us; 1x1 36.7, 2x2 34.0, 4x1 49.4; tiled kernel 37.9
 void set_direct_nt_shape(int ni, int waves) { g_nt_ni = ni == 1 || ni == 2 ? ni : 4; g_nt_waves = waves >= 1 && waves <= 4 ? waves : 2; }
 
@@ -321,22 +361,40 @@ bool direct_nt_supported(int M, int N, int K, const float *A, int lda, const flo
 }
 
 hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
-                            const float *bias, hipStream_t st) {
+                            const float *bias, hipStream_t st, LaunchProbe pr) {
+#define KS_LAUNCH(MI_) do { if (pr.start) hipExtLaunchKernelGGL((k_direct_nt_ks<MI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
+                            else hipLaunchKernelGGL((k_direct_nt_ks<MI_>), grid, block, 0, st, a); } while (0)
   DirectNtArgs a{M, N, K, A, lda, B, ldb, Cm, ldc, bias};
+  if (N <= 8192 && K % (4 * 32 * FD) == 0) {                 // narrow result: K split over the four waves of a workgroup
+    const dim3 grid((N + 15) / 16), block(256);
+    switch ((M + 15) / 16) {
+      case 1: KS_LAUNCH(1); break;
+      case 2: KS_LAUNCH(2); break;
+      case 3: KS_LAUNCH(3); break;
+      case 4: KS_LAUNCH(4); break;
+      case 5: KS_LAUNCH(5); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef KS_LAUNCH
+    return hipGetLastError();
+  }
   // columns per wave (16*NI) and waves per workgroup: experiment knobs (g_nt_ni, g_nt_waves)
   const int ni = g_nt_ni, nw = g_nt_waves;
   const dim3 grid((N + 16 * ni * nw - 1) / (16 * ni * nw)), block(64 * nw);
+#define NT_GO(MI_, NI_) do { if (pr.start) hipExtLaunchKernelGGL((k_direct_nt<MI_, NI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
+                             else hipLaunchKernelGGL((k_direct_nt<MI_, NI_>), grid, block, 0, st, a); } while (0)
 #define NT_CASE(MI_)                                                                                   \
   case MI_:                                                                                            \
-    if (ni == 1) hipLaunchKernelGGL((k_direct_nt<MI_, 1>), grid, block, 0, st, a);                      \
-    else if (ni == 2) hipLaunchKernelGGL((k_direct_nt<MI_, 2>), grid, block, 0, st, a);                 \
-    else hipLaunchKernelGGL((k_direct_nt<MI_, 4>), grid, block, 0, st, a);                              \
+    if (ni == 1) NT_GO(MI_, 1);                                                                        \
+    else if (ni == 2) NT_GO(MI_, 2);                                                                   \
+    else NT_GO(MI_, 4);                                                                                \
     break;
   switch ((M + 15) / 16) {
     NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5)
     default: return hipErrorInvalidValue;
   }
 #undef NT_CASE
+#undef NT_GO
   return hipGetLastError();
 }
 

@@ -65,7 +65,7 @@ hipError_t launch_gemm_tn_coal(int M, int N, int K, const float *A, int lda, con
 void set_direct_nt_shape(int ni, int waves);
 bool direct_nt_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb);
 hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
-                            const float *bias, hipStream_t st);
+                            const float *bias, hipStream_t st, LaunchProbe pr = {});
 // the same product as six bf16 MFMA products of three-way split operands (fp32 accuracy; klstm_fold3.hip); scratch holds the planes
 bool fold_bf16x3_supported(const Dims &d);
 void set_fold_bf16x3(int v);
