@@ -130,14 +130,6 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
   const bool d_on = a.din && (int)blockIdx.x < ngr + ngx, d_isr = (int)blockIdx.x < ngr;
   const int dcol = d_isr ? (int)blockIdx.x * 4 : ((int)blockIdx.x - ngr) * 4;
   if (tid < 16) reinterpret_cast<int *>(lds)[tid] = 0;
-  if (d_on) {
-    const float *src = (d_isr ? a.wrT : a.wxT) + (size_t)dcol * K;
-    for (int i = tid; i < NSLOT * 512; i += NT) {
-      const int ln = i & 63, e = (i >> 6) & 3, p = (i >> 8) & 1, sl = i >> 9;
-      const int cell = 32 * sl + 16 * p + (ln >> 2);
-      wD[i] = cell < C ? src[(size_t)(ln & 3) * K + e * C + cell] : 0.f;
-    }
-  }
   __syncthreads();
   PT_DECL();
 
@@ -329,6 +321,17 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
       const int clc = cl < C ? cl : 0;
       svoff[u] = clc * 32 + h * 16;
       wpi[u] = a.pi[clc]; wpf[u] = a.pf[clc]; wpo[u] = a.po[clc];
+    }
+    // The A operands of the d_r / in_diff columns: every SC wave fills the LDS slots it will read itself (wave-private, in-order
+    // DS queue: no synchronisation), AFTER the workgroup barrier -- in front of it these 51 KB per workgroup delayed the P wave's
+    // P(T) and with it the first publish of every workgroup (2 us per launch).
+    if (d_on) {
+      const float *src = (d_isr ? a.wrT : a.wxT) + (size_t)dcol * K + (size_t)j * K;
+#pragma unroll 8
+      for (int q = 0; q < NU * 8; q++) {             // q = (slot u, half p, gate e); 8 loads in flight
+        const int e = q & 3, p = (q >> 2) & 1, sl = (q >> 3) * NSC + w, cell = 32 * sl + 16 * p + b;
+        wD[((sl * 2 + p) * 4 + e) * 64 + lane] = cell < C ? src[e * C + cell] : 0.f;
+      }
     }
     // plane addresses: lane part in a VGPR, slot part in the immediate, stream / gate / frame parts in the scalar offset
     const int voffG = (2 * h * K + 32 * w + c32) * 4, voffC = (2 * h * C + 32 * w + c32) * 4;
