@@ -1122,6 +1122,13 @@ klstm_status klstm_affine_backpropagate(const float *out_diff, int rows, int out
                                         int in_dim, float *in_diff, int id_stride, void *hip_stream) {
   if (!out_diff || !W || !in_diff) return fail(KLSTM_ERR_ARG, "klstm_affine_backpropagate: null argument");
   hipStream_t st = (hipStream_t)hip_stream;
+  if (skinny_nn_supported(rows, in_dim, out_dim, out_diff, od_stride, W, in_dim, in_diff, id_stride)) {   // few frames, wide layer (klstm_fold.hip)
+    float *ws = nullptr;
+    klstm_status s = splitk_workspace(st, skinny_nn_workspace_floats(rows, in_dim, out_dim), &ws);
+    if (s != KLSTM_OK) return s;
+    HIPCHK(launch_skinny_nn(rows, in_dim, out_dim, out_diff, od_stride, W, in_dim, in_diff, id_stride, ws, st));
+    return KLSTM_OK;
+  }
   int klen = 0;
   const int ks = gemm_splitk_plan(rows, in_dim, out_dim, &klen);       // contraction over the (long) output axis
   if (ks > 1) {

@@ -352,6 +352,242 @@ __global__ __launch_bounds__(256) void k_direct_nt_ks(DirectNtArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// C[M x N] = A[M x K] B[K x N] for FEW rows, a narrow result and a LONG contraction (AffineTransform::BackpropagateFnc of the
+// output layer: in_diff[80 x 512] = out_diff[80 x 16624] W[16624 x 512], nnet.proto:4): all the parallelism is along K.
+//   workgroup (n-range of 128 columns, K slice of 256 rows of B): its four waves take 64 rows each, both 32-row chunks
+//   requested up front, operands straight into MFMA registers, no LDS in the loop:
+//     A  lane (row i16, k-group kg) loads the 32 bytes at k = k0 + 8kg of its row (as in direct_kloop)
+//     B  is n-contiguous: lane (i16, kg) loads, for MFMA step e, the 16 bytes B[k0 + 8kg + e][n0 + 64jj + 4 i16 .. +3] --
+//        4 rows x 256 contiguous bytes per instruction.  Component c of that load is column i16 of the VIRTUAL 16-column
+//        block {n0 + 64jj + 4i + c : i = 0..15}: any 16 columns can be an MFMA block, and this choice leaves every lane with
+//        four CONSECUTIVE result columns (one 16-byte store per row).
+//   The four partial tiles of a workgroup are added through LDS (each wave owns a quarter of the blocks and adds the other
+//   three waves' copies in fixed order), the workgroup's partial goes to ws[K slice][M][N]; k_skinny_nn_reduce adds the K
+//   slices in order (deterministic, like every other reduction here).
+// 80 x 512 x 16624: split-K pair of the tiled kernel 34 us -> this pair ~17 us (1.36 GFLOP = 9.7 us at the fp32 MFMA peak).
+// ---------------------------------------------------------------------------------------------------------------------
+struct SkinnyNnArgs {
+  int M, N, K;
+  const float *A; int lda;
+  const float *B; int ldb;
+  float *ws; int nks;
+  float *Cm; int ldc;
+  int rem;                // the first `rem` wave slots (K slice * 4 + wave) take a ninth group of 8 rows
+};
+__device__ __forceinline__ float4 keep4(const float4 &v, bool c) {      // zero without a select the compiler could turn into a branch around the load
+  const unsigned m = c ? 0xffffffffu : 0u;
+  return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
+                     __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
+}
+template <int MI>
+__global__ __launch_bounds__(256) void k_skinny_nn(SkinnyNnArgs a) {
+  constexpr int NB = 8, OWN = MI * NB / 4;           // blocks per wave tile; blocks a wave owns in the reduction (MI * 8 % 4 == 0)
+  extern __shared__ __attribute__((aligned(16))) f32x4 part[];   // [owner][source slot 0..2][OWN][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int nr = a.N / 128, n0 = ((int)blockIdx.x % nr) * 128, ks = (int)blockIdx.x / nr;
+  // rows of B: wave slot s = 4 ks + wave takes 64 rows (two chunks of 32) from row 8 (8 s + min(s, rem)), the first `rem` slots 8
+  // more -- so that a contraction that is not a multiple of 256 x 64 slices (16624 = 2078 groups of 8 over 256 slots) still
+  // fits ONE round of workgroups: with 65 slices of 256 rows the 4 workgroups of the 65th ran alone behind the other 256
+  const int slot = ks * 4 + wave, kw = 8 * (8 * slot + min(slot, a.rem));
+  const bool extra = slot < a.rem;
+  float4 ra[2][MI][2], rb[2][8][2];
+  float2 xa[MI];
+  float4 xb[2][2];
+  {
+    const int kx = kw + 64 + 2 * kg;                 // ninth group: k = kx + e, e = 0, 1
+    const bool xin = extra && kx + 2 <= a.K;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+      const int m = 16 * mi + i16;
+      xa[mi] = *reinterpret_cast<const float2 *>(a.A + (size_t)(m < a.M ? m : 0) * a.lda + (xin ? kx : 0));
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const float *p = a.B + (size_t)(xin ? kx + e : 0) * a.ldb + n0 + 4 * i16;
+      xb[e][0] = *reinterpret_cast<const float4 *>(p);
+      xb[e][1] = *reinterpret_cast<const float4 *>(p + 64);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const int k0 = kw + 32 * c + 8 * kg;
+    const bool kin = k0 + 8 <= a.K;                  // K % 8 == 0
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+      const int m = 16 * mi + i16;
+      const float *p = a.A + (size_t)(m < a.M ? m : 0) * a.lda + (kin ? k0 : 0);
+      ra[c][mi][0] = *reinterpret_cast<const float4 *>(p);          // (rows past M and k past K are zeroed at use: touching a loaded
+      ra[c][mi][1] = *reinterpret_cast<const float4 *>(p + 4);      //  register here would make the wave wait before the next request)
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float *p = a.B + (size_t)(kin ? k0 + e : 0) * a.ldb + n0 + 4 * i16;
+      rb[c][e][0] = *reinterpret_cast<const float4 *>(p);          // (rows past K meet zeros of A)
+      rb[c][e][1] = *reinterpret_cast<const float4 *>(p + 64);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);                 // ALL 2 x (2 MI + 16) loads are in flight before the first MFMA (left alone, hipcc sinks
+                                                     //  them between the MFMAs two at a time: one memory latency per pair, 39 us)
+  f32x4 acc[MI][NB];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) acc[mi][nb] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float av[MI];
+      const unsigned kmask = kw + 32 * c + 8 * kg + 8 <= a.K ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) {
+        const float4 &q = ra[c][mi][e >> 2];
+        const float raw = (e & 3) == 0 ? q.x : (e & 3) == 1 ? q.y : (e & 3) == 2 ? q.z : q.w;
+        av[mi] = __uint_as_float(__float_as_uint(raw) & (16 * mi + i16 < a.M ? kmask : 0u));
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++) {
+        const float bv[4] = {rb[c][e][jj].x, rb[c][e][jj].y, rb[c][e][jj].z, rb[c][e][jj].w};
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+          for (int mi = 0; mi < MI; mi++)
+            acc[mi][jj * 4 + cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[cc], acc[mi][jj * 4 + cc], 0, 0, 0);
+      }
+    }
+  if (extra) {
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      float av[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) av[mi] = 16 * mi + i16 < a.M ? (e ? xa[mi].y : xa[mi].x) : 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++) {
+        const float bv[4] = {xb[e][jj].x, xb[e][jj].y, xb[e][jj].z, xb[e][jj].w};
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+          for (int mi = 0; mi < MI; mi++)
+            acc[mi][jj * 4 + cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[cc], acc[mi][jj * 4 + cc], 0, 0, 0);
+      }
+    }
+  }
+  // ---- the four waves' tiles -> one: block q = mi * 8 + nb belongs to wave q & 3; source s hands it to owner o in slot s - (s > o)
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const int q = mi * NB + nb, o = q & 3;
+      if (o != wave) part[((o * 3 + (wave - (wave > o ? 1 : 0))) * OWN + (q >> 2)) * 64 + lane] = acc[mi][nb];
+    }
+  __syncthreads();
+  float *wp = a.ws + (size_t)ks * a.M * a.N;
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const int q = mi * NB + nb;
+      if ((q & 3) != wave) continue;
+      f32x4 v[4];                                    // contributions in source order 0, 1, 2, 3 (own in its place)
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+        v[s] = s == wave ? acc[mi][nb] : part[((wave * 3 + (s - (s > wave ? 1 : 0))) * OWN + (q >> 2)) * 64 + lane];
+      acc[mi][nb] = ((v[0] + v[1]) + v[2]) + v[3];
+    }
+  // lane (i16, kg) of block (mi, jj, cc): rows 16mi + 4kg + r at column n0 + 64jj + 4 i16 + cc: the four cc blocks of a lane
+  // are one 16-byte piece -- but they belong to four different owner waves (q & 3 = cc): back through LDS, then row-wise stores
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+      if (((mi * NB + nb) & 3) == wave) part[(mi * NB + nb) * 64 + lane] = acc[mi][nb];
+  __syncthreads();
+  // 256 threads: thread = (block pair (mi, jj) = tid >> 6 ... ): walk (mi, jj) pairs, 64 lanes each
+  for (int pr = wave; pr < MI * 2; pr += 4) {
+    const int mi = pr >> 1, jj = pr & 1;
+    f32x4 c4[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) c4[cc] = part[(mi * NB + jj * 4 + cc) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int m = 16 * mi + 4 * kg + r;
+      if (m < a.M)
+        *reinterpret_cast<float4 *>(wp + (size_t)m * a.N + n0 + 64 * jj + 4 * i16) = make_float4(c4[0][r], c4[1][r], c4[2][r], c4[3][r]);
+    }
+  }
+}
+// C = sum over K slices of ws, in slice order.  One thread per float4 of C and group of slices; groups combined through LDS.
+__global__ __launch_bounds__(256) void k_skinny_nn_reduce(SkinnyNnArgs a) {
+  __shared__ float4 red[8][32];
+  const int tid = threadIdx.x, el = tid & 31, grp = tid >> 5;        // 32 float4 of C per workgroup, 8 slice groups
+  const size_t e4 = (size_t)blockIdx.x * 32 + el, tot4 = (size_t)a.M * a.N / 4;
+  const int per = (a.nks + 7) / 8, s0 = grp * per, s1 = min(a.nks, s0 + per);
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e4 < tot4)
+    for (int s = s0; s < s1; s++) {
+      const float4 v = *reinterpret_cast<const float4 *>(a.ws + ((size_t)s * tot4 + e4) * 4);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+  red[grp][el] = sum;
+  __syncthreads();
+  if (grp == 0 && e4 < tot4) {
+    float4 t = red[0][el];
+#pragma unroll
+    for (int g = 1; g < 8; g++) { t.x += red[g][el].x; t.y += red[g][el].y; t.z += red[g][el].z; t.w += red[g][el].w; }
+    const size_t m = e4 * 4 / a.N, n = e4 * 4 % a.N;
+    *reinterpret_cast<float4 *>(a.Cm + m * a.ldc + n) = t;
+  }
+}
+
+// K slices: groups of 8 rows over wave slots of 8 groups (+ 1 for the first `rem` slots), at most 256 workgroups
+static bool skinny_nn_plan(int N, int K, int *nks, int *rem) {
+  const int noct = K / 8, nr = N / 128, max_slots = 4 * (256 / nr);
+  int slots = (noct + 7) / 8;
+  *rem = 0;
+  if (slots > max_slots) { slots = max_slots; *rem = noct - 8 * slots; }
+  *nks = (slots + 3) / 4;
+  return *rem <= slots;
+}
+bool skinny_nn_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *Cm, int ldc) {
+  int nks, rem;
+  return g_fold_direct != 0 && M >= 1 && M <= 80 && N % 128 == 0 && N <= 1024 && K >= 4096 && K % 8 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+         ldc % 4 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(Cm)) & 15) == 0 &&
+         skinny_nn_plan(N, K, &nks, &rem);
+}
+size_t skinny_nn_workspace_floats(int M, int N, int K) {
+  int nks, rem;
+  skinny_nn_plan(N, K, &nks, &rem);
+  return (size_t)nks * M * N;
+}
+hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc, float *ws,
+                            hipStream_t st) {
+  int nks, rem;
+  if (!skinny_nn_plan(N, K, &nks, &rem)) return hipErrorInvalidValue;
+  SkinnyNnArgs a{M, N, K, A, lda, B, ldb, ws, nks, Cm, ldc, rem};
+  const int mi = (M + 15) / 16;
+  const dim3 grid((N / 128) * a.nks), block(256);
+  const size_t shm = (size_t)4 * 3 * (mi * 8 / 4) * 64 * sizeof(f32x4) > (size_t)mi * 8 * 64 * sizeof(f32x4)
+                         ? (size_t)4 * 3 * (mi * 8 / 4) * 64 * sizeof(f32x4) : (size_t)mi * 8 * 64 * sizeof(f32x4);
+#define SK_GO(MI_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_skinny_nn<MI_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+                        hipLaunchKernelGGL((k_skinny_nn<MI_>), grid, block, shm, st, a); } while (0)
+  switch (mi) {
+    case 1: SK_GO(1); break;
+    case 2: SK_GO(2); break;
+    case 3: SK_GO(3); break;
+    case 4: SK_GO(4); break;
+    case 5: SK_GO(5); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef SK_GO
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(k_skinny_nn_reduce, dim3((unsigned)(((size_t)M * N / 4 + 31) / 32)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 static int g_nt_ni = 2, g_nt_waves = 1;   //    // measured at 80 x 16624 x 512 (tools/nt_sweep.py): 29.5 us; 1x1 36.7, 2x2 34.0, 4x1 49.4; tiled kernel 37.9
 void set_direct_nt_shape(int ni, int waves) { g_nt_ni = ni == 1 || ni == 2 ? ni : 4; g_nt_waves = waves >= 1 && waves <= 4 ? waves : 2; }
 

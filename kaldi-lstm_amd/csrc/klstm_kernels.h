@@ -128,6 +128,11 @@ struct GradsUpdate {
   // optional: the bf16 planes of the fold operands (fold_bf16x3_planes) are written from the updated W_gifo_r / W_r_m too
   unsigned short *a3 = nullptr, *b3 = nullptr; long a_plane = 0, b_plane = 0;
 };
+// C = A B for few rows, a narrow result and a long contraction (klstm_fold.hip: the output layer's in_diff); ws holds one partial per K slice
+bool skinny_nn_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *Cm, int ldc);
+size_t skinny_nn_workspace_floats(int M, int N, int K);
+hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc, float *ws,
+                            hipStream_t st);
 // C = A B^T + bias on the bf16 pipe (both operands rounded, fp32 accumulate): the batched x-projection of the bf16 operand mode
 bool gemm_bf16_nt_supported(int M, int K, const float *A, int lda, const float *B, int ldb);
 hipError_t launch_gemm_bf16_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
