@@ -858,11 +858,15 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
     HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
                         probe(e, "k_grads_update"), false, &u, e->pctrl));
   } else {
-    e->planes_fresh = false;
     const float *fold_grad = e->mmt_pending ? e->grads : nullptr;
     e->mmt_pending = false;
+    // (data-parallel order: gradient -> all-reduce -> this) the planes of the fold operands come out of the same pass
+    GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
+    e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d) &&
+                      update_repack_vectorised(d, e->params, e->corr, fold_grad, e->wrT, e->wmT, e->wxT);
+    if (e->planes_fresh) fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
-                                e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl));
+                                e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr));
   }
   // (Packing the BPTT operands on a second stream, overlapped with the next forward pass, was measured to cost
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)

@@ -149,7 +149,10 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
 //   lr == 0 && !grad: pure repack (after klstm_set_params)
 hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_blob, const float *grad_blob,
                                 float mmt, float lr, float clip, float *wrT, float *wmT, float *wxT,
-                                hipStream_t st, LaunchProbe pr = {}, const unsigned *guard = nullptr);
+                                hipStream_t st, LaunchProbe pr = {}, const unsigned *guard = nullptr,
+                                const GradsUpdate *planes = nullptr);   // planes->a3 / b3: also write the fold operands' bf16 planes (vector kernel only)
+bool update_repack_vectorised(const Dims &d, const float *param_blob, const float *corr_blob, const float *grad_blob, const float *wrT,
+                              const float *wmT, const float *wxT);
 // guard (both): the two status words of the persistent chain (ctrl[2], ctrl[6]); when either is non-zero the kernels return
 // without touching anything -- a minibatch whose chain gave up must not reach the momentum buffers or the parameters
 

@@ -2224,6 +2224,9 @@ struct UpdArgs {
   int tb[3];                // first block of matrix i;  vector blocks start at tb_vec
   int tb_vec;
   long voff, vlen;          // vector parameters (bias + 3 peepholes) are contiguous in the blob
+  // optional (vector kernel): the three bf16 planes of the fold operands, written from the same tiles (klstm_fold3.hip):
+  // a3 in W_gifo_r's own layout (matrix 1), b3 in W_r_m^T's (matrix 2, the transposed destination's)
+  unsigned short *a3, *b3; long a_plane, b_plane;
 };
 
 __device__ __forceinline__ float upd_elem(const UpdArgs &a, long idx) {
@@ -2310,7 +2313,13 @@ __global__ __launch_bounds__(256) void k_update_repack_v(UpdArgs a) {
     const int p = tid + 256 * u, rl = p >> 4, cq = (p & 15) * 4;
     const int r = by + rl, c = bx + cq;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows && c + 4 <= cols) v = upd_vec(a, a.off[mi] + (long)r * cols + c);
+    if (r < rows && c + 4 <= cols) {
+      v = upd_vec(a, a.off[mi] + (long)r * cols + c);
+      if (mi == 1 && a.a3) {
+        const float v4[4] = {v.x, v.y, v.z, v.w};
+        bf16_split3_store4(v4, a.a3 + (size_t)r * cols + c, a.a_plane);
+      }
+    }
     *reinterpret_cast<float4 *>(tile + rl * 68 + cq) = v;
   }
   __syncthreads();
@@ -2321,7 +2330,9 @@ __global__ __launch_bounds__(256) void k_update_repack_v(UpdArgs a) {
     const int c = bx + cl, r = by + rq;       // dst[c][r .. r+3]
     if (c < cols && r + 4 <= rows) {
       const float *tp = tile + rq * 68 + cl;
-      *reinterpret_cast<float4 *>(dst + (size_t)c * rows + r) = make_float4(tp[0], tp[68], tp[2 * 68], tp[3 * 68]);
+      const float v4[4] = {tp[0], tp[68], tp[2 * 68], tp[3 * 68]};
+      *reinterpret_cast<float4 *>(dst + (size_t)c * rows + r) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+      if (mi == 2 && a.b3) bf16_split3_store4(v4, a.b3 + (size_t)c * rows + r, a.b_plane);
     }
   }
 }
@@ -3156,12 +3167,18 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
   KLAUNCH(k_grads, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
 }
 
+bool update_repack_vectorised(const Dims &d, const float *param_blob, const float *corr_blob, const float *grad_blob, const float *wrT,
+                              const float *wmT, const float *wxT) {
+  return d.C % 4 == 0 && d.R % 4 == 0 && d.I % 4 == 0 && aligned16(param_blob) && aligned16(corr_blob) &&
+         (!grad_blob || aligned16(grad_blob)) && aligned16(wrT) && aligned16(wmT) && aligned16(wxT);
+}
 hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_blob, const float *grad_blob,
                                 float mmt, float lr, float clip, float *wrT, float *wmT, float *wxT,
-                                hipStream_t st, LaunchProbe pr, const unsigned *guard) {
+                                hipStream_t st, LaunchProbe pr, const unsigned *guard, const GradsUpdate *planes) {
   const int C = d.C, R = d.R, I = d.I;
   UpdArgs a;
   a.guard = guard;
+  a.a3 = a.b3 = nullptr; a.a_plane = a.b_plane = 0;
   a.param = param_blob; a.corr = corr_blob; a.grad = grad_blob; a.mmt = mmt; a.lr = lr; a.clip = clip;
   a.touch = (lr != 0.f || grad_blob != nullptr || clip > 0.f) ? 1 : 0;
   const long o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_wm = o_b + 7 * C;
@@ -3176,6 +3193,7 @@ hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_bl
   for (int i = 0; i < 3; i++) { a.tb[i] = nb; nb += cdiv(a.rows[i], tsz) * cdiv(a.cols[i], tsz); }
   a.tb_vec = nb;
   nb += cdiv(7 * C, 1024);
+  if (vec && planes) { a.a3 = planes->a3; a.b3 = planes->b3; a.a_plane = planes->a_plane; a.b_plane = planes->b_plane; }
   if (vec) KLAUNCH(k_update_repack_v, dim3(nb), dim3(256), st, pr, a);
   KLAUNCH(k_update_repack, dim3(nb), dim3(256), st, pr, a);
 }
