@@ -245,6 +245,9 @@ def main():
                     help="engine option 'graph': hipGraph replay per call (robust against a busy host thread) or plain "
                          "stream launches (no fixed cost per graph launch); auto = time both before the warm-up, keep the faster")
     ap.add_argument("--option", action="append", default=[], help="engine option key=value (A/B experiments), repeatable")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="one rank, but through the N > 1 code path: gradient -> klstm_allreduce_grads on a 1-rank RCCL communicator -> "
+                         "momentum -> two-launch Update (what every rank of a multi-GPU run executes, minus the wire)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,9 +258,10 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -300,7 +304,7 @@ def main():
     in_diff = torch.empty(T_BPTT * S, I_DIM, device="cuda")
     # N>1: one all-reduce (sum, fp32) of the 8.73 MB gradient blob per minibatch, issued by libklstm.so itself (RCCL); a run
     # on several GPUs that cannot make the library-owned communicator fails instead of silently measuring something else
-    dp = k.DataParallelLstm(eng, require_native=world > 1)
+    dp = k.DataParallelLstm(eng, force_collective=args.force_collective, require_native=world > 1 or args.force_collective)
     torch.cuda.synchronize()
 
     def step(i):
@@ -488,7 +492,7 @@ def main():
                                       else "reference-shaped (gates + projection, d_r + d_m kernels per step)"),
                        "update": ("gradient products + momentum + Update as one pass (klstm_backpropagate with KLSTM_BPTT_FUSE_UPDATE: the "
                                   "Update follows immediately, as in Kaldi's Component::Backpropagate)" if "k_grads_update" in kern else
-                                  "gradient products, all-reduce, momentum + Update" if world > 1 else "gradient products, then Update"),
+                                  "gradient products, all-reduce, momentum + Update" if (world > 1 or args.force_collective) else "gradient products, then Update"),
                        "parallelism": "dp%d over streams, 1 all-reduce/minibatch" % world if world > 1 else "single GPU",
                        "collective": dp.collective_name, "ranks_seen": dp.ranks_seen},
             "timed": {"steps": nsteps_total, "seconds": dt_total},
@@ -509,8 +513,9 @@ def main():
             res["cpu_baseline"] = cpu_baseline(S, args.cpu_seconds)
         print(json.dumps(res))
     eng.close()
-    if world > 1:
-        dist.barrier()
+    if dist is not None:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 
