@@ -374,6 +374,9 @@ struct SkinnyNnArgs {
   float *ws; int nks;
   float *Cm; int ldc;
   int rem;                // the first `rem` wave slots (K slice * 4 + wave) take a ninth group of 8 rows
+#ifdef KLSTM_SKINNY_TIMING
+  long long *dbg;         // per workgroup: shader clocks entry -> loads issued -> MFMAs done -> exit (tools/skinny_probe.hip)
+#endif
 };
 __device__ __forceinline__ float4 keep4(const float4 &v, bool c) {      // zero without a select the compiler could turn into a branch around the load
   const unsigned m = c ? 0xffffffffu : 0u;
@@ -387,6 +390,9 @@ __global__ __launch_bounds__(256) void k_skinny_nn(SkinnyNnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kg = lane >> 4;
   const int nr = a.N / 128, n0 = ((int)blockIdx.x % nr) * 128, ks = (int)blockIdx.x / nr;
+#ifdef KLSTM_SKINNY_TIMING
+  const long long t_c0 = clock64(), t_w0 = wall_clock64();
+#endif
   // rows of B: wave slot s = 4 ks + wave takes 64 rows (two chunks of 32) from row 8 (8 s + min(s, rem)), the first `rem` slots 8
   // more -- so that a contraction that is not a multiple of 256 x 64 slices (16624 = 2078 groups of 8 over 256 slots) still
   // fits ONE round of workgroups: with 65 slices of 256 rows the 4 workgroups of the 65th ran alone behind the other 256
@@ -428,6 +434,9 @@ __global__ __launch_bounds__(256) void k_skinny_nn(SkinnyNnArgs a) {
       rb[c][e][1] = *reinterpret_cast<const float4 *>(p + 64);
     }
   }
+#ifdef KLSTM_SKINNY_TIMING
+  const long long t_c1 = clock64();
+#endif
   __builtin_amdgcn_sched_barrier(0);                 // ALL 2 x (2 MI + 16) loads are in flight before the first MFMA (left alone, hipcc sinks
                                                      //  them between the MFMAs two at a time: one memory latency per pair, 39 us)
   f32x4 acc[MI][NB];
@@ -474,6 +483,10 @@ __global__ __launch_bounds__(256) void k_skinny_nn(SkinnyNnArgs a) {
       }
     }
   }
+#ifdef KLSTM_SKINNY_TIMING
+  __builtin_amdgcn_sched_barrier(0);
+  const long long t_c2 = clock64();
+#endif
   // ---- the four waves' tiles -> one: block q = mi * 8 + nb belongs to wave q & 3; source s hands it to owner o in slot s - (s > o)
 #pragma unroll
   for (int mi = 0; mi < MI; mi++)
@@ -518,6 +531,12 @@ __global__ __launch_bounds__(256) void k_skinny_nn(SkinnyNnArgs a) {
         *reinterpret_cast<float4 *>(wp + (size_t)m * a.N + n0 + 64 * jj + 4 * i16) = make_float4(c4[0][r], c4[1][r], c4[2][r], c4[3][r]);
     }
   }
+#ifdef KLSTM_SKINNY_TIMING
+  if (lane == 0) {
+    long long *q = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+    q[0] = t_c1 - t_c0; q[1] = t_c2 - t_c1; q[2] = clock64() - t_c2; q[3] = wall_clock64() - t_w0; q[4] = t_w0;
+  }
+#endif
 }
 // C = sum over K slices of ws, in slice order.  One thread per float4 of C and group of slices; groups combined through LDS.
 __global__ __launch_bounds__(256) void k_skinny_nn_reduce(SkinnyNnArgs a) {
@@ -542,6 +561,9 @@ __global__ __launch_bounds__(256) void k_skinny_nn_reduce(SkinnyNnArgs a) {
   }
 }
 
+#ifdef KLSTM_SKINNY_TIMING
+static long long *g_skinny_dbg = nullptr;
+#endif
 // K slices: groups of 8 rows over wave slots of 8 groups (+ 1 for the first `rem` slots), at most 256 workgroups
 static bool skinny_nn_plan(int N, int K, int *nks, int *rem) {
   const int noct = K / 8, nr = N / 128, max_slots = 4 * (256 / nr);
@@ -566,7 +588,11 @@ hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const 
                             hipStream_t st) {
   int nks, rem;
   if (!skinny_nn_plan(N, K, &nks, &rem)) return hipErrorInvalidValue;
+#ifdef KLSTM_SKINNY_TIMING
+  SkinnyNnArgs a{M, N, K, A, lda, B, ldb, ws, nks, Cm, ldc, rem, g_skinny_dbg};
+#else
   SkinnyNnArgs a{M, N, K, A, lda, B, ldb, ws, nks, Cm, ldc, rem};
+#endif
   const int mi = (M + 15) / 16;
   const dim3 grid((N / 128) * a.nks), block(256);
   const size_t shm = (size_t)4 * 3 * (mi * 8 / 4) * 64 * sizeof(f32x4) > (size_t)mi * 8 * 64 * sizeof(f32x4)
