@@ -31,6 +31,7 @@
 #include "klstm_math.h"
 
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 namespace klstm {
 
@@ -614,8 +615,137 @@ hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same NT product with the M rows of A SHARED by the four waves of a workgroup through LDS (AffineTransform::PropagateFnc of
+// the output layer, 80 x 16624 over K = 512): k_direct_nt makes every wave fetch all of A itself, so either half the SIMDs idle
+// (two 16-column blocks per wave: 520 waves, 41 k MFMA clocks each) or every CU pulls 650 KB (one block per wave) -- and a CU
+// ingests 30-55 GB/s.  Here a workgroup = 4 waves x one 16-column block; per 32-k chunk the 256 threads
+// stage the 10 KB of A once (global -> registers two chunks ahead -> LDS, rows padded to 36 floats: the operand reads of 16
+// rows x 4 k-groups are conflict-free), ONE barrier per chunk, two LDS buffers; B stays register-direct with a ring of 4 chunks.
+// Per CU: 160 KB of A + 128 KB of B instead of 448-650 KB.  (Round 2 tried this with one chunk of lead and measured 48 us: the
+// loads need the depth they have here.)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MI>
+__global__ __launch_bounds__(256) void k_nt_shared_a(DirectNtArgs a) {
+  constexpr int LDA = 36, ROWS = 16 * MI, UNITS = ROWS * 8, NH = (UNITS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float As[4][ROWS * LDA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int nchunk = a.K / 32;
+  // A staging units of this thread: (row, 16-byte piece of the 128-byte chunk row)
+  const float *gsrc[NH];
+  int ldst[NH];
+  bool gon[NH];
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    const int u = tid + 256 * h, row = u >> 3, pc = u & 7;
+    gon[h] = u < UNITS && row < a.M;
+    gsrc[h] = a.A + (size_t)(gon[h] ? row : 0) * a.lda + 4 * pc;
+    ldst[h] = u < UNITS ? row * LDA + 4 * pc : -1;
+  }
+  // One pass over K for this wave's column block nbk (16 columns from 16 * nbk) and the row blocks [m_lo, m_lo + NM) of A.
+  // All four waves run the same barrier sequence; a wave without work (nbk < 0) stages A and multiplies nothing.
+  auto kpass = [&](int nbk, int m_lo, auto NMC) {
+    constexpr int NM = decltype(NMC)::value;
+    const int nb = 16 * (nbk < 0 ? 0 : nbk) + i16;
+    const float *bp = a.B + (size_t)(nb < a.N ? nb : 0) * a.ldb + 8 * kg;
+    float4 ga[4][NH], rb[8][2];                       // A: 3 chunks of lead (+ the one in LDS), B: 7
+    auto loadA = [&](int slot, int c) {
+#pragma unroll
+      for (int h = 0; h < NH; h++) ga[slot][h] = *reinterpret_cast<const float4 *>(gsrc[h] + 32 * c);
+    };
+    auto stashA = [&](int slot, int buf) {
+#pragma unroll
+      for (int h = 0; h < NH; h++)
+        if (ldst[h] >= 0) *reinterpret_cast<float4 *>(&As[buf][ldst[h]]) = keep4(ga[slot][h], gon[h]);
+    };
+    auto loadB = [&](int slot, int c) {
+      rb[slot][0] = *reinterpret_cast<const float4 *>(bp + 32 * c);
+      rb[slot][1] = *reinterpret_cast<const float4 *>(bp + 32 * c + 4);
+    };
+    f32x4 acc[NM];
+#pragma unroll
+    for (int mi = 0; mi < NM; mi++) acc[mi] = (f32x4){0, 0, 0, 0};
+    // Pipeline (chunk = 32 k): global request of A four chunks ahead and of B seven; A chunk c + 2 goes into LDS buffer (c + 2) & 3
+    // during step c, the operand registers of chunk c + 1 are read from LDS during step c (before the MFMAs of chunk c, which
+    // run on the other register set), ONE barrier per step.  (Operands read at the top of their own step: 20 us at 141
+    // workgroups -- an LDS round trip and a barrier in front of every 40 MFMAs.)
+#pragma unroll
+    for (int d = 0; d < 4; d++) loadA(d, d < nchunk ? d : nchunk - 1);
+#pragma unroll
+    for (int d = 0; d < 7; d++) loadB(d, d < nchunk ? d : nchunk - 1);
+    stashA(0, 0);
+    stashA(1, 1);
+    __syncthreads();
+    float4 av0[NM][2], av1[NM][2];
+    auto readA = [&](float4 (&av)[NM][2], int buf) {
+      const float *ab = As[buf] + (m_lo * 16 + i16) * LDA + 8 * kg;
+#pragma unroll
+      for (int mi = 0; mi < NM; mi++) {
+        av[mi][0] = *reinterpret_cast<const float4 *>(ab + mi * 16 * LDA);
+        av[mi][1] = *reinterpret_cast<const float4 *>(ab + mi * 16 * LDA + 4);
+      }
+    };
+    readA(av0, 0);
+    auto step = [&](int c, auto JC, float4 (&cur)[NM][2], float4 (&nxt)[NM][2]) {   // J = c & 7 at compile time: register ring slots must
+      constexpr int J = decltype(JC)::value;                                        // be static (runtime slots: rings in scratch, 61 us)
+      // (unconditional requests, the chunk index clamped: a request under a condition makes hipcc drain the whole queue at its
+      //  next use; the last ones re-read the last chunk and are never used)
+      loadA(J & 3, c + 4 < nchunk ? c + 4 : nchunk - 1);
+      loadB((J + 7) & 7, c + 7 < nchunk ? c + 7 : nchunk - 1);
+      readA(nxt, (J + 1) & 3);
+      const float bv[8] = {rb[J][0].x, rb[J][0].y, rb[J][0].z, rb[J][0].w, rb[J][1].x, rb[J][1].y, rb[J][1].z, rb[J][1].w};
+      if (nbk >= 0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+#pragma unroll
+          for (int mi = 0; mi < NM; mi++) {
+            const float4 &q = cur[mi][e >> 2];
+            acc[mi] = MFMA16((e & 3) == 0 ? q.x : (e & 3) == 1 ? q.y : (e & 3) == 2 ? q.z : q.w, bv[e], acc[mi]);
+          }
+      }
+      stashA((J + 2) & 3, (J + 2) & 3);                // chunk c + 2 (requested two steps ago); its buffer held chunk c - 2
+      __syncthreads();
+    };
+    for (int c0 = 0; c0 < nchunk; c0 += 8) {           // K % 256 == 0
+      step(c0, std::integral_constant<int, 0>(), av0, av1);
+      step(c0 + 1, std::integral_constant<int, 1>(), av1, av0);
+      step(c0 + 2, std::integral_constant<int, 2>(), av0, av1);
+      step(c0 + 3, std::integral_constant<int, 3>(), av1, av0);
+      step(c0 + 4, std::integral_constant<int, 4>(), av0, av1);
+      step(c0 + 5, std::integral_constant<int, 5>(), av1, av0);
+      step(c0 + 6, std::integral_constant<int, 6>(), av0, av1);
+      step(c0 + 7, std::integral_constant<int, 7>(), av1, av0);
+    }
+    if (nbk < 0 || nb >= a.N) return;
+    const float bias = a.bias ? a.bias[nb] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < NM; mi++) {
+      const float e[4] = {acc[mi].x, acc[mi].y, acc[mi].z, acc[mi].w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = 16 * (m_lo + mi) + 4 * kg + r;
+        if (m < a.M) a.Cm[(size_t)m * a.ldc + nb] = e[r] + bias;
+      }
+    }
+  };
+  // main pass: column block 4 * workgroup + wave, all row blocks.  The 16-column blocks beyond 4 x (number of workgroups)
+  // -- 16624 columns = 1039 blocks against 1024 SIMDs: a 1025th..1039th wave would double the kernel -- are cut into
+  // (block, row block) units and handed out as ONE extra unit to the first waves: 6/5 of the time instead of 2x.
+  const int slot = (int)blockIdx.x * 4 + wave, nb_main = (int)gridDim.x * 4, nb_total = (a.N + 15) / 16;
+  kpass(slot < nb_total ? slot : -1, 0, std::integral_constant<int, MI>());
+  const int xunits = (nb_total - nb_main) * MI;
+  if ((int)blockIdx.x * 4 >= xunits) return;           // (workgroup-uniform)
+  kpass(slot < xunits ? nb_main + slot / MI : -1, slot < xunits ? slot % MI : 0, std::integral_constant<int, 1>());
+}
+
+static int g_nt_shared = 1;
 static int g_nt_ni = 2, g_nt_waves = 1;   //    // measured at 80 x 16624 x 512 (tools/nt_sweep.py): 29.5 us; 1x1 36.7, 2x2 34.0, 4x1 49.4; tiled kernel 37.9
-void set_direct_nt_shape(int ni, int waves) { g_nt_ni = ni == 1 || ni == 2 ? ni : 4; g_nt_waves = waves >= 1 && waves <= 4 ? waves : 2; }
+void set_direct_nt_shape(int ni, int waves) {       // ni = 0, waves = 0 (option value 0): wide results on k_direct_nt again, not on k_nt_shared_a (A-B)
+  g_nt_shared = (ni == 0 && waves == 0) ? 0 : (ni == 9 && waves == 9) ? 2 : 1;     // 99: k_nt_shared_a at every width
+  if (g_nt_shared != 1) return;
+  g_nt_ni = ni == 1 || ni == 2 ? ni : 4; g_nt_waves = waves >= 1 && waves <= 4 ? waves : 2;
+}
 
 bool direct_nt_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb) {
   return g_fold_direct != 0 && M >= 1 && M <= 80 && N >= 64 && K % (32 * FD) == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
@@ -643,6 +773,28 @@ hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const 
   // columns per wave (16*NI) and waves per workgroup: experiment knobs (g_nt_ni, g_nt_waves)
   const int ni = g_nt_ni, nw = g_nt_waves;
   const dim3 grid((N + 16 * ni * nw - 1) / (16 * ni * nw)), block(64 * nw);
+  // wide result: A shared through LDS -- where it measured faster (tools/t_affprop.py, 80 rows over K = 512): 9000 columns 20.6 vs
+  // 26.6 us; at the output layer's 16624 columns (1039 blocks on 1024 SIMDs) 28.2-30.7 vs 29.5 us for every variant tried (staging
+  // depth 2/3 or 4/7 chunks, operands read one step ahead, the blocks past 1024 as extra (block, row block) units): no gain, so
+  // that width stays on k_direct_nt unless the option asks (direct_nt_shape = 99)
+  if (N > 8192 && K % 256 == 0 && g_nt_shared && (N <= 14336 || g_nt_shared == 2)) {
+    const int nbt = (N + 15) / 16, mi_ = (M + 15) / 16;
+    int wgs = (nbt + 3) / 4;
+    if (wgs > 256 && (nbt - 1024) * mi_ <= 1024) wgs = 256;      // the blocks past 1024 go out as extra (block, row block) units
+    const dim3 grid(wgs), block(256);
+#define SA_GO(MI_) do { if (pr.start) hipExtLaunchKernelGGL((k_nt_shared_a<MI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
+                        else hipLaunchKernelGGL((k_nt_shared_a<MI_>), grid, block, 0, st, a); } while (0)
+    switch ((M + 15) / 16) {
+      case 1: SA_GO(1); break;
+      case 2: SA_GO(2); break;
+      case 3: SA_GO(3); break;
+      case 4: SA_GO(4); break;
+      case 5: SA_GO(5); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef SA_GO
+    return hipGetLastError();
+  }
 #define NT_GO(MI_, NI_) do { if (pr.start) hipExtLaunchKernelGGL((k_direct_nt<MI_, NI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
                              else hipLaunchKernelGGL((k_direct_nt<MI_, NI_>), grid, block, 0, st, a); } while (0)
 #define NT_CASE(MI_)                                                                                   \

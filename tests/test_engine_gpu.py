@@ -436,7 +436,8 @@ def test_time_shift_and_transmit(rows, cols, shift, pad):
 @pytest.mark.parametrize("N,K,M", [(80, 512, 1000), (12, 24, 37), (640, 32, 129),
                                    (12, 24, 2100), (80, 512, 4203),     # long output axis: split-K in_diff (last slice ragged)
                                    (24, 64, 16624),                     # the reference's output layer width: row-in-registers softmax / xent
-                                   (80, 512, 16624), (37, 128, 4104)])  # few rows, narrow in_diff, long contraction: k_skinny_nn (ragged last K slice)
+                                   (80, 512, 16624), (37, 128, 4104),   # few rows, narrow in_diff, long contraction: k_skinny_nn (ragged last K slice)
+                                   (80, 512, 9000), (37, 256, 12296)])  # wide propagate with A shared through LDS: k_nt_shared_a (ragged last block)
 def test_affine_softmax_xent_tail(N, K, M):
     """AffineTransform fwd/bwd/update, Softmax and Xent::EvalMasked (nnet-loss.cc:76-142) vs numpy restatements.
     Tolerances: fp32 GEMMs with K-ordered MFMA sums vs numpy's BLAS: 2e-5 of the tensor maximum."""

@@ -1,0 +1,23 @@
+"""Device time of klstm_affine_propagate (few rows, wide layer) -- k_nt_shared_a against k_direct_nt (option direct_nt_shape = 0)."""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kaldi_lstm_amd as k
+s = torch.cuda.Stream()
+e = k.Engine(40, 64, 32, 4)
+def t(label, x, W, b, out):
+    with torch.cuda.stream(s):
+        for _ in range(5): k.affine_propagate(x, W, b, out, s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(50): k.affine_propagate(x, W, b, out, s)
+        e1.record(s); e1.synchronize()
+        print("%-44s %.1f us" % (label, e0.elapsed_time(e1) / 50 * 1e3), flush=True)
+for N, K, M in ((80, 512, 16624), (37, 512, 16624), (80, 256, 16624), (80, 512, 9000)):
+    x = torch.randn(N, K, device="cuda"); W = torch.randn(M, K, device="cuda") * 0.1; b = torch.randn(M, device="cuda"); out = torch.empty(N, M, device="cuda")
+    torch.cuda.synchronize()
+    e.set_option("direct_nt_shape", 99)
+    t("rows %d in %d out %d: A shared in LDS" % (N, K, M), x, W, b, out)
+    ref = out.clone()
+    e.set_option("direct_nt_shape", 0)
+    t("rows %d in %d out %d: register-direct" % (N, K, M), x, W, b, out)
+    print("   max |difference| %.2e of %.1f; vs torch %.2e" % ((ref - out).abs().max().item(), out.abs().max().item(), (ref - (x @ W.T + b)).abs().max().item()))
