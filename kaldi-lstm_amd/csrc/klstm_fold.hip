@@ -717,6 +717,30 @@ __global__ __launch_bounds__(256) void k_nt_shared_a(DirectNtArgs a) {
       step(c0 + 6, std::integral_constant<int, 6>(), av0, av1);
       step(c0 + 7, std::integral_constant<int, 7>(), av1, av0);
     }
+    if (NM == MI) {
+      // main pass: the workgroup's 16 MI x 64 result tile goes through LDS (the staging buffers are free behind the last barrier)
+      // and leaves as 16-byte pieces, 256 contiguous bytes per row -- lane-per-element stores write 64-byte half lines
+      float *cs = &As[0][0];                           // [ROWS][68]
+      const float bias = (nbk >= 0 && nb < a.N && a.bias) ? a.bias[nb] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < NM; mi++) {
+        const float e[4] = {acc[mi].x, acc[mi].y, acc[mi].z, acc[mi].w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) cs[(16 * mi + 4 * kg + r) * 68 + wave * 16 + i16] = e[r] + bias;
+      }
+      __syncthreads();
+      const int c0 = (int)blockIdx.x * 64;
+      for (int u = tid; u < ROWS * 16; u += 256) {
+        const int m = u >> 4, cq = (u & 15) * 4, n = c0 + cq;
+        if (m >= a.M || n >= a.N) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(cs + m * 68 + cq);
+        float *dp = a.Cm + (size_t)m * a.ldc + n;
+        if (n + 4 <= a.N && (a.ldc & 3) == 0) *reinterpret_cast<float4 *>(dp) = v;
+        else { const float ev[4] = {v.x, v.y, v.z, v.w}; for (int q = 0; q < 4 && n + q < a.N; q++) dp[q] = ev[q]; }
+      }
+      __syncthreads();                                 // (the extra pass stages into the same buffers)
+      return;
+    }
     if (nbk < 0 || nb >= a.N) return;
     const float bias = a.bias ? a.bias[nb] : 0.f;
 #pragma unroll
