@@ -164,6 +164,25 @@ klstm_status klstm_comm_count(void *comm, int *nranks);       /* ncclCommCount: 
 klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm);
 klstm_status klstm_allreduce_buffer(float *buf_dev, size_t n, void *rccl_comm, void *hip_stream);
 
+/* One-shot all-reduce over peer-mapped blobs (kaldi-lstm_amd/csrc/klstm_oneshot.hip).  PREPARED AND OFF: nothing in
+ * the library calls it, and it has never run across devices (one-GPU lease) -- only as a 1-rank self-loop and between two
+ * processes on one GPU.  Every rank: create (its own blob of n floats, hipMalloc memory), export two handles, hand them to every
+ * peer by any means, connect with everybody's handles in rank order, then once per minibatch klstm_oneshot_allreduce (in place,
+ * on hip_stream; all ranks, same order).  Sums are added in rank order by ONE rank per 1/N slice: bit-identical on all ranks.
+ * Every wait is bounded (timeout_ms, default 2000); klstm_oneshot_status reads 0 or the phase that expired (after a stream
+ * synchronisation). */
+typedef struct klstm_oneshot klstm_oneshot;
+typedef struct { unsigned char bytes[80]; } klstm_ipc_handle;     /* hipIpcMemHandle_t of the allocation + the blob's offset in it */
+klstm_status klstm_oneshot_create(int device, float *blob_dev, long n, klstm_oneshot **out);
+klstm_status klstm_oneshot_export(klstm_oneshot *g, klstm_ipc_handle *blob, klstm_ipc_handle *flags);
+klstm_status klstm_oneshot_connect(klstm_oneshot *g, int rank, int nranks, const klstm_ipc_handle *blobs, const klstm_ipc_handle *flags);
+klstm_status klstm_oneshot_allreduce(klstm_oneshot *g, void *hip_stream, int timeout_ms);
+klstm_status klstm_oneshot_status(klstm_oneshot *g, unsigned *status);
+klstm_status klstm_oneshot_destroy(klstm_oneshot *g);
+const char *klstm_oneshot_last_error(void);
+/* on the engine's stream, behind its gradient products (the group was created on klstm_grad_blob_ptr(engine)) */
+klstm_status klstm_allreduce_grads_oneshot(klstm_engine *e, klstm_oneshot *group, int timeout_ms);
+
 /* DP mode only, after the all-reduce of klstm_grad_blob():  corr = momentum*corr + grad. */
 klstm_status klstm_apply_momentum(klstm_engine *e, float momentum);
 

@@ -6,7 +6,7 @@ This Python package is plumbing over that ABI for tests, bench.py and torch.dist
 launch; it contains no arithmetic and NO CPU fallback: if the library or a GPU is missing,
 calls raise.
 """
-from .binding import (Engine, KlstmError, RcclComm, lib_path, load_library, time_shift, affine_propagate,  # noqa: F401
+from .binding import (Engine, KlstmError, RcclComm, OneshotAllreduce, lib_path, load_library, time_shift, affine_propagate,  # noqa: F401
                       affine_backpropagate, affine_update, affine_gradient, sgd_momentum_update, softmax,
                       xent_eval_masked, xent_eval_masked_post, DEFER_MOMENTUM)
 from .batcher import MultiStreamBatcher  # noqa: F401,E402

@@ -84,6 +84,14 @@ def load_library():
     lib.klstm_sgd_momentum_update.argtypes = [P, P, P, ctypes.c_long, F, F, P]
     lib.klstm_xent_eval_masked.argtypes = [P, I, I, I, P, P, P, I, P, P, P]
     lib.klstm_xent_eval_masked_post.argtypes = [P, I, I, I, P, P, P, P, P, I, P, P, P, P]
+    lib.klstm_oneshot_create.argtypes = [I, P, ctypes.c_long, ctypes.POINTER(P)]
+    lib.klstm_oneshot_export.argtypes = [P, P, P]
+    lib.klstm_oneshot_connect.argtypes = [P, I, I, P, P]
+    lib.klstm_oneshot_allreduce.argtypes = [P, P, I]
+    lib.klstm_oneshot_status.argtypes = [P, ctypes.POINTER(ctypes.c_uint)]
+    lib.klstm_oneshot_destroy.argtypes = [P]
+    lib.klstm_oneshot_last_error.restype = ctypes.c_char_p
+    lib.klstm_allreduce_grads_oneshot.argtypes = [P, P, I]
     lib.klstm_comm_get_unique_id.argtypes = [P]
     lib.klstm_comm_init_rank.argtypes = [I, I, I, P, ctypes.POINTER(P)]
     lib.klstm_comm_destroy.argtypes = [P]
@@ -332,6 +340,52 @@ class RcclComm:
             self.close()
         except Exception:
             pass
+
+
+class OneshotAllreduce:
+    """klstm_oneshot_*: the one-shot all-reduce over peer-mapped blobs (klstm_oneshot.hip).  Prepared and OFF by default: never run
+    across devices.  `blob` is a contiguous CUDA float32 tensor (kept alive here); exchange() is the launcher's job: it takes a
+    function that all-gathers a bytes object over the ranks (torch.distributed.all_gather_object, MPI ...)."""
+    HANDLE = 80
+
+    def __init__(self, blob, device=0):
+        import torch
+        assert blob.is_cuda and blob.dtype == torch.float32 and blob.is_contiguous()
+        self.lib, self.blob = load_library(), blob
+        self.h = ctypes.c_void_p()
+        self._chk(self.lib.klstm_oneshot_create(device, blob.data_ptr(), blob.numel(), ctypes.byref(self.h)))
+
+    def _chk(self, st):
+        if st != 0:
+            raise KlstmError(st, (self.lib.klstm_oneshot_last_error() or b"").decode())
+
+    def export(self):
+        hb, hf = ctypes.create_string_buffer(self.HANDLE), ctypes.create_string_buffer(self.HANDLE)
+        self._chk(self.lib.klstm_oneshot_export(self.h, hb, hf))
+        return hb.raw + hf.raw
+
+    def connect(self, rank, nranks, all_handles):
+        """all_handles: the export() bytes of every rank, in rank order (this rank's own entry is not opened)"""
+        hb = ctypes.create_string_buffer(b"".join(x[:self.HANDLE] for x in all_handles), self.HANDLE * nranks)
+        hf = ctypes.create_string_buffer(b"".join(x[self.HANDLE:] for x in all_handles), self.HANDLE * nranks)
+        self._chk(self.lib.klstm_oneshot_connect(self.h, rank, nranks, hb, hf))
+
+    def allreduce(self, stream=None, timeout_ms=2000):
+        self._chk(self.lib.klstm_oneshot_allreduce(self.h, _sp(stream), timeout_ms))
+
+    def allreduce_engine(self, engine, timeout_ms=2000):
+        """on the engine's own stream, behind its gradient products (the group must sit on engine.grad_blob_tensor())"""
+        engine._chk(self.lib.klstm_allreduce_grads_oneshot(engine.h, self.h, timeout_ms))
+
+    def status(self):
+        v = ctypes.c_uint(0)
+        self._chk(self.lib.klstm_oneshot_status(self.h, ctypes.byref(v)))
+        return v.value
+
+    def close(self):
+        if self.h:
+            self.lib.klstm_oneshot_destroy(self.h)
+            self.h = ctypes.c_void_p()
 
 
 def time_shift(x, out, shift, stream=None):

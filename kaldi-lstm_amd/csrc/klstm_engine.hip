@@ -1314,6 +1314,20 @@ klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm) {
   return st;
 }
 
+// The same step through the one-shot exchange over peer-mapped blobs (klstm_oneshot.hip: prepared, off by default, never run
+// across devices).  The group must have been created on THIS engine's gradient blob (klstm_grad_blob_ptr / a bound blob).
+klstm_status klstm_allreduce_grads_oneshot(klstm_engine *e, klstm_oneshot *group, int timeout_ms) {
+  if (!e || !group) return fail(KLSTM_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }
+  const LaunchProbe pr = probe(e, "oneshot_allreduce");
+  if (pr.start) HIPCHK(hipEventRecord(pr.start, e->stream));
+  const klstm_status st = klstm_oneshot_allreduce(group, e->stream, timeout_ms);
+  if (pr.stop) HIPCHK(hipEventRecord(pr.stop, e->stream));
+  if (st != KLSTM_OK) return fail(st, "klstm_oneshot_allreduce: %s", klstm_oneshot_last_error());
+  return KLSTM_OK;
+}
+
 }  // extern "C"
 
 // ---- test support: hold compute units busy (uneven-load tests of the persistent chain) ----

@@ -1,0 +1,242 @@
+// kaldi-lstm_amd/csrc/klstm_oneshot.hip -- one-shot all-reduce of the gradient blob over peer-mapped memory (VERDICT
+// r02 item 6).  PREPARED, OFF BY DEFAULT, NEVER RUN ACROSS DEVICES: this round's lease has one GPU.  What has run is the
+// 1-rank self-loop and two PROCESSES on one GPU (hipIpc handles, the flag protocol, the arithmetic:
+// tests/test_oneshot_gpu.py); the cross-device memory ordering it relies on is stated below and is unverified.
+//
+// The default collective is one ncclAllReduce of 8.73 MB per minibatch (klstm_allreduce_grads).  At that size RCCL is in its
+// latency-dominated regime; the alternative is what a ring does in 2 (N - 1) hops done in two: every rank maps every peer's
+// gradient blob (hipIpcGetMemHandle / hipIpcOpenMemHandle; xGMI is point-to-point, all 7 links carry traffic at once) and ONE
+// kernel per rank
+//   A  arrival:  writes epoch into slot [rank] of every peer's flag array, waits until its own array shows every peer
+//   B  reduce:   adds slice `rank` (1/N of the blob) of all N blobs in rank order -- one rank computes a slice, so every rank
+//                ends with bit-identical sums -- and writes the result into slice `rank` of all N blobs
+//   C  departure: after a system-scope fence, writes epoch into slot [N + rank] of every peer, waits for every peer's
+// 2 x 7 x 1.09 MB per rank over 7 links in both directions: ~2 x 25 us at 45-50 GB/s per link + two flag round trips.
+//
+// Memory ordering assumed (documented HIP / HSA behaviour, not measured here): the blob is hipMalloc memory; the kernel that
+// produced it ended before this one started on the same stream (its writes are in memory: end-of-kernel release at system
+// scope); peer data is read and written with system-coherent accesses (sc0 sc1: no line of a peer's memory is served from or
+// parked in this device's L2); flags are 32-bit system-scope relaxed atomics, preceded by __threadfence_system(); the kernel that
+// consumes the reduced blob starts with a system-scope acquire (stale lines of the OWN blob, written by peers, are dropped).
+#include "klstm_kernels.h"
+#include "klstm_persist_dev.h"
+#include "../../include/klstm.h"
+
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+
+namespace klstm {
+
+constexpr int ONESHOT_MAX_RANKS = 8;
+
+struct OneshotArgs {
+  int rank, nranks;
+  long n;                                     // floats in the blob (n % 4 == 0 handled by the tail loop)
+  unsigned epoch;
+  float *blob[ONESHOT_MAX_RANKS];             // peer-mapped gradient blobs (own pointer at [rank])
+  unsigned *flags[ONESHOT_MAX_RANKS];         // peer-mapped flag arrays: [0..N) arrival, [N..2N) departure, [2N] status
+  unsigned *done;                             // own counter: workgroups that finished phase B
+  long long limit;                            // wall-clock ticks (100 MHz) a flag wait may take
+};
+
+__device__ __forceinline__ unsigned sys_load(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void sys_store(unsigned *p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// wait until own flags [base, base + N) all carry `epoch`; false on timeout (status word set)
+__device__ bool wait_all(const OneshotArgs &a, int base) {
+  unsigned *mine = a.flags[a.rank];
+  const long long t0 = wall_clock64();
+  for (;;) {
+    bool ok = true;
+    for (int q = 0; q < a.nranks; q++) ok &= sys_load(mine + base + q) == a.epoch;
+    if (ok) return true;
+    if (wall_clock64() - t0 > a.limit) { sys_store(mine + 2 * a.nranks, 0x80000000u | (unsigned)base); return false; }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_oneshot_allreduce(OneshotArgs a) {
+  __shared__ int ok_s;
+  const int tid = threadIdx.x, N = a.nranks;
+  // ---- A: arrival.  Workgroup 0 tells every peer; every workgroup waits on its OWN device's flag array.
+  if (blockIdx.x == 0 && tid < N) {
+    __threadfence_system();
+    sys_store(a.flags[tid] + a.rank, a.epoch);
+  }
+  if (tid == 0) ok_s = wait_all(a, 0) ? 1 : 0;
+  __syncthreads();
+  if (!ok_s) return;
+  // ---- B: slice `rank` = [lo, hi) in units of float4 (the last slice takes the remainder)
+  const long n4 = a.n / 4, per = (n4 + N - 1) / N, lo = per * a.rank, hi = lo + per < n4 ? lo + per : n4;
+  // system-coherent accesses (sc0 sc1 = aux 17): nothing of a peer's memory is served from, or parked in, this device's L2
+  constexpr int AUX = 17;
+  __amdgpu_buffer_rsrc_t rs[ONESHOT_MAX_RANKS];
+#pragma unroll
+  for (int q = 0; q < ONESHOT_MAX_RANKS; q++) rs[q] = buf_rsrc(a.blob[q < N ? q : N - 1], (int)(a.n * 4));
+  for (long i = lo + (long)blockIdx.x * 256 + tid; i < hi; i += (long)gridDim.x * 256) {
+    const int off = (int)(i * 16);
+    u32x4 v[ONESHOT_MAX_RANKS];
+#pragma unroll
+    for (int q = 0; q < ONESHOT_MAX_RANKS; q++) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs[q], off, 0, AUX);   // (q >= N: a copy of the last)
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < ONESHOT_MAX_RANKS; q++)        // rank order: one rank adds a slice, so every rank ends with the same bits
+      if (q < N) { s.x += __uint_as_float(v[q].x); s.y += __uint_as_float(v[q].y); s.z += __uint_as_float(v[q].z); s.w += __uint_as_float(v[q].w); }
+    const u32x4 o = {__float_as_uint(s.x), __float_as_uint(s.y), __float_as_uint(s.z), __float_as_uint(s.w)};
+#pragma unroll
+    for (int q = 0; q < ONESHOT_MAX_RANKS; q++)
+      if (q < N) __builtin_amdgcn_raw_buffer_store_b128(o, rs[q], off, 0, AUX);
+  }
+  if (a.rank == N - 1 && blockIdx.x == 0)             // the n % 4 tail
+    for (long i = n4 * 4 + tid; i < a.n; i += 256) {
+      float s = 0.f;
+      for (int q = 0; q < N; q++) s += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(buf_rsrc(a.blob[q], (int)(a.n * 4)), (int)(i * 4), 0, AUX));
+      for (int q = 0; q < N; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), buf_rsrc(a.blob[q], (int)(a.n * 4)), (int)(i * 4), 0, AUX);
+    }
+  // ---- C: departure.  The last workgroup to finish B tells every peer, then waits for every peer.
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = atomicAdd(a.done, 1u);
+    ok_s = old == gridDim.x - 1 ? 1 : 0;
+    if (ok_s) __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!ok_s) return;
+  if (tid < N) sys_store(a.flags[tid] + N + a.rank, a.epoch);
+  if (tid == 0) (void)wait_all(a, N);
+}
+
+struct OneshotGroup {
+  int rank = 0, nranks = 0, device = 0;
+  float *blob[ONESHOT_MAX_RANKS] = {};
+  unsigned *flags[ONESHOT_MAX_RANKS] = {};
+  bool opened_blob[ONESHOT_MAX_RANKS] = {}, opened_flags[ONESHOT_MAX_RANKS] = {};
+  void *base_blob[ONESHOT_MAX_RANKS] = {}, *base_flags[ONESHOT_MAX_RANKS] = {};
+  unsigned *own_flags = nullptr, *done = nullptr;
+  float *own_blob = nullptr;
+  long n = 0;
+  unsigned epoch = 0;
+};
+
+}  // namespace klstm
+
+using namespace klstm;
+
+static thread_local std::string g_oneshot_err;
+static klstm_status ofail(klstm_status st, const char *what, hipError_t e) {
+  g_oneshot_err = std::string(what) + ": " + hipGetErrorString(e);
+  return st;
+}
+#define OCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return ofail(KLSTM_ERR_HIP, #x, e_); } while (0)
+
+extern "C" {
+
+const char *klstm_oneshot_last_error(void) { return g_oneshot_err.c_str(); }
+
+klstm_status klstm_oneshot_create(int device, float *blob_dev, long n, klstm_oneshot **out) {
+  if (!blob_dev || n <= 0 || n >= (1L << 29) || !out) { g_oneshot_err = "klstm_oneshot_create: bad argument"; return KLSTM_ERR_ARG; }
+  OCHK(hipSetDevice(device));
+  auto *g = new OneshotGroup;
+  g->device = device; g->own_blob = blob_dev; g->n = n;
+  OCHK(hipMalloc(&g->own_flags, (2 * ONESHOT_MAX_RANKS + 2) * sizeof(unsigned)));
+  OCHK(hipMemset(g->own_flags, 0, (2 * ONESHOT_MAX_RANKS + 2) * sizeof(unsigned)));
+  OCHK(hipMalloc(&g->done, sizeof(unsigned)));
+  OCHK(hipMemset(g->done, 0, sizeof(unsigned)));
+  *out = reinterpret_cast<klstm_oneshot *>(g);
+  return KLSTM_OK;
+}
+
+klstm_status klstm_oneshot_export(klstm_oneshot *h, klstm_ipc_handle *blob, klstm_ipc_handle *flags) {
+  auto *g = reinterpret_cast<OneshotGroup *>(h);
+  if (!g || !blob || !flags) { g_oneshot_err = "klstm_oneshot_export: null argument"; return KLSTM_ERR_ARG; }
+  static_assert(sizeof(hipIpcMemHandle_t) + sizeof(unsigned long long) <= sizeof(klstm_ipc_handle), "klstm_ipc_handle too small");
+  OCHK(hipSetDevice(g->device));
+  // a handle names a whole ALLOCATION: the blob may sit inside one (a framework's caching allocator), so its offset travels along
+  auto pack = [](void *p, klstm_ipc_handle *out) -> hipError_t {
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    hipError_t er = hipMemGetAddressRange(&base, &size, p);
+    if (er != hipSuccess) return er;
+    hipIpcMemHandle_t hh;
+    er = hipIpcGetMemHandle(&hh, base);
+    if (er != hipSuccess) return er;
+    const unsigned long long off = (unsigned long long)(static_cast<char *>(p) - static_cast<char *>(base));
+    std::memset(out, 0, sizeof(*out));
+    std::memcpy(out->bytes, &hh, sizeof(hh));
+    std::memcpy(out->bytes + sizeof(hh), &off, sizeof(off));
+    return hipSuccess;
+  };
+  OCHK(pack(g->own_blob, blob));
+  OCHK(pack(g->own_flags, flags));
+  return KLSTM_OK;
+}
+
+klstm_status klstm_oneshot_connect(klstm_oneshot *h, int rank, int nranks, const klstm_ipc_handle *blobs, const klstm_ipc_handle *flags) {
+  auto *g = reinterpret_cast<OneshotGroup *>(h);
+  if (!g || nranks < 1 || nranks > ONESHOT_MAX_RANKS || rank < 0 || rank >= nranks || (nranks > 1 && (!blobs || !flags))) {
+    g_oneshot_err = "klstm_oneshot_connect: bad argument (1..8 ranks)";
+    return KLSTM_ERR_ARG;
+  }
+  OCHK(hipSetDevice(g->device));
+  g->rank = rank; g->nranks = nranks;
+  for (int q = 0; q < nranks; q++) {
+    if (q == rank) { g->blob[q] = g->own_blob; g->flags[q] = g->own_flags; continue; }     // (a process cannot open its own handle)
+    hipIpcMemHandle_t hb, hf;
+    unsigned long long ob = 0, of = 0;
+    std::memcpy(&hb, blobs[q].bytes, sizeof(hb)); std::memcpy(&ob, blobs[q].bytes + sizeof(hb), sizeof(ob));
+    std::memcpy(&hf, flags[q].bytes, sizeof(hf)); std::memcpy(&of, flags[q].bytes + sizeof(hf), sizeof(of));
+    void *pb = nullptr, *pf = nullptr;
+    OCHK(hipIpcOpenMemHandle(&pb, hb, hipIpcMemLazyEnablePeerAccess));
+    g->base_blob[q] = pb; g->blob[q] = reinterpret_cast<float *>(static_cast<char *>(pb) + ob); g->opened_blob[q] = true;
+    OCHK(hipIpcOpenMemHandle(&pf, hf, hipIpcMemLazyEnablePeerAccess));
+    g->base_flags[q] = pf; g->flags[q] = reinterpret_cast<unsigned *>(static_cast<char *>(pf) + of); g->opened_flags[q] = true;
+  }
+  return KLSTM_OK;
+}
+
+// In place, on hip_stream; every rank of the group calls it once per minibatch, in the same order (the epoch is the call count).
+klstm_status klstm_oneshot_allreduce(klstm_oneshot *h, void *hip_stream, int timeout_ms) {
+  auto *g = reinterpret_cast<OneshotGroup *>(h);
+  if (!g || !g->nranks) { g_oneshot_err = "klstm_oneshot_allreduce: group not connected"; return KLSTM_ERR_ARG; }
+  OCHK(hipSetDevice(g->device));
+  OneshotArgs a;
+  a.rank = g->rank; a.nranks = g->nranks; a.n = g->n; a.epoch = ++g->epoch;
+  for (int q = 0; q < ONESHOT_MAX_RANKS; q++) { a.blob[q] = g->blob[q]; a.flags[q] = g->flags[q]; }
+  a.done = g->done;
+  a.limit = (long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000;       // wall clock: 100 MHz
+  const long n4 = g->n / 4, per = (n4 + g->nranks - 1) / g->nranks;
+  int grid = (int)((per + 255) / 256);
+  grid = grid < 1 ? 1 : grid > 64 ? 64 : grid;          // few workgroups: the links are the limit, and every rank's kernel must be resident at once
+  hipLaunchKernelGGL(k_oneshot_allreduce, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+  OCHK(hipGetLastError());
+  return KLSTM_OK;
+}
+
+// 0: fine; otherwise the phase whose wait expired (read after a synchronisation of the stream)
+klstm_status klstm_oneshot_status(klstm_oneshot *h, unsigned *status) {
+  auto *g = reinterpret_cast<OneshotGroup *>(h);
+  if (!g || !status) { g_oneshot_err = "klstm_oneshot_status: null argument"; return KLSTM_ERR_ARG; }
+  OCHK(hipSetDevice(g->device));
+  OCHK(hipMemcpy(status, g->own_flags + 2 * (g->nranks ? g->nranks : 1), sizeof(unsigned), hipMemcpyDeviceToHost));
+  return KLSTM_OK;
+}
+
+klstm_status klstm_oneshot_destroy(klstm_oneshot *h) {
+  auto *g = reinterpret_cast<OneshotGroup *>(h);
+  if (!g) return KLSTM_OK;
+  (void)hipSetDevice(g->device);
+  for (int q = 0; q < ONESHOT_MAX_RANKS; q++) {
+    if (g->opened_blob[q]) (void)hipIpcCloseMemHandle(g->base_blob[q]);
+    if (g->opened_flags[q]) (void)hipIpcCloseMemHandle(g->base_flags[q]);
+  }
+  if (g->own_flags) (void)hipFree(g->own_flags);
+  if (g->done) (void)hipFree(g->done);
+  delete g;
+  return KLSTM_OK;
+}
+
+}  // extern "C"

@@ -74,7 +74,7 @@ class DataParallelLstm:
     DEFER_MOMENTUM = 1
     FUSE_UPDATE = 2       # klstm.h: the Update follows immediately (it does, two lines below)
 
-    def __init__(self, engine, group=None, force_collective=False, require_native=False):
+    def __init__(self, engine, group=None, force_collective=False, require_native=False, oneshot=False):
         """require_native: fail instead of falling back to torch.distributed's all_reduce when the library-owned RCCL
         communicator cannot be made on a GPU process group (bench.py --gpus N: the line must say what it measured)."""
         import torch.distributed as dist
@@ -96,6 +96,18 @@ class DataParallelLstm:
                                 "klstm_allreduce_grads (RCCL ncclAllReduce, in place, on the engine's stream)" if self.comm is not None else
                                 "torch.distributed.all_reduce (%s)" % (dist.get_backend(group) if dist.is_initialized() else "?"))
         self.ranks_seen = self.comm.count() if self.comm is not None else self.world
+        # oneshot=True (default OFF; klstm_oneshot.hip: prepared, never run across devices): the gradient blob of every rank is
+        # mapped into every other rank (hipIpc handles handed around over the process group) and ONE kernel per rank reduces its
+        # 1/N slice from all peers and writes it back to all of them, instead of ncclAllReduce
+        self.oneshot = None
+        if oneshot and self.collective and hasattr(engine, "grad_blob_tensor"):
+            from .binding import OneshotAllreduce
+            self._blob = engine.grad_blob_tensor()
+            self.oneshot = OneshotAllreduce(self._blob, device=self._blob.device.index or 0)
+            hs = [None] * self.world
+            dist.all_gather_object(hs, self.oneshot.export(), group=group)
+            self.oneshot.connect(dist.get_rank(group), self.world, hs)
+            self.collective_name = "klstm_allreduce_grads_oneshot (peer-mapped blobs, one kernel per rank; EXPERIMENTAL)"
 
     def broadcast_params(self, src=0):
         """Make every replica start from rank `src`'s parameters (device to device on GPUs)."""
@@ -119,7 +131,9 @@ class DataParallelLstm:
             e.backpropagate(x, out_diff, in_diff, momentum, self.FUSE_UPDATE)
         else:
             e.backpropagate(x, out_diff, in_diff, momentum, self.DEFER_MOMENTUM)
-            if self.comm is not None:
+            if self.oneshot is not None:
+                self.oneshot.allreduce_engine(e)
+            elif self.comm is not None:
                 e.allreduce_grads(self.comm)
             else:
                 if self._blob is None:
