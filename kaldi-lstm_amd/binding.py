@@ -282,6 +282,7 @@ class Engine:
 
     def set_option(self, key, value):
         self._chk(self.lib.klstm_set_option(self.h, key.encode(), int(value)))
+        self.__dict__.setdefault("options", {})[key] = int(value)       # (what the caller asked for: dp.py looks at "bf16")
 
     def profile_query(self, kernel):
         tot, n = ctypes.c_double(), ctypes.c_long()

@@ -1920,6 +1920,7 @@ struct GradsArgs {
   const unsigned *guard;   // status words of the persistent chain ([2], [6]): non-zero -> the minibatch is invalid, touch nothing
   GemmJob wx, wr, wm;
   int nb0, nb1, nb2, nvec;   // tile-id ranges of the three products, then nvec column-sum blocks
+  int bf16_narrow;           // k_grads_bf16: 128 x 64 tiles instead of 128 x 128
   int C, S, T;
   const float *dgifo, *cc;
   float beta;
@@ -2018,9 +2019,10 @@ __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
 constexpr int GRADS_BF16_MIN_ROWS = 256;
 constexpr int BT = 128, BK = 64, LDQ = 36, PLANE = 32 * LDQ + 16;   // see the layout note above
 
+template <int XQ = 32>                                // x quads of the tile (32: 128 columns, 16: 64)
 __device__ __forceinline__ void fetch_pair(const float *__restrict__ P, int ld, int X, int K, int x0, int k0, int u,
                                            float4 (&r)[2], int &ok) {
-  const int kp = u >> 5, xq = u & 31;
+  const int kp = u / XQ, xq = u % XQ;
   const int k = k0 + 2 * kp, x = x0 + 4 * xq;
   const bool xin = x + 4 <= X;                       // X % 4 == 0 on this path
   const float *p0 = P + (size_t)min(k, K - 1) * ld + (xin ? x : 0);
@@ -2033,9 +2035,10 @@ __device__ __forceinline__ unsigned pack_pair(float lo, float hi) {
   const bf16x2 h = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(unsigned, h);
 }
+template <int XQ = 32>
 __device__ __forceinline__ void stash_pair(unsigned *Ls, int u, const float4 (&rr)[2], int ok) {
   const float4 r[2] = {keep_if(rr[0], (ok & 1) != 0), keep_if(rr[1], (ok & 2) != 0)};
-  const int kp = u >> 5, xq = u & 31;
+  const int kp = u / XQ, xq = u % XQ;
   unsigned *d = Ls + xq * LDQ + kp;
   d[0] = pack_pair(r[0].x, r[1].x);
   d[PLANE] = pack_pair(r[0].y, r[1].y);
@@ -2043,55 +2046,63 @@ __device__ __forceinline__ void stash_pair(unsigned *Ls, int u, const float4 (&r
   d[3 * PLANE] = pack_pair(r[0].w, r[1].w);
 }
 
+// NJ = 16-column blocks per wave: 4 = 128 x 128 tiles, 2 = 128 x 64 (twice the workgroups: the K loop exposes a memory latency per
+// tile, and 288 tiles of 128 x 128 leave the 256 CUs with one workgroup each)
+template <int NJ>
 __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int n0, unsigned *As, unsigned *Bs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kg = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
+    for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
   constexpr int NU = (BK / 2) * 32 / 256;            // (k pair, x quad) units per thread and operand
-  float4 ra[NU][2], rb[NU][2];
-  int oa[NU], ob[NU];
+  constexpr int NUB = (BK / 2) * (8 * NJ) / 256;     // ... of B: 32 NJ columns = 8 NJ quads
+  float4 ra[NU][2], rb[NUB][2];
+  int oa[NU], ob[NUB];
 #pragma unroll
-  for (int h = 0; h < NU; h++) {
-    fetch_pair(g.A, g.lda, g.M, g.K, m0, 0, tid + 256 * h, ra[h], oa[h]);
-    fetch_pair(g.B, g.ldb, g.N, g.K, n0, 0, tid + 256 * h, rb[h], ob[h]);
-  }
+  for (int h = 0; h < NU; h++) fetch_pair(g.A, g.lda, g.M, g.K, m0, 0, tid + 256 * h, ra[h], oa[h]);
+#pragma unroll
+  for (int h = 0; h < NUB; h++) fetch_pair<8 * NJ>(g.B, g.ldb, g.N, g.K, n0, 0, tid + 256 * h, rb[h], ob[h]);
   for (int k0 = 0; k0 < g.K; k0 += BK) {
 #pragma unroll
-    for (int h = 0; h < NU; h++) { stash_pair(As, tid + 256 * h, ra[h], oa[h]); stash_pair(Bs, tid + 256 * h, rb[h], ob[h]); }
+    for (int h = 0; h < NU; h++) stash_pair(As, tid + 256 * h, ra[h], oa[h]);
+#pragma unroll
+    for (int h = 0; h < NUB; h++) stash_pair<8 * NJ>(Bs, tid + 256 * h, rb[h], ob[h]);
     __syncthreads();
     if (k0 + BK < g.K) {
 #pragma unroll
-      for (int h = 0; h < NU; h++) {
-        fetch_pair(g.A, g.lda, g.M, g.K, m0, k0 + BK, tid + 256 * h, ra[h], oa[h]);
-        fetch_pair(g.B, g.ldb, g.N, g.K, n0, k0 + BK, tid + 256 * h, rb[h], ob[h]);
-      }
+      for (int h = 0; h < NU; h++) fetch_pair(g.A, g.lda, g.M, g.K, m0, k0 + BK, tid + 256 * h, ra[h], oa[h]);
+#pragma unroll
+      for (int h = 0; h < NUB; h++) fetch_pair<8 * NJ>(g.B, g.ldb, g.N, g.K, n0, k0 + BK, tid + 256 * h, rb[h], ob[h]);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ks++) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[4], bfr[NJ];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int xa = wr * 64 + i * 16 + i16, xb = wc * 64 + i * 16 + i16;
+        const int xa = wr * 64 + i * 16 + i16;
         af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(As + (xa & 3) * PLANE + (xa >> 2) * LDQ + ks * 16 + kg * 4));
-        bfr[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(Bs + (xb & 3) * PLANE + (xb >> 2) * LDQ + ks * 16 + kg * 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int xb = wc * 16 * NJ + j * 16 + i16;
+        bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(Bs + (xb & 3) * PLANE + (xb >> 2) * LDQ + ks * 16 + kg * 4));
       }
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int n = n0 + wc * 64 + j * 16 + i16;
+    for (int j = 0; j < NJ; j++) {
+      const int n = n0 + wc * 16 * NJ + j * 16 + i16;
       if (n >= g.N) continue;
       const float e[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
 #pragma unroll
@@ -2122,61 +2133,68 @@ __device__ __forceinline__ void stash_row8(unsigned *Ls, int u, const float4 (&r
   w.z = pack_pair(r[1].x, r[1].y); w.w = pack_pair(r[1].z, r[1].w);
   *reinterpret_cast<uint4 *>(Ls + (xl & 3) * PLANE + (xl >> 2) * LDQ + 4 * (u & 7)) = w;
 }
+// NJ: 16-column blocks per wave (4: 128-column tiles; 2: 64-column tiles -- twice the workgroups for results with few tiles)
+template <int NJ>
 __global__ __launch_bounds__(256) void k_gemm_bf16_nt(GemmJob g) {
+  constexpr int BTN = 32 * NJ;
   __shared__ __attribute__((aligned(16))) unsigned As[4 * PLANE];
   __shared__ __attribute__((aligned(16))) unsigned Bs[4 * PLANE];
-  const int ntm = (g.M + BT - 1) / BT, ntn = (g.N + BT - 1) / BT, nt = ntm * ntn;
+  const int ntm = (g.M + BT - 1) / BT, ntn = (g.N + BTN - 1) / BTN, nt = ntm * ntn;
   const int cpx = (nt + 7) >> 3;
   const int b = (int)(blockIdx.x & 7) * cpx + (int)(blockIdx.x >> 3);     // XCD x: a contiguous n-major range (A is small, B streams once)
   if (b >= nt) return;
-  const int m0 = (b % ntm) * BT, n0 = (b / ntm) * BT;
+  const int m0 = (b % ntm) * BT, n0 = (b / ntm) * BTN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kg = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
-  constexpr int NU = BT * (BK / 8) / 256;            // (row, 8-k group) units per thread and operand
-  float4 ra[NU][2], rb[NU][2];
-  int oa[NU], ob[NU];
+    for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
+  constexpr int NU = BT * (BK / 8) / 256, NUB = BTN * (BK / 8) / 256;   // (row, 8-k group) units per thread: A, B
+  float4 ra[NU][2], rb[NUB][2];
+  int oa[NU], ob[NUB];
 #pragma unroll
-  for (int h = 0; h < NU; h++) {
-    fetch_row8(g.A, g.lda, g.M, g.K, m0, 0, tid + 256 * h, ra[h], oa[h]);
-    fetch_row8(g.B, g.ldb, g.N, g.K, n0, 0, tid + 256 * h, rb[h], ob[h]);
-  }
+  for (int h = 0; h < NU; h++) fetch_row8(g.A, g.lda, g.M, g.K, m0, 0, tid + 256 * h, ra[h], oa[h]);
+#pragma unroll
+  for (int h = 0; h < NUB; h++) fetch_row8(g.B, g.ldb, g.N, g.K, n0, 0, tid + 256 * h, rb[h], ob[h]);
   for (int k0 = 0; k0 < g.K; k0 += BK) {
 #pragma unroll
-    for (int h = 0; h < NU; h++) { stash_row8(As, tid + 256 * h, ra[h], oa[h]); stash_row8(Bs, tid + 256 * h, rb[h], ob[h]); }
+    for (int h = 0; h < NU; h++) stash_row8(As, tid + 256 * h, ra[h], oa[h]);
+#pragma unroll
+    for (int h = 0; h < NUB; h++) stash_row8(Bs, tid + 256 * h, rb[h], ob[h]);
     __syncthreads();
     if (k0 + BK < g.K) {
 #pragma unroll
-      for (int h = 0; h < NU; h++) {
-        fetch_row8(g.A, g.lda, g.M, g.K, m0, k0 + BK, tid + 256 * h, ra[h], oa[h]);
-        fetch_row8(g.B, g.ldb, g.N, g.K, n0, k0 + BK, tid + 256 * h, rb[h], ob[h]);
-      }
+      for (int h = 0; h < NU; h++) fetch_row8(g.A, g.lda, g.M, g.K, m0, k0 + BK, tid + 256 * h, ra[h], oa[h]);
+#pragma unroll
+      for (int h = 0; h < NUB; h++) fetch_row8(g.B, g.ldb, g.N, g.K, n0, k0 + BK, tid + 256 * h, rb[h], ob[h]);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ks++) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[4], bfr[NJ];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int xa = wr * 64 + i * 16 + i16, xb = wc * 64 + i * 16 + i16;
+        const int xa = wr * 64 + i * 16 + i16;
         af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(As + (xa & 3) * PLANE + (xa >> 2) * LDQ + ks * 16 + kg * 4));
-        bfr[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(Bs + (xb & 3) * PLANE + (xb >> 2) * LDQ + ks * 16 + kg * 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int xb = wc * 16 * NJ + j * 16 + i16;
+        bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(Bs + (xb & 3) * PLANE + (xb >> 2) * LDQ + ks * 16 + kg * 4));
       }
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
   // lane (i16, kg): rows 4kg + (0..3) of block i at column i16 of block j: 16 lanes = 64 contiguous bytes per row
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int n = n0 + wc * 64 + j * 16 + i16;
+  for (int j = 0; j < NJ; j++) {
+    const int n = n0 + wc * 16 * NJ + j * 16 + i16;
     if (n >= g.N) continue;
     const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
@@ -2202,8 +2220,13 @@ __global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
   if (b < a.nb2) {
     const GemmJob &g = b < a.nb0 ? a.wx : b < a.nb1 ? a.wr : a.wm;
     const int lb = b < a.nb0 ? b : b < a.nb1 ? b - a.nb0 : b - a.nb1;
-    const int ntn = (g.N + BT - 1) / BT;
-    gemm_tile_bf16_tn(g, (lb / ntn) * BT, (lb % ntn) * BT, As, Bs);
+    if (a.bf16_narrow) {
+      const int ntn = (g.N + BT / 2 - 1) / (BT / 2);
+      gemm_tile_bf16_tn<2>(g, (lb / ntn) * BT, (lb % ntn) * (BT / 2), As, Bs);
+    } else {
+      const int ntn = (g.N + BT - 1) / BT;
+      gemm_tile_bf16_tn<4>(g, (lb / ntn) * BT, (lb % ntn) * BT, As, Bs);
+    }
     return;
   }
   grads_column_sums(a, b - a.nb2, reinterpret_cast<float *>(As), reinterpret_cast<float *>(Bs));
@@ -3036,8 +3059,13 @@ bool gemm_bf16_nt_supported(int M, int K, const float *A, int lda, const float *
 hipError_t launch_gemm_bf16_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
                                const float *bias, hipStream_t st, LaunchProbe pr) {
   const GemmJob g = make_job(false, true, M, N, K, A, lda, B, ldb, 0.f, Cm, ldc, bias);
-  const dim3 grid(cdiv(cdiv(N, BT) * cdiv(M, BT), 8) * 8), block(256);
-  KLAUNCH(k_gemm_bf16_nt, grid, block, st, pr, g);
+  const dim3 block(256);
+  if (cdiv(N, BT) * cdiv(M, BT) < 384) {             // few 128 x 128 tiles (640 x 4096: 160 on 256 CUs): 128 x 64
+    const dim3 grid(cdiv(cdiv(N, BT / 2) * cdiv(M, BT), 8) * 8);
+    KLAUNCH(k_gemm_bf16_nt<2>, grid, block, st, pr, g);
+  }
+  const dim3 grid(cdiv(cdiv(N, BT) * cdiv(M, BT), 8) * 8);
+  KLAUNCH(k_gemm_bf16_nt<4>, grid, block, st, pr, g);
 }
 
 // Cm = beta*Cm + A^T B (gradient of a weight matrix, K = frames), then P -= lr*Cm in the same pass (GemmJob::P):
@@ -3130,6 +3158,7 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
   const float *dg1 = dgifo + (size_t)S * 4 * C;                      // DGIFO[1..T]
   GradsArgs a;
   a.guard = guard;
+  a.bf16_narrow = 0;
   a.wx = make_job(true, false, 4 * C, I, TS, dg1, 4 * C, in, in_stride, beta, dst + o_wx, I, nullptr);             // :468
   a.wr = make_job(true, false, 4 * C, R, TS, dg1, 4 * C, rr, R, beta, dst + o_wr, R, nullptr);                      // :471 (YR[0..T-1])
   a.wm = make_job(true, false, R, C, TS, dr + (size_t)S * R, R, mm + (size_t)S * C, C, beta, dst + o_wm, C, nullptr); // :486
@@ -3159,9 +3188,13 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
                      in_stride % 4 == 0 && C % 4 == 0 && R % 4 == 0 && I % 4 == 0;
   if (bf_ok && upd) return hipErrorInvalidValue;
   if (bf_ok) {                                        // 128x128 tiles on the bf16 pipe
-    a.nb0 = cdiv(4 * C, BT) * cdiv(I, BT);
-    a.nb1 = a.nb0 + cdiv(4 * C, BT) * cdiv(R, BT);
-    a.nb2 = a.nb1 + cdiv(R, BT) * cdiv(C, BT);
+    // 128 x 64 tiles while 128 x 128 ones would not even give every CU a workgroup (measured at 1024/512, 640 frames: 192 tiles
+    // (40 inputs) 24.8 -> 21.3 us; 288 tiles (512 inputs) 30 -> 33.5 us: stays wide)
+    a.bf16_narrow = cdiv(4 * C, BT) * (cdiv(I, BT) + cdiv(R, BT)) + cdiv(R, BT) * cdiv(C, BT) < 256 ? 1 : 0;
+    const int btn = a.bf16_narrow ? BT / 2 : BT;
+    a.nb0 = cdiv(4 * C, BT) * cdiv(I, btn);
+    a.nb1 = a.nb0 + cdiv(4 * C, BT) * cdiv(R, btn);
+    a.nb2 = a.nb1 + cdiv(R, BT) * cdiv(C, btn);
     KLAUNCH(k_grads_bf16, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
   }
   KLAUNCH(k_grads, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
