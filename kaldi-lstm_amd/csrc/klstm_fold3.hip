@@ -9,11 +9,14 @@
 // the only roundings are the fp32 accumulations (as in the fp32 MFMA) and the three dropped terms (~3 * 2^-24 relative to
 // |a||b|, the size of one fp32 rounding).  tests/test_engine_gpu.py holds the result to the tolerance of the fp32 kernel.
 //
-//   k_split3        both operands -> three bf16 planes each, once per Update (reads 8 MB, writes 12 MB)
-//   k_fold_bf16x3   128 x 96 tiles (2 x 2 waves of 64 x 48 = 4 x 3 MFMA blocks x 6 products), K in stages of 32:
+//   k_split3        both operands -> three bf16 planes each (reads 8 MB, writes 12 MB, 4.5 us) -- only when the parameters changed
+//                   outside an Update (set_params ...): both Update kernels write the planes from the tile they have just updated
+//                   (klstm_kernels.hip: GradsUpdate::a3 / b3, bf16_split3_store4)
+//   k_fold_bf16x3   128 x 96 tiles (2 x 2 MFMA waves of 64 x 48 = 4 x 3 MFMA blocks x 6 products), K in stages of 32:
 //                   one stage = 3 planes x (128 + 96) rows x 64 B = 42 KB, brought in by LDS-DMA
-//                   (global_load_lds_dwordx4: 16 rows x 64 B per wave instruction, no registers), double buffered, ONE
-//                   barrier per stage.  LDS rows are 64 B; the 16-byte k-group of row r sits in slot kg ^ ((-(r >> 2)) & 3)
+//                   (global_load_lds_dwordx4: 16 rows x 64 B per wave instruction, no registers) issued by FOUR LOADER WAVES,
+//                   three buffers, ONE barrier per stage; the MFMA waves read the next stage's operands into a second register
+//                   set under the current stage's MFMAs (measurements: DESIGN.md 3d, tools/fold3_probe.hip).  LDS rows are 64 B; the 16-byte k-group of row r sits in slot kg ^ ((-(r >> 2)) & 3)
 //                   (swizzle applied on the SOURCE side of the DMA, whose destination is lane-linear): the ds_read_b128 of
 //                   an MFMA operand (16 rows x 4 k-groups) touches every bank quad once per 16-lane group.
 //                   800/512: 25 x 9 = 225 workgroups, one round of the 256 CUs, 88 % of them busy.
