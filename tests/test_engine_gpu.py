@@ -966,6 +966,21 @@ def test_persistent_chain(I, C, R, S, T, want_in_diff, waves, tpw):
     check(recs, tol_act=3e-5, tol_grad=3e-4 if C > 200 else 1e-4, C=C, S=S, T=T)
 
 
+@pytest.mark.parametrize("I,C,R,S,T", [(64, 904, 64, 5, 13),       # backward geometry switch at C > 896 (16 waves x 3 slots), partial last slot
+                                       (128, 1024, 32, 8, 13),     # 256 workgroups = every CU, two stream groups, batched x-projection
+                                       (8, 1000, 64, 1, 33),       # ragged fold tiles (1000 = 10.4 x 96), one stream
+                                       (512, 520, 32, 2, 33),      # wide input through the register-direct x-projection, narrow projection
+                                       (40, 200, 128, 7, 9),       # few workgroups, 7 streams (second group of 3)
+                                       (128, 520, 512, 7, 8),      # R close to C: d_r / in_diff columns do not all fit the workgroups
+                                       (8, 264, 256, 3, 20)])      # C / 4 = 66 workgroups, partial slots everywhere
+def test_persistent_chain_odd_shapes(I, C, R, S, T):
+    """Shapes picked from tools/persist_fuzz.py's random walk (150 shapes green there): the corners of the persistent kernels'
+    geometry tables and of the fold product's tiling, against the oracle at the tolerances of test_persistent_chain."""
+    recs = run_chunks(I, C, R, S, T, nchunks=2, scale=0.01, momentum=0.9, lr=1e-5, want_in_diff=True, od_scale=0.1, persist=2,
+                      waves=0, tpw=0)
+    check(recs, tol_act=3e-5, tol_grad=3e-4, C=C, S=S, T=T)
+
+
 def test_persistent_chain_replay_state_bridge_and_whole_utterance():
     """(a) hipGraph replay of the persistent launches equals plain launches bit for bit over several minibatches (the
     granule tags come from a device-resident epoch, so a replay with frozen kernel arguments still sees fresh tags);
