@@ -105,7 +105,7 @@ __device__ __forceinline__ float dpp_quad(unsigned v, bool odd_pair) {
 
 template <int NW, int NU>
 __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
-  constexpr int NSC = NW - 2, NSLOT = NSC * NU, NT = NW * 64;
+  constexpr int NSC = NW - 2, NSLOT = NSC * NU;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned *abortf = reinterpret_cast<unsigned *>(lds);
   int *pcnt = reinterpret_cast<int *>(lds) + 1;      // d_m partials written (one count per SC wave and step)
