@@ -286,9 +286,11 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  "persist_spin_us" (bound of a single in-kernel wait, default 50 000), "persist_ncu" (pretend CU count),
  *                  "persist_test_stall_fwd" / "persist_test_stall_bwd" (workgroup 0 withholds its publish of that step:
  *                  forces the give-up path)
- *   "fold_bf16x3"  0/1  the fold product W_rm = W_gifo_r * W_r_m as six bf16 MFMA products of three-way split operands
- *                  (fp32 accuracy: every partial product exact, fp32 accumulation, dropped terms below 2^-24; DESIGN.md 3d;
- *                  default 1) or on the fp32 MFMA (0; process-wide, A-B experiments).  "fold_direct" 0: the generic tile kernel
+ *   "fold_bf16x3"  0/1/2  the fold product W_rm = W_gifo_r * W_r_m on the 16-bit matrix cores at fp32 accuracy (DESIGN.md 3d;
+ *                  every partial product exact in fp32, fp32 accumulation): 2 (default) = two fp16 planes per operand, three
+ *                  products, dropped terms ~7e-7 relative (parameters must stay below 65504 in magnitude: beyond, the product
+ *                  carries Inf / NaN); 1 = three bf16 planes, six products, dropped terms below 2^-24, fp32 range; 0 = the fp32
+ *                  MFMA kernel.  Process-wide (A-B experiments).  "fold_direct" 0: the generic tile kernel
  *   "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.

@@ -854,7 +854,7 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
     const Dims dg{e->I, e->C, e->R, e->S, e->gp_T};
     GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
     e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d);
-    if (e->planes_fresh) fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
+    if (e->planes_fresh) { fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane); u.split_mode = fold_split_mode(); }
     HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
                         probe(e, "k_grads_update"), false, &u, e->pctrl));
   } else {
@@ -864,7 +864,7 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
     GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
     e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d) &&
                       update_repack_vectorised(d, e->params, e->corr, fold_grad, e->wrT, e->wmT, e->wxT);
-    if (e->planes_fresh) fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
+    if (e->planes_fresh) { fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane); u.split_mode = fold_split_mode(); }
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
                                 e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr));
   }
@@ -1014,7 +1014,8 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
   if (!strcmp(key, "fold_bf16x3")) {             // 0: the fold product on the fp32 MFMA (klstm_fold.hip) (A-B; process-wide)
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
-    set_fold_bf16x3(value);
+    set_fold_bf16x3(value);                   // 1: bf16 x 3 planes, 2: fp16 x 2 planes (the planes at hand are in the other format)
+    e->planes_fresh = false;
     e->fold_dirty = true;
     return KLSTM_OK;
   }

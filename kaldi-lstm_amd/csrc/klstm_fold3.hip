@@ -1,4 +1,6 @@
-// kaldi-lstm_amd/csrc/klstm_fold3.hip -- the fold product W_rm = W_gifo_r W_r_m on the bf16 matrix cores at fp32 accuracy.
+// kaldi-lstm_amd/csrc/klstm_fold3.hip -- the fold product W_rm = W_gifo_r W_r_m on the 16-bit matrix cores at fp32 accuracy.
+//
+// Two operand formats (option "fold_bf16x3"): 2 (default) = two fp16 planes, three products; 1 = three bf16 planes, six products.
 //
 // klstm_fold.hip runs the product on v_mfma_f32_16x16x4_f32 (256 FLOP/clk/CU): 2.6 GFLOP at 800/512 = 16.7 us at that peak,
 // 32 us measured.  The bf16 MFMA (v_mfma_f32_16x16x32_bf16) is 16x faster per instruction-clock, enough to pay for a
@@ -8,6 +10,15 @@
 // six bf16 products accumulated in fp32, smallest first: every partial product of two bf16 numbers is EXACT in fp32, so
 // the only roundings are the fp32 accumulations (as in the fp32 MFMA) and the three dropped terms (~3 * 2^-24 relative to
 // |a||b|, the size of one fp32 rounding).  tests/test_engine_gpu.py holds the result to the tolerance of the fp32 kernel.
+//
+// fp16 x 2 (NPL = 2, the default): a = a1 + a2 / 2048, a1 = fp16(a), a2 = fp16((a - a1) * 2048) (klstm_math.h f16_split2: 11 + 11
+// mantissa bits, the residual scaled so that it stays a normal fp16 number), a b ~= a1 b1 + (a1 b2 + a2 b1) / 2048: THREE products,
+// the cross terms in an accumulator set of their own (every partial product still exact in fp32), dropped: a2 b2 and the two
+// truncations, ~7e-7 |a||b| per term -- half of what the fp32 accumulation of a 512-term sum rounds away anyway.  Measured: every
+// parity test at unchanged tolerances, the 50-chunk drift run identical to the bf16 x 3 form (out 4.3e-6, in_diff 4.9e-6), the
+// product 21.5 -> 15.2 us (K loop 26.9 k -> 15.9 k clocks: MFMA-bound, 576 instead of 1152 MFMAs per wave), planes 8 MB instead
+// of 12.  Range: fp16 -- parameters beyond +-65504 overflow the first plane (W_rm then carries Inf / NaN, loudly); bf16 x 3 has the
+// fp32 range.
 //
 //   k_split3        both operands -> three bf16 planes each (reads 8 MB, writes 12 MB, 4.5 us) -- only when the parameters changed
 //                   outside an Update (set_params ...): both Update kernels write the planes from the tile they have just updated
@@ -33,6 +44,7 @@ namespace klstm {
 #pragma clang fp contract(off)
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -42,6 +54,7 @@ struct Split3Args {
   unsigned short *dst[2];
   size_t plane[2];       // elements per plane
   size_t n8[2];          // groups of 8 elements
+  int mode;              // 1: three bf16 planes, 2: two fp16 planes (klstm_math.h f16_split2)
 };
 
 __global__ __launch_bounds__(256) void k_split3(Split3Args a) {
@@ -54,13 +67,14 @@ __global__ __launch_bounds__(256) void k_split3(Split3Args a) {
     u16x8_t h1, h2, h3;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      unsigned short b1, b2, b3;
-      bf16_split3(v[e], b1, b2, b3);
+      unsigned short b1, b2, b3 = 0;
+      if (a.mode == 2) f16_split2(v[e], b1, b2);
+      else bf16_split3(v[e], b1, b2, b3);
       h1[e] = b1; h2[e] = b2; h3[e] = b3;
     }
     *reinterpret_cast<u16x8_t *>(a.dst[w] + i) = h1;
     *reinterpret_cast<u16x8_t *>(a.dst[w] + a.plane[w] + i) = h2;
-    *reinterpret_cast<u16x8_t *>(a.dst[w] + 2 * a.plane[w] + i) = h3;
+    if (a.mode != 2) *reinterpret_cast<u16x8_t *>(a.dst[w] + 2 * a.plane[w] + i) = h3;
   }
 }
 
@@ -79,11 +93,12 @@ struct Fold3Args {
 
 // LW: four more waves (4..7, one per SIMD) issue all the LDS-DMA requests, the MFMA waves none.
 // NODMA: timing experiment (tools/fold3_probe.hip), stages past the first NBUF - 1 are not requested.
-template <int MI, int NI, int NBUF, bool NODMA = false, bool LW = false>
+// NPL: planes per operand: 3 = bf16 x 3 (six products), 2 = fp16 x 2 (three products, two accumulator sets; klstm_math.h f16_split2)
+template <int MI, int NI, int NBUF, bool NODMA = false, bool LW = false, int NPL = 3>
 __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
   constexpr int BM = 32 * MI, BN = 32 * NI, WM = 16 * MI, WN = 16 * NI;
-  constexpr int APL = BM * 64, BPL = BN * 64, STG = 3 * (APL + BPL);   // bytes: one plane tile of A / B, one stage
-  constexpr int NA = 3 * (BM / 16), NQ = NA + 3 * (BN / 16);           // DMA instructions of a stage (1 KB each)
+  constexpr int APL = BM * 64, BPL = BN * 64, STG = NPL * (APL + BPL);   // bytes: one plane tile of A / B, one stage
+  constexpr int NA = NPL * (BM / 16), NQ = NA + NPL * (BN / 16);           // DMA instructions of a stage (1 KB each)
   constexpr int NJ = (NQ + 3) / 4;                                     // per wave
   constexpr int FLD = WM + 4;                                          // epilogue transpose: floats per column
   static_assert(4 * WN * FLD * 4 <= NBUF * STG, "epilogue transpose does not fit the staging buffers");
@@ -148,7 +163,7 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
   const bool loader = LW && wave >= 4;
   const int tw = wave & 3, wr = tw >> 1, wc = tw & 1;                  // loader wave w + 4 shares the epilogue of MFMA wave w
   const int sw = (kg ^ ((-(i16 >> 2)) & 3)) * 16;
-  const int aoff = (wr * WM + i16) * 64 + sw, boff = 3 * APL + (wc * WN + i16) * 64 + sw;
+  const int aoff = (wr * WM + i16) * 64 + sw, boff = NPL * APL + (wc * WN + i16) * 64 + sw;
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; mi++)
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
   // in order) and its LDS reads of stage k-1 are complete; the barrier makes both true for everyone, so buffer (k-1) % NBUF
   // can take stage k + NBUF - 1; then the reads of stage k are issued.
   int rb = 0, ib = NBUF - 1;
-  auto advance = [&](int k, bf16x8_t (&af)[3][MI], bf16x8_t (&bf)[3][NI]) {
+  auto advance = [&](int k, bf16x8_t (&af)[NPL][MI], bf16x8_t (&bf)[NPL][NI]) {
     const int ahead = nstage - 1 - k < NBUF - 2 ? nstage - 1 - k : NBUF - 2;
     if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NBUF >= 4 ? 2 * NJ : 0) : "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NBUF >= 3 ? NJ : 0) : "memory");
@@ -173,22 +188,40 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
     rb = rb + 1 == NBUF ? 0 : rb + 1;
     ib = ib + 1 == NBUF ? 0 : ib + 1;
 #pragma unroll
-    for (int p = 0; p < 3; p++) {
+    for (int p = 0; p < NPL; p++) {
 #pragma unroll
       for (int mi = 0; mi < MI; mi++) af[p][mi] = *reinterpret_cast<const bf16x8_t *>(sb + p * APL + aoff + mi * 1024);
 #pragma unroll
       for (int ni = 0; ni < NI; ni++) bf[p][ni] = *reinterpret_cast<const bf16x8_t *>(sb + p * BPL + boff + ni * 1024);
     }
   };
-  auto multiply = [&](const bf16x8_t (&af)[3][MI], const bf16x8_t (&bf)[3][NI]) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+  f32x4 accx[NPL == 2 ? MI : 1][NPL == 2 ? NI : 1];   // fp16 x 2: the cross terms a1 b2 + a2 b1 (their planes carry a factor 2^11)
 #pragma unroll
-    for (int t = 0; t < 6; t++)
+  for (int mi = 0; mi < (NPL == 2 ? MI : 1); mi++)
+#pragma unroll
+    for (int ni = 0; ni < (NPL == 2 ? NI : 1); ni++) accx[mi][ni] = (f32x4){0, 0, 0, 0};
+  auto multiply = [&](const bf16x8_t (&af)[NPL][MI], const bf16x8_t (&bf)[NPL][NI]) {
+    if constexpr (NPL == 3) {
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+#pragma unroll
+      for (int t = 0; t < 6; t++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[t]][mi], bf[PB[t]][ni], acc[mi][ni], 0, 0, 0);
+    } else {
 #pragma unroll
       for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[t]][mi], bf[PB[t]][ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ni++) {
+          const f16x8_t a0 = __builtin_bit_cast(f16x8_t, af[0][mi]), a1 = __builtin_bit_cast(f16x8_t, af[1][mi]);
+          const f16x8_t b0 = __builtin_bit_cast(f16x8_t, bf[0][ni]), b1 = __builtin_bit_cast(f16x8_t, bf[1][ni]);
+          accx[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, accx[mi][ni], 0, 0, 0);
+          accx[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, accx[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[mi][ni], 0, 0, 0);
+        }
+    }
   };
 #ifdef KLSTM_FOLD3_TIMING
   long long t_c1 = 0, t_c2 = 0;
@@ -202,7 +235,7 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
       for (int s = 0; s < NBUF - 1; s++)
         if (s < nstage) issue(s, s);
     }
-    bf16x8_t af0[3][MI], bf0[3][NI], af1[3][MI], bf1[3][NI];
+    bf16x8_t af0[NPL][MI], bf0[NPL][NI], af1[NPL][MI], bf1[NPL][NI];
     advance(0, af0, bf0);
 #ifdef KLSTM_FOLD3_TIMING
     t_c1 = clock64();
@@ -219,6 +252,12 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
     t_c2 = clock64();
 #endif
     __syncthreads();                                                   // the staging buffers become the transpose buffers
+    if constexpr (NPL == 2) {
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) acc[mi][ni] = acc[mi][ni] + accx[mi][ni] * (1.f / 2048.f);   // (exact scaling, one rounding)
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; mi++)
 #pragma unroll
@@ -264,8 +303,9 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
 #ifdef KLSTM_FOLD3_TIMING
 static long long *g_fold3_dbg = nullptr;
 #endif
-static int g_fold_bf16x3 = 1;
+static int g_fold_bf16x3 = 2;      // 0: fp32 MFMA kernel (klstm_fold.hip), 1: bf16 x 3, 2: fp16 x 2
 void set_fold_bf16x3(int v) { g_fold_bf16x3 = v; }
+int fold_split_mode() { return g_fold_bf16x3 == 2 ? 2 : 1; }
 bool fold_bf16x3_supported(const Dims &d) { return g_fold_bf16x3 != 0 && d.C % 4 == 0 && d.R % 32 == 0; }
 size_t fold_bf16x3_scratch_bytes(const Dims &d) { return (size_t)3 * 5 * d.C * d.R * sizeof(unsigned short); }
 
@@ -275,15 +315,34 @@ void fold_bf16x3_planes(const Dims &d, void *scratch, unsigned short **a3, long 
   *b3 = *a3 + 3 * *a_plane;
 }
 
+template <int NPL>
+static hipError_t launch_fold_planes(const Fold3Args &a, hipStream_t st, LaunchProbe pr) {
+  constexpr int MI = 4, NI = 3, NBUF = 3;
+  constexpr int shm = NBUF * NPL * (32 * MI + 32 * NI) * 64 > 4 * 16 * NI * (16 * MI + 4) * 4 ? NBUF * NPL * (32 * MI + 32 * NI) * 64
+                                                                                              : 4 * 16 * NI * (16 * MI + 4) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_bf16x3<MI, NI, NBUF, false, true, NPL>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    if (err != hipSuccess) return err;
+    attr_set = true;
+  }
+  const dim3 grid((a.nwg + 7) / 8 * 8), block(512);
+  if (pr.start) hipExtLaunchKernelGGL((k_fold_bf16x3<MI, NI, NBUF, false, true, NPL>), grid, block, shm, st, pr.start, pr.stop, 0, a);
+  else hipLaunchKernelGGL((k_fold_bf16x3<MI, NI, NBUF, false, true, NPL>), grid, block, shm, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
                               int nch2, hipStream_t st, LaunchProbe pr_split, LaunchProbe pr, bool planes_fresh) {
-  constexpr int MI = 4, NI = 3, NBUF = 3;
+  constexpr int MI = 4, NI = 3;
   unsigned short *a3 = static_cast<unsigned short *>(scratch);
   const size_t apl = (size_t)4 * d.C * d.R, bpl = (size_t)d.C * d.R;
   unsigned short *b3 = a3 + 3 * apl;
   Split3Args s;
   s.src[0] = wr; s.src[1] = wmT; s.dst[0] = a3; s.dst[1] = b3; s.plane[0] = apl; s.plane[1] = bpl;
   s.n8[0] = apl / 8; s.n8[1] = bpl / 8;
+  s.mode = fold_split_mode();
   const unsigned sgrid = (unsigned)std::min<size_t>((s.n8[0] + s.n8[1] + 255) / 256, 2048);
   if (!planes_fresh) {
     if (pr_split.start) hipExtLaunchKernelGGL(k_split3, dim3(sgrid), dim3(256), 0, st, pr_split.start, pr_split.stop, 0, s);
@@ -301,17 +360,7 @@ hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, 
   a.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); a.nch2 = nch2;
   a.nbn = (d.C + 32 * NI - 1) / (32 * NI);
   a.nwg = ((4 * d.C + 32 * MI - 1) / (32 * MI)) * a.nbn;
-  constexpr int shm = NBUF * 3 * (32 * MI + 32 * NI) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_bf16x3<MI, NI, NBUF, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    if (err != hipSuccess) return err;
-    attr_set = true;
-  }
-  const dim3 grid((a.nwg + 7) / 8 * 8), block(512);
-  if (pr.start) hipExtLaunchKernelGGL((k_fold_bf16x3<MI, NI, NBUF, false, true>), grid, block, shm, st, pr.start, pr.stop, 0, a);
-  else hipLaunchKernelGGL((k_fold_bf16x3<MI, NI, NBUF, false, true>), grid, block, shm, st, a);
-  return hipGetLastError();
+  return s.mode == 2 ? launch_fold_planes<2>(a, st, pr) : launch_fold_planes<3>(a, st, pr);
 }
 
 }  // namespace klstm

@@ -68,7 +68,8 @@ hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const 
                             const float *bias, hipStream_t st, LaunchProbe pr = {});
 // the same product as six bf16 MFMA products of three-way split operands (fp32 accuracy; klstm_fold3.hip); scratch holds the planes
 bool fold_bf16x3_supported(const Dims &d);
-void set_fold_bf16x3(int v);
+void set_fold_bf16x3(int v);       // 0: fp32 MFMA kernel, 1: bf16 x 3 planes (six products), 2: fp16 x 2 planes (three products)
+int fold_split_mode();              // 1 / 2: the plane format the product kernel expects right now
 size_t fold_bf16x3_scratch_bytes(const Dims &d);
 hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
                               int nch2, hipStream_t st, LaunchProbe pr_split = {}, LaunchProbe pr = {}, bool planes_fresh = false);
@@ -127,6 +128,7 @@ struct GradsUpdate {
   float *params; float lr, clip; float *wrT, *wmT, *wxT;
   // optional: the bf16 planes of the fold operands (fold_bf16x3_planes) are written from the updated W_gifo_r / W_r_m too
   unsigned short *a3 = nullptr, *b3 = nullptr; long a_plane = 0, b_plane = 0;
+  int split_mode = 1;      // fold_split_mode()
 };
 // C = A B for few rows, a narrow result and a long contraction (klstm_fold.hip: the output layer's in_diff); ws holds one partial per K slice
 bool skinny_nn_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *Cm, int ldc);

@@ -1505,7 +1505,8 @@ struct GemmJob {
   // gradient product with the Update folded in (launch_grads with a GradsUpdate): Cm is the momentum buffer,
   // Cm = beta*Cm + A*B (:468-487), clipped if clip > 0, then P -= lr*Cm (:504-512); Ct then receives the UPDATED P
   float *P; float lr, clip;
-  unsigned short *s3; long s3pl; int s3t;   // three bf16 planes of the UPDATED P (s3t = 0: P's layout, ld = ldc; 1: Ct's layout, ld = ldct)
+  int s3mode;                                // plane format (klstm_math.h split_store4)
+  unsigned short *s3; long s3pl; int s3t;   // the bf16 / fp16 planes of the UPDATED P (s3t = 0: P's layout, ld = ldc; 1: Ct's layout, ld = ldct)
   int coal;               // 1: Cm = beta*Cm + A*B through the same coalesced 16-byte epilogue without P (N, ldc % 4 == 0, aligned, no bias)
 };
 
@@ -1714,7 +1715,7 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
           *reinterpret_cast<float4 *>(cs) = pv;
           if (g.s3 && !g.s3t) {
             const float v4[4] = {pv.x, pv.y, pv.z, pv.w};
-            bf16_split3_store4(v4, g.s3 + (size_t)m * g.ldc + n, g.s3pl);
+            split_store4(g.s3mode, v4, g.s3 + (size_t)m * g.ldc + n, g.s3pl);
           }
         }
       }
@@ -1729,7 +1730,7 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
         const float *cs = Cs + mq * GLX + nl;
         const float v4[4] = {cs[0], cs[GLX], cs[2 * GLX], cs[3 * GLX]};
         *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(v4[0], v4[1], v4[2], v4[3]);
-        if (g.s3 && g.s3t) bf16_split3_store4(v4, g.s3 + (size_t)n * g.ldct + m, g.s3pl);
+        if (g.s3 && g.s3t) split_store4(g.s3mode, v4, g.s3 + (size_t)n * g.ldct + m, g.s3pl);
       }
     }
     return;
@@ -2249,7 +2250,7 @@ struct UpdArgs {
   long voff, vlen;          // vector parameters (bias + 3 peepholes) are contiguous in the blob
   // optional (vector kernel): the three bf16 planes of the fold operands, written from the same tiles (klstm_fold3.hip):
   // a3 in W_gifo_r's own layout (matrix 1), b3 in W_r_m^T's (matrix 2, the transposed destination's)
-  unsigned short *a3, *b3; long a_plane, b_plane;
+  unsigned short *a3, *b3; long a_plane, b_plane; int split_mode;
 };
 
 __device__ __forceinline__ float upd_elem(const UpdArgs &a, long idx) {
@@ -2340,7 +2341,7 @@ __global__ __launch_bounds__(256) void k_update_repack_v(UpdArgs a) {
       v = upd_vec(a, a.off[mi] + (long)r * cols + c);
       if (mi == 1 && a.a3) {
         const float v4[4] = {v.x, v.y, v.z, v.w};
-        bf16_split3_store4(v4, a.a3 + (size_t)r * cols + c, a.a_plane);
+        split_store4(a.split_mode, v4, a.a3 + (size_t)r * cols + c, a.a_plane);
       }
     }
     *reinterpret_cast<float4 *>(tile + rl * 68 + cq) = v;
@@ -2355,7 +2356,7 @@ __global__ __launch_bounds__(256) void k_update_repack_v(UpdArgs a) {
       const float *tp = tile + rq * 68 + cl;
       const float v4[4] = {tp[0], tp[68], tp[2 * 68], tp[3 * 68]};
       *reinterpret_cast<float4 *>(dst + (size_t)c * rows + r) = make_float4(v4[0], v4[1], v4[2], v4[3]);
-      if (mi == 2 && a.b3) bf16_split3_store4(v4, a.b3 + (size_t)c * rows + r, a.b_plane);
+      if (mi == 2 && a.b3) split_store4(a.split_mode, v4, a.b3 + (size_t)c * rows + r, a.b_plane);
     }
   }
 }
@@ -3033,7 +3034,7 @@ static GemmJob make_job(bool transA, bool transB, int M, int N, int K, const flo
   g.Cm = Cm; g.ldc = ldc; g.bias = bias;
   g.Ct = nullptr; g.ldct = 0; g.C2 = nullptr; g.ldc2 = 0; g.C3 = nullptr; g.tail0 = 0;
   g.gperm = 0; g.pk1 = nullptr; g.nch1 = 0; g.pk2 = nullptr; g.nch2 = 0;
-  g.P = nullptr; g.lr = 0.f; g.clip = 0.f; g.coal = 0; g.s3 = nullptr; g.s3pl = 0; g.s3t = 0;
+  g.P = nullptr; g.lr = 0.f; g.clip = 0.f; g.coal = 0; g.s3 = nullptr; g.s3pl = 0; g.s3t = 0; g.s3mode = 1;
   // branch-free 8-wide fetches need aligned rows and a contiguous extent that is a multiple of 8
   g.vecA = aligned16(A) && lda % 4 == 0 && (transA ? M : K) % 8 == 0;
   g.vecB = aligned16(B) && ldb % 4 == 0 && (transB ? K : N) % 8 == 0;
@@ -3176,8 +3177,8 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
     a.wx.Ct = upd->wxT; a.wx.ldct = 4 * C;           // [I x 4C]
     a.wr.Ct = upd->wrT; a.wr.ldct = 4 * C;           // [R x 4C]
     a.wm.Ct = upd->wmT; a.wm.ldct = R;               // [C x R]
-    if (upd->a3) { a.wr.s3 = upd->a3; a.wr.s3pl = upd->a_plane; a.wr.s3t = 0; }
-    if (upd->b3) { a.wm.s3 = upd->b3; a.wm.s3pl = upd->b_plane; a.wm.s3t = 1; }
+    if (upd->a3) { a.wr.s3 = upd->a3; a.wr.s3pl = upd->a_plane; a.wr.s3t = 0; a.wr.s3mode = upd->split_mode; }
+    if (upd->b3) { a.wm.s3 = upd->b3; a.wm.s3pl = upd->b_plane; a.wm.s3t = 1; a.wm.s3mode = upd->split_mode; }
     a.p_bias = pb + o_b; a.p_pi = pb + o_pi; a.p_pf = pb + o_pf; a.p_po = pb + o_po;
   }
   if (!upd && aligned16(dst) && C % 4 == 0 && R % 4 == 0 && I % 4 == 0) a.wx.coal = a.wr.coal = a.wm.coal = 1;
@@ -3211,7 +3212,7 @@ hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_bl
   const int C = d.C, R = d.R, I = d.I;
   UpdArgs a;
   a.guard = guard;
-  a.a3 = a.b3 = nullptr; a.a_plane = a.b_plane = 0;
+  a.a3 = a.b3 = nullptr; a.a_plane = a.b_plane = 0; a.split_mode = 1;
   a.param = param_blob; a.corr = corr_blob; a.grad = grad_blob; a.mmt = mmt; a.lr = lr; a.clip = clip;
   a.touch = (lr != 0.f || grad_blob != nullptr || clip > 0.f) ? 1 : 0;
   const long o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_wm = o_b + 7 * C;
@@ -3226,7 +3227,7 @@ hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_bl
   for (int i = 0; i < 3; i++) { a.tb[i] = nb; nb += cdiv(a.rows[i], tsz) * cdiv(a.cols[i], tsz); }
   a.tb_vec = nb;
   nb += cdiv(7 * C, 1024);
-  if (vec && planes) { a.a3 = planes->a3; a.b3 = planes->b3; a.a_plane = planes->a_plane; a.b_plane = planes->b_plane; }
+  if (vec && planes) { a.a3 = planes->a3; a.b3 = planes->b3; a.a_plane = planes->a_plane; a.b_plane = planes->b_plane; a.split_mode = planes->split_mode; }
   if (vec) KLAUNCH(k_update_repack_v, dim3(nb), dim3(256), st, pr, a);
   KLAUNCH(k_update_repack, dim3(nb), dim3(256), st, pr, a);
 }

@@ -87,4 +87,25 @@ __device__ __forceinline__ void bf16_split3_store4(const float (&v)[4], unsigned
     *reinterpret_cast<uint2 *>(dst + q * plane) = make_uint2(h[q][0] | ((unsigned)h[q][1] << 16), h[q][2] | ((unsigned)h[q][3] << 16));
 }
 
+// Two-way fp16 split (the lighter fold product, klstm_fold3.hip NPL = 2): x = h1 + h2 / 2048 up to 2^-22 |x|; the residual is
+// scaled by 2^11 before it is rounded so that it stays a NORMAL fp16 number for |x| down to 2^-14 (below that the absolute
+// error, < 2^-36, is far under a product's rounding).  The product kernel keeps a1 b1 and (a1 b2 + a2 b1) in separate
+// accumulators and folds the 2^-11 in at the end.
+__device__ __forceinline__ void f16_split2(float x, unsigned short &h1, unsigned short &h2) {
+  const _Float16 a = (_Float16)x;                       // RNE
+  const float r = x - (float)a;                         // exact
+  const _Float16 b = (_Float16)(r * 2048.f);
+  h1 = __builtin_bit_cast(unsigned short, a); h2 = __builtin_bit_cast(unsigned short, b);
+}
+// mode 1: three bf16 planes, mode 2: two fp16 planes (plane 1 scaled by 2^11)
+__device__ __forceinline__ void split_store4(int mode, const float (&v)[4], unsigned short *dst, long plane) {
+  if (mode != 2) { bf16_split3_store4(v, dst, plane); return; }
+  unsigned short h[2][4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) f16_split2(v[e], h[0][e], h[1][e]);
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+    *reinterpret_cast<uint2 *>(dst + q * plane) = make_uint2(h[q][0] | ((unsigned)h[q][1] << 16), h[q][2] | ((unsigned)h[q][3] << 16));
+}
+
 }  // namespace klstm

@@ -33,7 +33,7 @@ int main() {
   const size_t apl = (size_t)4 * C * R, bpl = (size_t)C * R;
   unsigned short *b3 = a3 + 3 * apl;
   Split3Args s;
-  s.src[0] = wr; s.src[1] = wmT; s.dst[0] = a3; s.dst[1] = b3; s.plane[0] = apl; s.plane[1] = bpl; s.n8[0] = apl / 8; s.n8[1] = bpl / 8;
+  s.src[0] = wr; s.src[1] = wmT; s.dst[0] = a3; s.dst[1] = b3; s.plane[0] = apl; s.plane[1] = bpl; s.n8[0] = apl / 8; s.n8[1] = bpl / 8; s.mode = 1;
   for (unsigned g : {512u, 1024u, 2048u})  {
     char nm[96]; snprintf(nm, sizeof nm, "k_split3, %u workgroups", g);
     time(nm, [&]() { hipLaunchKernelGGL(k_split3, dim3(g), dim3(256), 0, st, s); });
@@ -60,17 +60,24 @@ int main() {
   a.C = C; a.R = R; a.a3 = a3; a.b3 = b3; a.a_plane = apl; a.b_plane = bpl;
   a.pk1 = reinterpret_cast<float4 *>(pk[0]); a.nch1 = nch1; a.pk2 = reinterpret_cast<float4 *>(pk[1]); a.nch2 = nch2;
 #define VAR(MI, NI, NB, ND) VARL(MI, NI, NB, ND, false)
-#define VARL(MI, NI, NB, ND, LW) do { \
+#define VARL(MI, NI, NB, ND, LW) VARP(MI, NI, NB, ND, LW, 3)
+#define VARP(MI, NI, NB, ND, LW, NPL) do { \
     a.nbn = cdv(C, 32 * NI); a.nwg = cdv(4 * C, 32 * MI) * a.nbn; \
-    const int shm = NB * 3 * (32 * MI + 32 * NI) * 64; \
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_bf16x3<MI, NI, NB, ND, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, shm)); \
-    char nm[128]; snprintf(nm, sizeof nm, "product %dx%d tiles, %d buffers (%d KB LDS), %d workgroups%s", 32 * MI, 32 * NI, NB, shm / 1024, a.nwg, ND ? ", NO refills" : LW ? ", 4 loader waves" : ""); \
-    time(nm, [&]() { hipLaunchKernelGGL((k_fold_bf16x3<MI, NI, NB, ND, LW>), dim3((a.nwg + 7) / 8 * 8), dim3(LW ? 512 : 256), shm, st, a); }); \
+    const int shm = NB * NPL * (32 * MI + 32 * NI) * 64; \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_bf16x3<MI, NI, NB, ND, LW, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, shm)); \
+    char nm[128]; snprintf(nm, sizeof nm, "%s product %dx%d tiles, %d buffers (%d KB LDS), %d workgroups%s", NPL == 2 ? "fp16x2" : "bf16x3", 32 * MI, 32 * NI, NB, shm / 1024, a.nwg, ND ? ", NO refills" : LW ? ", 4 loader waves" : ""); \
+    time(nm, [&]() { hipLaunchKernelGGL((k_fold_bf16x3<MI, NI, NB, ND, LW, NPL>), dim3((a.nwg + 7) / 8 * 8), dim3(LW ? 512 : 256), shm, st, a); }); \
     anatomy((a.nwg + 7) / 8 * 8); } while (0)
   VAR(4, 3, 2, false);
   VAR(4, 3, 3, false);
   VAR(4, 3, 3, true);
   VARL(4, 3, 3, false, true);
+  s.mode = 2; hipLaunchKernelGGL(k_split3, dim3(1024), dim3(256), 0, st, s); CK(hipStreamSynchronize(st));
+  VARP(4, 3, 3, false, true, 2);
+  VARP(4, 3, 4, false, true, 2);
+  VARP(4, 4, 3, false, true, 2);
+  VARP(4, 3, 3, true, true, 2);
+  s.mode = 1; hipLaunchKernelGGL(k_split3, dim3(1024), dim3(256), 0, st, s); CK(hipStreamSynchronize(st));
   VARL(2, 5, 3, false, true);
   VARL(2, 5, 2, false, true);
   VARL(3, 3, 3, false, true);
