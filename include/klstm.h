@@ -291,6 +291,11 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  products, dropped terms ~7e-7 relative (parameters must stay below 65504 in magnitude: beyond, the product
  *                  carries Inf / NaN); 1 = three bf16 planes, six products, dropped terms below 2^-24, fp32 range; 0 = the fp32
  *                  MFMA kernel.  Process-wide (A-B experiments).  "fold_direct" 0: the generic tile kernel
+ *   "direct_nt_shape"  klstm_affine_propagate of at most 80 rows into more than 8192 columns (the output layer of a small-minibatch
+ *                  step): default = the rows shared through LDS and the product on the f16 matrix cores at
+ *                  fp32 accuracy (both operands split into two fp16 planes on the fly, three products, fp32 accumulation; inputs
+ *                  and weights must stay below 65504 in magnitude); 99 = the same layout on the fp32 MFMA; 0 = the register-direct
+ *                  kernel (fp32 MFMA); 10*NI + waves = geometry of the register-direct kernel.  Process-wide (A-B experiments)
  *   "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.

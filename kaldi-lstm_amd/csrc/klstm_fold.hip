@@ -763,10 +763,137 @@ __global__ __launch_bounds__(256) void k_nt_shared_a(DirectNtArgs a) {
   kpass(slot < xunits ? nb_main + slot / MI : -1, slot < xunits ? slot % MI : 0, std::integral_constant<int, 1>());
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product on the f16 matrix cores at fp32 accuracy, operands split ON THE FLY (klstm_math.h f16_split2: x = h1 + h2 / 2048,
+// three products, cross terms in their own accumulators -- the scheme of the fold product, klstm_fold3.hip): the rows of A are
+// split once per workgroup when they are staged into LDS (two fp16 planes, rows of 64 bytes, the 16-byte k-group of row r in slot
+// kg ^ ((-(r >> 2)) & 3): conflict-free operand reads), the rows of B in registers by the wave that streams them (each element of
+// B is used by exactly one wave).  15 MFMAs of 16x16x32 per 32-k chunk and wave instead of 40 of 16x16x4.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 nt_f16x8 __attribute__((ext_vector_type(8)));
+template <int MI>
+__global__ __launch_bounds__(256, 2) void k_nt_shared_a16(DirectNtArgs a) {
+  constexpr bool DB = true;                              // operands of A read from LDS one step ahead
+  constexpr int BD = MI >= 5 ? 6 : 7, AD = MI >= 5 ? 3 : 4;   // A: loaded AD chunks ahead, in LDS two chunks ahead                    // chunks of B in flight per wave (registers: two waves per SIMD must fit)
+  constexpr int ROWS = 16 * MI, UNITS = ROWS * 8, NH = (UNITS + 255) / 256, PLB = ROWS * 64;   // bytes of one plane of one buffer
+  __shared__ __attribute__((aligned(16))) unsigned char As[4][2][PLB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int nchunk = a.K / 32;
+  const float *gsrc[NH];
+  int ldst[NH];
+  bool gon[NH];
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    const int u = tid + 256 * h, row = u >> 3, pc = u & 7;             // piece pc = floats 4 pc .. 4 pc + 3 of the chunk row
+    gon[h] = u < UNITS && row < a.M;
+    gsrc[h] = a.A + (size_t)(gon[h] ? row : 0) * a.lda + 4 * pc;
+    ldst[h] = u < UNITS ? row * 64 + (((pc >> 1) ^ ((-(row >> 2)) & 3)) * 16) + (pc & 1) * 8 : -1;
+  }
+  auto kpass = [&](int nbk, int m_lo, auto NMC) {
+    constexpr int NM = decltype(NMC)::value;
+    const int nb = 16 * (nbk < 0 ? 0 : nbk) + i16;
+    const float *bp = a.B + (size_t)(nb < a.N ? nb : 0) * a.ldb + 8 * kg;
+    float4 ga[4][NH], rb[8][2];
+    auto loadA = [&](int slot, int c) {
+#pragma unroll
+      for (int h = 0; h < NH; h++) ga[slot][h] = *reinterpret_cast<const float4 *>(gsrc[h] + 32 * c);
+    };
+    auto stashA = [&](int slot, int buf) {
+#pragma unroll
+      for (int h = 0; h < NH; h++)
+        if (ldst[h] >= 0) {
+          const float4 v = keep4(ga[slot][h], gon[h]);
+          uint2 h1, h2;
+          f16_split2_pair(v.x, v.y, h1.x, h2.x);
+          f16_split2_pair(v.z, v.w, h1.y, h2.y);
+          *reinterpret_cast<uint2 *>(&As[buf][0][ldst[h]]) = h1;
+          *reinterpret_cast<uint2 *>(&As[buf][1][ldst[h]]) = h2;
+        }
+    };
+    auto loadB = [&](int slot, int c) {
+      rb[slot][0] = *reinterpret_cast<const float4 *>(bp + 32 * c);
+      rb[slot][1] = *reinterpret_cast<const float4 *>(bp + 32 * c + 4);
+    };
+    f32x4 acc[NM], accx[NM];
+#pragma unroll
+    for (int mi = 0; mi < NM; mi++) { acc[mi] = (f32x4){0, 0, 0, 0}; accx[mi] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+    for (int d = 0; d < AD; d++) loadA(d, d < nchunk ? d : nchunk - 1);
+#pragma unroll
+    for (int d = 0; d < BD; d++) loadB(d, d < nchunk ? d : nchunk - 1);
+    stashA(0, 0);
+    stashA(1, 1);
+    __syncthreads();
+    const int aoff = (m_lo * 16 + i16) * 64 + ((kg ^ ((-(i16 >> 2)) & 3)) * 16);
+    nt_f16x8 av0[NM][2], av1[NM][2];
+    auto readA = [&](nt_f16x8 (&av)[NM][2], int buf) {
+#pragma unroll
+      for (int mi = 0; mi < NM; mi++) {
+        av[mi][0] = *reinterpret_cast<const nt_f16x8 *>(&As[buf][0][aoff + mi * 1024]);
+        av[mi][1] = *reinterpret_cast<const nt_f16x8 *>(&As[buf][1][aoff + mi * 1024]);
+      }
+    };
+    if (DB) readA(av0, 0);
+    auto step = [&](int c, auto JC, nt_f16x8 (&cur)[NM][2], nt_f16x8 (&nxt)[NM][2]) {
+      constexpr int J = decltype(JC)::value;
+      loadA((J + AD) & 3, c + AD < nchunk ? c + AD : nchunk - 1);
+      loadB((J + BD) & 7, c + BD < nchunk ? c + BD : nchunk - 1);
+      if (DB) readA(nxt, (J + 1) & 3);
+      else readA(cur, J & 3);
+      const float bf[8] = {rb[J][0].x, rb[J][0].y, rb[J][0].z, rb[J][0].w, rb[J][1].x, rb[J][1].y, rb[J][1].z, rb[J][1].w};
+      uint4 u1, u2;
+      f16_split2_pair(bf[0], bf[1], u1.x, u2.x);
+      f16_split2_pair(bf[2], bf[3], u1.y, u2.y);
+      f16_split2_pair(bf[4], bf[5], u1.z, u2.z);
+      f16_split2_pair(bf[6], bf[7], u1.w, u2.w);
+      const nt_f16x8 b1 = __builtin_bit_cast(nt_f16x8, u1), b2 = __builtin_bit_cast(nt_f16x8, u2);
+      if (nbk >= 0) {
+#pragma unroll
+        for (int mi = 0; mi < NM; mi++) {
+          accx[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[mi][0], b2, accx[mi], 0, 0, 0);
+          accx[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[mi][1], b1, accx[mi], 0, 0, 0);
+          acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[mi][0], b1, acc[mi], 0, 0, 0);
+        }
+      }
+      stashA((J + 2) & 3, (J + 2) & 3);
+      __syncthreads();
+    };
+    for (int c0 = 0; c0 < nchunk; c0 += 8) {           // K % 256 == 0
+      step(c0, std::integral_constant<int, 0>(), av0, av1);
+      step(c0 + 1, std::integral_constant<int, 1>(), av1, av0);
+      step(c0 + 2, std::integral_constant<int, 2>(), av0, av1);
+      step(c0 + 3, std::integral_constant<int, 3>(), av1, av0);
+      step(c0 + 4, std::integral_constant<int, 4>(), av0, av1);
+      step(c0 + 5, std::integral_constant<int, 5>(), av1, av0);
+      step(c0 + 6, std::integral_constant<int, 6>(), av0, av1);
+      step(c0 + 7, std::integral_constant<int, 7>(), av1, av0);
+    }
+#pragma unroll
+    for (int mi = 0; mi < NM; mi++) acc[mi] = acc[mi] + accx[mi] * (1.f / 2048.f);
+    if (nbk < 0 || nb >= a.N) return;
+    const float bias = a.bias ? a.bias[nb] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < NM; mi++) {
+      const float e[4] = {acc[mi].x, acc[mi].y, acc[mi].z, acc[mi].w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = 16 * (m_lo + mi) + 4 * kg + r;
+        if (m < a.M) a.Cm[(size_t)m * a.ldc + nb] = e[r] + bias;
+      }
+    }
+  };
+  const int slot = (int)blockIdx.x * 4 + wave, nb_main = (int)gridDim.x * 4, nb_total = (a.N + 15) / 16;
+  kpass(slot < nb_total ? slot : -1, 0, std::integral_constant<int, MI>());
+  const int xunits = (nb_total - nb_main) * MI;
+  if ((int)blockIdx.x * 4 >= xunits) return;
+  kpass(slot < xunits ? nb_main + slot / MI : -1, slot < xunits ? slot % MI : 0, std::integral_constant<int, 1>());
+}
+
 static int g_nt_shared = 1;
 static int g_nt_ni = 2, g_nt_waves = 1;   //    // measured at 80 x 16624 x 512 (tools/nt_sweep.py): 29.5 us; 1x1 36.7, 2x2 34.0, 4x1 49.4; tiled kernel 37.9
-void set_direct_nt_shape(int ni, int waves) {       // ni = 0, waves = 0 (option value 0): wide results on k_direct_nt again, not on k_nt_shared_a (A-B)
-  g_nt_shared = (ni == 0 && waves == 0) ? 0 : (ni == 9 && waves == 9) ? 2 : 1;     // 99: k_nt_shared_a at every width
+void set_direct_nt_shape(int ni, int waves) {       // option value 0: wide results on k_direct_nt again (A-B); 99: on the fp32 k_nt_shared_a;
+  g_nt_shared = (ni == 0 && waves == 0) ? 0 : (ni == 9 && waves == 9) ? 2 : (ni == 9 && waves == 8) ? 3 : 1;     // 98 (and every other value): on k_nt_shared_a16
   if (g_nt_shared != 1) return;
   g_nt_ni = ni == 1 || ni == 2 ? ni : 4; g_nt_waves = waves >= 1 && waves <= 4 ? waves : 2;
 }
@@ -797,16 +924,18 @@ hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const 
   // columns per wave (16*NI) and waves per workgroup: experiment knobs (g_nt_ni, g_nt_waves)
   const int ni = g_nt_ni, nw = g_nt_waves;
   const dim3 grid((N + 16 * ni * nw - 1) / (16 * ni * nw)), block(64 * nw);
-  // wide result: A shared through LDS -- where it measured faster (tools/t_affprop.py, 80 rows over K = 512): 9000 columns 20.6 vs
-  // 26.6 us; at the output layer's 16624 columns (1039 blocks on 1024 SIMDs) 28.2-30.7 vs 29.5 us for every variant tried (staging
-  // depth 2/3 or 4/7 chunks, operands read one step ahead, the blocks past 1024 as extra (block, row block) units): no gain, so
-  // that width stays on k_direct_nt unless the option asks (direct_nt_shape = 99)
-  if (N > 8192 && K % 256 == 0 && g_nt_shared && (N <= 14336 || g_nt_shared == 2)) {
+  // wide result: A shared through LDS.  tools/t_affprop.py, 80 rows over K = 512, 16624 / 9000 columns: k_direct_nt 29.7 / 26.7 us,
+  // k_nt_shared_a (fp32 MFMA, one wave per SIMD, the blocks past 1024 as a second pass) 29.1 / 18.9 us, k_nt_shared_a16 (f16 x 2
+  // operands split on the fly, two waves per SIMD so that all 260 workgroups are resident at once) 20.6 / 14.5 us: the default.
+  // direct_nt_shape = 99 asks for the fp32 form, 0 for k_direct_nt
+  if (N > 8192 && K % 256 == 0 && g_nt_shared) {
     const int nbt = (N + 15) / 16, mi_ = (M + 15) / 16;
     int wgs = (nbt + 3) / 4;
-    if (wgs > 256 && (nbt - 1024) * mi_ <= 1024) wgs = 256;      // the blocks past 1024 go out as extra (block, row block) units
+    if (g_nt_shared == 2 && wgs > 256 && (nbt - 1024) * mi_ <= 1024) wgs = 256;      // the blocks past 1024 go out as extra (block, row block) units
     const dim3 grid(wgs), block(256);
-#define SA_GO(MI_) do { if (pr.start) hipExtLaunchKernelGGL((k_nt_shared_a<MI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
+#define SA_GO(MI_) do { if (g_nt_shared != 2) { if (pr.start) hipExtLaunchKernelGGL((k_nt_shared_a16<MI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
+                                                else hipLaunchKernelGGL((k_nt_shared_a16<MI_>), grid, block, 0, st, a); } \
+                        else if (pr.start) hipExtLaunchKernelGGL((k_nt_shared_a<MI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
                         else hipLaunchKernelGGL((k_nt_shared_a<MI_>), grid, block, 0, st, a); } while (0)
     switch ((M + 15) / 16) {
       case 1: SA_GO(1); break;

@@ -97,15 +97,25 @@ __device__ __forceinline__ void f16_split2(float x, unsigned short &h1, unsigned
   const _Float16 b = (_Float16)(r * 2048.f);
   h1 = __builtin_bit_cast(unsigned short, a); h2 = __builtin_bit_cast(unsigned short, b);
 }
+// two at once: the packed conversions and packed fp32 arithmetic of gfx950 (v_cvt_pk_f16_f32, v_pk_add_f32, v_pk_mul_f32) -- three
+// instructions per element instead of six; same bits as f16_split2.  h1 / h2 = the pairs (x0 low half, x1 high half)
+typedef _Float16 klstm_h2 __attribute__((ext_vector_type(2)));
+typedef float klstm_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void f16_split2_pair(float x0, float x1, unsigned &h1, unsigned &h2) {
+  const klstm_f2 f = {x0, x1};
+  const klstm_h2 a = __builtin_convertvector(f, klstm_h2);
+  const klstm_f2 r = (f - __builtin_convertvector(a, klstm_f2)) * 2048.f;
+  const klstm_h2 b = __builtin_convertvector(r, klstm_h2);
+  h1 = __builtin_bit_cast(unsigned, a); h2 = __builtin_bit_cast(unsigned, b);
+}
 // mode 1: three bf16 planes, mode 2: two fp16 planes (plane 1 scaled by 2^11)
 __device__ __forceinline__ void split_store4(int mode, const float (&v)[4], unsigned short *dst, long plane) {
   if (mode != 2) { bf16_split3_store4(v, dst, plane); return; }
-  unsigned short h[2][4];
+  unsigned h[2][2];
+  f16_split2_pair(v[0], v[1], h[0][0], h[1][0]);
+  f16_split2_pair(v[2], v[3], h[0][1], h[1][1]);
 #pragma unroll
-  for (int e = 0; e < 4; e++) f16_split2(v[e], h[0][e], h[1][e]);
-#pragma unroll
-  for (int q = 0; q < 2; q++)
-    *reinterpret_cast<uint2 *>(dst + q * plane) = make_uint2(h[q][0] | ((unsigned)h[q][1] << 16), h[q][2] | ((unsigned)h[q][3] << 16));
+  for (int q = 0; q < 2; q++) *reinterpret_cast<uint2 *>(dst + q * plane) = make_uint2(h[q][0], h[q][1]);
 }
 
 }  // namespace klstm

@@ -1,4 +1,4 @@
-"""Device time of klstm_affine_propagate (few rows, wide layer) -- k_nt_shared_a against k_direct_nt (option direct_nt_shape = 0)."""
+"""Device time of klstm_affine_propagate (few rows, wide layer): k_nt_shared_a16 (f16 x 2, the default; option direct_nt_shape = 98), the fp32 k_nt_shared_a (99) and k_direct_nt (0)."""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kaldi_lstm_amd as k
@@ -15,8 +15,12 @@ def t(label, x, W, b, out):
 for N, K, M in ((80, 512, 16624), (37, 512, 16624), (80, 256, 16624), (80, 512, 9000)):
     x = torch.randn(N, K, device="cuda"); W = torch.randn(M, K, device="cuda") * 0.1; b = torch.randn(M, device="cuda"); out = torch.empty(N, M, device="cuda")
     torch.cuda.synchronize()
+    e.set_option("direct_nt_shape", 98)
+    t("rows %d in %d out %d: A shared, f16 x 2 split" % (N, K, M), x, W, b, out)
+    r16 = out.clone()
     e.set_option("direct_nt_shape", 99)
     t("rows %d in %d out %d: A shared in LDS" % (N, K, M), x, W, b, out)
+    print("   f16-split vs fp32 kernel: max |difference| %.2e" % (r16 - out).abs().max().item())
     ref = out.clone()
     e.set_option("direct_nt_shape", 0)
     t("rows %d in %d out %d: register-direct" % (N, K, M), x, W, b, out)
