@@ -1004,6 +1004,10 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     set_direct_nt_shape(value / 10, value % 10);
     return KLSTM_OK;
   }
+  if (!strcmp(key, "outer_f16")) {               // 0: the wide gradient product on the fp32 tile kernel (A-B; process-wide)
+    set_outer_f16(value);
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "fold_direct")) {             // 0: the fold product on the generic 64x64-tile kernel (A-B; process-wide)
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
@@ -1152,6 +1156,12 @@ klstm_status klstm_affine_update(const float *in, int in_stride, const float *ou
                                  float lr_bias, float momentum, void *hip_stream) {
   if (!in || !out_diff || !W || !bias || !W_corr || !bias_corr) return fail(KLSTM_ERR_ARG, "klstm_affine_update: null argument");
   hipStream_t st = (hipStream_t)hip_stream;
+  if (outer_f16_supported(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, W_corr, in_dim, W)) {   // few frames, wide layer (klstm_outer.hip)
+    HIPCHK(launch_outer_f16(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, momentum, W_corr, in_dim, W, lr, momentum,
+                            bias_corr, st));
+    HIPCHK(launch_axpy(bias, bias_corr, -lr_bias, out_dim, st));
+    return KLSTM_OK;
+  }
   if (in_dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(W_corr)) & 15) == 0) {
     // gradient product, momentum and Update of the weight matrix in one pass (no second trip over the 3 x 34 MB)
     HIPCHK(launch_gemm_tn_update(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, momentum, W_corr, W, in_dim, lr, st));
@@ -1167,6 +1177,11 @@ klstm_status klstm_affine_gradient(const float *in, int in_stride, const float *
                                    int out_dim, float *W_grad, float *bias_grad, void *hip_stream) {
   if (!in || !out_diff || !W_grad || !bias_grad) return fail(KLSTM_ERR_ARG, "klstm_affine_gradient: null argument");
   hipStream_t st = (hipStream_t)hip_stream;
+  if (outer_f16_supported(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, W_grad, in_dim, nullptr)) {
+    HIPCHK(launch_outer_f16(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, 0.f, W_grad, in_dim, nullptr, 0.f, 0.f,
+                            bias_grad, st));
+    return KLSTM_OK;
+  }
   if (in_dim % 4 == 0 && (reinterpret_cast<uintptr_t>(W_grad) & 15) == 0)
     HIPCHK(launch_gemm_tn_coal(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, 0.f, W_grad, in_dim, st));
   else

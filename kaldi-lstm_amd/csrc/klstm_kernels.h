@@ -59,6 +59,12 @@ hipError_t launch_fold_direct(const Dims &d, const float *wr, const float *wmT, 
 // Cm = beta*Cm + A^T B and P -= lr*Cm in one pass (N, ldc % 4 == 0, 16-byte aligned Cm and P)
 hipError_t launch_gemm_tn_update(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm,
                                  float *P, int ldc, float lr, hipStream_t st, LaunchProbe pr = {});
+// klstm_outer.hip: G = A^T B for few frames (K <= 96) and a wide result on the f16 matrix cores at fp32 accuracy, + column sums of A
+bool outer_f16_supported(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, const float *Cm, int ldc,
+                         const float *P);
+hipError_t launch_outer_f16(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, float beta, float *Cm, int ldc,
+                            float *P, float lr, float beta_b, float *bias, hipStream_t st, LaunchProbe pr = {});
+void set_outer_f16(int on);
 hipError_t launch_gemm_tn_coal(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm,
                                int ldc, hipStream_t st, LaunchProbe pr = {});
 // C = A B^T + bias for up to 80 rows and many columns, operands straight into MFMA registers (klstm_fold.hip)

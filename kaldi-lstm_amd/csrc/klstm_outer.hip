@@ -1,0 +1,260 @@
+// kaldi-lstm_amd/csrc/klstm_outer.hip -- gradient of a wide AffineTransform at few frames: G = out_diff^T in  (M = out_dim rows,
+// N = in_dim columns, contraction over K = frames of the minibatch, 80 at 4 streams x 20 frames): AffineTransform::Update of the
+// output layer 512 -> 16624 ([UPSTREAM] nnet-affine-transform.h, not vendored in the reference -- include/klstm.h, output tail:
+// linearity_corr = mmt * linearity_corr + out_diff^T in, bias_corr = mmt * bias_corr + column sums of out_diff).
+//
+// The product is 1.36 GFLOP writing 34 MB; the 64 x 64-tile fp32 kernel (klstm_kernels.hip k_gemm<true, false>) took 27 us for it
+// (+ 3 us for the column sums in a launch of their own): 2080 tiles whose 80-deep contraction is over before the loads of the tile
+// are amortised, and 10 us of fp32 MFMA issue on top.
+//
+// k_outer16: the product on the f16 matrix cores at fp32 accuracy (klstm_math.h f16_split2_pair: x = h1 + h2 / 2048, both normal
+// fp16 down to |x| = 2^-14; three products a1 b1 + (a1 b2 + a2 b1) / 2048 with the cross terms in their own accumulators, as the
+// fold product, klstm_fold3.hip; dropped a2 b2 ~ 2^-22 relative), both operands split in registers, no LDS, no barrier, no
+// workspace.  Both operands are stored k-major ([frame][column]), the MFMA wants 8 consecutive k of one row per lane: lane
+// (i16, kg) loads the float4 at columns 4 i16 .. 4 i16 + 3 of frames 32c + 8 kg + e, e = 0..7 (every load instruction = four
+// 256-byte runs), and the e-th components of the eight registers ARE the operands of the four "virtual" 16-row blocks
+// {4 i + cm : i = 0..15}, cm = 0..3 -- the transpose costs nothing.  With the same assignment on the n side the four accumulators
+// of a lane are one 16-byte piece of a row of G and sixteen lanes write 256 contiguous bytes.
+// A workgroup = one strip of 64 rows of G (260 strips at 16624: all resident at once at one or two waves per SIMD); each of the
+// four waves splits the strip's 64 columns of out_diff ONCE (all K <= 96 frames, kept as fp16 planes in registers: 32 per
+// chunk of 32 frames) and walks its 64-column tiles of `in` (two at N = 512) with the raw rows of the next step in flight
+// under the 48 MFMAs of the current one.  Wave 0 also sums the strip's columns of out_diff (the bias gradient: no second launch).
+// The epilogue is the store (gradient), or  corr = mmt * corr + G; W -= lr * corr  (Update in the same pass).
+// (First version, kept in the history: planes written k-contiguous by a prep launch, 16-byte operand loads from them: 8.9 + 26 us
+//  -- every 128-byte line of the planes fetched twice through a 32 KB L1, 200 MB of operand ingest.)
+// Values must stay below 65504 in magnitude (fp16 range): out_diff of a softmax / cross-entropy layer is within [-1, 1].
+#include "klstm_kernels.h"
+#include "klstm_math.h"
+#include <hip/hip_ext.h>
+#include <type_traits>
+
+namespace klstm {
+
+typedef float of32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 of16x8 __attribute__((ext_vector_type(8)));
+
+struct OuterArgs {
+  const float *diff; int ldd;          // [K][M]
+  const float *x; int ldx;             // [K][N]
+  int K, M, N;
+  int m_main, nextra;                  // strips cover rows [0, m_main); rows m_main .. m_main + nextra - 1 go out one per workgroup (VALU)
+  float beta_b; float *bias;           // bias = beta_b * bias + column sums of diff
+  float beta; float *Cm; int ldc;      // Cm = beta * Cm + G
+  float *P; float lr;                  // P -= lr * Cm  (nullptr: gradient only)
+};
+
+__device__ __forceinline__ of32x4 outer_keep(of32x4 v, bool on) { return on ? v : (of32x4){0.f, 0.f, 0.f, 0.f}; }
+
+// eight rows (frames) x four columns of raw values -> per column cm the eight frames as two fp16 planes
+__device__ __forceinline__ void outer_split(const of32x4 (&raw)[8], of16x8 (&p1)[4], of16x8 (&p2)[4]) {
+#pragma unroll
+  for (int cm = 0; cm < 4; cm++) {
+    uint4 u1, u2;
+    f16_split2_pair(raw[0][cm], raw[1][cm], u1.x, u2.x);
+    f16_split2_pair(raw[2][cm], raw[3][cm], u1.y, u2.y);
+    f16_split2_pair(raw[4][cm], raw[5][cm], u1.z, u2.z);
+    f16_split2_pair(raw[6][cm], raw[7][cm], u1.w, u2.w);
+    p1[cm] = __builtin_bit_cast(of16x8, u1); p2[cm] = __builtin_bit_cast(of16x8, u2);
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int m0 = (int)blockIdx.x * 64;
+  const int mc = m0 + 4 * i16;                           // this lane's four columns of out_diff (rows of G); M % 4 == 0
+  const bool m_in = mc < a.m_main;
+  // ---- a row past the strips (16624 = 256 strips of 64 + 240 rows: a 257th..260th workgroup would run alone behind the other 256):
+  //      workgroup b also produces row m_main + b, on the vector ALU in exact fp32, from the rows of `in` its waves hold for the
+  //      MFMA operands anyway: lane (i16, kg) multiplies its eight frames of a chunk with that row's eight values of out_diff,
+  //      the four frame groups meet through two lane exchanges ----
+  const bool has_x = (int)blockIdx.x < a.nextra;
+  const int mx = has_x ? a.m_main + (int)blockIdx.x : 0;
+  __shared__ __attribute__((aligned(16))) float xd[32 * NCH];
+  of32x4 rawb[NCH][8];
+  auto loadChunk = [&](int j, auto, of32x4 (&dst)[8], int c) {
+    const int nc = 64 * (wave + 4 * j) + 4 * i16;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int k = 32 * c + 8 * kg + e;
+      dst[e] = *reinterpret_cast<const of32x4 *>(a.x + (size_t)(k < a.K ? k : 0) * a.ldx + (nc < a.N ? nc : 0));
+    }
+  };
+  auto loadTile = [&](int j) {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) loadChunk(j, std::integral_constant<int, 0>(), rawb[c], c);
+  };
+  // ---- the strip's columns of out_diff: all chunks, split once ----
+  of16x8 a1[NCH][4], a2[NCH][4];
+  of32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+  {
+    of32x4 raw[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int k = 32 * c + 8 * kg + e;
+        raw[c][e] = *reinterpret_cast<const of32x4 *>(a.diff + (size_t)(k < a.K ? k : 0) * a.ldd + (m_in ? mc : 0));
+      }
+    if (tid < 32 * NCH) xd[tid] = has_x && tid < a.K ? a.diff[(size_t)tid * a.ldd + mx] : 0.f;   // (LDS: 24 registers less per lane)
+    loadTile(0);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        raw[c][e] = outer_keep(raw[c][e], m_in && 32 * c + 8 * kg + e < a.K);
+        colsum += raw[c][e];
+      }
+      outer_split(raw[c], a1[c], a2[c]);
+    }
+  }
+  if (wave == 0 && a.bias) {                             // the four k-groups of a column sit in lanes i16 + 16 kg
+    of32x4 v = colsum;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      v[q] += __shfl_xor(v[q], 16);
+      v[q] += __shfl_xor(v[q], 32);
+    }
+    if (kg == 0 && m_in) {
+      float4 *bp = reinterpret_cast<float4 *>(a.bias + mc);
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (a.beta_b != 0.f) { const float4 b = *bp; o.x += a.beta_b * b.x; o.y += a.beta_b * b.y; o.z += a.beta_b * b.z; o.w += a.beta_b * b.w; }
+      *bp = o;
+    }
+  }
+  __syncthreads();                                       // xd
+  if (wave == 0 && has_x && a.bias) {
+    float bs = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+      if (lane < 32) bs += xd[32 * c + lane];
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) bs += __shfl_xor(bs, o);
+    if (lane == 0) a.bias[mx] = (a.beta_b != 0.f ? a.beta_b * a.bias[mx] : 0.f) + bs;
+  }
+  // ---- this wave's 64-column tiles of `in`: the raw rows of the NEXT tile in flight under the 48 NCH MFMAs of the current one ----
+  const int ntile = (a.N + 63) / 64, nmine = wave < ntile ? (ntile - wave + 3) / 4 : 0;
+  if (nmine == 0) return;
+#pragma unroll 1
+  for (int j = 0; j < nmine; j++) {
+    const int nc = 64 * (wave + 4 * j) + 4 * i16;
+    of32x4 acc[4][4], accx[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+      for (int cn = 0; cn < 4; cn++) { acc[mi][cn] = (of32x4){0, 0, 0, 0}; accx[mi][cn] = (of32x4){0, 0, 0, 0}; }
+    of32x4 xg = {0.f, 0.f, 0.f, 0.f};
+    const int jn = j + 1 < nmine ? j + 1 : j;            // (unconditional: past the end the same rows again, never used)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      of16x8 b1[4], b2[4];
+#pragma unroll
+      for (int e = 0; e < 8; e++) rawb[c][e] = outer_keep(rawb[c][e], nc < a.N && 32 * c + 8 * kg + e < a.K);
+      outer_split(rawb[c], b1, b2);
+      if (has_x) {
+        const of32x4 d0 = *reinterpret_cast<const of32x4 *>(&xd[32 * c + 8 * kg]), d1 = *reinterpret_cast<const of32x4 *>(&xd[32 * c + 8 * kg + 4]);
+#pragma unroll
+        for (int e = 0; e < 4; e++) xg += d0[e] * rawb[c][e] + d1[e] * rawb[c][e + 4];
+      }
+      loadChunk(jn, std::integral_constant<int, 0>(), rawb[c], c);
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int cn = 0; cn < 4; cn++) {
+          accx[mi][cn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[c][mi], b2[cn], accx[mi][cn], 0, 0, 0);
+          accx[mi][cn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[c][mi], b1[cn], accx[mi][cn], 0, 0, 0);
+          acc[mi][cn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[c][mi], b1[cn], acc[mi][cn], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);                 // (the next chunk's planes are not built ahead: registers)
+    }
+    if (nc >= a.N) continue;
+    if (has_x) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        xg[q] += __shfl_xor(xg[q], 16);
+        xg[q] += __shfl_xor(xg[q], 32);
+      }
+      if (kg == 0) {
+        float4 g = make_float4(xg[0], xg[1], xg[2], xg[3]);
+        float4 *cp = reinterpret_cast<float4 *>(a.Cm + (size_t)mx * a.ldc + nc);
+        if (a.beta != 0.f) {
+          const float4 o = *cp;
+          g.x += a.beta * o.x; g.y += a.beta * o.y; g.z += a.beta * o.z; g.w += a.beta * o.w;
+        }
+        *cp = g;
+        if (a.P) {
+          float4 *pp = reinterpret_cast<float4 *>(a.P + (size_t)mx * a.ldc + nc);
+          float4 p = *pp;
+          p.x -= a.lr * g.x; p.y -= a.lr * g.y; p.z -= a.lr * g.z; p.w -= a.lr * g.w;
+          *pp = p;
+        }
+      }
+    }
+    // accumulator (mi, cn)[r] = G[m0 + 4 (4 kg + r) + mi][nc + cn]
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = m0 + 16 * kg + 4 * r + mi;
+        if (m >= a.m_main) continue;
+        float4 g = make_float4(acc[mi][0][r] + accx[mi][0][r] * (1.f / 2048.f), acc[mi][1][r] + accx[mi][1][r] * (1.f / 2048.f),
+                               acc[mi][2][r] + accx[mi][2][r] * (1.f / 2048.f), acc[mi][3][r] + accx[mi][3][r] * (1.f / 2048.f));
+        float4 *cp = reinterpret_cast<float4 *>(a.Cm + (size_t)m * a.ldc + nc);
+        if (a.beta != 0.f) {
+          const float4 o = *cp;
+          g.x += a.beta * o.x; g.y += a.beta * o.y; g.z += a.beta * o.z; g.w += a.beta * o.w;
+        }
+        *cp = g;
+        if (a.P) {
+          float4 *pp = reinterpret_cast<float4 *>(a.P + (size_t)m * a.ldc + nc);
+          float4 p = *pp;
+          p.x -= a.lr * g.x; p.y -= a.lr * g.y; p.z -= a.lr * g.z; p.w -= a.lr * g.w;
+          *pp = p;
+        }
+      }
+  }
+}
+
+static int g_outer_f16 = 1;
+void set_outer_f16(int on) { g_outer_f16 = on; }
+
+// few frames (the contraction: three chunks of 32 are held in registers), a wide result: below ~2k rows of G the strips do not fill the chip
+bool outer_f16_supported(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, const float *Cm, int ldc,
+                         const float *P) {
+  return g_outer_f16 != 0 && K >= 1 && K <= 96 && M >= 2048 && M % 4 == 0 && N >= 64 && N % 4 == 0 && ldc % 4 == 0 && ldd % 4 == 0 &&
+         ldx % 4 == 0 && ((reinterpret_cast<uintptr_t>(Cm) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(diff) |
+                           reinterpret_cast<uintptr_t>(x)) & 15) == 0 && diff && x;
+}
+hipError_t launch_outer_f16(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, float beta, float *Cm, int ldc,
+                            float *P, float lr, float beta_b, float *bias, hipStream_t st, LaunchProbe pr) {
+  OuterArgs a;
+  a.diff = diff; a.ldd = ldd; a.x = x; a.ldx = ldx; a.K = K; a.M = M; a.N = N;
+  a.beta_b = beta_b; a.bias = bias; a.beta = beta; a.Cm = Cm; a.ldc = ldc; a.P = P; a.lr = lr;
+  // one round of workgroups where a few rows past a whole number of strips per CU would start a second one
+  static int ncu_of[64];                                 // per device, asked once
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (ncu_of[dev] == 0) {
+      int v = 0;
+      ncu_of[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
+    }
+    ncu = ncu_of[dev];
+  }
+  int nstrip = (M + 63) / 64;
+  a.m_main = M; a.nextra = 0;
+  if (nstrip > ncu && M - 64 * ncu <= ncu) { nstrip = ncu; a.m_main = 64 * ncu; a.nextra = M - a.m_main; }
+  const dim3 grid(nstrip), block(256);
+#define OUTER_GO(NCH_) do { if (pr.start) hipExtLaunchKernelGGL(k_outer16<NCH_>, grid, block, 0, st, pr.start, pr.stop, 0, a); \
+                            else hipLaunchKernelGGL(k_outer16<NCH_>, grid, block, 0, st, a); } while (0)
+  switch ((K + 31) / 32) {
+    case 1: OUTER_GO(1); break;
+    case 2: OUTER_GO(2); break;
+    case 3: OUTER_GO(3); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef OUTER_GO
+  return hipGetLastError();
+}
+
+}  // namespace klstm

@@ -477,6 +477,37 @@ def test_affine_softmax_xent_tail(N, K, M):
     assert np.all(diff.cpu().numpy()[mask == 0] == 0.0)         # masked frames give exactly zero diff (:107)
 
 
+@pytest.mark.parametrize("N,K,M", [(80, 512, 16624),    # 256 strips of 64 + 240 rows that ride along, one per workgroup (klstm_outer.hip)
+                                   (96, 512, 16388),     # four rows past the strips, three full chunks of frames
+                                   (1, 64, 2048), (33, 68, 2052), (64, 512, 9000),   # one / two chunks, ragged last strip, N % 64 != 0
+                                   (80, 512, 33000),     # more than two rounds of strips: no rows ride along
+                                   (97, 512, 16624), (80, 512, 1000)])               # outside the kernel's range: tiled fp32 kernel
+def test_affine_gradient_wide(N, K, M):
+    """klstm_affine_gradient (W_grad = out_diff^T in, bias_grad = column sums) of a wide layer at few frames, operands in strided
+    views: the f16 x 2 matrix-core kernel (klstm_outer.hip) and the tiled fp32 kernel agree with float64 to 2e-6 of the largest
+    entry (fp32 accumulation of <= 97 products; the split drops terms ~2^-22 relative), the column sums to 2e-6; memory outside
+    the views is untouched."""
+    import kaldi_lstm_amd as k
+    rng = np.random.RandomState(M + N)
+    x = rng.randn(N, K).astype(np.float32)
+    diff = (rng.rand(N, M) - 0.5).astype(np.float32)
+    diff[rng.rand(N) < 0.2] = 0.0                        # masked frames
+    xs = torch.full((N, K + 4), 7.0, device="cuda"); xs[:, :K] = dev(x)
+    ds = torch.full((N, M + 8), 7.0, device="cuda"); ds[:, :M] = dev(diff)
+    gW = torch.full((M + 1, K), 5.0, device="cuda"); gb = torch.full((M + 1,), 5.0, device="cuda")
+    e = k.Engine(40, 64, 32, 4)
+    ref = diff.astype(np.float64).T @ x.astype(np.float64)
+    for on in (1, 0):
+        e.set_option("outer_f16", on)
+        gW.fill_(5.0); gb.fill_(5.0)
+        k.affine_gradient(xs[:, :K], ds[:, :M], gW[:M], gb[:M])
+        torch.cuda.synchronize()
+        assert relerr(gW[:M].cpu().numpy(), ref) <= 2e-6, on
+        assert relerr(gb[:M].cpu().numpy(), diff.astype(np.float64).sum(0)) <= 2e-6, on
+        assert torch.all(gW[M] == 5.0) and gb[M].item() == 5.0
+    e.set_option("outer_f16", 1)
+
+
 @pytest.mark.parametrize("N,M", [(12, 37), (80, 4203), (24, 16624)])
 def test_xent_eval_masked_general_posteriors(N, M):
     """Xent::EvalMasked with the reference's Posterior argument (nnet-loss.cc:76-142): several weighted pdfs per frame,
