@@ -1004,6 +1004,10 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     set_direct_nt_shape(value / 10, value % 10);
     return KLSTM_OK;
   }
+  if (!strcmp(key, "skinny_f16")) {              // 0: in_diff of a wide layer on the fp32 MFMA kernel (A-B; process-wide)
+    set_skinny_f16(value);
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "outer_f16")) {               // 0: the wide gradient product on the fp32 tile kernel (A-B; process-wide)
     set_outer_f16(value);
     return KLSTM_OK;

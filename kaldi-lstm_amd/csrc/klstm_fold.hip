@@ -547,9 +547,13 @@ __global__ __launch_bounds__(256) void k_skinny_nn_reduce(SkinnyNnArgs a) {
   const int per = (a.nks + 7) / 8, s0 = grp * per, s1 = min(a.nks, s0 + per);
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e4 < tot4)
-    for (int s = s0; s < s1; s++) {
-      const float4 v = *reinterpret_cast<const float4 *>(a.ws + ((size_t)s * tot4 + e4) * 4);
-      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    for (int sb = s0; sb < s1; sb += 8) {              // eight slices' loads in flight, added in slice order
+      float4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const float4 *>(a.ws + ((size_t)min(sb + q, s1 - 1) * tot4 + e4) * 4);
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if (sb + q < s1) { sum.x += v[q].x; sum.y += v[q].y; sum.z += v[q].z; sum.w += v[q].w; }
     }
   red[grp][el] = sum;
   __syncthreads();
@@ -560,6 +564,130 @@ __global__ __launch_bounds__(256) void k_skinny_nn_reduce(SkinnyNnArgs a) {
     const size_t m = e4 * 4 / a.N, n = e4 * 4 % a.N;
     *reinterpret_cast<float4 *>(a.Cm + m * a.ldc + n) = t;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product on the f16 matrix cores at fp32 accuracy (klstm_math.h f16_split2_pair, three products, cross terms in their own
+// accumulators -- klstm_fold3.hip / klstm_outer.hip), both operands split in registers: A rows are k-contiguous (8 consecutive k
+// of a lane's row = two 16-byte loads = one operand), B is the virtual-column layout above (component cn of the eight rows a
+// lane loads = the operand of column block cn).  Workgroup (64-column tile t, K group g): ntile x G = one round of the chip;
+// the 32-row chunks of K are dealt evenly to the 4 G wave slots (16624 = 519.5 chunks over 128 slots: 4 or 5 each), the raw rows
+// of the next chunk in flight under the 12 MI MFMAs of the current one; the four waves' tiles meet in LDS in wave order and
+// go to ws[g][M][N]; k_skinny_nn_reduce adds the G groups in order.  80 x 512 x 16624: 30.6 us (k_skinny_nn: 7 us until the
+// loads are issued, then 10 us of fp32 MFMAs, then the reduction, nothing overlapped) -> see tools/t_indiff.py.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 sk_f16x8 __attribute__((ext_vector_type(8)));
+template <int MI>
+__global__ __launch_bounds__(256) void k_skinny_nn16(SkinnyNnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float part16[];    // [4 waves][16 MI rows][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int ntile = (a.N + 63) / 64, t = (int)blockIdx.x % ntile, g = (int)blockIdx.x / ntile;
+  const int nc = 64 * t + 4 * i16;
+  const bool n_in = nc < a.N;
+  const int nchunk = (a.K + 31) / 32, nslot = 4 * a.nks, slot = 4 * g + wave;
+  const int c0 = (int)((long)slot * nchunk / nslot), c1 = (int)((long)(slot + 1) * nchunk / nslot);
+  const float *ap[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) ap[mi] = a.A + (size_t)min(16 * mi + i16, a.M - 1) * a.lda;
+  const float *bp = a.B + (n_in ? nc : 0);
+  sk_f32x4 ra[3][MI][2], rb[3][8];
+  auto loadA = [&](sk_f32x4 (&da)[MI][2], int c_) {
+    const int c = c_ < c1 ? c_ : c1 - 1;                 // (unconditional: past the slot's last chunk the same rows again, never used)
+    const int k = 32 * c + 8 * kg, ka = k + 8 <= a.K ? k : 0;        // K % 8 == 0
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+      da[mi][0] = *reinterpret_cast<const sk_f32x4 *>(ap[mi] + ka);
+      da[mi][1] = *reinterpret_cast<const sk_f32x4 *>(ap[mi] + ka + 4);
+    }
+  };
+  auto loadB = [&](sk_f32x4 (&db)[8], int c_) {
+    const int c = c_ < c1 ? c_ : c1 - 1;
+    const int k = 32 * c + 8 * kg;
+#pragma unroll
+    for (int e = 0; e < 8; e++) db[e] = *reinterpret_cast<const sk_f32x4 *>(bp + (size_t)(k + e < a.K ? k + e : 0) * a.ldb);
+  };
+  sk_f32x4 acc[MI][4], accx[MI][4];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int cn = 0; cn < 4; cn++) { acc[mi][cn] = (sk_f32x4){0, 0, 0, 0}; accx[mi][cn] = (sk_f32x4){0, 0, 0, 0}; }
+  // one chunk: B planes first and the rows of B three chunks on requested into the registers just freed (W streams from HBM), then row
+  // block by row block: split A's eight values, 12 MFMAs; A's rows three chunks on requested at the end
+  auto body = [&](int c, sk_f32x4 (&ca)[MI][2], sk_f32x4 (&cb)[8]) {
+    const bool kin = 32 * c + 8 * kg + 8 <= a.K;
+    sk_f16x8 b1[4], b2[4];
+#pragma unroll
+    for (int cn = 0; cn < 4; cn++) {
+      uint4 u1, u2;
+      f16_split2_pair(cb[0][cn], cb[1][cn], u1.x, u2.x);
+      f16_split2_pair(cb[2][cn], cb[3][cn], u1.y, u2.y);
+      f16_split2_pair(cb[4][cn], cb[5][cn], u1.z, u2.z);
+      f16_split2_pair(cb[6][cn], cb[7][cn], u1.w, u2.w);
+      b1[cn] = __builtin_bit_cast(sk_f16x8, u1); b2[cn] = __builtin_bit_cast(sk_f16x8, u2);   // (rows past K meet zeros of A)
+    }
+    loadB(cb, c + 3);
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+      const bool on = kin && 16 * mi + i16 < a.M;
+      const sk_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const sk_f32x4 v0 = on ? ca[mi][0] : z, v1 = on ? ca[mi][1] : z;
+      uint4 u1, u2;
+      f16_split2_pair(v0[0], v0[1], u1.x, u2.x);
+      f16_split2_pair(v0[2], v0[3], u1.y, u2.y);
+      f16_split2_pair(v1[0], v1[1], u1.z, u2.z);
+      f16_split2_pair(v1[2], v1[3], u1.w, u2.w);
+      const sk_f16x8 a1 = __builtin_bit_cast(sk_f16x8, u1), a2 = __builtin_bit_cast(sk_f16x8, u2);
+#pragma unroll
+      for (int cn = 0; cn < 4; cn++) {
+        accx[mi][cn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2[cn], accx[mi][cn], 0, 0, 0);
+        accx[mi][cn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1[cn], accx[mi][cn], 0, 0, 0);
+        acc[mi][cn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[cn], acc[mi][cn], 0, 0, 0);
+      }
+    }
+    loadA(ca, c + 3);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (c0 < c1) {
+    loadB(rb[0], c0); loadA(ra[0], c0);
+    loadB(rb[1], c0 + 1); loadA(ra[1], c0 + 1);
+    loadB(rb[2], c0 + 2); loadA(ra[2], c0 + 2);
+    for (int c = c0; c < c1; c += 3) {                   // three chunks in flight: 24 KB per wave
+      body(c, ra[0], rb[0]);
+      if (c + 1 < c1) body(c + 1, ra[1], rb[1]);
+      if (c + 2 < c1) body(c + 2, ra[2], rb[2]);
+    }
+  }
+  // ---- the four waves' tiles -> one, in wave order; accumulator (mi, cn)[r] = C[16 mi + 4 kg + r][nc + cn] ----
+  float *mine = part16 + (size_t)wave * (16 * MI) * 64;
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      sk_f32x4 v;
+#pragma unroll
+      for (int cn = 0; cn < 4; cn++) v[cn] = acc[mi][cn][r] + accx[mi][cn][r] * (1.f / 2048.f);
+      *reinterpret_cast<sk_f32x4 *>(mine + (16 * mi + 4 * kg + r) * 64 + 4 * i16) = v;
+    }
+  __syncthreads();
+  float *wp = a.ws + (size_t)g * a.M * a.N;
+  for (int q = tid; q < a.M * 16; q += 256) {            // 16 pieces of 16 bytes per row
+    const int row = q >> 4, col = 4 * (q & 15);
+    if (64 * t + col >= a.N) continue;
+    const float *p = part16 + row * 64 + col;
+    const sk_f32x4 v = ((*reinterpret_cast<const sk_f32x4 *>(p) + *reinterpret_cast<const sk_f32x4 *>(p + 16 * MI * 64)) +
+                        *reinterpret_cast<const sk_f32x4 *>(p + 2 * 16 * MI * 64)) + *reinterpret_cast<const sk_f32x4 *>(p + 3 * 16 * MI * 64);
+    *reinterpret_cast<sk_f32x4 *>(wp + (size_t)row * a.N + 64 * t + col) = v;
+  }
+}
+static int g_skinny16 = 1;
+void set_skinny_f16(int on) { g_skinny16 = on; }
+static int skinny16_groups(int N, int K) {
+  const int ntile = (N + 63) / 64, nchunk = (K + 31) / 32;
+  int G = 256 / ntile;
+  if (G > nchunk / 4) G = nchunk / 4;
+  return G < 1 ? 1 : G;
 }
 
 #ifdef KLSTM_SKINNY_TIMING
@@ -576,19 +704,45 @@ static bool skinny_nn_plan(int N, int K, int *nks, int *rem) {
 }
 bool skinny_nn_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *Cm, int ldc) {
   int nks, rem;
-  return g_fold_direct != 0 && M >= 1 && M <= 80 && N % 128 == 0 && N <= 1024 && K >= 4096 && K % 8 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+  if (g_skinny16 && g_fold_direct != 0 && M >= 1 && M <= 80 && N % 4 == 0 && N >= 64 && N <= 1024 && K >= 4096 && K % 8 == 0 && lda % 4 == 0 &&
+      ldb % 4 == 0 && ldc % 4 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(Cm)) & 15) == 0)
+    return true;
+  return g_fold_direct != 0 && M >= 1 && M <= 80 && N >= 128 && N % 128 == 0 && N <= 1024 && K >= 4096 && K % 8 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
          ldc % 4 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(Cm)) & 15) == 0 &&
          skinny_nn_plan(N, K, &nks, &rem);
 }
 size_t skinny_nn_workspace_floats(int M, int N, int K) {
   int nks, rem;
-  skinny_nn_plan(N, K, &nks, &rem);
-  return (size_t)nks * M * N;
+  if (N % 128 != 0 || N < 128 || !skinny_nn_plan(N, K, &nks, &rem)) nks = 0;
+  const int g16 = skinny16_groups(N, K);
+  return (size_t)(nks > g16 ? nks : g16) * M * N;
 }
 hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc, float *ws,
                             hipStream_t st) {
   int nks, rem;
-  if (!skinny_nn_plan(N, K, &nks, &rem)) return hipErrorInvalidValue;
+  if (g_skinny16) {
+    SkinnyNnArgs a{};
+    a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.ws = ws; a.nks = skinny16_groups(N, K); a.Cm = Cm; a.ldc = ldc;
+    const int mi = (M + 15) / 16;
+    const dim3 grid(((N + 63) / 64) * a.nks), block(256);
+    const size_t shm = (size_t)4 * 16 * mi * 64 * sizeof(float);
+#define SK16_GO(MI_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_skinny_nn16<MI_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+                          hipLaunchKernelGGL((k_skinny_nn16<MI_>), grid, block, shm, st, a); } while (0)
+    switch (mi) {
+      case 1: SK16_GO(1); break;
+      case 2: SK16_GO(2); break;
+      case 3: SK16_GO(3); break;
+      case 4: SK16_GO(4); break;
+      case 5: SK16_GO(5); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef SK16_GO
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_skinny_nn_reduce, dim3((unsigned)(((size_t)M * N / 4 + 31) / 32)), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
+  if (N % 128 != 0 || N < 128 || !skinny_nn_plan(N, K, &nks, &rem)) return hipErrorInvalidValue;
 #ifdef KLSTM_SKINNY_TIMING
   SkinnyNnArgs a{M, N, K, A, lda, B, ldb, ws, nks, Cm, ldc, rem, g_skinny_dbg};
 #else

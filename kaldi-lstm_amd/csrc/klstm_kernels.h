@@ -65,6 +65,7 @@ bool outer_f16_supported(int M, int N, int K, const float *diff, int ldd, const 
 hipError_t launch_outer_f16(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, float beta, float *Cm, int ldc,
                             float *P, float lr, float beta_b, float *bias, hipStream_t st, LaunchProbe pr = {});
 void set_outer_f16(int on);
+void set_skinny_f16(int on);           // klstm_fold.hip: 0 = in_diff of a wide layer on the fp32 MFMA kernel (k_skinny_nn), A-B
 hipError_t launch_gemm_tn_coal(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm,
                                int ldc, hipStream_t st, LaunchProbe pr = {});
 // C = A B^T + bias for up to 80 rows and many columns, operands straight into MFMA registers (klstm_fold.hip)

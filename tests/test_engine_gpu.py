@@ -508,6 +508,31 @@ def test_affine_gradient_wide(N, K, M):
     e.set_option("outer_f16", 1)
 
 
+@pytest.mark.parametrize("N,K,M", [(80, 512, 16624), (80, 68, 4104), (37, 196, 16624), (1, 64, 4096), (16, 1024, 8200),
+                                   (80, 512, 4088)])                 # contraction below 4096: tiled split-K kernel
+def test_affine_backpropagate_wide(N, K, M):
+    """klstm_affine_backpropagate (in_diff = out_diff W) of a wide layer at few frames, strided views: the f16 x 2 matrix-core
+    kernel (k_skinny_nn16: ragged last chunk of the contraction, column tiles past in_dim, K groups of 4 or 5 chunks) and the
+    fp32 kernels against float64: 2e-6 of the largest entry (fp32 accumulation over <= 16624 products in a fixed order)."""
+    import kaldi_lstm_amd as k
+    rng = np.random.RandomState(M + K)
+    W = (0.1 * rng.randn(M, K)).astype(np.float32)
+    diff = (rng.rand(N, M) - 0.5).astype(np.float32)
+    ds = torch.full((N, M + 8), 7.0, device="cuda"); ds[:, :M] = dev(diff)
+    ind = torch.full((N + 1, K + 4), 5.0, device="cuda")
+    Wd = dev(W)
+    e = k.Engine(40, 64, 32, 4)
+    ref = diff.astype(np.float64) @ W.astype(np.float64)
+    for on in (1, 0):
+        e.set_option("skinny_f16", on)
+        ind.fill_(5.0)
+        k.affine_backpropagate(ds[:, :M], Wd, ind[:N, :K])
+        torch.cuda.synchronize()
+        assert relerr(ind[:N, :K].cpu().numpy(), ref) <= 2e-6, on
+        assert torch.all(ind[N] == 5.0) and torch.all(ind[:, K:] == 5.0)
+    e.set_option("skinny_f16", 1)
+
+
 @pytest.mark.parametrize("N,M", [(12, 37), (80, 4203), (24, 16624)])
 def test_xent_eval_masked_general_posteriors(N, M):
     """Xent::EvalMasked with the reference's Posterior argument (nnet-loss.cc:76-142): several weighted pdfs per frame,

@@ -17,8 +17,14 @@ for N, K, M in ((80, 512, 16624), (16, 512, 16624), (80, 128, 16624), (80, 512, 
     diff = torch.randn(N, M, device="cuda"); W = torch.randn(M, K, device="cuda") * 0.1; ind = torch.empty(N, K, device="cuda")
     torch.cuda.synchronize()
     e.set_option("fold_direct", 1)
-    t("rows %d in %d out %d: skinny" % (N, K, M), diff, W, ind)
+    t("rows %d in %d out %d: skinny, f16 x 2 in registers" % (N, K, M), diff, W, ind)
+    r16 = ind.clone()
+    e.set_option("skinny_f16", 0)
+    t("rows %d in %d out %d: skinny, fp32 MFMA" % (N, K, M), diff, W, ind)
+    e.set_option("skinny_f16", 1)
     ref = ind.clone()
+    r64 = (diff.double() @ W.double())
+    print("   vs fp64: f16 x 2 %.2e, fp32 %.2e of %.1f" % ((r16 - r64).abs().max().item(), (ref - r64).abs().max().item(), r64.abs().max().item()))
     e.set_option("fold_direct", 0)
     t("rows %d in %d out %d: tiled split-K" % (N, K, M), diff, W, ind)
     print("   max |difference| %.2e of %.1f" % ((ref - ind).abs().max().item(), ind.abs().max().item()))
