@@ -1004,6 +1004,12 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     set_direct_nt_shape(value / 10, value % 10);
     return KLSTM_OK;
   }
+  if (!strcmp(key, "skinny_f16_pair")) {         // 0: d_r / in_diff of the folded BPTT tail on the tiled split-K kernel (A-B; process-wide)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    set_skinny_f16_pair(value);
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "skinny_f16")) {              // 0: in_diff of a wide layer on the fp32 MFMA kernel (A-B; process-wide)
     set_skinny_f16(value);
     return KLSTM_OK;

@@ -578,12 +578,16 @@ __global__ __launch_bounds__(256) void k_skinny_nn_reduce(SkinnyNnArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 sk_f16x8 __attribute__((ext_vector_type(8)));
+// (two products in one launch: blocks [0, nb1) work on a, the rest on b -- d_r and in_diff of the folded BPTT tail, launch_bwd_tail)
 template <int MI>
-__global__ __launch_bounds__(256) void k_skinny_nn16(SkinnyNnArgs a) {
+__global__ __launch_bounds__(256) void k_skinny_nn16(SkinnyNnArgs a_, SkinnyNnArgs b_, int nb1) {
   extern __shared__ __attribute__((aligned(16))) float part16[];    // [4 waves][16 MI rows][64]
+  const bool second = (int)blockIdx.x >= nb1;
+  const SkinnyNnArgs &a = second ? b_ : a_;
+  const int bid = second ? (int)blockIdx.x - nb1 : (int)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kg = lane >> 4;
-  const int ntile = (a.N + 63) / 64, t = (int)blockIdx.x % ntile, g = (int)blockIdx.x / ntile;
+  const int ntile = (a.N + 63) / 64, t = bid % ntile, g = bid / ntile;
   const int nc = 64 * t + 4 * i16;
   const bool n_in = nc < a.N;
   const int nchunk = (a.K + 31) / 32, nslot = 4 * a.nks, slot = 4 * g + wave;
@@ -683,6 +687,8 @@ __global__ __launch_bounds__(256) void k_skinny_nn16(SkinnyNnArgs a) {
 }
 static int g_skinny16 = 1;
 void set_skinny_f16(int on) { g_skinny16 = on; }
+static int g_skinny16_pair = 1;
+void set_skinny_f16_pair(int on) { g_skinny16_pair = on; }
 static int skinny16_groups(int N, int K) {
   const int ntile = (N + 63) / 64, nchunk = (K + 31) / 32;
   int G = 256 / ntile;
@@ -727,7 +733,7 @@ hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const 
     const dim3 grid(((N + 63) / 64) * a.nks), block(256);
     const size_t shm = (size_t)4 * 16 * mi * 64 * sizeof(float);
 #define SK16_GO(MI_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_skinny_nn16<MI_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-                          hipLaunchKernelGGL((k_skinny_nn16<MI_>), grid, block, shm, st, a); } while (0)
+                          hipLaunchKernelGGL((k_skinny_nn16<MI_>), grid, block, shm, st, a, a, (int)grid.x); } while (0)
     switch (mi) {
       case 1: SK16_GO(1); break;
       case 2: SK16_GO(2); break;
@@ -766,6 +772,44 @@ hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const 
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL(k_skinny_nn_reduce, dim3((unsigned)(((size_t)M * N / 4 + 31) / 32)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// Two products over the same rows of A in one launch (the tail of the folded BPTT: d_r = DGIFO[2..] W_gifo_r and in_diff =
+// DGIFO[1..] W_gifo_x, 80 x 512 over K = 3200 each): partials to ws1 / ws2 as [G][M][N]; the caller's reduction adds the G slices.
+// Returns G (0: not applicable -- the caller keeps its tiled split-K pair).
+int skinny16_pair_groups(int M, int N1, int N2, int K, int max_groups) {
+  if (!g_skinny16 || !g_skinny16_pair || g_fold_direct == 0 || M < 1 || M > 80 || K < 1024 || K % 8 != 0 || N1 % 4 != 0 || N2 % 4 != 0 || N1 < 64 ||
+      (N2 != 0 && N2 < 64))
+    return 0;
+  const int nt = (N1 + 63) / 64 + (N2 + 63) / 64, nchunk = (K + 31) / 32;
+  if (nt > 64) return 0;
+  int G = 256 / nt;
+  if (G > nchunk / 4) G = nchunk / 4;
+  if (G > max_groups) G = max_groups;
+  return G < 1 ? 0 : G;
+}
+hipError_t launch_skinny16_pair(int M, int K, const float *A1, const float *A2, int lda, const float *B1, int N1, const float *B2, int N2,
+                                float *ws1, float *ws2, int G, hipStream_t st, LaunchProbe pr) {
+  SkinnyNnArgs a{}, b{};
+  a.M = M; a.N = N1; a.K = K; a.A = A1; a.lda = lda; a.B = B1; a.ldb = N1; a.ws = ws1; a.nks = G;
+  b = a; b.N = N2 > 0 ? N2 : N1; b.A = A2; b.B = B2; b.ldb = b.N; b.ws = ws2;
+  const int nb1 = ((N1 + 63) / 64) * G, nb2 = N2 > 0 ? ((N2 + 63) / 64) * G : 0;
+  const int mi = (M + 15) / 16;
+  const dim3 grid(nb1 + nb2), block(256);
+  const size_t shm = (size_t)4 * 16 * mi * 64 * sizeof(float);
+#define SK16P_GO(MI_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_skinny_nn16<MI_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+                           if (pr.start) hipExtLaunchKernelGGL((k_skinny_nn16<MI_>), grid, block, shm, st, pr.start, pr.stop, 0, a, b, nb1); \
+                           else hipLaunchKernelGGL((k_skinny_nn16<MI_>), grid, block, shm, st, a, b, nb1); } while (0)
+  switch (mi) {
+    case 1: SK16P_GO(1); break;
+    case 2: SK16P_GO(2); break;
+    case 3: SK16P_GO(3); break;
+    case 4: SK16P_GO(4); break;
+    case 5: SK16P_GO(5); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef SK16P_GO
   return hipGetLastError();
 }
 

@@ -65,6 +65,10 @@ bool outer_f16_supported(int M, int N, int K, const float *diff, int ldd, const 
 hipError_t launch_outer_f16(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, float beta, float *Cm, int ldc,
                             float *P, float lr, float beta_b, float *bias, hipStream_t st, LaunchProbe pr = {});
 void set_outer_f16(int on);
+int skinny16_pair_groups(int M, int N1, int N2, int K, int max_groups);       // klstm_fold.hip: two skinny products in one launch
+hipError_t launch_skinny16_pair(int M, int K, const float *A1, const float *A2, int lda, const float *B1, int N1, const float *B2, int N2,
+                                float *ws1, float *ws2, int G, hipStream_t st, LaunchProbe pr = {});
+void set_skinny_f16_pair(int on);
 void set_skinny_f16(int on);           // klstm_fold.hip: 0 = in_diff of a wide layer on the fp32 MFMA kernel (k_skinny_nn), A-B
 hipError_t launch_gemm_tn_coal(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm,
                                int ldc, hipStream_t st, LaunchProbe pr = {});

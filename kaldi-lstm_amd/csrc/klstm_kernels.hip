@@ -3131,12 +3131,22 @@ hipError_t launch_bwd_tail(const Dims &d, const float *dgifo, const float *wr, c
                            LaunchProbe pr2) {
   const int M = d.T * d.S, K4 = 4 * d.C;
   int kl = 0;
-  const int ks = gemm_splitk_plan(M, d.R, K4, &kl);
+  int ks = gemm_splitk_plan(M, d.R, K4, &kl);
+  // few frames: both products on the f16 matrix cores at fp32 accuracy, all rows per wave (klstm_fold.hip k_skinny_nn16; 80 frames,
+  // 800/512/512: 16.3 us for the tiled split-K launch -> see DESIGN.md 10)
+  const int G16 = aligned16(dgifo) && aligned16(wr) && aligned16(wx) ? skinny16_pair_groups(M, d.R, in_diff ? d.I : 0, K4, ks) : 0;
   const GemmJob g1 = make_job(false, false, M, d.R, K4, dgifo + (size_t)2 * d.S * K4, K4, wr, d.R, 0.f, nullptr, d.R, nullptr);
   const GemmJob g2 = make_job(false, false, M, d.I, K4, dgifo + (size_t)d.S * K4, K4, wx, d.I, 0.f, nullptr, d.I, nullptr);
   const int nb1 = cdiv(M, GT) * cdiv(d.R, GT), nb2 = in_diff ? cdiv(M, GT) * cdiv(d.I, GT) : 0;
   float *ws2 = ws + (size_t)ks * M * d.R;
-  auto first = [&]() -> hipError_t { KLAUNCH(k_gemm_splitk2, dim3(nb1 + nb2, 1, ks), dim3(256), st, pr, g1, g2, nb1, kl, ws, ws2); };
+  auto first = [&]() -> hipError_t {
+    if (G16 > 0) {
+      const int G = G16;
+      ks = G;                                            // (ws2 above was placed for the larger tiled plan: still in range)
+      return launch_skinny16_pair(M, K4, dgifo + (size_t)2 * d.S * K4, dgifo + (size_t)d.S * K4, K4, wr, d.R, wx, in_diff ? d.I : 0, ws, ws2, G, st, pr);
+    }
+    KLAUNCH(k_gemm_splitk2, dim3(nb1 + nb2, 1, ks), dim3(256), st, pr, g1, g2, nb1, kl, ws, ws2);
+  };
   hipError_t err = first();
   if (err != hipSuccess) return err;
   ReduceArgs r1, r2;
