@@ -32,6 +32,8 @@ namespace klstm {
 
 typedef float of32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 of16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void *outer_gptr;
+typedef __attribute__((address_space(3))) void *outer_lptr;
 
 struct OuterArgs {
   const float *diff; int ldd;          // [K][M]
@@ -58,7 +60,10 @@ __device__ __forceinline__ void outer_split(const of32x4 (&raw)[8], of16x8 (&p1)
   }
 }
 
-template <int NCH>
+// UPD: the epilogue is AffineTransform::Update.  The tile's 2 x 16 rows of corr and W (32 KB per wave) are requested when the tile
+// starts, by LDS-DMA (global_load_lds_dwordx4: no registers, lane-linear destination = each lane later reads back its own 16 bytes),
+// and have landed under the tile's MFMAs: 128 KB of dynamic LDS per workgroup.
+template <int NCH, bool UPD>
 __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kg = lane >> 4;
@@ -72,7 +77,10 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
   const bool has_x = (int)blockIdx.x < a.nextra;
   const int mx = has_x ? a.m_main + (int)blockIdx.x : 0;
   __shared__ __attribute__((aligned(16))) float xd[32 * NCH];
-  of32x4 rawb[NCH][8];
+  extern __shared__ __attribute__((aligned(16))) char outer_rows[];   // UPD: [4 waves][corr | W][16 rows][64 lanes x 16 bytes]
+  char *wrows = outer_rows + wave * 32768;
+  constexpr int RB = UPD ? 1 : NCH;                      // (UPD: the row addresses of the tile live across its MFMAs: a one-chunk lead of `in`)
+  of32x4 rawb[RB][8];
   auto loadChunk = [&](int j, auto, of32x4 (&dst)[8], int c) {
     const int nc = 64 * (wave + 4 * j) + 4 * i16;
 #pragma unroll
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
   };
   auto loadTile = [&](int j) {
 #pragma unroll
-    for (int c = 0; c < NCH; c++) loadChunk(j, std::integral_constant<int, 0>(), rawb[c], c);
+    for (int c = 0; c < RB; c++) loadChunk(j, std::integral_constant<int, 0>(), rawb[c], c);
   };
   // ---- the strip's columns of out_diff: all chunks, split once ----
   of16x8 a1[NCH][4], a2[NCH][4];
@@ -139,6 +147,18 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
 #pragma unroll 1
   for (int j = 0; j < nmine; j++) {
     const int nc = 64 * (wave + 4 * j) + 4 * i16;
+    if (UPD && nc < a.N) {
+      asm volatile("" ::: "memory");                     // (the previous tile's rows have been read back)
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int m = min(m0 + 16 * kg + 4 * r + mi, a.m_main - 1);
+          __builtin_amdgcn_global_load_lds((outer_gptr)(a.Cm + (size_t)m * a.ldc + nc), (outer_lptr)(wrows + (mi * 4 + r) * 1024), 16, 0, 0);
+          if (a.P)
+            __builtin_amdgcn_global_load_lds((outer_gptr)(a.P + (size_t)m * a.ldc + nc), (outer_lptr)(wrows + 16384 + (mi * 4 + r) * 1024), 16, 0, 0);
+        }
+    }
     of32x4 acc[4][4], accx[4][4];
 #pragma unroll
     for (int mi = 0; mi < 4; mi++)
@@ -149,15 +169,17 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       of16x8 b1[4], b2[4];
+      const int cb = UPD ? 0 : c;                        // (a constant once the loop is unrolled)
 #pragma unroll
-      for (int e = 0; e < 8; e++) rawb[c][e] = outer_keep(rawb[c][e], nc < a.N && 32 * c + 8 * kg + e < a.K);
-      outer_split(rawb[c], b1, b2);
+      for (int e = 0; e < 8; e++) rawb[cb][e] = outer_keep(rawb[cb][e], nc < a.N && 32 * c + 8 * kg + e < a.K);
+      outer_split(rawb[cb], b1, b2);
       if (has_x) {
         const of32x4 d0 = *reinterpret_cast<const of32x4 *>(&xd[32 * c + 8 * kg]), d1 = *reinterpret_cast<const of32x4 *>(&xd[32 * c + 8 * kg + 4]);
 #pragma unroll
-        for (int e = 0; e < 4; e++) xg += d0[e] * rawb[c][e] + d1[e] * rawb[c][e + 4];
+        for (int e = 0; e < 4; e++) xg += d0[e] * rawb[cb][e] + d1[e] * rawb[cb][e + 4];
       }
-      loadChunk(jn, std::integral_constant<int, 0>(), rawb[c], c);
+      if (UPD) loadChunk(c + 1 < NCH ? j : jn, std::integral_constant<int, 0>(), rawb[0], c + 1 < NCH ? c + 1 : 0);
+      else loadChunk(jn, std::integral_constant<int, 0>(), rawb[cb], c);
 #pragma unroll
       for (int mi = 0; mi < 4; mi++)
 #pragma unroll
@@ -192,25 +214,35 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
       }
     }
     // accumulator (mi, cn)[r] = G[m0 + 4 (4 kg + r) + mi][nc + cn]
+    if (!UPD) {                                          // gradient only: sixteen stores
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int m = m0 + 16 * kg + 4 * r + mi;
+          if (m >= a.m_main) continue;
+          *reinterpret_cast<float4 *>(a.Cm + (size_t)m * a.ldc + nc) =
+              make_float4(acc[mi][0][r] + accx[mi][0][r] * (1.f / 2048.f), acc[mi][1][r] + accx[mi][1][r] * (1.f / 2048.f),
+                          acc[mi][2][r] + accx[mi][2][r] * (1.f / 2048.f), acc[mi][3][r] + accx[mi][3][r] * (1.f / 2048.f));
+        }
+      continue;
+    }
+    // Update in the same pass
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile's rows of corr and W are in LDS (so are the next tile's rows of `in`)
 #pragma unroll
     for (int mi = 0; mi < 4; mi++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int m = m0 + 16 * kg + 4 * r + mi;
         if (m >= a.m_main) continue;
-        float4 g = make_float4(acc[mi][0][r] + accx[mi][0][r] * (1.f / 2048.f), acc[mi][1][r] + accx[mi][1][r] * (1.f / 2048.f),
-                               acc[mi][2][r] + accx[mi][2][r] * (1.f / 2048.f), acc[mi][3][r] + accx[mi][3][r] * (1.f / 2048.f));
-        float4 *cp = reinterpret_cast<float4 *>(a.Cm + (size_t)m * a.ldc + nc);
-        if (a.beta != 0.f) {
-          const float4 o = *cp;
-          g.x += a.beta * o.x; g.y += a.beta * o.y; g.z += a.beta * o.z; g.w += a.beta * o.w;
-        }
-        *cp = g;
+        const of32x4 oc = *reinterpret_cast<const of32x4 *>(wrows + (mi * 4 + r) * 1024 + lane * 16);
+        of32x4 g = {acc[mi][0][r] + accx[mi][0][r] * (1.f / 2048.f), acc[mi][1][r] + accx[mi][1][r] * (1.f / 2048.f),
+                    acc[mi][2][r] + accx[mi][2][r] * (1.f / 2048.f), acc[mi][3][r] + accx[mi][3][r] * (1.f / 2048.f)};
+        g += a.beta * oc;
+        *reinterpret_cast<of32x4 *>(a.Cm + (size_t)m * a.ldc + nc) = g;
         if (a.P) {
-          float4 *pp = reinterpret_cast<float4 *>(a.P + (size_t)m * a.ldc + nc);
-          float4 p = *pp;
-          p.x -= a.lr * g.x; p.y -= a.lr * g.y; p.z -= a.lr * g.z; p.w -= a.lr * g.w;
-          *pp = p;
+          const of32x4 op = *reinterpret_cast<const of32x4 *>(wrows + 16384 + (mi * 4 + r) * 1024 + lane * 16);
+          *reinterpret_cast<of32x4 *>(a.P + (size_t)m * a.ldc + nc) = op - a.lr * g;
         }
       }
   }
@@ -245,8 +277,11 @@ hipError_t launch_outer_f16(int M, int N, int K, const float *diff, int ldd, con
   a.m_main = M; a.nextra = 0;
   if (nstrip > ncu && M - 64 * ncu <= ncu) { nstrip = ncu; a.m_main = 64 * ncu; a.nextra = M - a.m_main; }
   const dim3 grid(nstrip), block(256);
-#define OUTER_GO(NCH_) do { if (pr.start) hipExtLaunchKernelGGL(k_outer16<NCH_>, grid, block, 0, st, pr.start, pr.stop, 0, a); \
-                            else hipLaunchKernelGGL(k_outer16<NCH_>, grid, block, 0, st, a); } while (0)
+#define OUTER_GO2(NCH_, UPD_) do { const unsigned shm = UPD_ ? 131072u : 0u; \
+                                   if (UPD_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_outer16<NCH_, UPD_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+                                   if (pr.start) hipExtLaunchKernelGGL((k_outer16<NCH_, UPD_>), grid, block, shm, st, pr.start, pr.stop, 0, a); \
+                                   else hipLaunchKernelGGL((k_outer16<NCH_, UPD_>), grid, block, shm, st, a); } while (0)
+#define OUTER_GO(NCH_) do { if (beta != 0.f || P) OUTER_GO2(NCH_, true); else OUTER_GO2(NCH_, false); } while (0)
   switch ((K + 31) / 32) {
     case 1: OUTER_GO(1); break;
     case 2: OUTER_GO(2); break;
@@ -254,6 +289,7 @@ hipError_t launch_outer_f16(int M, int N, int K, const float *diff, int ldd, con
     default: return hipErrorInvalidValue;
   }
 #undef OUTER_GO
+#undef OUTER_GO2
   return hipGetLastError();
 }
 
