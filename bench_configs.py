@@ -207,7 +207,7 @@ def run_c4(args, k):
     # trainer reports every few thousand frames); --option eager_loss=1: read back every minibatch instead
     lazy = "eager_loss=1" not in args.option
     fused = "fuse_single_rank=0" not in args.option
-    net = k.DataParallelNnet(layers, k.SoftmaxXentDP(k, lazy=lazy, stream=stream), alloc=lambda n: torch.zeros(n, device="cuda"),
+    net = k.DataParallelNnet(layers, k.SoftmaxXentDP(k, lazy=lazy, stream=stream, accumulate=lazy), alloc=lambda n: torch.zeros(n, device="cuda"),
                              fuse_single_rank=fused)
     nchunk = 50
     feats = torch.randn(nchunk, T * S, I, device="cuda")
@@ -215,17 +215,14 @@ def run_c4(args, k):
     mask = torch.ones(T * S, device="cuda")
     ones = [1] * S
 
-    acc = [torch.zeros((), dtype=torch.float64, device="cuda"), torch.zeros((), device="cuda"), torch.zeros((), device="cuda")]
     seen = []
 
     def raw(c):
-        xe, correct, valid = net.train_step(feats[c], tg[c], mask, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
-        if lazy:
-            acc[0] += xe; acc[1] += correct; acc[2] += valid
+        net.train_step(feats[c], tg[c], mask, MOMENTUM, LR, reset_flags=ones if c == 0 else None)   # (lazy: statistics onto net.loss.totals)
 
     def after(c):
         if lazy and c == nchunk - 1:
-            seen.append((float(acc[0].item()), int(acc[1].item()), int(acc[2].item())))    # one read-back per utterance round
+            seen.append(tuple(net.loss.totals.tolist()))                                # one read-back per utterance round
     torch.cuda.synchronize()
     step = _WholeStep(raw, stream, nchunk, graphed and lazy, after)
     step.prepare()

@@ -249,6 +249,13 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
                                     const float *mask_dev, float *diff, int diff_stride, float *row_xent_dev,
                                     float *row_correct_dev, void *hip_stream);
 
+/* The three per-minibatch statistics of Xent::EvalMasked added onto device totals (the reference adds them to loss_, frames_,
+ * correct_ on the host after copying the scalars back, google/nnet/nnet-loss.cc:110-142): totals_dev[0] += sum row_xent,
+ * totals_dev[1] += sum row_correct, totals_dev[2] += sum mask, in double, fixed order, no synchronisation.  A trainer that
+ * reports every N minibatches (bd-nnet-train-lstm-streams.cc:240-257) reads the three doubles once per report. */
+klstm_status klstm_xent_accumulate(const float *row_xent_dev, const float *row_correct_dev, const float *mask_dev, int rows,
+                                   double *totals_dev, void *hip_stream);
+
 /* Xent::EvalMasked for GENERAL posteriors (google/nnet/nnet-loss.cc:76-142): frame r carries the entries
  * post_pdf/post_weight[post_offsets[r] .. post_offsets[r+1]) (CSR, device arrays; repeated pdfs of a frame add up like the
  * reference's `tgt(t, pdf) += weight`, :86-96).  diff = (net_out - target) * mask; per row: cross entropy -mask*sum t*log(y),

@@ -84,6 +84,7 @@ def load_library():
     lib.klstm_sgd_momentum_update.argtypes = [P, P, P, ctypes.c_long, F, F, P]
     lib.klstm_xent_eval_masked.argtypes = [P, I, I, I, P, P, P, I, P, P, P]
     lib.klstm_xent_eval_masked_post.argtypes = [P, I, I, I, P, P, P, P, P, I, P, P, P, P]
+    lib.klstm_xent_accumulate.argtypes = [P, P, P, I, P, P]
     lib.klstm_oneshot_create.argtypes = [I, P, ctypes.c_long, ctypes.POINTER(P)]
     lib.klstm_oneshot_export.argtypes = [P, P, P]
     lib.klstm_oneshot_connect.argtypes = [P, I, I, P, P]
@@ -449,10 +450,12 @@ def softmax(x, out, stream=None):
     _chk(lib.klstm_softmax(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), out.stride(0), _sp(stream)))
 
 
-def xent_eval_masked(net_out, target, mask, diff, stream=None, lazy=False, rows_out=None):
+def xent_eval_masked(net_out, target, mask, diff, stream=None, lazy=False, rows_out=None, totals=None):
     """Returns (cross_entropy_sum, correct, valid_frames); fills diff = (net_out - onehot) * mask.
     lazy: no synchronisation -- the three statistics come back as 0-d device tensors (a trainer that reports every N
-    minibatches adds them up on the device and reads them once); rows_out = (row_xent, row_correct) buffers to reuse."""
+    minibatches adds them up on the device and reads them once); rows_out = (row_xent, row_correct) buffers to reuse.
+    totals: a float64[3] device tensor -- the statistics are ADDED to it by one small launch (klstm_xent_accumulate) and
+    (None, None, None) comes back: nothing else runs per minibatch."""
     import torch
     lib = load_library()
     assert target.dtype == torch.int32 and mask.dtype == torch.float32
@@ -460,6 +463,10 @@ def xent_eval_masked(net_out, target, mask, diff, stream=None, lazy=False, rows_
     rx, rc = rows_out if rows_out is not None else (torch.empty(rows, device=net_out.device), torch.empty(rows, device=net_out.device))
     _chk(lib.klstm_xent_eval_masked(net_out.data_ptr(), rows, net_out.shape[1], net_out.stride(0), target.data_ptr(),
                                     mask.data_ptr(), diff.data_ptr(), diff.stride(0), rx.data_ptr(), rc.data_ptr(), _sp(stream)))
+    if totals is not None:
+        assert totals.dtype == torch.float64 and totals.numel() == 3 and totals.is_contiguous()
+        _chk(lib.klstm_xent_accumulate(rx.data_ptr(), rc.data_ptr(), mask.data_ptr(), rows, totals.data_ptr(), _sp(stream)))
+        return None, None, None
     if lazy:
         return rx.sum(dtype=torch.float64), rc.sum(), mask.sum()
     if stream is not None:

@@ -1222,6 +1222,13 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
   return KLSTM_OK;
 }
 
+klstm_status klstm_xent_accumulate(const float *row_xent_dev, const float *row_correct_dev, const float *mask_dev, int rows,
+                                   double *totals_dev, void *hip_stream) {
+  if (!row_xent_dev || !row_correct_dev || !mask_dev || !totals_dev || rows < 0) return fail(KLSTM_ERR_ARG, "klstm_xent_accumulate: bad argument");
+  if (rows > 0) HIPCHK(launch_xent_accumulate(row_xent_dev, row_correct_dev, mask_dev, rows, totals_dev, (hipStream_t)hip_stream));
+  return KLSTM_OK;
+}
+
 klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int cols, int stride, const int *post_offsets_dev,
                                          const int *post_pdf_dev, const float *post_weight_dev, const float *mask_dev, float *diff,
                                          int diff_stride, float *row_xent_dev, float *row_entropy_dev, float *row_correct_dev,

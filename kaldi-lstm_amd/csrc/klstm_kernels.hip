@@ -3272,6 +3272,28 @@ hipError_t launch_xent_post(const float *y, int rows, int cols, int stride, cons
   KLAUNCH(k_xent_post_rows, dim3(rows), dim3(256), st, pr, y, cols, stride, post_off, post_pdf, post_w, mask, diff, diff_stride, row_xent,
           row_ent, row_correct);
 }
+// Loss statistics of a minibatch onto device totals (Xent::EvalMasked adds its three scalars to loss_, correct_, frames_ on the host,
+// nnet-loss.cc:136-141; a trainer that reports every N minibatches reads the totals once): totals[0] += sum row_xent (double),
+// totals[1] += sum row_correct, totals[2] += sum mask.  One workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void k_xent_accumulate(const float *__restrict__ row_xent, const float *__restrict__ row_correct,
+                                                          const float *__restrict__ mask, int rows, double *totals) {
+  __shared__ double red[3][256];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) { s0 += (double)row_xent[r]; s1 += (double)row_correct[r]; s2 += (double)mask[r]; }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o)
+#pragma unroll
+      for (int q = 0; q < 3; q++) red[q][threadIdx.x] += red[q][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) totals[threadIdx.x] += red[threadIdx.x][0];
+}
+hipError_t launch_xent_accumulate(const float *row_xent, const float *row_correct, const float *mask, int rows, double *totals, hipStream_t st) {
+  LaunchProbe pr;
+  KLAUNCH(k_xent_accumulate, dim3(1), dim3(256), st, pr, row_xent, row_correct, mask, rows, totals);
+}
 hipError_t launch_col_sum(const float *src, int rows, int cols, int stride, float beta, float *dst, hipStream_t st) {
   LaunchProbe pr;
   KLAUNCH(k_col_sum, dim3(cdiv(cols, 64)), dim3(256), st, pr, src, rows, cols, stride, beta, dst);

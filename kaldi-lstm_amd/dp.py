@@ -246,10 +246,13 @@ class AffineDP:
 class SoftmaxXentDP:
     """Softmax + Xent::EvalMasked (google/nnet/nnet-loss.cc:76-142) on the device ops of the C-ABI.
     lazy: the statistics stay 0-d device tensors (no host synchronisation per minibatch; the reference's trainer prints
-    them every few thousand frames, bd-nnet-train-lstm-streams.cc:240-257)."""
+    them every few thousand frames, bd-nnet-train-lstm-streams.cc:240-257).
+    accumulate: the statistics are added to `self.totals` (float64[3] on the device: cross entropy, correct, frames --
+    Xent's loss_, correct_, frames_, nnet-loss.cc:138-142) by one small launch per minibatch; eval returns None for them."""
 
-    def __init__(self, ops, lazy=False, stream=None):
-        self.ops, self.lazy, self.stream = ops, lazy, stream
+    def __init__(self, ops, lazy=False, stream=None, accumulate=False):
+        self.ops, self.lazy, self.stream, self.accumulate = ops, lazy, stream, accumulate
+        self.totals = None
         self._post = self._diff = self._rows = None
 
     def eval(self, net_out, targets, mask):
@@ -257,7 +260,10 @@ class SoftmaxXentDP:
             self._post, self._diff = torch.empty_like(net_out), torch.empty_like(net_out)
             self._rows = (torch.empty(net_out.shape[0], device=net_out.device), torch.empty(net_out.shape[0], device=net_out.device))
         self.ops.softmax(net_out, self._post, self.stream)
-        xe, correct, valid = self.ops.xent_eval_masked(self._post, targets, mask, self._diff, stream=self.stream, lazy=self.lazy, rows_out=self._rows)
+        if self.accumulate and self.totals is None:
+            self.totals = torch.zeros(3, dtype=torch.float64, device=net_out.device)
+        xe, correct, valid = self.ops.xent_eval_masked(self._post, targets, mask, self._diff, stream=self.stream, lazy=self.lazy, rows_out=self._rows,
+                                                       totals=self.totals if self.accumulate else None)
         return self._diff, xe, correct, valid
 
 

@@ -533,6 +533,30 @@ def test_affine_backpropagate_wide(N, K, M):
     e.set_option("skinny_f16", 1)
 
 
+def test_xent_statistics_accumulate_on_device():
+    """klstm_xent_accumulate: the statistics of three minibatches added onto a float64[3] device tensor equal the sums of what the
+    synchronous call returns for each (cross entropy to 1e-12 relative -- same per-row values, double sums; counts exactly), and the
+    loss object of the data-parallel mirror exposes them as `totals`."""
+    import kaldi_lstm_amd as k
+    rng = np.random.RandomState(5)
+    N, M = 80, 4203
+    loss = k.SoftmaxXentDP(k, accumulate=True)
+    want = np.zeros(3)
+    for it in range(3):
+        a = dev(rng.randn(N, M))
+        target = torch.from_numpy(rng.randint(0, M, N).astype(np.int32)).cuda()
+        mask = torch.from_numpy((rng.rand(N) > 0.3).astype(np.float32)).cuda()
+        diff, xe, correct, valid = loss.eval(a, target, mask)
+        assert xe is None and correct is None and valid is None
+        y = torch.empty_like(a); d2 = torch.empty_like(a)
+        k.softmax(a, y)
+        want += np.array(k.xent_eval_masked(y, target, mask, d2), dtype=np.float64)
+        assert torch.equal(diff, d2)
+    torch.cuda.synchronize()
+    got = np.array(loss.totals.tolist())
+    assert abs(got[0] - want[0]) <= 1e-12 * abs(want[0]) and got[1] == want[1] and got[2] == want[2]
+
+
 @pytest.mark.parametrize("N,M", [(12, 37), (80, 4203), (24, 16624)])
 def test_xent_eval_masked_general_posteriors(N, M):
     """Xent::EvalMasked with the reference's Posterior argument (nnet-loss.cc:76-142): several weighted pdfs per frame,
