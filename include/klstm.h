@@ -298,11 +298,17 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  products, dropped terms ~7e-7 relative (parameters must stay below 65504 in magnitude: beyond, the product
  *                  carries Inf / NaN); 1 = three bf16 planes, six products, dropped terms below 2^-24, fp32 range; 0 = the fp32
  *                  MFMA kernel.  Process-wide (A-B experiments).  "fold_direct" 0: the generic tile kernel
- *   "direct_nt_shape"  klstm_affine_propagate of at most 80 rows into more than 8192 columns (the output layer of a small-minibatch
- *                  step): default = the rows shared through LDS and the product on the f16 matrix cores at
- *                  fp32 accuracy (both operands split into two fp16 planes on the fly, three products, fp32 accumulation; inputs
- *                  and weights must stay below 65504 in magnitude); 99 = the same layout on the fp32 MFMA; 0 = the register-direct
- *                  kernel (fp32 MFMA); 10*NI + waves = geometry of the register-direct kernel.  Process-wide (A-B experiments)
+ *   "direct_nt_shape", "outer_f16", "skinny_f16", "skinny_f16_pair"  the three products of a WIDE AffineTransform at few frames
+ *                  (the output layer of a small-minibatch step) run on the f16 matrix cores at fp32 accuracy:
+ *                  both operands split into two fp16 numbers on the fly (x = h1 + h2 / 2048), three products with fp32
+ *                  accumulation, the dropped term ~2^-22 relative; measured error against float64 at or below the fp32 MFMA
+ *                  kernels'.  Inputs, weights and out_diff must stay below 65504 in magnitude (beyond: Inf / NaN).
+ *                  klstm_affine_propagate of <= 80 rows into > 8192 columns: "direct_nt_shape" 99 = the same layout on the fp32
+ *                  MFMA, 0 = the register-direct fp32 kernel, 10*NI + waves = geometry of that kernel;
+ *                  klstm_affine_gradient / klstm_affine_update of <= 96 rows and >= 2048 outputs: "outer_f16" 0 = fp32 tiles;
+ *                  klstm_affine_backpropagate of <= 80 rows over >= 4096 outputs: "skinny_f16" 0 = fp32 MFMA;
+ *                  d_r / in_diff of an engine whose input is too wide for the persistent backward launch: "skinny_f16_pair" 0 =
+ *                  the tiled split-K kernel.  All process-wide (A-B experiments and tests)
  *   "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.
