@@ -1166,10 +1166,15 @@ klstm_status klstm_affine_update(const float *in, int in_stride, const float *ou
                                  float lr_bias, float momentum, void *hip_stream) {
   if (!in || !out_diff || !W || !bias || !W_corr || !bias_corr) return fail(KLSTM_ERR_ARG, "klstm_affine_update: null argument");
   hipStream_t st = (hipStream_t)hip_stream;
-  if (outer_f16_supported(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, W_corr, in_dim, W)) {   // few frames, wide layer (klstm_outer.hip)
-    HIPCHK(launch_outer_f16(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, momentum, W_corr, in_dim, W, lr, momentum,
-                            bias_corr, st));
-    HIPCHK(launch_axpy(bias, bias_corr, -lr_bias, out_dim, st));
+  if (outer_f16_supported(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, W_corr, in_dim, W, bias_corr)) {   // few frames, wide layer (klstm_outer.hip)
+    if (reinterpret_cast<uintptr_t>(bias) & 15) {        // (the bias step rides along in 16-byte pieces)
+      HIPCHK(launch_outer_f16(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, momentum, W_corr, in_dim, W, lr, momentum,
+                              bias_corr, nullptr, 0.f, st));
+      HIPCHK(launch_axpy(bias, bias_corr, -lr_bias, out_dim, st));
+    } else {
+      HIPCHK(launch_outer_f16(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, momentum, W_corr, in_dim, W, lr, momentum,
+                              bias_corr, bias, lr_bias, st));
+    }
     return KLSTM_OK;
   }
   if (in_dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(W_corr)) & 15) == 0) {
@@ -1187,9 +1192,9 @@ klstm_status klstm_affine_gradient(const float *in, int in_stride, const float *
                                    int out_dim, float *W_grad, float *bias_grad, void *hip_stream) {
   if (!in || !out_diff || !W_grad || !bias_grad) return fail(KLSTM_ERR_ARG, "klstm_affine_gradient: null argument");
   hipStream_t st = (hipStream_t)hip_stream;
-  if (outer_f16_supported(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, W_grad, in_dim, nullptr)) {
+  if (outer_f16_supported(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, W_grad, in_dim, nullptr, bias_grad)) {
     HIPCHK(launch_outer_f16(out_dim, in_dim, rows, out_diff, od_stride, in, in_stride, 0.f, W_grad, in_dim, nullptr, 0.f, 0.f,
-                            bias_grad, st));
+                            bias_grad, nullptr, 0.f, st));
     return KLSTM_OK;
   }
   if (in_dim % 4 == 0 && (reinterpret_cast<uintptr_t>(W_grad) & 15) == 0)

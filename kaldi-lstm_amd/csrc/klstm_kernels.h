@@ -61,9 +61,9 @@ hipError_t launch_gemm_tn_update(int M, int N, int K, const float *A, int lda, c
                                  float *P, int ldc, float lr, hipStream_t st, LaunchProbe pr = {});
 // klstm_outer.hip: G = A^T B for few frames (K <= 96) and a wide result on the f16 matrix cores at fp32 accuracy, + column sums of A
 bool outer_f16_supported(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, const float *Cm, int ldc,
-                         const float *P);
+                         const float *P, const float *bias);
 hipError_t launch_outer_f16(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, float beta, float *Cm, int ldc,
-                            float *P, float lr, float beta_b, float *bias, hipStream_t st, LaunchProbe pr = {});
+                            float *P, float lr, float beta_b, float *bias, float *bias_p, float lr_b, hipStream_t st, LaunchProbe pr = {});
 void set_outer_f16(int on);
 int skinny16_pair_groups(int M, int N1, int N2, int K, int max_groups);       // klstm_fold.hip: two skinny products in one launch
 hipError_t launch_skinny16_pair(int M, int K, const float *A1, const float *A2, int lda, const float *B1, int N1, const float *B2, int N2,

@@ -41,6 +41,7 @@ struct OuterArgs {
   int K, M, N;
   int m_main, nextra;                  // strips cover rows [0, m_main); rows m_main .. m_main + nextra - 1 go out one per workgroup (VALU)
   float beta_b; float *bias;           // bias = beta_b * bias + column sums of diff
+  float *bias_p; float lr_b;           // bias_p -= lr_b * bias  (nullptr: not)
   float beta; float *Cm; int ldc;      // Cm = beta * Cm + G
   float *P; float lr;                  // P -= lr * Cm  (nullptr: gradient only)
 };
@@ -129,6 +130,12 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
       float4 o = make_float4(v[0], v[1], v[2], v[3]);
       if (a.beta_b != 0.f) { const float4 b = *bp; o.x += a.beta_b * b.x; o.y += a.beta_b * b.y; o.z += a.beta_b * b.z; o.w += a.beta_b * b.w; }
       *bp = o;
+      if (a.bias_p) {
+        float4 *pp = reinterpret_cast<float4 *>(a.bias_p + mc);
+        float4 p = *pp;
+        p.x -= a.lr_b * o.x; p.y -= a.lr_b * o.y; p.z -= a.lr_b * o.z; p.w -= a.lr_b * o.w;
+        *pp = p;
+      }
     }
   }
   __syncthreads();                                       // xd
@@ -139,7 +146,11 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
       if (lane < 32) bs += xd[32 * c + lane];
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) bs += __shfl_xor(bs, o);
-    if (lane == 0) a.bias[mx] = (a.beta_b != 0.f ? a.beta_b * a.bias[mx] : 0.f) + bs;
+    if (lane == 0) {
+      const float o = (a.beta_b != 0.f ? a.beta_b * a.bias[mx] : 0.f) + bs;
+      a.bias[mx] = o;
+      if (a.bias_p) a.bias_p[mx] -= a.lr_b * o;
+    }
   }
   // ---- this wave's 64-column tiles of `in`: the raw rows of the NEXT tile in flight under the 48 NCH MFMAs of the current one ----
   const int ntile = (a.N + 63) / 64, nmine = wave < ntile ? (ntile - wave + 3) / 4 : 0;
@@ -253,15 +264,16 @@ void set_outer_f16(int on) { g_outer_f16 = on; }
 
 // few frames (the contraction: three chunks of 32 are held in registers), a wide result: below ~2k rows of G the strips do not fill the chip
 bool outer_f16_supported(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, const float *Cm, int ldc,
-                         const float *P) {
+                         const float *P, const float *bias) {
   return g_outer_f16 != 0 && K >= 1 && K <= 96 && M >= 2048 && M % 4 == 0 && N >= 64 && N % 4 == 0 && ldc % 4 == 0 && ldd % 4 == 0 &&
          ldx % 4 == 0 && ((reinterpret_cast<uintptr_t>(Cm) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(diff) |
-                           reinterpret_cast<uintptr_t>(x)) & 15) == 0 && diff && x;
+                           reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0 && diff && x;
 }
 hipError_t launch_outer_f16(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, float beta, float *Cm, int ldc,
-                            float *P, float lr, float beta_b, float *bias, hipStream_t st, LaunchProbe pr) {
+                            float *P, float lr, float beta_b, float *bias, float *bias_p, float lr_b, hipStream_t st, LaunchProbe pr) {
   OuterArgs a;
   a.diff = diff; a.ldd = ldd; a.x = x; a.ldx = ldx; a.K = K; a.M = M; a.N = N;
+  a.bias_p = bias ? bias_p : nullptr; a.lr_b = lr_b;
   a.beta_b = beta_b; a.bias = bias; a.beta = beta; a.Cm = Cm; a.ldc = ldc; a.P = P; a.lr = lr;
   // one round of workgroups where a few rows past a whole number of strips per CU would start a second one
   static int ncu_of[64];                                 // per device, asked once
