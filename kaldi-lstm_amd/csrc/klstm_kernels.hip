@@ -1687,6 +1687,16 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
 #pragma unroll
         for (int r = 0; r < 4; r++) Cs[(wr * 32 + mi * 16 + 4 * kg + r) * GLX + wc * 32 + ni * 16 + i16] = e[r];
       }
+    // this thread's four pieces of the old corr and parameter tiles, all requested before the first store (a load behind a store
+    // waits for it: the compiler cannot know that the rows do not overlap -- four memory round trips per tile instead of one)
+    float4 oc4[4], op4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int p = tid + 256 * u, m = m0 + (p >> 4), n = n0 + (p & 15) * 4;
+      const size_t off = m < g.M && n + 4 <= g.N ? (size_t)m * g.ldc + n : 0;
+      oc4[u] = g.beta != 0.f ? *reinterpret_cast<const float4 *>(g.Cm + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      op4[u] = g.P ? *reinterpret_cast<const float4 *>(g.P + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -1697,11 +1707,10 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
         const float4 a = *reinterpret_cast<const float4 *>(cs);
         float4 *cp = reinterpret_cast<float4 *>(g.Cm + (size_t)m * g.ldc + n);
         float4 *pp = reinterpret_cast<float4 *>((g.P ? g.P : g.Cm) + (size_t)m * g.ldc + n);
-        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g.P) pv = *pp;
+        float4 pv = op4[u];
         float c[4] = {a.x, a.y, a.z, a.w};
         if (g.beta != 0.f) {
-          const float4 o = *cp;
+          const float4 o = oc4[u];
           c[0] = g.beta * o.x + c[0]; c[1] = g.beta * o.y + c[1]; c[2] = g.beta * o.z + c[2]; c[3] = g.beta * o.w + c[3];
         }
         if (g.clip > 0.f) {
