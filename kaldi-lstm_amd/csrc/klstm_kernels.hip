@@ -2306,18 +2306,27 @@ __global__ __launch_bounds__(256) void k_update_repack(UpdArgs a) {
 // thread takes four float4 pieces of a tile row-wise (256 contiguous bytes per tile row), the updated tile goes through LDS
 // and leaves transposed as float4 pieces along the row axis.  k_update_repack's 4-byte accesses in 128-byte segments
 // reach ~4 TB/s of the 35 MB it moves; this form ~6.
-__device__ __forceinline__ float4 upd_vec(const UpdArgs &a, long idx) {
-  float4 p = *reinterpret_cast<const float4 *>(a.param + idx);
+// the three 16-byte loads of one piece, and the arithmetic + stores on them: a tile's four pieces are all requested before the first
+// store (a load behind a store waits for it -- the compiler cannot know that the rows do not overlap)
+struct UpdPiece { float4 p, c, g; };
+__device__ __forceinline__ UpdPiece upd_vec_load(const UpdArgs &a, long idx) {
+  UpdPiece q;
+  q.p = *reinterpret_cast<const float4 *>(a.param + idx);
+  q.c = a.touch ? *reinterpret_cast<const float4 *>(a.corr + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+  q.g = a.touch && a.grad ? *reinterpret_cast<const float4 *>(a.grad + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+  return q;
+}
+__device__ __forceinline__ float4 upd_vec_apply(const UpdArgs &a, long idx, const UpdPiece &q) {
+  float4 p = q.p;
   if (a.touch) {
-    float4 c = *reinterpret_cast<const float4 *>(a.corr + idx);
-    float cv[4] = {c.x, c.y, c.z, c.w};
+    float cv[4] = {q.c.x, q.c.y, q.c.z, q.c.w};
     if (a.grad) {
-      const float4 g = *reinterpret_cast<const float4 *>(a.grad + idx);
+      const float4 g = q.g;
       cv[0] = a.mmt * cv[0] + g.x; cv[1] = a.mmt * cv[1] + g.y; cv[2] = a.mmt * cv[2] + g.z; cv[3] = a.mmt * cv[3] + g.w;
     }
     if (a.clip > 0.f) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) { cv[q] = cv[q] < -a.clip ? -a.clip : cv[q]; cv[q] = cv[q] > a.clip ? a.clip : cv[q]; }
+      for (int q_ = 0; q_ < 4; q_++) { cv[q_] = cv[q_] < -a.clip ? -a.clip : cv[q_]; cv[q_] = cv[q_] > a.clip ? a.clip : cv[q_]; }
     }
     if (a.grad || a.clip > 0.f) *reinterpret_cast<float4 *>(a.corr + idx) = make_float4(cv[0], cv[1], cv[2], cv[3]);
     p.x = p.x + (-a.lr) * cv[0]; p.y = p.y + (-a.lr) * cv[1]; p.z = p.z + (-a.lr) * cv[2]; p.w = p.w + (-a.lr) * cv[3];
@@ -2341,13 +2350,19 @@ __global__ __launch_bounds__(256) void k_update_repack_v(UpdArgs a) {
   const int lb = b - a.tb[mi];
   const int ntc = (cols + 63) / 64;
   const int by = (lb / ntc) * 64, bx = (lb % ntc) * 64;
+  UpdPiece piece[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int p = tid + 256 * u, r = by + (p >> 4), c = bx + (p & 15) * 4;
+    piece[u] = upd_vec_load(a, a.off[mi] + (r < rows && c + 4 <= cols ? (long)r * cols + c : 0));
+  }
 #pragma unroll
   for (int u = 0; u < 4; u++) {
     const int p = tid + 256 * u, rl = p >> 4, cq = (p & 15) * 4;
     const int r = by + rl, c = bx + cq;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < rows && c + 4 <= cols) {
-      v = upd_vec(a, a.off[mi] + (long)r * cols + c);
+      v = upd_vec_apply(a, a.off[mi] + (long)r * cols + c, piece[u]);
       if (mi == 1 && a.a3) {
         const float v4[4] = {v.x, v.y, v.z, v.w};
         split_store4(a.split_mode, v4, a.a3 + (size_t)r * cols + c, a.a_plane);
