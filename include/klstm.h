@@ -309,6 +309,9 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  klstm_affine_backpropagate of <= 80 rows over >= 4096 outputs: "skinny_f16" 0 = fp32 MFMA;
  *                  d_r / in_diff of an engine whose input is too wide for the persistent backward launch: "skinny_f16_pair" 0 =
  *                  the tiled split-K kernel.  All process-wide (A-B experiments and tests)
+ *   "fp16_products"  0/1  0 = no product runs on fp16 planes (all of the above on their fp32 kernels, the fold product on three
+ *                  bf16 planes, which have the fp32 range): for a net whose activations, weights or derivatives can pass 65504 in
+ *                  magnitude.  1 = the defaults again.  Process-wide
  *   "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.

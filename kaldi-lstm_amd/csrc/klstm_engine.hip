@@ -1033,6 +1033,18 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     e->fold_dirty = true;
     return KLSTM_OK;
   }
+  if (!strcmp(key, "fp16_products")) {           // 0: nothing runs on fp16 planes (values beyond 65504: klstm.h); 1: the defaults again.  Process-wide
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    set_fold_bf16x3(value ? 2 : 1);           // (the fold product keeps the matrix cores: three bf16 planes have the fp32 range)
+    e->planes_fresh = false;
+    e->fold_dirty = true;
+    if (value) set_direct_nt_shape(2, 1); else set_direct_nt_shape(0, 0);
+    set_outer_f16(value ? 1 : 0);
+    set_skinny_f16(value ? 1 : 0);
+    set_skinny_f16_pair(value ? 1 : 0);
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "fuse_x")) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);

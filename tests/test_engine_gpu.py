@@ -533,6 +533,28 @@ def test_affine_backpropagate_wide(N, K, M):
     e.set_option("skinny_f16", 1)
 
 
+def test_fp16_products_option_switches_every_fp16_kernel_off():
+    """"fp16_products" = 0: values beyond the fp16 range go through the output layer's three products (and a fold product) without
+    Inf / NaN; with the default (1) the same calls return non-finite numbers -- the documented range limit (klstm.h)."""
+    import kaldi_lstm_amd as k
+    rng = np.random.RandomState(3)
+    N, K, M = 80, 512, 9000
+    x = dev(rng.randn(N, K)) * 1e5                        # |x| up to ~4e5 > 65504
+    W = dev(0.01 * rng.randn(M, K)); b = torch.zeros(M, device="cuda")
+    out = torch.empty(N, M, device="cuda")
+    e = k.Engine(40, 64, 32, 4)
+    ref = (x.double() @ W.double().t()).float()
+    try:
+        e.set_option("fp16_products", 0)
+        k.affine_propagate(x, W, b, out); torch.cuda.synchronize()
+        assert torch.isfinite(out).all() and relerr(out.cpu().numpy(), ref.cpu().numpy()) <= 2e-5
+        e.set_option("fp16_products", 1)
+        k.affine_propagate(x, W, b, out); torch.cuda.synchronize()
+        assert not torch.isfinite(out).all()
+    finally:
+        e.set_option("fp16_products", 1)
+
+
 def test_xent_statistics_accumulate_on_device():
     """klstm_xent_accumulate: the statistics of three minibatches added onto a float64[3] device tensor equal the sums of what the
     synchronous call returns for each (cross entropy to 1e-12 relative -- same per-row values, double sums; counts exactly), and the
