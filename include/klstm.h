@@ -249,6 +249,15 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
                                     const float *mask_dev, float *diff, int diff_stride, float *row_xent_dev,
                                     float *row_correct_dev, void *hip_stream);
 
+/* Softmax followed by Xent::EvalMasked (one-hot targets) as ONE pass over the rows: the same arithmetic in the same order as
+ * klstm_softmax + klstm_xent_eval_masked (bit-identical diff and statistics), without the trip of the posterior matrix
+ * through memory.  post may be NULL (a training step only needs diff); if not NULL it receives the softmax output.
+ * Rows the one-pass kernel does not serve (cols % 4 != 0, cols < 2048 or > 32768, unaligned rows) run the two kernels through
+ * `post`, which must then be given (KLSTM_ERR_ARG otherwise). */
+klstm_status klstm_softmax_xent_masked(const float *net_in, int rows, int cols, int in_stride, float *post, int post_stride,
+                                       const int *targets_dev, const float *mask_dev, float *diff, int diff_stride,
+                                       float *row_xent_dev, float *row_correct_dev, void *hip_stream);
+
 /* The three per-minibatch statistics of Xent::EvalMasked added onto device totals (the reference adds them to loss_, frames_,
  * correct_ on the host after copying the scalars back, google/nnet/nnet-loss.cc:110-142): totals_dev[0] += sum row_xent,
  * totals_dev[1] += sum row_correct, totals_dev[2] += sum mask, in double, fixed order, no synchronisation.  A trainer that

@@ -1239,6 +1239,24 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
   return KLSTM_OK;
 }
 
+klstm_status klstm_softmax_xent_masked(const float *net_in, int rows, int cols, int in_stride, float *post, int post_stride,
+                                       const int *targets_dev, const float *mask_dev, float *diff, int diff_stride, float *row_xent_dev,
+                                       float *row_correct_dev, void *hip_stream) {
+  if (!net_in || !targets_dev || !mask_dev || !diff || !row_xent_dev || !row_correct_dev)
+    return fail(KLSTM_ERR_ARG, "klstm_softmax_xent_masked: null argument");
+  if (rows <= 0) return KLSTM_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const hipError_t e = launch_softmax_xent(net_in, rows, cols, in_stride, post, post_stride, targets_dev, mask_dev, diff, diff_stride,
+                                           row_xent_dev, row_correct_dev, st);
+  if (e == hipSuccess) return KLSTM_OK;
+  if (e != hipErrorNotSupported) HIPCHK(e);
+  // rows the one-pass kernel does not serve: the two kernels, through the caller's posterior matrix
+  if (!post) return fail(KLSTM_ERR_ARG, "klstm_softmax_xent_masked: this shape needs the posterior matrix (post) as the buffer between its two kernels");
+  HIPCHK(launch_softmax(net_in, rows, cols, in_stride, post, post_stride, st));
+  HIPCHK(launch_xent(post, rows, cols, post_stride, targets_dev, mask_dev, diff, diff_stride, row_xent_dev, row_correct_dev, st));
+  return KLSTM_OK;
+}
+
 klstm_status klstm_xent_accumulate(const float *row_xent_dev, const float *row_correct_dev, const float *mask_dev, int rows,
                                    double *totals_dev, void *hip_stream) {
   if (!row_xent_dev || !row_correct_dev || !mask_dev || !totals_dev || rows < 0) return fail(KLSTM_ERR_ARG, "klstm_xent_accumulate: bad argument");

@@ -187,6 +187,8 @@ hipError_t launch_time_shift(const float *in, int rows, int cols, int in_stride,
 hipError_t launch_softmax(const float *in, int rows, int cols, int in_stride, float *out, int out_stride, hipStream_t st);
 hipError_t launch_xent(const float *y, int rows, int cols, int stride, const int *target, const float *mask, float *diff,
                        int diff_stride, float *row_xent, float *row_correct, hipStream_t st);
+hipError_t launch_softmax_xent(const float *in, int rows, int cols, int in_stride, float *post, int post_stride, const int *target,
+                               const float *mask, float *diff, int diff_stride, float *row_xent, float *row_correct, hipStream_t st);
 hipError_t launch_xent_accumulate(const float *row_xent, const float *row_correct, const float *mask, int rows, double *totals, hipStream_t st);
 hipError_t launch_xent_post(const float *y, int rows, int cols, int stride, const int *post_off, const int *post_pdf, const float *post_w,
                             const float *mask, float *diff, int diff_stride, float *row_xent, float *row_ent, float *row_correct,

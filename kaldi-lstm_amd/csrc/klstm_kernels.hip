@@ -2618,6 +2618,75 @@ __global__ __launch_bounds__(1024) void k_xent_rows_v(const float *__restrict__ 
     row_correct[row] = (m == 1.f && bi == tgt) ? 1.f : 0.f;
   }
 }
+// Softmax and Xent::EvalMasked of a wide row in ONE pass: k_softmax_rows_v's arithmetic, then k_xent_rows_v's on the registers
+// (same operations in the same order: the same bits as the pair), the posterior row written only if the caller wants it.
+// 80 x 16624: 9.2 + 6.3 us and 21 MB -> one launch, 10.6 MB.
+__global__ __launch_bounds__(1024) void k_softmax_xent_rows_v(const float *__restrict__ in, int cols, int in_stride, float *__restrict__ post,
+                                                             int post_stride, const int *__restrict__ target, const float *__restrict__ mask,
+                                                             float *__restrict__ diff, int diff_stride, float *__restrict__ row_xent,
+                                                             float *__restrict__ row_correct) {
+  __shared__ float sm[16];
+  __shared__ float smv[16];
+  __shared__ int smi[16];
+  __shared__ float s_yt;
+  const int row = blockIdx.x;
+  const float4 *ip = reinterpret_cast<const float4 *>(in + (size_t)row * in_stride);
+  float4 *dp = reinterpret_cast<float4 *>(diff + (size_t)row * diff_stride);
+  const int tgt = target[row];
+  const float m = mask[row];
+  const int n4 = cols >> 2;
+  float4 v[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int c = threadIdx.x + 1024 * u;
+    const float4 t = ip[c < n4 ? c : 0];
+    v[u] = c < n4 ? t : make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+  }
+  float mx = -3.4e38f;
+#pragma unroll
+  for (int u = 0; u < 8; u++) mx = fmaxf(mx, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+  mx = block_reduce(mx, sm, true);
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const bool on = threadIdx.x + 1024 * u < n4;
+    v[u].x = on ? expf(v[u].x - mx) : 0.f; v[u].y = on ? expf(v[u].y - mx) : 0.f;
+    v[u].z = on ? expf(v[u].z - mx) : 0.f; v[u].w = on ? expf(v[u].w - mx) : 0.f;
+    sum += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+  }
+  sum = block_reduce(sum, sm, false);
+  const float inv = 1.f / sum;
+  float best = -3.4e38f; int bi = 0x7fffffff;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int c = threadIdx.x + 1024 * u;
+    if (c < n4) {
+      const float e[4] = {v[u].x * inv, v[u].y * inv, v[u].z * inv, v[u].w * inv};
+      if (post) reinterpret_cast<float4 *>(post + (size_t)row * post_stride)[c] = make_float4(e[0], e[1], e[2], e[3]);
+      float d[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int col = 4 * c + j;
+        d[j] = (e[j] - (col == tgt ? 1.f : 0.f)) * m;
+        if (col == tgt) s_yt = e[j];
+        if (e[j] > best) { best = e[j]; bi = col; }          // ascending columns per thread: first maximum wins
+      }
+      dp[c] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { smv[wave] = best; smi[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; w++) if (smv[w] > best || (smv[w] == best && smi[w] < bi)) { best = smv[w]; bi = smi[w]; }
+    row_xent[row] = (tgt >= 0 && tgt < cols) ? -m * logf(s_yt) : 0.f;
+    row_correct[row] = (m == 1.f && bi == tgt) ? 1.f : 0.f;
+  }
+}
 // dst[j] = beta*dst[j] + sum_rows src[row][j]   (AddRowSumMat)
 // dst[j] = beta*dst[j] + sum over rows of src[r][j]: 64 columns x 4 row groups per workgroup, 8 loads in flight per thread
 // (a serial row loop costs one memory latency per row: 20 us for 80 rows), row groups combined through LDS in fixed order
@@ -3288,6 +3357,16 @@ hipError_t launch_xent(const float *y, int rows, int cols, int stride, const int
                     aligned16(y) && aligned16(diff);
   if (wide) KLAUNCH(k_xent_rows_v, dim3(rows), dim3(1024), st, pr, y, cols, stride, target, mask, diff, diff_stride, row_xent, row_correct);
   KLAUNCH(k_xent_rows, dim3(rows), dim3(256), st, pr, y, cols, stride, target, mask, diff, diff_stride, row_xent, row_correct);
+}
+// one pass when the row fits the registers of 1024 threads (returns hipErrorNotSupported otherwise: the caller runs the pair)
+hipError_t launch_softmax_xent(const float *in, int rows, int cols, int in_stride, float *post, int post_stride, const int *target,
+                               const float *mask, float *diff, int diff_stride, float *row_xent, float *row_correct, hipStream_t st) {
+  LaunchProbe pr;
+  const bool wide = cols % 4 == 0 && cols <= 32768 && cols >= 2048 && in_stride % 4 == 0 && diff_stride % 4 == 0 && aligned16(in) &&
+                    aligned16(diff) && (!post || (post_stride % 4 == 0 && aligned16(post)));
+  if (!wide) return hipErrorNotSupported;
+  KLAUNCH(k_softmax_xent_rows_v, dim3(rows), dim3(1024), st, pr, in, cols, in_stride, post, post_stride, target, mask, diff, diff_stride,
+          row_xent, row_correct);
 }
 hipError_t launch_xent_post(const float *y, int rows, int cols, int stride, const int *post_off, const int *post_pdf, const float *post_w,
                             const float *mask, float *diff, int diff_stride, float *row_xent, float *row_ent, float *row_correct,

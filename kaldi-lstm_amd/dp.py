@@ -250,8 +250,9 @@ class SoftmaxXentDP:
     accumulate: the statistics are added to `self.totals` (float64[3] on the device: cross entropy, correct, frames --
     Xent's loss_, correct_, frames_, nnet-loss.cc:138-142) by one small launch per minibatch; eval returns None for them."""
 
-    def __init__(self, ops, lazy=False, stream=None, accumulate=False):
+    def __init__(self, ops, lazy=False, stream=None, accumulate=False, one_pass=True):
         self.ops, self.lazy, self.stream, self.accumulate = ops, lazy, stream, accumulate
+        self.one_pass = one_pass and hasattr(ops, "softmax_xent_masked")   # (the CPU twins of the tests have the two ops only)
         self.totals = None
         self._post = self._diff = self._rows = None
 
@@ -259,9 +260,17 @@ class SoftmaxXentDP:
         if self._post is None or self._post.shape != net_out.shape:
             self._post, self._diff = torch.empty_like(net_out), torch.empty_like(net_out)
             self._rows = (torch.empty(net_out.shape[0], device=net_out.device), torch.empty(net_out.shape[0], device=net_out.device))
-        self.ops.softmax(net_out, self._post, self.stream)
         if self.accumulate and self.totals is None:
             self.totals = torch.zeros(3, dtype=torch.float64, device=net_out.device)
+        if self.one_pass:
+            # rows the one-pass kernel serves do not need the posterior matrix at all (klstm.h); the others go through it
+            c = net_out.shape[1]
+            wide = c % 4 == 0 and 2048 <= c <= 32768 and net_out.stride(0) % 4 == 0 and net_out.data_ptr() % 16 == 0
+            xe, correct, valid = self.ops.softmax_xent_masked(net_out, targets, mask, self._diff, post=None if wide else self._post,
+                                                              stream=self.stream, lazy=self.lazy, rows_out=self._rows,
+                                                              totals=self.totals if self.accumulate else None)
+            return self._diff, xe, correct, valid
+        self.ops.softmax(net_out, self._post, self.stream)
         xe, correct, valid = self.ops.xent_eval_masked(self._post, targets, mask, self._diff, stream=self.stream, lazy=self.lazy, rows_out=self._rows,
                                                        totals=self.totals if self.accumulate else None)
         return self._diff, xe, correct, valid

@@ -555,6 +555,33 @@ def test_fp16_products_option_switches_every_fp16_kernel_off():
         e.set_option("fp16_products", 1)
 
 
+@pytest.mark.parametrize("N,M", [(80, 16624), (12, 2048), (24, 4203), (7, 33000), (5, 1000)])
+def test_softmax_xent_one_pass_equals_the_pair(N, M):
+    """klstm_softmax_xent_masked against klstm_softmax + klstm_xent_eval_masked: bit-identical diff, posterior and statistics where
+    the one-pass kernel runs (wide aligned rows; with and without the posterior output), the same through the two-kernel route
+    elsewhere (odd width, narrow, too wide), which needs the posterior buffer and says so."""
+    import kaldi_lstm_amd as k
+    rng = np.random.RandomState(N + M)
+    a = dev(3.0 * rng.randn(N, M))
+    target = torch.from_numpy(rng.randint(0, M, N).astype(np.int32)).cuda()
+    mask = torch.from_numpy((rng.rand(N) > 0.3).astype(np.float32)).cuda()
+    y = torch.empty_like(a); d_ref = torch.empty_like(a)
+    k.softmax(a, y)
+    ref = k.xent_eval_masked(y, target, mask, d_ref)
+    wide = M % 4 == 0 and 2048 <= M <= 32768
+    for with_post in (True, False):
+        post = torch.zeros_like(a) if with_post else None
+        d = torch.full_like(a, 9.0)
+        if not with_post and not wide:
+            with pytest.raises(k.KlstmError):
+                k.softmax_xent_masked(a, target, mask, d, post=None)
+            continue
+        got = k.softmax_xent_masked(a, target, mask, d, post=post)
+        assert torch.equal(d, d_ref) and got == ref
+        if with_post:
+            assert torch.equal(post, y)
+
+
 def test_xent_statistics_accumulate_on_device():
     """klstm_xent_accumulate: the statistics of three minibatches added onto a float64[3] device tensor equal the sums of what the
     synchronous call returns for each (cross entropy to 1e-12 relative -- same per-row values, double sums; counts exactly), and the
