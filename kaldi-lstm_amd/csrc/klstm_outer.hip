@@ -9,17 +9,20 @@
 //
 // k_outer16: the product on the f16 matrix cores at fp32 accuracy (klstm_math.h f16_split2_pair: x = h1 + h2 / 2048, both normal
 // fp16 down to |x| = 2^-14; three products a1 b1 + (a1 b2 + a2 b1) / 2048 with the cross terms in their own accumulators, as the
-// fold product, klstm_fold3.hip; dropped a2 b2 ~ 2^-22 relative), both operands split in registers, no LDS, no barrier, no
+// fold product, klstm_fold3.hip; dropped a2 b2 ~ 2^-22 relative), both operands split in registers, no LDS in the product, no
 // workspace.  Both operands are stored k-major ([frame][column]), the MFMA wants 8 consecutive k of one row per lane: lane
 // (i16, kg) loads the float4 at columns 4 i16 .. 4 i16 + 3 of frames 32c + 8 kg + e, e = 0..7 (every load instruction = four
 // 256-byte runs), and the e-th components of the eight registers ARE the operands of the four "virtual" 16-row blocks
 // {4 i + cm : i = 0..15}, cm = 0..3 -- the transpose costs nothing.  With the same assignment on the n side the four accumulators
 // of a lane are one 16-byte piece of a row of G and sixteen lanes write 256 contiguous bytes.
-// A workgroup = one strip of 64 rows of G (260 strips at 16624: all resident at once at one or two waves per SIMD); each of the
+// A workgroup = one strip of 64 rows of G, one wave per SIMD (16624 rows: 256 strips in ONE round of the chip, the 240 rows past them
+// ride along one per workgroup on the vector ALU -- see the kernel); each of the
 // four waves splits the strip's 64 columns of out_diff ONCE (all K <= 96 frames, kept as fp16 planes in registers: 32 per
-// chunk of 32 frames) and walks its 64-column tiles of `in` (two at N = 512) with the raw rows of the next step in flight
-// under the 48 MFMAs of the current one.  Wave 0 also sums the strip's columns of out_diff (the bias gradient: no second launch).
-// The epilogue is the store (gradient), or  corr = mmt * corr + G; W -= lr * corr  (Update in the same pass).
+// chunk of 32 frames) and walks its 64-column tiles of `in` (two at N = 512) with the raw rows of the next tile in flight
+// under the 144 MFMAs of the current one.  Wave 0 also sums the strip's columns of out_diff (the bias gradient: no second launch).
+// The epilogue is the store (gradient), or  corr = mmt * corr + G; W -= lr * corr; bias -= lr_b * bias_corr  (Update in the same
+// pass: template flag UPD, the tile's rows of corr and W brought in by LDS-DMA under its MFMAs).
+// 80 x 16624 x 512: 29.9 -> 16.4 us (gradient), 42.1 -> 33.2 us (Update); DESIGN.md 9 item 5 has the ablations and dead ends.
 // (First version, kept in the history: planes written k-contiguous by a prep launch, 16-byte operand loads from them: 8.9 + 26 us
 //  -- every 128-byte line of the planes fetched twice through a 32 KB L1, 200 MB of operand ingest.)
 // Values must stay below 65504 in magnitude (fp16 range): out_diff of a softmax / cross-entropy layer is within [-1, 1].
