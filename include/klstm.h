@@ -253,10 +253,12 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
  * klstm_softmax + klstm_xent_eval_masked (bit-identical diff and statistics), without the trip of the posterior matrix
  * through memory.  post may be NULL (a training step only needs diff); if not NULL it receives the softmax output.
  * Rows the one-pass kernel does not serve (cols % 4 != 0, cols < 2048 or > 32768, unaligned rows) run the two kernels through
- * `post`, which must then be given (KLSTM_ERR_ARG otherwise). */
+ * `post`, which must then be given (KLSTM_ERR_ARG otherwise).  totals_dev (may be NULL): three doubles on the device that the
+ * statistics of this minibatch are added to, as klstm_xent_accumulate does, inside the same launch (the workgroup that
+ * finishes last adds the rows up in a fixed order). */
 klstm_status klstm_softmax_xent_masked(const float *net_in, int rows, int cols, int in_stride, float *post, int post_stride,
                                        const int *targets_dev, const float *mask_dev, float *diff, int diff_stride,
-                                       float *row_xent_dev, float *row_correct_dev, void *hip_stream);
+                                       float *row_xent_dev, float *row_correct_dev, double *totals_dev, void *hip_stream);
 
 /* The three per-minibatch statistics of Xent::EvalMasked added onto device totals (the reference adds them to loss_, frames_,
  * correct_ on the host after copying the scalars back, google/nnet/nnet-loss.cc:110-142): totals_dev[0] += sum row_xent,

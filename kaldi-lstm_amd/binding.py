@@ -85,7 +85,7 @@ def load_library():
     lib.klstm_xent_eval_masked.argtypes = [P, I, I, I, P, P, P, I, P, P, P]
     lib.klstm_xent_eval_masked_post.argtypes = [P, I, I, I, P, P, P, P, P, I, P, P, P, P]
     lib.klstm_xent_accumulate.argtypes = [P, P, P, I, P, P]
-    lib.klstm_softmax_xent_masked.argtypes = [P, I, I, I, P, I, P, P, P, I, P, P, P]
+    lib.klstm_softmax_xent_masked.argtypes = [P, I, I, I, P, I, P, P, P, I, P, P, P, P]
     lib.klstm_oneshot_create.argtypes = [I, P, ctypes.c_long, ctypes.POINTER(P)]
     lib.klstm_oneshot_export.argtypes = [P, P, P]
     lib.klstm_oneshot_connect.argtypes = [P, I, I, P, P]
@@ -486,13 +486,14 @@ def softmax_xent_masked(net_in, target, mask, diff, post=None, stream=None, lazy
     assert target.dtype == torch.int32 and mask.dtype == torch.float32
     rows = net_in.shape[0]
     rx, rc = rows_out if rows_out is not None else (torch.empty(rows, device=net_in.device), torch.empty(rows, device=net_in.device))
-    _chk(lib.klstm_softmax_xent_masked(net_in.data_ptr(), rows, net_in.shape[1], net_in.stride(0), post.data_ptr() if post is not None else None,
-                                       post.stride(0) if post is not None else 0, target.data_ptr(), mask.data_ptr(), diff.data_ptr(),
-                                       diff.stride(0), rx.data_ptr(), rc.data_ptr(), _sp(stream)))
     if totals is not None:
         assert totals.dtype == torch.float64 and totals.numel() == 3 and totals.is_contiguous()
-        _chk(lib.klstm_xent_accumulate(rx.data_ptr(), rc.data_ptr(), mask.data_ptr(), rows, totals.data_ptr(), _sp(stream)))
-        return None, None, None
+    _chk(lib.klstm_softmax_xent_masked(net_in.data_ptr(), rows, net_in.shape[1], net_in.stride(0), post.data_ptr() if post is not None else None,
+                                       post.stride(0) if post is not None else 0, target.data_ptr(), mask.data_ptr(), diff.data_ptr(),
+                                       diff.stride(0), rx.data_ptr(), rc.data_ptr(), totals.data_ptr() if totals is not None else None,
+                                       _sp(stream)))
+    if totals is not None:
+        return None, None, None                            # (added to `totals` inside the same launch)
     if lazy:
         return rx.sum(dtype=torch.float64), rc.sum(), mask.sum()
     if stream is not None:

@@ -1239,21 +1239,42 @@ klstm_status klstm_xent_eval_masked(const float *net_out, int rows, int cols, in
   return KLSTM_OK;
 }
 
+// ticket word of the one-pass loss kernel (which workgroup is the last of a launch): one per (device, stream), zero between launches
+static klstm_status loss_ticket(hipStream_t st, unsigned **ticket) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, unsigned *> pool;
+  int devid = 0;
+  HIPCHK(hipGetDevice(&devid));
+  std::lock_guard<std::mutex> lk(mu);
+  unsigned *&slot = pool[std::make_pair(devid, st)];
+  if (!slot) {
+    HIPCHK(hipMalloc(&slot, sizeof(unsigned)));
+    HIPCHK(hipMemset(slot, 0, sizeof(unsigned)));       // (synchronous with respect to the host: done before any launch uses it)
+  }
+  *ticket = slot;
+  return KLSTM_OK;
+}
 klstm_status klstm_softmax_xent_masked(const float *net_in, int rows, int cols, int in_stride, float *post, int post_stride,
                                        const int *targets_dev, const float *mask_dev, float *diff, int diff_stride, float *row_xent_dev,
-                                       float *row_correct_dev, void *hip_stream) {
+                                       float *row_correct_dev, double *totals_dev, void *hip_stream) {
   if (!net_in || !targets_dev || !mask_dev || !diff || !row_xent_dev || !row_correct_dev)
     return fail(KLSTM_ERR_ARG, "klstm_softmax_xent_masked: null argument");
   if (rows <= 0) return KLSTM_OK;
   hipStream_t st = (hipStream_t)hip_stream;
+  unsigned *ticket = nullptr;
+  if (totals_dev) {
+    const klstm_status s = loss_ticket(st, &ticket);
+    if (s != KLSTM_OK) return s;
+  }
   const hipError_t e = launch_softmax_xent(net_in, rows, cols, in_stride, post, post_stride, targets_dev, mask_dev, diff, diff_stride,
-                                           row_xent_dev, row_correct_dev, st);
+                                           row_xent_dev, row_correct_dev, totals_dev, ticket, st);
   if (e == hipSuccess) return KLSTM_OK;
   if (e != hipErrorNotSupported) HIPCHK(e);
   // rows the one-pass kernel does not serve: the two kernels, through the caller's posterior matrix
   if (!post) return fail(KLSTM_ERR_ARG, "klstm_softmax_xent_masked: this shape needs the posterior matrix (post) as the buffer between its two kernels");
   HIPCHK(launch_softmax(net_in, rows, cols, in_stride, post, post_stride, st));
   HIPCHK(launch_xent(post, rows, cols, post_stride, targets_dev, mask_dev, diff, diff_stride, row_xent_dev, row_correct_dev, st));
+  if (totals_dev) HIPCHK(launch_xent_accumulate(row_xent_dev, row_correct_dev, mask_dev, rows, totals_dev, st));
   return KLSTM_OK;
 }
 

@@ -188,7 +188,8 @@ hipError_t launch_softmax(const float *in, int rows, int cols, int in_stride, fl
 hipError_t launch_xent(const float *y, int rows, int cols, int stride, const int *target, const float *mask, float *diff,
                        int diff_stride, float *row_xent, float *row_correct, hipStream_t st);
 hipError_t launch_softmax_xent(const float *in, int rows, int cols, int in_stride, float *post, int post_stride, const int *target,
-                               const float *mask, float *diff, int diff_stride, float *row_xent, float *row_correct, hipStream_t st);
+                               const float *mask, float *diff, int diff_stride, float *row_xent, float *row_correct, double *totals,
+                               unsigned *ticket, hipStream_t st);
 hipError_t launch_xent_accumulate(const float *row_xent, const float *row_correct, const float *mask, int rows, double *totals, hipStream_t st);
 hipError_t launch_xent_post(const float *y, int rows, int cols, int stride, const int *post_off, const int *post_pdf, const float *post_w,
                             const float *mask, float *diff, int diff_stride, float *row_xent, float *row_ent, float *row_correct,

@@ -2623,12 +2623,14 @@ __global__ __launch_bounds__(1024) void k_xent_rows_v(const float *__restrict__ 
 // 80 x 16624: 9.2 + 6.3 us and 21 MB -> one launch, 10.6 MB.
 __global__ __launch_bounds__(1024) void k_softmax_xent_rows_v(const float *__restrict__ in, int cols, int in_stride, float *__restrict__ post,
                                                              int post_stride, const int *__restrict__ target, const float *__restrict__ mask,
-                                                             float *__restrict__ diff, int diff_stride, float *__restrict__ row_xent,
-                                                             float *__restrict__ row_correct) {
+                                                             float *__restrict__ diff, int diff_stride, float *row_xent,
+                                                             float *row_correct, double *totals, unsigned *ticket) {
   __shared__ float sm[16];
   __shared__ float smv[16];
   __shared__ int smi[16];
   __shared__ float s_yt;
+  __shared__ int s_last;
+  __shared__ double s_tot[3][16];
   const int row = blockIdx.x;
   const float4 *ip = reinterpret_cast<const float4 *>(in + (size_t)row * in_stride);
   float4 *dp = reinterpret_cast<float4 *>(diff + (size_t)row * diff_stride);
@@ -2686,6 +2688,30 @@ __global__ __launch_bounds__(1024) void k_softmax_xent_rows_v(const float *__res
     row_xent[row] = (tgt >= 0 && tgt < cols) ? -m * logf(s_yt) : 0.f;
     row_correct[row] = (m == 1.f && bi == tgt) ? 1.f : 0.f;
   }
+  if (!totals) return;
+  // statistics onto the device totals without a launch of their own: the workgroup that takes the last ticket sees every row's two
+  // numbers (release fence before the ticket, device-scope loads after it) and adds them up in a fixed order
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+  for (int r = threadIdx.x; r < (int)gridDim.x; r += 1024) {
+    t0 += (double)__hip_atomic_load(row_xent + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t1 += (double)__hip_atomic_load(row_correct + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t2 += (double)mask[r];
+  }
+  for (int o = 32; o > 0; o >>= 1) { t0 += __shfl_xor(t0, o); t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+  if (lane == 0) { s_tot[0][wave] = t0; s_tot[1][wave] = t1; s_tot[2][wave] = t2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+    for (int w = 0; w < 16; w++) t += s_tot[threadIdx.x][w];
+    totals[threadIdx.x] += t;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ready for the next launch on this stream)
 }
 // dst[j] = beta*dst[j] + sum_rows src[row][j]   (AddRowSumMat)
 // dst[j] = beta*dst[j] + sum over rows of src[r][j]: 64 columns x 4 row groups per workgroup, 8 loads in flight per thread
@@ -3360,13 +3386,14 @@ hipError_t launch_xent(const float *y, int rows, int cols, int stride, const int
 }
 // one pass when the row fits the registers of 1024 threads (returns hipErrorNotSupported otherwise: the caller runs the pair)
 hipError_t launch_softmax_xent(const float *in, int rows, int cols, int in_stride, float *post, int post_stride, const int *target,
-                               const float *mask, float *diff, int diff_stride, float *row_xent, float *row_correct, hipStream_t st) {
+                               const float *mask, float *diff, int diff_stride, float *row_xent, float *row_correct, double *totals,
+                               unsigned *ticket, hipStream_t st) {
   LaunchProbe pr;
   const bool wide = cols % 4 == 0 && cols <= 32768 && cols >= 2048 && in_stride % 4 == 0 && diff_stride % 4 == 0 && aligned16(in) &&
                     aligned16(diff) && (!post || (post_stride % 4 == 0 && aligned16(post)));
   if (!wide) return hipErrorNotSupported;
   KLAUNCH(k_softmax_xent_rows_v, dim3(rows), dim3(1024), st, pr, in, cols, in_stride, post, post_stride, target, mask, diff, diff_stride,
-          row_xent, row_correct);
+          row_xent, row_correct, totals, ticket);
 }
 hipError_t launch_xent_post(const float *y, int rows, int cols, int stride, const int *post_off, const int *post_pdf, const float *post_w,
                             const float *mask, float *diff, int diff_stride, float *row_xent, float *row_ent, float *row_correct,

@@ -582,13 +582,15 @@ def test_softmax_xent_one_pass_equals_the_pair(N, M):
             assert torch.equal(post, y)
 
 
-def test_xent_statistics_accumulate_on_device():
-    """klstm_xent_accumulate: the statistics of three minibatches added onto a float64[3] device tensor equal the sums of what the
-    synchronous call returns for each (cross entropy to 1e-12 relative -- same per-row values, double sums; counts exactly), and the
-    loss object of the data-parallel mirror exposes them as `totals`."""
+@pytest.mark.parametrize("N,M", [(80, 4203), (80, 16624), (1, 2048), (640, 4096)])
+def test_xent_statistics_accumulate_on_device(N, M):
+    """Loss statistics on the device: the statistics of three minibatches added onto a float64[3] device tensor equal the sums of
+    what the synchronous call returns for each (cross entropy to 1e-12 relative -- same per-row values, double sums; counts
+    exactly), and the loss object of the data-parallel mirror exposes them as `totals`.  Odd widths go through klstm_softmax,
+    klstm_xent_eval_masked and klstm_xent_accumulate; wide aligned rows through the one-pass kernel, whose last workgroup adds the
+    rows up (1 and 640 workgroups: the ticket returns to zero between launches)."""
     import kaldi_lstm_amd as k
     rng = np.random.RandomState(5)
-    N, M = 80, 4203
     loss = k.SoftmaxXentDP(k, accumulate=True)
     want = np.zeros(3)
     for it in range(3):
