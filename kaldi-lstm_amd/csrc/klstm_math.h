@@ -87,9 +87,10 @@ __device__ __forceinline__ void bf16_split3_store4(const float (&v)[4], unsigned
     *reinterpret_cast<uint2 *>(dst + q * plane) = make_uint2(h[q][0] | ((unsigned)h[q][1] << 16), h[q][2] | ((unsigned)h[q][3] << 16));
 }
 
-// Two-way fp16 split (the lighter fold product, klstm_fold3.hip NPL = 2): x = h1 + h2 / 2048 up to 2^-22 |x|; the residual is
-// scaled by 2^11 before it is rounded so that it stays a NORMAL fp16 number for |x| down to 2^-14 (below that the absolute
-// error, < 2^-36, is far under a product's rounding).  The product kernel keeps a1 b1 and (a1 b2 + a2 b1) in separate
+// Two-way fp16 split (the lighter fold product, klstm_fold3.hip NPL = 2; the output layer's products, klstm_outer.hip): x = h1 + h2 / 2048
+// up to 2^-22 |x| for 2^-14 <= |x| < 65504; the residual (<= 2^-11 |x|) is scaled by 2^11 before it is rounded -- unscaled it would
+// sit in fp16's subnormal range for every |x| < 2^-3 and lose bits (tests/test_f16_split.py: 2^-14 relative around 2^-10).  Below
+// 2^-14 the absolute error, < 2^-35, is far under a product's rounding.  The product kernel keeps a1 b1 and (a1 b2 + a2 b1) in separate
 // accumulators and folds the 2^-11 in at the end.
 __device__ __forceinline__ void f16_split2(float x, unsigned short &h1, unsigned short &h2) {
   const _Float16 a = (_Float16)x;                       // RNE
