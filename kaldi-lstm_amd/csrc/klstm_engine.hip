@@ -1011,6 +1011,8 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     return KLSTM_OK;
   }
   if (!strcmp(key, "skinny_f16")) {              // 0: in_diff of a wide layer on the fp32 MFMA kernel (A-B; process-wide)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);                                // (the two-job launch of the BPTT tail looks at it too)
     set_skinny_f16(value);
     return KLSTM_OK;
   }
