@@ -227,6 +227,11 @@ def cpu_baseline(S, budget_s):
     return res
 
 
+def folded_chain(eng):
+    """Did the engine's last minibatch run on a chain that needs the fold product W_rm = W_gifo_r W_r_m?"""
+    return eng.profile_query("persist_launches")[1] > 0 or eng.S <= 8
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,17 +250,51 @@ def main():
                     help="engine option 'graph': hipGraph replay per call (robust against a busy host thread) or plain "
                          "stream launches (no fixed cost per graph launch); auto = time both before the warm-up, keep the faster")
     ap.add_argument("--option", action="append", default=[], help="engine option key=value (A/B experiments), repeatable")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch check only (runs without GPUs): bring the N ranks up exactly as a real run does -- the self-launch under "
+                         "torch.distributed.run when WORLD_SIZE is not set -- on the gloo backend, all-reduce one number, print one JSON line")
+    ap.add_argument("--collective", choices=("auto", "rccl", "oneshot"), default="auto",
+                    help="N > 1: the gradient all-reduce -- ncclAllReduce (klstm_allreduce_grads), the one-shot exchange over peer-mapped "
+                         "blobs (klstm_oneshot.hip), or auto = both are checked against each other and timed inside the warm-up, the faster "
+                         "one runs the timed steps (`allreduce_ab` in the line)")
     ap.add_argument("--force-collective", action="store_true",
                     help="one rank, but through the N > 1 code path: gradient -> klstm_allreduce_grads on a 1-rank RCCL communicator -> "
                          "momentum -> two-launch Update (what every rank of a multi-GPU run executes, minus the wire)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started like the N = 1 line: become the launcher -- one rank per GPU under torch.distributed.run
+        # on this node, the same command line; rank 0 prints the one JSON line
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with --nproc-per-node equal to --gpus, or without a launcher)" % (args.gpus, world))
+    if args.dry_launch:
+        import torch.distributed as dist
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(t)
+            dist.barrier()
+            total = float(t.item())
+            dist.destroy_process_group()
+        else:
+            total = 1.0
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": world, "launcher": os.environ.get("TORCHELASTIC_RUN_ID") is not None or world > 1,
+                              "allreduce_check": total, "expected": world * (world + 1) / 2.0}))
+        return
     dist = None
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_collective:
@@ -304,7 +343,18 @@ def main():
     in_diff = torch.empty(T_BPTT * S, I_DIM, device="cuda")
     # N>1: one all-reduce (sum, fp32) of the 8.73 MB gradient blob per minibatch, issued by libklstm.so itself (RCCL); a run
     # on several GPUs that cannot make the library-owned communicator fails instead of silently measuring something else
-    dp = k.DataParallelLstm(eng, force_collective=args.force_collective, require_native=world > 1 or args.force_collective)
+    collective_on = world > 1 or args.force_collective
+    want_oneshot = collective_on and args.collective in ("auto", "oneshot")
+    oneshot_note = None
+    try:
+        dp = k.DataParallelLstm(eng, force_collective=args.force_collective, require_native=collective_on, oneshot=want_oneshot)
+    except Exception as ex:                      # (peer mapping refused, e.g. no IPC between these devices: say so, run on RCCL)
+        if not want_oneshot:
+            raise
+        oneshot_note = "one-shot exchange could not be set up (%s): RCCL only" % ex
+        print("bench.py: " + oneshot_note, file=sys.stderr)
+        dp = k.DataParallelLstm(eng, force_collective=args.force_collective, require_native=collective_on)
+    allreduce_ab = None
     torch.cuda.synchronize()
 
     def step(i):
@@ -320,6 +370,53 @@ def main():
         return max_over_ranks(time.perf_counter() - t0)
 
     with torch.cuda.stream(stream):
+        # ---- N > 1: which all-reduce (untimed): the same local gradient through ncclAllReduce and through the one-shot exchange,
+        # results compared, both timed over 16 steps, the faster one kept -- and RCCL kept, loudly, whenever the one-shot status
+        # word is not clean or the sums differ
+        if dp.oneshot is not None:
+            eng.propagate(feats[0], out); eng.backpropagate(feats[0], odiff[0], in_diff, MOMENTUM, 1)
+            blob = eng.grad_blob_tensor()
+            local = blob.clone()
+            eng.allreduce_grads(dp.comm); eng.synchronize()
+            via_rccl = blob.clone()
+            blob.copy_(local)
+            dp.oneshot.allreduce_engine(eng)
+            err, st1 = None, None
+            try:
+                eng.synchronize()
+            except Exception as ex:
+                err = str(ex)
+            st1 = dp.oneshot.status()
+            via_one = blob.clone()
+            maxrel = float(((via_rccl - via_one).abs().max() / (via_rccl.abs().max() + 1e-30)).item())
+            blob.copy_(via_rccl)
+            eng.apply_momentum(MOMENTUM); eng.update(LR)
+            good = torch.tensor([1 if (err is None and st1 == 0 and maxrel <= 1e-6) else 0], dtype=torch.int32, device="cuda")
+            if world > 1:
+                dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            allreduce_ab = {"max_rel_diff_first_step": maxrel, "oneshot_status": st1, "oneshot_error": err}
+            times = {}
+            for name in (("rccl", "oneshot") if int(good.item()) else ("rccl",)):
+                dp.use_oneshot = name == "oneshot"
+                for i in range(4):
+                    step(i)
+                times[name] = timed_block(step, 4, 16) / 16 * 1e3
+                if name == "oneshot":
+                    st2 = torch.tensor([dp.oneshot.status()], dtype=torch.int32, device="cuda")
+                    if world > 1:
+                        dist.all_reduce(st2, op=dist.ReduceOp.MAX)
+                    if int(st2.item()) != 0:
+                        allreduce_ab["oneshot_status"] = int(st2.item())
+                        times.pop("oneshot")
+            allreduce_ab.update({k_ + "_ms_per_step": v for k_, v in times.items()})
+            pick = args.collective if args.collective != "auto" else min(times, key=times.get)
+            if pick not in times:
+                print("bench.py: the one-shot exchange did not pass its check (%s): the timed steps run on RCCL" % allreduce_ab, file=sys.stderr)
+                pick = "rccl"
+            dp.use_oneshot = pick == "oneshot"
+            allreduce_ab["chosen"] = pick
+        elif oneshot_note:
+            allreduce_ab = {"chosen": "rccl", "note": oneshot_note}
         # ---- launch mode A/B (untimed, independent of --warmup): 4 + 16 steps per mode
         launch = args.launch
         ab = None
@@ -378,7 +475,7 @@ def main():
                      "k_gates_fold", "k_gemm_rbatch", "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step",
                      "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx", "k_fwd_persist", "k_bwd_persist",
                      "k_grads", "k_grads_update", "k_update_repack", "k_pack", "k_pack_fwd", "k_pack_bwd", "k_apply_momentum",
-                     "rccl_allreduce"):
+                     "rccl_allreduce", "oneshot_allreduce"):
             tot, n = eng.profile_query(name)
             if n:
                 kern[name] = {"avg_us": tot / n, "launches_per_step": n / NPROF, "us_per_step": tot / NPROF}
@@ -404,6 +501,34 @@ def main():
             dt8 = timed_block(step8, 10, n8)
             s8 = {"value": n8 * T_BPTT * 8 / dt8, "unit": "frames/s", "ms_per_step": dt8 / n8 * 1e3, "streams": 8, "steps": n8}
             e8.close()
+
+        # ---- what arithmetic produced the number, and the same workload with every product on fp32-range arithmetic
+        fold_names = {0: "f32 (v_mfma_f32_16x16x4_f32)", 1: "bf16x3 (three bf16 planes per operand, six products, fp32 accumulate: fp32 range and accuracy)",
+                      2: "fp16x2 (two fp16 planes per operand, three products, fp32 accumulate: 22-bit operands; range guard -> bf16x3)"}
+        arithmetic = {"recurrence_products": "f32 MFMA (v_mfma_f32_4x4x1_16b_f32 / 16x16x4_f32), fp32 accumulate",
+                      "gradient_products": "f32 MFMA", "elementwise": "f32",
+                      "fold": fold_names.get(eng.profile_query("fold_mode")[1], "?") if folded_chain(eng) else "none (no fold product on this chain)",
+                      "fp16_range_guard_events": eng.profile_query("fp16_redo")[1]}
+        strict = None
+        if world == 1 and not args.no_extras:
+            strict = {}
+            for tag, mode in (("fold_f32", 0), ("fold_bf16x3", 1)):
+                es = make_engine(S)
+                es.set_option("fold_bf16x3", mode)
+                es.set_option("graph", 2 if launch == "graph" else 0)
+
+                def step_s(i, es=es):
+                    c = i % nchunk
+                    if c == 0:
+                        es.reset(ones)
+                    es.propagate(feats[c], out); es.backpropagate(feats[c], odiff[c], in_diff, MOMENTUM, 2); es.update(LR)
+                for i in range(10):
+                    step_s(i)
+                ns = 400
+                dts = timed_block(step_s, 10, ns)
+                strict[tag] = {"value": ns * T_BPTT * S / dts, "unit": "frames/s", "ms_per_step": dts / ns * 1e3, "steps": ns,
+                               "fold": fold_names[mode]}
+                es.close()
 
     frames_per_step = T_BPTT * S * world
     value = nsteps_total * frames_per_step / dt_total
@@ -487,6 +612,7 @@ def main():
                                       if S == 8 else "custom stream count"),
                        "streams_per_gpu": S, "total_streams": S * world, "bptt": T_BPTT,
                        "frames_per_step": frames_per_step, "launch": launch, "launch_ab": ab,
+                       "arithmetic": arithmetic,
                        "recurrence": ("persistent weights-resident chain" if "k_bwd_persist" in kern or "k_fwd_persist" in kern else
                                       "folded (W_rm = W_gifo_r W_r_m, one kernel per step and direction)" if folded
                                       else "reference-shaped (gates + projection, d_r + d_m kernels per step)"),
@@ -494,7 +620,7 @@ def main():
                                   "Update follows immediately, as in Kaldi's Component::Backpropagate)" if "k_grads_update" in kern else
                                   "gradient products, all-reduce, momentum + Update" if (world > 1 or args.force_collective) else "gradient products, then Update"),
                        "parallelism": "dp%d over streams, 1 all-reduce/minibatch" % world if world > 1 else "single GPU",
-                       "collective": dp.collective_name, "ranks_seen": dp.ranks_seen},
+                       "collective": dp.collective_in_use(), "ranks_seen": dp.ranks_seen},
             "timed": {"steps": nsteps_total, "seconds": dt_total},
             "first_k_steps": {"steps": K, "seconds": dt_first, "ms_per_step": dt_first / K * 1e3,
                               "value": K * frames_per_step / dt_first},
@@ -503,12 +629,20 @@ def main():
             "chain_us_per_step": chain_us, "non_chain_us_per_step": sum(v["us_per_step"] for v in kern.values()) - chain_us,
             "kernels": kern,
         }
-        if "rccl_allreduce" in kern:                # exposed time of the gradient all-reduce per minibatch (events on the engine's stream)
-            res["allreduce_us"] = kern["rccl_allreduce"]["us_per_step"]
+        for nm in ("rccl_allreduce", "oneshot_allreduce"):   # exposed time of the gradient all-reduce per minibatch (events on the engine's stream)
+            if nm in kern:
+                res["allreduce_us"] = kern[nm]["us_per_step"]
         if ragged:
             res["ragged"] = ragged
         if s8:
             res["s8_per_gpu"] = s8
+        if strict:
+            # the headline workload with the fold product on fp32 operands (every product of the path then is an fp32 MFMA) and on
+            # three bf16 planes (fp32 range, matrix cores): `value` itself runs what config.arithmetic.fold says
+            res["strict_f32"] = strict["fold_f32"]
+            res["fold_bf16x3"] = strict["fold_bf16x3"]
+        if allreduce_ab:
+            res["allreduce_ab"] = allreduce_ab
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(S, args.cpu_seconds)
         print(json.dumps(res))

@@ -235,6 +235,20 @@ def run_c4(args, k):
         ms_eager = dte / ne * 1e3
     graphed_used = graphed and lazy
     kern = _engine_kernels(engines, step, args.warmup + n)
+    shard = None
+    if fused:
+        # what a rank of the 8-GPU run executes, minus the wire: pure local gradients into ONE 57.6 MB blob (the all-reduce payload),
+        # then momentum + Update as passes of their own (the fused per-layer Update above has no blob to reduce)
+        net2 = k.DataParallelNnet(layers, net.loss, alloc=lambda n_: torch.zeros(n_, device="cuda"), fuse_single_rank=False)
+
+        def raw2(c):
+            net2.train_step(feats[c], tg[c], mask, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
+        step2 = _WholeStep(raw2, stream, nchunk, False, after)
+        step2.prepare()
+        dt2, n2, _ = _timed(step2, 10, max(20, args.steps // 2), min(1.0, args.min_seconds))
+        shard = {"value": T * S / (dt2 / n2 * 1e-3), "unit": "frames/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
+                 "path": "local gradients into one fused 57.6 MB blob (the payload of the one all-reduce per minibatch), then momentum + Update: "
+                         "a rank of the 8-GPU run minus the wire"}
     # device time of the output tail, part by part
     x80 = torch.randn(T * S, R, device="cuda"); aff = layers[-1]; loss = net.loss
     torch.cuda.synchronize()
@@ -253,15 +267,18 @@ def run_c4(args, k):
             "value": T * S / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1, "steps": n, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "2 stacked LstmProjectedStreams (40->512->512, cell 800) + AffineTransform 512->16624 + Softmax + Xent::EvalMasked, "
-                                   "NumStream=4 per GPU (the per-GPU shard of BASELINE.json configs[3]: 32 streams on 8 GPUs), T_bptt=20, one fused "
-                                   "57.6 MB gradient blob, loss statistics %s" % ("accumulated on the device, read back every 50 minibatches" if lazy else "read back every minibatch"),
+                                   "NumStream=4 (one GPU's streams of BASELINE.json configs[3]: 32 streams on 8 GPUs), T_bptt=20, %s, "
+                                   "loss statistics %s" % ("SINGLE-GPU training step: gradient + momentum + Update as one pass per layer, no gradient blob, no "
+                                                           "all-reduce (`multi_gpu_shard_path` = the path a rank of the 8-GPU run takes)" if fused else
+                                                           "multi-GPU shard path: local gradients into one fused 57.6 MB blob, then momentum + Update",
+                                                           "accumulated on the device, read back every 50 minibatches" if lazy else "read back every minibatch"),
                        "streams_per_gpu": S, "frames_per_step": T * S,
                        "launch": "one hipGraph per minibatch (captured per input chunk)" if graphed_used else
                                  "call by call from Python on one explicit stream (--option whole_step_graph=1: one hipGraph per minibatch; "
                                  "measured equal: 0.569 vs 0.564 ms)",
                        "ms_per_step_call_by_call": ms_eager},
             "roofline": _roof(fl * T * S, ms, PEAK_F32_MFMA_TF, "f32", "86.2 MFLOP per frame (SURVEY.md 8(d))"),
-            "sections_us": sections, "kernels": kern}
+            "multi_gpu_shard_path": shard, "sections_us": sections, "kernels": kern}
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -286,8 +303,9 @@ def run_c5(args, k):
         e.set_option("bf16", 1)
         engines.append(e)
     od = 0.1 * torch.randn(T * S, R, device="cuda")
-    net = k.DataParallelNnet([k.LstmDP(e) for e in engines], _FixedDiffLoss(od), alloc=lambda n: torch.zeros(n, device="cuda"),
-                             fuse_single_rank="fuse_single_rank=0" not in args.option)
+    fused = "fuse_single_rank=0" not in args.option
+    layers = [k.LstmDP(e) for e in engines]
+    net = k.DataParallelNnet(layers, _FixedDiffLoss(od), alloc=lambda n: torch.zeros(n, device="cuda"), fuse_single_rank=fused)
     nchunk = 50
     feats = torch.randn(nchunk, T * S, I, device="cuda")
     ones = [1] * S
@@ -300,6 +318,16 @@ def run_c5(args, k):
     dt, n, dt_first = _timed(step, args.warmup, max(20, args.steps // 5), args.min_seconds)
     ms = dt / n * 1e3
     kern = _engine_kernels(engines, step, args.warmup + n)
+    shard = None
+    if fused:                                          # (as in run_c4: the path a rank of the 8-GPU run takes, minus the wire)
+        net2 = k.DataParallelNnet(layers, _FixedDiffLoss(od), alloc=lambda n_: torch.zeros(n_, device="cuda"), fuse_single_rank=False)
+
+        def step2(i):
+            c = i % nchunk
+            net2.train_step(feats[c], None, None, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
+        dt2, n2, _ = _timed(step2, 10, max(20, args.steps // 10), min(1.0, args.min_seconds))
+        shard = {"value": T * S / (dt2 / n2 * 1e-3), "unit": "frames/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
+                 "path": "local gradients into one fused 49 MB blob (the payload of the one all-reduce per minibatch), then momentum + Update"}
     for e in engines:
         e.close()
     fl = sum(lstm_flops_per_frame(dims_in[l], C, R) for l in range(NL))
@@ -307,10 +335,12 @@ def run_c5(args, k):
             "value": T * S / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1, "steps": n, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "3 stacked LstmProjectedStreams cell 1024 / proj 512 (40->512->512->512), NumStream=32 per GPU (the per-GPU shard "
-                                   "of BASELINE.json configs[4]: 256 streams on 8 GPUs), T_bptt=20, bf16 operands / fp32 accumulate / fp32 masters",
+                                   "of BASELINE.json configs[4]: 256 streams on 8 GPUs), T_bptt=20, bf16 operands / fp32 accumulate / fp32 masters; "
+                                   "%s" % ("SINGLE-GPU training step (per-layer Update without a gradient blob; `multi_gpu_shard_path` = what a rank of "
+                                           "the 8-GPU run executes)" if fused else "multi-GPU shard path (fused gradient blob, separate momentum + Update)"),
                        "streams_per_gpu": S, "frames_per_step": T * S},
             "roofline": _roof(fl * T * S, ms, PEAK_BF16_MFMA_TF, "bf16", "73.3 MFLOP per frame (SURVEY.md 8(d)); launch-per-step chain"),
-            "kernels": kern}
+            "multi_gpu_shard_path": shard, "kernels": kern}
 
 
 RUN = {"c1": run_c1, "c4": run_c4, "c5": run_c5}

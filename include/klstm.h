@@ -294,26 +294,54 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  directions from 8 frames per stream).  Same results up to fp32 summation order.  Needs one compute unit
  *                  per workgroup (C/4 backward, C/4 or C/8 forward): an engine on a device (partition) with fewer compute
  *                  units keeps to one launch per step, and klstm_last_error() says so when the option asked for it.
- *                  Every in-kernel wait is bounded; a launch that gives up sets a status word that (a) makes the Update
- *                  kernels of this engine return without touching momentum or parameters, (b) is reported as KLSTM_ERR_HIP
- *                  by the next call that looks (propagate / backpropagate / update poll a host-mapped copy without a
- *                  synchronisation; klstm_synchronize and every device-to-host getter read the device words), after which
- *                  the engine stays on the launch-per-step chain.  Outputs and carried state of that minibatch are invalid.
+ *                  Every in-kernel wait is bounded.  A launch that GIVES UP (its workgroups were not all resident: another
+ *                  process holds part of the chip) records its ordinal and a status word; on the device, every persistent
+ *                  launch and every gradient / momentum / Update kernel queued behind it sees the word and does nothing, and
+ *                  the carried state the minibatch started from is intact (double-buffered).  The first call that looks
+ *                  (propagate / backpropagate / update / reset poll a host-mapped word without a synchronisation;
+ *                  klstm_synchronize, the getters and klstm_allreduce_grads read the device words) answers it WITHOUT an
+ *                  error: the calls of the CURRENT minibatch -- since the last klstm_propagate / klstm_reset began -- are run
+ *                  again on the launch-per-step chain with the arguments they came with (bit-identical to an engine that never
+ *                  used the persistent chain), so `in`, `out_diff` and the output buffers of a minibatch must stay the
+ *                  caller-provided, unchanged buffers until the next klstm_propagate / klstm_reset on the engine (Kaldi's
+ *                  Nnet keeps them exactly that long).  A minibatch older than that cannot be run again: it is DROPPED -- no
+ *                  Update, no state advance -- and counted.  `persist_cooldown` minibatches (default 64) on the launch-per-step
+ *                  chain follow, then the persistent chain is tried again.  klstm_last_error() carries a remark;
+ *                  klstm_profile_query(e, "persist_giveups" | "persist_replayed" | "persist_dropped" | "persist_launches", ..)
+ *                  returns the counts in *launches (no "profile" option needed).
+ *                  "persist_verify" 0/1: 1 = klstm_propagate / klstm_backpropagate wait for their persistent launch, so a
+ *                  give-up is answered INSIDE the call, before the caller (or a neighbouring component) has read `out` /
+ *                  `in_diff`: fully transparent, at the price of one host wait per call (~6 us of launch gap each; Kaldi
+ *                  synchronises per minibatch anyway: the C++ mirror turns it on).  0 (default of the C-ABI): asynchronous, as above.
+ *                  Not supported: a hipGraph captured by the CALLER around engine calls that take the persistent chain (the
+ *                  engine cannot count launches inside a foreign graph): use "persist" = 0 there.
  *                  Per-engine knobs (A-B experiments and tests): "persist_waves" (forward and backward geometry: 8, 12, 16),
  *                  "persist_bwd_waves" (12, 16), "persist_tpw", "persist_nap0", "persist_nap", "persist_nap0_bwd",
  *                  "persist_spin_us" (bound of a single in-kernel wait, default 50 000), "persist_ncu" (pretend CU count),
  *                  "persist_test_stall_fwd" / "persist_test_stall_bwd" (workgroup 0 withholds its publish of that step:
  *                  forces the give-up path)
- *   "fold_bf16x3"  0/1/2  the fold product W_rm = W_gifo_r * W_r_m on the 16-bit matrix cores at fp32 accuracy (DESIGN.md 3d;
- *                  every partial product exact in fp32, fp32 accumulation): 2 (default) = two fp16 planes per operand, three
- *                  products, dropped terms ~7e-7 relative (parameters must stay below 65504 in magnitude: beyond, the product
- *                  carries Inf / NaN); 1 = three bf16 planes, six products, dropped terms below 2^-24, fp32 range; 0 = the fp32
- *                  MFMA kernel.  Process-wide (A-B experiments).  "fold_direct" 0: the generic tile kernel
+ *   "fold_bf16x3"  0/1/2  the fold product W_rm = W_gifo_r * W_r_m of THIS engine on the 16-bit matrix cores at fp32 accuracy
+ *                  (every partial product exact in fp32, fp32 accumulation): 2 (default) = two fp16 planes per
+ *                  operand, three products, dropped terms ~7e-7 relative; 1 = three bf16 planes, six products, dropped terms
+ *                  below 2^-24; 0 = the fp32 MFMA kernel.  RANGE: identical to the reference's fp32 products in every mode -- in
+ *                  mode 2 a parameter at or beyond 65520 (the fp16 range) is noticed by the product itself (range guard, below),
+ *                  the affected tiles are recomputed in fp32 and the engine moves to mode 1 by itself.  Parameters below 2^-14
+ *                  carry an absolute error of 2^-36 (not a relative one of 2^-22): nothing for a weight matrix whose largest
+ *                  entries are above 1e-4.  "fold_direct" 0: the generic tile kernel (process-wide)
  *   "direct_nt_shape", "outer_f16", "skinny_f16", "skinny_f16_pair"  the three products of a WIDE AffineTransform at few frames
  *                  (the output layer of a small-minibatch step) run on the f16 matrix cores at fp32 accuracy:
  *                  both operands split into two fp16 numbers on the fly (x = h1 + h2 / 2048), three products with fp32
  *                  accumulation, the dropped term ~2^-22 relative; measured error against float64 at or below the fp32 MFMA
- *                  kernels'.  Inputs, weights and out_diff must stay below 65504 in magnitude (beyond: Inf / NaN).
+ *                  kernels'.  RANGE GUARD: the numeric range is the reference's (fp32).  Upper side: an operand at or beyond
+ *                  65520 becomes Inf in its first plane and every accumulator it meets Inf / NaN -- never a finite wrong
+ *                  number; each wave looks at its accumulators after its K loop, recomputes its outputs in plain fp32 when it
+ *                  finds one, and counts the event in a host-mapped word; the launcher reads the word before every launch and
+ *                  keeps that product on its fp32 kernel from then on (klstm_profile_query(e, "fp16_redo" | "fp16_redo_nt" |
+ *                  "fp16_redo_outer" | "fp16_redo_skinny" | "fp16_redo_fold", ..) returns the counts in *launches).  Lower side:
+ *                  DERIVATIVE operands are scaled by a power of two before the split and the result scaled back (exact): every
+ *                  column of out_diff by its own in klstm_affine_gradient / _update, out_diff / dgifo by 2^12 in
+ *                  klstm_affine_backpropagate and the BPTT tail -- entries of 1e-7 (late training) keep fp32 accuracy (22 bits
+ *                  down to 2^-26, an absolute error below 2^-47 under that; derivatives of 16 and more take the guard's path).
  *                  klstm_affine_propagate of <= 80 rows into > 8192 columns: "direct_nt_shape" 99 = the same layout on the fp32
  *                  MFMA, 0 = the register-direct fp32 kernel, 10*NI + waves = geometry of that kernel;
  *                  klstm_affine_gradient / klstm_affine_update of <= 96 rows and >= 2048 outputs: "outer_f16" 0 = fp32 tiles;
@@ -321,8 +349,9 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  d_r / in_diff of an engine whose input is too wide for the persistent backward launch: "skinny_f16_pair" 0 =
  *                  the tiled split-K kernel.  All process-wide (A-B experiments and tests)
  *   "fp16_products"  0/1  0 = no product runs on fp16 planes (all of the above on their fp32 kernels, the fold product on three
- *                  bf16 planes, which have the fp32 range): for a net whose activations, weights or derivatives can pass 65504 in
- *                  magnitude.  1 = the defaults again.  Process-wide
+ *                  bf16 planes): saves a net whose activations, weights or derivatives pass 65504 all the time the one slow
+ *                  call of the range guard.  1 = the defaults again, the guard's counters cleared.  Process-wide (reaches the
+ *                  cached graphs of every live engine)
  *   "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.

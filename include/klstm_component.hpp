@@ -225,13 +225,27 @@ class LstmProjectedStreams {
       Check(klstm_backpropagate(eng_, in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
                                 in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, in.NumRows(),
                                 opts_.momentum, BpttFlags()));
-    host_fresh_ = host_fresh_ && true;
   }
-  // The caller that KNOWS Update follows immediately on the same (input, out_diff) pair -- Kaldi's Component::Backpropagate,
-  // here Nnet::Backpropagate -- says so; the engine may then leave the gradient products to klstm_update and run them in
-  // one pass with the Update (KLSTM_BPTT_FUSE_UPDATE keeps the raw `in` pointer until then).  A bare BackpropagateFnc
-  // (gradient checks, custom adapters) keeps the engine's default: the products run inside the call.
+  // The caller that KNOWS Update follows immediately on the same (input, out_diff) pair says so; the engine may then leave the
+  // gradient products to klstm_update and run them in one pass with the Update (KLSTM_BPTT_FUSE_UPDATE keeps the raw `in`
+  // pointer until then) -- the 4-launch minibatch bench.py measures.  Inside Kaldi that is ALWAYS the case: BackpropagateFnc is
+  // protected there and its one caller, Component::Backpropagate (nnet-component.h), runs Update right behind it -- the shim of
+  // INTEGRATION.md sets the flag in its constructor; Backpropagate() below is that Kaldi method for users of this mirror.
+  // A bare BackpropagateFnc (gradient checks, custom adapters) keeps the engine's default: the products run inside the call.
   void SetUpdateFollows(bool v) { update_follows_ = v; }
+  // Kaldi nnet1's Component::Backpropagate for an updatable component: BackpropagateFnc, then Update on the same pair.
+  void Backpropagate(const MatrixView &in, const MatrixView &out, const MatrixView &out_diff, MatrixView *in_diff) {
+    const bool keep = update_follows_;
+    update_follows_ = true;
+    try { BackpropagateFnc(in, out, out_diff, in_diff); } catch (...) { update_follows_ = keep; throw; }
+    update_follows_ = keep;
+    Update(in, out_diff);
+  }
+  // "persist_verify" (klstm.h): wait for every persistent launch and answer a give-up inside the call, so that no neighbouring
+  // component ever reads an invalid `out` / `in_diff`.  ON by default in this mirror -- a Kaldi trainer synchronises per
+  // minibatch anyway (Xent::EvalMasked copies its sums to the host, nnet-loss.cc:110-141) and shares its GPU with whatever else
+  // the machine runs; a pipelined trainer that owns the GPU turns it off for ~8 % more throughput at 4 streams.
+  void SetPersistVerify(bool v) { persist_verify_ = v; if (eng_) Check(klstm_set_option(eng_, "persist_verify", v ? 1 : 0)); }
   int BpttFlags() const { return dp_comm_ ? KLSTM_BPTT_DEFER_MOMENTUM : update_follows_ ? KLSTM_BPTT_FUSE_UPDATE : KLSTM_BPTT_DEFAULT; }
 
   // Update, ...streams.h:501-512 (arguments unused there too)
@@ -285,6 +299,7 @@ class LstmProjectedStreams {
     if (state_c_.size() == (size_t)nstream_ * ncell_ && state_r_.size() == (size_t)nstream_ * nrecur_)
       Check(klstm_set_state_host(eng_, state_c_.data(), state_r_.data()));          // carried over by Copy()
     state_c_.clear(); state_r_.clear();
+    Check(klstm_set_option(eng_, "persist_verify", persist_verify_ ? 1 : 0));
     for (const auto &kv : options_) Check(klstm_set_option(eng_, kv.first.c_str(), kv.second));
   }
   void PullParams() const {
@@ -337,6 +352,7 @@ class LstmProjectedStreams {
   mutable std::vector<BaseFloat> params_;   // host shadow, GetParams order
   mutable bool host_fresh_;                 // params_ == device parameters
   bool update_follows_ = false;             // set by the caller that runs Update right behind BackpropagateFnc
+  bool persist_verify_ = true;              // SetPersistVerify
   std::vector<BaseFloat> corr_;             // only to carry *_corr_ across Copy()
   bool corr_pending_;
   std::vector<BaseFloat> state_c_, state_r_;        // only to carry prev_nnet_state_ (c, r columns) across Copy()

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -25,6 +26,7 @@
 #include "klstm_kernels.h"
 
 using namespace klstm;
+void klstm_oneshot_set_abort_words(klstm_oneshot *h, unsigned *guard_word_dev, unsigned *host_mapped_word);   // klstm_oneshot.hip
 
 static thread_local std::string g_err;
 static klstm_status fail(klstm_status st, const char *fmt, ...) {
@@ -54,6 +56,20 @@ static void note(const char *fmt, ...) {
 
 struct ProbeRec { std::string name; hipEvent_t start, stop; };
 
+// The calls of the current minibatch -- since the last klstm_propagate / klstm_reset BEGAN; from then on the caller may reuse the
+// previous minibatch's buffers -- with the arguments they came with: what the engine re-runs on the launch-per-step chain when
+// a persistent launch of this minibatch gave up (recover()).
+struct MbRec {
+  bool have_fwd = false, have_bwd = false, have_upd = false;
+  unsigned fwd_seq = 0, bwd_seq = 0;          // ordinal of the call's persistent launch (0: it did not use one)
+  int sp_before = 0;                          // state buffer the forward started from
+  const float *in = nullptr; int rows = 0, in_stride = 0; float *out = nullptr; int out_stride = 0;
+  const float *bin = nullptr; int bin_stride = 0; const float *od = nullptr; int od_stride = 0; float *idf = nullptr; int id_stride = 0;
+  float mmt = 0.f; int flags = 0;
+  float lr = 0.f, clip = 0.f;
+};
+static const klstm_status KLSTM_RECOVERED = (klstm_status)100;   // internal: a give-up was found and answered (never leaves the library)
+
 struct klstm_engine {
   int I = 0, C = 0, R = 0, S = 0, device = 0;
   hipStream_t stream = nullptr;
@@ -63,7 +79,10 @@ struct klstm_engine {
   float *grads_own = nullptr;   // the engine's own gradient blob (grads points elsewhere after klstm_bind_grad_blob)
   float *wrT = nullptr, *wmT = nullptr, *wxT = nullptr;   // transposed copies for the BPTT kernels
   float *pk[4] = {nullptr, nullptr, nullptr, nullptr};    // packed MFMA-operand-ordered copies (vector kernels)
-  float *prev_c = nullptr, *prev_r = nullptr;
+  // carried state, double-buffered: a forward pass reads [sp] and writes [sp ^ 1], then the engine flips sp -- a persistent
+  // launch that gives up leaves the state it started from intact, and so does everything queued behind it (device-side guard)
+  float *prev_c[2] = {nullptr, nullptr}, *prev_r[2] = {nullptr, nullptr};
+  int sp = 0;
   int *flags_dev = nullptr;
   float *stage[4] = {nullptr, nullptr, nullptr, nullptr};   // host-matrix staging: in, out, out_diff, in_diff (dense rows)
   int stage_rows = 0;
@@ -98,6 +117,17 @@ struct klstm_engine {
   unsigned long long *gran[2] = {nullptr, nullptr};   // granule slots of the forward / backward chain
   unsigned *pctrl = nullptr;    // 2 x 4 words: {epoch, finished workgroups, status, pad} per direction
   unsigned *pstat_host = nullptr;   // pinned, device-mapped word the persistent kernels set when they give up (polled without a sync)
+  // ---- give-up handling of the persistent chain (recover()) ----
+  unsigned pseq = 0;            // persistent launches enqueued so far, both directions (the device counts the same in pctrl[8])
+  int persist_verify = 0;       // option: wait for every persistent launch and answer a give-up before the call returns
+  int cooldown = 0, cooldown_len = 64;   // minibatches on the launch-per-step chain after a give-up, then the persistent chain again
+  long n_giveups = 0, n_replayed = 0, n_dropped = 0;
+  bool replaying = false;
+  struct FwdMark { unsigned seq; int sp_before; };
+  FwdMark marks[8]; int nmarks = 0;       // the last persistent forward launches: which state buffer each started from
+  MbRec rec;
+  std::vector<int> resets;      // Reset flags since the last forward pass was enqueued (applied again when the state goes back a buffer)
+  int fold_mode = 2;            // fold product: 0 fp32 MFMA, 1 three bf16 planes, 2 two fp16 planes (option "fold_bf16x3")
   void *fold_scratch = nullptr;             // bf16 planes of the two fold operands (klstm_fold3.hip)
   bool planes_fresh = false;                // ... and they were written from the current parameters (by the fused Update)
   float *pk_fold[2] = {nullptr, nullptr};   // packed [W_rm | W_x] (gates order) and W_rm^T (4-row geometry)
@@ -144,6 +174,19 @@ static void free_planes(klstm_engine *e) {
 static void drop_graphs(klstm_engine *e) {
   for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
   e->graphs.clear();
+}
+
+// every live engine: a process-wide knob (which kernel a product runs on) must reach the cached graphs of ALL of them
+static std::mutex g_engines_mu;
+static std::set<klstm_engine *> g_engines;
+static void knob_changed_everywhere(int fold_mode = -1) {
+  std::lock_guard<std::mutex> lk(g_engines_mu);
+  for (klstm_engine *x : g_engines) {
+    if (hipSetDevice(x->device) != hipSuccess) continue;
+    (void)hipStreamSynchronize(x->stream);
+    drop_graphs(x);
+    if (fold_mode >= 0) { x->fold_mode = fold_mode; x->planes_fresh = false; x->fold_dirty = true; }
+  }
 }
 
 static klstm_status ensure_planes(klstm_engine *e, int T) {
@@ -218,7 +261,7 @@ static klstm_status flush_momentum(klstm_engine *e) {
   { klstm_status gs = flush_grads(e); if (gs != KLSTM_OK) return gs; }
   if (!e->mmt_pending) return KLSTM_OK;
   e->mmt_pending = false;
-  HIPCHK(launch_apply_momentum(e->corr, e->grads, e->mmt_value, e->nparams, e->stream, probe(e, "k_apply_momentum")));
+  HIPCHK(launch_apply_momentum(e->corr, e->grads, e->mmt_value, e->nparams, e->stream, probe(e, "k_apply_momentum"), e->pctrl));
   return KLSTM_OK;
 }
 
@@ -251,6 +294,7 @@ static bool persist_bwd_wanted(const klstm_engine *e, int T) {
   return e->use_persist != 1 && persist_bwd_supported(d, e->popt) && persist_bwd_grid(d) <= e->ncu;
 }
 static bool persist_wanted(const klstm_engine *e, int T) {
+  if (e->replaying || e->cooldown > 0) return false;       // (a minibatch being re-run after a give-up, and the minibatches after it)
   if (e->use_persist == 0 || e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0]) return false;
   const Dims d{e->I, e->C, e->R, e->S, T};
   if (!use_fused_x(e) && !persist_x_batched(d)) return false;   // (x inside the step unless the input is wide: then the batched product feeds the launch)
@@ -283,36 +327,113 @@ static klstm_status ensure_persist(klstm_engine *e) {
     (void)hipGetLastError();
     e->pstat_host = nullptr;                       // (no early notice then: the status words are still read at every sync)
   }
+  e->popt.guard = e->pctrl;
   return KLSTM_OK;
 }
-// After a host synchronisation: did a bounded spin of a persistent launch expire?  (Only possible when its workgroups
-// were not co-resident, e.g. another process holds most of the chip.)  The engine then stops using that path.
+// ---- a persistent launch gave up (a bounded in-kernel wait expired: its workgroups were not all resident, e.g. another process
+// holds part of the chip) ----
+// What the device has done by itself: the launch recorded its ordinal and a status word; every persistent launch and every
+// gradient / momentum / Update kernel queued behind it found the word and did nothing; the carried state the failed minibatch
+// started from is intact (double buffer).  What happens here, at the first call that looks (a poll of the host-mapped word at
+// the head of propagate / backpropagate / update / reset, or any synchronising call): the status is cleared, the state index goes
+// back to the buffer the first affected forward pass started from, and the calls of the CURRENT minibatch whose launches sit at or
+// behind the failure are run again on the launch-per-step chain with the arguments they came with (their buffers are still the
+// engine's to read: klstm.h "persist") -- results bit-identical to an engine that never used the persistent chain.  Anything
+// older cannot be run again (the caller has its buffers back): that minibatch is dropped -- no Update, no state advance -- and
+// counted.  The engine stays on the launch-per-step chain for `cooldown_len` minibatches, then tries the persistent one again.
+// Option "persist_verify" = 1 makes every persistent call wait for its launch, so that a give-up is always answered inside the
+// call that caused it, before the caller has seen `out` / `in_diff`.
+static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int in_stride, float *out, int out_stride);
+static klstm_status do_backpropagate(klstm_engine *e, const float *in, int in_stride, const float *out_diff, int out_diff_stride,
+                                     float *in_diff, int in_diff_stride, int rows, float momentum, int flags);
+static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad);
+static klstm_status apply_reset(klstm_engine *e, const std::vector<int> &flags);
+
+static klstm_status recover(klstm_engine *e, const unsigned (&w)[16]) {
+  unsigned fseq = 0;                                  // ordinal of the first launch that gave up
+  for (unsigned v : {w[3], w[7]}) if (v && (!fseq || v < fseq)) fseq = v;
+  unsigned z[16] = {0};
+  z[0] = w[0]; z[4] = w[4]; z[8] = w[8];              // epochs and the launch counter stay
+  HIPCHK(hipMemcpy(e->pctrl, z, sizeof(z), hipMemcpyHostToDevice));
+  e->n_giveups++;
+  e->cooldown = e->cooldown_len;
+  // host-side bookkeeping of work the device skipped
+  e->grads_pending = false; e->mmt_pending = false;
+  e->planes_fresh = false; e->fold_dirty = true; e->foldx_fresh = false;
+  if (e->pk[0]) e->pk_stale = 15;
+  e->bwd_persist = false;
+  drop_graphs(e);
+  const int sp_now = e->sp;
+  for (int i = 0; i < e->nmarks; i++)
+    if (!fseq || e->marks[i].seq >= fseq) { e->sp = e->marks[i].sp_before; break; }
+  e->nmarks = 0;
+  const MbRec r = e->rec;
+  e->rec = MbRec();
+  const bool re_fwd = r.have_fwd && r.fwd_seq && fseq && r.fwd_seq >= fseq;
+  const bool re_bwd = r.have_bwd && (re_fwd || (r.bwd_seq && fseq && r.bwd_seq >= fseq));
+  const bool re_upd = r.have_upd && re_bwd;
+  if (e->sp != sp_now && !(re_fwd && e->sp == r.sp_before)) {
+    // the state went back further than this minibatch's forward pass (or that pass cannot be run again): Resets the caller has
+    // issued since were applied to the abandoned buffer
+    const klstm_status rs = apply_reset(e, e->resets);
+    if (rs != KLSTM_OK) return rs;
+  }
+  const unsigned affected = fseq && e->pseq >= fseq ? e->pseq - fseq + 1 : 1;
+  const unsigned covered = (re_fwd ? 1u : 0u) + (re_bwd && r.bwd_seq ? 1u : 0u);
+  if (re_fwd || re_bwd) {
+    e->replaying = true;
+    klstm_status st = KLSTM_OK;
+    if (re_fwd) st = do_propagate(e, r.in, r.rows, r.in_stride, r.out, r.out_stride);
+    if (st == KLSTM_OK && re_bwd) st = do_backpropagate(e, r.bin, r.bin_stride, r.od, r.od_stride, r.idf, r.id_stride, r.rows, r.mmt, r.flags);
+    if (st == KLSTM_OK && re_upd) st = do_update(e, r.lr, r.clip);
+    e->replaying = false;
+    if (st != KLSTM_OK) return st;
+    e->n_replayed++;
+  }
+  if (affected > covered) e->n_dropped++;
+  note("persistent recurrence chain gave up (forward status %x, backward status %x, launch %u of %u): %s; %d minibatches on the "
+       "launch-per-step chain follow", w[2], w[6], fseq, e->pseq,
+       affected > covered ? (covered ? "this minibatch was run again on the launch-per-step chain, an earlier one was dropped (no Update, no state advance)"
+                                     : "that minibatch was dropped (no Update, no state advance: its buffers were the caller's again)")
+                          : "the minibatch was run again on the launch-per-step chain",
+       e->cooldown_len);
+  return KLSTM_RECOVERED;
+}
+
+// After a host synchronisation of the engine's stream: did a persistent launch give up?  KLSTM_RECOVERED: yes, and it has been
+// answered (work may have been enqueued: a caller that has already read results reads them again).
 static klstm_status check_persist(klstm_engine *e) {
   if (!e->persist_dirty || !e->pctrl) return KLSTM_OK;
   e->persist_dirty = false;
-  if (e->pstat_host) *e->pstat_host = 0u;
+  if (e->pstat_host) *reinterpret_cast<volatile unsigned *>(e->pstat_host) = 0u;
   unsigned w[16];
   HIPCHK(hipMemcpy(w, e->pctrl, sizeof(w), hipMemcpyDeviceToHost));
-  if (w[2] == 0 && w[6] == 0) return KLSTM_OK;
-  e->grads_pending = false; e->mmt_pending = false;   // (what was queued for the Update belongs to the invalid minibatch)
-  const unsigned z[16] = {w[0], 0, 0, 0, w[4], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  HIPCHK(hipMemcpy(e->pctrl, z, sizeof(z), hipMemcpyHostToDevice));
-  e->use_persist = 0;
-  e->planes_fresh = false;
+  if (w[9] != 0) {
+    // the one-shot all-reduce (experimental, klstm_oneshot.hip) did not see every peer in time: the blob was not reduced, the
+    // Update kernels of this rank saw the word and did nothing -- but other ranks may have stepped: the run cannot continue
+    const unsigned z9 = 0u;
+    HIPCHK(hipMemcpy(e->pctrl + 9, &z9, sizeof(z9), hipMemcpyHostToDevice));
+    e->grads_pending = false; e->mmt_pending = false;
+    return fail(KLSTM_ERR_HIP, "one-shot all-reduce timed out (phase %x): a peer did not arrive; the gradient blob was NOT reduced and this "
+                "rank's Update was NOT applied -- replicas may have diverged, stop the run (or use klstm_allreduce_grads)", w[9]);
+  }
+  if (w[2] == 0 && w[6] == 0) { e->nmarks = 0; return KLSTM_OK; }     // (everything enqueued so far has run and is good)
+  return recover(e, w);
+}
+// synchronise + look; KLSTM_OK also when a give-up was found and answered
+static klstm_status settle(klstm_engine *e) {
+  if (!e->persist_dirty) return KLSTM_OK;
   HIPCHK(hipStreamSynchronize(e->stream));
-  drop_graphs(e);
-  return fail(KLSTM_ERR_HIP, "persistent recurrence chain timed out (forward status %x, backward status %x): its workgroups were not "
-              "co-resident; outputs and state of that minibatch are invalid, its Update was NOT applied (the update kernels read "
-              "the status words), the engine falls back to one launch per step", w[2], w[6]);
+  const klstm_status st = check_persist(e);
+  return st == KLSTM_RECOVERED ? KLSTM_OK : st;
 }
 
 // Early notice without a synchronisation: the kernels set a host-mapped word when they give up.  Called at the head of
-// propagate / backpropagate / update; what it reports belongs to an EARLIER call (launches are asynchronous).
+// propagate / backpropagate / update / reset; what it finds belongs to an EARLIER call (launches are asynchronous).
 static klstm_status poll_persist(klstm_engine *e) {
   if (!e->pstat_host || !*reinterpret_cast<volatile unsigned *>(e->pstat_host)) return KLSTM_OK;
-  HIPCHK(hipStreamSynchronize(e->stream));
   e->persist_dirty = true;
-  return check_persist(e);
+  return settle(e);
 }
 
 static klstm_status ensure_packs(klstm_engine *e) {
@@ -337,11 +458,18 @@ static klstm_status ensure_fold(klstm_engine *e, bool need_x) {
   }
   const bool pack_x = need_x && !e->foldx_fresh;
   if (!e->fold_dirty && !pack_x) return KLSTM_OK;
-  if (!e->fold_scratch && fold_bf16x3_supported(d)) HIPCHK(hipMalloc(&e->fold_scratch, fold_bf16x3_scratch_bytes(d)));
-  const bool f3 = e->fold_scratch && fold_bf16x3_supported(d);
+  if (e->fold_mode == 2 && redo_count(REDO_FOLD) != 0) {
+    // range guard (klstm_math.h): a parameter passed the fp16 range -- the product was recomputed in fp32 where it mattered; from
+    // here on three bf16 planes (fp32 range, six products instead of three), engines of this process alike
+    e->fold_mode = 1; e->planes_fresh = false;
+    if (e->use_graph) { HIPCHK(hipStreamSynchronize(e->stream)); drop_graphs(e); }
+    note("fold product: a parameter beyond the fp16 range (65504) was met; the product runs on three bf16 planes from now on");
+  }
+  if (!e->fold_scratch && fold_bf16x3_supported(d, e->fold_mode)) HIPCHK(hipMalloc(&e->fold_scratch, fold_bf16x3_scratch_bytes(d)));
+  const bool f3 = e->fold_scratch && fold_bf16x3_supported(d, e->fold_mode);
   HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, pack_x, e->stream, probe(e, "k_fold"),
                      pack_x ? probe(e, "k_pack_foldx") : LaunchProbe(), f3 ? e->fold_scratch : nullptr,
-                     f3 ? probe(e, "k_split3") : LaunchProbe(), f3 && e->planes_fresh));
+                     f3 ? probe(e, "k_split3") : LaunchProbe(), f3 && e->planes_fresh, e->fold_mode));
   if (pack_x) e->foldx_fresh = true;
   e->fold_dirty = false;
   return KLSTM_OK;
@@ -370,6 +498,7 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
   HIPCHK(hipSetDevice(device));
   klstm_engine *e = new klstm_engine();
   e->ncu = prop.multiProcessorCount;
+  e->fold_mode = fold_default_mode();
   e->I = input_dim; e->C = cell_dim; e->R = recur_dim; e->S = num_stream; e->device = device;
   e->nparams = e->o_wm() + (long)e->R * e->C;
   if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
@@ -404,8 +533,10 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
   alloc0(&e->wrT, (size_t)4 * e->C * e->R * sizeof(float));
   alloc0(&e->wmT, (size_t)e->R * e->C * sizeof(float));
   alloc0(&e->wxT, (size_t)4 * e->C * e->I * sizeof(float));
-  alloc0(&e->prev_c, (size_t)e->S * e->C * sizeof(float));
-  alloc0(&e->prev_r, (size_t)e->S * e->R * sizeof(float));
+  for (int b = 0; b < 2; b++) {
+    alloc0(&e->prev_c[b], (size_t)e->S * e->C * sizeof(float));
+    alloc0(&e->prev_r[b], (size_t)e->S * e->R * sizeof(float));
+  }
   {
     const Dims d{e->I, e->C, e->R, e->S, 0};
     if (pack_supported(d)) {
@@ -417,19 +548,21 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
   if (st == KLSTM_OK && hipMalloc(&e->flags_dev, (size_t)e->S * sizeof(int)) != hipSuccess)
     st = fail(KLSTM_ERR_HIP, "hipMalloc(flags) failed");
   if (st != KLSTM_OK) { klstm_destroy(e); return st; }
+  { std::lock_guard<std::mutex> lk(g_engines_mu); g_engines.insert(e); }
   *out = e;
   return KLSTM_OK;
 }
 
 void klstm_destroy(klstm_engine *e) {
   if (!e) return;
+  { std::lock_guard<std::mutex> lk(g_engines_mu); g_engines.erase(e); }
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   drop_graphs(e);
   for (auto &r : e->probes) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
   free_planes(e);
-  float *ps[] = {e->params, e->grads_own ? e->grads_own : e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c, e->prev_r, e->pk[0], e->pk[1], e->pk[2], e->pk[3],
+  float *ps[] = {e->params, e->grads_own ? e->grads_own : e->grads, e->corr, e->wrT, e->wmT, e->wxT, e->prev_c[0], e->prev_c[1], e->prev_r[0], e->prev_r[1], e->pk[0], e->pk[1], e->pk[2], e->pk[3],
                  e->pk_fold[0], e->pk_fold[1]};
   for (float *p : ps) if (p) (void)hipFree(p);
   if (e->flags_dev) (void)hipFree(e->flags_dev);
@@ -471,9 +604,12 @@ static klstm_status blob_h2d(klstm_engine *e, float *dst, const float *src) {
 static klstm_status blob_d2h(klstm_engine *e, float *dst, const float *src) {
   if (!e || !dst) return fail(KLSTM_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipMemcpyAsync(dst, src, (size_t)e->nparams * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return check_persist(e);
+  for (;;) {
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)e->nparams * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const klstm_status st = check_persist(e);
+    if (st != KLSTM_RECOVERED) return st;              // (a give-up was answered just now: what was copied is older than that)
+  }
 }
 
 klstm_status klstm_set_params_host(klstm_engine *e, const float *flat) {
@@ -503,37 +639,51 @@ klstm_status klstm_reset(klstm_engine *e, const int *flags, int n) {
   if (!e || !flags) return fail(KLSTM_ERR_ARG, "klstm_reset: null argument");
   if (n != e->S) return fail(KLSTM_ERR_SHAPE, "klstm_reset: %d flags for %d streams", n, e->S);
   HIPCHK(hipSetDevice(e->device));
-  // zero contiguous runs of flagged streams (the reference issues one SetZero per stream, :215-219)
-  int s = 0;
-  while (s < n) {
-    if (flags[s] != 1) { s++; continue; }
-    int s1 = s;
-    while (s1 < n && flags[s1] == 1) s1++;
-    HIPCHK(hipMemsetAsync(e->prev_c + (size_t)s * e->C, 0, (size_t)(s1 - s) * e->C * sizeof(float), e->stream));
-    HIPCHK(hipMemsetAsync(e->prev_r + (size_t)s * e->R, 0, (size_t)(s1 - s) * e->R * sizeof(float), e->stream));
-    s = s1;
-  }
-  return KLSTM_OK;
+  e->rec = MbRec();                                   // a new minibatch begins: the previous one's buffers are the caller's again
+  { klstm_status ps = poll_persist(e); if (ps != KLSTM_OK) return ps; }
+  const std::vector<int> f(flags, flags + n);
+  if (e->resets.empty()) e->resets = f;
+  else for (int s = 0; s < n; s++) if (f[s] == 1) e->resets[s] = 1;
+  return apply_reset(e, f);
 }
 
 klstm_status klstm_get_state_host(klstm_engine *e, float *c, float *r) {
   if (!e || !c || !r) return fail(KLSTM_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipMemcpyAsync(c, e->prev_c, (size_t)e->S * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(r, e->prev_r, (size_t)e->S * e->R * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  { klstm_status ss = settle(e); if (ss != KLSTM_OK) return ss; }       // (which buffer is current depends on it)
+  HIPCHK(hipMemcpyAsync(c, e->prev_c[e->sp], (size_t)e->S * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(r, e->prev_r[e->sp], (size_t)e->S * e->R * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return KLSTM_OK;
 }
 klstm_status klstm_set_state_host(klstm_engine *e, const float *c, const float *r) {
   if (!e || !c || !r) return fail(KLSTM_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipMemcpyAsync(e->prev_c, c, (size_t)e->S * e->C * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->prev_r, r, (size_t)e->S * e->R * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  { klstm_status ss = settle(e); if (ss != KLSTM_OK) return ss; }
+  HIPCHK(hipMemcpyAsync(e->prev_c[e->sp], c, (size_t)e->S * e->C * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->prev_r[e->sp], r, (size_t)e->S * e->R * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->resets.clear();                                  // (the state is what the caller says, whatever was reset before)
   return KLSTM_OK;
 }
 
 }  // extern "C"
+
+// Reset (...streams.h:212-220) on the CURRENT state buffer: zero contiguous runs of flagged streams (the reference issues one
+// SetZero per stream, :215-219)
+static klstm_status apply_reset(klstm_engine *e, const std::vector<int> &flags) {
+  const int n = (int)flags.size();
+  int s = 0;
+  while (s < n) {
+    if (flags[s] != 1) { s++; continue; }
+    int s1 = s;
+    while (s1 < n && flags[s1] == 1) s1++;
+    HIPCHK(hipMemsetAsync(e->prev_c[e->sp] + (size_t)s * e->C, 0, (size_t)(s1 - s) * e->C * sizeof(float), e->stream));
+    HIPCHK(hipMemsetAsync(e->prev_r[e->sp] + (size_t)s * e->R, 0, (size_t)(s1 - s) * e->R * sizeof(float), e->stream));
+    s = s1;
+  }
+  return KLSTM_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // launch sequences
@@ -544,7 +694,8 @@ static FwdPtrs fwd_ptrs(klstm_engine *e) {
   p.pi = e->params + e->o_pi(); p.pf = e->params + e->o_pf(); p.po = e->params + e->o_po();
   p.wm = e->params + e->o_wm();
   p.gifo = e->gifo; p.cc = e->cc; p.hh = e->hh; p.mm = e->mm; p.rr = e->rr;
-  p.prev_c = e->prev_c; p.prev_r = e->prev_r;
+  p.prev_c = e->prev_c[e->sp]; p.prev_r = e->prev_r[e->sp];
+  p.next_c = e->prev_c[e->sp ^ 1]; p.next_r = e->prev_r[e->sp ^ 1];
   p.pk_gates = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[0]) : nullptr;
   p.pk_proj = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[1]) : nullptr;
   p.pk_fold = reinterpret_cast<const float4 *>(e->pk_fold[0]);
@@ -691,23 +842,18 @@ static klstm_status run_graphed(klstm_engine *e, const klstm_engine::Key &key, F
 
 extern "C" {
 
-klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_stride, float *out, int out_stride) {
-  if (!e || ((!in || !out) && rows != 0)) return fail(KLSTM_ERR_ARG, "klstm_propagate: null argument");
-  if (rows < 0 || rows % e->S != 0)
-    return fail(KLSTM_ERR_SHAPE, "klstm_propagate: rows (%d) %% num_stream (%d) != 0", rows, e->S);
-  if (rows == 0) {          // T = 0: the reference's loops simply do not run (:261, :328 with zero rows); state is unchanged
-    e->T_fwd = 0;
-    e->T_bwd = -1;
-    return KLSTM_OK;
-  }
-  HIPCHK(hipSetDevice(e->device));
-  { klstm_status ps = poll_persist(e); if (ps != KLSTM_OK) return ps; }
-  { klstm_status gs = flush_grads(e); if (gs != KLSTM_OK) return gs; }   // (deferred gradient products read the planes of the last minibatch)
-  if (in_stride < e->I || out_stride < e->R) return fail(KLSTM_ERR_ARG, "klstm_propagate: stride smaller than row width");
+}  // extern "C"
+
+// The body of klstm_propagate (arguments checked by the caller): also what recover() runs a minibatch again with.
+static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int in_stride, float *out, int out_stride) {
   const int T = rows / e->S;
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
   e->fwd_persist = persist_wanted(e, T);
+  if (!e->replaying && e->cooldown > 0) e->cooldown--;       // (counted in minibatches that ran on the launch-per-step chain)
+  // launch-per-step kernels are not guarded on the device: nothing of them may be queued behind a persistent launch that
+  // nobody has looked at yet
+  if (!e->fwd_persist && (st = settle(e)) != KLSTM_OK) return st;
   e->bwd_persist = e->fwd_persist && persist_bwd_wanted(e, T);
   e->fwd_folded = e->fwd_persist || fold_wanted(e, T);
   if (e->fwd_persist && (st = ensure_persist(e)) != KLSTM_OK) return st;
@@ -719,13 +865,77 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
     HIPCHK(launch_pack(d0, e->params, e->wrT, e->wmT, e->wxT, e->pk, 1, e->use_bf16, e->stream, probe(e, "k_pack")));
     e->pk_stale &= ~1;
   }
-  klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, e->fwd_persist ? -3 : e->fwd_folded ? -2 : -1);
+  klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, (e->fwd_persist ? -3 : e->fwd_folded ? -2 : -1) * 2 - e->sp);
   st = run_graphed(e, key, [&]() { return seq_forward(e, in, in_stride, out, out_stride, T); },
                    e->fwd_persist && persist_r_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, e->popt));
   if (st != KLSTM_OK) return st;
+  if (e->fwd_persist) {                               // (counted here, not inside the launch sequence: a graph replay is a launch too)
+    e->pseq++;
+    e->persist_dirty = true;
+    if (e->nmarks == 8) { for (int i = 1; i < 8; i++) e->marks[i - 1] = e->marks[i]; e->nmarks = 7; }
+    e->marks[e->nmarks++] = klstm_engine::FwdMark{e->pseq, e->sp};
+  }
+  e->sp ^= 1;                                         // c(T), r(T) were written to the other buffer: it is the carried state now
+  e->resets.clear();
   e->T_fwd = T;
   e->T_bwd = -1;
   return KLSTM_OK;
+}
+
+static klstm_status do_backpropagate(klstm_engine *e, const float *in, int in_stride, const float *out_diff, int out_diff_stride,
+                                     float *in_diff, int in_diff_stride, int rows, float momentum, int flags) {
+  (void)rows;
+  const int T = e->T_fwd;
+  klstm_status st;
+  if (!e->bwd_persist && (st = settle(e)) != KLSTM_OK) return st;     // (unguarded step kernels read the forward launch's planes)
+  if (e->fwd_folded) { klstm_status fs = ensure_fold(e, !e->fwd_persist); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
+  klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
+                        flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0));
+  // (one or two launches: the persistent kernel with P and the tail inside, plus at most the gradient products)
+  const bool bwd_short = e->bwd_persist && persist_p_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, e->popt) &&
+                         persist_tail_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, in_diff != nullptr, e->popt) && e->persist_tail != 0;
+  st = run_graphed(e, key, [&]() {
+    return seq_backward(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, T, momentum, flags);
+  }, bwd_short);
+  if (st != KLSTM_OK) return st;
+  if (e->bwd_persist) { e->pseq++; e->persist_dirty = true; }
+  e->T_bwd = T;
+  if (grads_fusable(e, T, flags, e->fwd_folded ? false : e->use_bf16)) {
+    e->grads_pending = true;
+    e->gp_in = in; e->gp_in_stride = in_stride; e->gp_T = T; e->gp_mmt = momentum; e->gp_bf16 = e->fwd_folded ? false : e->use_bf16;
+  }
+  return KLSTM_OK;
+}
+
+// persist_verify: the call waits for its persistent launch and answers a give-up before it returns
+static klstm_status verify_now(klstm_engine *e) {
+  if (!e->persist_verify || !e->persist_dirty) return KLSTM_OK;
+  return settle(e);
+}
+
+extern "C" {
+
+klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_stride, float *out, int out_stride) {
+  if (!e || ((!in || !out) && rows != 0)) return fail(KLSTM_ERR_ARG, "klstm_propagate: null argument");
+  if (rows < 0 || rows % e->S != 0)
+    return fail(KLSTM_ERR_SHAPE, "klstm_propagate: rows (%d) %% num_stream (%d) != 0", rows, e->S);
+  if (rows == 0) {          // T = 0: the reference's loops simply do not run (:261, :328 with zero rows); state is unchanged
+    e->T_fwd = 0;
+    e->T_bwd = -1;
+    return KLSTM_OK;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  e->rec = MbRec();                                   // a new minibatch begins: the previous one's buffers are the caller's again
+  { klstm_status ps = poll_persist(e); if (ps != KLSTM_OK) return ps; }
+  { klstm_status gs = flush_grads(e); if (gs != KLSTM_OK) return gs; }   // (deferred gradient products read the planes of the last minibatch)
+  if (in_stride < e->I || out_stride < e->R) return fail(KLSTM_ERR_ARG, "klstm_propagate: stride smaller than row width");
+  const int sp0 = e->sp;
+  klstm_status st = do_propagate(e, in, rows, in_stride, out, out_stride);
+  if (st != KLSTM_OK) return st;
+  MbRec &r = e->rec;
+  r.have_fwd = true; r.fwd_seq = e->fwd_persist ? e->pseq : 0; r.sp_before = sp0;
+  r.in = in; r.rows = rows; r.in_stride = in_stride; r.out = out; r.out_stride = out_stride;
+  return verify_now(e);
 }
 
 klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride, const float *out_diff,
@@ -750,23 +960,13 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
     e->T_bwd = 0;
     return KLSTM_OK;
   }
-  const int T = e->T_fwd;
-  if (e->fwd_folded) { klstm_status fs = ensure_fold(e, !e->fwd_persist); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
-  klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
-                        flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0));
-  // (one or two launches: the persistent kernel with P and the tail inside, plus at most the gradient products)
-  const bool bwd_short = e->bwd_persist && persist_p_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, e->popt) &&
-                         persist_tail_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, in_diff != nullptr, e->popt) && e->persist_tail != 0;
-  klstm_status st = run_graphed(e, key, [&]() {
-    return seq_backward(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, T, momentum, flags);
-  }, bwd_short);
+  klstm_status st = do_backpropagate(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, rows, momentum, flags);
   if (st != KLSTM_OK) return st;
-  e->T_bwd = T;
-  if (grads_fusable(e, T, flags, e->fwd_folded ? false : e->use_bf16)) {
-    e->grads_pending = true;
-    e->gp_in = in; e->gp_in_stride = in_stride; e->gp_T = T; e->gp_mmt = momentum; e->gp_bf16 = e->fwd_folded ? false : e->use_bf16;
-  }
-  return KLSTM_OK;
+  MbRec &r = e->rec;
+  r.have_bwd = true; r.bwd_seq = e->bwd_persist ? e->pseq : 0;
+  r.bin = in; r.bin_stride = in_stride; r.od = out_diff; r.od_stride = out_diff_stride; r.idf = in_diff; r.id_stride = in_diff_stride;
+  r.mmt = momentum; r.flags = flags;
+  return verify_now(e);
 }
 
 // ---- host-matrix variants: stage through dense device buffers, run the device path, copy back ----
@@ -804,6 +1004,7 @@ klstm_status klstm_propagate_host(klstm_engine *e, const float *in, int rows, in
   if (st != KLSTM_OK) return st;
   if ((st = copy_rows(e, e->stage[0], e->I, in, in_stride, e->I, rows, hipMemcpyHostToDevice)) != KLSTM_OK) return st;
   if ((st = klstm_propagate(e, e->stage[0], rows, e->I, e->stage[1], e->R)) != KLSTM_OK) return st;
+  if ((st = settle(e)) != KLSTM_OK) return st;        // (the staged rows are still in place: a give-up is answered before anything is copied back)
   if ((st = copy_rows(e, out, out_stride, e->stage[1], e->R, e->R, rows, hipMemcpyDeviceToHost)) != KLSTM_OK) return st;
   HIPCHK(hipStreamSynchronize(e->stream));
   return KLSTM_OK;
@@ -825,6 +1026,7 @@ klstm_status klstm_backpropagate_host(klstm_engine *e, const float *in, int in_s
   if ((st = copy_rows(e, e->stage[2], e->R, out_diff, out_diff_stride, e->R, rows, hipMemcpyHostToDevice)) != KLSTM_OK) return st;
   st = klstm_backpropagate(e, e->stage[0], e->I, e->stage[2], e->R, in_diff ? e->stage[3] : nullptr, e->I, rows, momentum, flags);
   if (st != KLSTM_OK) return st;
+  if ((st = settle(e)) != KLSTM_OK) return st;
   if (in_diff && (st = copy_rows(e, in_diff, in_diff_stride, e->stage[3], e->I, e->I, rows, hipMemcpyDeviceToHost)) != KLSTM_OK) return st;
   HIPCHK(hipStreamSynchronize(e->stream));
   return KLSTM_OK;
@@ -842,10 +1044,8 @@ klstm_status klstm_apply_momentum(klstm_engine *e, float momentum) {
   return KLSTM_OK;
 }
 
-klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
-  if (!e) return fail(KLSTM_ERR_ARG, "null engine");
-  HIPCHK(hipSetDevice(e->device));
-  { klstm_status ps = poll_persist(e); if (ps != KLSTM_OK) return ps; }
+}  // extern "C"
+static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
   // theta -= lr * corr, and the transposed copies the BPTT kernels read are refreshed in the same pass
   if (e->grads_pending) {
@@ -853,8 +1053,8 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
     e->grads_pending = false;
     const Dims dg{e->I, e->C, e->R, e->S, e->gp_T};
     GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
-    e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d);
-    if (e->planes_fresh) { fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane); u.split_mode = fold_split_mode(); }
+    e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d, e->fold_mode);
+    if (e->planes_fresh) { fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane); u.split_mode = e->fold_mode == 2 ? 2 : 1; }
     HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
                         probe(e, "k_grads_update"), false, &u, e->pctrl));
   } else {
@@ -862,9 +1062,9 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
     e->mmt_pending = false;
     // (data-parallel order: gradient -> all-reduce -> this) the planes of the fold operands come out of the same pass
     GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
-    e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d) &&
+    e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d, e->fold_mode) &&
                       update_repack_vectorised(d, e->params, e->corr, fold_grad, e->wrT, e->wmT, e->wxT);
-    if (e->planes_fresh) { fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane); u.split_mode = fold_split_mode(); }
+    if (e->planes_fresh) { fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane); u.split_mode = e->fold_mode == 2 ? 2 : 1; }
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
                                 e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr));
   }
@@ -881,11 +1081,26 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
   return KLSTM_OK;
 }
 
+extern "C" {
+klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
+  if (!e) return fail(KLSTM_ERR_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  { klstm_status ps = poll_persist(e); if (ps != KLSTM_OK) return ps; }
+  const klstm_status st = do_update(e, learn_rate, clip_grad);
+  if (st != KLSTM_OK) return st;
+  e->rec.have_upd = true; e->rec.lr = learn_rate; e->rec.clip = clip_grad;
+  return KLSTM_OK;
+}
+
 klstm_status klstm_synchronize(klstm_engine *e) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return check_persist(e);
+  for (;;) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const klstm_status st = check_persist(e);
+    if (st != KLSTM_RECOVERED) return st;              // (answered a give-up: wait for what that enqueued)
+    e->persist_dirty = false;
+  }
 }
 
 klstm_status klstm_get_activations_host(klstm_engine *e, int which, float *dst) {
@@ -894,7 +1109,7 @@ klstm_status klstm_get_activations_host(klstm_engine *e, int which, float *dst) 
   if (T < 0) return fail(KLSTM_ERR_STATE, "klstm_get_activations_host: nothing has run yet");
   if (T == 0 || !e->gifo) { memset(dst, 0, (size_t)2 * e->S * (7 * e->C + e->R) * sizeof(float)); return KLSTM_OK; }
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  { klstm_status ss = klstm_synchronize(e); if (ss != KLSTM_OK) return ss; }
   const int S = e->S, C = e->C, R = e->R, W = 7 * C + R;
   const size_t nrows = (size_t)(T + 2) * S;
   memset(dst, 0, nrows * W * sizeof(float));
@@ -976,7 +1191,8 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
   if (!strncmp(key, "persist", 7) && strcmp(key, "persist_tail")) {
     // "persist": -1 auto, 0 off, 1 forward launch only, 2 both directions whenever the shape allows.  The rest are knobs of
     // THIS engine's persistent launches (kernel arguments and geometry): A-B experiments and tests.
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipSetDevice(e->device));
+    { klstm_status ss = klstm_synchronize(e); if (ss != KLSTM_OK) return ss; }
     drop_graphs(e);                                 // captured launches bake geometry and kernel arguments
     if (!strcmp(key, "persist")) e->use_persist = value;
     else if (!strcmp(key, "persist_tpw")) e->popt.tpw = value;
@@ -989,6 +1205,8 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else if (!strcmp(key, "persist_test_stall_fwd")) e->popt.test_stall_fwd = value;            // test hooks: force the timeout path
     else if (!strcmp(key, "persist_test_stall_bwd")) e->popt.test_stall_bwd = value;
     else if (!strcmp(key, "persist_ncu")) e->ncu = value;                                       // test hook: pretend the device has this many CUs
+    else if (!strcmp(key, "persist_verify")) e->persist_verify = value != 0;
+    else if (!strcmp(key, "persist_cooldown")) { e->cooldown_len = value < 0 ? 0 : value; if (e->cooldown > e->cooldown_len) e->cooldown = e->cooldown_len; }
     else return fail(KLSTM_ERR_ARG, "klstm_set_option: unknown key '%s'", key);
     return KLSTM_OK;
   }
@@ -998,53 +1216,56 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     e->persist_tail = value;
     return KLSTM_OK;
   }
-  if (!strcmp(key, "direct_nt_shape")) {         // value = 10*NI + waves (A-B; process-wide)
-    HIPCHK(hipStreamSynchronize(e->stream));
-    drop_graphs(e);
+  // Process-wide knobs (which kernel a product runs on; A-B experiments and tests): the cached graphs of EVERY live engine hold
+  // the old kernels, so all of them are dropped (knob_changed_everywhere), not only this engine's.
+  if (!strcmp(key, "direct_nt_shape")) {         // value = 10*NI + waves
     set_direct_nt_shape(value / 10, value % 10);
+    knob_changed_everywhere();
+    HIPCHK(hipSetDevice(e->device));
     return KLSTM_OK;
   }
-  if (!strcmp(key, "skinny_f16_pair")) {         // 0: d_r / in_diff of the folded BPTT tail on the tiled split-K kernel (A-B; process-wide)
-    HIPCHK(hipStreamSynchronize(e->stream));
-    drop_graphs(e);
+  if (!strcmp(key, "skinny_f16_pair")) {         // 0: d_r / in_diff of the folded BPTT tail on the tiled split-K kernel
     set_skinny_f16_pair(value);
+    knob_changed_everywhere();
+    HIPCHK(hipSetDevice(e->device));
     return KLSTM_OK;
   }
-  if (!strcmp(key, "skinny_f16")) {              // 0: in_diff of a wide layer on the fp32 MFMA kernel (A-B; process-wide)
-    HIPCHK(hipStreamSynchronize(e->stream));
-    drop_graphs(e);                                // (the two-job launch of the BPTT tail looks at it too)
+  if (!strcmp(key, "skinny_f16")) {              // 0: in_diff of a wide layer on the fp32 MFMA kernel (the two-job launch of the BPTT tail looks at it too)
     set_skinny_f16(value);
+    knob_changed_everywhere();
+    HIPCHK(hipSetDevice(e->device));
     return KLSTM_OK;
   }
-  if (!strcmp(key, "outer_f16")) {               // 0: the wide gradient product on the fp32 tile kernel (A-B; process-wide)
+  if (!strcmp(key, "outer_f16")) {               // 0: the wide gradient product on the fp32 tile kernel
     set_outer_f16(value);
+    knob_changed_everywhere();
+    HIPCHK(hipSetDevice(e->device));
     return KLSTM_OK;
   }
-  if (!strcmp(key, "fold_direct")) {             // 0: the fold product on the generic 64x64-tile kernel (A-B; process-wide)
-    HIPCHK(hipStreamSynchronize(e->stream));
-    drop_graphs(e);
+  if (!strcmp(key, "fold_direct")) {             // 0: the fold product on the generic 64x64-tile kernel
     set_fold_direct(value);
-    e->fold_dirty = true;
+    knob_changed_everywhere(-1);
+    { std::lock_guard<std::mutex> lk(g_engines_mu); for (klstm_engine *x : g_engines) x->fold_dirty = true; }
+    HIPCHK(hipSetDevice(e->device));
     return KLSTM_OK;
   }
-  if (!strcmp(key, "fold_bf16x3")) {             // 0: the fold product on the fp32 MFMA (klstm_fold.hip) (A-B; process-wide)
+  if (!strcmp(key, "fold_bf16x3")) {             // the fold product of THIS engine: 0 fp32 MFMA (klstm_fold.hip), 1 three bf16 planes, 2 two fp16 planes
+    HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
-    set_fold_bf16x3(value);                   // 1: bf16 x 3 planes, 2: fp16 x 2 planes (the planes at hand are in the other format)
+    e->fold_mode = value < 0 ? 0 : value > 2 ? 2 : value;   // (the planes at hand are in another format)
     e->planes_fresh = false;
     e->fold_dirty = true;
     return KLSTM_OK;
   }
-  if (!strcmp(key, "fp16_products")) {           // 0: nothing runs on fp16 planes (values beyond 65504: klstm.h); 1: the defaults again.  Process-wide
-    HIPCHK(hipStreamSynchronize(e->stream));
-    drop_graphs(e);
+  if (!strcmp(key, "fp16_products")) {           // 0: nothing runs on fp16 planes; 1: the defaults again (and the range guard's counters cleared).  Process-wide
     set_fold_bf16x3(value ? 2 : 1);           // (the fold product keeps the matrix cores: three bf16 planes have the fp32 range)
-    e->planes_fresh = false;
-    e->fold_dirty = true;
-    if (value) set_direct_nt_shape(2, 1); else set_direct_nt_shape(0, 0);
+    if (value) { set_direct_nt_shape(2, 1); redo_clear(); } else set_direct_nt_shape(0, 0);
     set_outer_f16(value ? 1 : 0);
     set_skinny_f16(value ? 1 : 0);
     set_skinny_f16_pair(value ? 1 : 0);
+    knob_changed_everywhere(value ? 2 : 1);
+    HIPCHK(hipSetDevice(e->device));
     return KLSTM_OK;
   }
   if (!strcmp(key, "fuse_x")) {
@@ -1068,7 +1289,19 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
 klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *total_us, long *launches) {
   if (!e || !kernel || !total_us || !launches) return fail(KLSTM_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  { klstm_status ss = klstm_synchronize(e); if (ss != KLSTM_OK) return ss; }
+  // event counters (no option needed): give-ups of the persistent chain and what became of them; range-guard events of the fp16-plane products
+  {
+    const struct { const char *name; long v; } ctr[] = {
+        {"persist_giveups", e->n_giveups}, {"persist_replayed", e->n_replayed}, {"persist_dropped", e->n_dropped},
+        {"persist_launches", (long)e->pseq}, {"persist_cooldown", (long)e->cooldown},
+        {"fp16_redo", (long)redo_count(REDO_FOLD) + redo_count(REDO_NT) + redo_count(REDO_OUTER) + redo_count(REDO_SKINNY)},
+        {"fp16_redo_fold", (long)redo_count(REDO_FOLD)}, {"fp16_redo_nt", (long)redo_count(REDO_NT)},
+        {"fp16_redo_outer", (long)redo_count(REDO_OUTER)}, {"fp16_redo_skinny", (long)redo_count(REDO_SKINNY)},
+        {"fold_mode", (long)e->fold_mode}};
+    for (const auto &c : ctr)
+      if (!strcmp(kernel, c.name)) { *total_us = 0.0; *launches = c.v; return KLSTM_OK; }
+  }
   for (auto &r : e->probes) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
@@ -1396,6 +1629,10 @@ klstm_status klstm_allreduce_buffer(float *buf_dev, size_t n, void *rccl_comm, v
 klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
+  // A persistent launch of this minibatch that gave up left the gradient products undone (they are guarded): the blob must not
+  // reach the other ranks like that -- they would apply the step, this rank would not.  Look first (a host wait, only while the
+  // persistent chain is in use); a give-up is answered by running the minibatch again, then everybody reduces real gradients.
+  { klstm_status ss = settle(e); if (ss != KLSTM_OK) return ss; }
   { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }     // a pending corr += grads must see the LOCAL sums
   // option "profile": the exposed time of the collective between two events on the engine's stream ("rccl_allreduce")
   const LaunchProbe pr = probe(e, "rccl_allreduce");
@@ -1410,7 +1647,11 @@ klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm) {
 klstm_status klstm_allreduce_grads_oneshot(klstm_engine *e, klstm_oneshot *group, int timeout_ms) {
   if (!e || !group) return fail(KLSTM_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->device));
+  { klstm_status ss = settle(e); if (ss != KLSTM_OK) return ss; }             // (as in klstm_allreduce_grads)
   { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }
+  { klstm_status es = ensure_persist(e); if (es != KLSTM_OK) return es; }     // (the control words: a timeout of the exchange gates this engine's Update)
+  klstm_oneshot_set_abort_words(group, e->pctrl + 9, e->popt.hstat);
+  e->persist_dirty = true;
   const LaunchProbe pr = probe(e, "oneshot_allreduce");
   if (pr.start) HIPCHK(hipEventRecord(pr.start, e->stream));
   const klstm_status st = klstm_oneshot_allreduce(group, e->stream, timeout_ms);

@@ -232,6 +232,7 @@ struct DirectNtArgs {
   const float *B; int ldb;
   float *Cm; int ldc;
   const float *bias;
+  unsigned *redo;         // range guard of the f16 form (k_nt_shared_a16): host-mapped event counter, or null
 };
 
 template <int MI, int NI>
@@ -375,6 +376,7 @@ struct SkinnyNnArgs {
   float *ws; int nks;
   float *Cm; int ldc;
   int rem;                // the first `rem` wave slots (K slice * 4 + wave) take a ninth group of 8 rows
+  unsigned *redo;         // range guard of the f16 form (k_skinny_nn16): host-mapped event counter, or null
 #ifdef KLSTM_SKINNY_TIMING
   long long *dbg;         // per workgroup: shader clocks entry -> loads issued -> MFMAs done -> exit (tools/skinny_probe.hip)
 #endif
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(256) void k_skinny_nn16(SkinnyNnArgs a_, SkinnyNnAr
     for (int mi = 0; mi < MI; mi++) {
       const bool on = kin && 16 * mi + i16 < a.M;
       const sk_f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const sk_f32x4 v0 = on ? ca[mi][0] : z, v1 = on ? ca[mi][1] : z;
+      const sk_f32x4 v0 = (on ? ca[mi][0] : z) * DERIV_SCALE, v1 = (on ? ca[mi][1] : z) * DERIV_SCALE;   // (A is a derivative: klstm_math.h)
       uint4 u1, u2;
       f16_split2_pair(v0[0], v0[1], u1.x, u2.x);
       f16_split2_pair(v0[2], v0[3], u1.y, u2.y);
@@ -663,17 +665,34 @@ __global__ __launch_bounds__(256) void k_skinny_nn16(SkinnyNnArgs a_, SkinnyNnAr
       if (c + 2 < c1) body(c + 2, ra[2], rb[2]);
     }
   }
-  // ---- the four waves' tiles -> one, in wave order; accumulator (mi, cn)[r] = C[16 mi + 4 kg + r][nc + cn] ----
+  // ---- the four waves' tiles -> one, in wave order; accumulator (mi, cn)[r] = C[16 mi + 4 kg + r][nc + cn] over this wave's
+  //      chunks: the two accumulator sets into one, the derivative scale out again ----
   float *mine = part16 + (size_t)wave * (16 * MI) * 64;
+  float probe = 0.f;
 #pragma unroll
   for (int mi = 0; mi < MI; mi++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       sk_f32x4 v;
 #pragma unroll
-      for (int cn = 0; cn < 4; cn++) v[cn] = acc[mi][cn][r] + accx[mi][cn][r] * (1.f / 2048.f);
+      for (int cn = 0; cn < 4; cn++) {
+        v[cn] = (acc[mi][cn][r] + accx[mi][cn][r] * (1.f / 2048.f)) * DERIV_UNSCALE;
+        probe = nonfinite_probe(probe, v[cn]);
+      }
       *reinterpret_cast<sk_f32x4 *>(mine + (16 * mi + 4 * kg + r) * 64 + 4 * i16) = v;
     }
+  // range guard (klstm_math.h): an operand beyond the fp16 range -> the wave's partial tile again in plain fp32, written over its
+  // LDS copy (same wave: the LDS queue keeps the order)
+  if (wave_any(probe != probe)) {
+    redo_note(a.redo);
+    const int k0 = 32 * c0, k1 = min(32 * c1, a.K);
+#pragma unroll 1
+    for (int q = 0; q < MI * 16; q++) {
+      const int mi = q >> 4, cn = (q >> 2) & 3, r = q & 3, m = 16 * mi + 4 * kg + r;
+      mine[m * 64 + 4 * i16 + cn] =
+          (m < a.M && n_in && k1 > k0) ? redo_dot(a.A + (size_t)m * a.lda + k0, 1, a.B + (size_t)k0 * a.ldb + nc + cn, a.ldb, k1 - k0) : 0.f;
+    }
+  }
   __syncthreads();
   float *wp = a.ws + (size_t)g * a.M * a.N;
   for (int q = tid; q < a.M * 16; q += 256) {            // 16 pieces of 16 bytes per row
@@ -710,7 +729,7 @@ static bool skinny_nn_plan(int N, int K, int *nks, int *rem) {
 }
 bool skinny_nn_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *Cm, int ldc) {
   int nks, rem;
-  if (g_skinny16 && g_fold_direct != 0 && M >= 1 && M <= 80 && N % 4 == 0 && N >= 64 && N <= 1024 && K >= 4096 && K % 8 == 0 && lda % 4 == 0 &&
+  if (g_skinny16 && redo_count(REDO_SKINNY) == 0 && g_fold_direct != 0 && M >= 1 && M <= 80 && N % 4 == 0 && N >= 64 && N <= 1024 && K >= 4096 && K % 8 == 0 && lda % 4 == 0 &&
       ldb % 4 == 0 && ldc % 4 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(Cm)) & 15) == 0)
     return true;
   return g_fold_direct != 0 && M >= 1 && M <= 80 && N >= 128 && N % 128 == 0 && N <= 1024 && K >= 4096 && K % 8 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
@@ -726,9 +745,10 @@ size_t skinny_nn_workspace_floats(int M, int N, int K) {
 hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc, float *ws,
                             hipStream_t st) {
   int nks, rem;
-  if (g_skinny16) {
+  if (g_skinny16 && redo_count(REDO_SKINNY) == 0) {
     SkinnyNnArgs a{};
     a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.ws = ws; a.nks = skinny16_groups(N, K); a.Cm = Cm; a.ldc = ldc;
+    a.redo = redo_counters() ? redo_counters() + REDO_SKINNY : nullptr;
     const int mi = (M + 15) / 16;
     const dim3 grid(((N + 63) / 64) * a.nks), block(256);
     const size_t shm = (size_t)4 * 16 * mi * 64 * sizeof(float);
@@ -750,9 +770,9 @@ hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const 
   }
   if (N % 128 != 0 || N < 128 || !skinny_nn_plan(N, K, &nks, &rem)) return hipErrorInvalidValue;
 #ifdef KLSTM_SKINNY_TIMING
-  SkinnyNnArgs a{M, N, K, A, lda, B, ldb, ws, nks, Cm, ldc, rem, g_skinny_dbg};
+  SkinnyNnArgs a{M, N, K, A, lda, B, ldb, ws, nks, Cm, ldc, rem, nullptr, g_skinny_dbg};
 #else
-  SkinnyNnArgs a{M, N, K, A, lda, B, ldb, ws, nks, Cm, ldc, rem};
+  SkinnyNnArgs a{M, N, K, A, lda, B, ldb, ws, nks, Cm, ldc, rem, nullptr};
 #endif
   const int mi = (M + 15) / 16;
   const dim3 grid((N / 128) * a.nks), block(256);
@@ -779,7 +799,7 @@ hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const 
 // DGIFO[1..] W_gifo_x, 80 x 512 over K = 3200 each): partials to ws1 / ws2 as [G][M][N]; the caller's reduction adds the G slices.
 // Returns G (0: not applicable -- the caller keeps its tiled split-K pair).
 int skinny16_pair_groups(int M, int N1, int N2, int K, int max_groups) {
-  if (!g_skinny16 || !g_skinny16_pair || g_fold_direct == 0 || M < 1 || M > 80 || K < 1024 || K % 8 != 0 || N1 % 4 != 0 || N2 % 4 != 0 || N1 < 64 ||
+  if (!g_skinny16 || !g_skinny16_pair || redo_count(REDO_SKINNY) != 0 || g_fold_direct == 0 || M < 1 || M > 80 || K < 1024 || K % 8 != 0 || N1 % 4 != 0 || N2 % 4 != 0 || N1 < 64 ||
       (N2 != 0 && N2 < 64))
     return 0;
   const int nt = (N1 + 63) / 64 + (N2 + 63) / 64, nchunk = (K + 31) / 32;
@@ -793,6 +813,7 @@ hipError_t launch_skinny16_pair(int M, int K, const float *A1, const float *A2, 
                                 float *ws1, float *ws2, int G, hipStream_t st, LaunchProbe pr) {
   SkinnyNnArgs a{}, b{};
   a.M = M; a.N = N1; a.K = K; a.A = A1; a.lda = lda; a.B = B1; a.ldb = N1; a.ws = ws1; a.nks = G;
+  a.redo = redo_counters() ? redo_counters() + REDO_SKINNY : nullptr;
   b = a; b.N = N2 > 0 ? N2 : N1; b.A = A2; b.B = B2; b.ldb = b.N; b.ws = ws2;
   const int nb1 = ((N1 + 63) / 64) * G, nb2 = N2 > 0 ? ((N2 + 63) / 64) * G : 0;
   const int mi = (M + 15) / 16;
@@ -1067,17 +1088,34 @@ __global__ __launch_bounds__(256, 2) void k_nt_shared_a16(DirectNtArgs a) {
       step(c0 + 6, std::integral_constant<int, 6>(), av0, av1);
       step(c0 + 7, std::integral_constant<int, 7>(), av1, av0);
     }
-#pragma unroll
-    for (int mi = 0; mi < NM; mi++) acc[mi] = acc[mi] + accx[mi] * (1.f / 2048.f);
-    if (nbk < 0 || nb >= a.N) return;
-    const float bias = a.bias ? a.bias[nb] : 0.f;
+    float probe = 0.f;
 #pragma unroll
     for (int mi = 0; mi < NM; mi++) {
-      const float e[4] = {acc[mi].x, acc[mi].y, acc[mi].z, acc[mi].w};
+      acc[mi] = acc[mi] + accx[mi] * (1.f / 2048.f);
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int m = 16 * (m_lo + mi) + 4 * kg + r;
-        if (m < a.M) a.Cm[(size_t)m * a.ldc + nb] = e[r] + bias;
+      for (int r = 0; r < 4; r++) probe = nonfinite_probe(probe, acc[mi][r]);
+    }
+    const bool live = nbk >= 0 && nb < a.N;
+    const float bias = (live && a.bias) ? a.bias[nb] : 0.f;
+    if (live) {
+#pragma unroll
+      for (int mi = 0; mi < NM; mi++) {
+        const float e[4] = {acc[mi].x, acc[mi].y, acc[mi].z, acc[mi].w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int m = 16 * (m_lo + mi) + 4 * kg + r;
+          if (m < a.M) a.Cm[(size_t)m * a.ldc + nb] = e[r] + bias;
+        }
+      }
+    }
+    // range guard (klstm_math.h): an input or weight beyond the fp16 range left Inf / NaN in this wave's column block -> the block
+    // again in plain fp32, stored over what went out above (same lane, same address: ordered)
+    if (wave_any(probe != probe)) {
+      redo_note(a.redo);
+#pragma unroll 1
+      for (int q = 0; q < NM * 4; q++) {
+        const int m = 16 * (m_lo + (q >> 2)) + 4 * kg + (q & 3);
+        if (live && m < a.M) a.Cm[(size_t)m * a.ldc + nb] = redo_dot(a.A + (size_t)m * a.lda, 1, a.B + (size_t)nb * a.ldb, 1, a.K) + bias;
       }
     }
   };
@@ -1105,7 +1143,8 @@ hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const 
                             const float *bias, hipStream_t st, LaunchProbe pr) {
 #define KS_LAUNCH(MI_) do { if (pr.start) hipExtLaunchKernelGGL((k_direct_nt_ks<MI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
                             else hipLaunchKernelGGL((k_direct_nt_ks<MI_>), grid, block, 0, st, a); } while (0)
-  DirectNtArgs a{M, N, K, A, lda, B, ldb, Cm, ldc, bias};
+  DirectNtArgs a{M, N, K, A, lda, B, ldb, Cm, ldc, bias, redo_counters() ? redo_counters() + REDO_NT : nullptr};
+  const bool f16_ok = redo_count(REDO_NT) == 0;          // (once the range guard has fired, wide results stay on the fp32 form)
   if (N <= 8192 && K % (4 * 32 * FD) == 0) {                 // narrow result: K split over the four waves of a workgroup
     const dim3 grid((N + 15) / 16), block(256);
     switch ((M + 15) / 16) {
@@ -1129,9 +1168,9 @@ hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const 
   if (N > 8192 && K % 256 == 0 && g_nt_shared) {
     const int nbt = (N + 15) / 16, mi_ = (M + 15) / 16;
     int wgs = (nbt + 3) / 4;
-    if (g_nt_shared == 2 && wgs > 256 && (nbt - 1024) * mi_ <= 1024) wgs = 256;      // the blocks past 1024 go out as extra (block, row block) units
+    if ((g_nt_shared == 2 || !f16_ok) && wgs > 256 && (nbt - 1024) * mi_ <= 1024) wgs = 256;      // the blocks past 1024 go out as extra (block, row block) units
     const dim3 grid(wgs), block(256);
-#define SA_GO(MI_) do { if (g_nt_shared != 2) { if (pr.start) hipExtLaunchKernelGGL((k_nt_shared_a16<MI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
+#define SA_GO(MI_) do { if (g_nt_shared != 2 && f16_ok) { if (pr.start) hipExtLaunchKernelGGL((k_nt_shared_a16<MI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
                                                 else hipLaunchKernelGGL((k_nt_shared_a16<MI_>), grid, block, 0, st, a); } \
                         else if (pr.start) hipExtLaunchKernelGGL((k_nt_shared_a<MI_>), grid, block, 0, st, pr.start, pr.stop, 0, a); \
                         else hipLaunchKernelGGL((k_nt_shared_a<MI_>), grid, block, 0, st, a); } while (0)

@@ -39,6 +39,9 @@
 
 #include <hip/hip_ext.h>
 
+#include <cstring>
+#include <mutex>
+
 namespace klstm {
 
 #pragma clang fp contract(off)
@@ -80,6 +83,8 @@ __global__ __launch_bounds__(256) void k_split3(Split3Args a) {
 
 struct Fold3Args {
   int C, R;
+  const float *wr, *wmT;      // the fp32 operands themselves (W_gifo_r [4C x R], W_r_m^T [C x R]): the range guard's redo path reads them
+  unsigned *redo;             // host-mapped event counter of that path (or null)
   const unsigned short *a3;   // W_gifo_r split: [3][4C x R] bf16, rows in g,i,f,o blocks of C
   const unsigned short *b3;   // W_r_m^T split:  [3][C x R]
   size_t a_plane, b_plane;
@@ -264,6 +269,28 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
       for (int ni = 0; ni < NI; ni++)
         *reinterpret_cast<float4 *>(cs + (16 * ni + i16) * FLD + 16 * mi + 4 * kg) =
             make_float4(acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w);
+    if constexpr (NPL == 2) {
+      // range guard (klstm_math.h): a parameter beyond the fp16 range left Inf / NaN in this wave's tile -> the tile again in plain
+      // fp32 from the fp32 matrices, written over the transpose buffer (same wave: the LDS queue keeps the order; no barrier in
+      // here, the other waves go on to the workgroup barrier below)
+      float probe = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) probe = nonfinite_probe(probe, acc[mi][ni][r]);
+      if (wave_any(probe != probe)) {
+        redo_note(a.redo);
+#pragma unroll 1
+        for (int q = 0; q < MI * NI * 4; q++) {
+          const int mi = q / (NI * 4), ni = (q >> 2) % NI, r = q & 3;
+          const int n = n0 + 16 * ni + i16, x = m0 + 16 * mi + 4 * kg + r;   // x: logical row 4*cell + gate
+          cs[(16 * ni + i16) * FLD + 16 * mi + 4 * kg + r] =
+              ((x >> 2) < C && n < C) ? redo_dot(a.wr + ((size_t)(x & 3) * C + (x >> 2)) * R, 1, a.wmT + (size_t)n * R, 1, R) : 0.f;
+        }
+      }
+    }
   }
   if (LW) __syncthreads();                                             // with loader waves the two packed operands are written by different waves
   else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -303,10 +330,30 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
 #ifdef KLSTM_FOLD3_TIMING
 static long long *g_fold3_dbg = nullptr;
 #endif
-static int g_fold_bf16x3 = 2;      // 0: fp32 MFMA kernel (klstm_fold.hip), 1: bf16 x 3, 2: fp16 x 2
-void set_fold_bf16x3(int v) { g_fold_bf16x3 = v; }
-int fold_split_mode() { return g_fold_bf16x3 == 2 ? 2 : 1; }
-bool fold_bf16x3_supported(const Dims &d) { return g_fold_bf16x3 != 0 && d.C % 4 == 0 && d.R % 32 == 0; }
+static int g_fold_bf16x3 = 2;      // default mode of new engines: 0: fp32 MFMA kernel (klstm_fold.hip), 1: bf16 x 3, 2: fp16 x 2
+void set_fold_bf16x3(int v) { g_fold_bf16x3 = v < 0 ? 0 : v > 2 ? 2 : v; }
+int fold_default_mode() { return g_fold_bf16x3; }
+bool fold_bf16x3_supported(const Dims &d, int mode) { return mode != 0 && d.C % 4 == 0 && d.R % 32 == 0; }
+
+// ---- event counters of the range guard (klstm_kernels.h): REDO_WORDS host-mapped words, portable across devices ----
+static unsigned *g_redo_host = nullptr, *g_redo_dev = nullptr;
+static std::once_flag g_redo_once;
+unsigned *redo_counters() {
+  std::call_once(g_redo_once, [] {
+    void *hp = nullptr, *dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return; }
+    memset(hp, 0, 64);
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(hp); return; }
+    g_redo_host = static_cast<unsigned *>(hp); g_redo_dev = static_cast<unsigned *>(dp);
+  });
+  return g_redo_dev;
+}
+unsigned redo_count(int which) {
+  return g_redo_host && which >= 0 && which < REDO_WORDS ? reinterpret_cast<volatile unsigned *>(g_redo_host)[which] : 0u;
+}
+void redo_clear() {
+  if (g_redo_host) for (int i = 0; i < REDO_WORDS; i++) reinterpret_cast<volatile unsigned *>(g_redo_host)[i] = 0u;
+}
 size_t fold_bf16x3_scratch_bytes(const Dims &d) { return (size_t)3 * 5 * d.C * d.R * sizeof(unsigned short); }
 
 void fold_bf16x3_planes(const Dims &d, void *scratch, unsigned short **a3, long *a_plane, unsigned short **b3, long *b_plane) {
@@ -320,12 +367,10 @@ static hipError_t launch_fold_planes(const Fold3Args &a, hipStream_t st, LaunchP
   constexpr int MI = 4, NI = 3, NBUF = 3;
   constexpr int shm = NBUF * NPL * (32 * MI + 32 * NI) * 64 > 4 * 16 * NI * (16 * MI + 4) * 4 ? NBUF * NPL * (32 * MI + 32 * NI) * 64
                                                                                               : 4 * 16 * NI * (16 * MI + 4) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  {   // (per launch, like every other kernel here: the attribute belongs to the current DEVICE, engines may sit on several)
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_bf16x3<MI, NI, NBUF, false, true, NPL>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     if (err != hipSuccess) return err;
-    attr_set = true;
   }
   const dim3 grid((a.nwg + 7) / 8 * 8), block(512);
   if (pr.start) hipExtLaunchKernelGGL((k_fold_bf16x3<MI, NI, NBUF, false, true, NPL>), grid, block, shm, st, pr.start, pr.stop, 0, a);
@@ -333,7 +378,7 @@ static hipError_t launch_fold_planes(const Fold3Args &a, hipStream_t st, LaunchP
   return hipGetLastError();
 }
 
-hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
+hipError_t launch_fold_bf16x3(const Dims &d, int mode, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
                               int nch2, hipStream_t st, LaunchProbe pr_split, LaunchProbe pr, bool planes_fresh) {
   constexpr int MI = 4, NI = 3;
   unsigned short *a3 = static_cast<unsigned short *>(scratch);
@@ -342,7 +387,7 @@ hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, 
   Split3Args s;
   s.src[0] = wr; s.src[1] = wmT; s.dst[0] = a3; s.dst[1] = b3; s.plane[0] = apl; s.plane[1] = bpl;
   s.n8[0] = apl / 8; s.n8[1] = bpl / 8;
-  s.mode = fold_split_mode();
+  s.mode = mode == 2 ? 2 : 1;
   const unsigned sgrid = (unsigned)std::min<size_t>((s.n8[0] + s.n8[1] + 255) / 256, 2048);
   if (!planes_fresh) {
     if (pr_split.start) hipExtLaunchKernelGGL(k_split3, dim3(sgrid), dim3(256), 0, st, pr_split.start, pr_split.stop, 0, s);
@@ -355,7 +400,8 @@ hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, 
 #ifdef KLSTM_FOLD3_TIMING
   a.dbg = g_fold3_dbg;
 #endif
-  a.C = d.C; a.R = d.R; a.a3 = a3; a.b3 = b3; a.a_plane = apl; a.b_plane = bpl;
+  a.C = d.C; a.R = d.R; a.wr = wr; a.wmT = wmT; a.redo = redo_counters() ? redo_counters() + REDO_FOLD : nullptr;
+  a.a3 = a3; a.b3 = b3; a.a_plane = apl; a.b_plane = bpl;
   a.pk1 = reinterpret_cast<float4 *>(pk_fold[0]); a.nch1 = nch1;
   a.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); a.nch2 = nch2;
   a.nbn = (d.C + 32 * NI - 1) / (32 * NI);

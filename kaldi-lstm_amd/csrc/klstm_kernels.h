@@ -15,7 +15,9 @@ struct Dims { int I, C, R, S, T; };
 struct FwdPtrs {
   const float *wx, *wr, *bias, *pi, *pf, *po, *wm;   // canonical [N x K] row-major weights
   float *gifo, *cc, *hh, *mm, *rr;
-  float *prev_c, *prev_r;                            // carried state [S x C], [S x R]
+  const float *prev_c, *prev_r;                      // carried state [S x C], [S x R] the minibatch starts from (:231) ...
+  float *next_c, *next_r;                            // ... and where c(T), r(T) go (:331): double-buffered by the engine, so that a
+                                                     // minibatch whose persistent launch gave up can be run again from the same state
   const float4 *pk_gates, *pk_proj;                  // packed (MFMA-operand-ordered) weight copies, or null
   const float4 *pk_fold;                             // packed [W_rm | W_x] of the folded recurrence, or null
   bool fat;                                          // allow the 64-row x 32-stream kernels when S > 16
@@ -38,6 +40,16 @@ struct BwdPtrs {
 
 // optional per-launch timing through hipExtLaunchKernelGGL start/stop events
 struct LaunchProbe { hipEvent_t start = nullptr, stop = nullptr; };
+
+// Range guard of the fp16-plane products (klstm_math.h nonfinite_probe): a wave whose accumulators came out non-finite -- an operand
+// beyond the fp16 range -- recomputes its outputs in plain fp32 and counts the event in one of these host-mapped words (pinned,
+// portable; readable on the host without a synchronisation).  The launchers look at the word of their product before every
+// launch and take that product to its fp32-range kernel once it is non-zero (the fold product: three bf16 planes); option
+// "fp16_products" = 1 clears the words and returns to the defaults.
+enum { REDO_FOLD = 0, REDO_NT = 1, REDO_OUTER = 2, REDO_SKINNY = 3, REDO_WORDS = 8 };
+unsigned *redo_counters();          // device-visible address of the REDO_WORDS words, or nullptr (then nothing is counted)
+unsigned redo_count(int which);     // host read
+void redo_clear();
 
 // forward step t (1..T).  fuse_x: the x_t * W_gifo_x^T + bias term (...streams.h:246,:259) is
 // contracted inside the step kernel (x = in rows of frame t); otherwise gifo already holds it.
@@ -78,17 +90,18 @@ bool direct_nt_supported(int M, int N, int K, const float *A, int lda, const flo
 hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
                             const float *bias, hipStream_t st, LaunchProbe pr = {});
 // the same product as six bf16 MFMA products of three-way split operands (fp32 accuracy; klstm_fold3.hip); scratch holds the planes
-bool fold_bf16x3_supported(const Dims &d);
-void set_fold_bf16x3(int v);       // 0: fp32 MFMA kernel, 1: bf16 x 3 planes (six products), 2: fp16 x 2 planes (three products)
-int fold_split_mode();              // 1 / 2: the plane format the product kernel expects right now
+// mode (per engine, option "fold_bf16x3"): 0: fp32 MFMA kernel, 1: bf16 x 3 planes (six products), 2: fp16 x 2 planes (three products)
+bool fold_bf16x3_supported(const Dims &d, int mode);
+void set_fold_bf16x3(int v);       // the default mode of engines created from now on
+int fold_default_mode();
 size_t fold_bf16x3_scratch_bytes(const Dims &d);
-hipError_t launch_fold_bf16x3(const Dims &d, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
+hipError_t launch_fold_bf16x3(const Dims &d, int mode, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
                               int nch2, hipStream_t st, LaunchProbe pr_split = {}, LaunchProbe pr = {}, bool planes_fresh = false);
                               // planes_fresh: the split pass is skipped (the fused Update wrote the planes: GradsUpdate::a3 / b3)
 void fold_bf16x3_planes(const Dims &d, void *scratch, unsigned short **a3, long *a_plane, unsigned short **b3, long *b_plane);
 hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
                        hipStream_t st, LaunchProbe pr = {}, LaunchProbe pr2 = {}, void *scratch3 = nullptr, LaunchProbe pr3 = {},
-                       bool planes_fresh = false);
+                       bool planes_fresh = false, int mode3 = 2);
                        // scratch3 (fold_bf16x3_scratch_bytes) selects the bf16x3 kernel when it supports the shape; pr3 = its split pass
                        // pk_fold zero-filled once by the caller; pack_x = false: launch_pack(.., foldx) already wrote the W_x chunks
 hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_stride, float *ws, hipStream_t st,
@@ -139,7 +152,7 @@ struct GradsUpdate {
   float *params; float lr, clip; float *wrT, *wmT, *wxT;
   // optional: the bf16 planes of the fold operands (fold_bf16x3_planes) are written from the updated W_gifo_r / W_r_m too
   unsigned short *a3 = nullptr, *b3 = nullptr; long a_plane = 0, b_plane = 0;
-  int split_mode = 1;      // fold_split_mode()
+  int split_mode = 1;      // the engine's fold mode: 1 = three bf16 planes, 2 = two fp16 planes
 };
 // C = A B for few rows, a narrow result and a long contraction (klstm_fold.hip: the output layer's in_diff); ws holds one partial per K slice
 bool skinny_nn_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *Cm, int ldc);
@@ -198,7 +211,8 @@ hipError_t launch_col_sum(const float *src, int rows, int cols, int stride, floa
 hipError_t launch_axpy(float *y, const float *x, float a, long n, hipStream_t st);
 
 hipError_t launch_sgd_momentum(float *param, float *corr, const float *grad, float mmt, float lr, long n, hipStream_t st);
-hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {});
+hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {},
+                                 const unsigned *guard = nullptr);
 
 // Weights-resident persistent chain (klstm_persist.hip forward, klstm_persist_bwd.hip backward; NumStream <= 8, folded
 // recurrence, x term fused): ONE launch per direction runs all T steps with the packed fold operands held in registers and
@@ -215,6 +229,10 @@ struct PersistOpts {
   long long spin_limit = 0;       // wall-clock ticks (100 MHz) a single in-kernel wait may take (0 = 50 ms)
   int test_stall_fwd = 0, test_stall_bwd = 0;   // test hook: workgroup 0 withholds its publish of this step -> timeout path
   unsigned *hstat = nullptr;      // host-mapped status word: set by a launch that gives up (the engine polls it without a sync)
+  unsigned *guard = nullptr;      // the engine's control words: a launch that finds a status word ([2], [6]) set by an EARLIER launch does
+                                  // nothing (whatever was queued behind a give-up leaves state, planes and parameters alone);
+                                  // [8] counts the persistent launches of the engine that have run (both directions, in stream order):
+                                  // the first launch that gives up records its ordinal ([8] + 1) in its ctrl[3]
   long long *dbg = nullptr;       // tools/persist_anatomy (KLSTM_PERSIST_TIMING builds only)
 };
 bool persist_supported(const Dims &d, const PersistOpts &o);       // forward

@@ -1927,7 +1927,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce2(ReduceArgs r1, ReduceArg
 //   blocks [nb2, nb3)      bias / peephole column sums (AddRowSumMat, AddDiagMatMat x3)
 // ---------------------------------------------------------------------------------------------
 struct GradsArgs {
-  const unsigned *guard;   // status words of the persistent chain ([2], [6]): non-zero -> the minibatch is invalid, touch nothing
+  const unsigned *guard;   // the engine's control words: status of the persistent chain ([2], [6]) or of the one-shot all-reduce ([9]) non-zero -> the minibatch is invalid, touch nothing
   GemmJob wx, wr, wm;
   int nb0, nb1, nb2, nvec;   // tile-id ranges of the three products, then nvec column-sum blocks
   int bf16_narrow;           // k_grads_bf16: 128 x 64 tiles instead of 128 x 128
@@ -1995,7 +1995,7 @@ __device__ __forceinline__ void grads_column_sums(const GradsArgs &a, int vb, fl
 }
 
 __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
-  if (a.guard && (a.guard[2] | a.guard[6])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
+  if (a.guard && (a.guard[2] | a.guard[6] | a.guard[9])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ __attribute__((aligned(16))) float As[GLDS];
   __shared__ __attribute__((aligned(16))) float Bs[GLDS];
   // XCD-aware order: workgroup w lands on XCD w % 8 (observed dispatch rule, speed only); XCD x gets the contiguous
@@ -2220,7 +2220,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_nt(GemmJob g) {
 }
 
 __global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
-  if (a.guard && (a.guard[2] | a.guard[6])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
+  if (a.guard && (a.guard[2] | a.guard[6] | a.guard[9])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ __attribute__((aligned(16))) unsigned As[4 * PLANE];
   __shared__ __attribute__((aligned(16))) unsigned Bs[4 * PLANE];
   const int nbt = a.nb2 + a.nvec;
@@ -2276,7 +2276,7 @@ __device__ __forceinline__ float upd_elem(const UpdArgs &a, long idx) {
 }
 
 __global__ __launch_bounds__(256) void k_update_repack(UpdArgs a) {
-  if (a.guard && (a.guard[2] | a.guard[6])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
+  if (a.guard && (a.guard[2] | a.guard[6] | a.guard[9])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ float tile[32][33];
   const int b = blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   if (b >= a.tb_vec) {
@@ -2336,7 +2336,7 @@ __device__ __forceinline__ float4 upd_vec_apply(const UpdArgs &a, long idx, cons
 }
 
 __global__ __launch_bounds__(256) void k_update_repack_v(UpdArgs a) {
-  if (a.guard && (a.guard[2] | a.guard[6])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
+  if (a.guard && (a.guard[2] | a.guard[6] | a.guard[9])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ __attribute__((aligned(16))) float tile[64 * 68];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= a.tb_vec) {
@@ -2750,7 +2750,8 @@ __global__ void k_sgd_momentum(float *__restrict__ param, float *__restrict__ co
     param[i] = param[i] + (-lr) * c;
   }
 }
-__global__ void k_apply_momentum(float *__restrict__ corr, const float *__restrict__ grad, float mmt, long n) {
+__global__ void k_apply_momentum(float *__restrict__ corr, const float *__restrict__ grad, float mmt, long n, const unsigned *guard) {
+  if (guard && (guard[2] | guard[6] | guard[9])) return;          // a persistent launch of this minibatch gave up: its gradient must not reach the momentum buffers
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     corr[i] = mmt * corr[i] + grad[i];
 }
@@ -2840,7 +2841,7 @@ hipError_t launch_gates_step(const Dims &d0, const FwdPtrs &p, int t, bool fuse_
   a.x_stride = in_stride;
   a.c_mirror = t == 1 ? p.cc : nullptr;
   a.r_mirror = (t == 1 && !fold) ? p.rr : nullptr;
-  a.c_save = t == d.T ? p.prev_c : nullptr;
+  a.c_save = t == d.T ? p.next_c : nullptr;          // (the carried state is double-buffered: read prev_*, write next_*)
   const float4 *wpk = fold ? p.pk_fold : p.pk_gates;
   const bool vec = wpk != nullptr && aligned16(p.rr) && aligned16(p.prev_r) && aligned16(p.mm) &&
                    (!fuse_x || (aligned16(in) && in_stride % 4 == 0));
@@ -2898,7 +2899,7 @@ hipError_t launch_proj_step(const Dims &d, const FwdPtrs &p, int t, float *out, 
   ProjArgs a;
   a.C = d.C; a.R = d.R; a.S = d.S; a.t = t;
   a.wm = p.wm; a.mm = p.mm; a.rr = p.rr; a.out = out; a.out_stride = out_stride;
-  a.r_save = t == d.T ? p.prev_r : nullptr;
+  a.r_save = t == d.T ? p.next_r : nullptr;
   a.vecOut = aligned16(out) && out_stride % 4 == 0 && d.R % 4 == 0;
   const bool vec = p.pk_proj != nullptr && aligned16(p.mm) && aligned16(p.rr) && aligned16(p.prev_r);
   if (vec) {
@@ -3078,7 +3079,7 @@ __global__ __launch_bounds__(256) void k_pack_foldx(const float *__restrict__ wx
 // step kernels (NT form on the transposed copy W_r_m^T [C x R]: both operands k-contiguous); then the x chunks.
 // pk_fold[0/1] must have been zero-filled once (padding rows / k tails are never written).
 hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
-                       hipStream_t st, LaunchProbe pr, LaunchProbe pr2, void *scratch3, LaunchProbe pr3, bool planes_fresh) {
+                       hipStream_t st, LaunchProbe pr, LaunchProbe pr2, void *scratch3, LaunchProbe pr3, bool planes_fresh, int mode3) {
   const long o_wr = (long)4 * d.C * d.I;
   GemmJob g = make_job(false, true, 4 * d.C, d.C, d.R, param_blob + o_wr, d.R, wmT, d.R, 0.f, nullptr, d.C, nullptr);
   g.gperm = d.C;
@@ -3086,8 +3087,8 @@ hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT,
   g.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); g.nch2 = cdiv(4 * d.C, KCH4);
   const dim3 grid(cdiv(cdiv(d.C, GT) * cdiv(4 * d.C, GT), 8) * 8), block(256);
   auto first = [&]() -> hipError_t {
-    if (scratch3 && fold_bf16x3_supported(d))
-      return launch_fold_bf16x3(d, param_blob + o_wr, wmT, scratch3, pk_fold, g.nch1, g.nch2, st, pr3, pr, planes_fresh);   // klstm_fold3.hip
+    if (scratch3 && fold_bf16x3_supported(d, mode3))
+      return launch_fold_bf16x3(d, mode3, param_blob + o_wr, wmT, scratch3, pk_fold, g.nch1, g.nch2, st, pr3, pr, planes_fresh);   // klstm_fold3.hip
     if (fold_direct_supported(d)) return launch_fold_direct(d, param_blob + o_wr, wmT, pk_fold, g.nch1, g.nch2, st, pr);   // klstm_fold.hip
     KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
   };
@@ -3105,11 +3106,11 @@ hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_st
   const int ks = gemm_splitk_plan(M, d.R, d.C, &kl);
   if (ks > 1 && ws)
     return launch_gemm_splitk(false, true, M, d.R, d.C, p.mm + (size_t)d.S * d.C, d.C, p.wm, d.C, 0.f, p.rr + (size_t)d.S * d.R,
-                              d.R, nullptr, ws, ks, kl, st, nullptr, 0, pr, pr2, out, out_stride, p.prev_r, M - d.S);
+                              d.R, nullptr, ws, ks, kl, st, nullptr, 0, pr, pr2, out, out_stride, p.next_r, M - d.S);
   GemmJob g = make_job(false, true, M, d.R, d.C, p.mm + (size_t)d.S * d.C, d.C, p.wm, d.C, 0.f,
                        p.rr + (size_t)d.S * d.R, d.R, nullptr);
   g.C2 = out; g.ldc2 = out_stride;
-  g.C3 = p.prev_r; g.tail0 = M - d.S;
+  g.C3 = p.next_r; g.tail0 = M - d.S;
   const dim3 grid(cdiv(cdiv(d.R, GT) * cdiv(M, GT), 8) * 8), block(256);
   KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
 }
@@ -3440,8 +3441,8 @@ hipError_t launch_sgd_momentum(float *param, float *corr, const float *grad, flo
   LaunchProbe pr;
   KLAUNCH(k_sgd_momentum, dim3(ew_grid(n)), dim3(256), st, pr, param, corr, grad, mmt, lr, n);
 }
-hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr) {
-  KLAUNCH(k_apply_momentum, dim3(ew_grid(n)), dim3(256), st, pr, corr, grad, mmt, n);
+hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr, const unsigned *guard) {
+  KLAUNCH(k_apply_momentum, dim3(ew_grid(n)), dim3(256), st, pr, corr, grad, mmt, n, guard);
 }
 
 }  // namespace klstm

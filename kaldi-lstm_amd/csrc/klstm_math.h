@@ -109,6 +109,31 @@ __device__ __forceinline__ void f16_split2_pair(float x0, float x1, unsigned &h1
   const klstm_h2 b = __builtin_convertvector(r, klstm_h2);
   h1 = __builtin_bit_cast(unsigned, a); h2 = __builtin_bit_cast(unsigned, b);
 }
+// ---- range guard of the fp16-plane products ------------------------------------------------------------------------------
+// The reference's products are fp32 (cblas_sgemm / cublasSgemm, kaldi-matrix.cc:160-175): any finite operand is legal.  An
+// fp16 plane overflows for |x| >= 65520 (h1 = Inf, h2 = -Inf).  An Inf operand can only produce Inf or NaN -- never a finite
+// wrong number -- and it reaches EVERY accumulator whose row / column it sits in, so a look at a wave's accumulators after the
+// K loop detects it: v * 0 is NaN exactly when v is Inf or NaN.  The wave then recomputes ITS outputs with plain fp32
+// multiply-adds from the fp32 operands (slow and rare: one dot product per accumulator element and lane) and counts the event in
+// a host-mapped word; the host takes that product to its fp32-range kernel from the next call on (klstm_kernels.h redo_*).
+// A result that overflows fp32 itself takes the same path and comes out non-finite again, as it does in the reference.
+__device__ __forceinline__ float nonfinite_probe(float t, float v) { return __builtin_fmaf(v, 0.f, t); }
+__device__ __forceinline__ bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+__device__ __forceinline__ void redo_note(unsigned *ctr) {      // (called from wave-uniform code: lane 0 is active)
+  if (ctr && (threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// sequential fp32 dot product of the redo path: n terms, strides in elements
+__device__ __forceinline__ float redo_dot(const float *a, long sa, const float *b, long sb, int n) {
+  float s = 0.f;
+  for (int k = 0; k < n; k++) s = __builtin_fmaf(a[(long)k * sa], b[(long)k * sb], s);
+  return s;
+}
+// Derivative operands (out_diff, dgifo) of the on-the-fly split kernels are multiplied by 2^12 before they are split and the result
+// by 2^-12 afterwards (both exact): the two planes then carry 22 bits for 2^-26 <= |x| < 16 instead of 2^-14 <= |x| < 65504 --
+// late-training derivatives of 1e-7 keep full precision (unscaled: 3e-4 relative); below 2^-26 the absolute error is < 2^-47;
+// at 16 and above the range guard takes over.
+constexpr float DERIV_SCALE = 4096.f, DERIV_UNSCALE = 1.f / 4096.f;
+
 // mode 1: three bf16 planes, mode 2: two fp16 planes (plane 1 scaled by 2^11)
 __device__ __forceinline__ void split_store4(int mode, const float (&v)[4], unsigned short *dst, long plane) {
   if (mode != 2) { bf16_split3_store4(v, dst, plane); return; }

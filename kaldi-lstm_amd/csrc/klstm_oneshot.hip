@@ -37,6 +37,9 @@ struct OneshotArgs {
   float *blob[ONESHOT_MAX_RANKS];             // peer-mapped gradient blobs (own pointer at [rank])
   unsigned *flags[ONESHOT_MAX_RANKS];         // peer-mapped flag arrays: [0..N) arrival, [N..2N) departure, [2N] status
   unsigned *done;                             // own counter: workgroups that finished phase B
+  unsigned *go;                               // own word: workgroup 0's verdict on the arrival phase (epoch: go on; epoch | 2^31: a peer is missing)
+  unsigned *abort_word, *abort_host;          // (or null) set when a wait expires: the engine's guard word -- its Update kernels then leave momentum
+                                              // and parameters alone -- and the host-mapped word the engine polls without a synchronisation
   long long limit;                            // wall-clock ticks (100 MHz) a flag wait may take
 };
 
@@ -54,7 +57,12 @@ __device__ bool wait_all(const OneshotArgs &a, int base) {
     bool ok = true;
     for (int q = 0; q < a.nranks; q++) ok &= sys_load(mine + base + q) == a.epoch;
     if (ok) return true;
-    if (wall_clock64() - t0 > a.limit) { sys_store(mine + 2 * a.nranks, 0x80000000u | (unsigned)base); return false; }
+    if (wall_clock64() - t0 > a.limit) {
+      sys_store(mine + 2 * a.nranks, 0x80000000u | (unsigned)base);
+      if (a.abort_word) __hip_atomic_store(a.abort_word, 0x80000000u | (unsigned)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.abort_host) sys_store(a.abort_host, 1u);
+      return false;
+    }
     __builtin_amdgcn_s_sleep(8);
   }
 }
@@ -67,9 +75,26 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneshotArgs a) {
     __threadfence_system();
     sys_store(a.flags[tid] + a.rank, a.epoch);
   }
-  if (tid == 0) ok_s = wait_all(a, 0) ? 1 : 0;
+  // The timeout is decided ONCE, by workgroup 0, and published in a word of this device; everybody else follows it (every
+  // workgroup deciding for itself could leave some in phase B and others gone: the `done` count below would never complete,
+  // and every later call would skip its departure phase).  A launch whose arrival phase failed skips phase B -- the blob stays
+  // this rank's local gradient -- but still runs the accounting of phase C.
+  if (tid == 0) {
+    if (blockIdx.x == 0) {
+      ok_s = wait_all(a, 0) ? 1 : 0;
+      __hip_atomic_store(a.go, ok_s ? a.epoch : (a.epoch | 0x80000000u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      unsigned v;
+      const long long t0 = wall_clock64();
+      while (((v = __hip_atomic_load(a.go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) & 0x7fffffffu) != a.epoch) {
+        if (wall_clock64() - t0 > 2 * a.limit) { v = 0x80000000u; break; }       // (workgroup 0 never ran: not co-resident)
+        __builtin_amdgcn_s_sleep(8);
+      }
+      ok_s = (v & 0x80000000u) ? 0 : 1;
+    }
+  }
   __syncthreads();
-  if (!ok_s) return;
+  const bool arrived = ok_s != 0;
   // ---- B: slice `rank` = [lo, hi) in units of float4 (the last slice takes the remainder)
   const long n4 = a.n / 4, per = (n4 + N - 1) / N, lo = per * a.rank, hi = lo + per < n4 ? lo + per : n4;
   // system-coherent accesses (sc0 sc1 = aux 17): nothing of a peer's memory is served from, or parked in, this device's L2
@@ -77,7 +102,7 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneshotArgs a) {
   __amdgpu_buffer_rsrc_t rs[ONESHOT_MAX_RANKS];
 #pragma unroll
   for (int q = 0; q < ONESHOT_MAX_RANKS; q++) rs[q] = buf_rsrc(a.blob[q < N ? q : N - 1], (int)(a.n * 4));
-  for (long i = lo + (long)blockIdx.x * 256 + tid; i < hi; i += (long)gridDim.x * 256) {
+  for (long i = lo + (long)blockIdx.x * 256 + tid; arrived && i < hi; i += (long)gridDim.x * 256) {
     const int off = (int)(i * 16);
     u32x4 v[ONESHOT_MAX_RANKS];
 #pragma unroll
@@ -91,7 +116,7 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneshotArgs a) {
     for (int q = 0; q < ONESHOT_MAX_RANKS; q++)
       if (q < N) __builtin_amdgcn_raw_buffer_store_b128(o, rs[q], off, 0, AUX);
   }
-  if (a.rank == N - 1 && blockIdx.x == 0)             // the n % 4 tail
+  if (arrived && a.rank == N - 1 && blockIdx.x == 0)  // the n % 4 tail
     for (long i = n4 * 4 + tid; i < a.n; i += 256) {
       float s = 0.f;
       for (int q = 0; q < N; q++) s += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(buf_rsrc(a.blob[q], (int)(a.n * 4)), (int)(i * 4), 0, AUX));
@@ -106,7 +131,7 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneshotArgs a) {
     if (ok_s) __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (!ok_s) return;
+  if (!ok_s || !arrived) return;
   if (tid < N) sys_store(a.flags[tid] + N + a.rank, a.epoch);
   if (tid == 0) (void)wait_all(a, N);
 }
@@ -118,6 +143,7 @@ struct OneshotGroup {
   bool opened_blob[ONESHOT_MAX_RANKS] = {}, opened_flags[ONESHOT_MAX_RANKS] = {};
   void *base_blob[ONESHOT_MAX_RANKS] = {}, *base_flags[ONESHOT_MAX_RANKS] = {};
   unsigned *own_flags = nullptr, *done = nullptr;
+  unsigned *abort_word = nullptr, *abort_host = nullptr;   // klstm_oneshot_set_abort_words
   float *own_blob = nullptr;
   long n = 0;
   unsigned epoch = 0;
@@ -206,7 +232,8 @@ klstm_status klstm_oneshot_allreduce(klstm_oneshot *h, void *hip_stream, int tim
   OneshotArgs a;
   a.rank = g->rank; a.nranks = g->nranks; a.n = g->n; a.epoch = ++g->epoch;
   for (int q = 0; q < ONESHOT_MAX_RANKS; q++) { a.blob[q] = g->blob[q]; a.flags[q] = g->flags[q]; }
-  a.done = g->done;
+  a.done = g->done; a.go = g->own_flags + 2 * ONESHOT_MAX_RANKS + 1;
+  a.abort_word = g->abort_word; a.abort_host = g->abort_host;
   a.limit = (long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000;       // wall clock: 100 MHz
   const long n4 = g->n / 4, per = (n4 + g->nranks - 1) / g->nranks;
   int grid = (int)((per + 255) / 256);
@@ -224,6 +251,14 @@ klstm_status klstm_oneshot_status(klstm_oneshot *h, unsigned *status) {
   OCHK(hipMemcpy(status, g->own_flags + 2 * (g->nranks ? g->nranks : 1), sizeof(unsigned), hipMemcpyDeviceToHost));
   return KLSTM_OK;
 }
+
+}  // extern "C"
+// (engine-internal, klstm_engine.hip) where a timeout is also recorded: the engine's guard word and its host-mapped notice word
+void klstm_oneshot_set_abort_words(klstm_oneshot *h, unsigned *guard_word_dev, unsigned *host_mapped_word) {
+  auto *g = reinterpret_cast<OneshotGroup *>(h);
+  if (g) { g->abort_word = guard_word_dev; g->abort_host = host_mapped_word; }
+}
+extern "C" {
 
 klstm_status klstm_oneshot_destroy(klstm_oneshot *h) {
   auto *g = reinterpret_cast<OneshotGroup *>(h);

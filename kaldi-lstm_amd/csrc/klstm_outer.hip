@@ -25,7 +25,9 @@
 // 80 x 16624 x 512: 29.9 -> 16.4 us (gradient), 42.1 -> 33.2 us (Update); DESIGN.md 9 item 5 has the ablations and dead ends.
 // (First version, kept in the history: planes written k-contiguous by a prep launch, 16-byte operand loads from them: 8.9 + 26 us
 //  -- every 128-byte line of the planes fetched twice through a 32 KB L1, 200 MB of operand ingest.)
-// Values must stay below 65504 in magnitude (fp16 range): out_diff of a softmax / cross-entropy layer is within [-1, 1].
+// Range: every column of out_diff is scaled by its own power of two before the split (see the kernel), `in` is split as it is; an
+// entry beyond the fp16 range (|x| >= 65520) makes the wave's accumulators non-finite, which the wave notices and answers by
+// recomputing its tile in plain fp32 (klstm_math.h "range guard") -- the launcher then keeps this product on the fp32 tile kernel.
 #include "klstm_kernels.h"
 #include "klstm_math.h"
 #include <hip/hip_ext.h>
@@ -47,6 +49,7 @@ struct OuterArgs {
   float *bias_p; float lr_b;           // bias_p -= lr_b * bias  (nullptr: not)
   float beta; float *Cm; int ldc;      // Cm = beta * Cm + G
   float *P; float lr;                  // P -= lr * Cm  (nullptr: gradient only)
+  unsigned *redo;                      // range guard: host-mapped event counter (klstm_kernels.h REDO_OUTER), or null
 };
 
 __device__ __forceinline__ of32x4 outer_keep(of32x4 v, bool on) { return on ? v : (of32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
   // ---- the strip's columns of out_diff: all chunks, split once ----
   of16x8 a1[NCH][4], a2[NCH][4];
   of32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+  __shared__ float cinv_s[64];                           // per column of the strip: the inverse of the power of two it was scaled by
   {
     of32x4 raw[NCH][8];
 #pragma unroll
@@ -111,13 +115,32 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
       }
     if (tid < 32 * NCH) xd[tid] = has_x && tid < a.K ? a.diff[(size_t)tid * a.ldd + mx] : 0.f;   // (LDS: 24 registers less per lane)
     loadTile(0);
+    of32x4 mx = {0.f, 0.f, 0.f, 0.f}, cscale;
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
+    for (int c = 0; c < NCH; c++)
 #pragma unroll
       for (int e = 0; e < 8; e++) {
         raw[c][e] = outer_keep(raw[c][e], m_in && 32 * c + 8 * kg + e < a.K);
         colsum += raw[c][e];
+        mx = __builtin_elementwise_max(mx, __builtin_elementwise_abs(raw[c][e]));
       }
+    // out_diff is a derivative: late in training its entries are 1e-7 and smaller, where two fp16 planes keep 2^-35 absolute
+    // (3e-4 relative).  Every COLUMN of out_diff (= row of G) is brought to [2^11, 2^12) by its own power of two before the split
+    // (exact) and the row of G is multiplied back in the epilogue: 22 bits for every entry within 2^25 of its column's largest.
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      float m = mx[q];
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const int eb = (int)((__float_as_uint(m) >> 23) & 0xffu);          // biased exponent of the column's largest entry
+      const int sb = eb == 0 ? 127 : min(265 - eb, 253);               // scale = 2^(sb - 127): largest entry -> [2^11, 2^12)
+      cscale[q] = __uint_as_float((unsigned)sb << 23);
+      if (wave == 0 && kg == 0) cinv_s[4 * i16 + q] = __uint_as_float((unsigned)(254 - sb) << 23);   // (every wave holds the same 64 columns; read behind the barrier below)
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) raw[c][e] *= cscale;
       outer_split(raw[c], a1[c], a2[c]);
     }
   }
@@ -227,7 +250,9 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
         }
       }
     }
-    // accumulator (mi, cn)[r] = G[m0 + 4 (4 kg + r) + mi][nc + cn]
+    // accumulator (mi, cn)[r] = G[m0 + 4 (4 kg + r) + mi][nc + cn], still scaled by the row's power of two (row 4 (4 kg + r) + mi
+    // = column mi of lane i16 = 4 kg + r: cinv_s)
+    float probe = 0.f;                                   // range guard (klstm_math.h): NaN as soon as one entry of the tile is Inf / NaN
     if (!UPD) {                                          // gradient only: sixteen stores
 #pragma unroll
       for (int mi = 0; mi < 4; mi++)
@@ -235,30 +260,50 @@ __global__ __launch_bounds__(256) void k_outer16(OuterArgs a) {
         for (int r = 0; r < 4; r++) {
           const int m = m0 + 16 * kg + 4 * r + mi;
           if (m >= a.m_main) continue;
-          *reinterpret_cast<float4 *>(a.Cm + (size_t)m * a.ldc + nc) =
-              make_float4(acc[mi][0][r] + accx[mi][0][r] * (1.f / 2048.f), acc[mi][1][r] + accx[mi][1][r] * (1.f / 2048.f),
-                          acc[mi][2][r] + accx[mi][2][r] * (1.f / 2048.f), acc[mi][3][r] + accx[mi][3][r] * (1.f / 2048.f));
+          const float inv = cinv_s[4 * (4 * kg + r) + mi];
+          const of32x4 g = {(acc[mi][0][r] + accx[mi][0][r] * (1.f / 2048.f)) * inv, (acc[mi][1][r] + accx[mi][1][r] * (1.f / 2048.f)) * inv,
+                            (acc[mi][2][r] + accx[mi][2][r] * (1.f / 2048.f)) * inv, (acc[mi][3][r] + accx[mi][3][r] * (1.f / 2048.f)) * inv};
+          probe = nonfinite_probe(nonfinite_probe(nonfinite_probe(nonfinite_probe(probe, g[0]), g[1]), g[2]), g[3]);
+          *reinterpret_cast<of32x4 *>(a.Cm + (size_t)m * a.ldc + nc) = g;
         }
-      continue;
+    } else {
+      // Update in the same pass
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's rows of corr and W are in LDS (so are the next tile's rows of `in`)
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int m = m0 + 16 * kg + 4 * r + mi;
+          if (m >= a.m_main) continue;
+          const of32x4 oc = *reinterpret_cast<const of32x4 *>(wrows + (mi * 4 + r) * 1024 + lane * 16);
+          const float inv = cinv_s[4 * (4 * kg + r) + mi];
+          of32x4 g = {(acc[mi][0][r] + accx[mi][0][r] * (1.f / 2048.f)) * inv, (acc[mi][1][r] + accx[mi][1][r] * (1.f / 2048.f)) * inv,
+                      (acc[mi][2][r] + accx[mi][2][r] * (1.f / 2048.f)) * inv, (acc[mi][3][r] + accx[mi][3][r] * (1.f / 2048.f)) * inv};
+          probe = nonfinite_probe(nonfinite_probe(nonfinite_probe(nonfinite_probe(probe, g[0]), g[1]), g[2]), g[3]);
+          g += a.beta * oc;
+          *reinterpret_cast<of32x4 *>(a.Cm + (size_t)m * a.ldc + nc) = g;
+          if (a.P) {
+            const of32x4 op = *reinterpret_cast<const of32x4 *>(wrows + 16384 + (mi * 4 + r) * 1024 + lane * 16);
+            *reinterpret_cast<of32x4 *>(a.P + (size_t)m * a.ldc + nc) = op - a.lr * g;
+          }
+        }
     }
-    // Update in the same pass
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile's rows of corr and W are in LDS (so are the next tile's rows of `in`)
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int m = m0 + 16 * kg + 4 * r + mi;
-        if (m >= a.m_main) continue;
-        const of32x4 oc = *reinterpret_cast<const of32x4 *>(wrows + (mi * 4 + r) * 1024 + lane * 16);
-        of32x4 g = {acc[mi][0][r] + accx[mi][0][r] * (1.f / 2048.f), acc[mi][1][r] + accx[mi][1][r] * (1.f / 2048.f),
-                    acc[mi][2][r] + accx[mi][2][r] * (1.f / 2048.f), acc[mi][3][r] + accx[mi][3][r] * (1.f / 2048.f)};
-        g += a.beta * oc;
-        *reinterpret_cast<of32x4 *>(a.Cm + (size_t)m * a.ldc + nc) = g;
-        if (a.P) {
-          const of32x4 op = *reinterpret_cast<const of32x4 *>(wrows + 16384 + (mi * 4 + r) * 1024 + lane * 16);
-          *reinterpret_cast<of32x4 *>(a.P + (size_t)m * a.ldc + nc) = op - a.lr * g;
-        }
+    // An entry of `in` or of out_diff beyond the fp16 range left Inf / NaN in this wave's tile: the tile again in plain fp32, element
+    // by element, written over what went out above (same lane, same address: ordered).  The Update form takes the old corr / W
+    // values from the LDS copies the tile's epilogue used, which are still in place.
+    if (wave_any(probe != probe)) {
+      redo_note(a.redo);
+#pragma unroll 1
+      for (int q = 0; q < 64; q++) {
+        const int mi = q >> 4, cn = (q >> 2) & 3, r = q & 3;
+        const int m = m0 + 16 * kg + 4 * r + mi, n = nc + cn;
+        if (m >= a.m_main || n >= a.N) continue;
+        float g = redo_dot(a.diff + m, a.ldd, a.x + n, a.ldx, a.K);
+        if (UPD) g += a.beta * *reinterpret_cast<const float *>(wrows + (mi * 4 + r) * 1024 + lane * 16 + cn * 4);
+        a.Cm[(size_t)m * a.ldc + n] = g;
+        if (UPD && a.P) a.P[(size_t)m * a.ldc + n] = *reinterpret_cast<const float *>(wrows + 16384 + (mi * 4 + r) * 1024 + lane * 16 + cn * 4) - a.lr * g;
       }
+    }
   }
 }
 
@@ -268,7 +313,7 @@ void set_outer_f16(int on) { g_outer_f16 = on; }
 // few frames (the contraction: three chunks of 32 are held in registers), a wide result: below ~2k rows of G the strips do not fill the chip
 bool outer_f16_supported(int M, int N, int K, const float *diff, int ldd, const float *x, int ldx, const float *Cm, int ldc,
                          const float *P, const float *bias) {
-  return g_outer_f16 != 0 && K >= 1 && K <= 96 && M >= 2048 && M % 4 == 0 && N >= 64 && N % 4 == 0 && ldc % 4 == 0 && ldd % 4 == 0 &&
+  return g_outer_f16 != 0 && redo_count(REDO_OUTER) == 0 && K >= 1 && K <= 96 && M >= 2048 && M % 4 == 0 && N >= 64 && N % 4 == 0 && ldc % 4 == 0 && ldd % 4 == 0 &&
          ldx % 4 == 0 && ((reinterpret_cast<uintptr_t>(Cm) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(diff) |
                            reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0 && diff && x;
 }
@@ -278,6 +323,7 @@ hipError_t launch_outer_f16(int M, int N, int K, const float *diff, int ldd, con
   a.diff = diff; a.ldd = ldd; a.x = x; a.ldx = ldx; a.K = K; a.M = M; a.N = N;
   a.bias_p = bias ? bias_p : nullptr; a.lr_b = lr_b;
   a.beta_b = beta_b; a.bias = bias; a.beta = beta; a.Cm = Cm; a.ldc = ldc; a.P = P; a.lr = lr;
+  a.redo = redo_counters() ? redo_counters() + REDO_OUTER : nullptr;
   // one round of workgroups where a few rows past a whole number of strips per CU would start a second one
   static int ncu_of[64];                                 // per device, asked once
   int dev = 0, ncu = 256;

@@ -55,8 +55,12 @@ struct PersistFwdArgs {
   const float *x; int x_stride;   // input rows [T*S x I]
   const float *xg;                // non-null: x(t) W_gifo_x^T + bias is already in the gifo plane (batched product, :246/:259): wide inputs;
                                   // the kernel then runs with I = 0 (no x columns in the slabs, no x rows of the operands)
-  float *prev_c;                  // carried c [S x C]: read at step 1 (:231), written at step T (:331)
-  float *prev_r;                  // carried r [S x R]: read at step 1, written with r(T) (:331) (rin)
+  const float *prev_c;            // carried c [S x C], read at step 1 (:231)
+  const float *prev_r;            // carried r [S x R], read at step 1
+  float *next_c, *next_r;         // c(T) (:331) and, with rin, r(T) go here: ANOTHER buffer (the engine flips the pair per minibatch), so
+                                  // that a launch that gives up leaves the state it started from untouched
+  unsigned *guard;                // the engine's control words (or null): [2] / [6] set by an earlier launch -> do nothing; [8] = persistent
+                                  // launches of this engine that have run so far: this launch's ordinal, [8] + 1, goes into ctrl[3] if it gives up
   unsigned long long *gran;       // [2][C*4] granules, cell-major (4 stream slots per cell)
   unsigned *ctrl;                 // [0] epoch, [1] finished workgroups, [2] status (0 = ok)
   int nap0, nap;                  // sweepers sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
@@ -170,6 +174,13 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // a launch queued behind one that gave up (its status word is still set: the host has not looked yet) must not run: its
+  // inputs are that launch's invalid outputs.  (Workgroup-uniform; the epoch still moves on: finish().)
+  if (a.guard && (__hip_atomic_load(&a.guard[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                  __hip_atomic_load(&a.guard[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+    finish(a.ctrl, epoch, T + 2, a.guard ? a.guard + 8 : nullptr);
+    return;
+  }
   // zero both slabs once: pad columns and rows of absent streams stay zero for the whole launch
   for (int i = tid; i < SS * (LDB + LDU); i += PNT) lds[i] = 0.f;
   if (tid == 0) { *abortf = 0u; *projf = 0; *pubcnt = 0; }
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       buf_store_f32(rs_c, vc, sc, c);
       buf_store_f32(rs_h, vc, sc, h);
       buf_store_f32(rs_m, vc, sc, m);
-      if (t == T) a.prev_c[(size_t)es_g * C + e_cell] = c;       // :331 (c columns)
+      if (t == T) a.next_c[(size_t)es_g * C + e_cell] = c;       // :331 (c columns)
       cp = c;
     };
       // ---- step 1 closes over the CARRIED r (:275; set by Reset / the previous minibatch, possibly under older weights):
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
           *reinterpret_cast<float4 *>(a.rr + ((size_t)f * S + ps) * R + g4) = make_float4(v.x, v.y, v.z, v.w);
           float *op = a.out + ((size_t)(f - 1) * S + ps) * a.out_stride + g4;
           op[0] = v.x; op[1] = v.y; op[2] = v.z; op[3] = v.w;
-          if (f == T) *reinterpret_cast<float4 *>(a.prev_r + (size_t)ps * R + g4) = make_float4(v.x, v.y, v.z, v.w);
+          if (f == T) *reinterpret_cast<float4 *>(a.next_r + (size_t)ps * R + g4) = make_float4(v.x, v.y, v.z, v.w);
         }
       }
     }
@@ -394,6 +405,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
         if (!sweep_cells<PCELL, NG>(a.gran + (size_t)((t - 1) & 1) * C * SS, C, S, epoch + (unsigned)(t - 1), cell, mv, a.spin_limit, a.nap0, a.nap)) {
           *abortf = 1u;
           if (lane == 0) {
+            atomicCAS(&a.ctrl[3], 0u, launch_ordinal(a.guard));            // (which launch: the first one wins, everything behind it does nothing)
             atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
             if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           }
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
     }
   }
   PT_FLUSH(0);
-  finish(a.ctrl, epoch, T + 2);
+  finish(a.ctrl, epoch, T + 2, a.guard ? a.guard + 8 : nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -519,7 +531,8 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
   const int nch_k = a.nchm + pcdiv(a.I, KCH);                      // chunks this launch contracts
   a.wpk = p.pk_fold; a.wr = p.wr; a.wx = p.wx; a.wm = p.wm; a.bias = p.bias; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm; a.rr = p.rr;
-  a.x = in; a.x_stride = in_stride; a.prev_c = p.prev_c; a.prev_r = p.prev_r; a.gran = gran; a.ctrl = ctrl;
+  a.x = in; a.x_stride = in_stride; a.prev_c = p.prev_c; a.prev_r = p.prev_r; a.next_c = p.next_c; a.next_r = p.next_r; a.gran = gran; a.ctrl = ctrl;
+  a.guard = o.guard;
   a.rin = out && persist_r_in_kernel(d, o); a.out = out; a.out_stride = out_stride;
   a.nap0 = o.nap0 >= 0 ? o.nap0 : d.S > 4 ? 4 : 2; a.nap = o.nap >= 0 ? o.nap : 0;     // (behind the publish flag; measured: tools/persist_anatomy, tools/nap_sweep.py)
   a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;

@@ -65,6 +65,8 @@ struct PersistBwd2Args {
   long long spin_limit;           // wall-clock ticks (100 MHz) a single wait may take
   int test_stall;                 // test hook: workgroup 0 does not publish d_m(test_stall) (0: never)
   unsigned *hstat;                // host-mapped status word (or null): set when a wait expires, read by the engine without a sync
+  unsigned *guard;                // the engine's control words (or null): [2] / [6] set by an earlier launch -> do nothing; [8] = persistent
+                                  // launches of this engine that have run so far: this launch's ordinal, [8] + 1, goes into ctrl[3] if it gives up
 #ifdef KLSTM_PERSIST_TIMING
   long long *dbg;
 #endif
@@ -125,6 +127,13 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
   const int ngrp = (S + 3) >> 2;
   const long long limit = a.spin_limit;
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // queued behind a launch that gave up (status word still set: the host has not looked yet): the planes this launch would read
+  // are invalid -- do nothing (workgroup-uniform; the epoch still moves on)
+  if (a.guard && (__hip_atomic_load(&a.guard[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                  __hip_atomic_load(&a.guard[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+    finish(a.ctrl, epoch, ((S + 3) >> 2) * (T + 2), a.guard ? a.guard + 8 : nullptr);
+    return;
+  }
   // the d_r / in_diff columns of this workgroup: 4 rows of W_gifo_r^T (workgroups 0 .. R/4-1), then of W_gifo_x^T
   const int ngr = a.R / 4, ngx = (a.din & 2) ? a.I / 4 : 0;
   const bool d_on = a.din && (int)blockIdx.x < ngr + ngx, d_isr = (int)blockIdx.x < ngr;
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
               if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { dead = true; break; }
               if (wall_clock64() - t0 > limit) {
                 __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (lane == 0) atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+                if (lane == 0) { atomicCAS(&a.ctrl[3], 0u, launch_ordinal(a.guard)); atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t); }
                 dead = true;
                 break;
               }
@@ -471,10 +480,11 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
   }
   __syncthreads();
   if (tid == 0 && *abortf) {                         // (a bounded LDS wait expired or a sweep timed out)
+    atomicCAS(&a.ctrl[3], 0u, launch_ordinal(a.guard));
     atomicMax(&a.ctrl[2], 0x80000000u | 0x7fffu);
     if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  finish(a.ctrl, epoch, ngrp * (T + 2));
+  finish(a.ctrl, epoch, ngrp * (T + 2), a.guard ? a.guard + 8 : nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -544,6 +554,7 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
   a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;
   a.test_stall = o.test_stall_bwd;
   a.hstat = o.hstat;
+  a.guard = o.guard;
 #ifdef KLSTM_PERSIST_TIMING
   a.dbg = o.dbg;
 #endif

@@ -100,6 +100,8 @@ class DataParallelLstm:
         # mapped into every other rank (hipIpc handles handed around over the process group) and ONE kernel per rank reduces its
         # 1/N slice from all peers and writes it back to all of them, instead of ncclAllReduce
         self.oneshot = None
+        self.use_oneshot = False
+        self._rccl_name = self.collective_name
         if oneshot and self.collective and hasattr(engine, "grad_blob_tensor"):
             from .binding import OneshotAllreduce
             self._blob = engine.grad_blob_tensor()
@@ -107,7 +109,11 @@ class DataParallelLstm:
             hs = [None] * self.world
             dist.all_gather_object(hs, self.oneshot.export(), group=group)
             self.oneshot.connect(dist.get_rank(group), self.world, hs)
+            self.use_oneshot = True              # (a caller that wants both at hand -- bench.py's A/B -- switches this flag)
             self.collective_name = "klstm_allreduce_grads_oneshot (peer-mapped blobs, one kernel per rank; EXPERIMENTAL)"
+
+    def collective_in_use(self):
+        return self.collective_name if (self.oneshot is not None and self.use_oneshot) or self.oneshot is None else self._rccl_name
 
     def broadcast_params(self, src=0):
         """Make every replica start from rank `src`'s parameters (device to device on GPUs)."""
@@ -131,7 +137,7 @@ class DataParallelLstm:
             e.backpropagate(x, out_diff, in_diff, momentum, self.FUSE_UPDATE)
         else:
             e.backpropagate(x, out_diff, in_diff, momentum, self.DEFER_MOMENTUM)
-            if self.oneshot is not None:
+            if self.oneshot is not None and self.use_oneshot:
                 self.oneshot.allreduce_engine(e)
             elif self.comm is not None:
                 e.allreduce_grads(self.comm)
@@ -294,6 +300,13 @@ class DataParallelNnet:
         # single rank, nothing to reduce: layers that can do so run gradient + momentum + step as one pass (what the C++ mirror
         # does with KLSTM_BPTT_FUSE_UPDATE / klstm_affine_update); the fused gradient blob then stays unused
         self.fused = fuse_single_rank and not self.collective
+        if self.collective:
+            # A persistent launch that gives up leaves this rank's slice of the blob stale; in a stack, the layers above have
+            # consumed its output by then.  With a collective in the step the engines wait for their persistent launches and answer
+            # a give-up inside the call (klstm.h "persist_verify"), so that what is reduced is always a real gradient.
+            for l in layers:
+                if isinstance(l, LstmDP) and hasattr(l.e, "set_option"):
+                    l.e.set_option("persist_verify", 1)
         pad4 = lambda n: (n + 3) // 4 * 4                  # every slice starts 16-byte aligned (float4 stores)
         self.blob = alloc(sum(pad4(l.num_params) for l in layers))
         # device layers: the all-reduce is libklstm.so's klstm_allreduce_buffer (RCCL) on the layers' stream

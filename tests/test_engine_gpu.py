@@ -23,14 +23,32 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
 
 
+_LAUNCH_MODE = 1
+
+
+@pytest.fixture(autouse=True)
+def _launch_mode(request):
+    """Every test of this file that builds its engines with make_engine() runs TWICE: with the launch-per-step calls replayed
+    from hipGraphs (option "graph" = 1) and on plain stream launches (0: the product default, what bench.py, the tools and the
+    component tests run).  Parametrized by pytest_generate_tests below; other tests see the default."""
+    global _LAUNCH_MODE
+    _LAUNCH_MODE = getattr(request, "param", 1)
+    yield
+    _LAUNCH_MODE = 1
+
+
+def pytest_generate_tests(metafunc):
+    import inspect
+    src = inspect.getsource(metafunc.function)
+    if metafunc.module.__name__ == __name__ and ("make_engine(" in src or "run_chunks(" in src or "_uses_make_engine" in src):
+        metafunc.parametrize("_launch_mode", [1, 0], ids=["graph", "eager"], indirect=True)
+
+
 def make_engine(I, C, R, S, params):
-    """Engines of this file replay their launch-per-step calls from hipGraphs (option "graph" = 1; the product default is
-    plain launches, which the tools, bench.py, the component tests and every test that sets the option itself run):
-    KLSTM_TEST_GRAPH=0 runs the whole file on plain launches."""
-    import os
+    """See _launch_mode."""
     import kaldi_lstm_amd as k
     e = k.Engine(I, C, R, S)
-    e.set_option("graph", int(os.environ.get("KLSTM_TEST_GRAPH", "1")))
+    e.set_option("graph", _LAUNCH_MODE)
     e.set_params(params)
     return e
 
@@ -534,8 +552,9 @@ def test_affine_backpropagate_wide(N, K, M):
 
 
 def test_fp16_products_option_switches_every_fp16_kernel_off():
-    """"fp16_products" = 0: values beyond the fp16 range go through the output layer's three products (and a fold product) without
-    Inf / NaN; with the default (1) the same calls return non-finite numbers -- the documented range limit (klstm.h)."""
+    """"fp16_products" = 0: nothing runs on fp16 planes -- values beyond the fp16 range go through the output layer's propagate
+    without a single range-guard event.  (With the default, 1, the same call is ALSO finite and exact, at the price of the guard's
+    redo path on its first call: tests/test_range_gpu.py.)"""
     import kaldi_lstm_amd as k
     rng = np.random.RandomState(3)
     N, K, M = 80, 512, 9000
@@ -545,14 +564,18 @@ def test_fp16_products_option_switches_every_fp16_kernel_off():
     e = k.Engine(40, 64, 32, 4)
     ref = (x.double() @ W.double().t()).float()
     try:
+        e.set_option("fp16_products", 1)                  # (clears the guard's counters)
         e.set_option("fp16_products", 0)
         k.affine_propagate(x, W, b, out); torch.cuda.synchronize()
         assert torch.isfinite(out).all() and relerr(out.cpu().numpy(), ref.cpu().numpy()) <= 2e-5
+        assert e.profile_query("fp16_redo")[1] == 0
         e.set_option("fp16_products", 1)
         k.affine_propagate(x, W, b, out); torch.cuda.synchronize()
-        assert not torch.isfinite(out).all()
+        assert torch.isfinite(out).all() and relerr(out.cpu().numpy(), ref.cpu().numpy()) <= 2e-5
+        assert e.profile_query("fp16_redo_nt")[1] > 0
     finally:
         e.set_option("fp16_products", 1)
+        e.close()
 
 
 @pytest.mark.parametrize("N,M", [(80, 16624), (12, 2048), (24, 4203), (7, 33000), (5, 1000)])
@@ -923,7 +946,7 @@ def test_stacked_net_fused_single_rank_equals_the_two_pass_path():
             e.close()
 
 
-def test_config_c3_full_size_net_end_to_end():
+def test_config_c4_full_size_net_end_to_end():
     """BASELINE.json configs[3] at FULL size as ONE net (google/nnet.proto:1-6, README.md:24-29): LstmProjectedStreams 40 -> 800/512,
     LstmProjectedStreams 512 -> 800/512, AffineTransform 512 -> 16624, Softmax, Xent::EvalMasked; 32 streams over 8 GPUs = 4 per
     GPU, T = 20 -> 80 rows, 3 chained minibatches (carried state, momentum 0.9) through DataParallelNnet with ONE 57.6 MB fused
@@ -933,7 +956,7 @@ def test_config_c3_full_size_net_end_to_end():
                                    tol_param=5e-5, tol_grad=3e-4)
 
 
-def test_config_c4_three_layer_bf16_stack():
+def test_config_c5_three_layer_bf16_stack():
     """BASELINE.json configs[4]: 3 x LstmProjectedStreams cell 1024 / proj 512 (40 -> 512 -> 512 -> 512), NumStream 256 over
     8 GPUs = 32 per GPU, T = 20 (640 frames per minibatch -> the gradient products run on the bf16 pipe as well), option
     "bf16" (bf16 operands, fp32 accumulate, fp32 masters; a build extension, the reference is fp32 only).  Two chained

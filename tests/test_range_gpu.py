@@ -1,0 +1,185 @@
+"""Numeric range of the default path = the reference's.
+
+The reference multiplies in fp32 (cblas_sgemm / cublasSgemm, google/matrix/kaldi-matrix.cc:160-175; the products of
+google/nnet/bd-nnet-lstm-projected-streams.h:246,275,312,391,408,457): any finite fp32 operand is legal.  Four products here run
+on two fp16 planes per operand by default (x = h1 + h2 / 2048).  What keeps them inside the reference's
+range:
+
+* upper side -- the range guard (klstm_math.h): an operand at or beyond 65520 turns into Inf in its first plane, which makes every
+  accumulator it meets Inf / NaN; the wave sees that after its K loop and recomputes its outputs in plain fp32, counts the event
+  in a host-mapped word, and the launcher keeps that product on its fp32-range kernel from the next call on
+  (`profile_query("fp16_redo*")`; option "fp16_products" = 1 clears the words);
+* lower side -- derivative operands (out_diff, dgifo) are scaled by a power of two before the split (per column of out_diff in
+  the gradient product, 2^12 in the skinny products) and the result scaled back: entries of 1e-7, where two unscaled planes keep
+  3e-4 relative, come out at fp32 accuracy.
+
+Every test runs with NO option set, compares with float64 / the fp32 oracle, and looks at the counters.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import Oracle, make_params, param_sizes, split_blob
+from tests.test_engine_gpu import check_blob, dev, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _fresh_guard_state():
+    """The guard's counters and the kernels it has switched are process-wide: every test starts and ends on the defaults."""
+    import kaldi_lstm_amd as k
+    e = k.Engine(40, 64, 32, 4)
+    e.set_option("fp16_products", 1)
+    yield e
+    e.set_option("fp16_products", 1)
+    e.close()
+
+
+def _redo(e, which=""):
+    return e.profile_query("fp16_redo" + which)[1]
+
+
+def test_affine_propagate_inputs_beyond_the_fp16_range(_fresh_guard_state):
+    """|x| up to ~4e5 (the case tests/test_engine_gpu.py used to ASSERT non-finite for): finite and within 2e-5 of float64 with no
+    option set; the event is counted; the next call runs on the fp32 kernel (no new event) and agrees too."""
+    import kaldi_lstm_amd as k
+    e = _fresh_guard_state
+    rng = np.random.RandomState(3)
+    N, K, M = 80, 512, 9000
+    x = dev(rng.randn(N, K)) * 1e5
+    W = dev(0.01 * rng.randn(M, K)); b = dev(rng.randn(M))
+    out = torch.empty(N, M, device="cuda")
+    ref = (x.double() @ W.double().t() + b.double()).cpu().numpy()
+    assert _redo(e) == 0
+    k.affine_propagate(x, W, b, out); torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and relerr(out.cpu().numpy(), ref) <= 2e-5
+    n1 = _redo(e, "_nt")
+    assert n1 > 0, "the range guard did not fire: was the f16 kernel taken at all?"
+    out.zero_()
+    k.affine_propagate(x, W, b, out); torch.cuda.synchronize()
+    assert relerr(out.cpu().numpy(), ref) <= 2e-5 and _redo(e, "_nt") == n1       # (fp32 kernel from the second call on)
+    # weights beyond the range instead of inputs
+    e.set_option("fp16_products", 1)
+    x2 = dev(0.01 * rng.randn(N, K)); W2 = W * 1e7                               # |W| up to ~4e5
+    ref2 = (x2.double() @ W2.double().t() + b.double()).cpu().numpy()
+    k.affine_propagate(x2, W2, b, out); torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and relerr(out.cpu().numpy(), ref2) <= 2e-5 and _redo(e, "_nt") > 0
+    # and in range nothing fires
+    e.set_option("fp16_products", 1)
+    x3 = dev(rng.randn(N, K))
+    k.affine_propagate(x3, W, b, out); torch.cuda.synchronize()
+    assert relerr(out.cpu().numpy(), (x3.double() @ W.double().t() + b.double()).cpu().numpy()) <= 2e-5 and _redo(e) == 0
+
+
+@pytest.mark.parametrize("scale", [1e-7, 1e-9, 1.0, 4e5])
+def test_affine_backpropagate_over_fourteen_orders_of_magnitude(_fresh_guard_state, scale):
+    """in_diff = out_diff W for out_diff entries around `scale`: 1e-7 (late-training derivatives: 3e-4 relative on unscaled planes),
+    1e-9, 1, and 4e5 (beyond the planes' range even before the 2^12 of the derivative scale: the guard)."""
+    import kaldi_lstm_amd as k
+    e = _fresh_guard_state
+    rng = np.random.RandomState(11)
+    N, K, M = 80, 512, 16624
+    od = dev(rng.randn(N, M)) * scale
+    W = dev(0.05 * rng.randn(M, K))
+    ind = torch.empty(N, K, device="cuda")
+    ref = (od.double() @ W.double()).cpu().numpy()
+    k.affine_backpropagate(od, W, ind); torch.cuda.synchronize()
+    got = ind.cpu().numpy()
+    assert np.isfinite(got).all() and relerr(got, ref) <= (2e-5 if scale >= 1e-8 else 1e-4)
+    assert (_redo(e, "_skinny") > 0) == (scale > 16)
+
+
+@pytest.mark.parametrize("od_scale,x_scale", [(1e-7, 1.0), (1e-9, 1.0), (1.0, 1.0), (4e5, 1.0), (1.0, 4e5)])
+@pytest.mark.parametrize("update", [False, True])
+def test_affine_gradient_over_fourteen_orders_of_magnitude(_fresh_guard_state, od_scale, x_scale, update):
+    """G = out_diff^T in with every column of out_diff scaled by its own power of two: entries of 1e-7 and 1e-9 at fp32 accuracy
+    (rows of G are compared against their OWN maximum: a frame-independent tolerance would hide small rows behind large ones);
+    `in` beyond the range: the guard, also in the form with the Update in the epilogue (which takes the old momentum / weight
+    values of the tile from their LDS copies)."""
+    import kaldi_lstm_amd as k
+    e = _fresh_guard_state
+    rng = np.random.RandomState(5)
+    N, K, M = 80, 512, 4096
+    od = rng.randn(N, M).astype(np.float32)
+    od[:, ::3] *= 1e-3                                    # columns of very different size next to each other
+    od = dev(od) * od_scale
+    x = dev(rng.randn(N, K)) * x_scale
+    G_ref = (od.double().t() @ x.double()).cpu().numpy()
+    b_ref = od.double().sum(0).cpu().numpy()
+    if not update:
+        G = torch.empty(M, K, device="cuda"); bg = torch.empty(M, device="cuda")
+        k.affine_gradient(x, od, G, bg); torch.cuda.synchronize()
+        got = G.cpu().numpy()
+        assert np.isfinite(got).all()
+        rowmax = np.abs(G_ref).max(1, keepdims=True) + 1e-300
+        assert float((np.abs(got - G_ref) / rowmax).max()) <= 2e-5
+        assert relerr(bg.cpu().numpy(), b_ref) <= 2e-5
+    else:
+        W = dev(0.05 * rng.randn(M, K)); b = dev(rng.randn(M))
+        Wc = dev(0.01 * rng.randn(M, K)); bc = dev(0.01 * rng.randn(M))
+        lr, mmt = 1e-3, 0.9
+        Wc_ref = mmt * Wc.double().cpu().numpy() + G_ref
+        W_ref = W.double().cpu().numpy() - lr * Wc_ref
+        k.affine_update(x, od, W, b, Wc, bc, lr, lr, mmt); torch.cuda.synchronize()
+        assert torch.isfinite(W).all() and torch.isfinite(Wc).all()
+        assert relerr(Wc.cpu().numpy(), Wc_ref) <= 2e-5 and relerr(W.cpu().numpy(), W_ref) <= 2e-5
+    assert (_redo(e, "_outer") > 0) == (x_scale > 65504 or od_scale > 1e30)     # (out_diff is scaled per column: 4e5 is no event)
+
+
+def test_fold_product_with_parameters_beyond_the_fp16_range(_fresh_guard_state):
+    """|W_gifo_r| up to 1e5 (W_r_m correspondingly small, so that the layer still computes something): the fold product of the
+    default path (two fp16 planes written by the Update, klstm_fold3.hip) meets Inf planes, recomputes W_rm in fp32, and the engine
+    moves to three bf16 planes.  Three minibatches of fwd + BPTT + Update against the oracle at the usual tolerances."""
+    import kaldi_lstm_amd as k
+    g = _fresh_guard_state
+    I, C, R, S, T = 40, 800, 512, 4, 20
+    p = make_params(I, C, R, scale=0.01, seed=41).copy()
+    parts = split_blob(p, I, C, R)                        # (views into p)
+    parts["w_gifo_r"] *= 1e7                              # U[-0.01, 0.01] -> up to 1e5
+    parts["w_r_m"] *= 1e-7
+    assert np.abs(parts["w_gifo_r"]).max() > 65520
+    rng = np.random.RandomState(42)
+    o = Oracle(I, C, R, S, np.float32); o.set_params(p)
+    e = k.Engine(I, C, R, S); e.set_params(p)
+    out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+    for step in range(3):
+        x = rng.randn(T * S, I).astype(np.float32); od = (0.1 * rng.randn(T * S, R)).astype(np.float32)
+        xd, odd = dev(x), dev(od)
+        e.propagate(xd, out); e.backpropagate(xd, odd, idf, momentum=0.9, flags=2); e.update(1e-6); e.synchronize()
+        out_o = o.propagate(x); id_o = o.backpropagate(x, od, momentum=0.9); o.update(1e-6)
+        assert np.isfinite(out.cpu().numpy()).all()
+        assert relerr(out.cpu().numpy(), out_o) <= 3e-5 and relerr(idf.cpu().numpy(), id_o) <= 3e-4, step
+        check_blob(e.get_corr(), o.get_corr(), 3e-4, C, R, "corr")
+        check_blob(e.get_params(), o.get_params(), 3e-5, C, R, "params")
+    assert _redo(g, "_fold") > 0, "the range guard of the fold product did not fire"
+    assert e.profile_query("fold_mode")[1] == 1, "the engine did not move to three bf16 planes"
+    e.close()
+
+
+@pytest.mark.parametrize("I,od_scale", [(40, 1e-7), (512, 1e-7), (512, 1e-9), (512, 2000.0)])
+def test_lstm_layer_with_tiny_and_large_out_diff(_fresh_guard_state, I, od_scale):
+    """Whole layer, out_diff entries around 1e-7 / 1e-9 (BPTT is linear in out_diff: every derivative scales along) and around 2000
+    (dgifo x 2^12 passes the planes' range: the guard of the two-job product).  I = 512: d_r / in_diff run as the two-job f16 product
+    on dgifo (the input is too wide for the persistent backward launch); I = 40: inside the persistent launch, fp32 throughout."""
+    import kaldi_lstm_amd as k
+    g = _fresh_guard_state
+    C, R, S, T = 800, 512, 4, 20
+    p = make_params(I, C, R, scale=0.02, seed=51)
+    rng = np.random.RandomState(52)
+    o = Oracle(I, C, R, S, np.float32); o.set_params(p)
+    e = k.Engine(I, C, R, S); e.set_params(p)
+    out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+    for step in range(2):
+        x = rng.randn(T * S, I).astype(np.float32); od = (od_scale * rng.randn(T * S, R)).astype(np.float32)
+        xd, odd = dev(x), dev(od)
+        e.propagate(xd, out); e.backpropagate(xd, odd, idf, momentum=0.0); e.synchronize()
+        o.propagate(x); id_o = o.backpropagate(x, od, momentum=0.0)
+        got = idf.cpu().numpy()
+        assert np.isfinite(got).all() and relerr(got, id_o) <= 3e-4, (step, relerr(got, id_o))
+        check_blob(e.get_corr(), o.get_corr(), 5e-4, C, R, "corr")
+    if I == 512 and od_scale >= 1000:
+        assert _redo(g, "_skinny") > 0
+    else:
+        assert _redo(g) == 0
+    e.close()
