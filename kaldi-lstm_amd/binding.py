@@ -31,12 +31,16 @@ def load_library():
     if _LIB is not None:
         return _LIB
     path = lib_path()
+    alt = os.environ.get("KLSTM_LIB_PATH")             # A-B experiments (tools/): another build of the same sources, loaded as is
     try:                               # no-op unless the sources changed since the library was built (content hash)
+        if alt:
+            path = alt
         import importlib.util
         spec = importlib.util.spec_from_file_location("klstm_build", os.path.join(_HERE, "build.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        mod.build()
+        if not alt:
+            mod.build()
     except Exception as exc:       # noqa: BLE001
         raise KlstmError(-1, f"{path} missing or stale and could not be built with hipcc: {exc}") from exc
     lib = ctypes.CDLL(path)

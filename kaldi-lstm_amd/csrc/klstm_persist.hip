@@ -175,12 +175,14 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // a launch queued behind one that gave up (its status word is still set: the host has not looked yet) must not run: its
-  // inputs are that launch's invalid outputs.  (Workgroup-uniform; the epoch still moves on: finish().)
-  if (a.guard && (__hip_atomic_load(&a.guard[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
-                  __hip_atomic_load(&a.guard[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-    finish(a.ctrl, epoch, T + 2, a.guard ? a.guard + 8 : nullptr);
-    return;
-  }
+  // inputs are that launch's invalid outputs.  Requested here, looked at behind the barrier of step 1 -- behind every role's
+  // prologue loads (loads return in order: the look costs nothing; a branch up here cost 1.1 us per launch).  Before that barrier
+  // a launch only mirrors the carried state into time block 0 of the c / r planes; behind it a skipping launch does nothing.
+  unsigned behind_giveup = 0u;
+#ifndef KLSTM_NO_CHAIN_GUARD
+  if (a.guard) behind_giveup = __hip_atomic_load(&a.guard[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                               __hip_atomic_load(&a.guard[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   // zero both slabs once: pad columns and rows of absent streams stay zero for the whole launch
   for (int i = tid; i < SS * (LDB + LDU); i += PNT) lds[i] = 0.f;
   if (tid == 0) { *abortf = 0u; *projf = 0; *pubcnt = 0; }
@@ -213,6 +215,9 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       cpg[g] = a.prev_c[(size_t)(e_ong[g] ? 4 * g + es : 0) * C + lc];            // carried c(0) (:231)
       if (e_ong[g]) a.cc[(size_t)(4 * g + es) * C + e_cell] = cpg[g];              // time block 0 of the c plane: BPTT reads it (:231)
     }
+    // (the guard word was requested before prev_c and loads return in order: it is here.  Looked at NOW, in front of the weight
+    //  requests -- behind them the compiler waits for ALL of them, and the folded rows are meant to arrive under step 1: 1.3 us)
+    const bool skip_launch = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
     auto cell_math = [&](int t, int g, const f32x4 &v, const float4 &xp) {
       if (!e_ong[g]) return;
       const int es_g = 4 * g + es;                   // the stream
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       PT_MARK(5);
       lds_barrier();                                 // slab of step 1 ready
       PT_MARK(1);
+    if (!skip_launch) {
       f32x4 v1[NG];
 #pragma unroll
       for (int g = 0; g < NG; g++) {
@@ -333,6 +339,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       PT_MARK(4);                                    // cell math + stores
     }
     if (a.rin && !dead) lds_barrier();               // (slab of m(T) for the projection wave)
+    }
   } else if (wave == NCW) {
     // =========================== projection wave: r(t-1) = W_r_m m(t-1) (:312) from the slab of step t ===========================
     // Rows 4*blockIdx .. +3 of W_r_m resident (same 4-row geometry, K = C), the first R/4 workgroups; everything it does
@@ -340,6 +347,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
     // (:328) and, for frame T, the carried r (:331).  rin == 0 / other workgroups: keeps the barrier count only.
     const int kg = lane >> 2, bj = lane & 3;
     const int prow = (int)blockIdx.x * 4 + bj;
+    const bool skip = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;     // (in front of this wave's own requests; it is off the chain until step 2)
     float4 a0[MAXC], a1[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; i++) {
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       a1[i] = proj_on && k + 64 < C ? *reinterpret_cast<const float4 *>(a.wm + (size_t)prow * C + k + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     lds_barrier();                                   // step 1
-    for (int t = 2; t <= T + (a.rin ? 1 : 0); t++) {
+    for (int t = 2; !skip && t <= T + (a.rin ? 1 : 0); t++) {
       lds_barrier();
       if (*abortf) break;
       if (!proj_on) continue;
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       PT_MARK(0);                                    // sweep + slab store
       lds_barrier();
       PT_MARK(1);
-      if (*abortf) break;
+      if (*abortf || __builtin_amdgcn_readfirstlane(behind_giveup) != 0u) break;
     }
   }
   PT_FLUSH(0);

@@ -128,12 +128,14 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
   const long long limit = a.spin_limit;
   const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // queued behind a launch that gave up (status word still set: the host has not looked yet): the planes this launch would read
-  // are invalid -- do nothing (workgroup-uniform; the epoch still moves on)
-  if (a.guard && (__hip_atomic_load(&a.guard[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
-                  __hip_atomic_load(&a.guard[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-    finish(a.ctrl, epoch, ((S + 3) >> 2) * (T + 2), a.guard ? a.guard + 8 : nullptr);
-    return;
-  }
+  // are invalid -- do nothing.  Requested here, looked at by every role behind the loads of its own prologue (loads return in
+  // order: by then the word is there, the look costs nothing; a branch up here cost 1.2 us per launch).  A role that skips
+  // touches nothing global and takes no part in any LDS hand-shake; everybody meets again in finish().
+  unsigned behind_giveup = 0u;
+#ifndef KLSTM_NO_CHAIN_GUARD
+  if (a.guard) behind_giveup = __hip_atomic_load(&a.guard[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                               __hip_atomic_load(&a.guard[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   // the d_r / in_diff columns of this workgroup: 4 rows of W_gifo_r^T (workgroups 0 .. R/4-1), then of W_gifo_x^T
   const int ngr = a.R / 4, ngx = (a.din & 2) ? a.I / 4 : 0;
   const bool d_on = a.din && (int)blockIdx.x < ngr + ngx, d_isr = (int)blockIdx.x < ngr;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
     const float wpi = a.pi[ocell], wpf = a.pf[ocell], wpo = a.po[ocell];
     const float *redf = reinterpret_cast<const float *>(red);
     int np = 0;
-    bool dead = false;
+    bool dead = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
     for (int g = 0; g < ngrp && !dead; g++) {
       const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
       const bool on = lane < 16 && oj < Sg;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
     const float *red2f = reinterpret_cast<const float *>(red2);
     const int fi = (lane >> 2) & 3, fj = lane & 3;   // finishing lanes 0..15 = (column fi, stream fj)
     int nd = 0;
-    bool dead = false;
+    bool dead = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
     for (int g = 0; g < ngrp && !dead; g++) {
       const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
       if (g > 0 && a.pin && !lds_wait_ge(odone, g, abortf, limit)) break;   // (the P rows of the previous group are still being read)
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
     const __amdgpu_buffer_rsrc_t rs_g = buf_rsrc(a.gifo, (T + 2) * S * K * 4), rs_h = buf_rsrc(a.hh, (T + 2) * S * C * 4);
     const __amdgpu_buffer_rsrc_t rs_c = buf_rsrc(a.cc, (T + 2) * S * C * 4);
     int nd = 0;
-    bool dead = false;
+    bool dead = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
     for (int g = 0; g < ngrp && !dead; g++) {
       const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
       const bool need0 = 2 * h < Sg, need1 = 2 * h + 1 < Sg;

@@ -103,21 +103,26 @@ __device__ __forceinline__ bool lds_wait_ge(int *ctr, int target, unsigned *abor
 
 // end of launch: the last workgroup to arrive advances the epoch for the next call (a later launch cannot start before
 // every workgroup of this one has exited, so nobody reads ctrl[0] concurrently)
-// count (or null): the engine's launch counter (persistent launches that have run): the same workgroup moves it on by one.
-// (Read BEFORE the arrival is counted: the last workgroup writes it only after every workgroup has arrived, so whoever reads it
-//  in front of its own arrival -- here, or launch_ordinal() at a give-up -- sees the value the launch started with.)
+// count (or null): the engine's launch counter (persistent launches that have run): the LAST workgroup moves it on by one --
+// nobody else writes it during a launch, so launch_ordinal() at a give-up (always in front of that workgroup's own arrival
+// here) and the last workgroup itself both see the value the launch started with.
 __device__ __forceinline__ unsigned launch_ordinal(const unsigned *guard) {
+#ifdef KLSTM_NO_LAUNCH_COUNT
+  return 0u;
+#else
   return guard ? __hip_atomic_load(guard + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
+#endif
 }
 __device__ __forceinline__ void finish(unsigned *ctrl, unsigned epoch, int ntags, unsigned *count = nullptr) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned seq = count ? __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
     const unsigned old = atomicAdd(&ctrl[1], 1u);
     if (old == gridDim.x - 1) {
       __hip_atomic_store(&ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&ctrl[0], epoch + (unsigned)ntags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (count) __hip_atomic_store(count, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef KLSTM_NO_LAUNCH_COUNT
+      if (count) __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     }
   }
 }
