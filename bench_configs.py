@@ -93,10 +93,23 @@ class _WholeStep:
         torch.cuda.synchronize()
 
 
+_META_OPTIONS = ("whole_step_graph", "eager_loss", "fuse_single_rank")     # options of the bench itself, not of the engines
+
+
+def _apply_options(engines, args):
+    """--option key=value reaches every engine of the net (A-B runs: persist=0, graph=1, ...)."""
+    for kv in args.option:
+        key, val = kv.split("=")
+        if key not in _META_OPTIONS:
+            for e in engines:
+                e.set_option(key, int(val))
+
+
 def _engine_kernels(engines, step, base, nprof=10):
     names = ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj", "k_gates_fold", "k_gemm_rbatch",
              "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step", "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx",
-             "k_fwd_persist", "k_bwd_persist", "k_grads", "k_grads_update", "k_update_repack", "k_pack", "k_apply_momentum")
+             "k_fwd_persist", "k_bwd_persist", "k_fwd_persist_ms", "k_fold_ms", "k_grads", "k_grads_update", "k_update_repack", "k_pack",
+             "k_apply_momentum")
     for e in engines:
         e.set_option("profile", 1)
     for i in range(3):
@@ -200,6 +213,7 @@ def run_c4(args, k):
         e = k.Engine(dims_in[l], C, R, S, stream=stream)
         e.set_params(init_params(dims_in[l], C, R, 30 + l))
         engines.append(e)
+    _apply_options(engines, args)
     W = torch.from_numpy(((rng.rand(NPDF, R) - 0.5) * 0.02).astype(np.float32)).cuda()
     b = torch.zeros(NPDF, device="cuda")
     layers = [k.LstmDP(e) for e in engines] + [k.AffineDP(W, b, k, stream=stream)]
@@ -302,6 +316,7 @@ def run_c5(args, k):
         e.set_params(init_params(dims_in[l], C, R, 40 + l, scale=0.02))
         e.set_option("bf16", 1)
         engines.append(e)
+    _apply_options(engines, args)
     od = 0.1 * torch.randn(T * S, R, device="cuda")
     fused = "fuse_single_rank=0" not in args.option
     layers = [k.LstmDP(e) for e in engines]

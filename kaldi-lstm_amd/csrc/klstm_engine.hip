@@ -109,6 +109,9 @@ struct klstm_engine {
   int use_persist = -1;    // weights-resident persistent chain (klstm_persist.hip): -1 auto (both directions, from 8 frames per
                            // stream), 0 off, 1 forward only, 2 forward and backward whenever the shape allows
   bool fwd_persist = false; // the last propagate ran inside one persistent launch
+  bool fwd_ms = false;      // ... the many-stream bf16 one (klstm_persist_ms.hip): batched x term, launch, batched projection
+  float *wrm_nat = nullptr; // W_rm = W_gifo_r W_r_m as [4C x C] fp32 (a bf16 product, refreshed after every Update) for that launch
+  uint4 *gran_ms = nullptr; // its granule slots
   PersistOpts popt;         // per-engine knobs of the persistent kernels (options persist_waves, persist_tpw, persist_nap*, ...)
   int ncu = 0;              // compute units of the device: every workgroup of a persistent launch needs one of its own
   int persist_tail = 1;     // option "persist_tail": d_r / in_diff inside the persistent backward launch (0: batched products after it)
@@ -436,11 +439,35 @@ static klstm_status poll_persist(klstm_engine *e) {
   return settle(e);
 }
 
-static klstm_status ensure_packs(klstm_engine *e) {
-  if (!e->pk_stale || !e->pk[0]) { e->pk_stale = 0; return KLSTM_OK; }
+static klstm_status ensure_packs(klstm_engine *e, int want = 15) {       // want: bit i = operand array i is about to be read
+  if (!e->pk[0]) { e->pk_stale = 0; return KLSTM_OK; }
+  const int todo = e->pk_stale & want;
+  if (!todo) return KLSTM_OK;
   const Dims d{e->I, e->C, e->R, e->S, 0};
-  HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, e->pk_stale, e->use_bf16, e->stream, probe(e, "k_pack")));
-  e->pk_stale = 0;
+  HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, todo, e->use_bf16, e->stream, probe(e, "k_pack")));
+  e->pk_stale &= ~todo;
+  return KLSTM_OK;
+}
+// the many-stream bf16 forward launch: policy, buffers, refresh of W_rm
+static bool persist_ms_wanted(const klstm_engine *e, int T) {
+  if (e->replaying || e->cooldown > 0 || e->use_persist == 0 || !e->use_bf16 || !e->use_vector || !e->pk[0]) return false;
+  const Dims d{e->I, e->C, e->R, e->S, T};
+  return persist_ms_supported(d) && persist_ms_grid(d) <= e->ncu;
+}
+static klstm_status ensure_ms(klstm_engine *e) {
+  const Dims d{e->I, e->C, e->R, e->S, 0};
+  if (!e->wrm_nat) {
+    HIPCHK(hipMalloc(&e->wrm_nat, (size_t)4 * e->C * e->C * sizeof(float)));
+    const size_t gb = persist_ms_gran_bytes(d);
+    HIPCHK(hipMalloc(&e->gran_ms, gb));
+    HIPCHK(hipMemsetAsync(e->gran_ms, 0, gb, e->stream));
+    e->fold_dirty = true;
+  }
+  if (!e->fold_dirty) return KLSTM_OK;
+  // W_rm [4C x C] = W_gifo_r [4C x R] W_r_m [R x C], both operands rounded to bf16, fp32 accumulate (NT form on W_r_m^T)
+  HIPCHK(launch_gemm_bf16_nt(4 * e->C, e->C, e->R, e->params + e->o_wr(), e->R, e->wmT, e->R, e->wrm_nat, e->C, nullptr, e->stream,
+                             probe(e, "k_fold_ms")));
+  e->fold_dirty = false;
   return KLSTM_OK;
 }
 // need_x: the x chunks of the packed gates operand are read too (launch-per-step folded chain; the persistent kernel
@@ -569,6 +596,8 @@ void klstm_destroy(klstm_engine *e) {
   for (auto *g : e->gran) if (g) (void)hipFree(g);
   if (e->pctrl) (void)hipFree(e->pctrl);
   if (e->fold_scratch) (void)hipFree(e->fold_scratch);
+  if (e->wrm_nat) (void)hipFree(e->wrm_nat);
+  if (e->gran_ms) (void)hipFree(e->gran_ms);
   if (e->pstat_host) (void)hipHostFree(e->pstat_host);
   for (float *p : e->stage) if (p) (void)hipFree(p);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -723,7 +752,7 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
   const Dims d{e->I, e->C, e->R, e->S, T};
   const FwdPtrs p = fwd_ptrs(e);
   hipStream_t st = e->stream;
-  const bool fx = use_fused_x(e) && !(e->fwd_persist && persist_x_batched(d));
+  const bool fx = use_fused_x(e) && !(e->fwd_persist && persist_x_batched(d)) && !e->fwd_ms;
   if (!fx) {  // x -> g,i,f,o for all frames at once + bias (...streams.h:246, :259)
     if (e->use_bf16 && gemm_bf16_nt_supported(T * d.S, d.I, in, in_stride, p.wx, d.I))   // bf16 mode: operands rounded like the fused form's
       HIPCHK(launch_gemm_bf16_nt(T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias,
@@ -734,6 +763,12 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
     else
       HIPCHK(launch_gemm(false, true, T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, 0.f,
                          e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias, st, probe(e, "k_gemm_xproj")));
+  }
+  if (e->fwd_ms) {
+    // many streams, bf16 operands: all T steps of the folded recurrence in one launch, r(1..T) = m(1..T) W_r_m^T (:312) -- rr rows,
+    // the output rows (:328), the carried r (:331) -- riding along
+    HIPCHK(launch_fwd_persist_ms(d, p, e->wrm_nat, out, out_stride, e->gran_ms, e->pctrl, e->popt, st, probe(e, "k_fwd_persist_ms")));
+    return KLSTM_OK;
   }
   if (e->fwd_folded) {
     // step 1 closes over the CARRIED r (set by Reset / the previous minibatch, possibly under older weights): unfolded
@@ -850,26 +885,28 @@ static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
   e->fwd_persist = persist_wanted(e, T);
+  e->fwd_ms = !e->fwd_persist && persist_ms_wanted(e, T);
   if (!e->replaying && e->cooldown > 0) e->cooldown--;       // (counted in minibatches that ran on the launch-per-step chain)
   // launch-per-step kernels are not guarded on the device: nothing of them may be queued behind a persistent launch that
-  // nobody has looked at yet
-  if (!e->fwd_persist && (st = settle(e)) != KLSTM_OK) return st;
+  // nobody has looked at yet (the batched products in front of the many-stream launch only write planes it would have overwritten)
+  if (!e->fwd_persist && !e->fwd_ms && (st = settle(e)) != KLSTM_OK) return st;
   e->bwd_persist = e->fwd_persist && persist_bwd_wanted(e, T);
-  e->fwd_folded = e->fwd_persist || fold_wanted(e, T);
-  if (e->fwd_persist && (st = ensure_persist(e)) != KLSTM_OK) return st;
+  e->fwd_folded = e->fwd_persist || (!e->fwd_ms && fold_wanted(e, T));
+  if ((e->fwd_persist || e->fwd_ms) && (st = ensure_persist(e)) != KLSTM_OK) return st;
+  if (e->fwd_ms && (st = ensure_ms(e)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_fold(e, !e->fwd_persist)) != KLSTM_OK) return st;     // outside the graph: only after an Update
-  if (!e->fwd_folded && (st = ensure_packs(e)) != KLSTM_OK) return st;
+  if (!e->fwd_folded && (st = ensure_packs(e, e->fwd_ms ? 12 : 15)) != KLSTM_OK) return st;     // (the many-stream launch reads the natural matrices; BPTT its packed operands)
   if (e->fwd_folded && !e->fwd_persist && (e->pk_stale & 1) && e->pk[0]) {   // step 1 of the launch-per-step folded chain
     const Dims d0{e->I, e->C, e->R, e->S, 0};
     HIPCHK(launch_pack(d0, e->params, e->wrT, e->wmT, e->wxT, e->pk, 1, e->use_bf16, e->stream, probe(e, "k_pack")));
     e->pk_stale &= ~1;
   }
-  klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, (e->fwd_persist ? -3 : e->fwd_folded ? -2 : -1) * 2 - e->sp);
+  klstm_engine::Key key(T, in, in_stride, out, out_stride, nullptr, 0, 0.f, (e->fwd_ms ? -4 : e->fwd_persist ? -3 : e->fwd_folded ? -2 : -1) * 2 - e->sp);
   st = run_graphed(e, key, [&]() { return seq_forward(e, in, in_stride, out, out_stride, T); },
                    e->fwd_persist && persist_r_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, e->popt));
   if (st != KLSTM_OK) return st;
-  if (e->fwd_persist) {                               // (counted here, not inside the launch sequence: a graph replay is a launch too)
+  if (e->fwd_persist || e->fwd_ms) {                  // (counted here, not inside the launch sequence: a graph replay is a launch too)
     e->pseq++;
     e->persist_dirty = true;
     if (e->nmarks == 8) { for (int i = 1; i < 8; i++) e->marks[i - 1] = e->marks[i]; e->nmarks = 7; }
@@ -887,7 +924,9 @@ static klstm_status do_backpropagate(klstm_engine *e, const float *in, int in_st
   (void)rows;
   const int T = e->T_fwd;
   klstm_status st;
-  if (!e->bwd_persist && (st = settle(e)) != KLSTM_OK) return st;     // (unguarded step kernels read the forward launch's planes)
+  // (Launch-per-step BPTT kernels behind a persistent forward launch nobody has looked at yet are NOT waited for: if that launch gave
+  //  up they compute on invalid planes, but what they write -- derivative planes, in_diff -- is rewritten when the minibatch is run
+  //  again, and the gradient / Update kernels behind them are guarded.)
   if (e->fwd_folded) { klstm_status fs = ensure_fold(e, !e->fwd_persist); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
                         flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0));
@@ -933,7 +972,7 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   klstm_status st = do_propagate(e, in, rows, in_stride, out, out_stride);
   if (st != KLSTM_OK) return st;
   MbRec &r = e->rec;
-  r.have_fwd = true; r.fwd_seq = e->fwd_persist ? e->pseq : 0; r.sp_before = sp0;
+  r.have_fwd = true; r.fwd_seq = (e->fwd_persist || e->fwd_ms) ? e->pseq : 0; r.sp_before = sp0;
   r.in = in; r.rows = rows; r.in_stride = in_stride; r.out = out; r.out_stride = out_stride;
   return verify_now(e);
 }
@@ -1072,7 +1111,7 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
   // while the folded chain is in use only the step-1 gates operand (array 0) is read; the others are refreshed on demand
   // (and with the persistent forward kernel none at all: it reads the natural matrices)
-  const int mask = e->fwd_persist ? 0 : e->fwd_folded ? 1 : 15;
+  const int mask = e->fwd_persist ? 0 : e->fwd_ms ? 12 : e->fwd_folded ? 1 : 15;
   float *foldx = (e->fwd_folded && !e->fwd_persist && !e->use_bf16) ? e->pk_fold[0] : nullptr;
   if (e->pk[0] && (mask || foldx)) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, mask, e->use_bf16, e->stream, probe(e, "k_pack"), foldx));
   e->pk_stale = 15 & ~mask;

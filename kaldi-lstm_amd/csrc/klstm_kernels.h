@@ -162,7 +162,8 @@ hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const 
 // C = A B^T + bias on the bf16 pipe (both operands rounded, fp32 accumulate): the batched x-projection of the bf16 operand mode
 bool gemm_bf16_nt_supported(int M, int K, const float *A, int lda, const float *B, int ldb);
 hipError_t launch_gemm_bf16_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
-                               const float *bias, hipStream_t st, LaunchProbe pr = {});
+                               const float *bias, hipStream_t st, LaunchProbe pr = {}, float *C2 = nullptr, int ldc2 = 0,
+                               float *C3 = nullptr, int tail0 = 0);   // C2: a second copy of the result; C3: rows >= tail0, dense (ld = N)
 bool grads_bf16_tiles(const Dims &d, bool bf16);      // would launch_grads take the bf16 tile path?
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,
@@ -249,6 +250,15 @@ bool persist_tail_in_kernel(const Dims &d, bool want_in_diff, const PersistOpts 
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, const float *out_diff, int od_stride,
                               float *in_diff, int id_stride, bool tail_inside, unsigned long long *gran, unsigned *ctrl,
                               const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});
+
+// Many-stream (9..32) weights-resident forward chain of the bf16 operand mode (klstm_persist_ms.hip): one launch runs all T steps of
+// the folded recurrence; wrm = W_gifo_r W_r_m as [4C x C] fp32 (the caller's bf16 product, once per Update); the x term must be in
+// the gifo plane (batched product); r(1..T) -> rr plane, output rows and carried r come out of the same launch.
+bool persist_ms_supported(const Dims &d);
+int persist_ms_grid(const Dims &d);
+size_t persist_ms_gran_bytes(const Dims &d);
+hipError_t launch_fwd_persist_ms(const Dims &d, const FwdPtrs &p, const float *wrm, float *out, int out_stride, uint4 *gran, unsigned *ctrl,
+                                 const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});
 
 int get_small_max();
 void set_fat_fine(int v);       // A-B knob: half-size row tiles in the many-stream kernels (-1 auto, 0, 1)

@@ -2213,7 +2213,10 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_nt(GemmJob g) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int m = m0 + wr * 64 + i * 16 + 4 * kg + r;
-        if (m < g.M) g.Cm[(size_t)m * g.ldc + n] = e[r] + bv;
+        if (m >= g.M) continue;
+        g.Cm[(size_t)m * g.ldc + n] = e[r] + bv;
+        if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = e[r] + bv;            // (the batched projection: rr rows, output rows, carried r)
+        if (g.C3 && m >= g.tail0) g.C3[(size_t)(m - g.tail0) * g.N + n] = e[r] + bv;
       }
     }
   }
@@ -3178,8 +3181,9 @@ bool gemm_bf16_nt_supported(int M, int K, const float *A, int lda, const float *
   return M >= GRADS_BF16_MIN_ROWS && K >= 128 && K % 8 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B);
 }
 hipError_t launch_gemm_bf16_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
-                               const float *bias, hipStream_t st, LaunchProbe pr) {
-  const GemmJob g = make_job(false, true, M, N, K, A, lda, B, ldb, 0.f, Cm, ldc, bias);
+                               const float *bias, hipStream_t st, LaunchProbe pr, float *C2, int ldc2, float *C3, int tail0) {
+  GemmJob g = make_job(false, true, M, N, K, A, lda, B, ldb, 0.f, Cm, ldc, bias);
+  g.C2 = C2; g.ldc2 = ldc2; g.C3 = C3; g.tail0 = tail0;
   const dim3 block(256);
   if (cdiv(N, BT) * cdiv(M, BT) < 384) {             // few 128 x 128 tiles (640 x 4096: 160 on 256 CUs): 128 x 64
     const dim3 grid(cdiv(cdiv(N, BT / 2) * cdiv(M, BT), 8) * 8);

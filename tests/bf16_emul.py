@@ -24,13 +24,17 @@ def sigmoid(x):
 GRADS_BF16_MIN_ROWS = 256      # klstm_kernels.hip: the gradient products run on the bf16 pipe from this many frames on
 
 
-def minibatch(parts, x, od, c0, r0, S, fuse_x, want_in_diff=True):
+def minibatch(parts, x, od, c0, r0, S, fuse_x, want_in_diff=True, fold=False):
     """parts = [wx, wr, b, pi, pf, po, wm] fp32 arrays; x [T*S, I], od [T*S, R] time-major; c0 [S, C], r0 [S, R].
-    Returns out, in_diff, grads (7 arrays, pure gradient), cT, rT."""
+    Returns out, in_diff, grads (7 arrays, pure gradient), cT, rT.
+    fold: the many-stream weights-resident forward launch (klstm_persist_ms.hip): steps 2..T close over m(t-1) through
+    W_rm = W_gifo_r W_r_m -- itself a bf16 product with fp32 accumulation, its fp32 result rounded to bf16 when the launch loads it;
+    step 1 closes over the carried r as before; r(t) is still bf16(m(t)) x bf16(W_r_m) (output rows, BPTT operands)."""
     wx, wr, b, pi, pf, po, wm = [np.asarray(p, np.float64) for p in parts]
     C, R, I = pi.shape[0], wm.shape[0], wx.shape[1]
     T = x.shape[0] // S
     wrb, wmb, wxb = rb(wr), rb(wm), rb(wx)
+    wrmb = rb((wrb @ wmb).astype(np.float32)) if fold else None       # [4C x C]
     x = np.asarray(x, np.float64)
     f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)
     g = np.zeros((T + 2, S, C)); i = np.zeros_like(g); f = np.zeros_like(g); o = np.zeros_like(g)
@@ -39,7 +43,8 @@ def minibatch(parts, x, od, c0, r0, S, fuse_x, want_in_diff=True):
     x_bf16 = fuse_x or (T * S >= GRADS_BF16_MIN_ROWS and I >= 128)   # the batched x-projection runs on the bf16 pipe from 256 frames and 128 inputs on
     for t in range(1, T + 1):
         xt = x[(t - 1) * S:t * S]
-        a = (rb(xt) @ wxb.T if x_bf16 else f32(xt @ wx.T)) + b + rb(r[t - 1]) @ wrb.T
+        rec = rb(m[t - 1]) @ wrmb.T if (fold and t >= 2) else rb(r[t - 1]) @ wrb.T
+        a = (rb(xt) @ wxb.T if x_bf16 else f32(xt @ wx.T)) + b + rec
         ag, ai, af, ao = a[:, :C], a[:, C:2 * C], a[:, 2 * C:3 * C], a[:, 3 * C:]
         i[t] = sigmoid(ai + c[t - 1] * pi)
         f[t] = sigmoid(af + c[t - 1] * pf)

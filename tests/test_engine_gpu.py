@@ -956,8 +956,11 @@ def test_config_c4_full_size_net_end_to_end():
                                    tol_param=5e-5, tol_grad=3e-4)
 
 
-def test_config_c5_three_layer_bf16_stack():
-    """BASELINE.json configs[4]: 3 x LstmProjectedStreams cell 1024 / proj 512 (40 -> 512 -> 512 -> 512), NumStream 256 over
+@pytest.mark.parametrize("persist", [-1, 0])
+def test_config_c5_three_layer_bf16_stack(persist):
+    """persist = -1 (default): the forward pass of every layer is ONE weights-resident launch (klstm_persist_ms.hip, folded
+    recurrence: bf16_emul fold=True); 0: the launch-per-step chain.
+    BASELINE.json configs[4]: 3 x LstmProjectedStreams cell 1024 / proj 512 (40 -> 512 -> 512 -> 512), NumStream 256 over
     8 GPUs = 32 per GPU, T = 20 (640 frames per minibatch -> the gradient products run on the bf16 pipe as well), option
     "bf16" (bf16 operands, fp32 accumulate, fp32 masters; a build extension, the reference is fp32 only).  Two chained
     minibatches with Update in between.  Checked
@@ -972,7 +975,7 @@ def test_config_c5_three_layer_bf16_stack():
     params = [make_params(dims_in[l], C, R, scale=0.02, seed=92 + l) for l in range(NL)]
     engines, oracles = [], []
     for l in range(NL):
-        e = make_engine(dims_in[l], C, R, S, params[l]); e.set_option("bf16", 1); engines.append(e)
+        e = make_engine(dims_in[l], C, R, S, params[l]); e.set_option("bf16", 1); e.set_option("persist", persist); engines.append(e)
         o = Oracle(dims_in[l], C, R, S, np.float32); o.set_params(params[l]); oracles.append(o)
     pe = [p.astype(np.float32).copy() for p in params]
     corr = [np.zeros(p.size, np.float64) for p in params]
@@ -1005,7 +1008,7 @@ def test_config_c5_three_layer_bf16_stack():
         for l in range(NL):
             parts = [split_blob(pe[l], dims_in[l], C, R)[n] for n, _ in param_sizes(dims_in[l], C, R)]
             xin = acts[l].cpu().numpy(); odl = diffs[l + 1].cpu().numpy()
-            out_m, id_m, grads, cT, rT = bf16_emul.minibatch(parts, xin, odl, c0[l], r0[l], S, fuse_x=0)
+            out_m, id_m, grads, cT, rT = bf16_emul.minibatch(parts, xin, odl, c0[l], r0[l], S, fuse_x=0, fold=persist != 0)
             corr[l] = mmt * corr[l] + np.concatenate([a.ravel() for a in grads])
             assert relerr(acts[l + 1].cpu().numpy(), out_m) <= 6e-3, (ck, l)
             assert relerr(diffs[l].cpu().numpy(), id_m) <= 6e-3, (ck, l)
@@ -1370,3 +1373,73 @@ def test_backpropagate_fuse_update_flag(I, C, R, S, T, persist, clip):
             assert np.array_equal(a, b)
     if clip == 0.0:       # (without clipping the momentum buffer after the Update is what get_corr saw before it)
         assert np.array_equal(res[2][4][-1], res[0][2])
+
+
+@pytest.mark.parametrize("I,C,R,S,T", [(512, 1024, 512, 16, 20), (512, 1024, 512, 32, 20), (40, 1024, 512, 32, 20), (64, 256, 128, 24, 12),
+                                       (72, 160, 96, 13, 21)])
+def test_many_stream_persistent_forward_bf16(I, C, R, S, T):
+    """The weights-resident forward launch for 9..32 streams in bf16 operand mode (klstm_persist_ms.hip): one
+    launch runs all T steps of the folded recurrence, the x term and r(1..T) are batched products around it.  Three chained
+    minibatches (Update in between: W_rm is refreshed; carried state: step 1 closes over r) against tests/bf16_emul.py with
+    fold=True at the tolerance of the launch-per-step bf16 chain (6e-3 of each tensor's maximum), and the engine's own counters say
+    that it WAS this launch.  Shapes: full and half tile counts, a narrow first layer (fp32 batched x term), C / 4 = 64 and 40
+    workgroups, R != 512, a ragged stream tile (13 of 16), an odd T."""
+    from tests import bf16_emul
+    rng = np.random.RandomState(I + C + S)
+    p = make_params(I, C, R, scale=0.03, seed=5)
+    e = make_engine(I, C, R, S, p); e.set_option("bf16", 1); e.set_option("profile", 1)
+    pe = p.astype(np.float32).copy()
+    corr = np.zeros(p.size, np.float64)
+    c0 = np.zeros((S, C)); r0 = np.zeros((S, R))
+    mmt, lr = 0.9, 2e-3
+    out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+    for ck in range(3):
+        x = rng.randn(T * S, I).astype(np.float32); od = (0.3 * rng.randn(T * S, R)).astype(np.float32)
+        xd, odd = dev(x), dev(od)
+        e.propagate(xd, out); e.backpropagate(xd, odd, idf, momentum=mmt); e.synchronize()
+        parts = [split_blob(pe, I, C, R)[n] for n, _ in param_sizes(I, C, R)]
+        out_m, id_m, grads, cT, rT = bf16_emul.minibatch(parts, x, od, c0, r0, S, fuse_x=0, fold=True)
+        corr = mmt * corr + np.concatenate([a.ravel() for a in grads])
+        assert relerr(out.cpu().numpy(), out_m) <= 6e-3, ck
+        assert relerr(idf.cpu().numpy(), id_m) <= 6e-3, ck
+        check_blob(e.get_corr(), corr, 6e-3, C, R, f"chunk {ck}: corr")
+        cs, rs = e.get_state()
+        assert relerr(cs, cT) <= 6e-3 and relerr(rs, rT) <= 6e-3
+        c0, r0 = cs.astype(np.float64), rs.astype(np.float64)
+        e.update(lr)
+        pe = (pe.astype(np.float64) - lr * corr).astype(np.float32)
+    assert e.profile_query("k_fwd_persist_ms")[1] == 3 and e.profile_query("k_gates_step")[1] == 0
+    assert e.profile_query("persist_giveups")[1] == 0
+    e.close()
+
+
+def test_many_stream_persistent_forward_gives_up_and_is_run_again():
+    """The many-stream launch under the same give-up protocol as the small chain: workgroup 0 withholds its publishes of step 4,
+    every sweep of step 5 expires; the minibatch is run again on the launch-per-step chain -- bit-identical to a twin that never used
+    the launch -- and the engine returns to it after the cool-down."""
+    import kaldi_lstm_amd as k
+    I, C, R, S, T = 512, 1024, 512, 32, 20
+    p = make_params(I, C, R, scale=0.02, seed=15)
+    rng = np.random.RandomState(16)
+    e = k.Engine(I, C, R, S); e.set_params(p); e.set_option("bf16", 1)
+    t = k.Engine(I, C, R, S); t.set_params(p); t.set_option("bf16", 1); t.set_option("persist", 0)
+    e.set_option("persist_spin_us", 3000); e.set_option("persist_cooldown", 1); e.set_option("profile", 1)
+    e.set_option("persist_test_stall_fwd", 4)
+    bufs = lambda: (torch.empty(T * S, R, device="cuda"), torch.empty(T * S, I, device="cuda"))
+    (out, idf), (out_t, idf_t) = bufs(), bufs()
+    for step in range(3):
+        x = rng.randn(T * S, I).astype(np.float32); od = (0.3 * rng.randn(T * S, R)).astype(np.float32)
+        xd, odd = dev(x), dev(od)
+        for eng, o_, i_ in ((e, out, idf), (t, out_t, idf_t)):
+            eng.propagate(xd, o_); eng.backpropagate(xd, odd, i_, momentum=0.9); eng.update(1e-3); eng.synchronize()
+        if step == 0:
+            e.set_option("persist_test_stall_fwd", 0)
+            assert e.profile_query("persist_giveups")[1] == 1 and e.profile_query("persist_replayed")[1] == 1
+        if step < 2:                                   # the re-run minibatch and the cool-down minibatch: the twin's bits
+            for name, u, v in (("out", out.cpu().numpy(), out_t.cpu().numpy()), ("in_diff", idf.cpu().numpy(), idf_t.cpu().numpy()),
+                               ("corr", e.get_corr(), t.get_corr()), ("params", e.get_params(), t.get_params())):
+                assert np.array_equal(u, v), f"minibatch {step}: {name} differs from the twin's (max abs diff {np.abs(u - v).max():.3g})"
+        else:                                          # back on the weights-resident launch: bf16 rounding of a different chain
+            assert relerr(out.cpu().numpy(), out_t.cpu().numpy()) <= 2e-2
+    assert e.profile_query("k_fwd_persist_ms")[1] == 2 and e.profile_query("persist_giveups")[1] == 1
+    e.close(); t.close()
