@@ -110,7 +110,7 @@ struct klstm_engine {
                            // stream), 0 off, 1 forward only, 2 forward and backward whenever the shape allows
   bool fwd_persist = false; // the last propagate ran inside one persistent launch
   bool fwd_ms = false;      // ... the many-stream bf16 one (klstm_persist_ms.hip): batched x term, launch, batched projection
-  float *wrm_nat = nullptr; // W_rm = W_gifo_r W_r_m as [4C x C] fp32 (a bf16 product, refreshed after every Update) for that launch
+  unsigned short *wrm_l = nullptr;   // W_rm = W_gifo_r W_r_m as bf16, logical rows x C (a bf16 product, refreshed after every Update) for that launch
   uint4 *gran_ms = nullptr; // its granule slots
   PersistOpts popt;         // per-engine knobs of the persistent kernels (options persist_waves, persist_tpw, persist_nap*, ...)
   int ncu = 0;              // compute units of the device: every workgroup of a persistent launch needs one of its own
@@ -456,17 +456,19 @@ static bool persist_ms_wanted(const klstm_engine *e, int T) {
 }
 static klstm_status ensure_ms(klstm_engine *e) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
-  if (!e->wrm_nat) {
-    HIPCHK(hipMalloc(&e->wrm_nat, (size_t)4 * e->C * e->C * sizeof(float)));
+  if (!e->wrm_l) {
+    HIPCHK(hipMalloc(&e->wrm_l, (size_t)4 * e->C * e->C * sizeof(unsigned short)));
     const size_t gb = persist_ms_gran_bytes(d);
     HIPCHK(hipMalloc(&e->gran_ms, gb));
     HIPCHK(hipMemsetAsync(e->gran_ms, 0, gb, e->stream));
-    e->fold_dirty = true;
+    if (!e->fold_scratch) HIPCHK(hipMalloc(&e->fold_scratch, fold_bf16x3_scratch_bytes(d)));
+    e->fold_dirty = true; e->planes_fresh = false;
   }
   if (!e->fold_dirty) return KLSTM_OK;
-  // W_rm [4C x C] = W_gifo_r [4C x R] W_r_m [R x C], both operands rounded to bf16, fp32 accumulate (NT form on W_r_m^T)
-  HIPCHK(launch_gemm_bf16_nt(4 * e->C, e->C, e->R, e->params + e->o_wr(), e->R, e->wmT, e->R, e->wrm_nat, e->C, nullptr, e->stream,
-                             probe(e, "k_fold_ms")));
+  // W_rm [4C x C] = W_gifo_r [4C x R] W_r_m [R x C], both operands rounded to bf16 (one plane each: written by the Update, or by
+  // a split pass when the parameters changed some other way), fp32 accumulate, stored as bf16 (klstm_fold3.hip)
+  HIPCHK(launch_fold_ms(d, e->params + e->o_wr(), e->wmT, e->fold_scratch, e->wrm_l, e->stream, probe(e, "k_split3"), probe(e, "k_fold_ms"),
+                        e->planes_fresh));
   e->fold_dirty = false;
   return KLSTM_OK;
 }
@@ -596,7 +598,7 @@ void klstm_destroy(klstm_engine *e) {
   for (auto *g : e->gran) if (g) (void)hipFree(g);
   if (e->pctrl) (void)hipFree(e->pctrl);
   if (e->fold_scratch) (void)hipFree(e->fold_scratch);
-  if (e->wrm_nat) (void)hipFree(e->wrm_nat);
+  if (e->wrm_l) (void)hipFree(e->wrm_l);
   if (e->gran_ms) (void)hipFree(e->gran_ms);
   if (e->pstat_host) (void)hipHostFree(e->pstat_host);
   for (float *p : e->stage) if (p) (void)hipFree(p);
@@ -767,7 +769,7 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
   if (e->fwd_ms) {
     // many streams, bf16 operands: all T steps of the folded recurrence in one launch, r(1..T) = m(1..T) W_r_m^T (:312) -- rr rows,
     // the output rows (:328), the carried r (:331) -- riding along
-    HIPCHK(launch_fwd_persist_ms(d, p, e->wrm_nat, out, out_stride, e->gran_ms, e->pctrl, e->popt, st, probe(e, "k_fwd_persist_ms")));
+    HIPCHK(launch_fwd_persist_ms(d, p, e->wrm_l, out, out_stride, e->gran_ms, e->pctrl, e->popt, st, probe(e, "k_fwd_persist_ms")));
     return KLSTM_OK;
   }
   if (e->fwd_folded) {
@@ -1101,9 +1103,12 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
     e->mmt_pending = false;
     // (data-parallel order: gradient -> all-reduce -> this) the planes of the fold operands come out of the same pass
     GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
-    e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d, e->fold_mode) &&
+    e->planes_fresh = e->fold_scratch && (e->fwd_ms || (e->fwd_folded && fold_bf16x3_supported(d, e->fold_mode))) &&
                       update_repack_vectorised(d, e->params, e->corr, fold_grad, e->wrT, e->wmT, e->wxT);
-    if (e->planes_fresh) { fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane); u.split_mode = e->fold_mode == 2 ? 2 : 1; }
+    if (e->planes_fresh) {
+      fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
+      u.split_mode = e->fwd_ms ? 3 : e->fold_mode == 2 ? 2 : 1;        // (the many-stream bf16 launch: the operands themselves as bf16)
+    }
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
                                 e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr));
   }

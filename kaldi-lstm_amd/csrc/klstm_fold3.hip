@@ -57,7 +57,7 @@ struct Split3Args {
   unsigned short *dst[2];
   size_t plane[2];       // elements per plane
   size_t n8[2];          // groups of 8 elements
-  int mode;              // 1: three bf16 planes, 2: two fp16 planes (klstm_math.h f16_split2)
+  int mode;              // 1: three bf16 planes, 2: two fp16 planes (klstm_math.h f16_split2), 3: one bf16 plane
 };
 
 __global__ __launch_bounds__(256) void k_split3(Split3Args a) {
@@ -72,12 +72,13 @@ __global__ __launch_bounds__(256) void k_split3(Split3Args a) {
     for (int e = 0; e < 8; e++) {
       unsigned short b1, b2, b3 = 0;
       if (a.mode == 2) f16_split2(v[e], b1, b2);
+      else if (a.mode == 3) { b1 = bf16_rne(v[e]); b2 = 0; }
       else bf16_split3(v[e], b1, b2, b3);
       h1[e] = b1; h2[e] = b2; h3[e] = b3;
     }
     *reinterpret_cast<u16x8_t *>(a.dst[w] + i) = h1;
-    *reinterpret_cast<u16x8_t *>(a.dst[w] + a.plane[w] + i) = h2;
-    if (a.mode != 2) *reinterpret_cast<u16x8_t *>(a.dst[w] + 2 * a.plane[w] + i) = h3;
+    if (a.mode != 3) *reinterpret_cast<u16x8_t *>(a.dst[w] + a.plane[w] + i) = h2;
+    if (a.mode == 1) *reinterpret_cast<u16x8_t *>(a.dst[w] + 2 * a.plane[w] + i) = h3;
   }
 }
 
@@ -90,6 +91,7 @@ struct Fold3Args {
   size_t a_plane, b_plane;
   float4 *pk1; int nch1;
   float4 *pk2; int nch2;
+  unsigned short *wl;         // (NPL = 1) instead of pk1 / pk2: W_rm as bf16, LOGICAL rows (4 cell + gate) x C columns -- klstm_persist_ms.hip reads 16 consecutive rows per workgroup
   int nbn, nwg;
 #ifdef KLSTM_FOLD3_TIMING
   long long *dbg;             // per workgroup: shader clocks at entry / first operands / end of the K loop / exit (tools/fold3_probe.hip)
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
   constexpr int NA = NPL * (BM / 16), NQ = NA + NPL * (BN / 16);           // DMA instructions of a stage (1 KB each)
   constexpr int NJ = (NQ + 3) / 4;                                     // per wave
   constexpr int FLD = WM + 4;                                          // epilogue transpose: floats per column
-  static_assert(4 * WN * FLD * 4 <= NBUF * STG, "epilogue transpose does not fit the staging buffers");
+  static_assert(NPL == 1 || 4 * WN * FLD * 4 <= NBUF * STG, "epilogue transpose does not fit the staging buffers");   // (NPL = 1: the launcher sizes the LDS for the transpose)
   static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * NJ <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -206,7 +208,12 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
 #pragma unroll
     for (int ni = 0; ni < (NPL == 2 ? NI : 1); ni++) accx[mi][ni] = (f32x4){0, 0, 0, 0};
   auto multiply = [&](const bf16x8_t (&af)[NPL][MI], const bf16x8_t (&bf)[NPL][NI]) {
-    if constexpr (NPL == 3) {
+    if constexpr (NPL == 1) {
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+    } else if constexpr (NPL == 3) {
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
 #pragma unroll
       for (int t = 0; t < 6; t++)
@@ -295,6 +302,20 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
   if (LW) __syncthreads();                                             // with loader waves the two packed operands are written by different waves
   else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int cell0 = m0 >> 2;
+  if (a.wl) {
+    // bf16 operand mode: rows in LOGICAL order (row m0 + 16 tl + i = 4 cell + gate), four consecutive columns per lane -> 8 bytes of bf16
+    if (!loader)
+#pragma unroll
+      for (int it = 0; it < MI * NI; it++) {
+        const int tl = it / NI, nq = (it % NI) * 4 + kg, i = i16;
+        const int nl = 4 * nq, n = n0 + nl, x = m0 + tl * 16 + i;
+        const float *cp = cs + nl * FLD + tl * 16 + i;
+        if ((x >> 2) < C && n < C)
+          *reinterpret_cast<uint2 *>(a.wl + (size_t)x * C + n) = make_uint2(bf16_rne(cp[0]) | ((unsigned)bf16_rne(cp[FLD]) << 16),
+                                                                           bf16_rne(cp[2 * FLD]) | ((unsigned)bf16_rne(cp[3 * FLD]) << 16));
+      }
+    return;
+  }
   // gates operand: piece = (16-row tile tl, column quad nq, row i): 16 consecutive float4 (256 B) per (tl, nq)
   if (!loader)
 #pragma unroll
@@ -378,6 +399,46 @@ static hipError_t launch_fold_planes(const Fold3Args &a, hipStream_t st, LaunchP
   return hipGetLastError();
 }
 
+// The fold product of the bf16 operand mode: W_rm = bf16(W_gifo_r) bf16(W_r_m) with fp32 accumulation, stored as bf16 in logical-row
+// order (wl, [4C x C]).  scratch: plane 0 of each operand (mode 3 of the split; written by the Update when planes_fresh).
+// 128 x 128 tiles: 256 workgroups at 1024 / 512 = one round of the chip.
+hipError_t launch_fold_ms(const Dims &d, const float *wr, const float *wmT, void *scratch, unsigned short *wl, hipStream_t st,
+                          LaunchProbe pr_split, LaunchProbe pr, bool planes_fresh) {
+  constexpr int MI = 4, NI = 4, NBUF = 3;
+  unsigned short *a3 = static_cast<unsigned short *>(scratch);
+  const size_t apl = (size_t)4 * d.C * d.R, bpl = (size_t)d.C * d.R;
+  unsigned short *b3 = a3 + 3 * apl;
+  if (!planes_fresh) {
+    Split3Args s;
+    s.src[0] = wr; s.src[1] = wmT; s.dst[0] = a3; s.dst[1] = b3; s.plane[0] = apl; s.plane[1] = bpl;
+    s.n8[0] = apl / 8; s.n8[1] = bpl / 8;
+    s.mode = 3;
+    const unsigned sgrid = (unsigned)std::min<size_t>((s.n8[0] + s.n8[1] + 255) / 256, 2048);
+    if (pr_split.start) hipExtLaunchKernelGGL(k_split3, dim3(sgrid), dim3(256), 0, st, pr_split.start, pr_split.stop, 0, s);
+    else hipLaunchKernelGGL(k_split3, dim3(sgrid), dim3(256), 0, st, s);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+  }
+  Fold3Args a;
+#ifdef KLSTM_FOLD3_TIMING
+  a.dbg = g_fold3_dbg;
+#endif
+  a.C = d.C; a.R = d.R; a.wr = wr; a.wmT = wmT; a.redo = nullptr;
+  a.a3 = a3; a.b3 = b3; a.a_plane = apl; a.b_plane = bpl;
+  a.pk1 = nullptr; a.nch1 = 0; a.pk2 = nullptr; a.nch2 = 0; a.wl = wl;
+  a.nbn = (d.C + 32 * NI - 1) / (32 * NI);
+  a.nwg = ((4 * d.C + 32 * MI - 1) / (32 * MI)) * a.nbn;
+  constexpr int stage = NBUF * 1 * (32 * MI + 32 * NI) * 64, transp = 4 * 16 * NI * (16 * MI + 4) * 4;
+  constexpr int shm = stage > transp ? stage : transp;
+  auto kern = k_fold_bf16x3<MI, NI, NBUF, false, true, 1>;
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+  if (err != hipSuccess) return err;
+  const dim3 grid((a.nwg + 7) / 8 * 8), block(512);
+  if (pr.start) hipExtLaunchKernelGGL(kern, grid, block, shm, st, pr.start, pr.stop, 0, a);
+  else hipLaunchKernelGGL(kern, grid, block, shm, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_fold_bf16x3(const Dims &d, int mode, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
                               int nch2, hipStream_t st, LaunchProbe pr_split, LaunchProbe pr, bool planes_fresh) {
   constexpr int MI = 4, NI = 3;
@@ -403,7 +464,7 @@ hipError_t launch_fold_bf16x3(const Dims &d, int mode, const float *wr, const fl
   a.C = d.C; a.R = d.R; a.wr = wr; a.wmT = wmT; a.redo = redo_counters() ? redo_counters() + REDO_FOLD : nullptr;
   a.a3 = a3; a.b3 = b3; a.a_plane = apl; a.b_plane = bpl;
   a.pk1 = reinterpret_cast<float4 *>(pk_fold[0]); a.nch1 = nch1;
-  a.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); a.nch2 = nch2;
+  a.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); a.nch2 = nch2; a.wl = nullptr;
   a.nbn = (d.C + 32 * NI - 1) / (32 * NI);
   a.nwg = ((4 * d.C + 32 * MI - 1) / (32 * MI)) * a.nbn;
   return s.mode == 2 ? launch_fold_planes<2>(a, st, pr) : launch_fold_planes<3>(a, st, pr);

@@ -98,6 +98,10 @@ size_t fold_bf16x3_scratch_bytes(const Dims &d);
 hipError_t launch_fold_bf16x3(const Dims &d, int mode, const float *wr, const float *wmT, void *scratch, float *pk_fold[2], int nch1,
                               int nch2, hipStream_t st, LaunchProbe pr_split = {}, LaunchProbe pr = {}, bool planes_fresh = false);
                               // planes_fresh: the split pass is skipped (the fused Update wrote the planes: GradsUpdate::a3 / b3)
+// the fold product of the bf16 operand mode (klstm_persist_ms.hip): one bf16 plane per operand (split mode 3), result as bf16 in
+// logical-row order [4C x C]
+hipError_t launch_fold_ms(const Dims &d, const float *wr, const float *wmT, void *scratch, unsigned short *wl, hipStream_t st,
+                          LaunchProbe pr_split = {}, LaunchProbe pr = {}, bool planes_fresh = false);
 void fold_bf16x3_planes(const Dims &d, void *scratch, unsigned short **a3, long *a_plane, unsigned short **b3, long *b_plane);
 hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
                        hipStream_t st, LaunchProbe pr = {}, LaunchProbe pr2 = {}, void *scratch3 = nullptr, LaunchProbe pr3 = {},
@@ -252,12 +256,12 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
                               const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});
 
 // Many-stream (9..32) weights-resident forward chain of the bf16 operand mode (klstm_persist_ms.hip): one launch runs all T steps of
-// the folded recurrence; wrm = W_gifo_r W_r_m as [4C x C] fp32 (the caller's bf16 product, once per Update); the x term must be in
+// the folded recurrence; wrm = W_gifo_r W_r_m as bf16, logical rows (4 cell + gate) x C (launch_fold_ms, once per Update); the x term must be in
 // the gifo plane (batched product); r(1..T) -> rr plane, output rows and carried r come out of the same launch.
 bool persist_ms_supported(const Dims &d);
 int persist_ms_grid(const Dims &d);
 size_t persist_ms_gran_bytes(const Dims &d);
-hipError_t launch_fwd_persist_ms(const Dims &d, const FwdPtrs &p, const float *wrm, float *out, int out_stride, uint4 *gran, unsigned *ctrl,
+hipError_t launch_fwd_persist_ms(const Dims &d, const FwdPtrs &p, const unsigned short *wrm, float *out, int out_stride, uint4 *gran, unsigned *ctrl,
                                  const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});
 
 int get_small_max();

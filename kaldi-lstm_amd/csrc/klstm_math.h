@@ -134,8 +134,13 @@ __device__ __forceinline__ float redo_dot(const float *a, long sa, const float *
 // at 16 and above the range guard takes over.
 constexpr float DERIV_SCALE = 4096.f, DERIV_UNSCALE = 1.f / 4096.f;
 
-// mode 1: three bf16 planes, mode 2: two fp16 planes (plane 1 scaled by 2^11)
+// mode 1: three bf16 planes, mode 2: two fp16 planes (plane 1 scaled by 2^11), mode 3: ONE bf16 plane (the operand itself rounded
+// to bf16: the fold product of the bf16 operand mode, klstm_persist_ms.hip)
 __device__ __forceinline__ void split_store4(int mode, const float (&v)[4], unsigned short *dst, long plane) {
+  if (mode == 3) {
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(bf16_rne(v[0]) | ((unsigned)bf16_rne(v[1]) << 16), bf16_rne(v[2]) | ((unsigned)bf16_rne(v[3]) << 16));
+    return;
+  }
   if (mode != 2) { bf16_split3_store4(v, dst, plane); return; }
   unsigned h[2][2];
   f16_split2_pair(v[0], v[1], h[0][0], h[1][0]);

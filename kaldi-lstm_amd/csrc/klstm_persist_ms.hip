@@ -23,7 +23,7 @@
 // Step 1 closes over the CARRIED r (possibly produced under older weights): contracted against the natural W_gifo_r rows
 // (K = R), which die after it.
 // Rounding = that of the bf16 operand mode: weights and the staged activations (m, r(0)) to bf16 (RNE), fp32 accumulate, planes
-// fp32; W_rm itself is the fp32 result of a bf16 product, rounded to bf16 when it is loaded (tests/bf16_emul.py fold = True).
+// fp32; W_rm itself is a bf16 product with fp32 accumulation, rounded to bf16 when it is stored (tests/bf16_emul.py fold = True).
 #include "klstm_kernels.h"
 #include "klstm_math.h"
 #include "klstm_persist_dev.h"
@@ -39,7 +39,7 @@ typedef __bf16 ms_bf16x8 __attribute__((ext_vector_type(8)));
 struct PersistMsArgs {
   int C, R, S, T;
   int ldrow;                      // bytes per LDS slab row: 2 max(C, R) + 16
-  const float *wrm;               // folded W_rm [4C x C], rows in g,i,f,o blocks of C (fp32 result of the bf16 fold product)
+  const unsigned short *wrm;      // folded W_rm as bf16, LOGICAL rows (4 cell + gate) x C: the 16 rows of workgroup wg are rows 16 wg .. 16 wg + 15 (launch_fold_ms)
   const float *wr;                // natural W_gifo_r [4C x R] (step 1)
   const float *wm;                // natural W_r_m [R x C]: r(t) = W_r_m m(t) (:312) is contracted here too, 16 rows per workgroup (the first R / 16)
   float *out; int out_stride;     // output rows [T*S x R] (:328)
@@ -112,7 +112,8 @@ __global__ __launch_bounds__((4 + NSW) * 64) void k_fwd_persist_ms(PersistMsArgs
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int cf = wave * cw + j;
-      af[j] = ms_load8(a.wrm + arow * C + 32 * cf + 8 * kg, j < cw && cf < nch);
+      af[j] = (j < cw && cf < nch) ? *reinterpret_cast<const ms_bf16x8 *>(a.wrm + (size_t)(16 * wg + i16) * C + 32 * cf + 8 * kg)
+                                   : (ms_bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
     const unsigned char *brow = slab + i16 * ldrow + 16 * kg;
     // r(t-1) = W_r_m m(t-1) (:312) rides along from step 2 on: the slab of step t IS m(t-1) of all cells.  The first R / 16
@@ -254,6 +255,8 @@ __global__ __launch_bounds__((4 + NSW) * 64) void k_fwd_persist_ms(PersistMsArgs
         u32x4 q[PG];
         bool ok = false;
         const long long t0 = wall_clock64();
+        // (every pass asks for ALL of the thread's granules again: asking only for the missing ones -- predicated loads -- measured
+        //  slower, 100.6 vs 94.8 us per launch at 32 streams: the loads of a pass then leave one by one)
         for (unsigned spins = 0;; spins++) {
 #pragma unroll
           for (int i = 0; i < PG; i++) {
@@ -318,7 +321,7 @@ static hipError_t ms_launch(const PersistMsArgs &a, int grid, size_t shm, hipStr
   return hipGetLastError();
 }
 
-hipError_t launch_fwd_persist_ms(const Dims &d, const FwdPtrs &p, const float *wrm, float *out, int out_stride, uint4 *gran, unsigned *ctrl,
+hipError_t launch_fwd_persist_ms(const Dims &d, const FwdPtrs &p, const unsigned short *wrm, float *out, int out_stride, uint4 *gran, unsigned *ctrl,
                                  const PersistOpts &o, hipStream_t st, LaunchProbe pr) {
   if (!persist_ms_supported(d) || !wrm || !gran || !out) return hipErrorInvalidValue;
   PersistMsArgs a;
