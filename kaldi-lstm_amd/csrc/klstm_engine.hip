@@ -104,6 +104,7 @@ struct klstm_engine {
   int use_fold = -1;       // folded recurrence (W_rm = W_gifo_r W_r_m): -1 auto, 0 off, 1 on (whenever the shape allows)
   bool foldx_fresh = false; // the W_x chunks of pk_fold[0] were written by the last k_pack
   bool fold_dirty = true;  // W_rm / its packed copies are older than the parameters
+  bool pk2_fresh = false;  // the last fold product also wrote the 4-row array W_rm^T (pk_fold[1]: only the launch-per-step folded BPTT reads it)
   int pk_stale = 0;        // unfolded operand arrays (bits 1..3) not refreshed by the last Update because the folded path is in use
   bool fwd_folded = false; // the last propagate ran the folded chain (its backpropagate follows suit)
   int use_persist = -1;    // weights-resident persistent chain (klstm_persist.hip): -1 auto (both directions, from 8 frames per
@@ -474,7 +475,7 @@ static klstm_status ensure_ms(klstm_engine *e) {
 }
 // need_x: the x chunks of the packed gates operand are read too (launch-per-step folded chain; the persistent kernel
 // takes W_gifo_x from the natural matrix)
-static klstm_status ensure_fold(klstm_engine *e, bool need_x) {
+static klstm_status ensure_fold(klstm_engine *e, bool need_x, bool need_pk2 = true) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
   if (!e->pk_fold[0]) {
     long nf[2];
@@ -486,7 +487,7 @@ static klstm_status ensure_fold(klstm_engine *e, bool need_x) {
     e->fold_dirty = true;
   }
   const bool pack_x = need_x && !e->foldx_fresh;
-  if (!e->fold_dirty && !pack_x) return KLSTM_OK;
+  if (!e->fold_dirty && !pack_x && !(need_pk2 && !e->pk2_fresh)) return KLSTM_OK;
   if (e->fold_mode == 2 && redo_count(REDO_FOLD) != 0) {
     // range guard (klstm_math.h): a parameter passed the fp16 range -- the product was recomputed in fp32 where it mattered; from
     // here on three bf16 planes (fp32 range, six products instead of three), engines of this process alike
@@ -496,11 +497,13 @@ static klstm_status ensure_fold(klstm_engine *e, bool need_x) {
   }
   if (!e->fold_scratch && fold_bf16x3_supported(d, e->fold_mode)) HIPCHK(hipMalloc(&e->fold_scratch, fold_bf16x3_scratch_bytes(d)));
   const bool f3 = e->fold_scratch && fold_bf16x3_supported(d, e->fold_mode);
-  HIPCHK(launch_fold(d, e->params, e->wmT, e->pk_fold, pack_x, e->stream, probe(e, "k_fold"),
+  float *pkw[2] = {e->pk_fold[0], need_pk2 ? e->pk_fold[1] : nullptr};
+  HIPCHK(launch_fold(d, e->params, e->wmT, pkw, pack_x, e->stream, probe(e, "k_fold"),
                      pack_x ? probe(e, "k_pack_foldx") : LaunchProbe(), f3 ? e->fold_scratch : nullptr,
                      f3 ? probe(e, "k_split3") : LaunchProbe(), f3 && e->planes_fresh, e->fold_mode));
   if (pack_x) e->foldx_fresh = true;
   e->fold_dirty = false;
+  e->pk2_fresh = need_pk2;
   return KLSTM_OK;
 }
 
@@ -743,6 +746,8 @@ static BwdPtrs bwd_ptrs(klstm_engine *e) {
   p.pk_dr = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[2]) : nullptr;
   p.pk_dm = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[3]) : nullptr;
   p.pk_fold = reinterpret_cast<const float4 *>(e->pk_fold[1]);
+  p.pk_fold_gates = reinterpret_cast<const float4 *>(e->pk_fold[0]);
+  p.nch_gates = (e->C + 31) / 32 + (e->I + 31) / 32;
   p.fat = e->use_fat;
   p.bf16 = e->use_bf16;
   return p;
@@ -897,7 +902,8 @@ static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int
   if ((e->fwd_persist || e->fwd_ms) && (st = ensure_persist(e)) != KLSTM_OK) return st;
   if (e->fwd_ms && (st = ensure_ms(e)) != KLSTM_OK) return st;
   if (e->fwd_folded && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
-  if (e->fwd_folded && (st = ensure_fold(e, !e->fwd_persist)) != KLSTM_OK) return st;     // outside the graph: only after an Update
+  // (the persistent backward launch takes its columns of W_rm from the gates-order operand: the second layout is not written then)
+  if (e->fwd_folded && (st = ensure_fold(e, !e->fwd_persist, !e->bwd_persist)) != KLSTM_OK) return st;     // outside the graph: only after an Update
   if (!e->fwd_folded && (st = ensure_packs(e, e->fwd_ms ? 12 : 15)) != KLSTM_OK) return st;     // (the many-stream launch reads the natural matrices; BPTT its packed operands)
   if (e->fwd_folded && !e->fwd_persist && (e->pk_stale & 1) && e->pk[0]) {   // step 1 of the launch-per-step folded chain
     const Dims d0{e->I, e->C, e->R, e->S, 0};
@@ -929,7 +935,7 @@ static klstm_status do_backpropagate(klstm_engine *e, const float *in, int in_st
   // (Launch-per-step BPTT kernels behind a persistent forward launch nobody has looked at yet are NOT waited for: if that launch gave
   //  up they compute on invalid planes, but what they write -- derivative planes, in_diff -- is rewritten when the minibatch is run
   //  again, and the gradient / Update kernels behind them are guarded.)
-  if (e->fwd_folded) { klstm_status fs = ensure_fold(e, !e->fwd_persist); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
+  if (e->fwd_folded) { klstm_status fs = ensure_fold(e, !e->fwd_persist, !e->bwd_persist); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
                         flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0));
   // (one or two launches: the persistent kernel with P and the tail inside, plus at most the gradient products)

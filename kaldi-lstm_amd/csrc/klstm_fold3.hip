@@ -337,7 +337,7 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
     const float *cp = cs + (ct * 4 + cq) * FLD + kq * 16 + gate;
     const float4 v = make_float4(cp[0], cp[4], cp[8], cp[12]);
     const int k = gate * C + cell;
-    if (c < C && cell < C)
+    if (a.pk2 && c < C && cell < C)
       a.pk2[(((size_t)(c >> 2) * a.nch2 + (k >> 7)) * 2 + ((k >> 6) & 1)) * 64 + ((k & 63) >> 2) * 4 + cq] = v;
   }
 #ifdef KLSTM_FOLD3_TIMING

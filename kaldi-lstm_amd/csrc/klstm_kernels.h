@@ -34,6 +34,8 @@ struct BwdPtrs {
   int ks;                                            // number of slabs
   const float4 *pk_dr, *pk_dm;                       // packed weight copies, or null
   const float4 *pk_fold;                             // packed W_rm^T (4-row geometry) of the folded recurrence, or null
+  const float4 *pk_fold_gates; int nch_gates;        // the gates-order operand [W_rm | W_x] (FwdPtrs::pk_fold) and its chunks per row tile: the persistent
+                                                     // backward launch gathers its columns of W_rm from it (the 4-row array is then not needed at all)
   bool fat;
   bool bf16;
 };

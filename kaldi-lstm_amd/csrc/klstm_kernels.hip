@@ -1775,7 +1775,7 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
       {   // d_m array: piece = (column quad ct, gate, cell quad kq, cq = column % 4) -> 4 cells of one gate at one column
         const int cq = p & 3, kq = (p >> 2) & 3, gate = (p >> 4) & 3, ct = p >> 6;
         const int c = n0 + ct * 4 + cq, cell = cell0 + kq * 4;
-        if (c < g.N && cell < C) {
+        if (g.pk2 && c < g.N && cell < C) {                  // (pk2 null: only the gates-order operand is wanted)
           const float *cp = Cs + (kq * 16 + gate) * CLD + ct * 4 + cq;
           const float4 v = make_float4(cp[0], cp[4 * CLD], cp[8 * CLD], cp[12 * CLD]);
           const int k = gate * C + cell;

@@ -53,8 +53,9 @@ struct PersistBwd2Args {
   const float *wrT, *wxT;         // W_gifo_r^T [R x 4C], W_gifo_x^T [I x 4C]
   float *dr;                      // d_r plane [(T+2)*S x R], time-major row blocks
   float *in_diff; int id_stride;  // [T*S x I]
-  int nch;                        // 128-wide chunks over 4C
-  const float *wpk;               // packed W_rm^T, 4-row geometry: [C/4 tiles][nch][2][64] float4
+  int nch1;                       // 32-wide chunks per row tile of wpk (the m part and the x part of the folded gates operand)
+  const float *wpk;               // the folded GATES operand (klstm_fold.hip pk1: [C/4 row tiles][nch1][2][64] float4, float4 = 4 consecutive k of
+                                  // row 4 cell + gate): this workgroup's 4 columns of W_rm are ONE float4 per row, 16 rows = 256 contiguous bytes
   const float *pi, *pf, *po;
   const float *gifo, *cc, *hh;
   float *dgifo, *dc;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
     // OPERAND (contraction): lane = (k-group b = lane >> 2, stream j = lane & 3).  dgifo goes from one to the other through a
     // wave-private 2 KB LDS tile [gate][cell][stream] (in-order DS queue of ONE wave: no barrier, no counter).
     const int w = wave - 2, b = lane >> 2, j = lane & 3, c32 = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x, nch = a.nch;
+    const int tile = blockIdx.x;
     float *xt = xtile + w * 512;                     // [4 gates][32 cells][4 streams]
     float wA[NU][2][4];                              // W_rm^T[own cell j][k = e*C + cell] for the wave's cells, A-operand order
     float wpi[NU], wpf[NU], wpo[NU];
@@ -321,9 +322,10 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
         const int cell = 32 * sl + 16 * p + b;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const int k = e * C + (cell < C ? cell : 0);
-          // packed operand: float4 [(tile*nch + k/128)*128 + ((k/64)&1)*64 + 4*((k/4)&15) + row], component k & 3
-          const float v = a.wpk[((size_t)((size_t)tile * nch + (k >> 7)) * 128 + ((k >> 6) & 1) * 64 + 4 * ((k >> 2) & 15) + j) * 4 + (k & 3)];
+          // W_rm[row (cell, gate e)][k = own cell 4 tile + j]: gates operand, row tile cell / 4, k chunk tile / 8, half tile & 1,
+          // k-group (tile & 7) / 2, row slot 4 (cell & 3) + e, component j
+          const int cc = cell < C ? cell : 0;
+          const float v = a.wpk[(((((size_t)(cc >> 2) * a.nch1 + (tile >> 3)) * 2 + (tile & 1)) * 64 + ((tile & 7) >> 1) * 16 + 4 * (cc & 3) + e) << 2) + j];
           wA[u][p][e] = cell < C ? v : 0.f;
         }
       }
@@ -548,8 +550,8 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
   a.od = out_diff; a.od_stride = od_stride; a.wmT = p.wmT;
   a.din = tail_inside ? (in_diff ? 3 : 1) : 0; a.wrT = p.wrT; a.wxT = p.wxT; a.dr = p.dr; a.in_diff = in_diff; a.id_stride = id_stride;
   if (a.din && (!persist_tail_in_kernel(d, in_diff != nullptr, o) || !out_diff)) return hipErrorInvalidValue;
-  a.nch = pcdiv2(4 * d.C, 128);
-  a.wpk = reinterpret_cast<const float *>(p.pk_fold); a.pi = p.pi; a.pf = p.pf; a.po = p.po;
+  a.nch1 = p.nch_gates;
+  a.wpk = reinterpret_cast<const float *>(p.pk_fold_gates); a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.gran = gran; a.ctrl = ctrl;
   a.nap0 = o.nap0_bwd >= 0 ? o.nap0_bwd : 0;
   a.nap = o.nap >= 0 ? o.nap : 0;
@@ -561,7 +563,7 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
   a.dbg = o.dbg;
 #endif
   const PGeo2 g = pick_geo_bwd2(d, o);
-  if (!g.nw || !p.pk_fold || d.S > 8) return hipErrorInvalidValue;
+  if (!g.nw || !p.pk_fold_gates || d.S > 8) return hipErrorInvalidValue;
   const size_t shm = bwd2_lds_bytes(g, d.T, a.pin != 0);
   const int grid = persist_bwd_grid(d);
   if (g.nw == 16 && g.nu == 2) return plaunch2(k_bwd_persist2<16, 2>, grid, 1024, shm, st, pr, a);
