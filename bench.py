@@ -219,7 +219,10 @@ def cpu_baseline(S, budget_s):
         res.update({"value": n1 * T_BPTT * S / dt1, "cores": 1, "blas": blas})
         use_openblas(nthr)
         na, dta = timed(max(2.0, budget_s / 3))
-        res.update({"value_threaded": na * T_BPTT * S / dta, "cores_threaded": nthr})
+        res.update({"value_threaded": na * T_BPTT * S / dta, "cores_threaded": nthr,
+                    "threaded_note": "a LOWER bound, not a better baseline: at %d rows per step the reference's products are GEMV-sized "
+                                     "(the largest is %d x %d x %d), and OpenBLAS spends more on waking %d threads than they bring -- the "
+                                     "1-thread figure is the faster CPU path and is what `value` reports" % (S, S, 4 * C_DIM, R_DIM, nthr)})
         use_openblas(0)
     res["sample"] = (f"{n1} minibatches of {T_BPTT}x{S} frames ({dt1:.1f} s) with cblas_sgemm on 1 thread, {na} ({dta:.1f} s) on {nthr} "
                      f"BLAS threads, {n0} ({dt0:.1f} s) with the oracle's own loops; {cpu_model}, {ncores} physical / {logical} logical "

@@ -260,7 +260,7 @@ def run_c4(args, k):
         step2 = _WholeStep(raw2, stream, nchunk, False, after)
         step2.prepare()
         dt2, n2, _ = _timed(step2, 10, max(20, args.steps // 2), min(1.0, args.min_seconds))
-        shard = {"value": T * S / (dt2 / n2 * 1e-3), "unit": "frames/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
+        shard = {"value": T * S / (dt2 / n2), "unit": "frames/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
                  "path": "local gradients into one fused 57.6 MB blob (the payload of the one all-reduce per minibatch), then momentum + Update: "
                          "a rank of the 8-GPU run minus the wire"}
     # device time of the output tail, part by part
@@ -341,7 +341,7 @@ def run_c5(args, k):
             c = i % nchunk
             net2.train_step(feats[c], None, None, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
         dt2, n2, _ = _timed(step2, 10, max(20, args.steps // 10), min(1.0, args.min_seconds))
-        shard = {"value": T * S / (dt2 / n2 * 1e-3), "unit": "frames/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
+        shard = {"value": T * S / (dt2 / n2), "unit": "frames/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
                  "path": "local gradients into one fused 49 MB blob (the payload of the one all-reduce per minibatch), then momentum + Update"}
     for e in engines:
         e.close()
