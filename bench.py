@@ -648,12 +648,20 @@ def main():
             res["allreduce_ab"] = allreduce_ab
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(S, args.cpu_seconds)
-        print(json.dumps(res))
+        line = json.dumps(res)
     eng.close()
     if dist is not None:
         if world > 1:
             dist.barrier()
         dist.destroy_process_group()
+    # the ONE JSON line is the last thing on stdout: RCCL prints a version banner to stdout when its communicators go away
+    sys.stdout.flush()
+    if rank == 0:
+        print(line)
+        sys.stdout.flush()
+    if dist is not None:
+        sys.stderr.flush()
+        os._exit(0)                        # (no library exit handler writes behind the line)
 
 
 if __name__ == "__main__":

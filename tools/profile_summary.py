@@ -2,8 +2,9 @@
 committed under profiles/): kernel stats CSV, the PMC CSVs, and <tag>_pmc_traffic.json with
   * HBM bytes per launch per kernel = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are
     in KB; on gfx950 FETCH_SIZE reports half of wide coalesced reads),
-  * hbm_bytes_per_minibatch = sum over ALL dispatches of the run / number of minibatches (= launches of k_grads: exactly
-    one per minibatch) -- bench.py divides it by SURVEY 8(d)'s algorithmic bytes for `roofline.traffic_ratio`,
+  * hbm_bytes_per_minibatch = sum over the dispatches that recur every minibatch / number of minibatches (= launches of k_grads:
+    exactly one per minibatch) -- bench.py divides it by SURVEY 8(d)'s algorithmic bytes for `roofline.traffic_ratio`; what runs once
+    per process (set_params' packing, zero-fills) is `hbm_bytes_setup_once`; `..._incl_setup` = everything / minibatches (round <= 3),
   * mfma_busy_frac per kernel = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs): the gfx94x MfmaUtil formula
     reduce(SQ_VALU_MFMA_BUSY_CYCLES,sum) / (reduce(GRBM_GUI_ACTIVE,max) * SIMD_NUM) (counter_defs.yaml; ROCm 7.2 has no gfx950
     derived-counter section).  rocprofv3's CSV carries the SUM of GRBM_GUI_ACTIVE over its 8 XCC instances, which are all
@@ -56,6 +57,10 @@ for name, c in agg.items():
         kern[name]["mfma_busy_frac"] = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(c["GRBM_GUI_ACTIVE"]) / 8 * 1024)
         kern[name]["sq_busy_cycles_per_launch"] = sum(c["SQ_BUSY_CYCLES"]) / max(1, len(c["SQ_BUSY_CYCLES"]))
 nmb = kern.get("k_grads", {}).get("launches", 0)
+# steady state = the kernels that run once (or more) per minibatch; what runs once per PROCESS (set_params: k_update_repack_v, k_pack,
+# k_split3, the zero-fills of the planes) is listed as setup and not charged to a minibatch
+steady = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kern.values() if nmb and v["launches"] >= nmb) / nmb if nmb else None
+setup = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kern.values() if not nmb or v["launches"] < nmb)
 m = re.search(r"--streams-per-gpu[ =](\d+)", cmd)
 doc = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; separate "
                  "runs, tools/profile.sh) on `" + cmd + "`, T=20, 40/800/512",
@@ -63,7 +68,8 @@ doc = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA
                      "WRITE_SIZE uncalibrated)",
        "streams_per_gpu": int(m.group(1)) if m else 4,
        "chain": "persistent" if any(n.startswith("k_bwd_persist") for n in kern) else "launches",   # (which kind of kernel runs BPTT, the dominant chain)
-       "minibatches": nmb, "hbm_bytes_per_minibatch": total_bytes / nmb if nmb else None,
+       "minibatches": nmb, "hbm_bytes_per_minibatch": steady, "hbm_bytes_setup_once": setup,
+       "hbm_bytes_per_minibatch_incl_setup": total_bytes / nmb if nmb else None,
        "kernels": kern}
 json.dump(doc, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print("summary in", dst, ":", sorted(os.listdir(dst)))
