@@ -437,12 +437,31 @@ def main():
         for i in range(args.warmup):
             step(i)
         K = args.steps
-        dt_first = timed_block(step, args.warmup, K)
-        blocks = max(0, int(np.ceil((args.min_seconds - dt_first) / max(dt_first, 1e-9))))
-        dt_total, nsteps_total = dt_first, K
-        if blocks:
-            dt_total += timed_block(step, args.warmup + K, blocks * K)
-            nsteps_total += blocks * K
+
+        def timed_region():
+            dt_first = timed_block(step, args.warmup, K)
+            blocks = max(0, int(np.ceil((args.min_seconds - dt_first) / max(dt_first, 1e-9))))
+            dt_total, nsteps_total = dt_first, K
+            if blocks:
+                dt_total += timed_block(step, args.warmup + K, blocks * K)
+                nsteps_total += blocks * K
+            return dt_first, dt_total, nsteps_total
+        dt_first, dt_total, nsteps_total = timed_region()
+        if dp.oneshot is not None and dp.use_oneshot:
+            # the one-shot exchange must have come through the whole timed region clean on EVERY rank; otherwise the region is void
+            # (a rank that timed out reduced nothing) and is measured again on RCCL
+            st3 = torch.tensor([dp.oneshot.status()], dtype=torch.int32, device="cuda")
+            if world > 1:
+                dist.all_reduce(st3, op=dist.ReduceOp.MAX)
+            allreduce_ab["oneshot_status_after_timed_region"] = int(st3.item())
+            if int(st3.item()) != 0:
+                print("bench.py: the one-shot exchange reported status %d inside the timed region: measured again on RCCL" % int(st3.item()),
+                      file=sys.stderr)
+                dp.use_oneshot = False
+                allreduce_ab["chosen"] = "rccl (the one-shot exchange failed inside the timed region)"
+                for i in range(args.warmup):
+                    step(i)
+                dt_first, dt_total, nsteps_total = timed_region()
 
         # ---- ragged utterance lengths (900..1100): mask / Reset on the timed path
         ragged = None
