@@ -103,6 +103,14 @@ klstm_status klstm_get_grads_host(klstm_engine *e, float *flat);  /* pure gradie
 /* Device address of the contiguous gradient blob (num_params floats) for an in-place
  * all-reduce (RCCL ncclAllReduce / torch.distributed.all_reduce) in DP mode. */
 float *klstm_grad_blob(klstm_engine *e);
+/* Floats a collective over the engine's OWN gradient blob should cover: num_params rounded up to a multiple of 4, + 4.  The first of
+ * the extra floats is the VALIDITY WORD of data-parallel runs: the gradient kernel writes 0 (this rank's gradient is real) or 1 (a
+ * persistent launch of this minibatch gave up and the device-side guard stopped the gradient products); summed over the ranks together
+ * with the gradient, it tells every rank's momentum / Update kernels after the all-reduce whether ANY rank's gradient was not real, and
+ * then EVERY rank leaves that Update out -- replicas stay identical without a host wait in front of the collective
+ * (klstm_allreduce_grads below).  A caller that runs its own all-reduce over num_params floats only (torch.distributed on
+ * klstm_grad_blob()) does not get this: it sets "persist_verify" = 1 instead.  With a blob bound by klstm_bind_grad_blob: num_params. */
+long klstm_grad_blob_len(const klstm_engine *e);
 /* Use caller-owned device storage (num_params floats, 16-byte aligned) as this engine's gradient blob from now
  * on: a stacked net places the blobs of all its layers back to back in ONE buffer so that a minibatch needs one
  * all-reduce for the whole model.  NULL returns to the engine's own buffer. */
@@ -150,7 +158,13 @@ int klstm_pointer_on_device(const klstm_engine *e, const void *p);
 /* Data parallelism over utterance streams: every rank runs klstm_backpropagate(.., KLSTM_BPTT_DEFER_MOMENTUM),
  * then ONE in-place fp32 sum over the ranks of the gradient blob, then klstm_apply_momentum + klstm_update on every rank.
  *   klstm_allreduce_grads   ncclAllReduce(sum, fp32) of this engine's gradient blob (also a blob bound with
- *                           klstm_bind_grad_blob) over the ranks of `rccl_comm` (an ncclComm_t), enqueued on the engine's stream
+ *                           klstm_bind_grad_blob) over the ranks of `rccl_comm` (an ncclComm_t), enqueued on the engine's stream.
+ *                           A rank whose persistent chain gave up in this minibatch must not hand its (missing) gradient to the
+ *                           others: with the engine's own blob the validity word of klstm_grad_blob_len() rides along -- no host
+ *                           wait; the minibatch is left out by every rank and counted (klstm_profile_query "dp_updates_left_out"),
+ *                           and what the host has already heard of is answered (run again) before the collective is enqueued;
+ *                           with "persist_verify" = 1 or a bound blob the call waits for the engine's stream and answers a
+ *                           give-up first, so that every rank reduces a real gradient.
  *   klstm_allreduce_buffer  the same for any device buffer of n floats, e.g. the fused blob of a stacked net, on hip_stream
  *   klstm_comm_*            thin pass-throughs to ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy for callers without RCCL
  *                           headers: rank 0 obtains the 128-byte id and hands it to the other ranks by its own means (file,
@@ -180,7 +194,8 @@ klstm_status klstm_oneshot_allreduce(klstm_oneshot *g, void *hip_stream, int tim
 klstm_status klstm_oneshot_status(klstm_oneshot *g, unsigned *status);
 klstm_status klstm_oneshot_destroy(klstm_oneshot *g);
 const char *klstm_oneshot_last_error(void);
-/* on the engine's stream, behind its gradient products (the group was created on klstm_grad_blob_ptr(engine)) */
+/* on the engine's stream, behind its gradient products; the group was created on klstm_grad_blob(engine) over klstm_grad_blob_len(engine)
+ * floats (the validity word rides along, as in klstm_allreduce_grads) or over num_params floats (then the call waits and looks first) */
 klstm_status klstm_allreduce_grads_oneshot(klstm_engine *e, klstm_oneshot *group, int timeout_ms);
 
 /* DP mode only, after the all-reduce of klstm_grad_blob():  corr = momentum*corr + grad. */
@@ -307,8 +322,8 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  Nnet keeps them exactly that long).  A minibatch older than that cannot be run again: it is DROPPED -- no
  *                  Update, no state advance -- and counted.  `persist_cooldown` minibatches (default 64) on the launch-per-step
  *                  chain follow, then the persistent chain is tried again.  klstm_last_error() carries a remark;
- *                  klstm_profile_query(e, "persist_giveups" | "persist_replayed" | "persist_dropped" | "persist_launches", ..)
- *                  returns the counts in *launches (no "profile" option needed).
+ *                  klstm_profile_query(e, "persist_giveups" | "persist_replayed" | "persist_dropped" | "persist_launches" |
+ *                  "dp_updates_left_out", ..) returns the counts in *launches (no "profile" option needed).
  *                  "persist_verify" 0/1: 1 = klstm_propagate / klstm_backpropagate wait for their persistent launch, so a
  *                  give-up is answered INSIDE the call, before the caller (or a neighbouring component) has read `out` /
  *                  `in_diff`: fully transparent, at the price of one host wait per call (~6 us of launch gap each; Kaldi

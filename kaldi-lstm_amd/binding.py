@@ -54,6 +54,8 @@ def load_library():
         getattr(lib, f"klstm_{n}").argtypes = [P]
     lib.klstm_num_params.argtypes = [P]
     lib.klstm_num_params.restype = ctypes.c_long
+    lib.klstm_grad_blob_len.argtypes = [P]
+    lib.klstm_grad_blob_len.restype = ctypes.c_long
     for n in ("set_params_host", "get_params_host", "set_params_device", "get_corr_host",
               "set_corr_host", "get_grads_host"):
         getattr(lib, f"klstm_{n}").argtypes = [P, P]
@@ -180,14 +182,16 @@ class Engine:
     def grad_blob_ptr(self):
         return int(self.lib.klstm_grad_blob(self.h))
 
-    def grad_blob_tensor(self):
-        """Zero-copy torch view of the device gradient blob (for dist.all_reduce)."""
+    def grad_blob_tensor(self, full=False):
+        """Zero-copy torch view of the device gradient blob (for dist.all_reduce).  full=True: klstm_grad_blob_len() floats -- the
+        gradient plus the validity word of data-parallel runs (klstm.h), what the library's own collectives cover."""
         import torch
 
         class _Blob:
             pass
         b = _Blob()
-        b.__cuda_array_interface__ = {"shape": (self.num_params,), "typestr": "<f4",
+        n = int(self.lib.klstm_grad_blob_len(self.h)) if full else self.num_params
+        b.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4",
                                       "data": (self.grad_blob_ptr(), False), "version": 2}
         return torch.as_tensor(b, device="cuda")
 

@@ -27,6 +27,7 @@
 
 using namespace klstm;
 void klstm_oneshot_set_abort_words(klstm_oneshot *h, unsigned *guard_word_dev, unsigned *host_mapped_word);   // klstm_oneshot.hip
+long klstm_oneshot_floats(klstm_oneshot *h);                                                                   // klstm_oneshot.hip
 
 static thread_local std::string g_err;
 static klstm_status fail(klstm_status st, const char *fmt, ...) {
@@ -61,6 +62,7 @@ struct ProbeRec { std::string name; hipEvent_t start, stop; };
 // a persistent launch of this minibatch gave up (recover()).
 struct MbRec {
   bool have_fwd = false, have_bwd = false, have_upd = false;
+  bool have_ar = false;                       // the gradient all-reduce of this minibatch has been enqueued (with the validity word: klstm_allreduce_grads)
   unsigned fwd_seq = 0, bwd_seq = 0;          // ordinal of the call's persistent launch (0: it did not use one)
   int sp_before = 0;                          // state buffer the forward started from
   const float *in = nullptr; int rows = 0, in_stride = 0; float *out = nullptr; int out_stride = 0;
@@ -75,6 +77,9 @@ struct klstm_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   long nparams = 0;
+  long ar_len = 0;              // floats of the engine's OWN gradient blob: nparams rounded up to 4, + 4 of which the first is the validity
+                                // word of data-parallel runs (klstm_kernels.h launch_grads `mark`)
+  bool ar_marked = false;       // the blob went through an all-reduce WITH its validity word since the last gradient products
   float *params = nullptr, *grads = nullptr, *corr = nullptr;
   float *grads_own = nullptr;   // the engine's own gradient blob (grads points elsewhere after klstm_bind_grad_blob)
   float *wrT = nullptr, *wmT = nullptr, *wxT = nullptr;   // transposed copies for the BPTT kernels
@@ -252,6 +257,13 @@ static klstm_status ensure_ws(klstm_engine *e, int T) {
   return KLSTM_OK;
 }
 
+// The validity word of data-parallel runs: behind the engine's OWN gradient blob (a blob bound by the caller has no room for it).
+static float *ar_mark(const klstm_engine *e) {
+  float *own = e->grads_own ? e->grads_own : e->grads;
+  return e->grads == own && e->ar_len ? own + e->ar_len - 4 : nullptr;
+}
+static const float *ar_mark_if_reduced(const klstm_engine *e) { return e->ar_marked ? ar_mark(e) : nullptr; }
+
 // gradient products deferred by KLSTM_BPTT_FUSE_UPDATE, the ordinary way (somebody looks before the Update arrives)
 static klstm_status flush_grads(klstm_engine *e) {
   if (!e->grads_pending) return KLSTM_OK;
@@ -265,7 +277,8 @@ static klstm_status flush_momentum(klstm_engine *e) {
   { klstm_status gs = flush_grads(e); if (gs != KLSTM_OK) return gs; }
   if (!e->mmt_pending) return KLSTM_OK;
   e->mmt_pending = false;
-  HIPCHK(launch_apply_momentum(e->corr, e->grads, e->mmt_value, e->nparams, e->stream, probe(e, "k_apply_momentum"), e->pctrl));
+  HIPCHK(launch_apply_momentum(e->corr, e->grads, e->mmt_value, e->nparams, e->stream, probe(e, "k_apply_momentum"), e->pctrl,
+                               ar_mark_if_reduced(e)));
   return KLSTM_OK;
 }
 
@@ -357,7 +370,7 @@ static klstm_status recover(klstm_engine *e, const unsigned (&w)[16]) {
   unsigned fseq = 0;                                  // ordinal of the first launch that gave up
   for (unsigned v : {w[3], w[7]}) if (v && (!fseq || v < fseq)) fseq = v;
   unsigned z[16] = {0};
-  z[0] = w[0]; z[4] = w[4]; z[8] = w[8];              // epochs and the launch counter stay
+  z[0] = w[0]; z[4] = w[4]; z[8] = w[8]; z[10] = w[10];   // epochs, the launch counter and the count of Updates left out for a peer stay
   HIPCHK(hipMemcpy(e->pctrl, z, sizeof(z), hipMemcpyHostToDevice));
   e->n_giveups++;
   e->cooldown = e->cooldown_len;
@@ -373,8 +386,11 @@ static klstm_status recover(klstm_engine *e, const unsigned (&w)[16]) {
   e->nmarks = 0;
   const MbRec r = e->rec;
   e->rec = MbRec();
-  const bool re_fwd = r.have_fwd && r.fwd_seq && fseq && r.fwd_seq >= fseq;
-  const bool re_bwd = r.have_bwd && (re_fwd || (r.bwd_seq && fseq && r.bwd_seq >= fseq));
+  // A minibatch whose gradient all-reduce is already enqueued cannot be run again by ONE rank (the collective is everybody's): its
+  // validity word went out as 1, so every rank -- this one too: the Update kernels look at the reduced word -- leaves that Update
+  // out; here it counts as dropped.
+  const bool re_fwd = !r.have_ar && r.have_fwd && r.fwd_seq && fseq && r.fwd_seq >= fseq;
+  const bool re_bwd = !r.have_ar && r.have_bwd && (re_fwd || (r.bwd_seq && fseq && r.bwd_seq >= fseq));
   const bool re_upd = r.have_upd && re_bwd;
   if (e->sp != sp_now && !(re_fwd && e->sp == r.sp_before)) {
     // the state went back further than this minibatch's forward pass (or that pass cannot be run again): Resets the caller has
@@ -561,7 +577,8 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
     if (er == hipSuccess) er = hipMemsetAsync(*p, 0, bytes, e->stream);
     if (er != hipSuccess) st = fail(KLSTM_ERR_HIP, "hipMalloc/Memset(%zu): %s", bytes, hipGetErrorString(er));
   };
-  alloc0(&e->params, pb); alloc0(&e->grads, pb); alloc0(&e->corr, pb);
+  e->ar_len = ((e->nparams + 3) & ~3L) + 4;
+  alloc0(&e->params, pb); alloc0(&e->grads, (size_t)e->ar_len * sizeof(float)); alloc0(&e->corr, pb);
   alloc0(&e->wrT, (size_t)4 * e->C * e->R * sizeof(float));
   alloc0(&e->wmT, (size_t)e->R * e->C * sizeof(float));
   alloc0(&e->wxT, (size_t)4 * e->C * e->I * sizeof(float));
@@ -615,6 +632,7 @@ int klstm_recur_dim(const klstm_engine *e) { return e ? e->R : -1; }
 int klstm_num_stream(const klstm_engine *e) { return e ? e->S : -1; }
 long klstm_num_params(const klstm_engine *e) { return e ? e->nparams : -1; }
 float *klstm_grad_blob(klstm_engine *e) { return e ? e->grads : nullptr; }
+long klstm_grad_blob_len(const klstm_engine *e) { return !e ? -1 : ar_mark(e) ? e->ar_len : e->nparams; }
 klstm_status klstm_bind_grad_blob(klstm_engine *e, float *grad_dev) {
   if (!e) return fail(KLSTM_ERR_ARG, "null argument");
   if (grad_dev && (reinterpret_cast<uintptr_t>(grad_dev) & 15)) return fail(KLSTM_ERR_ARG, "klstm_bind_grad_blob: blob must be 16-byte aligned");
@@ -624,6 +642,7 @@ klstm_status klstm_bind_grad_blob(klstm_engine *e, float *grad_dev) {
   drop_graphs(e);                                   // captured launches hold the old address
   if (!e->grads_own) e->grads_own = e->grads;
   e->grads = grad_dev ? grad_dev : e->grads_own;
+  e->ar_marked = false;
   return KLSTM_OK;
 }
 float *klstm_param_blob(klstm_engine *e) { return e ? e->params : nullptr; }
@@ -836,7 +855,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
     if (grads_fusable(e, T, flags, false)) return KLSTM_OK;      // (klstm_update runs them together with the Update)
     HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, defer ? 0.f : mmt, defer ? e->grads : e->corr, st,
-                        probe(e, "k_grads"), false, nullptr, e->pctrl));
+                        probe(e, "k_grads"), false, nullptr, e->pctrl, defer ? ar_mark(e) : nullptr));
     return KLSTM_OK;
   }
   for (int t = T; t >= 1; t--) {
@@ -852,7 +871,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
   const float beta = defer ? 0.f : mmt;
   if (grads_fusable(e, T, flags, e->use_bf16)) return KLSTM_OK;
   HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, beta, dst, st,
-                      probe(e, "k_grads"), e->use_bf16, nullptr, e->pctrl));                  // :468-487
+                      probe(e, "k_grads"), e->use_bf16, nullptr, e->pctrl, defer ? ar_mark(e) : nullptr));                  // :468-487
   return KLSTM_OK;
 }
 
@@ -932,6 +951,7 @@ static klstm_status do_backpropagate(klstm_engine *e, const float *in, int in_st
   (void)rows;
   const int T = e->T_fwd;
   klstm_status st;
+  e->ar_marked = false;          // (new gradient products: whatever all-reduce the blob went through belongs to an earlier minibatch)
   // (Launch-per-step BPTT kernels behind a persistent forward launch nobody has looked at yet are NOT waited for: if that launch gave
   //  up they compute on invalid planes, but what they write -- derivative planes, in_diff -- is rewritten when the minibatch is run
   //  again, and the gradient / Update kernels behind them are guarded.)
@@ -1116,7 +1136,8 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
       u.split_mode = e->fwd_ms ? 3 : e->fold_mode == 2 ? 2 : 1;        // (the many-stream bf16 launch: the operands themselves as bf16)
     }
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
-                                e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr));
+                                e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr,
+                                fold_grad ? ar_mark_if_reduced(e) : nullptr, e->pctrl ? e->pctrl + 10 : nullptr));
   }
   // (Packing the BPTT operands on a second stream, overlapped with the next forward pass, was measured to cost
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
@@ -1351,6 +1372,12 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
         {"fold_mode", (long)e->fold_mode}};
     for (const auto &c : ctr)
       if (!strcmp(kernel, c.name)) { *total_us = 0.0; *launches = c.v; return KLSTM_OK; }
+    if (!strcmp(kernel, "dp_updates_left_out")) {      // Updates every rank left out because SOME rank's gradient of that minibatch was not real
+      unsigned v = 0;
+      if (e->pctrl) HIPCHK(hipMemcpy(&v, e->pctrl + 10, sizeof(v), hipMemcpyDeviceToHost));
+      *total_us = 0.0; *launches = (long)v;
+      return KLSTM_OK;
+    }
   }
   for (auto &r : e->probes) {
     float ms = 0.f;
@@ -1682,13 +1709,21 @@ klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm) {
   // A persistent launch of this minibatch that gave up left the gradient products undone (they are guarded): the blob must not
   // reach the other ranks like that -- they would apply the step, this rank would not.  Look first (a host wait, only while the
   // persistent chain is in use); a give-up is answered by running the minibatch again, then everybody reduces real gradients.
-  { klstm_status ss = settle(e); if (ss != KLSTM_OK) return ss; }
+  // Two ways to keep that from happening.  (a) The engine's own blob carries a validity word behind the gradient (written by the
+  // gradient kernel: 0 = real, 1 = stopped by the guard) that is summed with it; the Update kernels of EVERY rank leave the step out
+  // when the sum is non-zero -- no host wait, replicas identical, the minibatch counts as dropped ("dp_updates_left_out").  What the
+  // host has already heard of is still answered first (a look at the host-mapped word, no wait).  (b) With "persist_verify", or a
+  // blob bound by the caller (no room for the word): wait and look, as before.
+  float *mark = ar_mark(e);
+  if (e->persist_verify || !mark) { klstm_status ss = settle(e); if (ss != KLSTM_OK) return ss; }
+  else { klstm_status ss = poll_persist(e); if (ss != KLSTM_OK) return ss; }
   { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }     // a pending corr += grads must see the LOCAL sums
   // option "profile": the exposed time of the collective between two events on the engine's stream ("rccl_allreduce")
   const LaunchProbe pr = probe(e, "rccl_allreduce");
   if (pr.start) HIPCHK(hipEventRecord(pr.start, e->stream));
-  const klstm_status st = klstm_allreduce_buffer(e->grads, (size_t)e->nparams, rccl_comm, e->stream);   // in place, on the engine's stream: no event hops
+  const klstm_status st = klstm_allreduce_buffer(e->grads, (size_t)(mark ? e->ar_len : e->nparams), rccl_comm, e->stream);   // in place, on the engine's stream: no event hops
   if (pr.stop) HIPCHK(hipEventRecord(pr.stop, e->stream));
+  if (st == KLSTM_OK) { e->ar_marked = mark != nullptr; e->rec.have_ar = true; }
   return st;
 }
 
@@ -1697,7 +1732,13 @@ klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm) {
 klstm_status klstm_allreduce_grads_oneshot(klstm_engine *e, klstm_oneshot *group, int timeout_ms) {
   if (!e || !group) return fail(KLSTM_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->device));
-  { klstm_status ss = settle(e); if (ss != KLSTM_OK) return ss; }             // (as in klstm_allreduce_grads)
+  // (as in klstm_allreduce_grads: the validity word rides along when the group was created over klstm_grad_blob_len() floats)
+  float *mark = ar_mark(e);
+  const long gn = klstm_oneshot_floats(group);
+  if (mark && gn != e->ar_len) mark = nullptr;
+  if (!mark && gn != e->nparams) return fail(KLSTM_ERR_ARG, "klstm_allreduce_grads_oneshot: the group spans %ld floats, this engine's blob %ld (or %ld)", gn, e->nparams, e->ar_len);
+  if (e->persist_verify || !mark) { klstm_status ss = settle(e); if (ss != KLSTM_OK) return ss; }
+  else { klstm_status ss = poll_persist(e); if (ss != KLSTM_OK) return ss; }
   { klstm_status fs = flush_momentum(e); if (fs != KLSTM_OK) return fs; }
   { klstm_status es = ensure_persist(e); if (es != KLSTM_OK) return es; }     // (the control words: a timeout of the exchange gates this engine's Update)
   klstm_oneshot_set_abort_words(group, e->pctrl + 9, e->popt.hstat);
@@ -1707,6 +1748,7 @@ klstm_status klstm_allreduce_grads_oneshot(klstm_engine *e, klstm_oneshot *group
   const klstm_status st = klstm_oneshot_allreduce(group, e->stream, timeout_ms);
   if (pr.stop) HIPCHK(hipEventRecord(pr.stop, e->stream));
   if (st != KLSTM_OK) return fail(st, "klstm_oneshot_allreduce: %s", klstm_oneshot_last_error());
+  e->ar_marked = mark != nullptr; e->rec.have_ar = true;
   return KLSTM_OK;
 }
 

@@ -174,7 +174,11 @@ bool grads_bf16_tiles(const Dims &d, bool bf16);      // would launch_grads take
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,
                         hipStream_t st, LaunchProbe pr = {}, bool bf16 = false, const GradsUpdate *upd = nullptr,
-                        const unsigned *guard = nullptr);   // bf16: operands rounded to bf16, 16x16x32 MFMA, fp32 accumulate
+                        const unsigned *guard = nullptr, float *mark = nullptr);   // bf16: operands rounded to bf16, 16x16x32 MFMA, fp32 accumulate
+// mark (data-parallel runs): one float behind the gradient blob that travels through the all-reduce with it -- launch_grads writes 0
+// (this rank's gradient is real) or 1 (the guard stopped it); launch_update_repack / launch_apply_momentum given the same address AFTER
+// the all-reduce leave everything alone when the sum is non-zero (and count it in *peer_skip): a minibatch that was invalid on ANY rank
+// is left out by EVERY rank, without a host wait in front of the collective.
 
 // Update (:504-512) + refresh of the transposed weight copies in ONE launch.
 //   grad != nullptr : corr = mmt*corr + grad first (DP mode, after the all-reduce)
@@ -183,7 +187,7 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
 hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_blob, const float *grad_blob,
                                 float mmt, float lr, float clip, float *wrT, float *wmT, float *wxT,
                                 hipStream_t st, LaunchProbe pr = {}, const unsigned *guard = nullptr,
-                                const GradsUpdate *planes = nullptr);   // planes->a3 / b3: also write the fold operands' bf16 planes (vector kernel only)
+                                const GradsUpdate *planes = nullptr, const float *mark = nullptr, unsigned *peer_skip = nullptr);   // planes->a3 / b3: also write the fold operands' bf16 planes (vector kernel only)
 bool update_repack_vectorised(const Dims &d, const float *param_blob, const float *corr_blob, const float *grad_blob, const float *wrT,
                               const float *wmT, const float *wxT);
 // guard (both): the two status words of the persistent chain (ctrl[2], ctrl[6]); when either is non-zero the kernels return
@@ -219,7 +223,7 @@ hipError_t launch_axpy(float *y, const float *x, float a, long n, hipStream_t st
 
 hipError_t launch_sgd_momentum(float *param, float *corr, const float *grad, float mmt, float lr, long n, hipStream_t st);
 hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr = {},
-                                 const unsigned *guard = nullptr);
+                                 const unsigned *guard = nullptr, const float *mark = nullptr);
 
 // Weights-resident persistent chain (klstm_persist.hip forward, klstm_persist_bwd.hip backward; NumStream <= 8, folded
 // recurrence, x term fused): ONE launch per direction runs all T steps with the packed fold operands held in registers and

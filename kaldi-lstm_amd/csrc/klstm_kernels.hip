@@ -1928,6 +1928,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce2(ReduceArgs r1, ReduceArg
 // ---------------------------------------------------------------------------------------------
 struct GradsArgs {
   const unsigned *guard;   // the engine's control words: status of the persistent chain ([2], [6]) or of the one-shot all-reduce ([9]) non-zero -> the minibatch is invalid, touch nothing
+  float *mark;             // (or null) data-parallel runs: the validity word that rides at the end of the gradient blob through the all-reduce --
+                           // 0 when this rank's gradient is real, 1 when the guard stopped it; the SUM every rank receives gates every rank's Update
   GemmJob wx, wr, wm;
   int nb0, nb1, nb2, nvec;   // tile-id ranges of the three products, then nvec column-sum blocks
   int bf16_narrow;           // k_grads_bf16: 128 x 64 tiles instead of 128 x 128
@@ -1995,7 +1997,9 @@ __device__ __forceinline__ void grads_column_sums(const GradsArgs &a, int vb, fl
 }
 
 __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
-  if (a.guard && (a.guard[2] | a.guard[6] | a.guard[9])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
+  const bool invalid = a.guard && (a.guard[2] | a.guard[6] | a.guard[9]);
+  if (a.mark && blockIdx.x == 0 && threadIdx.x == 0) *a.mark = invalid ? 1.f : 0.f;
+  if (invalid) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ __attribute__((aligned(16))) float As[GLDS];
   __shared__ __attribute__((aligned(16))) float Bs[GLDS];
   // XCD-aware order: workgroup w lands on XCD w % 8 (observed dispatch rule, speed only); XCD x gets the contiguous
@@ -2223,7 +2227,9 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_nt(GemmJob g) {
 }
 
 __global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
-  if (a.guard && (a.guard[2] | a.guard[6] | a.guard[9])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
+  const bool invalid = a.guard && (a.guard[2] | a.guard[6] | a.guard[9]);
+  if (a.mark && blockIdx.x == 0 && threadIdx.x == 0) *a.mark = invalid ? 1.f : 0.f;
+  if (invalid) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ __attribute__((aligned(16))) unsigned As[4 * PLANE];
   __shared__ __attribute__((aligned(16))) unsigned Bs[4 * PLANE];
   const int nbt = a.nb2 + a.nvec;
@@ -2251,6 +2257,8 @@ __global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
 // ---------------------------------------------------------------------------------------------
 struct UpdArgs {
   const unsigned *guard;   // as in GradsArgs
+  const float *mark;       // (or null) the validity word behind the all-reduced gradient blob: non-zero = some rank's gradient of this minibatch was not real
+  unsigned *peer_skip;     // (or null) counts the Updates that were left out for that reason
   float *param, *corr;
   const float *grad;        // DP: corr = mmt*corr + grad first
   float mmt, lr, clip;
@@ -2279,7 +2287,13 @@ __device__ __forceinline__ float upd_elem(const UpdArgs &a, long idx) {
 }
 
 __global__ __launch_bounds__(256) void k_update_repack(UpdArgs a) {
-  if (a.guard && (a.guard[2] | a.guard[6] | a.guard[9])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
+  // a persistent launch of this minibatch gave up: leave momentum and parameters alone -- on THIS rank (guard) or on ANY rank (the
+  // reduced validity word: every rank leaves this Update out, the replicas stay identical; counted, the same number everywhere)
+  const bool own = a.guard && (a.guard[2] | a.guard[6] | a.guard[9]);
+  if (own || (a.mark && *a.mark != 0.f)) {
+    if (a.mark && a.peer_skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.peer_skip, 1u);
+    return;
+  }
   __shared__ float tile[32][33];
   const int b = blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   if (b >= a.tb_vec) {
@@ -2339,7 +2353,13 @@ __device__ __forceinline__ float4 upd_vec_apply(const UpdArgs &a, long idx, cons
 }
 
 __global__ __launch_bounds__(256) void k_update_repack_v(UpdArgs a) {
-  if (a.guard && (a.guard[2] | a.guard[6] | a.guard[9])) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
+  // a persistent launch of this minibatch gave up: leave momentum and parameters alone -- on THIS rank (guard) or on ANY rank (the
+  // reduced validity word: every rank leaves this Update out, the replicas stay identical; counted, the same number everywhere)
+  const bool own = a.guard && (a.guard[2] | a.guard[6] | a.guard[9]);
+  if (own || (a.mark && *a.mark != 0.f)) {
+    if (a.mark && a.peer_skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.peer_skip, 1u);
+    return;
+  }
   __shared__ __attribute__((aligned(16))) float tile[64 * 68];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= a.tb_vec) {
@@ -2753,8 +2773,10 @@ __global__ void k_sgd_momentum(float *__restrict__ param, float *__restrict__ co
     param[i] = param[i] + (-lr) * c;
   }
 }
-__global__ void k_apply_momentum(float *__restrict__ corr, const float *__restrict__ grad, float mmt, long n, const unsigned *guard) {
+__global__ void k_apply_momentum(float *__restrict__ corr, const float *__restrict__ grad, float mmt, long n, const unsigned *guard,
+                                 const float *mark) {
   if (guard && (guard[2] | guard[6] | guard[9])) return;          // a persistent launch of this minibatch gave up: its gradient must not reach the momentum buffers
+  if (mark && *mark != 0.f) return;                               // (or a peer's: UpdArgs::mark)
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     corr[i] = mmt * corr[i] + grad[i];
 }
@@ -3286,13 +3308,14 @@ bool grads_bf16_tiles(const Dims &d, bool bf16) { return bf16 && d.T * d.S >= GR
 
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst,
-                        hipStream_t st, LaunchProbe pr, bool bf16, const GradsUpdate *upd, const unsigned *guard) {
+                        hipStream_t st, LaunchProbe pr, bool bf16, const GradsUpdate *upd, const unsigned *guard, float *mark) {
   const int S = d.S, C = d.C, R = d.R, I = d.I, TS = d.T * d.S;
   const long o_wx = 0, o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_pi = o_b + 4 * C,
              o_pf = o_pi + C, o_po = o_pf + C, o_wm = o_po + C;
   const float *dg1 = dgifo + (size_t)S * 4 * C;                      // DGIFO[1..T]
   GradsArgs a;
   a.guard = guard;
+  a.mark = mark;
   a.bf16_narrow = 0;
   a.wx = make_job(true, false, 4 * C, I, TS, dg1, 4 * C, in, in_stride, beta, dst + o_wx, I, nullptr);             // :468
   a.wr = make_job(true, false, 4 * C, R, TS, dg1, 4 * C, rr, R, beta, dst + o_wr, R, nullptr);                      // :471 (YR[0..T-1])
@@ -3342,10 +3365,12 @@ bool update_repack_vectorised(const Dims &d, const float *param_blob, const floa
 }
 hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_blob, const float *grad_blob,
                                 float mmt, float lr, float clip, float *wrT, float *wmT, float *wxT,
-                                hipStream_t st, LaunchProbe pr, const unsigned *guard, const GradsUpdate *planes) {
+                                hipStream_t st, LaunchProbe pr, const unsigned *guard, const GradsUpdate *planes, const float *mark,
+                                unsigned *peer_skip) {
   const int C = d.C, R = d.R, I = d.I;
   UpdArgs a;
   a.guard = guard;
+  a.mark = mark; a.peer_skip = peer_skip;
   a.a3 = a.b3 = nullptr; a.a_plane = a.b_plane = 0; a.split_mode = 1;
   a.param = param_blob; a.corr = corr_blob; a.grad = grad_blob; a.mmt = mmt; a.lr = lr; a.clip = clip;
   a.touch = (lr != 0.f || grad_blob != nullptr || clip > 0.f) ? 1 : 0;
@@ -3445,8 +3470,9 @@ hipError_t launch_sgd_momentum(float *param, float *corr, const float *grad, flo
   LaunchProbe pr;
   KLAUNCH(k_sgd_momentum, dim3(ew_grid(n)), dim3(256), st, pr, param, corr, grad, mmt, lr, n);
 }
-hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr, const unsigned *guard) {
-  KLAUNCH(k_apply_momentum, dim3(ew_grid(n)), dim3(256), st, pr, corr, grad, mmt, n, guard);
+hipError_t launch_apply_momentum(float *corr, const float *grad, float mmt, long n, hipStream_t st, LaunchProbe pr, const unsigned *guard,
+                                 const float *mark) {
+  KLAUNCH(k_apply_momentum, dim3(ew_grid(n)), dim3(256), st, pr, corr, grad, mmt, n, guard, mark);
 }
 
 }  // namespace klstm

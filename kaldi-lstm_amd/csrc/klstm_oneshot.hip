@@ -16,7 +16,8 @@
 // Memory ordering assumed (documented HIP / HSA behaviour, not measured here): the blob is hipMalloc memory; the kernel that
 // produced it ended before this one started on the same stream (its writes are in memory: end-of-kernel release at system
 // scope); peer data is read and written with system-coherent accesses (sc0 sc1: no line of a peer's memory is served from or
-// parked in this device's L2); flags are 32-bit system-scope relaxed atomics, preceded by __threadfence_system(); the kernel that
+// parked in this device's L2); flags live in uncached (fine-grained) device memory and are 32-bit system-scope relaxed atomics,
+// preceded by __threadfence_system(); the kernel that
 // consumes the reduced blob starts with a system-scope acquire (stale lines of the OWN blob, written by peers, are dropped).
 #include "klstm_kernels.h"
 #include "klstm_persist_dev.h"
@@ -169,8 +170,21 @@ klstm_status klstm_oneshot_create(int device, float *blob_dev, long n, klstm_one
   OCHK(hipSetDevice(device));
   auto *g = new OneshotGroup;
   g->device = device; g->own_blob = blob_dev; g->n = n;
-  OCHK(hipMalloc(&g->own_flags, (2 * ONESHOT_MAX_RANKS + 2) * sizeof(unsigned)));
-  OCHK(hipMemset(g->own_flags, 0, (2 * ONESHOT_MAX_RANKS + 2) * sizeof(unsigned)));
+  // The flag words are written by PEER devices while a kernel of this device polls them: they must not be served from this device's
+  // L2 (ordinary hipMalloc memory is coherent with other agents only at kernel boundaries) -- uncached / fine-grained device memory,
+  // what RCCL allocates for the same purpose; plain hipMalloc only if the runtime offers neither (single-device tests still pass,
+  // across devices the waits would then expire and the caller falls back to RCCL).
+  const size_t fbytes = (2 * ONESHOT_MAX_RANKS + 2) * sizeof(unsigned);
+  void *fl = nullptr;
+  if (hipExtMallocWithFlags(&fl, fbytes, hipDeviceMallocUncached) != hipSuccess || !fl) {
+    (void)hipGetLastError(); fl = nullptr;
+    if (hipExtMallocWithFlags(&fl, fbytes, hipDeviceMallocFinegrained) != hipSuccess || !fl) {
+      (void)hipGetLastError(); fl = nullptr;
+      OCHK(hipMalloc(&fl, fbytes));
+    }
+  }
+  g->own_flags = static_cast<unsigned *>(fl);
+  OCHK(hipMemset(g->own_flags, 0, fbytes));
   OCHK(hipMalloc(&g->done, sizeof(unsigned)));
   OCHK(hipMemset(g->done, 0, sizeof(unsigned)));
   *out = reinterpret_cast<klstm_oneshot *>(g);
@@ -254,6 +268,7 @@ klstm_status klstm_oneshot_status(klstm_oneshot *h, unsigned *status) {
 
 }  // extern "C"
 // (engine-internal, klstm_engine.hip) where a timeout is also recorded: the engine's guard word and its host-mapped notice word
+long klstm_oneshot_floats(klstm_oneshot *h) { return h ? reinterpret_cast<OneshotGroup *>(h)->n : 0; }
 void klstm_oneshot_set_abort_words(klstm_oneshot *h, unsigned *guard_word_dev, unsigned *host_mapped_word) {
   auto *g = reinterpret_cast<OneshotGroup *>(h);
   if (g) { g->abort_word = guard_word_dev; g->abort_host = host_mapped_word; }

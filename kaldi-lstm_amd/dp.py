@@ -96,6 +96,10 @@ class DataParallelLstm:
                                 "klstm_allreduce_grads (RCCL ncclAllReduce, in place, on the engine's stream)" if self.comm is not None else
                                 "torch.distributed.all_reduce (%s)" % (dist.get_backend(group) if dist.is_initialized() else "?"))
         self.ranks_seen = self.comm.count() if self.comm is not None else self.world
+        if self.collective and self.comm is None and on_gpu and hasattr(engine, "set_option"):
+            # torch.distributed's all_reduce over the gradient alone: the library cannot put its validity word through it, so a rank
+            # whose persistent chain gave up has to be found BEFORE the collective -- every persistent call waits for its launch
+            engine.set_option("persist_verify", 1)
         # oneshot=True (default OFF; klstm_oneshot.hip: prepared, never run across devices): the gradient blob of every rank is
         # mapped into every other rank (hipIpc handles handed around over the process group) and ONE kernel per rank reduces its
         # 1/N slice from all peers and writes it back to all of them, instead of ncclAllReduce
@@ -104,8 +108,10 @@ class DataParallelLstm:
         self._rccl_name = self.collective_name
         if oneshot and self.collective and hasattr(engine, "grad_blob_tensor"):
             from .binding import OneshotAllreduce
-            self._blob = engine.grad_blob_tensor()
-            self.oneshot = OneshotAllreduce(self._blob, device=self._blob.device.index or 0)
+            # (the whole blob: the validity word of data-parallel runs rides behind the gradient, klstm.h klstm_grad_blob_len)
+            self._blob_full = engine.grad_blob_tensor(full=True)
+            self._blob = self._blob_full[:engine.num_params]
+            self.oneshot = OneshotAllreduce(self._blob_full, device=self._blob_full.device.index or 0)
             hs = [None] * self.world
             dist.all_gather_object(hs, self.oneshot.export(), group=group)
             self.oneshot.connect(dist.get_rank(group), self.world, hs)

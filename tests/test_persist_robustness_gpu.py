@@ -243,3 +243,73 @@ def test_persistent_chain_next_to_asynchronous_allreduces():
     persistent launches of the layers below (two stacked 800/512 layers, T = 20: the persistent chain is the default)."""
     _stacked_net_against_cpu_twins((40, 800, 512, 2, 131), S=4, T=20, scale=0.01, lr=1e-3, nsteps=3, overlap=True, port=29538,
                                    tol_param=5e-5, tol_grad=3e-4)
+
+
+@pytest.mark.parametrize("verify", [0, 1])
+def test_data_parallel_step_with_a_give_up_keeps_the_replicas_together(verify):
+    """The data-parallel order (gradient -> klstm_allreduce_grads -> momentum -> Update) on a 1-rank RCCL communicator, four
+    minibatches queued WITHOUT a host synchronisation; the backward launch of minibatch 1 gives up.
+    verify = 0 (the C-ABI's default): klstm_allreduce_grads does not wait for the device.  The gradient kernel of the failed
+    minibatch writes 1 into the validity word behind the blob, the word goes through the all-reduce with the gradient, and the
+    Update kernels -- of every rank -- leave that step out; so do the steps queued behind it until the host has heard of the
+    give-up.  Nothing is applied twice, nothing half: the parameters equal a twin that saw minibatch 0 and the minibatches from
+    the recovery on, and the left-out ones are counted ("dp_updates_left_out").
+    verify = 1: every persistent call waits for its launch; the give-up is answered inside klstm_backpropagate, the all-reduce
+    carries a real gradient, nothing is left out."""
+    import os
+    import torch.distributed as dist
+    import kaldi_lstm_amd as k
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        I, C, R, S, T, N = 40, 800, 512, 4, 20, 4
+        p = make_params(I, C, R, scale=0.01, seed=81)
+        rng = np.random.RandomState(82)
+        stream = torch.cuda.Stream()
+        e = k.Engine(I, C, R, S, stream=stream); e.set_params(p)
+        e.set_option("persist", 2); e.set_option("persist_spin_us", 3000); e.set_option("persist_verify", verify)
+        dp = k.DataParallelLstm(e, force_collective=True)
+        assert dp.collective and dp.comm is not None
+        t = k.Engine(I, C, R, S); t.set_params(p); t.set_option("persist", 0)
+        mbs = []
+        for i in range(N):
+            x, od = _minibatch(rng, I, R, S, T, 0.1)
+            mbs.append((dev(x), dev(od), torch.empty(T * S, R, device="cuda"), torch.empty(T * S, I, device="cuda")))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            for i, (xd, odd, out, idf) in enumerate(mbs):
+                e.set_option("persist_test_stall_bwd", 5 if i == 1 else 0)
+                dp.train_step(xd, out, odd, idf, 0.9, 1e-5, reset_flags=[1] * S if i == 0 else None)
+        e.synchronize()
+        assert e.profile_query("persist_giveups")[1] == 1
+        left_out = e.profile_query("dp_updates_left_out")[1]
+        if verify:
+            assert left_out == 0 and e.profile_query("persist_replayed")[1] == 1 and e.profile_query("persist_dropped")[1] == 0
+        else:
+            # (3 ms pass before the launch gives up; the host has queued all four minibatches long before: normally N - 1.  0 would
+            #  mean the host heard of it before minibatch 1's all-reduce went out and ran its BPTT again.)
+            assert 0 <= left_out <= N - 1
+        # the twin: minibatch 0; the forward pass of minibatch 1 was good and advanced the state, its Update is left out; the
+        # minibatches queued behind it did nothing at all (no Update, no state advance); then the rest
+        out_t = torch.empty(T * S, R, device="cuda"); idf_t = torch.empty(T * S, I, device="cuda")
+        for i, (xd, odd, _, _) in enumerate(mbs):
+            if i == 0:
+                t.reset([1] * S)
+            if 1 <= i < 1 + left_out:
+                if i == 1:
+                    t.propagate(xd, out_t)
+                continue
+            t.propagate(xd, out_t); t.backpropagate(xd, odd, idf_t, momentum=0.9); t.update(1e-5)
+        t.synchronize()
+        assert relerr(e.get_params(), t.get_params()) <= 1e-6
+        assert relerr(e.get_corr(), t.get_corr()) <= 2e-5
+        ce, re_ = e.get_state(); ct, rt = t.get_state()
+        assert relerr(ce, ct) <= 2e-5 and relerr(re_, rt) <= 2e-5
+        if left_out < N - 1:                       # the last minibatch was applied: its outputs are the twin's
+            assert relerr(mbs[-1][2].cpu().numpy(), out_t.cpu().numpy()) <= 2e-5
+            assert relerr(mbs[-1][3].cpu().numpy(), idf_t.cpu().numpy()) <= 3e-4
+        e.close(); t.close()
+    finally:
+        dist.destroy_process_group()
