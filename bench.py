@@ -349,14 +349,11 @@ def main():
     collective_on = world > 1 or args.force_collective
     want_oneshot = collective_on and args.collective in ("auto", "oneshot")
     oneshot_note = None
-    try:
-        dp = k.DataParallelLstm(eng, force_collective=args.force_collective, require_native=collective_on, oneshot=want_oneshot)
-    except Exception as ex:                      # (peer mapping refused, e.g. no IPC between these devices: say so, run on RCCL)
-        if not want_oneshot:
-            raise
-        oneshot_note = "one-shot exchange could not be set up (%s): RCCL only" % ex
-        print("bench.py: " + oneshot_note, file=sys.stderr)
-        dp = k.DataParallelLstm(eng, force_collective=args.force_collective, require_native=collective_on)
+    # (a rank that cannot set the exchange up -- peer mapping refused, no IPC between these devices -- does not raise on its own:
+    #  the ranks agree inside DataParallelLstm, dp.py _setup_oneshot, and everybody runs on RCCL)
+    dp = k.DataParallelLstm(eng, force_collective=args.force_collective, require_native=collective_on, oneshot=want_oneshot)
+    if want_oneshot and dp.oneshot is None:
+        oneshot_note = (dp.oneshot_note or "one-shot exchange could not be set up") + ": RCCL only"
     allreduce_ab = None
     torch.cuda.synchronize()
 

@@ -106,17 +106,47 @@ class DataParallelLstm:
         self.oneshot = None
         self.use_oneshot = False
         self._rccl_name = self.collective_name
+        self.oneshot_note = None
         if oneshot and self.collective and hasattr(engine, "grad_blob_tensor"):
-            from .binding import OneshotAllreduce
+            self._setup_oneshot(engine, dist, group)
+
+    def _setup_oneshot(self, engine, dist, group):
+        """Every rank takes the same decision (as in native_comm): a rank that cannot export or open a handle says so IN the
+        collectives everybody takes part in -- raising on its own would leave the others waiting -- and then nobody uses the
+        exchange (`oneshot_note` says why)."""
+        import sys
+        from .binding import OneshotAllreduce
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        one, handles, err = None, None, None
+        try:
             # (the whole blob: the validity word of data-parallel runs rides behind the gradient, klstm.h klstm_grad_blob_len)
             self._blob_full = engine.grad_blob_tensor(full=True)
             self._blob = self._blob_full[:engine.num_params]
-            self.oneshot = OneshotAllreduce(self._blob_full, device=self._blob_full.device.index or 0)
-            hs = [None] * self.world
-            dist.all_gather_object(hs, self.oneshot.export(), group=group)
-            self.oneshot.connect(dist.get_rank(group), self.world, hs)
-            self.use_oneshot = True              # (a caller that wants both at hand -- bench.py's A/B -- switches this flag)
-            self.collective_name = "klstm_allreduce_grads_oneshot (peer-mapped blobs, one kernel per rank; EXPERIMENTAL)"
+            one = OneshotAllreduce(self._blob_full, device=self._blob_full.device.index or 0)
+            handles = one.export()
+        except Exception as ex:
+            err = "rank %d: %s" % (rank, ex)
+        hs = [None] * self.world
+        dist.all_gather_object(hs, (handles, err), group=group)
+        errs = [h[1] for h in hs if h[1]]
+        if not errs:
+            try:
+                one.connect(rank, self.world, [h[0] for h in hs])
+            except Exception as ex:
+                err = "rank %d: %s" % (rank, ex)
+            es = [None] * self.world
+            dist.all_gather_object(es, err, group=group)
+            errs = [x for x in es if x]
+        if errs:
+            if one is not None:
+                one.close()
+            self.oneshot_note = "one-shot exchange not available (%s)" % "; ".join(errs)
+            if rank == 0:
+                print("kaldi_lstm_amd.dp: " + self.oneshot_note + ": the all-reduce stays on " + self._rccl_name, file=sys.stderr)
+            return
+        self.oneshot = one
+        self.use_oneshot = True              # (a caller that wants both at hand -- bench.py's A/B -- switches this flag)
+        self.collective_name = "klstm_allreduce_grads_oneshot (peer-mapped blobs, one kernel per rank; EXPERIMENTAL)"
 
     def collective_in_use(self):
         return self.collective_name if (self.oneshot is not None and self.use_oneshot) or self.oneshot is None else self._rccl_name

@@ -120,6 +120,45 @@ def test_two_rank_dp_equals_single_process():
     np.testing.assert_array_equal(res[0][1], res[1][1])                                  # and bit-identical to each other
 
 
+def oneshot_refusal_worker(rank, world, port, q):
+    import kaldi_lstm_amd as k
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params, xs, ods = data()
+
+    class Eng(OracleEngine):
+        def grad_blob_tensor(self, full=False):
+            if full and rank == 1:
+                raise RuntimeError("no peer mapping on this rank")
+            return self._grad                 # (a CPU tensor: rank 0's export is refused too, for a different reason)
+    eng = Eng(S_TOTAL // world, params)
+    dp = k.DataParallelLstm(eng, oneshot=True)       # must return on BOTH ranks, with the same decision
+    q.put((rank, dp.oneshot is None, dp.oneshot_note, dp.collective_in_use()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_oneshot_exchange_that_one_rank_cannot_set_up_is_dropped_by_all_ranks():
+    """bench.py --gpus N asks for the one-shot exchange; a rank that cannot export or open a handle must not leave the others
+    waiting in a collective: the ranks agree and everybody stays on the ordinary all-reduce (dp.py _setup_oneshot)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=oneshot_refusal_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, none, note, name in res:
+        assert none and "rank 1: no peer mapping on this rank" in note and "torch.distributed" in name
+    assert res[0][2] == res[1][2]
+
+
 def test_shard_time_major_layout():
     import kaldi_lstm_amd as k
     m = np.arange(3 * 4 * 2).reshape(12, 2)          # T=3, S=4
