@@ -38,7 +38,7 @@ int main() {
     char nm[96]; snprintf(nm, sizeof nm, "k_split3, %u workgroups", g);
     time(nm, [&]() { hipLaunchKernelGGL(k_split3, dim3(g), dim3(256), 0, st, s); });
   }
-  time("launch_fold_bf16x3 (split + product, as the engine runs it)", [&]() { CK(launch_fold_bf16x3(d, wr, wmT, scratch, pk, nch1, nch2, st, {}, {})); });
+  time("launch_fold_bf16x3 (split + product, as the engine runs it)", [&]() { CK(launch_fold_bf16x3(d, 1, wr, wmT, scratch, pk, nch1, nch2, st, {}, {})); });
   auto anatomy = [&](int nwg) {
     std::vector<long long> h(1024 * 8);
     CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
@@ -58,6 +58,7 @@ int main() {
   Fold3Args a;
   a.dbg = dbg;
   a.C = C; a.R = R; a.a3 = a3; a.b3 = b3; a.a_plane = apl; a.b_plane = bpl;
+  a.wr = wr; a.wmT = wmT; a.redo = nullptr; a.wl = nullptr;      // (range guard: no event counter here; logical-row bf16 output: the many-stream launch only)
   a.pk1 = reinterpret_cast<float4 *>(pk[0]); a.nch1 = nch1; a.pk2 = reinterpret_cast<float4 *>(pk[1]); a.nch2 = nch2;
 #define VAR(MI, NI, NB, ND) VARL(MI, NI, NB, ND, false)
 #define VARL(MI, NI, NB, ND, LW) VARP(MI, NI, NB, ND, LW, 3)

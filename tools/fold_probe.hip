@@ -3,6 +3,7 @@
 #include "../kaldi-lstm_amd/csrc/klstm_kernels.hip"
 #define KLSTM_FOLD_TIMING
 #include "../kaldi-lstm_amd/csrc/klstm_fold.hip"
+#include "../kaldi-lstm_amd/csrc/klstm_fold3.hip"      // (launch_fold of klstm_kernels.hip dispatches to it)
 #include <cstdio>
 #include <vector>
 #include <cmath>
