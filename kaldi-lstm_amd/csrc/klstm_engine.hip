@@ -1269,6 +1269,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else if (!strcmp(key, "persist_tpw")) e->popt.tpw = value;
     else if (!strcmp(key, "persist_waves")) { e->popt.waves = value; e->popt.bwd_waves = value; }
     else if (!strcmp(key, "persist_bwd_waves")) e->popt.bwd_waves = value;
+    else if (!strcmp(key, "persist_bwd_interleave")) e->popt.bwd_interleave = value;
     else if (!strcmp(key, "persist_nap0")) e->popt.nap0 = value;
     else if (!strcmp(key, "persist_nap")) e->popt.nap = value;
     else if (!strcmp(key, "persist_nap0_bwd")) e->popt.nap0_bwd = value;

@@ -237,6 +237,7 @@ struct PersistOpts {
   int nap0 = -1, nap = -1;        // sweepers sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
   int nap0_bwd = -1;              // the same for the backward launch
   int bwd_waves = 0;              // backward: 12 or 16 waves per workgroup
+  int bwd_interleave = -1;        // backward, 5..8 streams: the two groups of 4 as interleaved chains (-1 / 1) or one after the other (0)
   long long spin_limit = 0;       // wall-clock ticks (100 MHz) a single in-kernel wait may take (0 = 50 ms)
   int test_stall_fwd = 0, test_stall_bwd = 0;   // test hook: workgroup 0 withholds its publish of this step -> timeout path
   unsigned *hstat = nullptr;      // host-mapped status word: set by a launch that gives up (the engine polls it without a sync)

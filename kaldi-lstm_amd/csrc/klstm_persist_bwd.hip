@@ -28,9 +28,9 @@
 // same inputs).  Shipping dgifo instead (each workgroup computing only its own cells) would quadruple the swept bytes
 // (S x 4C values, 68-77 KB per workgroup and pass even in 16-byte {tag, 3 x fp32} granules) for no shorter chain: after the
 // sweep a replicated pair costs five multiply-adds.
-// 5..8 streams: the two groups of 4 run their chains one after the other inside the launch, against the same resident
-// weights (the exchange is latency bound at 4 streams and bandwidth bound at 8: two streams groups pipelined against each
-// other measured slower than in sequence, DESIGN.md 3c "dead ends"); each group has its own granule slots.
+// 5..8 streams: two groups of 4 against the same resident weights, each with its own granule slots -- as two INTERLEAVED chains
+// (k_bwd_persist2i below: 101 us per launch at 8 streams) or, option "persist_bwd_interleave" = 0, one chain after the other
+// (k_bwd_persist2: 129 us).
 // Wave roles: wave 0 = owner (combine, publish, dgifo / dc plane rows of the own cells), wave 1 = P wave (own columns of
 // P = out_diff W_r_m ahead of the chain; finishes d_r / in_diff), waves 2.. = SC waves.  Nothing global is ordered by
 // anything but the granule tags; every wait is bounded (per wait, wall clock).
@@ -492,6 +492,382 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------------
+// 5..8 streams, INTERLEAVED: the two groups of 4 streams are two independent chains (a group's step t needs that group's step
+// t + 1 from every workgroup, nothing of the other group).  k_bwd_persist2 runs them one after the other -- 2 T exchange round
+// trips in a row.  Here every role walks (frame t, group 0), (frame t, group 1), (frame t - 1, group 0), ...: while the d_m of one
+// group crosses the fabric the SC waves pull planes, apply and contract for the other, so a step-pair costs about two computes
+// instead of two computes plus two round trips.  Same arithmetic, same instruction sequences per (cell, stream) as
+// k_bwd_persist2: bit-identical results.  (Round 2 measured "groups pipelined against each other" slower -- in a kernel whose
+// sweeper waves polled while OTHER waves of the workgroup wanted the vector-memory queue; here a wave never polls and loads at
+// the same time, it does one after the other.)
+// What is per group: granule slots and tags (as before), the carry, the owner's pair state, the partial buffers `red`, the P
+// rows in LDS and the counters a role waits on for ONE group (partials written, publishes issued, frames of P): within a group
+// the chain itself keeps the producers from running ahead, across groups nothing does, so a shared counter could be satisfied
+// by a mix of two steps.  The d_r / in_diff partials keep their one counter with the hand-shake of k_bwd_persist2 (nobody adds
+// for set n before the P wave has consumed set n - 1).
+// -------------------------------------------------------------------------------------------------------------------
+template <int NW, int NU>
+__global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
+  constexpr int NSC = NW - 2, NSLOT = NSC * NU;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned *abortf = reinterpret_cast<unsigned *>(lds);
+  int *dcnt = reinterpret_cast<int *>(lds) + 2;      // d_r / in_diff partials written
+  int *dcons = reinterpret_cast<int *>(lds) + 3;     // d sets the P wave has consumed
+  int *pcnt = reinterpret_cast<int *>(lds) + 4;      // [2] d_m partials written, per group (one count per SC wave and step)
+  int *pdone = reinterpret_cast<int *>(lds) + 6;     // [2] frames of P in LDS, per group (descending frames)
+  int *pubn = reinterpret_cast<int *>(lds) + 8;      // [2] publishes the owner has issued, per group
+  f32x4 *red = reinterpret_cast<f32x4 *>(lds + 16);  // [2 groups][NSC][4 streams]: components = the 4 own cells
+  f32x4 *red2 = red + 2 * NSC * 4;                   // [2][NSC][4 streams]: components = the 4 d_r / in_diff columns
+  float *xtile = reinterpret_cast<float *>(red2 + 2 * NSC * 4);   // [NSC][4 gates][32 cells][4 streams]: natural -> operand order
+  float *wD = xtile + NSC * 512;                         // [NSLOT][2 sets][4 gates][64 lanes]: A operands of the d_r / in_diff columns
+  f32x4 *ldsP = reinterpret_cast<f32x4 *>(wD + NSLOT * 512);     // [2 groups][T][4 streams] (pin): components = the 4 own cells
+  const int C = a.C, S = a.S, T = a.T, K = 4 * a.C;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long limit = a.spin_limit;
+  const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned behind_giveup = 0u;                       // (as in k_bwd_persist2: looked at behind each role's prologue loads)
+#ifndef KLSTM_NO_CHAIN_GUARD
+  if (a.guard) behind_giveup = __hip_atomic_load(&a.guard[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                               __hip_atomic_load(&a.guard[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+  const int ngr = a.R / 4, ngx = (a.din & 2) ? a.I / 4 : 0;
+  const bool d_on = a.din && (int)blockIdx.x < ngr + ngx, d_isr = (int)blockIdx.x < ngr;
+  const int dcol = d_isr ? (int)blockIdx.x * 4 : ((int)blockIdx.x - ngr) * 4;
+  if (tid < 16) reinterpret_cast<int *>(lds)[tid] = 0;
+  __syncthreads();
+  const int Sg1 = S - 4;                             // streams of group 1 (group 0 has 4)
+
+  if (wave == 0) {
+    // =========================== owner: combine, publish, own plane rows ===========================
+    const int oi = (lane >> 2) & 3, oj = lane & 3;
+    const int ocell = (int)blockIdx.x * 4 + oi;
+    const float wpi = a.pi[ocell], wpf = a.pf[ocell], wpo = a.po[ocell];
+    const float *redf = reinterpret_cast<const float *>(red);
+    bool dead = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
+    bool on[2]; int srow[2]; unsigned long long *gr[2]; unsigned tag0[2];
+    float carry[2] = {0.f, 0.f}, dmv[2] = {0.f, 0.f};
+    float yg[2], yi[2], yf[2], yo[2], yh[2], cpv[2];
+    int np[2] = {0, 0};
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const int Sg = g ? Sg1 : 4;
+      on[g] = lane < 16 && oj < Sg;
+      srow[g] = 4 * g + (oj < Sg ? oj : 0);
+      gr[g] = a.gran + (size_t)g * 2 * C * 4;
+      tag0[g] = epoch + (unsigned)(g * (T + 2));
+    }
+    auto load_planes = [&](int t, int g) {
+      const float *gp = a.gifo + ((size_t)t * S + srow[g]) * K + ocell;
+      yg[g] = gp[0]; yi[g] = gp[C]; yf[g] = gp[2 * C]; yo[g] = gp[3 * C];
+      yh[g] = a.hh[((size_t)t * S + srow[g]) * C + ocell];
+      cpv[g] = a.cc[((size_t)(t - 1) * S + srow[g]) * C + ocell];
+    };
+    auto own_rows = [&](int t, int g) {
+      const Bptt2Coef cf = bptt2_coef(yg[g], yi[g], yf[g], yo[g], yh[g], cpv[g], wpi, wpf, wpo);
+      float dcv;
+      const float4 d = bptt2_apply(dmv[g], cf, carry[g], dcv);
+      if (on[g]) {
+        float *dp = a.dgifo + ((size_t)t * S + srow[g]) * K + ocell;
+        dp[0] = d.x; dp[C] = d.y; dp[2 * C] = d.z; dp[3 * C] = d.w;
+        a.dc[((size_t)t * S + srow[g]) * C + ocell] = dcv;
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      if (dead) break;
+      if (on[g]) {                                   // dgifo(T+1) = 0 (:351): operand rows of the batched d_r product (tail outside)
+        float *zp = a.dgifo + ((size_t)(T + 1) * S + srow[g]) * K + ocell;
+        zp[0] = 0.f; zp[C] = 0.f; zp[2 * C] = 0.f; zp[3 * C] = 0.f;
+      }
+      if (a.pin) {
+        if (!lds_wait_ge(pdone + g, 1, abortf, limit)) { dead = true; break; }
+        dmv[g] = reinterpret_cast<const float *>(&ldsP[(g * T + T - 1) * 4 + oj])[oi];
+      } else {
+        dmv[g] = a.P[((size_t)(T - 1) * S + srow[g]) * C + ocell];
+      }
+      if (on[g] && !(a.test_stall == T && blockIdx.x == 0)) publish(gr[g] + (size_t)(T & 1) * C * 4, ocell * 4 + oj, tag0[g] + (unsigned)T, dmv[g]);
+      __hip_atomic_store(pubn + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      load_planes(T, g);
+    }
+    for (int t = T; t >= 2 && !dead; t--) {
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        float pnext = 0.f;
+        if (!a.pin) pnext = a.P[((size_t)(t - 2) * S + srow[g]) * C + ocell];
+        ++np[g];
+        if (!lds_wait_ge(pcnt + g, NSC * np[g], abortf, limit)) { dead = true; break; }
+        float part[NSC];
+#pragma unroll
+        for (int w = 0; w < NSC; w++) part[w] = redf[((g * NSC + w) * 4 + oj) * 4 + oi];
+        if (a.pin) {
+          if (!lds_wait_ge(pdone + g, T - t + 2, abortf, limit)) { dead = true; break; }
+          pnext = reinterpret_cast<const float *>(&ldsP[(g * T + t - 2) * 4 + oj])[oi];
+        }
+        float sum = part[0];
+#pragma unroll
+        for (int w = 1; w < NSC; w++) sum += part[w];  // fixed order
+        const float dmn = sum + pnext;               // :408 with :391 substituted
+        if (on[g] && !(a.test_stall == t - 1 && blockIdx.x == 0))
+          publish(gr[g] + (size_t)((t - 1) & 1) * C * 4, ocell * 4 + oj, tag0[g] + (unsigned)(t - 1), dmn);
+        __hip_atomic_store(pubn + g, T - t + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        own_rows(t, g);
+        dmv[g] = dmn;
+        load_planes(t - 1, g);
+      }
+    }
+    if (!dead) { own_rows(1, 0); own_rows(1, 1); }
+  } else if (wave == 1) {
+    // =========================== P wave: own columns of P = out_diff W_r_m; finishes d_r / in_diff ===========================
+    const int kg = lane >> 2, bj = lane & 3, R = a.R;
+    float4 w0[4], w1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int k = 128 * i + 4 * kg, pc = (int)blockIdx.x * 4 + bj;
+      w0[i] = a.pin && k < R ? *reinterpret_cast<const float4 *>(a.wmT + (size_t)pc * R + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      w1[i] = a.pin && k + 64 < R ? *reinterpret_cast<const float4 *>(a.wmT + (size_t)pc * R + k + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float *red2f = reinterpret_cast<const float *>(red2);
+    const int fi = (lane >> 2) & 3, fj = lane & 3;   // finishing lanes 0..15 = (column fi, stream fj)
+    int nd = 0;
+    bool dead = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
+    int nextf = T - 1;                               // next frame of P (descending), BOTH groups per frame
+    auto p_until = [&](int flo) {
+      while (nextf >= flo && nextf >= 0) {
+        const int f = nextf;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          const bool rv = bj < (g ? Sg1 : 4);
+          const float *op = a.od + ((size_t)f * S + 4 * g + (rv ? bj : 0)) * a.od_stride + 4 * kg;
+          float4 b0[4], b1[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int k = 128 * i + 4 * kg;
+            b0[i] = rv && k < R ? *reinterpret_cast<const float4 *>(op + 128 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b1[i] = rv && k + 64 < R ? *reinterpret_cast<const float4 *>(op + 128 * i + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float av[8] = {w0[i].x, w0[i].y, w0[i].z, w0[i].w, w1[i].x, w1[i].y, w1[i].z, w1[i].w};
+            const float bv[8] = {b0[i].x, b0[i].y, b0[i].z, b0[i].w, b1[i].x, b1[i].y, b1[i].z, b1[i].w};
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) acc[jj & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[jj], bv[jj], acc[jj & 3], 0, 0, 0);
+          }
+          const f32x4 v = kgroup_sum_pl((acc[0] + acc[1]) + (acc[2] + acc[3]));
+          if (lane >= 12 && lane < 16) ldsP[(g * T + f) * 4 + bj] = v;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __hip_atomic_store(pdone + g, T - f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        nextf--;
+      }
+    };
+    if (!dead) {
+      // d_r(T) = out_diff(T): dgifo(T+1) = 0 (:351, :391)
+#pragma unroll
+      for (int g = 0; g < 2; g++)
+        if (d_on && d_isr && lane < 16 && fj < (g ? Sg1 : 4))
+          a.dr[((size_t)T * S + 4 * g + fj) * R + dcol + fi] = a.od[((size_t)(T - 1) * S + 4 * g + fj) * a.od_stride + dcol + fi];
+      if (a.pin) p_until(T - 2);
+      if (d_on) {
+        for (int t = T; t >= (d_isr ? 2 : 1) && !dead; t--) {
+          if (a.pin) p_until(t - 3);                 // one frame ahead of the owner
+#pragma unroll
+          for (int g = 0; g < 2; g++) {
+            const int Sg = g ? Sg1 : 4;
+            float odv = 0.f;
+            if (d_isr && lane < 16 && fj < Sg) odv = a.od[((size_t)(t - 2) * S + 4 * g + fj) * a.od_stride + dcol + fi];
+            ++nd;
+            if (!lds_wait_ge(dcnt, NSC * nd, abortf, limit)) { dead = true; break; }
+            float part[NSC];
+#pragma unroll
+            for (int w = 0; w < NSC; w++) part[w] = red2f[(((nd & 1) * NSC + w) * 4 + fj) * 4 + fi];
+            float sum = part[0];
+#pragma unroll
+            for (int w = 1; w < NSC; w++) sum += part[w];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __hip_atomic_store(dcons, nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane < 16 && fj < Sg) {
+              if (d_isr) a.dr[((size_t)(t - 1) * S + 4 * g + fj) * R + dcol + fi] = odv + sum;          // :391
+              else a.in_diff[((size_t)(t - 1) * S + 4 * g + fj) * a.id_stride + dcol + fi] = sum;       // :457
+            }
+          }
+        }
+      }
+      if (a.pin && !dead) p_until(0);
+    }
+  } else {
+    // =========================== sweep-and-contract waves (layouts: k_bwd_persist2) ===========================
+    const int w = wave - 2, b = lane >> 2, j = lane & 3, c32 = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x;
+    float *xt = xtile + w * 512;
+    float wA[NU][2][4];
+    float wpi[NU], wpf[NU], wpo[NU];
+    int svoff[NU];
+    unsigned cmask = 0;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const int sl = u * NSC + w;
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const int cell = 32 * sl + 16 * p + b;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int cc = cell < C ? cell : 0;
+          const float v = a.wpk[(((((size_t)(cc >> 2) * a.nch1 + (tile >> 3)) * 2 + (tile & 1)) * 64 + ((tile & 7) >> 1) * 16 + 4 * (cc & 3) + e) << 2) + j];
+          wA[u][p][e] = cell < C ? v : 0.f;
+        }
+      }
+      const int cl = 32 * sl + c32;
+      if (cl < C) cmask |= 1u << u;
+      const int clc = cl < C ? cl : 0;
+      svoff[u] = clc * 32 + h * 16;
+      wpi[u] = a.pi[clc]; wpf[u] = a.pf[clc]; wpo[u] = a.po[clc];
+    }
+    if (d_on) {
+      const float *src = (d_isr ? a.wrT : a.wxT) + (size_t)dcol * K + (size_t)j * K;
+#pragma unroll 8
+      for (int q = 0; q < NU * 8; q++) {
+        const int e = q & 3, p = (q >> 2) & 1, sl = (q >> 3) * NSC + w, cell = 32 * sl + 16 * p + b;
+        wD[((sl * 2 + p) * 4 + e) * 64 + lane] = cell < C ? src[e * C + cell] : 0.f;
+      }
+    }
+    const int voffG = (2 * h * K + 32 * w + c32) * 4, voffC = (2 * h * C + 32 * w + c32) * 4;
+    const __amdgpu_buffer_rsrc_t rs_g = buf_rsrc(a.gifo, (T + 2) * S * K * 4), rs_h = buf_rsrc(a.hh, (T + 2) * S * C * 4);
+    const __amdgpu_buffer_rsrc_t rs_c = buf_rsrc(a.cc, (T + 2) * S * C * 4);
+    const __amdgpu_buffer_rsrc_t rs_gr0 = buf_rsrc(a.gran, 2 * C * 32), rs_gr1 = buf_rsrc(a.gran + (size_t)2 * C * 4, 2 * C * 32);
+    int nd = 0;
+    bool dead = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
+    float carry[2][NU][2];
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+      for (int u = 0; u < NU; u++) { carry[g][u][0] = 0.f; carry[g][u][1] = 0.f; }
+    const int tlo = (d_on && !d_isr) ? 1 : 2;        // frame 1 is swept only where in_diff(1) is contracted
+    for (int t = T; t >= tlo && !dead; t--) {
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        const int Sg = g ? Sg1 : 4;
+        const bool need0 = 2 * h < Sg, need1 = 2 * h + 1 < Sg;
+        const __amdgpu_buffer_rsrc_t rs_gr = g ? rs_gr1 : rs_gr0;
+        // plane loads go out once the owner's publish of d_m(t) of THIS group has been issued (k_bwd_persist2)
+        if (!lds_wait_ge(pubn + g, T - t + 1, abortf, limit)) { dead = true; break; }
+        const int sG = (t * S + 4 * g) * K * 4, sC = (t * S + 4 * g) * C * 4;
+        Bptt2Coef cf[NU][2];
+#pragma unroll
+        for (int u = 0; u < NU; u++)
+#pragma unroll
+          for (int x = 0; x < 2; x++) {
+            const int imm = u * NSC * 32 * 4, oG = sG + x * K * 4, oC = sC + x * C * 4;
+            const float yg = buf_f32(rs_g, voffG + imm, oG), yi = buf_f32(rs_g, voffG + imm, oG + C * 4);
+            const float yf = buf_f32(rs_g, voffG + imm, oG + 2 * C * 4), yo = buf_f32(rs_g, voffG + imm, oG + 3 * C * 4);
+            const float yh = buf_f32(rs_h, voffC + imm, oC), cpv = buf_f32(rs_c, voffC + imm, oC - S * C * 4);
+            cf[u][x] = bptt2_coef(yg, yi, yf, yo, yh, cpv, wpi[u], wpf[u], wpo[u]);
+          }
+        // ---- sweep d_m(t) of group g ----
+        for (int i = 0; i < a.nap0; i++) __builtin_amdgcn_s_sleep(4);
+        const unsigned tag = epoch + (unsigned)(g * (T + 2)) + (unsigned)t;
+        const int soff = (t & 1) * C * 32;
+        u32x4 q[NU];
+        {
+          const long long t0 = wall_clock64();
+          for (unsigned spins = 0;; spins++) {
+#pragma unroll
+            for (int u = 0; u < NU; u++) q[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_gr, svoff[u], soff, 16);   // aux 16 = sc1
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+              const unsigned t0g = q[u].y, t1g = q[u].w;
+              const bool live = (cmask >> u) & 1u;
+              ok &= !live | (((!need0) | (t0g == tag)) & ((!need1) | (t1g == tag)));
+            }
+            if (__all(ok)) break;
+            if ((spins & 15) == 15) {
+              if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { dead = true; break; }
+              if (wall_clock64() - t0 > limit) {
+                __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) { atomicCAS(&a.ctrl[3], 0u, launch_ordinal(a.guard)); atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t); }
+                dead = true;
+                break;
+              }
+            }
+            for (int i = 0; i < a.nap; i++) __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        if (dead) break;
+        // ---- elementwise BPTT of frame t (:411-440), then into operand order through the wave's tile ----
+        float Bv[NU][2][4];
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+          const unsigned v0 = q[u].x, v1 = q[u].z;
+          const bool live = (cmask >> u) & 1u;
+          float dcv;
+          const float4 d0 = bptt2_apply(live ? __uint_as_float(v0) : 0.f, cf[u][0], carry[g][u][0], dcv);
+          const float4 d1 = bptt2_apply(live ? __uint_as_float(v1) : 0.f, cf[u][1], carry[g][u][1], dcv);
+          float2 *xw = reinterpret_cast<float2 *>(xt + c32 * 4 + 2 * h);
+          xw[0] = make_float2(d0.x, d1.x); xw[64] = make_float2(d0.y, d1.y);
+          xw[128] = make_float2(d0.z, d1.z); xw[192] = make_float2(d0.w, d1.w);
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Bv[u][p][e] = xt[e * 128 + p * 64 + lane];
+          asm volatile("" ::: "memory");
+        }
+        if (t > 1) {
+          f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+          for (int u = 0; u < NU; u++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+              acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[u][p][0], Bv[u][p][0], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[u][p][1], Bv[u][p][1], acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[u][p][2], Bv[u][p][2], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[u][p][3], Bv[u][p][3], acc1, 0, 0, 0);
+            }
+          const f32x4 v = kgroup_sum_pl(acc0 + acc1);
+          if (lane >= 12 && lane < 16) red[(g * NSC + w) * 4 + (lane & 3)] = v;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(pcnt + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (d_on && (t > 1 || !d_isr)) {
+          ++nd;
+          if (nd > 1 && !lds_wait_ge(dcons, nd - 1, abortf, limit)) { dead = true; break; }
+          float wd[NU][2][4];
+#pragma unroll
+          for (int u = 0; u < NU; u++)
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+              for (int e = 0; e < 4; e++) wd[u][p][e] = wD[(((u * NSC + w) * 2 + p) * 4 + e) * 64 + lane];
+          f32x4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+#pragma unroll
+          for (int u = 0; u < NU; u++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+              d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[u][p][0], Bv[u][p][0], d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[u][p][1], Bv[u][p][1], d1, 0, 0, 0);
+              d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[u][p][2], Bv[u][p][2], d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[u][p][3], Bv[u][p][3], d1, 0, 0, 0);
+            }
+          const f32x4 v = kgroup_sum_pl(d0 + d1);
+          if (lane >= 12 && lane < 16) red2[((nd & 1) * NSC + w) * 4 + (lane & 3)] = v;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(dcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && *abortf) {                         // (a bounded LDS wait expired or a sweep timed out)
+    atomicCAS(&a.ctrl[3], 0u, launch_ordinal(a.guard));
+    atomicMax(&a.ctrl[2], 0x80000000u | 0x7fffu);
+    if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  finish(a.ctrl, epoch, 2 * (T + 2), a.guard ? a.guard + 8 : nullptr);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
 // launcher
 // -------------------------------------------------------------------------------------------------------------------
 static inline int pcdiv2(int a, int b) { return (a + b - 1) / b; }
@@ -509,10 +885,12 @@ static PGeo2 pick_geo_bwd2(const Dims &d, const PersistOpts &o) {
   }
   return PGeo2{0, 0};
 }
-static size_t bwd2_lds_bytes(const PGeo2 &g, int T, bool pin) {
-  const int nsc = g.nw - 2, nslot = nsc * g.nu;
-  return (size_t)(16 + nsc * 16 + 2 * nsc * 16 + nsc * 512 + nslot * 512 + (pin ? T * 16 : 0)) * sizeof(float);
+static size_t bwd2_lds_bytes(const PGeo2 &g, int T, bool pin, bool interleaved = false) {
+  const int nsc = g.nw - 2, nslot = nsc * g.nu, ng = interleaved ? 2 : 1;       // (interleaved: `red` and the P rows per group)
+  return (size_t)(16 + ng * nsc * 16 + 2 * nsc * 16 + nsc * 512 + nslot * 512 + (pin ? ng * T * 16 : 0)) * sizeof(float);
 }
+// 5..8 streams: the two groups as interleaved chains (k_bwd_persist2i) unless the option says otherwise
+static bool bwd_interleaved(const Dims &d, const PersistOpts &o) { return d.S > 4 && o.bwd_interleave != 0; }
 
 bool persist_bwd_supported(const Dims &d, const PersistOpts &o) {
   if (d.S > 8 || d.C % 8 != 0 || d.R % 4 != 0 || d.C / 4 > 256) return false;
@@ -522,7 +900,7 @@ int persist_bwd_grid(const Dims &d) { return d.C / 4; }
 // P = out_diff W_r_m inside the backward launch: own columns in LDS (T frames x 4 streams x 4 cells), rows of W_r_m^T in registers
 bool persist_p_in_kernel(const Dims &d, const PersistOpts &o) {
   const PGeo2 g = pick_geo_bwd2(d, o);
-  return g.nw != 0 && d.R <= 512 && d.R % 4 == 0 && bwd2_lds_bytes(g, d.T, true) <= 152 * 1024;
+  return g.nw != 0 && d.R <= 512 && d.R % 4 == 0 && bwd2_lds_bytes(g, d.T, true, bwd_interleaved(d, o)) <= 152 * 1024;
 }
 // d_r and in_diff inside the backward launch: 4 columns per workgroup
 bool persist_tail_in_kernel(const Dims &d, bool want_in_diff, const PersistOpts &o) {
@@ -564,8 +942,15 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
 #endif
   const PGeo2 g = pick_geo_bwd2(d, o);
   if (!g.nw || !p.pk_fold_gates || d.S > 8) return hipErrorInvalidValue;
-  const size_t shm = bwd2_lds_bytes(g, d.T, a.pin != 0);
   const int grid = persist_bwd_grid(d);
+  if (bwd_interleaved(d, o)) {
+    const size_t shmi = bwd2_lds_bytes(g, d.T, a.pin != 0, true);
+    if (g.nw == 16 && g.nu == 2) return plaunch2(k_bwd_persist2i<16, 2>, grid, 1024, shmi, st, pr, a);
+    if (g.nw == 16 && g.nu == 3) return plaunch2(k_bwd_persist2i<16, 3>, grid, 1024, shmi, st, pr, a);
+    if (g.nw == 12 && g.nu == 3) return plaunch2(k_bwd_persist2i<12, 3>, grid, 768, shmi, st, pr, a);
+    return hipErrorInvalidValue;
+  }
+  const size_t shm = bwd2_lds_bytes(g, d.T, a.pin != 0);
   if (g.nw == 16 && g.nu == 2) return plaunch2(k_bwd_persist2<16, 2>, grid, 1024, shm, st, pr, a);
   if (g.nw == 16 && g.nu == 3) return plaunch2(k_bwd_persist2<16, 3>, grid, 1024, shm, st, pr, a);
   if (g.nw == 12 && g.nu == 3) return plaunch2(k_bwd_persist2<12, 3>, grid, 768, shm, st, pr, a);

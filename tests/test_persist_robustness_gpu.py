@@ -313,3 +313,26 @@ def test_data_parallel_step_with_a_give_up_keeps_the_replicas_together(verify):
         e.close(); t.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [5, 6, 8])
+def test_interleaved_stream_groups_of_the_backward_launch_are_bit_identical_to_groups_in_sequence(S):
+    """5..8 streams: the backward launch walks its two groups of 4 streams as two interleaved chains (k_bwd_persist2i: one group's
+    d_m crosses the fabric while the other group's planes are pulled and contracted) instead of one chain after the other
+    (k_bwd_persist2, option "persist_bwd_interleave" = 0).  Same instruction sequence per (cell, stream): every output, the
+    parameters, the momentum and the carried state must agree to the bit, over chained minibatches."""
+    import kaldi_lstm_amd as k
+    I, C, R, T = 40, 800, 512, 20
+    p = make_params(I, C, R, scale=0.01, seed=91)
+    rng = np.random.RandomState(92)
+    a = k.Engine(I, C, R, S); a.set_params(p); a.set_option("persist", 2)
+    b = k.Engine(I, C, R, S); b.set_params(p); b.set_option("persist", 2); b.set_option("persist_bwd_interleave", 0)
+    out_a = torch.empty(T * S, R, device="cuda"); idf_a = torch.empty(T * S, I, device="cuda")
+    out_b = torch.empty(T * S, R, device="cuda"); idf_b = torch.empty(T * S, I, device="cuda")
+    for i in range(3):
+        x, od = _minibatch(rng, I, R, S, T, 0.1)
+        xd, odd = dev(x), dev(od)
+        _step(a, xd, odd, out_a, idf_a, 1e-5)
+        _step(b, xd, odd, out_b, idf_b, 1e-5)
+        _same(_snapshot(a, out_a, idf_a), _snapshot(b, out_b, idf_b), "minibatch %d" % i)
+    a.close(); b.close()
