@@ -1137,7 +1137,7 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
     }
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
                                 e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr,
-                                fold_grad ? ar_mark_if_reduced(e) : nullptr, e->pctrl ? e->pctrl + 10 : nullptr));
+                                ar_mark_if_reduced(e), e->pctrl ? e->pctrl + 10 : nullptr));   // (also when the momentum pass ran on its own: a getter in between)
   }
   // (Packing the BPTT operands on a second stream, overlapped with the next forward pass, was measured to cost
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
