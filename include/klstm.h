@@ -321,7 +321,8 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  caller-provided, unchanged buffers until the next klstm_propagate / klstm_reset on the engine (Kaldi's
  *                  Nnet keeps them exactly that long).  A minibatch older than that cannot be run again: it is DROPPED -- no
  *                  Update, no state advance -- and counted.  `persist_cooldown` minibatches (default 64) on the launch-per-step
- *                  chain follow, then the persistent chain is tried again.  klstm_last_error() carries a remark;
+ *                  chain follow, then the persistent chain is tried again; a give-up that follows a re-arm closely doubles the
+ *                  cool-down (up to 65536 minibatches), a clean run as long as the last cool-down resets it.  klstm_last_error() carries a remark;
  *                  klstm_profile_query(e, "persist_giveups" | "persist_replayed" | "persist_dropped" | "persist_launches" |
  *                  "dp_updates_left_out", ..) returns the counts in *launches (no "profile" option needed).
  *                  "persist_verify" 0/1: 1 = klstm_propagate / klstm_backpropagate wait for their persistent launch, so a

@@ -130,6 +130,10 @@ struct klstm_engine {
   unsigned pseq = 0;            // persistent launches enqueued so far, both directions (the device counts the same in pctrl[8])
   int persist_verify = 0;       // option: wait for every persistent launch and answer a give-up before the call returns
   int cooldown = 0, cooldown_len = 64;   // minibatches on the launch-per-step chain after a give-up, then the persistent chain again
+  int cooldown_cur = 0;                  // this give-up's cool-down: doubles with every give-up that follows a re-arm closely (a co-tenant that
+                                         // stays would cost a spin limit + a re-run every cooldown_len minibatches), back to cooldown_len
+                                         // after as many clean persistent minibatches as the last cool-down was long
+  long clean_run = 0;                    // persistent minibatches since the last give-up
   long n_giveups = 0, n_replayed = 0, n_dropped = 0;
   bool replaying = false;
   struct FwdMark { unsigned seq; int sp_before; };
@@ -373,7 +377,10 @@ static klstm_status recover(klstm_engine *e, const unsigned (&w)[16]) {
   z[0] = w[0]; z[4] = w[4]; z[8] = w[8]; z[10] = w[10];   // epochs, the launch counter and the count of Updates left out for a peer stay
   HIPCHK(hipMemcpy(e->pctrl, z, sizeof(z), hipMemcpyHostToDevice));
   e->n_giveups++;
-  e->cooldown = e->cooldown_len;
+  if (e->cooldown_cur < e->cooldown_len || e->clean_run >= (long)e->cooldown_cur) e->cooldown_cur = e->cooldown_len;
+  else e->cooldown_cur = e->cooldown_cur >= (1 << 15) ? (1 << 16) : 2 * e->cooldown_cur;
+  e->cooldown = e->cooldown_cur;
+  e->clean_run = 0;
   // host-side bookkeeping of work the device skipped
   e->grads_pending = false; e->mmt_pending = false;
   e->planes_fresh = false; e->fold_dirty = true; e->foldx_fresh = false;
@@ -416,7 +423,7 @@ static klstm_status recover(klstm_engine *e, const unsigned (&w)[16]) {
        affected > covered ? (covered ? "this minibatch was run again on the launch-per-step chain, an earlier one was dropped (no Update, no state advance)"
                                      : "that minibatch was dropped (no Update, no state advance: its buffers were the caller's again)")
                           : "the minibatch was run again on the launch-per-step chain",
-       e->cooldown_len);
+       e->cooldown);
   return KLSTM_RECOVERED;
 }
 
@@ -913,6 +920,7 @@ static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int
   e->fwd_persist = persist_wanted(e, T);
   e->fwd_ms = !e->fwd_persist && persist_ms_wanted(e, T);
   if (!e->replaying && e->cooldown > 0) e->cooldown--;       // (counted in minibatches that ran on the launch-per-step chain)
+  else if (!e->replaying && (e->fwd_persist || e->fwd_ms)) e->clean_run++;
   // launch-per-step kernels are not guarded on the device: nothing of them may be queued behind a persistent launch that
   // nobody has looked at yet (the batched products in front of the many-stream launch only write planes it would have overwritten)
   if (!e->fwd_persist && !e->fwd_ms && (st = settle(e)) != KLSTM_OK) return st;
@@ -1278,7 +1286,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else if (!strcmp(key, "persist_test_stall_bwd")) e->popt.test_stall_bwd = value;
     else if (!strcmp(key, "persist_ncu")) e->ncu = value;                                       // test hook: pretend the device has this many CUs
     else if (!strcmp(key, "persist_verify")) e->persist_verify = value != 0;
-    else if (!strcmp(key, "persist_cooldown")) { e->cooldown_len = value < 0 ? 0 : value; if (e->cooldown > e->cooldown_len) e->cooldown = e->cooldown_len; }
+    else if (!strcmp(key, "persist_cooldown")) { e->cooldown_len = value < 0 ? 0 : value; e->cooldown_cur = 0; if (e->cooldown > e->cooldown_len) e->cooldown = e->cooldown_len; }
     else return fail(KLSTM_ERR_ARG, "klstm_set_option: unknown key '%s'", key);
     return KLSTM_OK;
   }

@@ -336,3 +336,29 @@ def test_interleaved_stream_groups_of_the_backward_launch_are_bit_identical_to_g
         _step(b, xd, odd, out_b, idf_b, 1e-5)
         _same(_snapshot(a, out_a, idf_a), _snapshot(b, out_b, idf_b), "minibatch %d" % i)
     a.close(); b.close()
+
+
+def test_cool_down_backs_off_while_the_give_ups_keep_coming():
+    """A co-tenant that stays: every attempt to go back to the persistent chain gives up again (here: the test hook stays on).  The
+    cool-down doubles with every give-up that follows a re-arm closely -- 2, 4, 8 minibatches with "persist_cooldown" = 2 -- instead of
+    paying a spin limit and a re-run every 2 minibatches: 4 give-ups in 20 minibatches (at 0, 3, 8, 17), not 7; results are those of an
+    engine that never used the persistent chain (every give-up was a forward one, answered inside the call: bit-identical)."""
+    import kaldi_lstm_amd as k
+    I, C, R, S, T, N = 40, 64, 32, 4, 8, 20
+    p = make_params(I, C, R, scale=0.2, seed=95)
+    rng = np.random.RandomState(96)
+    e = k.Engine(I, C, R, S); e.set_params(p)
+    t = k.Engine(I, C, R, S); t.set_params(p); t.set_option("persist", 0)
+    e.set_option("persist", 2); e.set_option("persist_spin_us", 2000); e.set_option("persist_verify", 1)
+    e.set_option("persist_cooldown", 2); e.set_option("persist_test_stall_fwd", 3)
+    out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+    out_t = torch.empty(T * S, R, device="cuda"); idf_t = torch.empty(T * S, I, device="cuda")
+    for i in range(N):
+        x, od = _minibatch(rng, I, R, S, T, 1.0)
+        xd, odd = dev(x), dev(od)
+        _step(e, xd, odd, out, idf, 1e-3)
+        _step(t, xd, odd, out_t, idf_t, 1e-3)
+    _same(_snapshot(e, out, idf), _snapshot(t, out_t, idf_t), "after 20 minibatches with 4 give-ups")
+    assert e.profile_query("persist_giveups")[1] == 4
+    assert e.profile_query("persist_replayed")[1] == 4 and e.profile_query("persist_dropped")[1] == 0
+    e.close(); t.close()
