@@ -528,6 +528,12 @@ def main():
                       "gradient_products": "f32 MFMA", "elementwise": "f32",
                       "fold": fold_names.get(eng.profile_query("fold_mode")[1], "?") if folded_chain(eng) else "none (no fold product on this chain)",
                       "fp16_range_guard_events": eng.profile_query("fp16_redo")[1]}
+        # every minibatch of the run was applied: no persistent launch gave up, no Update was left out (the counters of klstm.h "persist")
+        ev_names = ("persist_giveups", "persist_replayed", "persist_dropped", "dp_updates_left_out")
+        ev = torch.tensor([eng.profile_query(name)[1] for name in ev_names], dtype=torch.int64, device="cuda")
+        if world > 1:
+            dist.all_reduce(ev, op=dist.ReduceOp.MAX)          # (the largest count on any rank)
+        persist_events = dict(zip(ev_names, ev.tolist()))
         strict = None
         if world == 1 and not args.no_extras:
             strict = {}
@@ -662,6 +668,7 @@ def main():
             res["fold_bf16x3"] = strict["fold_bf16x3"]
         if allreduce_ab:
             res["allreduce_ab"] = allreduce_ab
+        res["persist_events"] = persist_events
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(S, args.cpu_seconds)
         line = json.dumps(res)
