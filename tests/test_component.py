@@ -147,6 +147,26 @@ def test_text_and_binary_matrix_reader_edge_cases(tmp_path):
     assert r.returncode == 3 and "ended inside the payload" in r.stdout
 
 
+def _check_moment_report(text, flat, I, C, R, suffix):
+    import re
+    names = ["w_gifo_x", "w_gifo_r", "bias", "peephole_i_c", "peephole_f_c", "peephole_o_c", "w_r_m"]
+    lens = [4 * C * I, 4 * C * R, 4 * C, C, C, C, R * C]
+    rows = re.findall(r"\n  (\w+)   \( min (\S+), max (\S+), mean (\S+), variance (\S+), skewness (\S+), kurtosis (\S+) \)", text)
+    assert [r[0] for r in rows] == [n + suffix for n in names], text
+    off = 0
+    for (name, *vals), n in zip(rows, lens):
+        v = np.asarray(flat[off:off + n], np.float64); off += n
+        d = v - v.mean()
+        var = (d ** 2).mean()
+        want = [v.min(), v.max(), v.mean(), var, (d ** 3).mean() / var ** 1.5, (d ** 4).mean() / var ** 2 - 3.0]
+        got = [float(x) for x in vals]
+        scale = np.abs(v).max()
+        for g, w, what in zip(got[:3], want[:3], ("min", "max", "mean")):
+            assert abs(g - w) <= 2e-3 * scale, (name, what, g, w)
+        assert abs(got[3] - want[3]) <= 5e-3 * want[3], (name, "variance", got[3], want[3])
+        assert abs(got[4] - want[4]) <= 2e-2 and abs(got[5] - want[5]) <= 5e-2 * max(1.0, abs(want[5])), (name, got[4:], want[4:])
+
+
 def _relerr(a, b):
     return float(np.abs(a.astype(np.float64) - b).max() / (np.abs(b).max() + 1e-30))
 
@@ -172,6 +192,7 @@ def test_component_train_steps_gpu(tmp_path, marker, S, mode, monkeypatch):
     if mode == "run_gpu_fold":                 # SetEngineOption("fold", 1): the folded chain behind the same Component calls
         monkeypatch.setenv("KLSTM_TEST_FOLD", "1")
         mode = "run_gpu"
+    dp = mode == "run_gpu_dp"
     if mode == "run_gpu_dp":                   # SetDataParallel(comm): deferred momentum -> klstm_allreduce_grads -> momentum -> update,
         monkeypatch.setenv("KLSTM_TEST_DP", "1:0:%s" % (tmp_path / "rccl.id"))     # all issued by the C++ mirror through the C-ABI
         mode = "run_gpu"
@@ -179,13 +200,18 @@ def test_component_train_steps_gpu(tmp_path, marker, S, mode, monkeypatch):
         monkeypatch.setenv("KLSTM_TEST_COPY", "1")
         monkeypatch.setenv("KLSTM_TEST_FOLD", "1")
         mode = "run_gpu"
-    run(mode, tmp_path / "m.nnet", tmp_path / "x.raw", tmp_path / "od.raw", T * S, lr, mmt, nsteps, tmp_path / "res")
+    res = run(mode, tmp_path / "m.nnet", tmp_path / "x.raw", tmp_path / "od.raw", T * S, lr, mmt, nsteps, tmp_path / "res")
     o = Oracle(I, C, R, S, np.float32); o.set_params(flat)
     std = marker == "<LstmProjected>"
     for _ in range(nsteps):
         if std:
             o.reset([1])
-        out_o = o.propagate(x); id_o = o.backpropagate(x, od, momentum=mmt); o.update(lr, clip_grad=50.0 if std else 0.0)
+        out_o = o.propagate(x)
+        corr_before_backprop = o.get_corr().copy()
+        id_o = o.backpropagate(x, od, momentum=mmt)
+        # (data-parallel order: BackpropagateFnc leaves the pure gradient in the blob, the momentum buffers move inside Update)
+        corr_before_update = corr_before_backprop if dp else o.get_corr().copy()
+        o.update(lr, clip_grad=50.0 if std else 0.0)
     if std:
         assert np.abs(o.get_corr()).max() == 50.0            # the clip is exercised
     assert _relerr(raw(tmp_path / "res.out").reshape(T * S, R), out_o) <= 5e-5
@@ -194,7 +220,10 @@ def test_component_train_steps_gpu(tmp_path, marker, S, mode, monkeypatch):
     # the trained model written by the component is a valid Kaldi binary model of the same numbers
     expect = kaldi_fmt.binary_model(raw(tmp_path / "res.params"), I, C, R, S, marker=marker)
     assert (tmp_path / "res.model").read_bytes() == expect
-    assert "w_gifo_x_corr_" in (tmp_path / "res.gradinfo").read_text()
+    # Info() / InfoGradient() (...streams.h:190-210): the seven tensors under the reference's names, in its order, each with the six
+    # moments of MomentStatistics -- InfoGradient was taken between the last BackpropagateFnc and its Update, Info after it
+    _check_moment_report((tmp_path / "res.gradinfo").read_text(), corr_before_update, I, C, R, "_corr_")
+    _check_moment_report(res.stdout.split("OK", 1)[1], o.get_params(), I, C, R, "_")
 
 
 def _pack_utts(utts):
