@@ -391,7 +391,8 @@ def main():
             maxrel = float(((via_rccl - via_one).abs().max() / (via_rccl.abs().max() + 1e-30)).item())
             blob.copy_(via_rccl)
             eng.apply_momentum(MOMENTUM); eng.update(LR)
-            good = torch.tensor([1 if (err is None and st1 == 0 and maxrel <= 1e-6) else 0], dtype=torch.int32, device="cuda")
+            # (two summation orders of N fp32 numbers: a few 1e-7 of the largest entry at 8 ranks; a rank's contribution missing: ~1/N)
+            good = torch.tensor([1 if (err is None and st1 == 0 and maxrel <= 1e-5) else 0], dtype=torch.int32, device="cuda")
             if world > 1:
                 dist.all_reduce(good, op=dist.ReduceOp.MIN)
             allreduce_ab = {"max_rel_diff_first_step": maxrel, "oneshot_status": st1, "oneshot_error": err}
