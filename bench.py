@@ -380,11 +380,11 @@ def main():
             eng.allreduce_grads(dp.comm); eng.synchronize()
             via_rccl = blob.clone()
             blob.copy_(local)
-            dp.oneshot.allreduce_engine(eng)
             err, st1 = None, None
             try:
+                dp.oneshot.allreduce_engine(eng)
                 eng.synchronize()
-            except Exception as ex:
+            except Exception as ex:                  # (a rank that cannot run the exchange says so in `good` below: nobody uses it then)
                 err = str(ex)
             st1 = dp.oneshot.status()
             via_one = blob.clone()
