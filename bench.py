@@ -399,15 +399,34 @@ def main():
             times = {}
             for name in (("rccl", "oneshot") if int(good.item()) else ("rccl",)):
                 dp.use_oneshot = name == "oneshot"
+                trouble = []
+
+                def guarded(i):
+                    # the exchange under test: a rank on which a step raises (its engine reports a timed-out exchange) stops stepping
+                    # but keeps the ranks' collectives aligned (the barriers and the max-over-ranks of timed_block); the others' waits
+                    # are bounded, so they get there too
+                    if trouble:
+                        return
+                    try:
+                        step(i)
+                    except Exception as ex:
+                        trouble.append(str(ex))
+                fn = guarded if name == "oneshot" else step
                 for i in range(4):
-                    step(i)
-                times[name] = timed_block(step, 4, 16) / 16 * 1e3
+                    fn(i)
+                times[name] = timed_block(fn, 4, 16) / 16 * 1e3
                 if name == "oneshot":
-                    st2 = torch.tensor([dp.oneshot.status()], dtype=torch.int32, device="cuda")
+                    bad = 1 if trouble else 0
+                    try:
+                        bad = max(bad, 1 if dp.oneshot.status() != 0 else 0)
+                        eng.synchronize()
+                    except Exception as ex:
+                        trouble.append(str(ex)); bad = 1
+                    st2 = torch.tensor([bad], dtype=torch.int32, device="cuda")
                     if world > 1:
                         dist.all_reduce(st2, op=dist.ReduceOp.MAX)
                     if int(st2.item()) != 0:
-                        allreduce_ab["oneshot_status"] = int(st2.item())
+                        allreduce_ab["oneshot_status"] = "failed inside the warm-up steps" + (": " + trouble[0] if trouble else " (on another rank)")
                         times.pop("oneshot")
             allreduce_ab.update({k_ + "_ms_per_step": v for k_, v in times.items()})
             pick = args.collective if args.collective != "auto" else min(times, key=times.get)
@@ -432,34 +451,53 @@ def main():
             ab = {"graph_ms_per_step": tm[0] / 16 * 1e3, "eager_ms_per_step": tm[1] / 16 * 1e3}
         eng.set_option("graph", 2 if launch == "graph" else 0)
         # ---- warm-up, then exactly K steps, then whole K-step blocks until --min-seconds of timed region
-        for i in range(args.warmup):
-            step(i)
         K = args.steps
 
-        def timed_region():
-            dt_first = timed_block(step, args.warmup, K)
+        region_trouble = []
+
+        def region_step(i):
+            # with the (experimental) one-shot exchange in the timed region: a rank whose engine reports a timed-out exchange stops
+            # stepping but keeps the ranks' collectives aligned; the region is void then and is measured again on RCCL (below)
+            if region_trouble:
+                return
+            try:
+                step(i)
+            except Exception as ex:
+                region_trouble.append(str(ex))
+        run_step = region_step if (dp.oneshot is not None and dp.use_oneshot) else step
+        for i in range(args.warmup):
+            run_step(i)
+
+        def timed_region(fn):
+            dt_first = timed_block(fn, args.warmup, K)
             blocks = max(0, int(np.ceil((args.min_seconds - dt_first) / max(dt_first, 1e-9))))
             dt_total, nsteps_total = dt_first, K
             if blocks:
-                dt_total += timed_block(step, args.warmup + K, blocks * K)
+                dt_total += timed_block(fn, args.warmup + K, blocks * K)
                 nsteps_total += blocks * K
             return dt_first, dt_total, nsteps_total
-        dt_first, dt_total, nsteps_total = timed_region()
+        dt_first, dt_total, nsteps_total = timed_region(run_step)
         if dp.oneshot is not None and dp.use_oneshot:
             # the one-shot exchange must have come through the whole timed region clean on EVERY rank; otherwise the region is void
             # (a rank that timed out reduced nothing) and is measured again on RCCL
-            st3 = torch.tensor([dp.oneshot.status()], dtype=torch.int32, device="cuda")
+            bad3 = 1 if region_trouble else 0
+            try:
+                bad3 = max(bad3, 1 if dp.oneshot.status() != 0 else 0)
+                eng.synchronize()
+            except Exception as ex:
+                region_trouble.append(str(ex)); bad3 = 1
+            st3 = torch.tensor([bad3], dtype=torch.int32, device="cuda")
             if world > 1:
                 dist.all_reduce(st3, op=dist.ReduceOp.MAX)
             allreduce_ab["oneshot_status_after_timed_region"] = int(st3.item())
             if int(st3.item()) != 0:
-                print("bench.py: the one-shot exchange reported status %d inside the timed region: measured again on RCCL" % int(st3.item()),
-                      file=sys.stderr)
+                print("bench.py: the one-shot exchange failed inside the timed region (%s): measured again on RCCL" %
+                      (region_trouble[0] if region_trouble else "on another rank"), file=sys.stderr)
                 dp.use_oneshot = False
                 allreduce_ab["chosen"] = "rccl (the one-shot exchange failed inside the timed region)"
                 for i in range(args.warmup):
                     step(i)
-                dt_first, dt_total, nsteps_total = timed_region()
+                dt_first, dt_total, nsteps_total = timed_region(step)
 
         # ---- ragged utterance lengths (900..1100): mask / Reset on the timed path
         ragged = None

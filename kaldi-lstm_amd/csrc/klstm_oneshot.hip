@@ -103,11 +103,23 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneshotArgs a) {
   __amdgpu_buffer_rsrc_t rs[ONESHOT_MAX_RANKS];
 #pragma unroll
   for (int q = 0; q < ONESHOT_MAX_RANKS; q++) rs[q] = buf_rsrc(a.blob[q < N ? q : N - 1], (int)(a.n * 4));
-  for (long i = lo + (long)blockIdx.x * 256 + tid; arrived && i < hi; i += (long)gridDim.x * 256) {
-    const int off = (int)(i * 16);
-    u32x4 v[ONESHOT_MAX_RANKS];
+  // The loads of the NEXT trip go out in front of this trip's stores: a wave's loads return in order behind its own stores, and a
+  // store to a peer is acknowledged a link round trip later -- with one trip in flight at a time the loop paid that latency per
+  // trip (1 rank, local memory: 11 trips = 22 us for 17 MB).
+  const long stride = (long)gridDim.x * 256;
+  long i = lo + (long)blockIdx.x * 256 + tid;
+  u32x4 v[ONESHOT_MAX_RANKS], vn[ONESHOT_MAX_RANKS];
+  auto fetch = [&](long idx, u32x4 (&dst)[ONESHOT_MAX_RANKS]) {
+    const int off = (int)(idx * 16);
 #pragma unroll
-    for (int q = 0; q < ONESHOT_MAX_RANKS; q++) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs[q], off, 0, AUX);   // (q >= N: a copy of the last)
+    for (int q = 0; q < ONESHOT_MAX_RANKS; q++)        // (uniform branches: a rank count below 8 must not pay for -- or send over a link -- loads nobody adds)
+      if (q < N) dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rs[q], off, 0, AUX);
+  };
+  if (arrived && i < hi) fetch(i, v);
+  while (arrived && i < hi) {
+    const long inext = i + stride;
+    if (inext < hi) fetch(inext, vn);
+    const int off = (int)(i * 16);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < ONESHOT_MAX_RANKS; q++)        // rank order: one rank adds a slice, so every rank ends with the same bits
@@ -116,6 +128,9 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneshotArgs a) {
 #pragma unroll
     for (int q = 0; q < ONESHOT_MAX_RANKS; q++)
       if (q < N) __builtin_amdgcn_raw_buffer_store_b128(o, rs[q], off, 0, AUX);
+#pragma unroll
+    for (int q = 0; q < ONESHOT_MAX_RANKS; q++) v[q] = vn[q];
+    i = inext;
   }
   if (arrived && a.rank == N - 1 && blockIdx.x == 0)  // the n % 4 tail
     for (long i = n4 * 4 + tid; i < a.n; i += 256) {
@@ -124,9 +139,12 @@ __global__ __launch_bounds__(256) void k_oneshot_allreduce(OneshotArgs a) {
       for (int q = 0; q < N; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), buf_rsrc(a.blob[q], (int)(a.n * 4)), (int)(i * 4), 0, AUX);
     }
   // ---- C: departure.  The last workgroup to finish B tells every peer, then waits for every peer.
-  __threadfence_system();
+  // Every thread waits for ITS stores (system-coherent write-through: acknowledged = in the peer's memory); ONE thread per workgroup
+  // then runs the system-scope release fence -- as a fence in every thread (768 waves x an L2 write-back scan) phase C cost 25 us.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
+    __threadfence_system();
     const unsigned old = atomicAdd(a.done, 1u);
     ok_s = old == gridDim.x - 1 ? 1 : 0;
     if (ok_s) __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -251,7 +269,8 @@ klstm_status klstm_oneshot_allreduce(klstm_oneshot *h, void *hip_stream, int tim
   a.limit = (long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000;       // wall clock: 100 MHz
   const long n4 = g->n / 4, per = (n4 + g->nranks - 1) / g->nranks;
   int grid = (int)((per + 255) / 256);
-  grid = grid < 1 ? 1 : grid > 64 ? 64 : grid;          // few workgroups: the links are the limit, and every rank's kernel must be resident at once
+  grid = grid < 1 ? 1 : grid > 192 ? 192 : grid;        // every workgroup of every rank's kernel must be resident at once (the kernel runs alone on its
+                                                        // stream: 256 CUs); 64 workgroups moved 17 MB of local memory in 26 us, too few loads in flight
   hipLaunchKernelGGL(k_oneshot_allreduce, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
   OCHK(hipGetLastError());
   return KLSTM_OK;
