@@ -761,6 +761,7 @@ static FwdPtrs fwd_ptrs(klstm_engine *e) {
   p.pk_fold = reinterpret_cast<const float4 *>(e->pk_fold[0]);
   p.fat = e->use_fat;
   p.bf16 = e->use_bf16;
+  p.wr_bf16 = (e->fwd_ms && e->fold_scratch) ? static_cast<const unsigned short *>(e->fold_scratch) : nullptr;   // (fold_bf16x3_planes: plane 0 of a3)
   return p;
 }
 static BwdPtrs bwd_ptrs(klstm_engine *e) {
@@ -1278,6 +1279,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else if (!strcmp(key, "persist_waves")) { e->popt.waves = value; e->popt.bwd_waves = value; }
     else if (!strcmp(key, "persist_bwd_waves")) e->popt.bwd_waves = value;
     else if (!strcmp(key, "persist_bwd_interleave")) e->popt.bwd_interleave = value;
+    else if (!strcmp(key, "persist_xl")) e->popt.xl = value;
     else if (!strcmp(key, "persist_nap0")) e->popt.nap0 = value;
     else if (!strcmp(key, "persist_nap")) e->popt.nap = value;
     else if (!strcmp(key, "persist_nap0_bwd")) e->popt.nap0_bwd = value;

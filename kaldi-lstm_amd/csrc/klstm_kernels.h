@@ -22,6 +22,8 @@ struct FwdPtrs {
   const float4 *pk_fold;                             // packed [W_rm | W_x] of the folded recurrence, or null
   bool fat;                                          // allow the 64-row x 32-stream kernels when S > 16
   bool bf16;                                         // pk_* hold bf16 operands; activations are rounded to bf16 when staged
+  const unsigned short *wr_bf16 = nullptr;           // (or null) W_gifo_r rounded to bf16, natural [4C x R] layout: the fold product's operand plane
+                                                     // (klstm_fold3.hip split mode 3), valid whenever the bf16 W_rm is
 };
 
 struct BwdPtrs {
@@ -238,6 +240,7 @@ struct PersistOpts {
   int nap0_bwd = -1;              // the same for the backward launch
   int bwd_waves = 0;              // backward: 12 or 16 waves per workgroup
   int bwd_interleave = -1;        // backward, 5..8 streams: the two groups of 4 as interleaved chains (-1 / 1) or one after the other (0)
+  int xl = -1;                    // many streams, bf16, C = 1024: one chain per XCD (klstm_persist_xl.hip; -1 / 1) or klstm_persist_ms.hip (0)
   long long spin_limit = 0;       // wall-clock ticks (100 MHz) a single in-kernel wait may take (0 = 50 ms)
   int test_stall_fwd = 0, test_stall_bwd = 0;   // test hook: workgroup 0 withholds its publish of this step -> timeout path
   unsigned *hstat = nullptr;      // host-mapped status word: set by a launch that gives up (the engine polls it without a sync)
@@ -265,6 +268,10 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
 // Many-stream (9..32) weights-resident forward chain of the bf16 operand mode (klstm_persist_ms.hip): one launch runs all T steps of
 // the folded recurrence; wrm = W_gifo_r W_r_m as bf16, logical rows (4 cell + gate) x C (launch_fold_ms, once per Update); the x term must be in
 // the gifo plane (batched product); r(1..T) -> rr plane, output rows and carried r come out of the same launch.
+bool persist_xl_supported(const Dims &d, const PersistOpts &o);      // klstm_persist_xl.hip takes this launch (same arguments, same buffers)
+size_t persist_xl_gran_bytes();
+hipError_t launch_fwd_persist_xl(const Dims &d, const FwdPtrs &p, const unsigned short *wrm, float *out, int out_stride, void *gran, unsigned *ctrl,
+                                 const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});
 bool persist_ms_supported(const Dims &d);
 int persist_ms_grid(const Dims &d);
 size_t persist_ms_gran_bytes(const Dims &d);

@@ -310,7 +310,10 @@ bool persist_ms_supported(const Dims &d) {
          d.T >= 3 && d.T * d.S >= 256;                                  // (the batched products of this mode run on the bf16 tiles from 256 frames on)
 }
 int persist_ms_grid(const Dims &d) { return d.C / 4; }
-size_t persist_ms_gran_bytes(const Dims &d) { return (size_t)2 * (d.C / 4) * 2 * MS_NG * 16; }
+size_t persist_ms_gran_bytes(const Dims &d) {      // (the XCD-local kernel of klstm_persist_xl.hip uses the same buffer: the larger of the two)
+  const size_t ms = (size_t)2 * (d.C / 4) * 2 * MS_NG * 16, xl = persist_xl_gran_bytes();
+  return ms > xl ? ms : xl;
+}
 
 template <int NT, int PG>
 static hipError_t ms_launch(const PersistMsArgs &a, int grid, size_t shm, hipStream_t st, LaunchProbe pr) {
@@ -324,6 +327,7 @@ static hipError_t ms_launch(const PersistMsArgs &a, int grid, size_t shm, hipStr
 hipError_t launch_fwd_persist_ms(const Dims &d, const FwdPtrs &p, const unsigned short *wrm, float *out, int out_stride, uint4 *gran, unsigned *ctrl,
                                  const PersistOpts &o, hipStream_t st, LaunchProbe pr) {
   if (!persist_ms_supported(d) || !wrm || !gran || !out) return hipErrorInvalidValue;
+  if (persist_xl_supported(d, o)) return launch_fwd_persist_xl(d, p, wrm, out, out_stride, gran, ctrl, o, st, pr);   // C = 1024: one chain per XCD
   PersistMsArgs a;
   a.C = d.C; a.R = d.R; a.S = d.S; a.T = d.T;
   a.ldrow = 2 * (d.C > d.R ? d.C : d.R) + 16;
