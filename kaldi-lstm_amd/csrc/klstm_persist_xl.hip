@@ -16,8 +16,8 @@
 // (klstm_engine.hip recover()).
 //   workgroup (XCC g, slot s): streams [g sx, g sx + sx), sx = ceil(S / 8); cells [32 s, 32 s + 32) = rows [128 s, 128 s + 128) of the
 //     logical-row bf16 W_rm (launch_fold_ms); wave (row tile i = wave / 2, K half kp = wave % 2): 16 rows x 512 k resident
-//   step t: every thread sweeps its share of the group's granules {tag, fp32 m(t-1)} (4 streams x 1024 cells, 8 bytes each), rounds to
-//     bf16 into the LDS slab [stream][cell]; barrier; v_mfma_f32_16x16x32_bf16 (weights on the M side, the group's streams on the N
+//   step t: every thread sweeps its share of the group's granules {tag, m(t-1) of two adjacent cells as bf16} (4 streams x 512 pairs, 8
+//     bytes each: one 16-byte load per thread and pass) into the LDS slab [stream][cell]; barrier; v_mfma_f32_16x16x32_bf16 (weights on the M side, the group's streams on the N
 //     side: a lane ends up with g, i, f, o of ITS (cell, stream)); K halves combined through LDS; barrier; the cell update
 //     (:278-309) on the lanes that own a pair, publish, plane rows.  x(t) W_gifo_x^T + bias is the batched product of the
 //     reference (:246, :259), in the gifo plane when the launch starts.
@@ -49,7 +49,7 @@ struct PersistXlArgs {
   float *gifo, *cc, *hh, *mm, *rr; // planes; gifo rows of frames 1..T hold x W_gifo_x^T + bias on entry
   const float *prev_c, *prev_r;
   float *next_c;
-  unsigned long long *gran;       // [8 groups][2 parities][4 streams][C] granules {tag, fp32}
+  unsigned long long *gran;       // [8 groups][2 parities][4 streams][C / 2] granules {tag, m of two adjacent cells as bf16}
   unsigned *xcnt;                 // [8] workgroups registered per XCC (the last workgroup of a launch puts them back to 0)
   unsigned *ctrl;                 // [0] epoch, [1] finished workgroups, [2] status, [3] ordinal of the launch that gave up
   unsigned *guard;
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
   if (!idle) {
     const int i16 = lane & 15, kg = lane >> 4;                          // MFMA operand lane: row / column i16, k-group kg
     const int ti = wave >> 1, kp = wave & 1;                            // row tile, K half
-    unsigned long long *gr = a.gran + (size_t)grp * 2 * 4 * C;          // the group's granules: [2 parities][4 streams][C]
-    const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(gr, 2 * 4 * C * 8);
+    unsigned long long *gr = a.gran + (size_t)grp * 2 * 4 * (C / 2);    // the group's granules: [2 parities][4 streams][C / 2 cell pairs]
+    const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(gr, 2 * 4 * (C / 2) * 8);
     // ---- cell-update lanes: wave (ti, kp = 0), lane (stream n = i16 < sxl, cell 4 ti + kg of the workgroup's 32) ----
     const bool cellw = kp == 0;
     const bool on = cellw && i16 < sxl;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
         xg = make_float4(gp[0], gp[C], gp[2 * C], gp[3 * C]);
       }
       if (!first) {
-        // ---- sweep m(t-1) of the group: thread = (stream n = tid >> 8, cells 4 (tid & 255) .. + 3): two 16-byte sc1 loads ----
+        // ---- sweep m(t-1) of the group: thread = (stream n = tid >> 8, cells 4 (tid & 255) .. + 3): ONE 16-byte sc1 load = two granules ----
         // (polling starts once this workgroup's own cell waves have issued their publishes of step t-1: klstm_persist.hip)
         {
           const long long w0 = wall_clock64();
@@ -157,14 +157,13 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
         const int n = tid >> 8, c4 = tid & 255;
         const bool live = n < sxl;
         const unsigned tag = epoch + (unsigned)(t - 1);
-        const int off = ((((t - 1) & 1) * 4 + (live ? n : 0)) * C + 4 * c4) * 8;
-        u32x4 q0, q1;
+        const int off = ((((t - 1) & 1) * 4 + (live ? n : 0)) * (C / 2) + 2 * c4) * 8;
+        u32x4 q0;
         bool ok = false;
         const long long t0 = wall_clock64();
         for (unsigned spins = 0;; spins++) {
           q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_gr, off, 0, 16);         // aux 16 = sc1
-          q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_gr, off + 16, 0, 16);
-          ok = !live | ((q0.y == tag) & (q0.w == tag) & (q1.y == tag) & (q1.w == tag));
+          ok = !live | ((q0.y == tag) & (q0.w == tag));
           if (__all(ok)) break;
           if ((spins & 31) == 31) {
             if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
@@ -180,10 +179,7 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
           }
         }
         // (the slab is free: every wave of this workgroup passed barrier (2) of step t-1 behind its reads)
-        if (live)
-          *reinterpret_cast<uint2 *>(slab + n * XL_LD + 8 * c4) =
-              make_uint2(bf16_rne(__uint_as_float(q0.x)) | ((unsigned)bf16_rne(__uint_as_float(q0.z)) << 16),
-                         bf16_rne(__uint_as_float(q1.x)) | ((unsigned)bf16_rne(__uint_as_float(q1.z)) << 16));
+        if (live) *reinterpret_cast<uint2 *>(slab + n * XL_LD + 8 * c4) = make_uint2(q0.x, q0.z);      // (bf16 already: rounded by the publisher)
       }
       lds_barrier();                                                    // (1) slab of step t ready
       if (*abortf) return false;
@@ -247,10 +243,12 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
         ao += wpo * c;                                                  // :303
         const float go = k_sigmoid(ao);                                 // :306
         const float m = h * go;                                         // :309
+        // publish m(t) (m(T) travels too: r(T)) as bf16 (what every consumer rounds it to), two adjacent cells per granule: the lane of
+        // the even cell takes its neighbour's value (16 lanes up) and issues ONE plain 8-byte store -- the line stays in this XCC's L2
+        const unsigned mb = bf16_rne(m), mb_up = (unsigned)__shfl_down((int)mb, 16);
+        if (on && (kg & 1) == 0 && !(a.test_stall == t && slot == 0 && grp == 0))
+          gr[((size_t)(t & 1) * 4 + i16) * (C / 2) + (cell >> 1)] = ((unsigned long long)(epoch + (unsigned)t) << 32) | (mb | (mb_up << 16));
         if (on) {
-          // publish m(t) (m(T) travels too: r(T)): ONE plain 8-byte store -- the line stays in this XCC's L2, where the group reads it
-          if (!(a.test_stall == t && slot == 0 && grp == 0))
-            gr[((size_t)(t & 1) * 4 + i16) * C + cell] = ((unsigned long long)(epoch + (unsigned)t) << 32) | __float_as_uint(m);
           float *gp = a.gifo + ((size_t)t * S + strm) * 4 * C + cell;
           gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
           const size_t pc = ((size_t)t * S + strm) * C + cell;
@@ -296,7 +294,7 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
 bool persist_xl_supported(const Dims &d, const PersistOpts &o) {
   return o.xl != 0 && d.C == XL_C && d.S >= 9 && d.S <= 32 && d.R % 32 == 0 && d.R >= 32 && d.R <= 512 && d.T >= 3 && d.T * d.S >= 256;
 }
-size_t persist_xl_gran_bytes() { return (size_t)8 * 2 * 4 * XL_C * 8 + 64; }   // granules + the eight per-XCC counters
+size_t persist_xl_gran_bytes() { return (size_t)8 * 2 * 4 * (XL_C / 2) * 8 + 64; }   // granules + the eight per-XCC counters
 
 hipError_t launch_fwd_persist_xl(const Dims &d, const FwdPtrs &p, const unsigned short *wrm, float *out, int out_stride, void *gran, unsigned *ctrl,
                                  const PersistOpts &o, hipStream_t st, LaunchProbe pr) {
@@ -308,7 +306,7 @@ hipError_t launch_fwd_persist_xl(const Dims &d, const FwdPtrs &p, const unsigned
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm; a.rr = p.rr;
   a.prev_c = p.prev_c; a.prev_r = p.prev_r; a.next_c = p.next_c;
   a.gran = static_cast<unsigned long long *>(gran);
-  a.xcnt = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(gran) + (size_t)8 * 2 * 4 * XL_C * 8);
+  a.xcnt = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(gran) + (size_t)8 * 2 * 4 * (XL_C / 2) * 8);
   a.ctrl = ctrl; a.guard = o.guard; a.hstat = o.hstat;
   a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;
   a.test_stall = o.test_stall_fwd;
