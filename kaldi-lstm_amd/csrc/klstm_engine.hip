@@ -118,6 +118,9 @@ struct klstm_engine {
   bool fwd_ms = false;      // ... the many-stream bf16 one (klstm_persist_ms.hip): batched x term, launch, batched projection
   unsigned short *wrm_l = nullptr;   // W_rm = W_gifo_r W_r_m as bf16, logical rows x C (a bf16 product, refreshed after every Update) for that launch
   uint4 *gran_ms = nullptr; // its granule slots
+  bool bwd_xl = false;      // ... and its BPTT as one chain per XCD (klstm_persist_xl.hip k_bwd_persist_xl)
+  unsigned short *wrmT_l = nullptr;   // W_rm^T as bf16 [C][4C logical rows] (written by the fold product next to wrm_l)
+  void *gran_xb = nullptr;  // the backward chain's granule slots
   PersistOpts popt;         // per-engine knobs of the persistent kernels (options persist_waves, persist_tpw, persist_nap*, ...)
   int ncu = 0;              // compute units of the device: every workgroup of a persistent launch needs one of its own
   int persist_tail = 1;     // option "persist_tail": d_r / in_diff inside the persistent backward launch (0: batched products after it)
@@ -247,6 +250,8 @@ static size_t ws_need(const klstm_engine *e, int T) {
   const size_t np = (size_t)gemm_splitk_plan((int)M, e->C, e->R, &kl) * M * e->C;                    // P
   if (nr > need) need = nr;
   if (np > need) need = np;
+  const size_t nx = (size_t)8 * M * (e->R > e->I ? e->R : e->I);                                     // the per-XCD BPTT chain's d_r / in_diff in 8 K slices
+  if (nx > need) need = nx;
   return need;
 }
 static klstm_status ensure_ws(klstm_engine *e, int T) {
@@ -385,7 +390,7 @@ static klstm_status recover(klstm_engine *e, const unsigned (&w)[16]) {
   e->grads_pending = false; e->mmt_pending = false;
   e->planes_fresh = false; e->fold_dirty = true; e->foldx_fresh = false;
   if (e->pk[0]) e->pk_stale = 15;
-  e->bwd_persist = false;
+  e->bwd_persist = false; e->bwd_xl = false;
   drop_graphs(e);
   const int sp_now = e->sp;
   for (int i = 0; i < e->nmarks; i++)
@@ -488,11 +493,19 @@ static klstm_status ensure_ms(klstm_engine *e) {
     if (!e->fold_scratch) HIPCHK(hipMalloc(&e->fold_scratch, fold_bf16x3_scratch_bytes(d)));
     e->fold_dirty = true; e->planes_fresh = false;
   }
+  const Dims dx{e->I, e->C, e->R, e->S, 32};          // (does the per-XCD BPTT chain apply to this layer?  T is checked per call)
+  if (!e->wrmT_l && e->popt.xl_bwd != 0 && persist_xl_supported(dx, e->popt)) {
+    HIPCHK(hipMalloc(&e->wrmT_l, (size_t)4 * e->C * e->C * sizeof(unsigned short)));
+    const size_t gb = persist_xl_bwd_gran_bytes();
+    HIPCHK(hipMalloc(&e->gran_xb, gb));
+    HIPCHK(hipMemsetAsync(e->gran_xb, 0, gb, e->stream));
+    e->fold_dirty = true;
+  }
   if (!e->fold_dirty) return KLSTM_OK;
   // W_rm [4C x C] = W_gifo_r [4C x R] W_r_m [R x C], both operands rounded to bf16 (one plane each: written by the Update, or by
   // a split pass when the parameters changed some other way), fp32 accumulate, stored as bf16 (klstm_fold3.hip)
   HIPCHK(launch_fold_ms(d, e->params + e->o_wr(), e->wmT, e->fold_scratch, e->wrm_l, e->stream, probe(e, "k_split3"), probe(e, "k_fold_ms"),
-                        e->planes_fresh));
+                        e->planes_fresh, e->wrmT_l));
   e->fold_dirty = false;
   return KLSTM_OK;
 }
@@ -627,6 +640,8 @@ void klstm_destroy(klstm_engine *e) {
   if (e->fold_scratch) (void)hipFree(e->fold_scratch);
   if (e->wrm_l) (void)hipFree(e->wrm_l);
   if (e->gran_ms) (void)hipFree(e->gran_ms);
+  if (e->wrmT_l) (void)hipFree(e->wrmT_l);
+  if (e->gran_xb) (void)hipFree(e->gran_xb);
   if (e->pstat_host) (void)hipHostFree(e->pstat_host);
   for (float *p : e->stage) if (p) (void)hipFree(p);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -836,6 +851,25 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
   const Dims d{e->I, e->C, e->R, e->S, T};
   const BwdPtrs p = bwd_ptrs(e);
   hipStream_t st = e->stream;
+  if (e->bwd_xl) {
+    // many streams, bf16, one BPTT chain per XCD: P = out_diff W_r_m for all frames, the chain d_m(t) = P(t) + dgifo(t+1) W_rm with the
+    // elementwise pass of the own cells, then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r (:391) and in_diff = dgifo W_gifo_x (:457)
+    // as batched products -- every product on the bf16 tiles with fp32 accumulation, operands rounded like the step kernels'
+    const int M = T * d.S, KS = 8, KL = 4 * d.C / KS;          // (K = 4C in 8 slices of 512: 40 output tiles -> 320 workgroups)
+    HIPCHK(launch_gemm_bf16_nt(M, d.C, d.R, out_diff, od_stride, p.wmT, d.R, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
+    HIPCHK(launch_bwd_persist_xl(d, p, e->wrmT_l, e->Pm, e->gran_xb, e->pctrl + 4, e->popt, st, probe(e, "k_bwd_persist_xl")));
+    HIPCHK(launch_gemm_bf16_nt_splitk(M, d.R, 4 * d.C, e->dgifo + (size_t)2 * d.S * 4 * d.C, 4 * d.C, p.wrT, 4 * d.C, 0.f,
+                                      e->dr + (size_t)d.S * d.R, d.R, out_diff, od_stride, e->ws, KS, KL, st, probe(e, "k_gemm_dr"),
+                                      probe(e, "k_reduce_dr")));
+    if (in_diff)
+      HIPCHK(launch_gemm_bf16_nt_splitk(M, d.I, 4 * d.C, e->dgifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.wxT, 4 * d.C, 0.f, in_diff, id_stride,
+                                        nullptr, 0, e->ws, KS, KL, st, probe(e, "k_gemm_indiff"), probe(e, "k_reduce_indiff")));
+    const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
+    if (grads_fusable(e, T, flags, e->use_bf16)) return KLSTM_OK;
+    HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, defer ? 0.f : mmt, defer ? e->grads : e->corr, st,
+                        probe(e, "k_grads"), e->use_bf16, nullptr, e->pctrl, defer ? ar_mark(e) : nullptr));
+    return KLSTM_OK;
+  }
   if (e->fwd_folded) {
     const float *wx = e->params + e->o_wx(), *wr = e->params + e->o_wr(), *wm = e->params + e->o_wm();
     const int M = T * d.S;
@@ -920,6 +954,7 @@ static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int
   if (st != KLSTM_OK) return st;
   e->fwd_persist = persist_wanted(e, T);
   e->fwd_ms = !e->fwd_persist && persist_ms_wanted(e, T);
+  e->bwd_xl = false;
   if (!e->replaying && e->cooldown > 0) e->cooldown--;       // (counted in minibatches that ran on the launch-per-step chain)
   else if (!e->replaying && (e->fwd_persist || e->fwd_ms)) e->clean_run++;
   // launch-per-step kernels are not guarded on the device: nothing of them may be queued behind a persistent launch that
@@ -929,10 +964,11 @@ static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int
   e->fwd_folded = e->fwd_persist || (!e->fwd_ms && fold_wanted(e, T));
   if ((e->fwd_persist || e->fwd_ms) && (st = ensure_persist(e)) != KLSTM_OK) return st;
   if (e->fwd_ms && (st = ensure_ms(e)) != KLSTM_OK) return st;
-  if (e->fwd_folded && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
+  e->bwd_xl = e->fwd_ms && e->wrmT_l && e->popt.xl_bwd != 0 && persist_xl_supported(Dims{e->I, e->C, e->R, e->S, T}, e->popt);
+  if ((e->fwd_folded || e->bwd_xl) && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
   // (the persistent backward launch takes its columns of W_rm from the gates-order operand: the second layout is not written then)
   if (e->fwd_folded && (st = ensure_fold(e, !e->fwd_persist, !e->bwd_persist)) != KLSTM_OK) return st;     // outside the graph: only after an Update
-  if (!e->fwd_folded && (st = ensure_packs(e, e->fwd_ms ? 12 : 15)) != KLSTM_OK) return st;     // (the many-stream launch reads the natural matrices; BPTT its packed operands)
+  if (!e->fwd_folded && (st = ensure_packs(e, e->fwd_ms ? (e->bwd_xl ? 0 : 12) : 15)) != KLSTM_OK) return st;     // (the many-stream launch reads the natural matrices; BPTT its packed operands)
   if (e->fwd_folded && !e->fwd_persist && (e->pk_stale & 1) && e->pk[0]) {   // step 1 of the launch-per-step folded chain
     const Dims d0{e->I, e->C, e->R, e->S, 0};
     HIPCHK(launch_pack(d0, e->params, e->wrT, e->wmT, e->wxT, e->pk, 1, e->use_bf16, e->stream, probe(e, "k_pack")));
@@ -966,7 +1002,7 @@ static klstm_status do_backpropagate(klstm_engine *e, const float *in, int in_st
   //  again, and the gradient / Update kernels behind them are guarded.)
   if (e->fwd_folded) { klstm_status fs = ensure_fold(e, !e->fwd_persist, !e->bwd_persist); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
-                        flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0));
+                        flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0) | (e->bwd_xl ? 1024 : 0));
   // (one or two launches: the persistent kernel with P and the tail inside, plus at most the gradient products)
   const bool bwd_short = e->bwd_persist && persist_p_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, e->popt) &&
                          persist_tail_in_kernel(Dims{e->I, e->C, e->R, e->S, T}, in_diff != nullptr, e->popt) && e->persist_tail != 0;
@@ -974,7 +1010,7 @@ static klstm_status do_backpropagate(klstm_engine *e, const float *in, int in_st
     return seq_backward(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, T, momentum, flags);
   }, bwd_short);
   if (st != KLSTM_OK) return st;
-  if (e->bwd_persist) { e->pseq++; e->persist_dirty = true; }
+  if (e->bwd_persist || e->bwd_xl) { e->pseq++; e->persist_dirty = true; }
   e->T_bwd = T;
   if (grads_fusable(e, T, flags, e->fwd_folded ? false : e->use_bf16)) {
     e->grads_pending = true;
@@ -1039,7 +1075,7 @@ klstm_status klstm_backpropagate(klstm_engine *e, const float *in, int in_stride
   klstm_status st = do_backpropagate(e, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, rows, momentum, flags);
   if (st != KLSTM_OK) return st;
   MbRec &r = e->rec;
-  r.have_bwd = true; r.bwd_seq = e->bwd_persist ? e->pseq : 0;
+  r.have_bwd = true; r.bwd_seq = (e->bwd_persist || e->bwd_xl) ? e->pseq : 0;
   r.bin = in; r.bin_stride = in_stride; r.od = out_diff; r.od_stride = out_diff_stride; r.idf = in_diff; r.id_stride = in_diff_stride;
   r.mmt = momentum; r.flags = flags;
   return verify_now(e);
@@ -1152,7 +1188,7 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
   // more in cross-stream event traffic than the ~4 us it hides; everything stays on the one stream.)
   // while the folded chain is in use only the step-1 gates operand (array 0) is read; the others are refreshed on demand
   // (and with the persistent forward kernel none at all: it reads the natural matrices)
-  const int mask = e->fwd_persist ? 0 : e->fwd_ms ? 12 : e->fwd_folded ? 1 : 15;
+  const int mask = e->fwd_persist ? 0 : e->fwd_ms ? (e->bwd_xl ? 0 : 12) : e->fwd_folded ? 1 : 15;   // (one chain per XCD in both directions: no packed operand is read)
   float *foldx = (e->fwd_folded && !e->fwd_persist && !e->use_bf16) ? e->pk_fold[0] : nullptr;
   if (e->pk[0] && (mask || foldx)) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, mask, e->use_bf16, e->stream, probe(e, "k_pack"), foldx));
   e->pk_stale = 15 & ~mask;
@@ -1280,6 +1316,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else if (!strcmp(key, "persist_bwd_waves")) e->popt.bwd_waves = value;
     else if (!strcmp(key, "persist_bwd_interleave")) e->popt.bwd_interleave = value;
     else if (!strcmp(key, "persist_xl")) e->popt.xl = value;
+    else if (!strcmp(key, "persist_xl_bwd")) e->popt.xl_bwd = value;
     else if (!strcmp(key, "persist_nap0")) e->popt.nap0 = value;
     else if (!strcmp(key, "persist_nap")) e->popt.nap = value;
     else if (!strcmp(key, "persist_nap0_bwd")) e->popt.nap0_bwd = value;

@@ -92,6 +92,7 @@ struct Fold3Args {
   float4 *pk1; int nch1;
   float4 *pk2; int nch2;
   unsigned short *wl;         // (NPL = 1) instead of pk1 / pk2: W_rm as bf16, LOGICAL rows (4 cell + gate) x C columns -- klstm_persist_ms.hip reads 16 consecutive rows per workgroup
+  unsigned short *wlT;        // (with wl, or null) the TRANSPOSE as well: [C columns of W_rm][4C logical rows] -- the backward chain's operand
   int nbn, nwg;
 #ifdef KLSTM_FOLD3_TIMING
   long long *dbg;             // per workgroup: shader clocks at entry / first operands / end of the K loop / exit (tools/fold3_probe.hip)
@@ -314,6 +315,18 @@ __global__ __launch_bounds__(LW ? 512 : 256) void k_fold_bf16x3(Fold3Args a) {
           *reinterpret_cast<uint2 *>(a.wl + (size_t)x * C + n) = make_uint2(bf16_rne(cp[0]) | ((unsigned)bf16_rne(cp[FLD]) << 16),
                                                                            bf16_rne(cp[2 * FLD]) | ((unsigned)bf16_rne(cp[3 * FLD]) << 16));
       }
+    if (!loader && a.wlT) {
+      // the transpose from the same tile: piece = (column, four consecutive logical rows) = 16 bytes of the column-major tile -> 8 bytes of bf16
+#pragma unroll
+      for (int it = 0; it < WM * WN / 4 / 64; it++) {
+        const int p = it * 64 + lane, col = p / (WM / 4), rq = p % (WM / 4);
+        const float4 v = *reinterpret_cast<const float4 *>(cs + col * FLD + 4 * rq);
+        const int n = n0 + col, x = m0 + 4 * rq;
+        if ((x >> 2) < C && n < C)
+          *reinterpret_cast<uint2 *>(a.wlT + (size_t)n * 4 * C + x) = make_uint2(bf16_rne(v.x) | ((unsigned)bf16_rne(v.y) << 16),
+                                                                                bf16_rne(v.z) | ((unsigned)bf16_rne(v.w) << 16));
+      }
+    }
     return;
   }
   // gates operand: piece = (16-row tile tl, column quad nq, row i): 16 consecutive float4 (256 B) per (tl, nq)
@@ -403,7 +416,7 @@ static hipError_t launch_fold_planes(const Fold3Args &a, hipStream_t st, LaunchP
 // order (wl, [4C x C]).  scratch: plane 0 of each operand (mode 3 of the split; written by the Update when planes_fresh).
 // 128 x 128 tiles: 256 workgroups at 1024 / 512 = one round of the chip.
 hipError_t launch_fold_ms(const Dims &d, const float *wr, const float *wmT, void *scratch, unsigned short *wl, hipStream_t st,
-                          LaunchProbe pr_split, LaunchProbe pr, bool planes_fresh) {
+                          LaunchProbe pr_split, LaunchProbe pr, bool planes_fresh, unsigned short *wlT) {
   constexpr int MI = 4, NI = 4, NBUF = 3;
   unsigned short *a3 = static_cast<unsigned short *>(scratch);
   const size_t apl = (size_t)4 * d.C * d.R, bpl = (size_t)d.C * d.R;
@@ -425,7 +438,7 @@ hipError_t launch_fold_ms(const Dims &d, const float *wr, const float *wmT, void
 #endif
   a.C = d.C; a.R = d.R; a.wr = wr; a.wmT = wmT; a.redo = nullptr;
   a.a3 = a3; a.b3 = b3; a.a_plane = apl; a.b_plane = bpl;
-  a.pk1 = nullptr; a.nch1 = 0; a.pk2 = nullptr; a.nch2 = 0; a.wl = wl;
+  a.pk1 = nullptr; a.nch1 = 0; a.pk2 = nullptr; a.nch2 = 0; a.wl = wl; a.wlT = wlT;
   a.nbn = (d.C + 32 * NI - 1) / (32 * NI);
   a.nwg = ((4 * d.C + 32 * MI - 1) / (32 * MI)) * a.nbn;
   constexpr int stage = NBUF * 1 * (32 * MI + 32 * NI) * 64, transp = 4 * 16 * NI * (16 * MI + 4) * 4;
@@ -464,7 +477,7 @@ hipError_t launch_fold_bf16x3(const Dims &d, int mode, const float *wr, const fl
   a.C = d.C; a.R = d.R; a.wr = wr; a.wmT = wmT; a.redo = redo_counters() ? redo_counters() + REDO_FOLD : nullptr;
   a.a3 = a3; a.b3 = b3; a.a_plane = apl; a.b_plane = bpl;
   a.pk1 = reinterpret_cast<float4 *>(pk_fold[0]); a.nch1 = nch1;
-  a.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); a.nch2 = nch2; a.wl = nullptr;
+  a.pk2 = reinterpret_cast<float4 *>(pk_fold[1]); a.nch2 = nch2; a.wl = nullptr; a.wlT = nullptr;
   a.nbn = (d.C + 32 * NI - 1) / (32 * NI);
   a.nwg = ((4 * d.C + 32 * MI - 1) / (32 * MI)) * a.nbn;
   return s.mode == 2 ? launch_fold_planes<2>(a, st, pr) : launch_fold_planes<3>(a, st, pr);

@@ -105,7 +105,8 @@ hipError_t launch_fold_bf16x3(const Dims &d, int mode, const float *wr, const fl
 // the fold product of the bf16 operand mode (klstm_persist_ms.hip): one bf16 plane per operand (split mode 3), result as bf16 in
 // logical-row order [4C x C]
 hipError_t launch_fold_ms(const Dims &d, const float *wr, const float *wmT, void *scratch, unsigned short *wl, hipStream_t st,
-                          LaunchProbe pr_split = {}, LaunchProbe pr = {}, bool planes_fresh = false);
+                          LaunchProbe pr_split = {}, LaunchProbe pr = {}, bool planes_fresh = false,
+                          unsigned short *wlT = nullptr);      // wlT: also the transpose, [C][4C logical rows] bf16 (klstm_persist_xl.hip backward)
 void fold_bf16x3_planes(const Dims &d, void *scratch, unsigned short **a3, long *a_plane, unsigned short **b3, long *b_plane);
 hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT, float *pk_fold[2], bool pack_x,
                        hipStream_t st, LaunchProbe pr = {}, LaunchProbe pr2 = {}, void *scratch3 = nullptr, LaunchProbe pr3 = {},
@@ -171,7 +172,11 @@ hipError_t launch_skinny_nn(int M, int N, int K, const float *A, int lda, const 
 bool gemm_bf16_nt_supported(int M, int K, const float *A, int lda, const float *B, int ldb);
 hipError_t launch_gemm_bf16_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
                                const float *bias, hipStream_t st, LaunchProbe pr = {}, float *C2 = nullptr, int ldc2 = 0,
-                               float *C3 = nullptr, int tail0 = 0);   // C2: a second copy of the result; C3: rows >= tail0, dense (ld = N)
+                               float *C3 = nullptr, int tail0 = 0, float beta = 0.f);   // C2: a second copy of the result; C3: rows >= tail0, dense (ld = N);
+                                                                                        // beta: Cm = beta Cm + A B^T (+ bias)
+hipError_t launch_gemm_bf16_nt_splitk(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm, int ldc,
+                                      const float *add, int add_ld, float *ws, int ks, int klen, hipStream_t st, LaunchProbe pr = {},
+                                      LaunchProbe pr2 = {});   // K in ks slices of klen (multiple of 64) through ws [ks][M x N]; C = beta C + add + A B^T
 bool grads_bf16_tiles(const Dims &d, bool bf16);      // would launch_grads take the bf16 tile path?
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,
@@ -241,6 +246,7 @@ struct PersistOpts {
   int bwd_waves = 0;              // backward: 12 or 16 waves per workgroup
   int bwd_interleave = -1;        // backward, 5..8 streams: the two groups of 4 as interleaved chains (-1 / 1) or one after the other (0)
   int xl = -1;                    // many streams, bf16, C = 1024: one chain per XCD (klstm_persist_xl.hip; -1 / 1) or klstm_persist_ms.hip (0)
+  int xl_bwd = -1;                // ... and the BPTT chain the same way (-1 / 1) or one launch per step (0)
   long long spin_limit = 0;       // wall-clock ticks (100 MHz) a single in-kernel wait may take (0 = 50 ms)
   int test_stall_fwd = 0, test_stall_bwd = 0;   // test hook: workgroup 0 withholds its publish of this step -> timeout path
   unsigned *hstat = nullptr;      // host-mapped status word: set by a launch that gives up (the engine polls it without a sync)
@@ -272,6 +278,9 @@ bool persist_xl_supported(const Dims &d, const PersistOpts &o);      // klstm_pe
 size_t persist_xl_gran_bytes();
 hipError_t launch_fwd_persist_xl(const Dims &d, const FwdPtrs &p, const unsigned short *wrm, float *out, int out_stride, void *gran, unsigned *ctrl,
                                  const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});
+size_t persist_xl_bwd_gran_bytes();
+hipError_t launch_bwd_persist_xl(const Dims &d, const BwdPtrs &p, const unsigned short *wrmT, const float *P, void *gran, unsigned *ctrl,
+                                 const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});   // wrmT: launch_fold_ms wlT; P = out_diff W_r_m [T*S x C]
 bool persist_ms_supported(const Dims &d);
 int persist_ms_grid(const Dims &d);
 size_t persist_ms_gran_bytes(const Dims &d);

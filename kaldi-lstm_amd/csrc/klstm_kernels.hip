@@ -1497,6 +1497,7 @@ struct GemmJob {
   float *Ct; int ldct;    // transposed copy  Ct[n][m]  (M % 4 == 0)
   float *C2; int ldc2;    // second copy      C2[m][n]
   float *C3; int tail0;   // rows m >= tail0 also to C3[m - tail0][n], dense (ld = N)
+  int kslice = 0;         // k_gemm_bf16_nt only: split K, slice length (0: off)
   // fold product only (launch_fold): rows of A are read in gates-packed order (gperm = C) and the result goes straight
   // into the two packed operand arrays of the folded step kernels instead of Cm
   int gperm;
@@ -2148,8 +2149,16 @@ __device__ __forceinline__ void stash_row8(unsigned *Ls, int u, const float4 (&r
   *reinterpret_cast<uint4 *>(Ls + (xl & 3) * PLANE + (xl >> 2) * LDQ + 4 * (u & 7)) = w;
 }
 // NJ: 16-column blocks per wave (4: 128-column tiles; 2: 64-column tiles -- twice the workgroups for results with few tiles)
+// Split K (launch_gemm_bf16_nt_splitk): blockIdx.y = K slice of g.kslice columns (0: the whole K), its partial tile goes to slab
+// blockIdx.y of g.Cm ([slices][M x N], dense); k_splitk_reduce adds the slabs in order.
 template <int NJ>
 __global__ __launch_bounds__(256) void k_gemm_bf16_nt(GemmJob g) {
+  if (g.kslice > 0) {
+    const int k0 = (int)blockIdx.y * g.kslice;
+    g.A += k0; g.B += k0;
+    g.K = g.K - k0 < g.kslice ? g.K - k0 : g.kslice;
+    g.Cm += (size_t)blockIdx.y * g.M * g.N;
+  }
   constexpr int BTN = 32 * NJ;
   __shared__ __attribute__((aligned(16))) unsigned As[4 * PLANE];
   __shared__ __attribute__((aligned(16))) unsigned Bs[4 * PLANE];
@@ -2218,7 +2227,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_nt(GemmJob g) {
       for (int r = 0; r < 4; r++) {
         const int m = m0 + wr * 64 + i * 16 + 4 * kg + r;
         if (m >= g.M) continue;
-        g.Cm[(size_t)m * g.ldc + n] = e[r] + bv;
+        g.Cm[(size_t)m * g.ldc + n] = e[r] + bv + (g.beta != 0.f ? g.beta * g.Cm[(size_t)m * g.ldc + n] : 0.f);
         if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = e[r] + bv;            // (the batched projection: rr rows, output rows, carried r)
         if (g.C3 && m >= g.tail0) g.C3[(size_t)(m - g.tail0) * g.N + n] = e[r] + bv;
       }
@@ -3199,12 +3208,30 @@ hipError_t launch_gemm(bool transA, bool transB, int M, int N, int K, const floa
 
 // C = A B^T + bias with both operands rounded to bf16 (bf16 operand mode; M >= GRADS_BF16_MIN_ROWS rows, K >= 128 -- at K = 40 the
 // 64x64 fp32 tiles are faster: 9.8 vs 12.1 us at 640 x 4096 --, K % 8 == 0, 16-byte aligned rows)
+// C = beta C + add + A B^T with K split into ks slices of klen (a multiple of 64): the partial products go to ws ([ks][M x N] floats),
+// k_splitk_reduce adds them in slice order.  For few output tiles and a long K (640 x 512 over K = 4096: 40 tiles of 128 x 64 took 80 us).
+hipError_t launch_gemm_bf16_nt_splitk(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm, int ldc,
+                                      const float *add, int add_ld, float *ws, int ks, int klen, hipStream_t st, LaunchProbe pr, LaunchProbe pr2) {
+  GemmJob g = make_job(false, true, M, N, K, A, lda, B, ldb, 0.f, ws, N, nullptr);
+  g.kslice = klen;
+  auto first = [&]() -> hipError_t {
+    const int ntm = cdiv(M, BT), ntn = cdiv(N, BT / 2), nt = ntm * ntn;
+    KLAUNCH(k_gemm_bf16_nt<2>, dim3(cdiv(nt, 8) * 8, ks), dim3(256), st, pr, g);
+  };
+  hipError_t err = first();
+  if (err != hipSuccess) return err;
+  ReduceArgs r;
+  r.ws = ws; r.ks = ks; r.M = M; r.N = N; r.beta = beta; r.Cm = Cm; r.ldc = ldc; r.bias = nullptr; r.add = add; r.add_ld = add_ld;
+  r.C2 = nullptr; r.ldc2 = 0; r.C3 = nullptr; r.tail0 = 0;
+  const long nb = ((long)M * N + 255) / 256;
+  KLAUNCH(k_splitk_reduce, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), st, pr2, r);
+}
 bool gemm_bf16_nt_supported(int M, int K, const float *A, int lda, const float *B, int ldb) {
   return M >= GRADS_BF16_MIN_ROWS && K >= 128 && K % 8 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B);
 }
 hipError_t launch_gemm_bf16_nt(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *Cm, int ldc,
-                               const float *bias, hipStream_t st, LaunchProbe pr, float *C2, int ldc2, float *C3, int tail0) {
-  GemmJob g = make_job(false, true, M, N, K, A, lda, B, ldb, 0.f, Cm, ldc, bias);
+                               const float *bias, hipStream_t st, LaunchProbe pr, float *C2, int ldc2, float *C3, int tail0, float beta) {
+  GemmJob g = make_job(false, true, M, N, K, A, lda, B, ldb, beta, Cm, ldc, bias);
   g.C2 = C2; g.ldc2 = ldc2; g.C3 = C3; g.tail0 = tail0;
   const dim3 block(256);
   if (cdiv(N, BT) * cdiv(M, BT) < 384) {             // few 128 x 128 tiles (640 x 4096: 160 on 256 CUs): 128 x 64

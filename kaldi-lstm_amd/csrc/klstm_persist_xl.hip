@@ -289,6 +289,206 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------------
+// BACKWARD chain, the same eight machines: d_m(t) = P(t) + dgifo(t+1) W_rm (...streams.h:391 substituted into :408; P = out_diff W_r_m,
+// the batched product in front of the launch), then the elementwise BPTT of the workgroup's OWN cells (:411-440) -- nothing is
+// replicated: what travels is dgifo(t) of the group's streams, 4 gates x 1024 cells x <= 4 streams as bf16 (the operand every
+// consumer rounds it to), inside the XCD.  A workgroup owns 32 output cells = 32 rows of W_rm^T over K = 4C (the fold product writes
+// the transpose next to W_rm: klstm_fold3.hip wlT): wave (row tile = wave / 8, K eighth = wave % 8) holds 16 rows x 512 k.
+// d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r (:391: the W_r_m gradient's operand) and in_diff = dgifo W_gifo_x (:457) are batched
+// products behind the launch.  Granule = 16 bytes {tag, (d_g, d_i), (d_f, d_o)} per (cell, stream): 8 contiguous bytes of the slab row
+// [k = 4 cell + gate].
+// -------------------------------------------------------------------------------------------------------------------
+struct PersistXlBwdArgs {
+  int S, T, sx;
+  const unsigned short *wrmT;     // [C][4C] bf16: row c = column c of W_rm over the logical rows k = 4 cell + gate
+  const float *P;                 // out_diff W_r_m [T*S x C]
+  const float *pi, *pf, *po;
+  const float *gifo, *cc, *hh;    // forward planes
+  float *dgifo, *dc;
+  uint4 *gran;                    // [8 groups][2 parities][4 streams][C] granules
+  unsigned *xcnt;
+  unsigned *ctrl;                 // the backward direction's control words
+  unsigned *guard;
+  unsigned *hstat;
+  long long spin_limit;
+  int test_stall;
+};
+
+constexpr int XL_LDB = 2 * 4 * XL_C + 16;            // backward slab row bytes: [4 cell + gate] bf16 + 16
+
+__global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
+  constexpr int C = XL_C, K = 4 * XL_C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *slab = smem;                                           // [5][XL_LDB]: rows 0..3 = dgifo(t+1) of the group's streams, row 4 = zeros
+  f32x4 *part = reinterpret_cast<f32x4 *>(smem + 5 * XL_LDB);           // [8 K eighths][2 row tiles][64]
+  unsigned *abortf = reinterpret_cast<unsigned *>(part + 16 * 64);
+  int *pubcnt = reinterpret_cast<int *>(abortf + 1);
+  unsigned *place = abortf + 2;
+  const int S = a.S, T = a.T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned epoch = __hip_atomic_load(&a.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned behind_giveup = 0u;
+  if (a.guard) behind_giveup = __hip_atomic_load(&a.guard[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                               __hip_atomic_load(&a.guard[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = tid * 16; i < 5 * XL_LDB; i += 1024 * 16) *reinterpret_cast<uint4 *>(slab + i) = make_uint4(0u, 0u, 0u, 0u);
+  if (tid == 0) {
+    *abortf = 0u; *pubcnt = 0;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;          // HW_REG_XCC_ID
+    place[0] = xcc;
+    place[1] = xcc < 8 ? atomicAdd(&a.xcnt[xcc], 1u) : 0xffffffffu;
+  }
+  __syncthreads();
+  const int grp = (int)place[0], slot = (int)place[1];
+  const int s0 = grp * a.sx, sxl = grp >= 8 ? 0 : (S - s0 < 0 ? 0 : (S - s0 < a.sx ? S - s0 : a.sx));
+  const bool misplaced = grp >= 8 || slot >= 32 || slot < 0;
+  const bool skip = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
+  if (misplaced && !skip && tid == 0) {
+    atomicCAS(&a.ctrl[3], 0u, launch_ordinal(a.guard));
+    atomicMax(&a.ctrl[2], 0x80000000u | 0x7ffeu);
+    if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const bool idle = misplaced || skip || sxl == 0;
+
+  if (!idle) {
+    const int i16 = lane & 15, kg = lane >> 4;
+    const int ti = wave >> 3, kp = wave & 7;                            // row tile (16 output cells), K eighth
+    uint4 *gr = a.gran + (size_t)grp * 2 * 4 * C;                        // the group's granules: [2 parities][4 streams][C cells]
+    const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(gr, 2 * 4 * C * 16);
+    // ---- elementwise lanes: the two waves with kp = 0, lane = (cell cl = lane & 15 of the wave's row tile, stream n2 = lane >> 4):
+    //      one (cell, stream) pair per lane (four pairs per lane in the MFMA result layout cost 56 registers of state and operands)
+    const bool cellw = kp == 0;
+    const int cl = lane & 15, n2 = lane >> 4;
+    const bool on = cellw && n2 < sxl;
+    const int cell = 32 * slot + 16 * ti + cl, strm = s0 + (n2 < sxl ? n2 : 0);
+    const float wpi = a.pi[cell], wpf = a.pf[cell], wpo = a.po[cell];
+    float dcn = 0.f, fn = 0.f, din = 0.f, dfn = 0.f;
+    if (on) {                                                           // dgifo(T+1) = 0 (:351): operand rows of the batched d_r product
+      float *zp = a.dgifo + ((size_t)(T + 1) * S + strm) * K + cell;
+      zp[0] = 0.f; zp[C] = 0.f; zp[2 * C] = 0.f; zp[3 * C] = 0.f;
+    }
+    // ---- the resident operand: 16 rows of W_rm^T (output cells 32 slot + 16 ti + i16) x this wave's eighth of K ----
+    xl_bf16x8 af[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      af[j] = *reinterpret_cast<const xl_bf16x8 *>(a.wrmT + (size_t)(32 * slot + 16 * ti + i16) * K + 512 * kp + 32 * j + 8 * kg);
+    const unsigned char *brow = slab + (i16 < 4 ? i16 : 4) * XL_LDB + 16 * kg;
+    bool dead = false;
+    for (int t = T; t >= 1 && !dead; t--) {
+      if (t < T) {
+        // ---- sweep dgifo(t+1) of the group: thread = (stream n = tid >> 8, cells 4 (tid & 255) .. + 3): four 16-byte sc1 loads ----
+        {
+          const long long w0 = wall_clock64();
+          for (unsigned spins = 0; __hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * (T - t); spins++) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 1023) == 1023 && wall_clock64() - w0 > a.spin_limit) break;
+          }
+        }
+        const int n = tid >> 8, c4 = tid & 255;
+        const bool live = n < sxl;
+        const unsigned tag = epoch + (unsigned)(t + 1);
+        const int off = ((((t + 1) & 1) * 4 + (live ? n : 0)) * C + 4 * c4) * 16;
+        u32x4 q[4];
+        bool ok = false;
+        const long long t0 = wall_clock64();
+        for (unsigned spins = 0;; spins++) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) q[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_gr, off + 16 * e, 0, 16);   // aux 16 = sc1
+          ok = !live | ((q[0].x == tag) & (q[1].x == tag) & (q[2].x == tag) & (q[3].x == tag));
+          if (__all(ok)) break;
+          if ((spins & 31) == 31) {
+            if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            if (wall_clock64() - t0 > a.spin_limit) break;
+          }
+        }
+        if (!__all(ok)) {
+          __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (lane == 0) {
+            atomicCAS(&a.ctrl[3], 0u, launch_ordinal(a.guard));
+            atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+            if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        if (live) {
+          uint4 *sp = reinterpret_cast<uint4 *>(slab + n * XL_LDB + 32 * c4);
+          sp[0] = make_uint4(q[0].y, q[0].z, q[1].y, q[1].z);
+          sp[1] = make_uint4(q[2].y, q[2].z, q[3].y, q[3].z);
+        }
+      }
+      // the own pair's operands of frame t: requested here, consumed behind the two barriers
+      float Pv = 0.f, yg = 0.f, yi = 0.f, yf = 0.f, yo = 0.f, yh = 0.f, cpv = 0.f;
+      if (on) {
+        Pv = a.P[((size_t)(t - 1) * S + strm) * C + cell];
+        const float *gp = a.gifo + ((size_t)t * S + strm) * K + cell;
+        yg = gp[0]; yi = gp[C]; yf = gp[2 * C]; yo = gp[3 * C];
+        yh = a.hh[((size_t)t * S + strm) * C + cell];
+        cpv = a.cc[((size_t)(t - 1) * S + strm) * C + cell];
+      }
+      lds_barrier();                                                    // (1) slab of dgifo(t+1) ready
+      if (*abortf) { dead = true; break; }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (t < T) {
+#pragma unroll
+        for (int hf = 0; hf < 8; hf++) {
+          xl_bf16x8 bv[2];
+#pragma unroll
+          for (int j = 0; j < 2; j++) bv[j] = *reinterpret_cast<const xl_bf16x8 *>(brow + 64 * (16 * kp + 2 * hf + j));
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2 * hf + j], bv[j], acc, 0, 0, 0);
+        }
+      }
+      part[(kp * 2 + ti) * 64 + lane] = acc;
+      lds_barrier();                                                    // (2) the partial tiles are in LDS
+      if (cellw) {
+        // d_m of this lane's (cell, stream): element (row cl, column n2) of the tile = component cl & 3 of result lane 16 (cl >> 2) + n2;
+        // the eight K parts in fixed order, then :408 with :391 substituted
+        const float *pf32 = reinterpret_cast<const float *>(part);
+        const int pe = ((cl >> 2) * 16 + n2) * 4 + (cl & 3);
+        float dm = pf32[(ti * 64) * 4 + pe];
+#pragma unroll
+        for (int w = 1; w < 8; w++) dm += pf32[((w * 2 + ti) * 64) * 4 + pe];
+        dm += Pv;
+        const float d_h = k_diff_tanh(dm * yo, yh);                     // :411-412
+        const float d_o = k_diff_sigmoid(dm * yh, yo);                  // :415-416
+        float d_c = d_h;                                                // :424
+        d_c = d_c + dcn * fn;                                           // :425
+        d_c = d_c + wpi * din;                                          // :426
+        d_c = d_c + wpf * dfn;                                          // :427
+        d_c = d_c + wpo * d_o;                                          // :428
+        const float dg = k_diff_tanh(d_c * yi, yg);                     // :439-440
+        const float di = k_diff_sigmoid(d_c * yg, yi);                  // :435-436
+        const float df = k_diff_sigmoid(d_c * cpv, yf);                 // :431-432
+        dcn = d_c; fn = yf; din = di; dfn = df;                         // what frame t - 1 needs of frame t
+        if (on) {
+          if (t > 1 && !(a.test_stall == t && slot == 0 && grp == 0))   // publish dgifo(t): one plain 16-byte store -- the line stays in this XCC's L2
+            gr[((size_t)(t & 1) * 4 + n2) * C + cell] =
+                make_uint4(epoch + (unsigned)t, bf16_rne(dg) | ((unsigned)bf16_rne(di) << 16), bf16_rne(df) | ((unsigned)bf16_rne(d_o) << 16), 0u);
+          float *dp = a.dgifo + ((size_t)t * S + strm) * K + cell;
+          dp[0] = dg; dp[C] = di; dp[2 * C] = df; dp[3 * C] = d_o;
+          a.dc[((size_t)t * S + strm) * C + cell] = d_c;
+        }
+        if (lane == 0) __hip_atomic_fetch_add(pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (*abortf) {
+      atomicCAS(&a.ctrl[3], 0u, launch_ordinal(a.guard));
+      atomicMax(&a.ctrl[2], 0x80000000u | 0x7fffu);
+      if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const unsigned old = atomicAdd(&a.ctrl[1], 1u);
+    if (old == gridDim.x - 1) {
+      for (int i = 0; i < 8; i++) __hip_atomic_store(&a.xcnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.ctrl[0], epoch + (unsigned)(T + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.guard) __hip_atomic_fetch_add(a.guard + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
 // launcher
 // -------------------------------------------------------------------------------------------------------------------
 bool persist_xl_supported(const Dims &d, const PersistOpts &o) {
@@ -314,6 +514,27 @@ hipError_t launch_fwd_persist_xl(const Dims &d, const FwdPtrs &p, const unsigned
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd_persist_xl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (pr.start) hipExtLaunchKernelGGL(k_fwd_persist_xl, dim3(256), dim3(1024), shm, st, pr.start, pr.stop, 0, a);
   else hipLaunchKernelGGL(k_fwd_persist_xl, dim3(256), dim3(1024), shm, st, a);
+  return hipGetLastError();
+}
+
+size_t persist_xl_bwd_gran_bytes() { return (size_t)8 * 2 * 4 * XL_C * 16 + 64; }
+
+hipError_t launch_bwd_persist_xl(const Dims &d, const BwdPtrs &p, const unsigned short *wrmT, const float *P, void *gran, unsigned *ctrl,
+                                 const PersistOpts &o, hipStream_t st, LaunchProbe pr) {
+  if (!persist_xl_supported(d, o) || !wrmT || !P || !gran) return hipErrorInvalidValue;
+  PersistXlBwdArgs a;
+  a.S = d.S; a.T = d.T; a.sx = (d.S + 7) / 8;
+  a.wrmT = wrmT; a.P = P; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
+  a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc;
+  a.gran = static_cast<uint4 *>(gran);
+  a.xcnt = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(gran) + (size_t)8 * 2 * 4 * XL_C * 16);
+  a.ctrl = ctrl; a.guard = o.guard; a.hstat = o.hstat;
+  a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;
+  a.test_stall = o.test_stall_bwd;
+  const size_t shm = (size_t)5 * XL_LDB + (size_t)16 * 64 * 16 + 32;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persist_xl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (pr.start) hipExtLaunchKernelGGL(k_bwd_persist_xl, dim3(256), dim3(1024), shm, st, pr.start, pr.stop, 0, a);
+  else hipLaunchKernelGGL(k_bwd_persist_xl, dim3(256), dim3(1024), shm, st, a);
   return hipGetLastError();
 }
 

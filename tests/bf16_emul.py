@@ -24,17 +24,19 @@ def sigmoid(x):
 GRADS_BF16_MIN_ROWS = 256      # klstm_kernels.hip: the gradient products run on the bf16 pipe from this many frames on
 
 
-def minibatch(parts, x, od, c0, r0, S, fuse_x, want_in_diff=True, fold=False):
+def minibatch(parts, x, od, c0, r0, S, fuse_x, want_in_diff=True, fold=False, fold_bwd=False):
     """parts = [wx, wr, b, pi, pf, po, wm] fp32 arrays; x [T*S, I], od [T*S, R] time-major; c0 [S, C], r0 [S, R].
     Returns out, in_diff, grads (7 arrays, pure gradient), cT, rT.
     fold: the many-stream weights-resident forward launch (klstm_persist_ms.hip): steps 2..T close over m(t-1) through
     W_rm = W_gifo_r W_r_m -- itself a bf16 product with fp32 accumulation, its fp32 result rounded to bf16 when the launch loads it;
-    step 1 closes over the carried r as before; r(t) is still bf16(m(t)) x bf16(W_r_m) (output rows, BPTT operands)."""
+    step 1 closes over the carried r as before; r(t) is still bf16(m(t)) x bf16(W_r_m) (output rows, BPTT operands).
+    fold_bwd: the BPTT chain of klstm_persist_xl.hip closes over dgifo the same way: d_m(t) = P(t) + bf16(dgifo(t+1)) x bf16(W_rm) with
+    P = bf16(out_diff) x bf16(W_r_m) (fp32 accumulate, kept in fp32); d_r (the W_r_m gradient's operand) and in_diff are unchanged."""
     wx, wr, b, pi, pf, po, wm = [np.asarray(p, np.float64) for p in parts]
     C, R, I = pi.shape[0], wm.shape[0], wx.shape[1]
     T = x.shape[0] // S
     wrb, wmb, wxb = rb(wr), rb(wm), rb(wx)
-    wrmb = rb((wrb @ wmb).astype(np.float32)) if fold else None       # [4C x C]
+    wrmb = rb((wrb @ wmb).astype(np.float32)) if (fold or fold_bwd) else None       # [4C x C]
     x = np.asarray(x, np.float64)
     f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)
     g = np.zeros((T + 2, S, C)); i = np.zeros_like(g); f = np.zeros_like(g); o = np.zeros_like(g)
@@ -57,9 +59,10 @@ def minibatch(parts, x, od, c0, r0, S, fuse_x, want_in_diff=True, fold=False):
     out = r[1:T + 1].reshape(T * S, R)
     dg = np.zeros((T + 2, S, 4 * C)); dc = np.zeros((T + 2, S, C)); dr = np.zeros((T + 2, S, R))
     od = np.asarray(od, np.float64).reshape(T, S, R)
+    Pf = f32(rb(od.reshape(T * S, R)) @ wmb).reshape(T, S, C) if fold_bwd else None
     for t in range(T, 0, -1):
         dr[t] = f32(od[t - 1] + rb(dg[t + 1]) @ wrb)
-        dm = rb(dr[t]) @ wmb
+        dm = Pf[t - 1] + rb(dg[t + 1]) @ wrmb if fold_bwd else rb(dr[t]) @ wmb
         dh = dm * o[t] * (1 - h[t] ** 2)
         do = dm * h[t] * o[t] * (1 - o[t])
         dgn = dg[t + 1]

@@ -1008,7 +1008,8 @@ def test_config_c5_three_layer_bf16_stack(persist):
         for l in range(NL):
             parts = [split_blob(pe[l], dims_in[l], C, R)[n] for n, _ in param_sizes(dims_in[l], C, R)]
             xin = acts[l].cpu().numpy(); odl = diffs[l + 1].cpu().numpy()
-            out_m, id_m, grads, cT, rT = bf16_emul.minibatch(parts, xin, odl, c0[l], r0[l], S, fuse_x=0, fold=persist != 0)
+            out_m, id_m, grads, cT, rT = bf16_emul.minibatch(parts, xin, odl, c0[l], r0[l], S, fuse_x=0, fold=persist != 0,
+                                                             fold_bwd=persist != 0 and C == 1024)      # (C = 1024: one chain per XCD in both directions)
             corr[l] = mmt * corr[l] + np.concatenate([a.ravel() for a in grads])
             assert relerr(acts[l + 1].cpu().numpy(), out_m) <= 6e-3, (ck, l)
             assert relerr(diffs[l].cpu().numpy(), id_m) <= 6e-3, (ck, l)
@@ -1398,7 +1399,8 @@ def test_many_stream_persistent_forward_bf16(I, C, R, S, T):
         xd, odd = dev(x), dev(od)
         e.propagate(xd, out); e.backpropagate(xd, odd, idf, momentum=mmt); e.synchronize()
         parts = [split_blob(pe, I, C, R)[n] for n, _ in param_sizes(I, C, R)]
-        out_m, id_m, grads, cT, rT = bf16_emul.minibatch(parts, x, od, c0, r0, S, fuse_x=0, fold=True)
+        # (C = 1024: one chain per XCD in both directions, klstm_persist_xl.hip -- the BPTT chain closes over dgifo through W_rm too)
+        out_m, id_m, grads, cT, rT = bf16_emul.minibatch(parts, x, od, c0, r0, S, fuse_x=0, fold=True, fold_bwd=C == 1024)
         corr = mmt * corr + np.concatenate([a.ravel() for a in grads])
         assert relerr(out.cpu().numpy(), out_m) <= 6e-3, ck
         assert relerr(idf.cpu().numpy(), id_m) <= 6e-3, ck
