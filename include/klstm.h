@@ -333,7 +333,7 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  engine cannot count launches inside a foreign graph): use "persist" = 0 there.
  *                  Per-engine knobs (A-B experiments and tests): "persist_waves" (forward and backward geometry: 8, 12, 16),
  *                  "persist_xl" (bf16, 9..32 streams, 1024 cells: 1 = the forward launch as one chain per XCD, the default; 0 = one
- *                  copy of the weights over all CUs),
+ *                  copy of the weights over all CUs), "persist_xl_bwd" (the same for the BPTT chain; 0 = one launch per step),
  *                  "persist_bwd_waves" (12, 16), "persist_bwd_interleave" (5..8 streams: 1 = the two stream groups of the backward
  *                  launch as interleaved chains, the default; 0 = one after the other; bit-identical results),
  *                  "persist_tpw", "persist_nap0", "persist_nap", "persist_nap0_bwd",

@@ -1,5 +1,5 @@
-// kaldi-lstm_amd/csrc/klstm_persist_xl.hip -- weights-RESIDENT forward chain for MANY streams (9 .. 32 per GPU, bf16 operand mode, C = 1024)
-// as EIGHT INDEPENDENT machines, one per XCD: the stream groups of an LSTM are independent chains, and an XCD has what one chain of
+// kaldi-lstm_amd/csrc/klstm_persist_xl.hip -- weights-RESIDENT forward and BPTT chains for MANY streams (9 .. 32 per GPU, bf16 operand mode,
+// C = 1024; BASELINE.json configs[4]) as EIGHT INDEPENDENT machines, one per XCD (k_fwd_persist_xl; k_bwd_persist_xl further down): the stream groups of an LSTM are independent chains, and an XCD has what one chain of
 // 4 streams needs -- 32 CUs whose registers hold a whole copy of W_rm between them (4096 x 1024 bf16 = 8 MB: 256 KB per CU, 64
 // VGPRs per lane at 16 waves) and an L2 of its own, so that the per-step all-to-all of m(t) never leaves the XCD.
 //
