@@ -3215,6 +3215,10 @@ hipError_t launch_gemm_bf16_nt_splitk(int M, int N, int K, const float *A, int l
   GemmJob g = make_job(false, true, M, N, K, A, lda, B, ldb, 0.f, ws, N, nullptr);
   g.kslice = klen;
   auto first = [&]() -> hipError_t {
+    if (N % 32 == 0) {                                // (128 x 32 tiles: more workgroups per CU to cover the load latency of a K tile)
+      const int nt1 = cdiv(M, BT) * cdiv(N, BT / 4);
+      KLAUNCH(k_gemm_bf16_nt<1>, dim3(cdiv(nt1, 8) * 8, ks), dim3(256), st, pr, g);
+    }
     const int ntm = cdiv(M, BT), ntn = cdiv(N, BT / 2), nt = ntm * ntn;
     KLAUNCH(k_gemm_bf16_nt<2>, dim3(cdiv(nt, 8) * 8, ks), dim3(256), st, pr, g);
   };
@@ -3234,6 +3238,10 @@ hipError_t launch_gemm_bf16_nt(int M, int N, int K, const float *A, int lda, con
   GemmJob g = make_job(false, true, M, N, K, A, lda, B, ldb, beta, Cm, ldc, bias);
   g.C2 = C2; g.ldc2 = ldc2; g.C3 = C3; g.tail0 = tail0;
   const dim3 block(256);
+  if (cdiv(N, BT / 2) * cdiv(M, BT) < 512 && N % 32 == 0) {   // few 128 x 64 tiles too: 128 x 32 -- every K tile of 64 exposes a memory latency, more
+    const dim3 grid(cdiv(cdiv(N, BT / 4) * cdiv(M, BT), 8) * 8);   // workgroups per CU cover it (640 x 1024 over K = 512: 15.9 -> 11 us; 640 x 4096: no change)
+    KLAUNCH(k_gemm_bf16_nt<1>, grid, block, st, pr, g);
+  }
   if (cdiv(N, BT) * cdiv(M, BT) < 384) {             // few 128 x 128 tiles (640 x 4096: 160 on 256 CUs): 128 x 64
     const dim3 grid(cdiv(cdiv(N, BT / 2) * cdiv(M, BT), 8) * 8);
     KLAUNCH(k_gemm_bf16_nt<2>, grid, block, st, pr, g);
