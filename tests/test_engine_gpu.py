@@ -1377,14 +1377,15 @@ def test_backpropagate_fuse_update_flag(I, C, R, S, T, persist, clip):
 
 
 @pytest.mark.parametrize("I,C,R,S,T", [(512, 1024, 512, 16, 20), (512, 1024, 512, 32, 20), (40, 1024, 512, 32, 20), (64, 256, 128, 24, 12),
-                                       (72, 160, 96, 13, 21)])
+                                       (72, 160, 96, 13, 21), (512, 1024, 256, 13, 21), (96, 1024, 128, 9, 29)])
 def test_many_stream_persistent_forward_bf16(I, C, R, S, T):
     """The weights-resident forward launch for 9..32 streams in bf16 operand mode (klstm_persist_ms.hip): one
     launch runs all T steps of the folded recurrence, the x term and r(1..T) are batched products around it.  Three chained
     minibatches (Update in between: W_rm is refreshed; carried state: step 1 closes over r) against tests/bf16_emul.py with
     fold=True at the tolerance of the launch-per-step bf16 chain (6e-3 of each tensor's maximum), and the engine's own counters say
     that it WAS this launch.  Shapes: full and half tile counts, a narrow first layer (fp32 batched x term), C / 4 = 64 and 40
-    workgroups, R != 512, a ragged stream tile (13 of 16), an odd T."""
+    workgroups, R != 512, a ragged stream tile (13 of 16), an odd T; the per-XCD chains (C = 1024) with ragged stream groups (13 = 2+2+..+1,
+    9 = 2+2+2+2+1+0..), R = 256 / 128 (projection rows on 16 / 8 of an XCC's 32 workgroups), the smallest T S they take."""
     from tests import bf16_emul
     rng = np.random.RandomState(I + C + S)
     p = make_params(I, C, R, scale=0.03, seed=5)
