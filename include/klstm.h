@@ -68,7 +68,7 @@ typedef enum {
 
 /* Message of the calling thread's most recent failing call ("" if none). */
 const char *klstm_last_error(void);
-/* Library / kernel-arch identification string, e.g. "klstm 0.3 gfx950 (...)". */
+/* Library / kernel-arch identification string, e.g. "klstm 0.4 gfx950 (...)". */
 const char *klstm_version(void);
 
 /* Replaces: LstmProjectedStreams(input_dim, output_dim) + <CellDim>/<NumStream> of

@@ -546,7 +546,7 @@ static klstm_status ensure_fold(klstm_engine *e, bool need_x, bool need_pk2 = tr
 extern "C" {
 
 const char *klstm_last_error(void) { return g_err.c_str(); }
-const char *klstm_version(void) { return "klstm 0.3 gfx950 (f32 MFMA, persistent weights-resident chain, bf16x3 fold product)"; }
+const char *klstm_version(void) { return "klstm 0.4 gfx950 (f32 MFMA, weights-resident chains for 1..8 streams and per-XCD for 9..32 in bf16, 16-bit split-operand products with range guard)"; }
 
 klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_stream, int device,
                           void *hip_stream, klstm_engine **out) {
@@ -856,7 +856,10 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     // elementwise pass of the own cells, then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r (:391) and in_diff = dgifo W_gifo_x (:457)
     // as batched products -- every product on the bf16 tiles with fp32 accumulation, operands rounded like the step kernels'
     const int M = T * d.S, KS = 8, KL = 4 * d.C / KS;          // (K = 4C in 8 slices of 512: 40 output tiles -> 320 workgroups)
-    HIPCHK(launch_gemm_bf16_nt(M, d.C, d.R, out_diff, od_stride, p.wmT, d.R, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
+    if (gemm_bf16_nt_supported(M, d.R, out_diff, od_stride, p.wmT, d.R))
+      HIPCHK(launch_gemm_bf16_nt(M, d.C, d.R, out_diff, od_stride, p.wmT, d.R, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
+    else                                              // (a caller's view that is not 16-byte aligned: the fp32 tiles take any layout)
+      HIPCHK(launch_gemm(false, true, M, d.C, d.R, out_diff, od_stride, p.wmT, d.R, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
     HIPCHK(launch_bwd_persist_xl(d, p, e->wrmT_l, e->Pm, e->gran_xb, e->pctrl + 4, e->popt, st, probe(e, "k_bwd_persist_xl")));
     HIPCHK(launch_gemm_bf16_nt_splitk(M, d.R, 4 * d.C, e->dgifo + (size_t)2 * d.S * 4 * d.C, 4 * d.C, p.wrT, 4 * d.C, 0.f,
                                       e->dr + (size_t)d.S * d.R, d.R, out_diff, od_stride, e->ws, KS, KL, st, probe(e, "k_gemm_dr"),
@@ -942,10 +945,6 @@ static klstm_status run_graphed(klstm_engine *e, const klstm_engine::Key &key, F
   HIPCHK(hipGraphLaunch(it->second, e->stream));
   return KLSTM_OK;
 }
-
-extern "C" {
-
-}  // extern "C"
 
 // The body of klstm_propagate (arguments checked by the caller): also what recover() runs a minibatch again with.
 static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int in_stride, float *out, int out_stride) {

@@ -1416,6 +1416,35 @@ def test_many_stream_persistent_forward_bf16(I, C, R, S, T):
     e.close()
 
 
+def test_per_xcd_chains_take_unaligned_views():
+    """Caller matrices that are views into wider ones (Kaldi's SubMatrix: a column range, a stride that is no multiple of 4 floats, a
+    base that is not 16-byte aligned): the per-XCD chains write `out` with scalar stores, reduce in_diff / d_r elementwise, and P =
+    out_diff W_r_m leaves the bf16 tiles (16-byte operand loads) for the fp32 ones, as the x term and the gradient products do for such
+    an `in`.  Against a twin fed contiguous copies: everything to the bf16 rounding of those products' operands."""
+    I, C, R, S, T = 512, 1024, 512, 16, 20
+    p = make_params(I, C, R, scale=0.03, seed=21)
+    rng = np.random.RandomState(22)
+    x = rng.randn(T * S, I).astype(np.float32); od = (0.3 * rng.randn(T * S, R)).astype(np.float32)
+    res = []
+    for views in (False, True):
+        e = make_engine(I, C, R, S, p); e.set_option("bf16", 1); e.set_option("profile", 1)
+        if views:
+            wide = lambda cols: torch.zeros(T * S, cols + 7, device="cuda")[:, 3:3 + cols]
+            xd, odd, out, idf = wide(I), wide(R), wide(R), wide(I)
+            xd.copy_(dev(x)); odd.copy_(dev(od))
+            assert odd.data_ptr() % 16 != 0 and odd.stride(0) % 4 != 0
+        else:
+            xd, odd = dev(x), dev(od)
+            out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+        e.propagate(xd, out); e.backpropagate(xd, odd, idf, momentum=0.0); e.synchronize()
+        assert e.profile_query("k_bwd_persist_xl")[1] == 1
+        res.append((out.cpu().numpy().copy(), idf.cpu().numpy().copy(), e.get_corr()))
+        e.close()
+    assert relerr(res[1][0], res[0][0]) <= 6e-3          # (the x term of a view runs on the fp32 tiles too)
+    assert relerr(res[1][1], res[0][1]) <= 1e-2
+    check_blob(res[1][2], res[0][2].astype(np.float64), 1e-2, C, R, "corr")
+
+
 @pytest.mark.parametrize("direction", ["fwd", "bwd"])
 def test_many_stream_persistent_forward_gives_up_and_is_run_again(direction):
     """The many-stream launches under the same give-up protocol as the small chain: workgroup 0 withholds its publishes of step 4,
