@@ -293,7 +293,7 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
 // the batched product in front of the launch), then the elementwise BPTT of the workgroup's OWN cells (:411-440) -- nothing is
 // replicated: what travels is dgifo(t) of the group's streams, 4 gates x 1024 cells x <= 4 streams as bf16 (the operand every
 // consumer rounds it to), inside the XCD.  A workgroup owns 32 output cells = 32 rows of W_rm^T over K = 4C (the fold product writes
-// the transpose next to W_rm: klstm_fold3.hip wlT): wave (row tile = wave / 8, K eighth = wave % 8) holds 16 rows x 512 k.
+// the transpose next to W_rm: klstm_fold3.hip wlT): wave w holds both row tiles (2 x 16 rows) x the K sixteenth [256 w, 256 w + 256): the operand slab is read once per k.
 // d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r (:391: the W_r_m gradient's operand) and in_diff = dgifo W_gifo_x (:457) are batched
 // products behind the launch.  Granule = 16 bytes {tag, (d_g, d_i), (d_f, d_o)} per (cell, stream): 8 contiguous bytes of the slab row
 // [k = 4 cell + gate].
@@ -320,8 +320,8 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
   constexpr int C = XL_C, K = 4 * XL_C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *slab = smem;                                           // [5][XL_LDB]: rows 0..3 = dgifo(t+1) of the group's streams, row 4 = zeros
-  f32x4 *part = reinterpret_cast<f32x4 *>(smem + 5 * XL_LDB);           // [8 K eighths][2 row tiles][64]
-  unsigned *abortf = reinterpret_cast<unsigned *>(part + 16 * 64);
+  f32x4 *part = reinterpret_cast<f32x4 *>(smem + 5 * XL_LDB);           // [16 K parts][2 row tiles][64]
+  unsigned *abortf = reinterpret_cast<unsigned *>(part + 32 * 64);
   int *pubcnt = reinterpret_cast<int *>(abortf + 1);
   unsigned *place = abortf + 2;
   const int S = a.S, T = a.T;
@@ -352,12 +352,13 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
 
   if (!idle) {
     const int i16 = lane & 15, kg = lane >> 4;
-    const int ti = wave >> 3, kp = wave & 7;                            // row tile (16 output cells), K eighth
+    const int kp = wave;                                                // K sixteenth (256 k) of BOTH row tiles: the slab is read once per k
+    const int ti = wave & 1;                                            // (elementwise waves 0 and 1: the row tile whose cells they update)
     uint4 *gr = a.gran + (size_t)grp * 2 * 4 * C;                        // the group's granules: [2 parities][4 streams][C cells]
     const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(gr, 2 * 4 * C * 16);
     // ---- elementwise lanes: the two waves with kp = 0, lane = (cell cl = lane & 15 of the wave's row tile, stream n2 = lane >> 4):
     //      one (cell, stream) pair per lane (four pairs per lane in the MFMA result layout cost 56 registers of state and operands)
-    const bool cellw = kp == 0;
+    const bool cellw = wave < 2;
     const int cl = lane & 15, n2 = lane >> 4;
     const bool on = cellw && n2 < sxl;
     const int cell = 32 * slot + 16 * ti + cl, strm = s0 + (n2 < sxl ? n2 : 0);
@@ -367,16 +368,17 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
       float *zp = a.dgifo + ((size_t)(T + 1) * S + strm) * K + cell;
       zp[0] = 0.f; zp[C] = 0.f; zp[2 * C] = 0.f; zp[3 * C] = 0.f;
     }
-    // ---- the resident operand: 16 rows of W_rm^T (output cells 32 slot + 16 ti + i16) x this wave's eighth of K ----
+    // ---- the resident operand: 2 x 16 rows of W_rm^T (output cells 32 slot + 16 tile + i16) x this wave's sixteenth of K ----
     xl_bf16x8 af[16];
 #pragma unroll
     for (int j = 0; j < 16; j++)
-      af[j] = *reinterpret_cast<const xl_bf16x8 *>(a.wrmT + (size_t)(32 * slot + 16 * ti + i16) * K + 512 * kp + 32 * j + 8 * kg);
+      af[j] = *reinterpret_cast<const xl_bf16x8 *>(a.wrmT + (size_t)(32 * slot + 16 * (j >> 3) + i16) * K + 256 * kp + 32 * (j & 7) + 8 * kg);
     const unsigned char *brow = slab + (i16 < 4 ? i16 : 4) * XL_LDB + 16 * kg;
     bool dead = false;
     for (int t = T; t >= 1 && !dead; t--) {
       if (t < T) {
-        // ---- sweep dgifo(t+1) of the group: thread = (stream n = tid >> 8, cells 4 (tid & 255) .. + 3): four 16-byte sc1 loads ----
+        // ---- sweep dgifo(t+1) of the group: thread = (stream n = tid >> 8, cells (tid & 255) + 256 e, e = 0..3): four 16-byte sc1 loads, each
+        //      one contiguous KB per wave (lane-strided 64 bytes instead: 32 lines per instruction x 4, 83 -> ... us at T = 20) ----
         {
           const long long w0 = wall_clock64();
           for (unsigned spins = 0; __hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * (T - t); spins++) {
@@ -387,13 +389,13 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
         const int n = tid >> 8, c4 = tid & 255;
         const bool live = n < sxl;
         const unsigned tag = epoch + (unsigned)(t + 1);
-        const int off = ((((t + 1) & 1) * 4 + (live ? n : 0)) * C + 4 * c4) * 16;
+        const int off = ((((t + 1) & 1) * 4 + (live ? n : 0)) * C + c4) * 16;
         u32x4 q[4];
         bool ok = false;
         const long long t0 = wall_clock64();
         for (unsigned spins = 0;; spins++) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) q[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_gr, off + 16 * e, 0, 16);   // aux 16 = sc1
+          for (int e = 0; e < 4; e++) q[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_gr, off + 4096 * e, 0, 16);   // aux 16 = sc1
           ok = !live | ((q[0].x == tag) & (q[1].x == tag) & (q[2].x == tag) & (q[3].x == tag));
           if (__all(ok)) break;
           if ((spins & 31) == 31) {
@@ -410,9 +412,9 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
           }
         }
         if (live) {
-          uint4 *sp = reinterpret_cast<uint4 *>(slab + n * XL_LDB + 32 * c4);
-          sp[0] = make_uint4(q[0].y, q[0].z, q[1].y, q[1].z);
-          sp[1] = make_uint4(q[2].y, q[2].z, q[3].y, q[3].z);
+          uint2 *sp = reinterpret_cast<uint2 *>(slab + n * XL_LDB + 8 * c4);     // slab row [k = 4 cell + gate] bf16: 8 bytes per cell
+#pragma unroll
+          for (int e = 0; e < 4; e++) sp[256 * e] = make_uint2(q[e].y, q[e].z);
         }
       }
       // the own pair's operands of frame t: requested here, consumed behind the two barriers
@@ -426,27 +428,31 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
       }
       lds_barrier();                                                    // (1) slab of dgifo(t+1) ready
       if (*abortf) { dead = true; break; }
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       if (t < T) {
 #pragma unroll
-        for (int hf = 0; hf < 8; hf++) {
+        for (int hf = 0; hf < 4; hf++) {
           xl_bf16x8 bv[2];
 #pragma unroll
-          for (int j = 0; j < 2; j++) bv[j] = *reinterpret_cast<const xl_bf16x8 *>(brow + 64 * (16 * kp + 2 * hf + j));
+          for (int j = 0; j < 2; j++) bv[j] = *reinterpret_cast<const xl_bf16x8 *>(brow + 64 * (8 * kp + 2 * hf + j));
 #pragma unroll
-          for (int j = 0; j < 2; j++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2 * hf + j], bv[j], acc, 0, 0, 0);
+          for (int j = 0; j < 2; j++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2 * hf + j], bv[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[8 + 2 * hf + j], bv[j], acc1, 0, 0, 0);
+          }
         }
       }
-      part[(kp * 2 + ti) * 64 + lane] = acc;
+      part[(kp * 2 + 0) * 64 + lane] = acc0;
+      part[(kp * 2 + 1) * 64 + lane] = acc1;
       lds_barrier();                                                    // (2) the partial tiles are in LDS
       if (cellw) {
         // d_m of this lane's (cell, stream): element (row cl, column n2) of the tile = component cl & 3 of result lane 16 (cl >> 2) + n2;
-        // the eight K parts in fixed order, then :408 with :391 substituted
+        // the sixteen K parts in fixed order, then :408 with :391 substituted
         const float *pf32 = reinterpret_cast<const float *>(part);
         const int pe = ((cl >> 2) * 16 + n2) * 4 + (cl & 3);
         float dm = pf32[(ti * 64) * 4 + pe];
 #pragma unroll
-        for (int w = 1; w < 8; w++) dm += pf32[((w * 2 + ti) * 64) * 4 + pe];
+        for (int w = 1; w < 16; w++) dm += pf32[((w * 2 + ti) * 64) * 4 + pe];
         dm += Pv;
         const float d_h = k_diff_tanh(dm * yo, yh);                     // :411-412
         const float d_o = k_diff_sigmoid(dm * yh, yo);                  // :415-416
@@ -531,7 +537,7 @@ hipError_t launch_bwd_persist_xl(const Dims &d, const BwdPtrs &p, const unsigned
   a.ctrl = ctrl; a.guard = o.guard; a.hstat = o.hstat;
   a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;
   a.test_stall = o.test_stall_bwd;
-  const size_t shm = (size_t)5 * XL_LDB + (size_t)16 * 64 * 16 + 32;
+  const size_t shm = (size_t)5 * XL_LDB + (size_t)32 * 64 * 16 + 32;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persist_xl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (pr.start) hipExtLaunchKernelGGL(k_bwd_persist_xl, dim3(256), dim3(1024), shm, st, pr.start, pr.stop, 0, a);
   else hipLaunchKernelGGL(k_bwd_persist_xl, dim3(256), dim3(1024), shm, st, a);
