@@ -18,8 +18,8 @@
 //     logical-row bf16 W_rm (launch_fold_ms); wave (row tile i = wave / 2, K half kp = wave % 2): 16 rows x 512 k resident
 //   step t: every thread sweeps its share of the group's granules {tag, m(t-1) of two adjacent cells as bf16} (4 streams x 512 pairs, 8
 //     bytes each: one 16-byte load per thread and pass) into the LDS slab [stream][cell]; barrier; v_mfma_f32_16x16x32_bf16 (weights on the M side, the group's streams on the N
-//     side: a lane ends up with g, i, f, o of ITS (cell, stream)); K halves combined through LDS; barrier; the cell update
-//     (:278-309) on the lanes that own a pair, publish, plane rows.  x(t) W_gifo_x^T + bias is the batched product of the
+//     side: a result lane holds g, i, f, o of one (cell, stream)); K halves combined through LDS; barrier; the cell update
+//     (:278-309) on two waves, lane = (cell of 16, stream): publish, plane rows in 64-byte runs.  x(t) W_gifo_x^T + bias is the batched product of the
 //     reference (:246, :259), in the gifo plane when the launch starts.
 //   r(t) = W_r_m m(t) (:312): 16 rows of W_r_m per workgroup (R <= 512), every wave a sixteenth of K, one pass later (the slab of
 //     step t + 1 IS m(t)); one more pass, T + 1, for r(T).
@@ -106,10 +106,14 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
     const int ti = wave >> 1, kp = wave & 1;                            // row tile, K half
     unsigned long long *gr = a.gran + (size_t)grp * 2 * 4 * (C / 2);    // the group's granules: [2 parities][4 streams][C / 2 cell pairs]
     const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(gr, 2 * 4 * (C / 2) * 8);
-    // ---- cell-update lanes: wave (ti, kp = 0), lane (stream n = i16 < sxl, cell 4 ti + kg of the workgroup's 32) ----
-    const bool cellw = kp == 0;
-    const bool on = cellw && i16 < sxl;
-    const int cell = 32 * slot + 4 * ti + kg, strm = s0 + (i16 < sxl ? i16 : 0);
+    // ---- cell-update lanes: waves 0 and 1, lane = (cell cl = lane & 15 of the wave's 16, stream n2 = lane >> 4): one (cell, stream) pair
+    //      per lane, taken out of the partial tiles in LDS (with the MFMA result layout as the cell layout -- 8 waves, 16 live lanes each --
+    //      every plane store wrote sixteen 16-byte runs and the workgroup issued 64 of them per step in front of the next sweep) ----
+    const bool cellw = wave < 2;
+    const int cl = lane & 15, n2 = lane >> 4, c32 = 16 * (wave & 1) + cl;
+    const bool on = cellw && n2 < sxl;
+    const int cell = 32 * slot + c32, strm = s0 + (n2 < sxl ? n2 : 0);
+    const int psrc = (c32 >> 2) * 64 + 16 * (c32 & 3) + n2;            // tile c32 / 4, result lane (k-group c32 % 4, column n2): g, i, f, o of the pair
     float cp = on ? a.prev_c[(size_t)strm * C + cell] : 0.f;            // carried c(0) (:231)
     if (on) a.cc[(size_t)strm * C + cell] = cp;                         // time block 0 of the c plane: BPTT reads it
     const float wpi = a.pi[cell], wpf = a.pf[cell], wpo = a.po[cell];
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
         // (polling starts once this workgroup's own cell waves have issued their publishes of step t-1: klstm_persist.hip)
         {
           const long long w0 = wall_clock64();
-          for (unsigned spins = 0; __hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 * (t - 1); spins++) {
+          for (unsigned spins = 0; __hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * (t - 1); spins++) {
             __builtin_amdgcn_s_sleep(1);
             if ((spins & 1023) == 1023 && wall_clock64() - w0 > a.spin_limit) break;
           }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
       }
       part[(kp * 8 + ti) * 64 + lane] = acc;
       lds_barrier();                                                    // (2) the partial tiles are in LDS
-      if (!first && projw && wave == 1) {
+      if (!first && projw && wave == 2) {
         // ---- r(t-1): lane (stream n = i16, rows 16 slot + 4 kg .. + 3): the sixteen K parts in fixed order ----
         f32x4 v = partr[lane];
 #pragma unroll
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
       }
       if (cellw && t <= T) {
         // ---- cell update of (cell, stream): the two K halves in fixed order, then :278-309 ----
-        const f32x4 v = part[ti * 64 + lane] + part[(8 + ti) * 64 + lane];
+        const f32x4 v = part[psrc] + part[8 * 64 + psrc];
         float ai = v.y + xg.y, af_ = v.z + xg.z, ao = v.w + xg.w;
         const float ag = v.x + xg.x;
         ai += wpi * cp;                                                 // :278
@@ -244,10 +248,10 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
         const float go = k_sigmoid(ao);                                 // :306
         const float m = h * go;                                         // :309
         // publish m(t) (m(T) travels too: r(T)) as bf16 (what every consumer rounds it to), two adjacent cells per granule: the lane of
-        // the even cell takes its neighbour's value (16 lanes up) and issues ONE plain 8-byte store -- the line stays in this XCC's L2
-        const unsigned mb = bf16_rne(m), mb_up = (unsigned)__shfl_down((int)mb, 16);
-        if (on && (kg & 1) == 0 && !(a.test_stall == t && slot == 0 && grp == 0))
-          gr[((size_t)(t & 1) * 4 + i16) * (C / 2) + (cell >> 1)] = ((unsigned long long)(epoch + (unsigned)t) << 32) | (mb | (mb_up << 16));
+        // the even cell takes its neighbour's value (the next lane) and issues ONE plain 8-byte store -- the line stays in this XCC's L2
+        const unsigned mb = bf16_rne(m), mb_up = (unsigned)__shfl_down((int)mb, 1);
+        if (on && (cl & 1) == 0 && !(a.test_stall == t && slot == 0 && grp == 0))
+          gr[((size_t)(t & 1) * 4 + n2) * (C / 2) + (cell >> 1)] = ((unsigned long long)(epoch + (unsigned)t) << 32) | (mb | (mb_up << 16));
         if (on) {
           float *gp = a.gifo + ((size_t)t * S + strm) * 4 * C + cell;
           gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
