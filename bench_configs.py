@@ -354,7 +354,7 @@ def run_c5(args, k):
                                    "%s" % ("SINGLE-GPU training step (per-layer Update without a gradient blob; `multi_gpu_shard_path` = what a rank of "
                                            "the 8-GPU run executes)" if fused else "multi-GPU shard path (fused gradient blob, separate momentum + Update)"),
                        "streams_per_gpu": S, "frames_per_step": T * S},
-            "roofline": _roof(fl * T * S, ms, PEAK_BF16_MFMA_TF, "bf16", "73.3 MFLOP per frame (SURVEY.md 8(d)); launch-per-step chain"),
+            "roofline": _roof(fl * T * S, ms, PEAK_BF16_MFMA_TF, "bf16", "73.3 MFLOP per frame (SURVEY.md 8(d)); weights-resident chains, one per XCD and direction (klstm_persist_xl.hip), batched products around them"),
             "multi_gpu_shard_path": shard, "kernels": kern}
 
 
