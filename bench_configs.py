@@ -108,7 +108,8 @@ def _apply_options(engines, args):
 def _engine_kernels(engines, step, base, nprof=10):
     names = ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj", "k_gates_fold", "k_gemm_rbatch",
              "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step", "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx",
-             "k_fwd_persist", "k_bwd_persist", "k_fwd_persist_ms", "k_fold_ms", "k_bwd_persist_xl", "k_gemm_P", "k_gemm_dr", "k_gemm_indiff", "k_grads", "k_grads_update", "k_update_repack", "k_pack",
+             "k_fwd_persist", "k_bwd_persist", "k_fwd_persist_ms", "k_fold_ms", "k_bwd_persist_xl", "k_gemm_dr", "k_reduce_dr", "k_gemm_indiff",
+             "k_reduce_indiff", "k_grads", "k_grads_update", "k_update_repack", "k_pack",
              "k_apply_momentum")
     for e in engines:
         e.set_option("profile", 1)
@@ -146,6 +147,36 @@ def _roof(flops_per_step, ms_per_step, peak_tf, dtype, note):
     tf = flops_per_step / (ms_per_step * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "whole minibatch (sections / kernels below)", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s",
             "frac": tf / peak_tf, "traffic": None, "dtype_peak": dtype, "note": note}
+
+
+def _dominant_kernel(kern, alg_flops_per_launch, peak_tf, csv_glob, csv_names):
+    """The kernel with the most device time per minibatch (summed over the layers): its ALGORITHMIC flops per launch over its
+    average launch duration -- by this run's HIP events (`frac`) and by the committed rocprofv3 --kernel-trace --stats summary of
+    the same command (`frac_rocprof`; static: not this run)."""
+    import csv, glob, os
+    agg = {}
+    for key, v in kern.items():
+        a = agg.setdefault(key.split(".", 1)[-1], [0.0, 0.0])
+        a[0] += v["us_per_step"]; a[1] += v["launches_per_step"]
+    cand = {nme: a for nme, a in agg.items() if nme in alg_flops_per_launch}
+    if not cand:
+        return None
+    name = max(cand, key=lambda nme: cand[nme][0])
+    avg_us = cand[name][0] / cand[name][1]
+    fl = alg_flops_per_launch[name]
+    out = {"kernel": name, "avg_us": avg_us, "us_per_step": cand[name][0], "alg_flops_per_launch": fl,
+           "achieved": fl / (avg_us * 1e-6) / 1e12, "unit": "TFLOP/s", "peak": peak_tf, "frac": fl / (avg_us * 1e-6) / 1e12 / peak_tf,
+           "limiter": "latency (in-launch exchange inside the XCD's L2)", "frac_rocprof": None, "rocprof": None}
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", csv_glob)))
+    if files:
+        best = None
+        for row in csv.DictReader(open(files[-1])):
+            if any(c in row["Name"] for c in csv_names.get(name, (name,))) and (best is None or float(row["TotalDurationNs"]) > best[1]):
+                best = (float(row["AverageNs"]) * 1e-3, float(row["TotalDurationNs"]), row["Name"])
+        if best:
+            out["frac_rocprof"] = fl / (best[0] * 1e-6) / 1e12 / peak_tf
+            out["rocprof"] = {"avg_us": best[0], "name": best[2], "file": "profiles/" + os.path.basename(files[-1])}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -346,6 +377,13 @@ def run_c5(args, k):
     for e in engines:
         e.close()
     fl = sum(lstm_flops_per_frame(dims_in[l], C, R) for l in range(NL))
+    roof = _roof(fl * T * S, ms, PEAK_BF16_MFMA_TF, "bf16", "73.3 MFLOP per frame (SURVEY.md 8(d)); weights-resident chains, one per XCD and direction (klstm_persist_xl.hip), batched products around them")
+    # the two chain launches: the reference's recurrent products of the T S frames one launch advances -- forward r(t-1) W_gifo_r^T (:275) and
+    # m(t) W_r_m^T (:312); backward dgifo(t+1) W_gifo_r (:391) and d_r(t) W_r_m (:408, the part that is not the batched P)
+    chain_fl = float(T * S) * (2 * 4 * C * R + 2 * R * C)
+    roof["dominant_kernel"] = _dominant_kernel(kern, {"k_fwd_persist_ms": chain_fl, "k_bwd_persist_xl": chain_fl}, PEAK_BF16_MFMA_TF,
+                                               "r[0-9][0-9]c5_rocprofv3_kernel_stats.csv",
+                                               {"k_fwd_persist_ms": ("k_fwd_persist_xl", "k_fwd_persist_ms"), "k_bwd_persist_xl": ("k_bwd_persist_xl",)})
     return {"metric": "frames/sec fwd+BPTT+update, 3x LstmProjectedStreams cell 1024 / proj 512, bf16, per-GPU shard",
             "value": T * S / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1, "steps": n, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -354,8 +392,7 @@ def run_c5(args, k):
                                    "%s" % ("SINGLE-GPU training step (per-layer Update without a gradient blob; `multi_gpu_shard_path` = what a rank of "
                                            "the 8-GPU run executes)" if fused else "multi-GPU shard path (fused gradient blob, separate momentum + Update)"),
                        "streams_per_gpu": S, "frames_per_step": T * S},
-            "roofline": _roof(fl * T * S, ms, PEAK_BF16_MFMA_TF, "bf16", "73.3 MFLOP per frame (SURVEY.md 8(d)); weights-resident chains, one per XCD and direction (klstm_persist_xl.hip), batched products around them"),
-            "multi_gpu_shard_path": shard, "kernels": kern}
+            "roofline": roof, "multi_gpu_shard_path": shard, "kernels": kern}
 
 
 RUN = {"c1": run_c1, "c4": run_c4, "c5": run_c5}

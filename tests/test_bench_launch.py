@@ -47,3 +47,28 @@ def test_mismatched_world_size_is_an_error_not_a_silent_single_rank_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True,
                        timeout=120, env=env, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_committed_bench_lines_agree_with_their_rocprof_tables():
+    """The judged numbers have two sources that must tell the same story: a bench line's per-kernel device times (HIP events inside the
+    run) and the rocprofv3 --kernel-trace --stats table of the same command committed next to it (`profiles/`).  For the configs[4]
+    line the dominant kernel's roofline fraction is computed from both (`bench_configs._dominant_kernel`); for the headline line the
+    tracer's averages sit a few percent above the events (its own overhead), never below and never far off."""
+    import csv, glob, json
+    import bench_configs as bc
+    prof = os.path.join(ROOT, "profiles")
+    lines = sorted(glob.glob(os.path.join(prof, "r[0-9][0-9]_bench_c5.json")))
+    assert lines
+    kern = json.load(open(lines[-1]))["kernels"]
+    fl = 640.0 * (2 * 4 * 1024 * 512 + 2 * 512 * 1024)
+    d = bc._dominant_kernel(kern, {"k_fwd_persist_ms": fl, "k_bwd_persist_xl": fl}, bc.PEAK_BF16_MFMA_TF, "r[0-9][0-9]c5_rocprofv3_kernel_stats.csv",
+                            {"k_fwd_persist_ms": ("k_fwd_persist_xl", "k_fwd_persist_ms"), "k_bwd_persist_xl": ("k_bwd_persist_xl",)})
+    assert d["kernel"] in ("k_fwd_persist_ms", "k_bwd_persist_xl") and d["rocprof"] is not None
+    assert 0.9 <= d["frac_rocprof"] / d["frac"] <= 1.02, d
+    head = json.load(open(sorted(glob.glob(os.path.join(prof, "r[0-9][0-9]_bench_n1.json")))[-1]))
+    table = {r["Name"]: float(r["AverageNs"]) * 1e-3 for r in csv.DictReader(open(sorted(glob.glob(os.path.join(prof, "r[0-9][0-9]_rocprofv3_kernel_stats.csv")))[-1]))}
+    for probe, sub in (("k_fwd_persist", "k_fwd_persist<"), ("k_bwd_persist", "k_bwd_persist2"), ("k_fold", "k_fold_bf16x3"), ("k_grads_update", "k_grads(")):
+        rp = [v for n, v in table.items() if sub in n]
+        assert rp, sub
+        ev = head["kernels"][probe]["avg_us"]
+        assert 0.97 <= max(rp) / ev <= 1.12, (probe, ev, rp)
