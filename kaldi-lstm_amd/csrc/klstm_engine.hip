@@ -1754,8 +1754,7 @@ klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
   // A persistent launch of this minibatch that gave up left the gradient products undone (they are guarded): the blob must not
-  // reach the other ranks like that -- they would apply the step, this rank would not.  Look first (a host wait, only while the
-  // persistent chain is in use); a give-up is answered by running the minibatch again, then everybody reduces real gradients.
+  // reach the other ranks like that -- they would apply the step, this rank would not.
   // Two ways to keep that from happening.  (a) The engine's own blob carries a validity word behind the gradient (written by the
   // gradient kernel: 0 = real, 1 = stopped by the guard) that is summed with it; the Update kernels of EVERY rank leave the step out
   // when the sum is non-zero -- no host wait, replicas identical, the minibatch counts as dropped ("dp_updates_left_out").  What the
@@ -1821,9 +1820,15 @@ __global__ __launch_bounds__(1024) void k_occupy(long long ticks, unsigned *wher
 extern "C" klstm_status klstm_debug_occupy(int device, int workgroups, int microseconds, void *hip_stream, unsigned *where_dev) {
   if (workgroups <= 0 || microseconds <= 0) return fail(KLSTM_ERR_ARG, "klstm_debug_occupy: bad arguments");
   HIPCHK(hipSetDevice(device));
-  static hipStream_t own = nullptr;
-  if (!hip_stream && !own) HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : own;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (!st) {                                         // a stream of its own per device (streams belong to the device they were made on)
+    static std::mutex mu;
+    static std::map<int, hipStream_t> own;
+    std::lock_guard<std::mutex> lk(mu);
+    hipStream_t &o = own[device];
+    if (!o) HIPCHK(hipStreamCreateWithFlags(&o, hipStreamNonBlocking));
+    st = o;
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   hipLaunchKernelGGL(k_occupy, dim3(workgroups), dim3(1024), 96 * 1024, st, (long long)microseconds * 100, where_dev);
   HIPCHK(hipGetLastError());
