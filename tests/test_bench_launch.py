@@ -72,3 +72,23 @@ def test_committed_bench_lines_agree_with_their_rocprof_tables():
         assert rp, sub
         ev = head["kernels"][probe]["avg_us"]
         assert 0.97 <= max(rp) / ev <= 1.12, (probe, ev, rp)
+
+
+def test_roofline_accounting_is_surveys_8d():
+    """`roofline.achieved` divides ALGORITHMIC work by measured time: the per-frame figures are SURVEY.md 8(d)'s, not what the folded
+    kernels execute.  Pinned here as numbers: FLOPs per frame 6 (4C I + 4C R + R C) = 13 056 000 at 40/800/512 (forward 4 352 000 -- what
+    one frame of a chain launch advances, either direction), the other layers of configs[3]/[4], 79 072 activation bytes per frame,
+    5 P 4 bytes of weights / gradients / momentum per minibatch."""
+    import bench as b
+    import bench_configs as bc
+    assert b.FLOPS_PER_FRAME == 13_056_000 == bc.lstm_flops_per_frame(40, 800, 512)
+    assert bc.lstm_flops_per_frame(512, 800, 512) == 22_118_400
+    assert bc.lstm_flops_per_frame(40, 1024, 512) == 16_711_680
+    assert bc.lstm_flops_per_frame(512, 1024, 512) == 28_311_552
+    assert abs(sum(bc.lstm_flops_per_frame(i, 1024, 512) for i in (40, 512, 512)) - 73.3e6) < 0.05e6          # configs[4]'s stack
+    for S in (1, 4, 8):
+        assert b.kernel_alg_flops("k_fwd_persist", S) == S * 4_352_000 == b.kernel_alg_flops("k_bwd_persist", S)
+        assert b.kernel_exec_flops("k_gates_fold", S) > b.kernel_alg_flops("k_gates_fold", S)                 # (the fold executes more than it is credited)
+    assert b.ACT_BYTES_PER_FRAME == 79_072
+    assert b.WEIGHT_BYTES_PER_MINIBATCH == 5 * bc.n_params(40, 800, 512) * 4 == 43_632_000
+    assert b.ACT_BYTES_PER_FRAME * 80 + b.WEIGHT_BYTES_PER_MINIBATCH == 49_957_760                            # the 49.96 MB the traffic ratio divides by
