@@ -230,6 +230,45 @@ def cpu_baseline(S, budget_s):
     return res
 
 
+
+def multi_gpu_summary(value, world, same_load, allreduce_us):
+    """The keys that make an N > 1 line self-explaining (N = 1 runs 4 streams, N > 1 runs 8 per GPU: value(N) / (N * value(1)) is
+    NOT an efficiency).  `single_gpu_same_load` = this job's per-GPU load (8 streams) on one GPU with no collective, measured by
+    every rank on its own GPU in the same process before the library's communicator exists (slowest rank); `efficiency_vs_same_load`
+    = value / (N * that); `allreduce_exposed_us` = time of the one gradient all-reduce per minibatch on the engine's stream (HIP
+    events around the collective: nothing overlaps it, the Update waits for it)."""
+    return {"single_gpu_same_load": same_load,
+            "efficiency_vs_same_load": (value / (world * same_load["value"])) if same_load and same_load.get("value") else None,
+            "allreduce_exposed_us": allreduce_us}
+
+
+def kaldi_adapter_leg(S, steps=400, warmup=50):
+    """The as-shipped-in-Kaldi figure: tools/kaldi_adapter_bench (C++: klstm_kaldi::LstmProjectedStreams of include/klstm_component.hpp
+    exactly as INTEGRATION.md 2 constructs it -- SetUpdateFollows(true), persist_verify = 1 --, Reset + PropagateFnc + BackpropagateFnc +
+    Update per minibatch on pitched device matrices) run as a child process on the same GPU while this process is idle."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "kaldi_adapter_bench")
+    try:
+        if not os.path.exists(exe):
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("klstm_build", os.path.join(ROOT, "kaldi-lstm_amd", "build.py"))
+            mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+            mod.build_adapter_bench()
+        out = {}
+        for tag, verify, d2h in (("", 1, 0), ("with_d2h_per_minibatch", 1, 1), ("persist_verify_0", 0, 0)):
+            r = subprocess.run([exe, str(S), str(steps), str(warmup), str(verify), str(d2h)], capture_output=True, text=True, timeout=120)
+            if r.returncode != 0:
+                raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            if tag:
+                out[tag] = {k_: d[k_] for k_ in ("value", "ms_per_step", "persist_giveups")}
+            else:
+                out.update(d)
+        return out
+    except Exception as ex:                               # (the headline does not depend on this leg; the line says what happened)
+        return {"error": str(ex)}
+
+
 def folded_chain(eng):
     """Did the engine's last minibatch run on a chain that needs the fold product W_rm = W_gifo_r W_r_m?"""
     return eng.profile_query("persist_launches")[1] > 0 or eng.S <= 8
@@ -295,8 +334,11 @@ def main():
         else:
             total = 1.0
         if rank == 0:
-            print(json.dumps({"dry_launch": True, "n_gpus": world, "launcher": os.environ.get("TORCHELASTIC_RUN_ID") is not None or world > 1,
-                              "allreduce_check": total, "expected": world * (world + 1) / 2.0}))
+            line = {"dry_launch": True, "n_gpus": world, "launcher": os.environ.get("TORCHELASTIC_RUN_ID") is not None or world > 1,
+                    "allreduce_check": total, "expected": world * (world + 1) / 2.0}
+            if world > 1:                             # the keys every real N > 1 line carries (values: placeholders of a dry run)
+                line.update(multi_gpu_summary(0.0, world, {"value": None, "unit": "frames/s", "ms_per_step": None, "streams": 8, "steps": 0}, None))
+            print(json.dumps(line))
         return
     dist = None
     torch.cuda.set_device(local_rank)
@@ -342,6 +384,32 @@ def main():
     eng = make_engine(S)
     feats, odiff = make_inputs(S, 1234 + rank, "cuda")
     nchunk = feats.shape[0]
+    same_load = None
+    if world > 1:
+        # the same per-GPU load on ONE GPU, no collective: every rank on its own GPU, before the library's communicator exists
+        with torch.cuda.stream(stream):
+            o_sl = torch.empty(T_BPTT * S, R_DIM, device="cuda"); i_sl = torch.empty(T_BPTT * S, I_DIM, device="cuda")
+
+            def step_sl(i):
+                c = i % nchunk
+                if c == 0:
+                    eng.reset(np.ones(S, np.int32))
+                eng.propagate(feats[c], o_sl); eng.backpropagate(feats[c], odiff[c], i_sl, MOMENTUM, 2); eng.update(LR)
+            for i in range(20):
+                step_sl(i)
+            n_sl = 200
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(20, 20 + n_sl):
+                step_sl(i)
+            torch.cuda.synchronize()
+            dt_sl = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+            dist.all_reduce(dt_sl, op=dist.ReduceOp.MAX)
+            dt_sl = float(dt_sl.item())
+        same_load = {"value": n_sl * T_BPTT * S / dt_sl, "unit": "frames/s", "ms_per_step": dt_sl / n_sl * 1e3, "streams": S, "steps": n_sl,
+                     "path": "single-GPU step (fused gradient + momentum + Update, no gradient blob, no collective); slowest of the %d ranks" % world}
+        eng.close()
+        eng = make_engine(S)                         # (fresh parameters and state for the run proper: identical on all ranks)
     out = torch.empty(T_BPTT * S, R_DIM, device="cuda")
     in_diff = torch.empty(T_BPTT * S, I_DIM, device="cuda")
     # N>1: one all-reduce (sum, fp32) of the 8.73 MB gradient blob per minibatch, issued by libklstm.so itself (RCCL); a run
@@ -594,6 +662,19 @@ def main():
                                "fold": fold_names[mode]}
                 es.close()
 
+    # ---- the other BASELINE.json configurations and the Kaldi-side adapter as secondary legs of the driver-timed line
+    legs, adapter = {}, None
+    if world == 1 and not args.no_extras and args.config == "c2" and S == 4:
+        import bench_configs
+        for tag, st_ in (("c4", 200), ("c5", 1000)):          # (run_c5 times steps // 5 minibatches)
+            la = argparse.Namespace(steps=st_, warmup=20, min_seconds=0.0, option=[], leg=True, no_cpu_baseline=True, cpu_seconds=0.0)
+            try:
+                legs[tag] = bench_configs.RUN[tag](la, k)
+            except Exception as ex:
+                legs[tag] = {"error": str(ex)}
+        torch.cuda.synchronize()
+        adapter = kaldi_adapter_leg(S)
+
     frames_per_step = T_BPTT * S * world
     value = nsteps_total * frames_per_step / dt_total
     ms_per_step = dt_total / nsteps_total * 1e3
@@ -648,7 +729,10 @@ def main():
                                    % (pmc.get("streams_per_gpu") if pmc else "?", pmc.get("chain") if pmc else "?", S,
                                       "the persistent chain" if dom.endswith("_persist") else "launch-per-step kernels")),
                 "avg_us": kern[dom]["avg_us"], "us_per_recurrence_step": per_step_us,
-                "alg_bytes_per_launch": a_bytes, "alg_flops_per_launch": a_flops,
+                # one launch of a persistent kernel advances all T recurrence steps of its direction
+                "alg_bytes_per_recurrence_step": a_bytes, "alg_flops_per_recurrence_step": a_flops,
+                "alg_bytes_per_launch": a_bytes * (T_BPTT if dom.endswith("_persist") else 1),
+                "alg_flops_per_launch": a_flops * (T_BPTT if dom.endswith("_persist") else 1),
                 "mfma_tflops": tflops, "mfma_frac": tflops / PEAK_F32_MFMA_TF, "hbm_gbs": gbs, "hbm_frac": gbs / (PEAK_HBM_TBS * 1e3),
                 "mfma_busy_frac_pmc": mfma_busy,
                 # SURVEY 8(d) whole-path figures on ms_per_step (weights resident within a chunk)
@@ -700,6 +784,12 @@ def main():
             res["ragged"] = ragged
         if s8:
             res["s8_per_gpu"] = s8
+        for tag, leg in legs.items():                  # BASELINE.json configs[3] / configs[4], per-GPU shard on this GPU (bench.py --config c4 | c5)
+            res[tag] = leg
+        if adapter:
+            res["kaldi_adapter"] = adapter
+        if world > 1:
+            res.update(multi_gpu_summary(value, world, same_load, res.get("allreduce_us")))
         if strict:
             # the headline workload with the fold product on fp32 operands (every product of the path then is an fp32 MFMA) and on
             # three bf16 planes (fp32 range, matrix cores): `value` itself runs what config.arithmetic.fold says

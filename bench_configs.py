@@ -108,7 +108,7 @@ def _apply_options(engines, args):
 def _engine_kernels(engines, step, base, nprof=10):
     names = ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj", "k_gates_fold", "k_gemm_rbatch",
              "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step", "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx",
-             "k_fwd_persist", "k_bwd_persist", "k_fwd_persist_ms", "k_fold_ms", "k_bwd_persist_xl", "k_gemm_dr", "k_reduce_dr", "k_gemm_indiff",
+             "k_fwd_persist", "k_bwd_persist", "k_fwd_persist_ms", "k_fwd_persist_xl", "k_fold_ms", "k_bwd_persist_xl", "k_gemm_dr", "k_reduce_dr", "k_gemm_indiff",
              "k_reduce_indiff", "k_grads", "k_grads_update", "k_update_repack", "k_pack",
              "k_apply_momentum")
     for e in engines:
@@ -279,6 +279,12 @@ def run_c4(args, k):
         dte, ne, _ = _timed(step, 10, args.steps, min(1.0, args.min_seconds))
         ms_eager = dte / ne * 1e3
     graphed_used = graphed and lazy
+    if getattr(args, "leg", False):                    # (a secondary leg of the default bench line: the timed steps only)
+        for e in engines:
+            e.close()
+        fl = lstm_flops_per_frame(I, C, R) + lstm_flops_per_frame(R, C, R) + 6 * NPDF * R
+        return {"value": T * S / (ms * 1e-3), "unit": "frames/s", "ms_per_step": ms, "steps": n, "dtype": "f32",
+                "mfma_frac": fl * T * S / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF}
     kern = _engine_kernels(engines, step, args.warmup + n)
     shard = None
     if fused:
@@ -363,6 +369,12 @@ def run_c5(args, k):
         net.train_step(feats[c], None, None, MOMENTUM, LR, reset_flags=ones if c == 0 else None)
     dt, n, dt_first = _timed(step, args.warmup, max(20, args.steps // 5), args.min_seconds)
     ms = dt / n * 1e3
+    if getattr(args, "leg", False):
+        for e in engines:
+            e.close()
+        fl = sum(lstm_flops_per_frame(dims_in[l], C, R) for l in range(NL))
+        return {"value": T * S / (ms * 1e-3), "unit": "frames/s", "ms_per_step": ms, "steps": n, "dtype": "bf16",
+                "mfma_frac": fl * T * S / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TF}
     kern = _engine_kernels(engines, step, args.warmup + n)
     shard = None
     if fused:                                          # (as in run_c4: the path a rank of the 8-GPU run takes, minus the wire)
@@ -381,9 +393,8 @@ def run_c5(args, k):
     # the two chain launches: the reference's recurrent products of the T S frames one launch advances -- forward r(t-1) W_gifo_r^T (:275) and
     # m(t) W_r_m^T (:312); backward dgifo(t+1) W_gifo_r (:391) and d_r(t) W_r_m (:408, the part that is not the batched P)
     chain_fl = float(T * S) * (2 * 4 * C * R + 2 * R * C)
-    roof["dominant_kernel"] = _dominant_kernel(kern, {"k_fwd_persist_ms": chain_fl, "k_bwd_persist_xl": chain_fl}, PEAK_BF16_MFMA_TF,
-                                               "r[0-9][0-9]c5_rocprofv3_kernel_stats.csv",
-                                               {"k_fwd_persist_ms": ("k_fwd_persist_xl", "k_fwd_persist_ms"), "k_bwd_persist_xl": ("k_bwd_persist_xl",)})
+    roof["dominant_kernel"] = _dominant_kernel(kern, {"k_fwd_persist_xl": chain_fl, "k_fwd_persist_ms": chain_fl, "k_bwd_persist_xl": chain_fl},
+                                               PEAK_BF16_MFMA_TF, "r[0-9][0-9]c5_rocprofv3_kernel_stats.csv", C5_ROCPROF_NAMES)
     return {"metric": "frames/sec fwd+BPTT+update, 3x LstmProjectedStreams cell 1024 / proj 512, bf16, per-GPU shard",
             "value": T * S / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1, "steps": n, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -394,5 +405,10 @@ def run_c5(args, k):
                        "streams_per_gpu": S, "frames_per_step": T * S},
             "roofline": roof, "multi_gpu_shard_path": shard, "kernels": kern}
 
+
+# engine probe -> substrings of the rocprofv3 kernel names it covers (round 4's lines called the per-XCD forward launch by the
+# name of the launcher it went through, k_fwd_persist_ms)
+C5_ROCPROF_NAMES = {"k_fwd_persist_ms": ("k_fwd_persist_xl", "k_fwd_persist_ms"), "k_fwd_persist_xl": ("k_fwd_persist_xl",),
+                    "k_bwd_persist_xl": ("k_bwd_persist_xl",)}
 
 RUN = {"c1": run_c1, "c4": run_c4, "c5": run_c5}

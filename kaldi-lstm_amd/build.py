@@ -86,6 +86,21 @@ def build(force=False, verbose=False):
     return LIB
 
 
+ADAPTER_SRC = os.path.join(HERE, "..", "tools", "kaldi_adapter_bench.cpp")
+ADAPTER_EXE = os.path.join(HERE, "..", "tools", "kaldi_adapter_bench")
+
+
+def build_adapter_bench():
+    """tools/kaldi_adapter_bench: the C++ component of include/klstm_component.hpp as the Kaldi shim drives it, timed (bench.py's
+    `kaldi_adapter` leg).  Plain g++ against the C-ABI: the mirror needs no HIP headers."""
+    cxx = shutil.which("g++") or shutil.which("c++") or "/opt/rocm/bin/hipcc"
+    tmp = ADAPTER_EXE + ".tmp.%d" % os.getpid()
+    subprocess.check_call([cxx, "-std=c++17", "-O2", "-I" + os.path.join(HERE, "..", "include"), ADAPTER_SRC, "-L" + HERE, "-lklstm",
+                           "-Wl,-rpath,$ORIGIN/../kaldi-lstm_amd", "-o", tmp])
+    os.replace(tmp, ADAPTER_EXE)
+    return ADAPTER_EXE
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
     print(LIB)

@@ -12,6 +12,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <set>
@@ -139,8 +140,12 @@ struct klstm_engine {
   long clean_run = 0;                    // persistent minibatches since the last give-up
   long n_giveups = 0, n_replayed = 0, n_dropped = 0;
   bool replaying = false;
-  struct FwdMark { unsigned seq; int sp_before; };
-  FwdMark marks[8]; int nmarks = 0;       // the last persistent forward launches: which state buffer each started from
+  // every persistent forward launch nobody has looked at yet: which state buffer it started from and the Reset flags the caller issued
+  // between the forward pass before it and this one (empty: none).  Pruned when a host synchronisation finds the status words clean;
+  // a caller that never looks is made to every MARKS_MAX minibatches (klstm_propagate).
+  struct FwdMark { unsigned seq; int sp_before; std::vector<int> resets; };
+  std::deque<FwdMark> marks;
+  static constexpr size_t MARKS_MAX = 4096;
   MbRec rec;
   std::vector<int> resets;      // Reset flags since the last forward pass was enqueued (applied again when the state goes back a buffer)
   int fold_mode = 2;            // fold product: 0 fp32 MFMA, 1 three bf16 planes, 2 two fp16 planes (option "fold_bf16x3")
@@ -392,10 +397,26 @@ static klstm_status recover(klstm_engine *e, const unsigned (&w)[16]) {
   if (e->pk[0]) e->pk_stale = 15;
   e->bwd_persist = false; e->bwd_xl = false;
   drop_graphs(e);
-  const int sp_now = e->sp;
-  for (int i = 0; i < e->nmarks; i++)
-    if (!fseq || e->marks[i].seq >= fseq) { e->sp = e->marks[i].sp_before; break; }
-  e->nmarks = 0;
+  // The carried state goes back to the buffer the FIRST affected forward launch started from (intact: every launch behind the failure
+  // did nothing).  Decided by the launch ordinal, not by which of the two buffers is current: the host may be any number of
+  // minibatches ahead.  Resets the caller issued after that launch was enqueued -- recorded with the later marks, or still pending
+  // since the last forward pass -- went to buffers that are abandoned now: they are applied again to the restored one.  (Resets
+  // issued BEFORE the first affected launch are in its buffer already.)
+  int i0 = -1;
+  for (size_t i = 0; i < e->marks.size(); i++)
+    if (!fseq || e->marks[i].seq >= fseq) { i0 = (int)i; break; }
+  std::vector<int> again;
+  if (i0 >= 0) {
+    e->sp = e->marks[i0].sp_before;
+    auto merge = [&](const std::vector<int> &f) {
+      if (f.empty()) return;
+      if (again.empty()) again.assign(f.size(), 0);
+      for (size_t s = 0; s < f.size() && s < again.size(); s++) if (f[s] == 1) again[s] = 1;
+    };
+    for (size_t j = (size_t)i0 + 1; j < e->marks.size(); j++) merge(e->marks[j].resets);
+    merge(e->resets);
+  }
+  e->marks.clear();
   const MbRec r = e->rec;
   e->rec = MbRec();
   // A minibatch whose gradient all-reduce is already enqueued cannot be run again by ONE rank (the collective is everybody's): its
@@ -404,10 +425,8 @@ static klstm_status recover(klstm_engine *e, const unsigned (&w)[16]) {
   const bool re_fwd = !r.have_ar && r.have_fwd && r.fwd_seq && fseq && r.fwd_seq >= fseq;
   const bool re_bwd = !r.have_ar && r.have_bwd && (re_fwd || (r.bwd_seq && fseq && r.bwd_seq >= fseq));
   const bool re_upd = r.have_upd && re_bwd;
-  if (e->sp != sp_now && !(re_fwd && e->sp == r.sp_before)) {
-    // the state went back further than this minibatch's forward pass (or that pass cannot be run again): Resets the caller has
-    // issued since were applied to the abandoned buffer
-    const klstm_status rs = apply_reset(e, e->resets);
+  if (!again.empty()) {
+    const klstm_status rs = apply_reset(e, again);
     if (rs != KLSTM_OK) return rs;
   }
   const unsigned affected = fseq && e->pseq >= fseq ? e->pseq - fseq + 1 : 1;
@@ -449,7 +468,7 @@ static klstm_status check_persist(klstm_engine *e) {
     return fail(KLSTM_ERR_HIP, "one-shot all-reduce timed out (phase %x): a peer did not arrive; the gradient blob was NOT reduced and this "
                 "rank's Update was NOT applied -- replicas may have diverged, stop the run (or use klstm_allreduce_grads)", w[9]);
   }
-  if (w[2] == 0 && w[6] == 0) { e->nmarks = 0; return KLSTM_OK; }     // (everything enqueued so far has run and is good)
+  if (w[2] == 0 && w[6] == 0) { e->marks.clear(); return KLSTM_OK; }     // (everything enqueued so far has run and is good)
   return recover(e, w);
 }
 // synchronise + look; KLSTM_OK also when a give-up was found and answered
@@ -816,7 +835,8 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
   if (e->fwd_ms) {
     // many streams, bf16 operands: all T steps of the folded recurrence in one launch, r(1..T) = m(1..T) W_r_m^T (:312) -- rr rows,
     // the output rows (:328), the carried r (:331) -- riding along
-    HIPCHK(launch_fwd_persist_ms(d, p, e->wrm_l, out, out_stride, e->gran_ms, e->pctrl, e->popt, st, probe(e, "k_fwd_persist_ms")));
+    HIPCHK(launch_fwd_persist_ms(d, p, e->wrm_l, out, out_stride, e->gran_ms, e->pctrl, e->popt, st,
+                                 probe(e, persist_xl_supported(d, e->popt) ? "k_fwd_persist_xl" : "k_fwd_persist_ms")));   // (the kernel's own name)
     return KLSTM_OK;
   }
   if (e->fwd_folded) {
@@ -831,7 +851,10 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
       for (int t = 2; t <= T; t++)
         HIPCHK(launch_gates_step(d, p, t, fx, in, in_stride, st, probe(e, "k_gates_fold"), true));
     }
-    HIPCHK(launch_rbatch(d, p, out, out_stride, e->ws, st, probe(e, "k_gemm_rbatch"), probe(e, "k_reduce_rbatch")));
+    // (behind a persistent launch the product that writes `out` and the carried r(T) -- the OTHER state buffer, the one a failed
+    //  minibatch's successor is run again from -- looks at the status words like every other kernel that must not outrun a give-up)
+    HIPCHK(launch_rbatch(d, p, out, out_stride, e->ws, st, probe(e, "k_gemm_rbatch"), probe(e, "k_reduce_rbatch"),
+                         e->fwd_persist ? e->pctrl : nullptr));
     return KLSTM_OK;
   }
   for (int t = 1; t <= T; t++) {
@@ -980,8 +1003,7 @@ static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int
   if (e->fwd_persist || e->fwd_ms) {                  // (counted here, not inside the launch sequence: a graph replay is a launch too)
     e->pseq++;
     e->persist_dirty = true;
-    if (e->nmarks == 8) { for (int i = 1; i < 8; i++) e->marks[i - 1] = e->marks[i]; e->nmarks = 7; }
-    e->marks[e->nmarks++] = klstm_engine::FwdMark{e->pseq, e->sp};
+    e->marks.push_back(klstm_engine::FwdMark{e->pseq, e->sp, e->resets});   // (the Resets since the forward pass before this one)
   }
   e->sp ^= 1;                                         // c(T), r(T) were written to the other buffer: it is the carried state now
   e->resets.clear();
@@ -1031,15 +1053,22 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   if (rows < 0 || rows % e->S != 0)
     return fail(KLSTM_ERR_SHAPE, "klstm_propagate: rows (%d) %% num_stream (%d) != 0", rows, e->S);
   if (rows == 0) {          // T = 0: the reference's loops simply do not run (:261, :328 with zero rows); state is unchanged
+    e->rec = MbRec();       // (a new minibatch all the same)
     e->T_fwd = 0;
     e->T_bwd = -1;
     return KLSTM_OK;
   }
   HIPCHK(hipSetDevice(e->device));
-  e->rec = MbRec();                                   // a new minibatch begins: the previous one's buffers are the caller's again
-  { klstm_status ps = poll_persist(e); if (ps != KLSTM_OK) return ps; }
-  { klstm_status gs = flush_grads(e); if (gs != KLSTM_OK) return gs; }   // (deferred gradient products read the planes of the last minibatch)
   if (in_stride < e->I || out_stride < e->R) return fail(KLSTM_ERR_ARG, "klstm_propagate: stride smaller than row width");
+  // (arguments are checked before anything is touched: a rejected call leaves the record of the current minibatch alone)
+  // A new minibatch begins: the previous one's buffers are the caller's again -- in Kaldi `in` IS the previous minibatch's buffer,
+  // refilled -- so a give-up of the previous minibatch that the host only hears of here cannot be run again with the arguments it
+  // came with: it is dropped and counted (klstm.h "persist"; "persist_verify" = 1 answers inside the call that launched instead).
+  e->rec = MbRec();
+  { klstm_status ps = poll_persist(e); if (ps != KLSTM_OK) return ps; }
+  // (a caller that has not looked for MARKS_MAX persistent minibatches: one host wait, so that the list of unverified launches stays bounded)
+  if (e->marks.size() >= klstm_engine::MARKS_MAX) { e->persist_dirty = true; klstm_status ss = settle(e); if (ss != KLSTM_OK) return ss; }
+  { klstm_status gs = flush_grads(e); if (gs != KLSTM_OK) return gs; }   // (deferred gradient products read the planes of the last minibatch)
   const int sp0 = e->sp;
   klstm_status st = do_propagate(e, in, rows, in_stride, out, out_stride);
   if (st != KLSTM_OK) return st;

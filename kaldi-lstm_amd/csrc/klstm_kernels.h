@@ -114,7 +114,9 @@ hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT,
                        // scratch3 (fold_bf16x3_scratch_bytes) selects the bf16x3 kernel when it supports the shape; pr3 = its split pass
                        // pk_fold zero-filled once by the caller; pack_x = false: launch_pack(.., foldx) already wrote the W_x chunks
 hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_stride, float *ws, hipStream_t st,
-                         LaunchProbe pr = {}, LaunchProbe pr2 = {});   // ws: split-K workspace (gemm_splitk_plan(T*S, R, C) slices)
+                         LaunchProbe pr = {}, LaunchProbe pr2 = {}, const unsigned *guard = nullptr);
+                         // ws: split-K workspace (gemm_splitk_plan(T*S, R, C) slices); guard: the engine's control words -- behind a
+                         // persistent launch that gave up ([2] | [6] != 0) the kernel that writes out / the carried r does nothing
 hipError_t launch_dmf_step(const Dims &d, const BwdPtrs &p, int t, const float *P, hipStream_t st, LaunchProbe pr = {});
 //   launch_bwd_tail d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r and in_diff = dgifo(1..T) W_gifo_x, one split-K launch pair
 size_t bwd_tail_ws_floats(const Dims &d);
@@ -148,7 +150,8 @@ int gemm_splitk_plan(int M, int N, int K, int *klen);
 hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, const float *A, int lda, const float *B,
                               int ldb, float beta, float *Cm, int ldc, const float *bias, float *ws, int ks, int klen,
                               hipStream_t st, const float *add = nullptr, int add_ld = 0, LaunchProbe pr = {},
-                              LaunchProbe pr2 = {}, float *C2 = nullptr, int ldc2 = 0, float *C3 = nullptr, int tail0 = 0);
+                              LaunchProbe pr2 = {}, float *C2 = nullptr, int ldc2 = 0, float *C3 = nullptr, int tail0 = 0,
+                              const unsigned *guard = nullptr);
                               // add: C = beta*C + add + sum of slices;  C2 / C3: mirrors of the result (second copy; rows >= tail0)
 
 // All seven gradient accumulations (...streams.h:468-487) in ONE launch: three A^T*B products

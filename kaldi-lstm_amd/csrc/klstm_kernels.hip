@@ -1509,6 +1509,7 @@ struct GemmJob {
   int s3mode;                                // plane format (klstm_math.h split_store4)
   unsigned short *s3; long s3pl; int s3t;   // the bf16 / fp16 planes of the UPDATED P (s3t = 0: P's layout, ld = ldc; 1: Ct's layout, ld = ldct)
   int coal;               // 1: Cm = beta*Cm + A*B through the same coalesced 16-byte epilogue without P (N, ldc % 4 == 0, aligned, no bias)
+  const unsigned *guard = nullptr;   // k_gemm only: the engine's control words; a persistent launch in front gave up ([2] | [6]) -> write nothing
 };
 
 // One operand tile = GT x GK elements = 2 x (8 floats per thread).  Operand stored [X x K] (TA=false: 8 consecutive k
@@ -1829,6 +1830,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmJob g) {
   const int cpx = (nbt + 7) >> 3;
   const int b = (int)(blockIdx.x & 7) * cpx + (int)(blockIdx.x >> 3);
   if (b >= nbt) return;
+  if (g.guard && (g.guard[2] | g.guard[6])) return;          // (grid-uniform, before any barrier)
   gemm_tile<TA, TB>(g, (b / ntn) * GT, (b % ntn) * GT, As, Bs);
 }
 
@@ -1857,8 +1859,10 @@ struct ReduceArgs {
   const float *add; int add_ld;       // C = beta*C + add + bias + sum of slices
   float *C2; int ldc2;                // mirrors, as in GemmJob
   float *C3; int tail0;
+  const unsigned *guard = nullptr;    // as in GemmJob
 };
 __global__ __launch_bounds__(256) void k_splitk_reduce(ReduceArgs a) {
+  if (a.guard && (a.guard[2] | a.guard[6])) return;
   const long total = (long)a.M * a.N;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int m = (int)(i / a.N), n = (int)(i - (long)m * a.N);
@@ -3134,17 +3138,18 @@ hipError_t launch_fold(const Dims &d, const float *param_blob, const float *wmT,
 
 // r(1..T) = m(1..T) W_r_m^T (:312) for all frames at once -> rr rows, out rows (:328), last block -> prev_r (:331)
 hipError_t launch_rbatch(const Dims &d, const FwdPtrs &p, float *out, int out_stride, float *ws, hipStream_t st,
-                         LaunchProbe pr, LaunchProbe pr2) {
+                         LaunchProbe pr, LaunchProbe pr2, const unsigned *guard) {
   const int M = d.T * d.S;
   int kl = 0;
   const int ks = gemm_splitk_plan(M, d.R, d.C, &kl);
   if (ks > 1 && ws)
     return launch_gemm_splitk(false, true, M, d.R, d.C, p.mm + (size_t)d.S * d.C, d.C, p.wm, d.C, 0.f, p.rr + (size_t)d.S * d.R,
-                              d.R, nullptr, ws, ks, kl, st, nullptr, 0, pr, pr2, out, out_stride, p.next_r, M - d.S);
+                              d.R, nullptr, ws, ks, kl, st, nullptr, 0, pr, pr2, out, out_stride, p.next_r, M - d.S, guard);
   GemmJob g = make_job(false, true, M, d.R, d.C, p.mm + (size_t)d.S * d.C, d.C, p.wm, d.C, 0.f,
                        p.rr + (size_t)d.S * d.R, d.R, nullptr);
   g.C2 = out; g.ldc2 = out_stride;
   g.C3 = p.next_r; g.tail0 = M - d.S;
+  g.guard = guard;
   const dim3 grid(cdiv(cdiv(d.R, GT) * cdiv(M, GT), 8) * 8), block(256);
   KLAUNCH((k_gemm<false, true>), grid, block, st, pr, g);
 }
@@ -3282,7 +3287,7 @@ int gemm_splitk_plan(int M, int N, int K, int *klen) {
 hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, const float *A, int lda, const float *B,
                               int ldb, float beta, float *Cm, int ldc, const float *bias, float *ws, int ks, int klen,
                               hipStream_t st, const float *add, int add_ld, LaunchProbe pr, LaunchProbe pr2, float *C2,
-                              int ldc2, float *C3, int tail0) {
+                              int ldc2, float *C3, int tail0, const unsigned *guard) {
   const GemmJob g = make_job(transA, transB, M, N, K, A, lda, B, ldb, 0.f, nullptr, N, nullptr);
   const dim3 grid(cdiv(N, GT), cdiv(M, GT), ks), block(256);
   auto first = [&]() -> hipError_t {
@@ -3295,7 +3300,7 @@ hipError_t launch_gemm_splitk(bool transA, bool transB, int M, int N, int K, con
   if (err != hipSuccess) return err;
   ReduceArgs r;
   r.ws = ws; r.ks = ks; r.M = M; r.N = N; r.beta = beta; r.Cm = Cm; r.ldc = ldc; r.bias = bias; r.add = add; r.add_ld = add_ld;
-  r.C2 = C2; r.ldc2 = ldc2; r.C3 = C3; r.tail0 = tail0;
+  r.C2 = C2; r.ldc2 = ldc2; r.C3 = C3; r.tail0 = tail0; r.guard = guard;
   const long nb = ((long)M * N + 255) / 256;
   KLAUNCH(k_splitk_reduce, dim3((unsigned)(nb > 2048 ? 2048 : nb)), block, st, pr2, r);
 }

@@ -25,3 +25,8 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    from tests import margins
+    margins.dump(os.path.join(ROOT, "gpurun_out", "parity_margins.json"))

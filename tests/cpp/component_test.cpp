@@ -252,8 +252,70 @@ int main(int argc, char **argv) {
       c->Write(f, true);
       std::cout << "OK\n" << c->Info() << "\n";
       if (comm) klstm_comm_destroy(comm);
+    } else if (mode == "run_gpu_full") {
+      // run_gpu_full <model> <x_raw> <od_raw> <flags_raw> <rows_per_minibatch> <nmb> <lr> <momentum> <out_prefix>
+      // The component exactly as the Kaldi shim of INTEGRATION.md 2 constructs and drives it, at ANY shape (the tests run the
+      // benchmarked one: 40/800/512, 4 streams x 20 frames, and <LstmProjected> over a 1000-frame utterance): SetUpdateFollows(true),
+      // persist_verify at the mirror's default, pitched device matrices, the trainer's call order per minibatch
+      // (bd-nnet-train-lstm-streams.cc:209-228: Reset(new_utt_flags) EVERY minibatch, Propagate, Backpropagate = BackpropagateFnc +
+      // Update).  Every minibatch has its own rows; out / in_diff of every minibatch are written out, then the parameters, the
+      // momentum buffers, the carried state and the engine's persistent-launch counters.
+      std::unique_ptr<LstmProjectedStreams> c(load_model(argv[2]));
+      const std::vector<float> x = read_raw(argv[3]), od = read_raw(argv[4]), fl = read_raw(argv[5]);
+      const int rows = atoi(argv[6]), nmb = atoi(argv[7]);
+      NnetTrainOptions opts;
+      opts.learn_rate = (float)atof(argv[8]);
+      opts.momentum = (float)atof(argv[9]);
+      const std::string prefix = argv[10];
+      c->SetTrainOptions(opts);
+      c->SetUpdateFollows(true);                               // the shim's constructor
+      const int I = c->InputDim(), R = c->OutputDim(), S = c->NumStream();
+      const bool streams = std::string(c->Marker()) == "<LstmProjectedStreams>";
+      if ((long)x.size() != (long)nmb * rows * I || (long)od.size() != (long)nmb * rows * R || (streams && (long)fl.size() != (long)nmb * S))
+        KLSTM_ERR("run_gpu_full: input sizes do not match " << nmb << " minibatches of " << rows << " rows");
+      const int xs = I + 4, os = R + 8, ds = R + 4, is = I + 12;       // CuMatrix rows are pitched (cu-matrix.cc:67-73)
+      float *dx, *dout, *dod, *did;
+      HIPOK(hipMalloc(&dx, (size_t)nmb * rows * xs * 4)); HIPOK(hipMalloc(&dout, (size_t)rows * os * 4));
+      HIPOK(hipMalloc(&dod, (size_t)nmb * rows * ds * 4)); HIPOK(hipMalloc(&did, (size_t)rows * is * 4));
+      HIPOK(hipMemcpy2D(dx, xs * 4, x.data(), I * 4, I * 4, (size_t)nmb * rows, hipMemcpyHostToDevice));
+      HIPOK(hipMemcpy2D(dod, ds * 4, od.data(), R * 4, R * 4, (size_t)nmb * rows, hipMemcpyHostToDevice));
+      std::vector<float> hout((size_t)nmb * rows * R), hid((size_t)nmb * rows * I);
+      for (int mb = 0; mb < nmb; mb++) {
+        MatrixView in(dx + (size_t)mb * rows * xs, rows, I, xs), out(dout, rows, R, os);
+        MatrixView out_diff(dod + (size_t)mb * rows * ds, rows, R, ds), in_diff(did, rows, I, is);
+        if (streams) {
+          std::vector<int> flags(S);
+          for (int s = 0; s < S; s++) flags[s] = fl[(size_t)mb * S + s] != 0.f;
+          c->Reset(flags);                                       // every minibatch, like nnet.Reset(new_utt_flags) (:209)
+        }
+        c->PropagateFnc(in, &out);
+        c->BackpropagateFnc(in, out, out_diff, &in_diff);
+        c->Update(in, out_diff);
+        // (what the trainer does next: Xent::EvalMasked of the following minibatch copies scalars to the host, nnet-loss.cc:110-141)
+        HIPOK(hipMemcpy2D(hout.data() + (size_t)mb * rows * R, R * 4, dout, os * 4, R * 4, rows, hipMemcpyDeviceToHost));
+        HIPOK(hipMemcpy2D(hid.data() + (size_t)mb * rows * I, I * 4, did, is * 4, I * 4, rows, hipMemcpyDeviceToHost));
+      }
+      write_raw(prefix + ".out", hout.data(), hout.size());
+      write_raw(prefix + ".in_diff", hid.data(), hid.size());
+      std::vector<float> p;
+      c->GetParams(&p);
+      write_raw(prefix + ".params", p.data(), p.size());
+      std::vector<float> corr(p.size()), sc((size_t)S * c->CellDim()), sr((size_t)S * R);
+      if (klstm_get_corr_host(c->Engine(), corr.data()) != KLSTM_OK) KLSTM_ERR("klstm_get_corr_host: " << klstm_last_error());
+      if (klstm_get_state_host(c->Engine(), sc.data(), sr.data()) != KLSTM_OK) KLSTM_ERR("klstm_get_state_host: " << klstm_last_error());
+      write_raw(prefix + ".corr", corr.data(), corr.size());
+      write_raw(prefix + ".state_c", sc.data(), sc.size());
+      write_raw(prefix + ".state_r", sr.data(), sr.size());
+      std::cout << "OK";
+      for (const char *key : {"persist_launches", "persist_giveups", "persist_replayed", "persist_dropped", "fp16_redo"}) {
+        double us = 0; long n = 0;
+        if (klstm_profile_query(c->Engine(), key, &us, &n) != KLSTM_OK) KLSTM_ERR("klstm_profile_query(" << key << "): " << klstm_last_error());
+        std::cout << " " << key << "=" << n;
+      }
+      std::cout << "\n";
+      HIPOK(hipFree(dx)); HIPOK(hipFree(dout)); HIPOK(hipFree(dod)); HIPOK(hipFree(did));
     } else {
-      std::cerr << "usage: component_test init_write|dump_params|convert|bad_proto|run_gpu|run_gpu_host ...\n";
+      std::cerr << "usage: component_test init_write|dump_params|convert|bad_proto|run_gpu|run_gpu_host|run_gpu_full ...\n";
       return 2;
     }
     return 0;

@@ -61,9 +61,9 @@ def test_committed_bench_lines_agree_with_their_rocprof_tables():
     assert lines
     kern = json.load(open(lines[-1]))["kernels"]
     fl = 640.0 * (2 * 4 * 1024 * 512 + 2 * 512 * 1024)
-    d = bc._dominant_kernel(kern, {"k_fwd_persist_ms": fl, "k_bwd_persist_xl": fl}, bc.PEAK_BF16_MFMA_TF, "r[0-9][0-9]c5_rocprofv3_kernel_stats.csv",
-                            {"k_fwd_persist_ms": ("k_fwd_persist_xl", "k_fwd_persist_ms"), "k_bwd_persist_xl": ("k_bwd_persist_xl",)})
-    assert d["kernel"] in ("k_fwd_persist_ms", "k_bwd_persist_xl") and d["rocprof"] is not None
+    d = bc._dominant_kernel(kern, {"k_fwd_persist_xl": fl, "k_fwd_persist_ms": fl, "k_bwd_persist_xl": fl}, bc.PEAK_BF16_MFMA_TF,
+                            "r[0-9][0-9]c5_rocprofv3_kernel_stats.csv", bc.C5_ROCPROF_NAMES)
+    assert d["kernel"] in ("k_fwd_persist_xl", "k_fwd_persist_ms", "k_bwd_persist_xl") and d["rocprof"] is not None
     assert 0.9 <= d["frac_rocprof"] / d["frac"] <= 1.02, d
     head = json.load(open(sorted(glob.glob(os.path.join(prof, "r[0-9][0-9]_bench_n1.json")))[-1]))
     table = {r["Name"]: float(r["AverageNs"]) * 1e-3 for r in csv.DictReader(open(sorted(glob.glob(os.path.join(prof, "r[0-9][0-9]_rocprofv3_kernel_stats.csv")))[-1]))}

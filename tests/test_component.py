@@ -9,6 +9,7 @@ import pytest
 
 from oracle.oracle import Oracle, make_params
 from tests import kaldi_fmt
+from tests.margins import bound
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "component_test")
@@ -224,6 +225,58 @@ def test_component_train_steps_gpu(tmp_path, marker, S, mode, monkeypatch):
     # moments of MomentStatistics -- InfoGradient was taken between the last BackpropagateFnc and its Update, Info after it
     _check_moment_report((tmp_path / "res.gradinfo").read_text(), corr_before_update, I, C, R, "_corr_")
     _check_moment_report(res.stdout.split("OK", 1)[1], o.get_params(), I, C, R, "_")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("marker,S,T,nmb", [("<LstmProjectedStreams>", 4, 20, 5), ("<LstmProjected>", 1, 1000, 2)])
+def test_component_at_the_benchmarked_shape_gpu(tmp_path, marker, S, T, nmb):
+    """The Kaldi-side component at the shape bench.py measures (BASELINE.json configs[1]: 40 -> 800 / 512, NumStream 4, T = 20;
+    and configs[0]: <LstmProjected> over 1000-frame utterances), constructed and driven exactly as the shim of INTEGRATION.md 2
+    does it: SetUpdateFollows(true), persist_verify at the mirror's default (1), pitched device matrices, and per minibatch the
+    trainer's call order -- Reset(new_utt_flags), PropagateFnc, BackpropagateFnc, Update
+    (bd-nnet-train-lstm-streams.cc:209-228; ...streams.h:222, :334-335, :501).  5 chained minibatches (state carried, streams 1
+    and 3 start new utterances at minibatch 2, all of them at minibatch 0), every minibatch's out / in_diff and the final
+    parameters, momentum buffers and carried state against the oracle at the ENGINE tests' bars; klstm_profile_query must show
+    that the persistent launches (the kernels bench.py times) were the ones that ran, and that none gave up."""
+    I, C, R = 40, 800, 512
+    flat = make_params(I, C, R, scale=0.01, seed=31)
+    (tmp_path / "m.nnet").write_bytes(kaldi_fmt.binary_model(flat, I, C, R, S, marker=marker))
+    rng = np.random.RandomState(5)
+    rows = T * S
+    x = rng.randn(nmb, rows, I).astype(np.float32)
+    od = (0.1 * rng.randn(nmb, rows, R)).astype(np.float32)
+    flags = np.zeros((nmb, S), np.float32)
+    flags[0, :] = 1
+    if S > 1:
+        flags[2, 1] = flags[2, 3] = 1
+    x.tofile(tmp_path / "x.raw"); od.tofile(tmp_path / "od.raw"); flags.tofile(tmp_path / "fl.raw")
+    lr, mmt = 1e-5, 0.9
+    res = run("run_gpu_full", tmp_path / "m.nnet", tmp_path / "x.raw", tmp_path / "od.raw", tmp_path / "fl.raw", rows, nmb, lr, mmt,
+              tmp_path / "res")
+    counters = dict(kv.split("=") for kv in res.stdout.split("\n")[0].split()[1:])
+    std = marker == "<LstmProjected>"
+    o = Oracle(I, C, R, S, np.float32); o.set_params(flat)
+    out_g = raw(tmp_path / "res.out").reshape(nmb, rows, R)
+    id_g = raw(tmp_path / "res.in_diff").reshape(nmb, rows, I)
+    for mb in range(nmb):
+        o.reset([1] if std else flags[mb].astype(np.int32))
+        out_o = o.propagate(x[mb])
+        id_o = o.backpropagate(x[mb], od[mb], momentum=mmt)
+        o.update(lr, clip_grad=50.0 if std else 0.0)
+        bound(_relerr(out_g[mb], out_o), 2e-5, "out")
+        bound(_relerr(id_g[mb], id_o), 5e-5, "in_diff")
+    from oracle.oracle import split_blob
+    gc, oc = split_blob(raw(tmp_path / "res.corr"), I, C, R), split_blob(o.get_corr(), I, C, R)
+    gp, op = split_blob(raw(tmp_path / "res.params"), I, C, R), split_blob(o.get_params(), I, C, R)
+    for name in gc:                                  # each of the seven tensors against its own maximum
+        bound(_relerr(gc[name], oc[name]), 5e-5, "corr." + name)
+        bound(_relerr(gp[name], op[name]), 2e-5, "params." + name)
+    st = o.get_state()
+    bound(_relerr(raw(tmp_path / "res.state_c").reshape(S, C), st[:, 4 * C:5 * C]), 2e-5, "state_c")
+    bound(_relerr(raw(tmp_path / "res.state_r").reshape(S, R), st[:, 7 * C:]), 2e-5, "state_r")
+    # the benchmarked kernels ran: one persistent launch per direction and minibatch, none gave up, nothing was run again
+    assert int(counters["persist_launches"]) == 2 * nmb, counters
+    assert counters["persist_giveups"] == "0" and counters["persist_replayed"] == "0" and counters["persist_dropped"] == "0", counters
 
 
 def _pack_utts(utts):

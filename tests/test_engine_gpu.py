@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from oracle.oracle import Oracle, make_params, param_sizes, split_blob
+from tests.margins import bound
 
 pytestmark = pytest.mark.gpu
 
@@ -108,37 +109,34 @@ def check_blob(g, o, tol, C, R, what):
     I = blob_dims(o.size, C, R)
     gs, os_ = split_blob(np.asarray(g), I, C, R), split_blob(np.asarray(o), I, C, R)
     for name in gs:
-        err = relerr(gs[name], os_[name])
-        assert err <= tol, f"{what}.{name}: {err:.3g} > {tol:.3g}"
+        bound(relerr(gs[name], os_[name]), tol, f"{what.split(': ')[-1]}.{name}")
 
 
 def check(recs, tol_act, tol_grad, C, S, T):
     """Per-tensor / per-column-group comparison: every slab column group (G, I, F, O, C, H, M, R forward; DG, DI, DF, DO, DC, DR
     backward) and every one of the seven gradient / parameter tensors is normalised by its own maximum."""
     for ck, rec in enumerate(recs):
-        assert relerr(*rec["out"]) <= tol_act, f"chunk {ck}: out"
+        bound(relerr(*rec["out"]), tol_act, "out")
         Yg, Yo = rec["Y"]
         R = Yg.shape[1] - 7 * C
         fwd_groups = [("G", 0, C), ("I", C, 2 * C), ("F", 2 * C, 3 * C), ("O", 3 * C, 4 * C), ("C", 4 * C, 5 * C),
                       ("H", 5 * C, 6 * C), ("M", 6 * C, 7 * C), ("R", 7 * C, 7 * C + R)]
         # frames 1..T, every column group; block 0 only C and R are defined on the engine side
         for name, lo, hi in fwd_groups:
-            err = relerr(Yg[S:(T + 1) * S, lo:hi], Yo[S:(T + 1) * S, lo:hi])
-            assert err <= tol_act, f"chunk {ck}: Y{name} {err:.3g}"
-        assert relerr(Yg[:S, 4 * C:5 * C], Yo[:S, 4 * C:5 * C]) <= tol_act
-        assert relerr(Yg[:S, 7 * C:], Yo[:S, 7 * C:]) <= tol_act
+            bound(relerr(Yg[S:(T + 1) * S, lo:hi], Yo[S:(T + 1) * S, lo:hi]), tol_act, f"Y{name}")
+        bound(relerr(Yg[:S, 4 * C:5 * C], Yo[:S, 4 * C:5 * C]), tol_act, "Y0.C")
+        bound(relerr(Yg[:S, 7 * C:], Yo[:S, 7 * C:]), tol_act, "Y0.R")
         Dg, Do = rec["D"]
         for name, lo, hi in fwd_groups:
             if name in ("H", "M"):                     # DH / DM are lane-local, never materialised
                 continue
-            err = relerr(Dg[S:(T + 1) * S, lo:hi], Do[S:(T + 1) * S, lo:hi])
-            assert err <= tol_grad, f"chunk {ck}: D{name} {err:.3g}"
+            bound(relerr(Dg[S:(T + 1) * S, lo:hi], Do[S:(T + 1) * S, lo:hi]), tol_grad, f"D{name}")
         if "in_diff" in rec:
-            assert relerr(*rec["in_diff"]) <= tol_grad, f"chunk {ck}: in_diff"
+            bound(relerr(*rec["in_diff"]), tol_grad, "in_diff")
         check_blob(*rec["corr"], tol_grad, C, R, f"chunk {ck}: corr")
         check_blob(*rec["params"], tol_act, C, R, f"chunk {ck}: params")
-        assert relerr(*rec["state_c"]) <= tol_act
-        assert relerr(*rec["state_r"]) <= tol_act
+        bound(relerr(*rec["state_c"]), tol_act, "state_c")
+        bound(relerr(*rec["state_r"]), tol_act, "state_r")
 
 
 @pytest.mark.parametrize("I,C,R,S,T", [
@@ -201,7 +199,7 @@ def test_config_c2_shape_5_chunks():
     lr 1e-5, momentum 0.9 (train_lstm_streams.sh:3-7), 5 chunks checked in full (every slab column group)."""
     I, C, R, S, T = 40, 800, 512, 4, 20
     recs = run_chunks(I, C, R, S, T, nchunks=5, scale=0.01, momentum=0.9, lr=1e-5, od_scale=0.1)
-    check(recs, tol_act=2e-5, tol_grad=2e-4, C=C, S=S, T=T)
+    check(recs, tol_act=2e-5, tol_grad=5e-5, C=C, S=S, T=T)
 
 
 @pytest.mark.parametrize("fold", [0, 1])
@@ -210,9 +208,11 @@ def test_config_c2_50_chunk_drift(fold):
     minibatches of BASELINE.json configs[1] (40/800/512, 4 streams, T = 20, lr 1e-5, momentum 0.9) with carried c/r state
     and 50 Updates, on the engine and on the oracle, each evolving its OWN parameters and state.  The folded chain
     (fold = 1) changes the fp32 rounding of every recurrent step (W_rm = W_gifo_r W_r_m is rounded once), so this is the
-    test that shows whether that drifts.  Per-chunk errors are recorded (gpurun_out/drift_fold<k>.json) and bounded:
-    out / state / parameters 1e-4, in_diff and every gradient tensor 5e-4 of the tensor's own maximum at EVERY chunk, and
-    the mean error of the last 10 chunks may not exceed 4x the mean of chunks 2..11 (no systematic growth)."""
+    test that shows whether that drifts.  Per-chunk errors are recorded (gpurun_out/drift_fold<k>.json) and bounded at
+    <= 10x what the kernels deliver (measured, profiles/r04_drift_fold*.json: out 4.4e-6, state 4.7e-6, in_diff 4.9e-6, the
+    worst gradient tensor 4.3e-6, the worst parameter tensor 2.8e-7): out / state / parameters 4e-5, in_diff and every gradient
+    tensor 5e-5 of the tensor's own maximum at EVERY chunk, and the mean error of the last 10 chunks may not exceed 4x the mean
+    of chunks 2..11 (no systematic growth)."""
     import json
     import os
     I, C, R, S, T, NCH = 40, 800, 512, 4, 20, 50
@@ -247,12 +247,14 @@ def test_config_c2_50_chunk_drift(fold):
     with open(os.path.join("gpurun_out", f"drift_fold{fold}.json"), "w") as fh:
         json.dump({"config": "40/800/512 S=4 T=20, 50 chunks, lr 1e-5 momentum 0.9", "fold": fold, "per_chunk": curve}, fh)
     for ck, rec in enumerate(curve):
-        assert rec["out"] <= 1e-4 and rec["state_c"] <= 1e-4 and rec["state_r"] <= 1e-4, (ck, rec)
-        assert rec["in_diff"] <= 5e-4, (ck, rec)
-        assert max(rec["corr"].values()) <= 5e-4, (ck, rec["corr"])
-        assert max(rec["params"].values()) <= 1e-4, (ck, rec["params"])
+        for key in ("out", "state_c", "state_r"):
+            bound(rec[key], 4e-5, key)
+        bound(rec["in_diff"], 5e-5, "in_diff")
+        for n in names:
+            bound(rec["corr"][n], 5e-5, "corr." + n)
+            bound(rec["params"][n], 4e-5, "params." + n)
         if "slab" in rec:
-            assert rec["slab"] <= 1e-4
+            bound(rec["slab"], 4e-5, "slab.GIFO")
     for key in ("out", "in_diff"):
         early = np.mean([r[key] for r in curve[1:11]]); late = np.mean([r[key] for r in curve[-10:]])
         assert late <= 4 * early + 1e-6, (key, early, late)
@@ -682,7 +684,7 @@ def test_full_size_layer_shapes_of_the_larger_configs(I, C, R, S):
     against the oracle (a few seconds of host time each).  Batched x-projection where S > 16, fused otherwise."""
     T = 20
     recs = run_chunks(I, C, R, S, T, nchunks=1, scale=0.01, momentum=0.9, lr=1e-5, od_scale=0.1)
-    check(recs, tol_act=3e-5, tol_grad=3e-4, C=C, S=S, T=T)
+    check(recs, tol_act=3e-5, tol_grad=5e-5, C=C, S=S, T=T)
 
 
 def test_varying_batch_length_regrows_planes_and_graphs():
@@ -1136,7 +1138,7 @@ def test_persistent_chain_odd_shapes(I, C, R, S, T):
     geometry tables and of the fold product's tiling, against the oracle at the tolerances of test_persistent_chain."""
     recs = run_chunks(I, C, R, S, T, nchunks=2, scale=0.01, momentum=0.9, lr=1e-5, want_in_diff=True, od_scale=0.1, persist=2,
                       waves=0, tpw=0)
-    check(recs, tol_act=3e-5, tol_grad=3e-4, C=C, S=S, T=T)
+    check(recs, tol_act=3e-5, tol_grad=5e-5, C=C, S=S, T=T)
 
 
 def test_persistent_chain_replay_state_bridge_and_whole_utterance():
@@ -1411,7 +1413,7 @@ def test_many_stream_persistent_forward_bf16(I, C, R, S, T):
         c0, r0 = cs.astype(np.float64), rs.astype(np.float64)
         e.update(lr)
         pe = (pe.astype(np.float64) - lr * corr).astype(np.float32)
-    assert e.profile_query("k_fwd_persist_ms")[1] == 3 and e.profile_query("k_gates_step")[1] == 0
+    assert e.profile_query("k_fwd_persist_xl" if C == 1024 else "k_fwd_persist_ms")[1] == 3 and e.profile_query("k_gates_step")[1] == 0
     assert e.profile_query("persist_giveups")[1] == 0
     e.close()
 
@@ -1480,5 +1482,5 @@ def test_many_stream_persistent_forward_gives_up_and_is_run_again(direction):
                 assert np.array_equal(u, v), f"minibatch {step}: {name} differs from the twin's (max abs diff {np.abs(u - v).max():.3g})"
         else:                                          # back on the weights-resident launch: bf16 rounding of a different chain
             assert relerr(out.cpu().numpy(), out_t.cpu().numpy()) <= 2e-2
-    assert e.profile_query("k_fwd_persist_ms")[1] == 2 and e.profile_query("persist_giveups")[1] == 1
+    assert e.profile_query("k_fwd_persist_ms")[1] + e.profile_query("k_fwd_persist_xl")[1] == 2 and e.profile_query("persist_giveups")[1] == 1
     e.close(); t.close()

@@ -171,6 +171,47 @@ def test_give_up_found_after_the_caller_moved_on_drops_that_minibatch_only():
     e.close(); t.close()
 
 
+@pytest.mark.parametrize("I,C,R,S,T", [(40, 800, 512, 4, 20),
+                                       (128, 520, 512, 7, 8)])     # R close to C: r(1..T) is a batched product BEHIND the forward launch
+def test_give_up_two_minibatches_back_keeps_the_resets_issued_since(I, C, R, S, T):
+    """ADVICE r04 (medium, twice): the host is TWO forward launches ahead when it hears of the give-up, and Reset() was called in
+    between.  Minibatch 0 runs clean (the carried state is not zero any more); the forward launch of minibatch 1 gives up; Reset
+    (streams 0 and 2 start new utterances) and minibatch 2 are queued behind it without anybody looking.  The state goes back to
+    the buffer minibatch 1 started from -- decided by launch ordinal, two buffer flips back looks like "no change" to a parity
+    test -- and the Reset issued since, which went into the abandoned buffer, is applied again: minibatch 2 must be BIT-IDENTICAL
+    to a twin that ran minibatch 0, the same Reset and minibatch 2 and never saw minibatch 1.  Second shape: the product that
+    writes `out` and the carried r(T) is a batched product behind the forward launch (R > C / tpw); queued behind a give-up it
+    must not touch the other state buffer -- the one the state goes back to (the kernel looks at the status words)."""
+    import kaldi_lstm_amd as k
+    p = make_params(I, C, R, scale=0.01, seed=91)
+    rng = np.random.RandomState(92)
+    e = k.Engine(I, C, R, S); e.set_params(p); e.set_option("persist", 2); e.set_option("persist_spin_us", 3000)
+    t = k.Engine(I, C, R, S); t.set_params(p); t.set_option("persist", 2)
+    bufs = []
+    for i in range(3):
+        x, od = _minibatch(rng, I, R, S, T, 0.1)
+        bufs.append((dev(x), dev(od), torch.empty(T * S, R, device="cuda"), torch.empty(T * S, I, device="cuda")))
+    flags = [1 if s in (0, 2) else 0 for s in range(S)]
+    for eng in (e, t):                                  # minibatch 0 on the persistent chain on both: identical, non-zero carried state
+        eng.reset([1] * S)
+        _step(eng, *bufs[0], 1e-5)
+        eng.synchronize()
+        assert eng.profile_query("persist_giveups")[1] == 0 and eng.profile_query("persist_launches")[1] == 2
+    e.set_option("persist_test_stall_fwd", 4)
+    _step(e, *bufs[1], 1e-5)                            # gives up (3 ms spin limit); nobody looks
+    e.reset(flags)
+    _step(e, *bufs[2], 1e-5)
+    got = _snapshot(e, bufs[2][2], bufs[2][3])
+    assert e.profile_query("persist_giveups")[1] == 1 and e.profile_query("persist_dropped")[1] == 1
+    t.set_option("persist", 0)                          # the chain a minibatch is run again on
+    t.reset(flags)
+    out_t = torch.empty(T * S, R, device="cuda"); idf_t = torch.empty(T * S, I, device="cuda")
+    _step(t, bufs[2][0], bufs[2][1], out_t, idf_t, 1e-5)
+    want = _snapshot(t, out_t, idf_t)
+    _same(got, want, "minibatch 2 behind the dropped minibatch 1, with a Reset in between")
+    e.close(); t.close()
+
+
 @pytest.mark.parametrize("S,hog", [(4, 40), (8, 48), (1, 48)])
 def test_uneven_load_is_bit_identical_to_the_idle_chip(S, hog):
     """40/800/512: 200 workgroups exchange d_m / m through the fabric every step while `hog` compute units are held by a

@@ -16,7 +16,7 @@ for T in (10, 20, 40):
         for _ in range(3): e.propagate(x, out); e.backpropagate(x, od, ind, 0.9, 2); e.update(1e-5)
         e.profile_query("k_fold_ms"); e.set_option("profile", 1)
         for _ in range(10): e.propagate(x, out); e.backpropagate(x, od, ind, 0.9, 2); e.update(1e-5)
-        tot, n = e.profile_query("k_fwd_persist_ms")
+        tot, n = e.profile_query("k_fwd_persist_xl" if xl else "k_fwd_persist_ms")
         tb, nb = e.profile_query("k_bwd_persist_xl")
         print("T=%d xl=%d: forward launch %.1f us (%d), BPTT launch %.1f us (%d)" % (T, xl, tot / max(n, 1), n, tb / max(nb, 1), nb), flush=True)
         e.close()
