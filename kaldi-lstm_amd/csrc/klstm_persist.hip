@@ -432,7 +432,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
     }
   }
   PT_FLUSH(0);
-  finish(a.ctrl, epoch, T + 2, a.guard ? a.guard + 8 : nullptr);
+  finish(a.ctrl, epoch, T + 2, a.guard ? a.guard + 8 : nullptr, a.guard, a.hstat ? a.hstat + 1 : nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------------------------

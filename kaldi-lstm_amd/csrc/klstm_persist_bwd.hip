@@ -488,7 +488,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
     atomicMax(&a.ctrl[2], 0x80000000u | 0x7fffu);
     if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  finish(a.ctrl, epoch, ngrp * (T + 2), a.guard ? a.guard + 8 : nullptr);
+  finish(a.ctrl, epoch, ngrp * (T + 2), a.guard ? a.guard + 8 : nullptr, a.guard, a.hstat ? a.hstat + 1 : nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
     atomicMax(&a.ctrl[2], 0x80000000u | 0x7fffu);
     if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  finish(a.ctrl, epoch, 2 * (T + 2), a.guard ? a.guard + 8 : nullptr);
+  finish(a.ctrl, epoch, 2 * (T + 2), a.guard ? a.guard + 8 : nullptr, a.guard, a.hstat ? a.hstat + 1 : nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------------------------

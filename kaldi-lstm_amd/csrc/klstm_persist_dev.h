@@ -113,7 +113,12 @@ __device__ __forceinline__ unsigned launch_ordinal(const unsigned *guard) {
   return guard ? __hip_atomic_load(guard + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
 #endif
 }
-__device__ __forceinline__ void finish(unsigned *ctrl, unsigned epoch, int ntags, unsigned *count = nullptr) {
+// hdone (or null): a HOST-MAPPED word the last workgroup writes when the launch is over: the new launch count in bits 0..30, bit 31 set when
+// a status word of the chain is up (this launch or one in front of it gave up).  A host that waits for a persistent launch
+// ("persist_verify") spins on this word instead of synchronising the stream: it hears of the end of the launch one PCIe write after
+// the last workgroup left, not one completion-signal round trip later.  One word carries both facts: nothing to order.
+__device__ __forceinline__ void finish(unsigned *ctrl, unsigned epoch, int ntags, unsigned *count = nullptr, const unsigned *guard = nullptr,
+                                       unsigned *hdone = nullptr) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = atomicAdd(&ctrl[1], 1u);
@@ -121,7 +126,13 @@ __device__ __forceinline__ void finish(unsigned *ctrl, unsigned epoch, int ntags
       __hip_atomic_store(&ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&ctrl[0], epoch + (unsigned)ntags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifndef KLSTM_NO_LAUNCH_COUNT
-      if (count) __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned n = 0u;
+      if (count) n = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      if (hdone && guard) {
+        const unsigned bad = __hip_atomic_load(guard + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                             __hip_atomic_load(guard + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hdone, (n & 0x7fffffffu) | (bad ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
 #endif
     }
   }

@@ -296,7 +296,7 @@ __global__ __launch_bounds__((4 + NSW) * 64) void k_fwd_persist_ms(PersistMsArgs
       lds_barrier();                                                   // (2)
     }
   }
-  finish(a.ctrl, epoch, T + 2, a.guard ? a.guard + 8 : nullptr);
+  finish(a.ctrl, epoch, T + 2, a.guard ? a.guard + 8 : nullptr, a.guard, a.hstat ? a.hstat + 1 : nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
