@@ -396,6 +396,14 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
  * NULL): 2 words per workgroup, filled with the XCC id and the HW_ID register of the compute unit it landed on. */
 klstm_status klstm_debug_occupy(int device, int workgroups, int microseconds, void *hip_stream, unsigned *where_dev);
 
+/* Test / probe support for the pipelined bf16 product of the many-stream chains (kaldi-lstm_amd/csrc/klstm_gemm16.hip):
+ * C = A B^T (+ bias[n]) (+ add[m][n]) for one or two products that share their K in ONE launch, operands rounded to bf16 when staged,
+ * fp32 accumulation, K split inside the launch.  mnk: M, N, K per job; ptrs: A [M x K], B [N x K], C, bias (or NULL), add (or NULL)
+ * per job, device pointers; lds: lda, ldb, ldc, add_ld per job; force_nj (1 / 2 / 4: tile width 32 nj) and force_ks (1 / 2 / 4 / 8
+ * K slices), 0 = the launcher's own plan; plan_out (or NULL) receives nj, ks and the number of output tiles. */
+klstm_status klstm_debug_gemm_bf16_nt2(int njobs, const int *mnk, const float *const *ptrs, const int *lds, int force_nj, int force_ks,
+                                       void *hip_stream, int *plan_out);
+
 #ifdef __cplusplus
 }
 #endif

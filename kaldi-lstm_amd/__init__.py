@@ -8,7 +8,7 @@ calls raise.
 """
 from .binding import (Engine, KlstmError, RcclComm, OneshotAllreduce, lib_path, load_library, time_shift, affine_propagate,  # noqa: F401
                       affine_backpropagate, affine_update, affine_gradient, sgd_momentum_update, softmax,
-                      xent_eval_masked, xent_eval_masked_post, softmax_xent_masked, DEFER_MOMENTUM)
+                      xent_eval_masked, xent_eval_masked_post, softmax_xent_masked, debug_gemm_bf16_nt2, DEFER_MOMENTUM)
 from .batcher import MultiStreamBatcher  # noqa: F401,E402
 from .dp import (DataParallelLstm, DataParallelNnet, LstmDP, AffineDP, SoftmaxXentDP,  # noqa: F401,E402
                  shard_time_major)

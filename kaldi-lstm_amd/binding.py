@@ -78,6 +78,7 @@ def load_library():
     lib.klstm_get_activations_host.argtypes = [P, I, P]
     lib.klstm_set_option.argtypes = [P, ctypes.c_char_p, I]
     lib.klstm_debug_occupy.argtypes = [I, I, I, P, P]
+    lib.klstm_debug_gemm_bf16_nt2.argtypes = [I, P, P, P, I, I, P, P]
     lib.klstm_profile_query.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_long)]
     lib.klstm_time_shift.argtypes = [P, I, I, I, P, I, I, P]
@@ -538,3 +539,25 @@ def xent_eval_masked_post(net_out, post, mask, diff, stream=None):
     else:
         torch.cuda.synchronize()
     return float(rx.double().sum().item()), float(re_.double().sum().item()), int(rc.sum().item()), int((mask == 1).sum().item())
+
+
+def debug_gemm_bf16_nt2(jobs, force_nj=0, force_ks=0, stream=None):
+    """klstm_debug_gemm_bf16_nt2 (klstm.h): jobs = [(A [M x K], B [N x K], C [M x N], bias or None, add or None), ...] (one or two torch
+    CUDA fp32 tensors each, row strides honoured): C = A B^T (+ bias) (+ add), operands rounded to bf16, fp32 accumulate, one launch.
+    Returns the plan that ran (nj, ks, output tiles)."""
+    lib = load_library()
+    n = len(jobs)
+    mnk = (ctypes.c_int * (3 * n))()
+    ptrs = (ctypes.c_void_p * (5 * n))()
+    lds = (ctypes.c_int * (4 * n))()
+    for q, (A, B, C, bias, add) in enumerate(jobs):
+        assert A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1 and A.shape[1] == B.shape[1]
+        mnk[3 * q:3 * q + 3] = [A.shape[0], B.shape[0], A.shape[1]]
+        ptrs[5 * q:5 * q + 5] = [A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                 add.data_ptr() if add is not None else None]
+        lds[4 * q:4 * q + 4] = [A.stride(0), B.stride(0), C.stride(0), add.stride(0) if add is not None else 0]
+    plan = (ctypes.c_int * 3)()
+    st = lib.klstm_debug_gemm_bf16_nt2(n, mnk, ptrs, lds, force_nj, force_ks, ctypes.c_void_p(stream) if stream else None, plan)
+    if st != 0:
+        raise KlstmError(st, lib.klstm_last_error().decode())
+    return tuple(plan)

@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = ["csrc/klstm_kernels.hip", "csrc/klstm_persist.hip", "csrc/klstm_persist_bwd.hip", "csrc/klstm_persist_ms.hip", "csrc/klstm_persist_xl.hip", "csrc/klstm_fold.hip", "csrc/klstm_fold3.hip", "csrc/klstm_oneshot.hip", "csrc/klstm_outer.hip",
+SRCS = ["csrc/klstm_kernels.hip", "csrc/klstm_persist.hip", "csrc/klstm_persist_bwd.hip", "csrc/klstm_persist_ms.hip", "csrc/klstm_persist_xl.hip", "csrc/klstm_fold.hip", "csrc/klstm_fold3.hip", "csrc/klstm_oneshot.hip", "csrc/klstm_outer.hip", "csrc/klstm_gemm16.hip",
         "csrc/klstm_engine.hip"]
 HDRS = ["csrc/klstm_kernels.h", "csrc/klstm_math.h", "csrc/klstm_persist_dev.h", "../include/klstm.h"]
 LIB = os.path.join(HERE, "libklstm.so")

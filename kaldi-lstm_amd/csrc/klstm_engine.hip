@@ -157,6 +157,8 @@ struct klstm_engine {
   float *Pm = nullptr;     // out_diff * W_r_m for all frames [(T_alloc) S x C]
   float *ws = nullptr;     // split-K workspace of the batched d_r / in_diff products
   size_t ws_floats = 0;
+  unsigned *tickets = nullptr;   // klstm_gemm16.hip: one word per output tile of a split-K launch (NT2_TICKETS words, zero between launches)
+  int use_nt2 = 1;         // option "gemm_nt2": the batched bf16 products on the pipelined kernel (0: round 4's kernel + reduction launches)
   bool use_bf16 = false;   // bf16 operands in the step kernels (option "bf16"); masters/planes/gradients stay fp32
   int fuse_x = -1;    // -1 auto (small NumStream), 0 batched x-projection GEMM, 1 fused into the step kernel
   bool profile = false;
@@ -259,7 +261,32 @@ static size_t ws_need(const klstm_engine *e, int T) {
   if (np > need) need = np;
   const size_t nx = (size_t)8 * M * (e->R > e->I ? e->R : e->I);                                     // the per-XCD BPTT chain's d_r / in_diff in 8 K slices
   if (nx > need) need = nx;
+  if (e->use_bf16 && M >= 256) {                                                                      // ... and on the pipelined kernel (klstm_gemm16.hip): padded tiles
+    const Nt2Job j[2] = {Nt2Job{(int)M, e->R, 4 * e->C, nullptr, 4 * e->C, nullptr, 4 * e->C, nullptr, e->R, nullptr, nullptr, 0},
+                         Nt2Job{(int)M, e->I, 4 * e->C, nullptr, 4 * e->C, nullptr, 4 * e->C, nullptr, e->I, nullptr, nullptr, 0}};
+    const Nt2Job jp{(int)M, e->C, e->R, nullptr, e->R, nullptr, e->R, nullptr, e->C, nullptr, nullptr, 0};
+    const Nt2Job jx{(int)M, 4 * e->C, e->I, nullptr, e->I, nullptr, e->I, nullptr, 4 * e->C, nullptr, nullptr, 0};
+    const size_t cand[4] = {gemm_bf16_nt2_plan(j, 2).ws_floats, gemm_bf16_nt2_plan(j, 1).ws_floats, gemm_bf16_nt2_plan(&jp, 1).ws_floats,
+                            gemm_bf16_nt2_plan(&jx, 1).ws_floats};
+    for (size_t n : cand) if (n > need) need = n;
+  }
   return need;
+}
+constexpr int NT2_TICKETS = 8192;
+static klstm_status ensure_tickets(klstm_engine *e) {
+  if (e->tickets) return KLSTM_OK;
+  HIPCHK(hipMalloc(&e->tickets, NT2_TICKETS * sizeof(unsigned)));
+  HIPCHK(hipMemsetAsync(e->tickets, 0, NT2_TICKETS * sizeof(unsigned), e->stream));
+  return KLSTM_OK;
+}
+// one or two batched bf16 products on the pipelined kernel; false: not taken (shape / alignment / workspace), the caller falls back
+static bool nt2_products(klstm_engine *e, const Nt2Job *jobs, int njobs, LaunchProbe pr, hipError_t *err) {
+  if (!e->use_nt2 || !e->tickets) return false;
+  for (int q = 0; q < njobs; q++) if (!gemm_bf16_nt2_supported(jobs[q])) return false;
+  const Nt2Plan pl = gemm_bf16_nt2_plan(jobs, njobs);
+  if (pl.ks > 1 && (pl.ws_floats > e->ws_floats || !e->ws || pl.nt > NT2_TICKETS)) return false;
+  *err = launch_gemm_bf16_nt2(jobs, njobs, pl, e->ws, e->ws_floats, e->tickets, NT2_TICKETS, e->stream, pr);
+  return true;
 }
 static klstm_status ensure_ws(klstm_engine *e, int T) {
   const size_t need = ws_need(e, T);
@@ -665,6 +692,7 @@ void klstm_destroy(klstm_engine *e) {
   if (e->gran_ms) (void)hipFree(e->gran_ms);
   if (e->wrmT_l) (void)hipFree(e->wrmT_l);
   if (e->gran_xb) (void)hipFree(e->gran_xb);
+  if (e->tickets) (void)hipFree(e->tickets);
   if (e->pstat_host) (void)hipHostFree(e->pstat_host);
   for (float *p : e->stage) if (p) (void)hipFree(p);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -826,7 +854,11 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
   hipStream_t st = e->stream;
   const bool fx = use_fused_x(e) && !(e->fwd_persist && persist_x_batched(d)) && !e->fwd_ms;
   if (!fx) {  // x -> g,i,f,o for all frames at once + bias (...streams.h:246, :259)
-    if (e->use_bf16 && gemm_bf16_nt_supported(T * d.S, d.I, in, in_stride, p.wx, d.I))   // bf16 mode: operands rounded like the fused form's
+    const Nt2Job jx{T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias, nullptr, 0};
+    hipError_t xerr = hipSuccess;
+    if (e->use_bf16 && gemm_bf16_nt_supported(T * d.S, d.I, in, in_stride, p.wx, d.I) && nt2_products(e, &jx, 1, probe(e, "k_gemm_xproj"), &xerr))
+      HIPCHK(xerr);                                                                      // (two K tiles in flight: klstm_gemm16.hip)
+    else if (e->use_bf16 && gemm_bf16_nt_supported(T * d.S, d.I, in, in_stride, p.wx, d.I))   // bf16 mode: operands rounded like the fused form's
       HIPCHK(launch_gemm_bf16_nt(T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I, e->gifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.bias,
                                  st, probe(e, "k_gemm_xproj")));
     else if (direct_nt_supported(T * d.S, 4 * d.C, d.I, in, in_stride, p.wx, d.I))       // few frames, wide input (klstm_fold.hip)
@@ -883,17 +915,30 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     // elementwise pass of the own cells, then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r (:391) and in_diff = dgifo W_gifo_x (:457)
     // as batched products -- every product on the bf16 tiles with fp32 accumulation, operands rounded like the step kernels'
     const int M = T * d.S, KS = 8, KL = 4 * d.C / KS;          // (K = 4C in 8 slices of 512: 40 output tiles -> 320 workgroups)
-    if (gemm_bf16_nt_supported(M, d.R, out_diff, od_stride, p.wmT, d.R))
+    const Nt2Job jp{M, d.C, d.R, out_diff, od_stride, p.wmT, d.R, e->Pm, d.C, nullptr, nullptr, 0};
+    hipError_t perr = hipSuccess;
+    if (gemm_bf16_nt_supported(M, d.R, out_diff, od_stride, p.wmT, d.R) && nt2_products(e, &jp, 1, probe(e, "k_gemm_P"), &perr))
+      HIPCHK(perr);
+    else if (gemm_bf16_nt_supported(M, d.R, out_diff, od_stride, p.wmT, d.R))
       HIPCHK(launch_gemm_bf16_nt(M, d.C, d.R, out_diff, od_stride, p.wmT, d.R, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
     else                                              // (a caller's view that is not 16-byte aligned: the fp32 tiles take any layout)
       HIPCHK(launch_gemm(false, true, M, d.C, d.R, out_diff, od_stride, p.wmT, d.R, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
     HIPCHK(launch_bwd_persist_xl(d, p, e->wrmT_l, e->Pm, e->gran_xb, e->pctrl + 4, e->popt, st, probe(e, "k_bwd_persist_xl")));
-    HIPCHK(launch_gemm_bf16_nt_splitk(M, d.R, 4 * d.C, e->dgifo + (size_t)2 * d.S * 4 * d.C, 4 * d.C, p.wrT, 4 * d.C, 0.f,
-                                      e->dr + (size_t)d.S * d.R, d.R, out_diff, od_stride, e->ws, KS, KL, st, probe(e, "k_gemm_dr"),
-                                      probe(e, "k_reduce_dr")));
-    if (in_diff)
-      HIPCHK(launch_gemm_bf16_nt_splitk(M, d.I, 4 * d.C, e->dgifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.wxT, 4 * d.C, 0.f, in_diff, id_stride,
-                                        nullptr, 0, e->ws, KS, KL, st, probe(e, "k_gemm_indiff"), probe(e, "k_reduce_indiff")));
+    // d_r and in_diff contract the same dgifo rows (one time block apart) over K = 4C: ONE launch of the pipelined kernel, the K
+    // slices' partial tiles added by the last-arriving slice (klstm_gemm16.hip) -- no reduction launches
+    const Nt2Job jt[2] = {Nt2Job{M, d.R, 4 * d.C, e->dgifo + (size_t)2 * d.S * 4 * d.C, 4 * d.C, p.wrT, 4 * d.C, e->dr + (size_t)d.S * d.R, d.R, nullptr,
+                                 out_diff, od_stride},
+                          Nt2Job{M, d.I, 4 * d.C, e->dgifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.wxT, 4 * d.C, in_diff, id_stride, nullptr, nullptr, 0}};
+    hipError_t terr = hipSuccess;
+    if (nt2_products(e, jt, in_diff ? 2 : 1, probe(e, "k_gemm_dr"), &terr)) HIPCHK(terr);
+    else {
+      HIPCHK(launch_gemm_bf16_nt_splitk(M, d.R, 4 * d.C, e->dgifo + (size_t)2 * d.S * 4 * d.C, 4 * d.C, p.wrT, 4 * d.C, 0.f,
+                                        e->dr + (size_t)d.S * d.R, d.R, out_diff, od_stride, e->ws, KS, KL, st, probe(e, "k_gemm_dr"),
+                                        probe(e, "k_reduce_dr")));
+      if (in_diff)
+        HIPCHK(launch_gemm_bf16_nt_splitk(M, d.I, 4 * d.C, e->dgifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.wxT, 4 * d.C, 0.f, in_diff, id_stride,
+                                          nullptr, 0, e->ws, KS, KL, st, probe(e, "k_gemm_indiff"), probe(e, "k_reduce_indiff")));
+    }
     const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
     if (grads_fusable(e, T, flags, e->use_bf16)) return KLSTM_OK;
     HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, defer ? 0.f : mmt, defer ? e->grads : e->corr, st,
@@ -991,7 +1036,8 @@ static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int
   if ((e->fwd_persist || e->fwd_ms) && (st = ensure_persist(e)) != KLSTM_OK) return st;
   if (e->fwd_ms && (st = ensure_ms(e)) != KLSTM_OK) return st;
   e->bwd_xl = e->fwd_ms && e->wrmT_l && e->popt.xl_bwd != 0 && persist_xl_supported(Dims{e->I, e->C, e->R, e->S, T}, e->popt);
-  if ((e->fwd_folded || e->bwd_xl) && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
+  if ((e->fwd_folded || e->bwd_xl || e->use_bf16) && (st = ensure_ws(e, T)) != KLSTM_OK) return st;
+  if (e->use_bf16 && (st = ensure_tickets(e)) != KLSTM_OK) return st;
   // (the persistent backward launch takes its columns of W_rm from the gates-order operand: the second layout is not written then)
   if (e->fwd_folded && (st = ensure_fold(e, !e->fwd_persist, !e->bwd_persist)) != KLSTM_OK) return st;     // outside the graph: only after an Update
   if (!e->fwd_folded && (st = ensure_packs(e, e->fwd_ms ? (e->bwd_xl ? 0 : 12) : 15)) != KLSTM_OK) return st;     // (the many-stream launch reads the natural matrices; BPTT its packed operands)
@@ -1379,6 +1425,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else if (!strcmp(key, "persist_ncu")) e->ncu = value;                                       // test hook: pretend the device has this many CUs
     else if (!strcmp(key, "persist_verify")) e->persist_verify = value != 0;
     else if (!strcmp(key, "persist_verify_spin")) e->verify_spin = value != 0;
+    else if (!strcmp(key, "gemm_nt2")) { HIPCHK(hipStreamSynchronize(e->stream)); drop_graphs(e); e->use_nt2 = value != 0; }
     else if (!strcmp(key, "persist_cooldown")) { e->cooldown_len = value < 0 ? 0 : value; e->cooldown_cur = 0; if (e->cooldown > e->cooldown_len) e->cooldown = e->cooldown_len; }
     else return fail(KLSTM_ERR_ARG, "klstm_set_option: unknown key '%s'", key);
     return KLSTM_OK;
@@ -1887,5 +1934,41 @@ extern "C" klstm_status klstm_debug_occupy(int device, int workgroups, int micro
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   hipLaunchKernelGGL(k_occupy, dim3(workgroups), dim3(1024), 96 * 1024, st, (long long)microseconds * 100, where_dev);
   HIPCHK(hipGetLastError());
+  return KLSTM_OK;
+}
+
+// Test / probe support for klstm_gemm16.hip (tools/gemm16_probe.py, tests/test_gemm16_gpu.py): C = A B^T (+ bias) (+ add) for one or
+// two products that share their K, bf16-rounded operands, fp32 accumulate, on hip_stream (NULL: the default stream).
+//   mnk: 3 ints per job; ptrs: A, B, C, bias, add per job (device pointers, bias / add may be null); lds: lda, ldb, ldc, add_ld per job
+//   force_nj / force_ks: 0 = the launcher's plan; plan_out (or null): nj, ks, output tiles of the plan that ran
+extern "C" klstm_status klstm_debug_gemm_bf16_nt2(int njobs, const int *mnk, const float *const *ptrs, const int *lds, int force_nj, int force_ks,
+                                                  void *hip_stream, int *plan_out) {
+  if (njobs == 0) { gemm_bf16_nt2_debug_buffer(reinterpret_cast<long long *>(const_cast<int *>(mnk))); return KLSTM_OK; }   // (probe: timing buffer on / off)
+  if (njobs < 1 || njobs > 2 || !mnk || !ptrs || !lds) return fail(KLSTM_ERR_ARG, "klstm_debug_gemm_bf16_nt2: bad arguments");
+  Nt2Job jobs[2];
+  for (int q = 0; q < njobs; q++) {
+    jobs[q] = Nt2Job{mnk[3 * q], mnk[3 * q + 1], mnk[3 * q + 2], ptrs[5 * q], lds[4 * q], ptrs[5 * q + 1], lds[4 * q + 1],
+                     const_cast<float *>(ptrs[5 * q + 2]), lds[4 * q + 2], ptrs[5 * q + 3], ptrs[5 * q + 4], lds[4 * q + 3]};
+    if (!gemm_bf16_nt2_supported(jobs[q])) return fail(KLSTM_ERR_SHAPE, "klstm_debug_gemm_bf16_nt2: job %d not supported by the kernel", q);
+  }
+  const Nt2Plan pl = gemm_bf16_nt2_plan(jobs, njobs, force_nj, force_ks);
+  static std::mutex mu;
+  static float *ws = nullptr; static size_t ws_floats = 0; static unsigned *tickets = nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (pl.ws_floats > ws_floats) {
+    HIPCHK(hipDeviceSynchronize());
+    if (ws) (void)hipFree(ws);
+    ws = nullptr; ws_floats = 0;
+    HIPCHK(hipMalloc(&ws, pl.ws_floats * sizeof(float)));
+    ws_floats = pl.ws_floats;
+  }
+  if (!tickets) {
+    HIPCHK(hipMalloc(&tickets, NT2_TICKETS * sizeof(unsigned)));
+    HIPCHK(hipMemset(tickets, 0, NT2_TICKETS * sizeof(unsigned)));
+  }
+  if (pl.nt > NT2_TICKETS) return fail(KLSTM_ERR_SHAPE, "klstm_debug_gemm_bf16_nt2: %d output tiles", pl.nt);
+  HIPCHK(launch_gemm_bf16_nt2(jobs, njobs, pl, ws, ws_floats, tickets, NT2_TICKETS, st));
+  if (plan_out) { plan_out[0] = pl.nj; plan_out[1] = pl.ks; plan_out[2] = pl.nt; }
   return KLSTM_OK;
 }

@@ -180,6 +180,23 @@ hipError_t launch_gemm_bf16_nt(int M, int N, int K, const float *A, int lda, con
 hipError_t launch_gemm_bf16_nt_splitk(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *Cm, int ldc,
                                       const float *add, int add_ld, float *ws, int ks, int klen, hipStream_t st, LaunchProbe pr = {},
                                       LaunchProbe pr2 = {});   // K in ks slices of klen (multiple of 64) through ws [ks][M x N]; C = beta C + add + A B^T
+// klstm_gemm16.hip: the same product, pipelined (two K tiles in flight behind the one being contracted), split K inside the launch
+// (last-arriving slice adds the slabs in slice order), K slice z on XCD z, one or two products that share their K per launch.
+//   C = A B^T (+ bias[n]) (+ add[m][n])
+struct Nt2Job {
+  int M, N, K;
+  const float *A; int lda;            // [M x K], k-contiguous rows, 16-byte aligned, lda % 4 == 0
+  const float *B; int ldb;            // [N x K]
+  float *C; int ldc;
+  const float *bias;                  // [N] or null
+  const float *add; int add_ld;       // [M x N] or null
+};
+struct Nt2Plan { int nj, ks, nt; size_t ws_floats; };       // 16-column blocks per wave (tile = 128 x 32 nj), K slices, output tiles, workspace
+bool gemm_bf16_nt2_supported(const Nt2Job &g);
+Nt2Plan gemm_bf16_nt2_plan(const Nt2Job *jobs, int njobs, int force_nj = 0, int force_ks = 0);
+hipError_t launch_gemm_bf16_nt2(const Nt2Job *jobs, int njobs, const Nt2Plan &pl, float *ws, size_t ws_floats, unsigned *tickets, int ntickets,
+                                hipStream_t st, LaunchProbe pr = {});   // tickets: >= pl.nt words, zero between launches (the kernel leaves them zero)
+void gemm_bf16_nt2_debug_buffer(long long *dev);      // probe support: 8 shader-clock sums per workgroup (null: off)
 bool grads_bf16_tiles(const Dims &d, bool bf16);      // would launch_grads take the bf16 tile path?
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,
