@@ -143,10 +143,43 @@ def _sections(parts, nrep=20):
     return out
 
 
-def _roof(flops_per_step, ms_per_step, peak_tf, dtype, note):
+def _pmc(config):
+    """The committed rocprofv3 PMC summary of `bench.py --config <config>` (profiles/rNN<config>_pmc_traffic.json, tools/profile.sh: separate
+    counter passes), or None.  STATIC: not measured by this process."""
+    import glob, json, os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]%s_pmc_traffic.json" % config)))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            d["file"] = "profiles/" + os.path.basename(f)
+            return d
+        except Exception:
+            pass
+    return None
+
+
+def _roof(flops_per_step, ms_per_step, peak_tf, dtype, note, config=None, alg_bytes_per_step=None):
     tf = flops_per_step / (ms_per_step * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "whole minibatch (sections / kernels below)", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s",
-            "frac": tf / peak_tf, "traffic": None, "dtype_peak": dtype, "note": note}
+    r = {"bound": "mfma", "kernel": "whole minibatch (sections / kernels below)", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s",
+         "frac": tf / peak_tf, "traffic": None, "dtype_peak": dtype, "note": note}
+    pmc = _pmc(config) if config else None
+    if pmc and pmc.get("hbm_bytes_per_minibatch"):
+        # HBM bytes per minibatch from the FETCH_SIZE / WRITE_SIZE passes (corrected as MI355X_MICROARCH.md prescribes) against the
+        # algorithmic bytes of SURVEY.md 8(d): activations per frame + every weight tensor five times per minibatch
+        r["traffic"] = pmc["hbm_bytes_per_minibatch"]
+        r["traffic_source"] = pmc["file"] + " (static: separate rocprofv3 --pmc passes, not this run)"
+        if alg_bytes_per_step:
+            r["alg_bytes_per_minibatch"] = alg_bytes_per_step
+            r["traffic_ratio"] = pmc["hbm_bytes_per_minibatch"] / alg_bytes_per_step
+        r["traffic_per_kernel"] = {k_: v["hbm_bytes_per_launch"] for k_, v in pmc.get("kernels", {}).items() if v.get("launches", 0) >= pmc.get("minibatches", 1)}
+    return r
+
+
+def lstm_alg_bytes(I, C, R, frames):
+    """activation bytes per frame (slab rows written + read, derivative rows, in / out rows) and every weight tensor
+    five times per minibatch (forward, backward, gradient read + write, update)."""
+    act = 4 * (2 * (7 * C + R) + 2 * 4 * C + 2 * R + 3 * I)
+    return act * frames + 5 * 4 * n_params(I, C, R)
 
 
 def _dominant_kernel(kern, alg_flops_per_launch, peak_tf, csv_glob, csv_names):
@@ -328,7 +361,8 @@ def run_c4(args, k):
                                  "call by call from Python on one explicit stream (--option whole_step_graph=1: one hipGraph per minibatch; "
                                  "measured equal: 0.569 vs 0.564 ms)",
                        "ms_per_step_call_by_call": ms_eager},
-            "roofline": _roof(fl * T * S, ms, PEAK_F32_MFMA_TF, "f32", "86.2 MFLOP per frame (SURVEY.md 8(d))"),
+            "roofline": _roof(fl * T * S, ms, PEAK_F32_MFMA_TF, "f32", "86.2 MFLOP per frame (SURVEY.md 8(d))", "c4",
+                              lstm_alg_bytes(I, C, R, T * S) + lstm_alg_bytes(R, C, R, T * S) + 5 * 4 * NPDF * (R + 1) + 4 * T * S * (2 * R + 3 * NPDF)),
             "multi_gpu_shard_path": shard, "sections_us": sections, "kernels": kern}
 
 
@@ -389,7 +423,8 @@ def run_c5(args, k):
     for e in engines:
         e.close()
     fl = sum(lstm_flops_per_frame(dims_in[l], C, R) for l in range(NL))
-    roof = _roof(fl * T * S, ms, PEAK_BF16_MFMA_TF, "bf16", "73.3 MFLOP per frame (SURVEY.md 8(d)); weights-resident chains, one per XCD and direction (klstm_persist_xl.hip), batched products around them")
+    roof = _roof(fl * T * S, ms, PEAK_BF16_MFMA_TF, "bf16", "73.3 MFLOP per frame (SURVEY.md 8(d)); weights-resident chains, one per XCD and direction (klstm_persist_xl.hip), batched products around them (klstm_gemm16.hip)",
+                 "c5", sum(lstm_alg_bytes(dims_in[l], C, R, T * S) for l in range(NL)))
     # the two chain launches: the reference's recurrent products of the T S frames one launch advances -- forward r(t-1) W_gifo_r^T (:275) and
     # m(t) W_r_m^T (:312); backward dgifo(t+1) W_gifo_r (:391) and d_r(t) W_r_m (:408, the part that is not the batched P)
     chain_fl = float(T * S) * (2 * 4 * C * R + 2 * R * C)

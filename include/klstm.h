@@ -370,11 +370,18 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  klstm_affine_backpropagate of <= 80 rows over >= 4096 outputs: "skinny_f16" 0 = fp32 MFMA;
  *                  d_r / in_diff of an engine whose input is too wide for the persistent backward launch: "skinny_f16_pair" 0 =
  *                  the tiled split-K kernel.  All process-wide (A-B experiments and tests)
- *   "fp16_products"  0/1  0 = no product runs on fp16 planes (all of the above on their fp32 kernels, the fold product on three
- *                  bf16 planes): saves a net whose activations, weights or derivatives pass 65504 all the time the one slow
- *                  call of the range guard.  1 = the defaults again, the guard's counters cleared.  Process-wide (reaches the
- *                  cached graphs of every live engine)
- *   "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
+ *   "fp16_products"  0/1  0 = no product of THIS engine and no stateless klstm_affine_* call on this engine's device runs on fp16 planes
+                  (all of the above on their fp32 kernels, the fold product on three bf16 planes): saves a net whose activations,
+                  weights or derivatives pass 65504 all the time the slow call of the range guard.  1 = the defaults again, the
+                  guards' counters and cool-downs cleared.  Other engines keep their own state.
+                  RANGE GUARD STATE: every engine has its own (event words, which families are latched, cool-downs); the stateless
+                  klstm_affine_* calls share one per device.  A family whose guard fired runs on its fp32-range kernel for a
+                  cool-down (64 fold products = Updates; 2048 looks of a stateless family), then the fp16 planes are tried again; a
+                  trigger that follows a re-arm closely doubles the cool-down (up to 2^20), a clean run as long as the last cool-down
+                  resets it; klstm_last_error() carries a remark when a family latches and when it comes back.
+                  klstm_profile_query(e, "fp16_redo*") = this engine's events + its device's stateless events; "fp16_redo_own" =
+                  this engine's only; "fold_mode" = the fold product's format as it runs (1 while latched)
+   "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.
  *   "fuse_x"  -1/0/1  x(t) W_gifo_x^T inside the step kernel (auto: NumStream <= 16) or as one batched product (:246)

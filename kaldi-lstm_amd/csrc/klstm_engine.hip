@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstddef>
 #include <cstdio>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <deque>
@@ -150,7 +151,10 @@ struct klstm_engine {
   static constexpr size_t MARKS_MAX = 4096;
   MbRec rec;
   std::vector<int> resets;      // Reset flags since the last forward pass was enqueued (applied again when the state goes back a buffer)
-  int fold_mode = 2;            // fold product: 0 fp32 MFMA, 1 three bf16 planes, 2 two fp16 planes (option "fold_bf16x3")
+  int fold_mode = 2;            // fold product, as asked for: 0 fp32 MFMA, 1 three bf16 planes, 2 two fp16 planes (option "fold_bf16x3")
+  int fold_eff = 2;             // ... as it runs: 1 instead of 2 while this engine's range guard keeps the fold product off the fp16 planes
+  RangeGuard *rg = nullptr;     // this engine's range guard (klstm_kernels.h): its fp16-plane products, their event words and cool-downs
+  unsigned knob_gen = 0;        // the process-wide A-B knobs' generation this engine's cached graphs were captured under
   void *fold_scratch = nullptr;             // bf16 planes of the two fold operands (klstm_fold3.hip)
   bool planes_fresh = false;                // ... and they were written from the current parameters (by the fused Update)
   float *pk_fold[2] = {nullptr, nullptr};   // packed [W_rm | W_x] (gates order) and W_rm^T (4-row geometry)
@@ -201,17 +205,23 @@ static void drop_graphs(klstm_engine *e) {
   e->graphs.clear();
 }
 
-// every live engine: a process-wide knob (which kernel a product runs on) must reach the cached graphs of ALL of them
+// The process-wide A-B knobs (which kernel a product runs on: "direct_nt_shape", "skinny_f16", "outer_f16", ...) must reach the cached
+// graphs of every live engine.  The caller's thread does not touch foreign engines (another thread may be driving them): it moves a
+// generation counter on, and every engine compares at the head of its own launching calls and drops its own graphs.
 static std::mutex g_engines_mu;
 static std::set<klstm_engine *> g_engines;
-static void knob_changed_everywhere(int fold_mode = -1) {
-  std::lock_guard<std::mutex> lk(g_engines_mu);
-  for (klstm_engine *x : g_engines) {
-    if (hipSetDevice(x->device) != hipSuccess) continue;
-    (void)hipStreamSynchronize(x->stream);
-    drop_graphs(x);
-    if (fold_mode >= 0) { x->fold_mode = fold_mode; x->planes_fresh = false; x->fold_dirty = true; }
+static std::atomic<unsigned> g_knob_gen{0};
+static void knob_changed_everywhere() { g_knob_gen.fetch_add(1, std::memory_order_relaxed); }
+static klstm_status knobs_seen(klstm_engine *e) {
+  const unsigned gen = g_knob_gen.load(std::memory_order_relaxed);
+  if (gen == e->knob_gen) return KLSTM_OK;
+  e->knob_gen = gen;
+  if (!e->graphs.empty()) {
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(KLSTM_ERR_HIP, "hipStreamSynchronize failed");
+    drop_graphs(e);
   }
+  e->fold_dirty = true;            // ("fold_direct": the fold product may run on another kernel)
+  return KLSTM_OK;
 }
 
 static klstm_status ensure_planes(klstm_engine *e, int T) {
@@ -311,6 +321,7 @@ static const float *ar_mark_if_reduced(const klstm_engine *e) { return e->ar_mar
 static klstm_status flush_grads(klstm_engine *e) {
   if (!e->grads_pending) return KLSTM_OK;
   e->grads_pending = false;
+  const RangeGuardScope rgs(e->rg);
   const Dims d{e->I, e->C, e->R, e->S, e->gp_T};
   HIPCHK(launch_grads(d, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
                       probe(e, "k_grads"), e->gp_bf16, nullptr, e->pctrl));
@@ -574,19 +585,22 @@ static klstm_status ensure_fold(klstm_engine *e, bool need_x, bool need_pk2 = tr
   }
   const bool pack_x = need_x && !e->foldx_fresh;
   if (!e->fold_dirty && !pack_x && !(need_pk2 && !e->pk2_fresh)) return KLSTM_OK;
-  if (e->fold_mode == 2 && redo_count(REDO_FOLD) != 0) {
-    // range guard (klstm_math.h): a parameter passed the fp16 range -- the product was recomputed in fp32 where it mattered; from
-    // here on three bf16 planes (fp32 range, six products instead of three), engines of this process alike
-    e->fold_mode = 1; e->planes_fresh = false;
-    if (e->use_graph) { HIPCHK(hipStreamSynchronize(e->stream)); drop_graphs(e); }
-    note("fold product: a parameter beyond the fp16 range (65504) was met; the product runs on three bf16 planes from now on");
+  // range guard (klstm_math.h): fp16 planes asked for -- one look at this engine's guard per fold product.  A parameter that passed the
+  // fp16 range was noticed by the product itself (recomputed in fp32 where it mattered); three bf16 planes (fp32 range, six products
+  // instead of three) for the guard's cool-down, then the fp16 planes again.  This engine only.
+  {
+    const int eff = e->fold_mode == 2 && redo_count(REDO_FOLD) != 0 ? 1 : e->fold_mode;
+    if (eff != e->fold_eff) {
+      e->fold_eff = eff; e->planes_fresh = false;
+      if (!e->graphs.empty()) { HIPCHK(hipStreamSynchronize(e->stream)); drop_graphs(e); }
+    }
   }
-  if (!e->fold_scratch && fold_bf16x3_supported(d, e->fold_mode)) HIPCHK(hipMalloc(&e->fold_scratch, fold_bf16x3_scratch_bytes(d)));
-  const bool f3 = e->fold_scratch && fold_bf16x3_supported(d, e->fold_mode);
+  if (!e->fold_scratch && fold_bf16x3_supported(d, e->fold_eff)) HIPCHK(hipMalloc(&e->fold_scratch, fold_bf16x3_scratch_bytes(d)));
+  const bool f3 = e->fold_scratch && fold_bf16x3_supported(d, e->fold_eff);
   float *pkw[2] = {e->pk_fold[0], need_pk2 ? e->pk_fold[1] : nullptr};
   HIPCHK(launch_fold(d, e->params, e->wmT, pkw, pack_x, e->stream, probe(e, "k_fold"),
                      pack_x ? probe(e, "k_pack_foldx") : LaunchProbe(), f3 ? e->fold_scratch : nullptr,
-                     f3 ? probe(e, "k_split3") : LaunchProbe(), f3 && e->planes_fresh, e->fold_mode));
+                     f3 ? probe(e, "k_split3") : LaunchProbe(), f3 && e->planes_fresh, e->fold_eff));
   if (pack_x) e->foldx_fresh = true;
   e->fold_dirty = false;
   e->pk2_fresh = need_pk2;
@@ -616,7 +630,9 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
   HIPCHK(hipSetDevice(device));
   klstm_engine *e = new klstm_engine();
   e->ncu = prop.multiProcessorCount;
-  e->fold_mode = fold_default_mode();
+  e->fold_mode = e->fold_eff = fold_default_mode();
+  e->rg = range_guard_create();
+  range_guard_set_note([](const char *m) { note("%s", m); });
   e->I = input_dim; e->C = cell_dim; e->R = recur_dim; e->S = num_stream; e->device = device;
   e->nparams = e->o_wm() + (long)e->R * e->C;
   if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
@@ -693,6 +709,7 @@ void klstm_destroy(klstm_engine *e) {
   if (e->wrmT_l) (void)hipFree(e->wrmT_l);
   if (e->gran_xb) (void)hipFree(e->gran_xb);
   if (e->tickets) (void)hipFree(e->tickets);
+  range_guard_destroy(e->rg);
   if (e->pstat_host) (void)hipHostFree(e->pstat_host);
   for (float *p : e->stage) if (p) (void)hipFree(p);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1021,6 +1038,8 @@ static klstm_status run_graphed(klstm_engine *e, const klstm_engine::Key &key, F
 // The body of klstm_propagate (arguments checked by the caller): also what recover() runs a minibatch again with.
 static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int in_stride, float *out, int out_stride) {
   const int T = rows / e->S;
+  const RangeGuardScope rgs(e->rg);                   // (this engine's fp16-plane products look at this engine's range guard)
+  { const klstm_status ks = knobs_seen(e); if (ks != KLSTM_OK) return ks; }
   klstm_status st = ensure_planes(e, T);
   if (st != KLSTM_OK) return st;
   e->fwd_persist = persist_wanted(e, T);
@@ -1066,7 +1085,9 @@ static klstm_status do_backpropagate(klstm_engine *e, const float *in, int in_st
                                      float *in_diff, int in_diff_stride, int rows, float momentum, int flags) {
   (void)rows;
   const int T = e->T_fwd;
+  const RangeGuardScope rgs(e->rg);
   klstm_status st;
+  { const klstm_status ks = knobs_seen(e); if (ks != KLSTM_OK) return ks; }
   e->ar_marked = false;          // (new gradient products: whatever all-reduce the blob went through belongs to an earlier minibatch)
   // (Launch-per-step BPTT kernels behind a persistent forward launch nobody has looked at yet are NOT waited for: if that launch gave
   //  up they compute on invalid planes, but what they write -- derivative planes, in_diff -- is rewritten when the minibatch is run
@@ -1258,14 +1279,15 @@ klstm_status klstm_apply_momentum(klstm_engine *e, float momentum) {
 }  // extern "C"
 static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
+  const RangeGuardScope rgs(e->rg);
   // theta -= lr * corr, and the transposed copies the BPTT kernels read are refreshed in the same pass
   if (e->grads_pending) {
     // KLSTM_BPTT_FUSE_UPDATE: gradient products, momentum, Update and the transposed copies in one pass
     e->grads_pending = false;
     const Dims dg{e->I, e->C, e->R, e->S, e->gp_T};
     GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
-    e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d, e->fold_mode);
-    if (e->planes_fresh) { fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane); u.split_mode = e->fold_mode == 2 ? 2 : 1; }
+    e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d, e->fold_eff);
+    if (e->planes_fresh) { fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane); u.split_mode = e->fold_eff == 2 ? 2 : 1; }
     HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
                         probe(e, "k_grads_update"), false, &u, e->pctrl));
   } else {
@@ -1273,11 +1295,11 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
     e->mmt_pending = false;
     // (data-parallel order: gradient -> all-reduce -> this) the planes of the fold operands come out of the same pass
     GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
-    e->planes_fresh = e->fold_scratch && (e->fwd_ms || (e->fwd_folded && fold_bf16x3_supported(d, e->fold_mode))) &&
+    e->planes_fresh = e->fold_scratch && (e->fwd_ms || (e->fwd_folded && fold_bf16x3_supported(d, e->fold_eff))) &&
                       update_repack_vectorised(d, e->params, e->corr, fold_grad, e->wrT, e->wmT, e->wxT);
     if (e->planes_fresh) {
       fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
-      u.split_mode = e->fwd_ms ? 3 : e->fold_mode == 2 ? 2 : 1;        // (the many-stream bf16 launch: the operands themselves as bf16)
+      u.split_mode = e->fwd_ms ? 3 : e->fold_eff == 2 ? 2 : 1;        // (the many-stream bf16 launch: the operands themselves as bf16)
     }
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
                                 e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr,
@@ -1383,6 +1405,12 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     if (value != 0 && !e->pk[0]) return fail(KLSTM_ERR_SHAPE, "bf16 mode needs I, C, R multiples of 8");
     e->use_bf16 = value != 0;
     HIPCHK(launch_pack(Dims{e->I, e->C, e->R, e->S, 0}, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream));
+    // Up to 8 streams the fp32 engine runs the weights-resident chain (one launch per direction); bf16 operand mode has no such chain
+    // below 9 streams and steps one launch per frame: SLOWER than fp32 there (measured at 40/800/512, T = 20: 4 streams 291 us per
+    // minibatch against 156 in fp32, 8 streams 312 against 238; profiles/r04_scale_probe.txt).  bf16 pays from 9 streams on.
+    if (e->use_bf16 && e->S <= 8)
+      note("bf16 operand mode at %d streams: slower than fp32 here (no weights-resident bf16 chain below 9 streams; fp32 runs one launch "
+           "per direction up to 8 streams) -- about 1.9x the time per minibatch at 4 streams, 1.3x at 8; it pays from 9 streams on", e->S);
     return KLSTM_OK;
   }
   if (!strcmp(key, "fat_fine")) {
@@ -1395,6 +1423,12 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
     set_small_nt2(value);
+    return KLSTM_OK;
+  }
+  if (!strcmp(key, "gemm_nt2")) {        // 0: the batched bf16 products around the many-stream chains on round 4's kernel + reduction launches
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    e->use_nt2 = value != 0;
     return KLSTM_OK;
   }
   if (!strcmp(key, "fold")) {            // -1 auto, 0 never, 1 whenever NumStream <= small_max
@@ -1425,7 +1459,6 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else if (!strcmp(key, "persist_ncu")) e->ncu = value;                                       // test hook: pretend the device has this many CUs
     else if (!strcmp(key, "persist_verify")) e->persist_verify = value != 0;
     else if (!strcmp(key, "persist_verify_spin")) e->verify_spin = value != 0;
-    else if (!strcmp(key, "gemm_nt2")) { HIPCHK(hipStreamSynchronize(e->stream)); drop_graphs(e); e->use_nt2 = value != 0; }
     else if (!strcmp(key, "persist_cooldown")) { e->cooldown_len = value < 0 ? 0 : value; e->cooldown_cur = 0; if (e->cooldown > e->cooldown_len) e->cooldown = e->cooldown_len; }
     else return fail(KLSTM_ERR_ARG, "klstm_set_option: unknown key '%s'", key);
     return KLSTM_OK;
@@ -1464,8 +1497,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
   }
   if (!strcmp(key, "fold_direct")) {             // 0: the fold product on the generic 64x64-tile kernel
     set_fold_direct(value);
-    knob_changed_everywhere(-1);
-    { std::lock_guard<std::mutex> lk(g_engines_mu); for (klstm_engine *x : g_engines) x->fold_dirty = true; }
+    knob_changed_everywhere();
     HIPCHK(hipSetDevice(e->device));
     return KLSTM_OK;
   }
@@ -1473,19 +1505,20 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
-    e->fold_mode = value < 0 ? 0 : value > 2 ? 2 : value;   // (the planes at hand are in another format)
+    e->fold_mode = e->fold_eff = value < 0 ? 0 : value > 2 ? 2 : value;   // (the planes at hand are in another format)
     e->planes_fresh = false;
     e->fold_dirty = true;
     return KLSTM_OK;
   }
-  if (!strcmp(key, "fp16_products")) {           // 0: nothing runs on fp16 planes; 1: the defaults again (and the range guard's counters cleared).  Process-wide
-    set_fold_bf16x3(value ? 2 : 1);           // (the fold product keeps the matrix cores: three bf16 planes have the fp32 range)
-    if (value) { set_direct_nt_shape(2, 1); redo_clear(); } else set_direct_nt_shape(0, 0);
-    set_outer_f16(value ? 1 : 0);
-    set_skinny_f16(value ? 1 : 0);
-    set_skinny_f16_pair(value ? 1 : 0);
-    knob_changed_everywhere(value ? 2 : 1);
-    HIPCHK(hipSetDevice(e->device));
+  if (!strcmp(key, "fp16_products")) {           // 0: nothing of THIS engine -- and no stateless klstm_affine_* call on this device -- runs on fp16 planes;
+    HIPCHK(hipSetDevice(e->device));             // 1: the defaults again, the guards' counters and cool-downs cleared.  Other engines keep their own state.
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    range_guard_reset(e->rg, value != 0);
+    range_guard_reset(nullptr, value != 0);
+    e->fold_mode = e->fold_eff = value ? 2 : 1;  // (the fold product keeps the matrix cores: three bf16 planes have the fp32 range)
+    e->planes_fresh = false;
+    e->fold_dirty = true;
     return KLSTM_OK;
   }
   if (!strcmp(key, "fuse_x")) {
@@ -1512,13 +1545,16 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
   { klstm_status ss = klstm_synchronize(e); if (ss != KLSTM_OK) return ss; }
   // event counters (no option needed): give-ups of the persistent chain and what became of them; range-guard events of the fp16-plane products
   {
+    auto ev = [&](int which) { return range_guard_events(e->rg, which) + range_guard_events(nullptr, which); };
     const struct { const char *name; long v; } ctr[] = {
         {"persist_giveups", e->n_giveups}, {"persist_replayed", e->n_replayed}, {"persist_dropped", e->n_dropped},
         {"persist_launches", (long)e->pseq}, {"persist_cooldown", (long)e->cooldown},
-        {"fp16_redo", (long)redo_count(REDO_FOLD) + redo_count(REDO_NT) + redo_count(REDO_OUTER) + redo_count(REDO_SKINNY)},
-        {"fp16_redo_fold", (long)redo_count(REDO_FOLD)}, {"fp16_redo_nt", (long)redo_count(REDO_NT)},
-        {"fp16_redo_outer", (long)redo_count(REDO_OUTER)}, {"fp16_redo_skinny", (long)redo_count(REDO_SKINNY)},
-        {"fold_mode", (long)e->fold_mode}};
+        // range-guard events: this engine's own products + the stateless klstm_affine_* calls made on this device (its default guard)
+        {"fp16_redo", ev(REDO_FOLD) + ev(REDO_NT) + ev(REDO_OUTER) + ev(REDO_SKINNY)},
+        {"fp16_redo_fold", ev(REDO_FOLD)}, {"fp16_redo_nt", ev(REDO_NT)},
+        {"fp16_redo_outer", ev(REDO_OUTER)}, {"fp16_redo_skinny", ev(REDO_SKINNY)}, {"fp16_redo_own", range_guard_events(e->rg, REDO_FOLD) +
+         range_guard_events(e->rg, REDO_NT) + range_guard_events(e->rg, REDO_OUTER) + range_guard_events(e->rg, REDO_SKINNY)},
+        {"fold_mode", (long)e->fold_eff}};
     for (const auto &c : ctr)
       if (!strcmp(kernel, c.name)) { *total_us = 0.0; *launches = c.v; return KLSTM_OK; }
     if (!strcmp(kernel, "dp_updates_left_out")) {      // Updates every rank left out because SOME rank's gradient of that minibatch was not real

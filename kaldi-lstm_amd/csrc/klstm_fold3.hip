@@ -369,24 +369,96 @@ void set_fold_bf16x3(int v) { g_fold_bf16x3 = v < 0 ? 0 : v > 2 ? 2 : v; }
 int fold_default_mode() { return g_fold_bf16x3; }
 bool fold_bf16x3_supported(const Dims &d, int mode) { return mode != 0 && d.C % 4 == 0 && d.R % 32 == 0; }
 
-// ---- event counters of the range guard (klstm_kernels.h): REDO_WORDS host-mapped words, portable across devices ----
-static unsigned *g_redo_host = nullptr, *g_redo_dev = nullptr;
-static std::once_flag g_redo_once;
-unsigned *redo_counters() {
-  std::call_once(g_redo_once, [] {
-    void *hp = nullptr, *dp = nullptr;
-    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return; }
-    memset(hp, 0, 64);
-    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(hp); return; }
-    g_redo_host = static_cast<unsigned *>(hp); g_redo_dev = static_cast<unsigned *>(dp);
-  });
-  return g_redo_dev;
+// ---- the range guard's state (klstm_kernels.h): per guard REDO_WORDS host-mapped event words (portable across devices), what has been
+// answered of them, and the cool-down of every product family ----
+struct RangeGuard {
+  unsigned *host = nullptr, *dev = nullptr;
+  unsigned seen[REDO_WORDS] = {0};
+  long events[REDO_WORDS] = {0};
+  long cool[REDO_WORDS] = {0};          // looks left on the fp32-range kernel
+  long cool_len[REDO_WORDS] = {0};      // length of the cool-down in progress / the last one
+  long clean[REDO_WORDS] = {0};         // fp16-plane looks since the last re-arm
+  bool enabled = true;
+  std::mutex mu;
+};
+static long guard_base_len(int which) { return which == REDO_FOLD ? 64 : 2048; }   // looks: one per fold product (= per Update); a few per stateless call
+static void (*g_guard_note)(const char *) = nullptr;
+void range_guard_set_note(void (*fn)(const char *)) { g_guard_note = fn; }
+RangeGuard *range_guard_create() {
+  RangeGuard *g = new RangeGuard();
+  void *hp = nullptr, *dp = nullptr;
+  if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return g; }   // (no words: nothing is counted)
+  memset(hp, 0, 64);
+  if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(hp); return g; }
+  g->host = static_cast<unsigned *>(hp); g->dev = static_cast<unsigned *>(dp);
+  return g;
+}
+void range_guard_destroy(RangeGuard *g) {
+  if (!g) return;
+  if (g->host) (void)hipHostFree(g->host);
+  delete g;
+}
+static thread_local RangeGuard *t_guard = nullptr;
+RangeGuard *range_guard_exchange(RangeGuard *g) { RangeGuard *p = t_guard; t_guard = g; return p; }
+static RangeGuard *device_default_guard() {
+  static std::mutex mu;
+  static RangeGuard *per_device[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
+  std::lock_guard<std::mutex> lk(mu);
+  if (!per_device[dev]) per_device[dev] = range_guard_create();
+  return per_device[dev];
+}
+static RangeGuard *current_guard() { return t_guard ? t_guard : device_default_guard(); }
+unsigned *redo_counters() { return current_guard()->dev; }
+void range_guard_reset(RangeGuard *g, bool enabled) {
+  if (!g) g = device_default_guard();
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (int i = 0; i < REDO_WORDS; i++) {
+    if (g->host) reinterpret_cast<volatile unsigned *>(g->host)[i] = 0u;
+    g->seen[i] = 0; g->events[i] = 0; g->cool[i] = 0; g->cool_len[i] = 0; g->clean[i] = 0;
+  }
+  g->enabled = enabled;
+}
+long range_guard_events(RangeGuard *g, int which) {
+  if (!g) g = device_default_guard();
+  if (which < 0 || which >= REDO_WORDS) return 0;
+  std::lock_guard<std::mutex> lk(g->mu);
+  const unsigned c = g->host ? reinterpret_cast<volatile unsigned *>(g->host)[which] : 0u;
+  return g->events[which] + (long)(c - g->seen[which]);
 }
 unsigned redo_count(int which) {
-  return g_redo_host && which >= 0 && which < REDO_WORDS ? reinterpret_cast<volatile unsigned *>(g_redo_host)[which] : 0u;
-}
-void redo_clear() {
-  if (g_redo_host) for (int i = 0; i < REDO_WORDS; i++) reinterpret_cast<volatile unsigned *>(g_redo_host)[i] = 0u;
+  RangeGuard *g = current_guard();
+  if (which < 0 || which >= REDO_WORDS) return 0u;
+  static const char *names[REDO_WORDS] = {"the fold product W_gifo_r W_r_m", "the wide output-layer product (klstm_affine_propagate)",
+                                          "the wide gradient product (klstm_affine_gradient / _update)",
+                                          "the skinny products (klstm_affine_backpropagate, d_r / in_diff of a wide layer)", "?", "?", "?", "?"};
+  char msg[320];
+  msg[0] = 0;
+  unsigned ret;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (!g->enabled) return 1u;
+    const unsigned c = g->host ? reinterpret_cast<volatile unsigned *>(g->host)[which] : 0u;
+    if (c != g->seen[which]) {                       // new events: (re-)start the cool-down
+      g->events[which] += (long)(c - g->seen[which]);
+      g->seen[which] = c;
+      const long base = guard_base_len(which);
+      if (g->cool_len[which] < base || g->clean[which] >= g->cool_len[which]) g->cool_len[which] = base;
+      else g->cool_len[which] = g->cool_len[which] >= (1L << 19) ? (1L << 20) : 2 * g->cool_len[which];
+      g->cool[which] = g->cool_len[which];
+      g->clean[which] = 0;
+      snprintf(msg, sizeof(msg), "range guard: %s met an operand beyond the fp16 range (recomputed in fp32 where it mattered); it stays on its "
+               "fp32-range kernel for the next %ld looks, then the fp16 planes are tried again", names[which], g->cool[which]);
+    }
+    if (g->cool[which] > 0) {
+      g->cool[which]--;
+      ret = 1u;
+      if (g->cool[which] == 0 && !msg[0]) snprintf(msg, sizeof(msg), "range guard: %s is back on its fp16 planes", names[which]);
+    } else { g->clean[which]++; ret = 0u; }
+  }
+  if (msg[0] && g_guard_note) g_guard_note(msg);
+  return ret;
 }
 size_t fold_bf16x3_scratch_bytes(const Dims &d) { return (size_t)3 * 5 * d.C * d.R * sizeof(unsigned short); }
 

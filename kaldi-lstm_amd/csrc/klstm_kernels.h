@@ -46,14 +46,32 @@ struct BwdPtrs {
 struct LaunchProbe { hipEvent_t start = nullptr, stop = nullptr; };
 
 // Range guard of the fp16-plane products (klstm_math.h nonfinite_probe): a wave whose accumulators came out non-finite -- an operand
-// beyond the fp16 range -- recomputes its outputs in plain fp32 and counts the event in one of these host-mapped words (pinned,
-// portable; readable on the host without a synchronisation).  The launchers look at the word of their product before every
-// launch and take that product to its fp32-range kernel once it is non-zero (the fold product: three bf16 planes); option
-// "fp16_products" = 1 clears the words and returns to the defaults.
+// beyond the fp16 range -- recomputes its outputs in plain fp32 and counts the event in a host-mapped word (pinned, portable; readable
+// on the host without a synchronisation).  The words and what follows from them are state of a RangeGuard: every engine has its own
+// (the launches an engine makes run with the engine's guard current on the calling thread), the stateless klstm_affine_* calls use
+// the calling device's default guard -- one engine's overflow does not change another engine's kernels.  A product family whose
+// word moved runs on its fp32-range kernel (the fold product: three bf16 planes) for a cool-down of `cool_len` looks, then the
+// fp16 planes are tried again; a trigger that follows a re-arm closely doubles the cool-down (up to 2^20), a clean run as long
+// as the last cool-down resets it -- like the persistent chain's give-up cool-down.  klstm_set_option "fp16_products" = 0 switches a
+// guard off (all families on their fp32-range kernels), = 1 clears it.
 enum { REDO_FOLD = 0, REDO_NT = 1, REDO_OUTER = 2, REDO_SKINNY = 3, REDO_WORDS = 8 };
-unsigned *redo_counters();          // device-visible address of the REDO_WORDS words, or nullptr (then nothing is counted)
-unsigned redo_count(int which);     // host read
-void redo_clear();
+struct RangeGuard;
+RangeGuard *range_guard_create();
+void range_guard_destroy(RangeGuard *g);
+RangeGuard *range_guard_exchange(RangeGuard *g);     // make g the calling thread's current guard (null: the device default); returns the previous one
+struct RangeGuardScope {                            // RAII form of the above
+  RangeGuard *prev;
+  explicit RangeGuardScope(RangeGuard *g) : prev(range_guard_exchange(g)) {}
+  ~RangeGuardScope() { range_guard_exchange(prev); }
+  RangeGuardScope(const RangeGuardScope &) = delete;
+  RangeGuardScope &operator=(const RangeGuardScope &) = delete;
+};
+void range_guard_reset(RangeGuard *g, bool enabled);  // g null: the current device's default guard.  Counters, latches and cool-downs cleared
+long range_guard_events(RangeGuard *g, int which);    // events counted so far (g null: the current device's default guard)
+void range_guard_set_note(void (*fn)(const char *));  // where "family X met an operand beyond the fp16 range" / "re-armed" remarks go
+unsigned *redo_counters();          // device-visible address of the current guard's REDO_WORDS words, or nullptr (then nothing is counted)
+unsigned redo_count(int which);     // one LOOK at a family of the current guard: non-zero = keep to the fp32-range kernel (new events, a
+                                    // cool-down in progress -- this look counts towards it --, or the guard is switched off)
 
 // forward step t (1..T).  fuse_x: the x_t * W_gifo_x^T + bias term (...streams.h:246,:259) is
 // contracted inside the step kernel (x = in rows of frame t); otherwise gifo already holds it.

