@@ -116,7 +116,7 @@ def kernel_alg_bytes(name, S, T):
 
 def kernel_streamed_bytes(name, S):
     """Bytes this launch HAS to move in the multi-launch design: its whole weight operand (nothing on-chip survives a kernel
-    boundary) plus the activation rows read and written (DESIGN.md section 3)."""
+    boundary) plus the activation rows read and written (DESIGN.md section 4)."""
     C, R, I = C_DIM, R_DIM, I_DIM
     w = {"k_gates_step": 4 * C * (R + I), "k_proj_step": R * C, "k_dr_step": (R + I) * 4 * C, "k_dm_step": C * R,
          "k_gates_fold": 4 * C * (C + I), "k_dmf_step": C * 4 * C}.get(name)
@@ -156,6 +156,7 @@ def pmc_profile(S=4):
             docs.append((json.load(open(f)), os.path.relpath(f, ROOT)))
         except Exception:
             pass
+    docs = [d for d in docs if d[0].get("config") not in ("c4", "c5") and d[0].get("kernels")]      # (those belong to bench_configs.py)
     same = [d for d in docs if d[0].get("streams_per_gpu", 4) == S]
     return same[-1] if same else docs[-1] if docs else (None, None)
 

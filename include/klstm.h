@@ -178,7 +178,7 @@ klstm_status klstm_comm_count(void *comm, int *nranks);       /* ncclCommCount: 
 klstm_status klstm_allreduce_grads(klstm_engine *e, void *rccl_comm);
 klstm_status klstm_allreduce_buffer(float *buf_dev, size_t n, void *rccl_comm, void *hip_stream);
 
-/* One-shot all-reduce over peer-mapped blobs (kaldi-lstm_amd/csrc/klstm_oneshot.hip; DESIGN.md 7).  PREPARED AND OFF: nothing in
+/* One-shot all-reduce over peer-mapped blobs (kaldi-lstm_amd/csrc/klstm_oneshot.hip; DESIGN.md 8).  PREPARED AND OFF: nothing in
  * the library calls it, and it has never run across devices (one-GPU lease) -- only as a 1-rank self-loop and between two
  * processes on one GPU.  Every rank: create (its own blob of n floats, hipMalloc memory), export two handles, hand them to every
  * peer by any means, connect with everybody's handles in rank order, then once per minibatch klstm_oneshot_allreduce (in place,
@@ -301,9 +301,9 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  launches per call on the launch-per-step chains).  1: a graph per call unless the call is one or
  *                  two launches anyway (persistent chain); 2: always
  *   "fold"    -1/0/1  folded recurrence W_rm = W_gifo_r * W_r_m: one kernel per step and direction instead of two
- *                  (DESIGN.md 3a); -1 = auto (NumStream <= 8 and >= 12 frames per stream), 1 = whenever NumStream <=
+ *                  (DESIGN.md 4a); -1 = auto (NumStream <= 8 and >= 12 frames per stream), 1 = whenever NumStream <=
  *                  16 and I, C, R are multiples of 8.  Same results up to fp32 summation order.
- *   "persist" -1/0/1/2  weights-resident persistent chain for NumStream <= 8 (DESIGN.md 3c): ONE launch per direction runs
+ *   "persist" -1/0/1/2  weights-resident persistent chain for NumStream <= 8 (DESIGN.md 4a): ONE launch per direction runs
  *                  all T steps with the folded operands held in registers and the per-step all-to-all done inside the
  *                  launch.  0 = off, 1 = forward launch only, 2 = both directions whenever the shape allows, -1 = auto (both
  *                  directions from 8 frames per stream).  Same results up to fp32 summation order.  Needs one compute unit
@@ -343,7 +343,7 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  "persist_test_stall_fwd" / "persist_test_stall_bwd" (workgroup 0 withholds its publish of that step:
  *                  forces the give-up path)
  *   "fold_bf16x3"  0/1/2  the fold product W_rm = W_gifo_r * W_r_m of THIS engine on the 16-bit matrix cores at fp32 accuracy
- *                  (DESIGN.md 3d; every partial product exact in fp32, fp32 accumulation): 2 (default) = two fp16 planes per
+ *                  (DESIGN.md 4b; every partial product exact in fp32, fp32 accumulation): 2 (default) = two fp16 planes per
  *                  operand, three products, dropped terms ~7e-7 relative; 1 = three bf16 planes, six products, dropped terms
  *                  below 2^-24; 0 = the fp32 MFMA kernel.  RANGE: identical to the reference's fp32 products in every mode -- in
  *                  mode 2 a parameter at or beyond 65520 (the fp16 range) is noticed by the product itself (range guard, below),
@@ -351,7 +351,7 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  carry an absolute error of 2^-36 (not a relative one of 2^-22): nothing for a weight matrix whose largest
  *                  entries are above 1e-4.  "fold_direct" 0: the generic tile kernel (process-wide)
  *   "direct_nt_shape", "outer_f16", "skinny_f16", "skinny_f16_pair"  the three products of a WIDE AffineTransform at few frames
- *                  (the output layer of a small-minibatch step; DESIGN.md 9 item 5) run on the f16 matrix cores at fp32 accuracy:
+ *                  (the output layer of a small-minibatch step; DESIGN.md 4f) run on the f16 matrix cores at fp32 accuracy:
  *                  both operands split into two fp16 numbers on the fly (x = h1 + h2 / 2048), three products with fp32
  *                  accumulation, the dropped term ~2^-22 relative; measured error against float64 at or below the fp32 MFMA
  *                  kernels'.  RANGE GUARD: the numeric range is the reference's (fp32).  Upper side: an operand at or beyond
@@ -383,7 +383,7 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
                   this engine's only; "fold_mode" = the fold product's format as it runs (1 while latched)
    "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
- *                  accumulate, fp32 masters (DESIGN.md 3b; the reference is fp32 only).  Needs I, C, R multiples of 8.
+ *                  accumulate, fp32 masters (DESIGN.md 4e; the reference is fp32 only).  Needs I, C, R multiples of 8.
  *   "fuse_x"  -1/0/1  x(t) W_gifo_x^T inside the step kernel (auto: NumStream <= 16) or as one batched product (:246)
  *   "vector", "fat", "small_max", "small_nt2"  kernel-family selection for A-B experiments and tests
  *   "profile" 0/1  run every kernel eagerly between its own start/stop HIP events on the

@@ -357,7 +357,7 @@ static bool fold_wanted(const klstm_engine *e, int T) {
   return e->use_fold == 1 ? T >= 2 : (T >= 12 && e->S <= 8);
 }
 static bool use_fused_x(const klstm_engine *e);
-// persistent chain (DESIGN.md 3c): needs the folded operands, up to 8 streams, the x term inside the step or -- wide inputs --
+// persistent chain (DESIGN.md 4a): needs the folded operands, up to 8 streams, the x term inside the step or -- wide inputs --
 // from the batched product; one launch per direction covers all T steps; auto = on from 8 frames per stream; one compute
 // unit per workgroup (an engine on a smaller device or partition keeps to one launch per step)
 static bool persist_bwd_wanted(const klstm_engine *e, int T) {

@@ -838,7 +838,7 @@ hipError_t launch_skinny16_pair(int M, int K, const float *A1, const float *A2, 
 // The same NT product with the M rows of A SHARED by the four waves of a workgroup through LDS (AffineTransform::PropagateFnc of
 // the output layer, 80 x 16624 over K = 512): k_direct_nt makes every wave fetch all of A itself, so either half the SIMDs idle
 // (two 16-column blocks per wave: 520 waves, 41 k MFMA clocks each) or every CU pulls 650 KB (one block per wave) -- and a CU
-// ingests 30-55 GB/s (DESIGN.md 3c / 3d).  Here a workgroup = 4 waves x one 16-column block; per 32-k chunk the 256 threads
+// ingests 30-55 GB/s (DESIGN.md 4a / 3d).  Here a workgroup = 4 waves x one 16-column block; per 32-k chunk the 256 threads
 // stage the 10 KB of A once (global -> registers two chunks ahead -> LDS, rows padded to 36 floats: the operand reads of 16
 // rows x 4 k-groups are conflict-free), ONE barrier per chunk, two LDS buffers; B stays register-direct with a ring of 4 chunks.
 // Per CU: 160 KB of A + 128 KB of B instead of 448-650 KB.  (Round 2 tried this with one chunk of lead and measured 48 us: the

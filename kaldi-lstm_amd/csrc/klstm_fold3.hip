@@ -27,7 +27,7 @@
 //                   one stage = 3 planes x (128 + 96) rows x 64 B = 42 KB, brought in by LDS-DMA
 //                   (global_load_lds_dwordx4: 16 rows x 64 B per wave instruction, no registers) issued by FOUR LOADER WAVES,
 //                   three buffers, ONE barrier per stage; the MFMA waves read the next stage's operands into a second register
-//                   set under the current stage's MFMAs (measurements: DESIGN.md 3d, tools/fold3_probe.hip).
+//                   set under the current stage's MFMAs (measurements: DESIGN.md 4b, tools/fold3_probe.hip).
 //                   LDS rows are 64 B; the 16-byte k-group of row r sits in slot kg ^ ((-(r >> 2)) & 3)
 //                   (swizzle applied on the SOURCE side of the DMA, whose destination is lane-linear): the ds_read_b128 of
 //                   an MFMA operand (16 rows x 4 k-groups) touches every bank quad once per 16-lane group.

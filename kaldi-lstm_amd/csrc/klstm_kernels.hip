@@ -3319,7 +3319,7 @@ hipError_t launch_bwd_tail(const Dims &d, const float *dgifo, const float *wr, c
   int kl = 0;
   int ks = gemm_splitk_plan(M, d.R, K4, &kl);
   // few frames: both products on the f16 matrix cores at fp32 accuracy, all rows per wave (klstm_fold.hip k_skinny_nn16; 80 frames,
-  // 800/512/512: 16.3 us for the tiled split-K launch -> see DESIGN.md 10)
+  // 800/512/512: 16.3 us for the tiled split-K launch -> see docs/DESIGN_rounds_1-4.md 10)
   const int G16 = aligned16(dgifo) && aligned16(wr) && aligned16(wx) ? skinny16_pair_groups(M, d.R, in_diff ? d.I : 0, K4, ks) : 0;
   const GemmJob g1 = make_job(false, false, M, d.R, K4, dgifo + (size_t)2 * d.S * K4, K4, wr, d.R, 0.f, nullptr, d.R, nullptr);
   const GemmJob g2 = make_job(false, false, M, d.I, K4, dgifo + (size_t)d.S * K4, K4, wx, d.I, 0.f, nullptr, d.I, nullptr);

@@ -22,7 +22,7 @@
 // under the 144 MFMAs of the current one.  Wave 0 also sums the strip's columns of out_diff (the bias gradient: no second launch).
 // The epilogue is the store (gradient), or  corr = mmt * corr + G; W -= lr * corr; bias -= lr_b * bias_corr  (Update in the same
 // pass: template flag UPD, the tile's rows of corr and W brought in by LDS-DMA under its MFMAs).
-// 80 x 16624 x 512: 29.9 -> 16.4 us (gradient), 42.1 -> 33.2 us (Update); DESIGN.md 9 item 5 has the ablations and dead ends.
+// 80 x 16624 x 512: 29.9 -> 16.4 us (gradient), 42.1 -> 33.2 us (Update); DESIGN.md 4f has the ablations and dead ends.
 // (First version, kept in the history: planes written k-contiguous by a prep launch, 16-byte operand loads from them: 8.9 + 26 us
 //  -- every 128-byte line of the planes fetched twice through a 32 KB L1, 200 MB of operand ingest.)
 // Range: every column of out_diff is scaled by its own power of two before the split (see the kernel), `in` is split as it is; an

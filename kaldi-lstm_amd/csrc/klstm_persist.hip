@@ -1,5 +1,5 @@
 // kaldi-lstm_amd/csrc/klstm_persist.hip -- weights-RESIDENT recurrence chain (engine option "persist"), FORWARD direction, up
-// to 8 streams (the backward direction: klstm_persist_bwd.hip); the default chain from 1 to 8 streams (DESIGN.md 3c).
+// to 8 streams (the backward direction: klstm_persist_bwd.hip); the default chain from 1 to 8 streams (DESIGN.md 4a).
 //
 // The launch-per-step chain (klstm_kernels.hip) re-fetches its whole weight operand (~10.5 MB at 40/800/512) in every one
 // of the 2T step kernels because nothing on-chip survives a kernel boundary: 12x the algorithmic HBM traffic of a

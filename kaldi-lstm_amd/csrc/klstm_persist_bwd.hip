@@ -27,7 +27,7 @@
 // Only d_m travels; dgifo is recomputed by every workgroup (replicas are bit-identical: same instruction sequence on the
 // same inputs).  Shipping dgifo instead (each workgroup computing only its own cells) would quadruple the swept bytes
 // (S x 4C values, 68-77 KB per workgroup and pass even in 16-byte {tag, 3 x fp32} granules) for no shorter chain: after the
-// sweep a replicated pair costs five multiply-adds (DESIGN.md 3c).
+// sweep a replicated pair costs five multiply-adds (DESIGN.md 4a).
 // 5..8 streams: two groups of 4 against the same resident weights, each with its own granule slots -- as two INTERLEAVED chains
 // (k_bwd_persist2i below: 101 us per launch at 8 streams) or, option "persist_bwd_interleave" = 0, one chain after the other
 // (k_bwd_persist2: 129 us).

@@ -3,7 +3,7 @@
 // next #4: "build the many-stream weights-resident forward chain -- stop sizing it".
 //
 // The launch-per-step chain spends 4.2-5.0 us per step KERNEL at 32 streams -- the price of a dependent launch that touches
-// memory, not of the step's work: two of them per forward step (gates :275-309, projection :312).  Here ONE
+// memory, not of the step's work (docs/DESIGN_rounds_1-4.md 9 item 1): two of them per forward step (gates :275-309, projection :312).  Here ONE
 // launch runs all T steps of the folded recurrence
 //     a(t) = [x(t) W_gifo_x^T + b] + W_rm m(t-1),   W_rm = W_gifo_r W_r_m        (:275 with r(t-1) = W_r_m m(t-1), :312)
 // for up to 32 streams: the x term is the batched product of the reference (:246, :259; already in the gifo plane when the launch

@@ -913,7 +913,7 @@ def test_stacked_net_fused_single_rank_equals_the_two_pass_path():
     """DataParallelNnet(fuse_single_rank=True) on one rank: every layer runs gradient + momentum + step as ONE pass
     (KLSTM_BPTT_FUSE_UPDATE in the LSTM engines, klstm_affine_update in the output layer -- Kaldi's Component::Backpropagate
     order) instead of gradient -> blob -> momentum -> step.  Same parameters after three minibatches as the two-pass net
-    (the LSTM engines bit-identical, DESIGN 3e; the output layer to fp32 rounding: it adds momentum*corr + grad in another order),
+    (the LSTM engines bit-identical, DESIGN 4c; the output layer to fp32 rounding: it adds momentum*corr + grad in another order),
     and the same loss statistics."""
     import kaldi_lstm_amd as k
     from tests import nnet_twins as tw

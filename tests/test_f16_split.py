@@ -1,5 +1,5 @@
 """Numerics of the two-plane fp16 split behind the matrix-core products (kaldi-lstm_amd/csrc/klstm_math.h f16_split2 / f16_split2_pair;
-DESIGN.md 3d, 9 item 5), restated in numpy -- no GPU needed.  x = h1 + h2 / 2048 with h1 = fp16(x) (round to nearest even) and
+DESIGN.md 4b, 9 item 5), restated in numpy -- no GPU needed.  x = h1 + h2 / 2048 with h1 = fp16(x) (round to nearest even) and
 h2 = fp16((x - h1) * 2048); the product kernels add a1 b1 + (a1 b2 + a2 b1) / 2048 in fp32 and drop a2 b2 / 2048^2."""
 import numpy as np
 

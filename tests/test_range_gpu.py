@@ -2,7 +2,7 @@
 
 The reference multiplies in fp32 (cblas_sgemm / cublasSgemm, google/matrix/kaldi-matrix.cc:160-175; the products of
 google/nnet/bd-nnet-lstm-projected-streams.h:246,275,312,391,408,457): any finite fp32 operand is legal.  Four products here run
-on two fp16 planes per operand by default (x = h1 + h2 / 2048; DESIGN.md 3d, 9 item 5).  What keeps them inside the reference's
+on two fp16 planes per operand by default (x = h1 + h2 / 2048; DESIGN.md 4b, 9 item 5).  What keeps them inside the reference's
 range:
 
 * upper side -- the range guard (klstm_math.h): an operand at or beyond 65520 turns into Inf in its first plane, which makes every

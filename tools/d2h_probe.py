@@ -1,4 +1,4 @@
-"""DESIGN.md 3c (5), VERDICT r03 next #2: does what Xent::EvalMasked does every minibatch -- a pageable device-to-host copy of a few
+"""DESIGN.md 4a (5), VERDICT r03 next #2: does what Xent::EvalMasked does every minibatch -- a pageable device-to-host copy of a few
 scalars (google/nnet/nnet-loss.cc:110-141) -- disturb the persistent chain WITHOUT a co-tenant?  (Round 3 saw persistent launches
 start with ~30 of 200 workgroups missing while a foreign kernel's flags were polled with pageable D2H copies.)
 N minibatches of the headline workload per mode: no copy / pageable 12-byte D2H per minibatch / pinned non-blocking copy + event;

@@ -2,7 +2,7 @@
 // barrier phases; in each phase every workgroup writes WORDS floats that depend on what it read in the previous phase (sc1 stores),
 // arrives -- on ONE monotonic counter (a device-scope atomic per workgroup) or on its OWN phase-tagged flag that every other workgroup
 // watches (no shared address, no atomic; thread t polls flag t) --, spins (bounded) until all G have arrived, then reads WORDS floats another workgroup wrote
-// (sc1 loads: no cache-wide invalidate).  Prices the "launch-free chain" of DESIGN.md 9 item 1 against the 4.2-5.0 us a dependent
+// (sc1 loads: no cache-wide invalidate).  Prices the "launch-free chain" of docs/DESIGN_rounds_1-4.md 9 item 1 against the 4.2-5.0 us a dependent
 // launch costs.  Diagnostic only; not part of libklstm.
 //   usage: gridbar_probe [steps=200] [threads=256] [words_per_thread=4]
 #include <hip/hip_runtime.h>

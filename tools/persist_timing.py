@@ -1,6 +1,6 @@
 """A/B of the recurrence chain at 40/800/512: launch-per-step folded chain vs the persistent weights-resident chain
 (option "persist"), per geometry, per stream count: whole minibatch (fwd + BPTT + update) and the per-kernel device
-times of the two chain launches.  Diagnostic."""
+times of the two chain launches.  Diagnostic (docs/DESIGN_rounds_1-4.md section 4 table)."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

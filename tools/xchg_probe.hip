@@ -3,7 +3,7 @@
 // (one sc1 store each) and then sweeps ALL N granules until every tag matches (MI355X_MICROARCH.md "allgather" row,
 // cdna_hip_programming.md Guideline 16 recipe R2).  The value published at step e+1 depends on a checksum over every
 // value of step e, so the chain is a true dependency chain and a stale read is detected by the host-side replay.
-// Diagnostic only (decides DESIGN.md section 4's persistent-chain question); not part of libklstm.
+// Diagnostic only (decides docs/DESIGN_rounds_1-4.md section 4's persistent-chain question); not part of libklstm.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
