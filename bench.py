@@ -388,8 +388,9 @@ def main():
     feats, odiff = make_inputs(S, 1234 + rank, "cuda")
     nchunk = feats.shape[0]
     same_load = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         # the same per-GPU load on ONE GPU, no collective: every rank on its own GPU, before the library's communicator exists
+        # (--force-collective: one rank through exactly this code, so that a one-GPU box exercises it)
         with torch.cuda.stream(stream):
             o_sl = torch.empty(T_BPTT * S, R_DIM, device="cuda"); i_sl = torch.empty(T_BPTT * S, I_DIM, device="cuda")
 
@@ -791,7 +792,7 @@ def main():
             res[tag] = leg
         if adapter:
             res["kaldi_adapter"] = adapter
-        if world > 1:
+        if world > 1 or args.force_collective:
             res.update(multi_gpu_summary(value, world, same_load, res.get("allreduce_us")))
         if strict:
             # the headline workload with the fold product on fp32 operands (every product of the path then is an fp32 MFMA) and on

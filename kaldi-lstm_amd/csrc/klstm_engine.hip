@@ -162,6 +162,7 @@ struct klstm_engine {
   float *ws = nullptr;     // split-K workspace of the batched d_r / in_diff products
   size_t ws_floats = 0;
   unsigned *tickets = nullptr;   // klstm_gemm16.hip: one word per output tile of a split-K launch (NT2_TICKETS words, zero between launches)
+  int fuse_update_ok = 1;  // option "fuse_update": 0 = KLSTM_BPTT_FUSE_UPDATE is ignored (gradient products and Update as separate passes; A-B runs)
   int use_nt2 = 1;         // option "gemm_nt2": the batched bf16 products on the pipelined kernel (0: round 4's kernel + reduction launches)
   bool use_bf16 = false;   // bf16 operands in the step kernels (option "bf16"); masters/planes/gradients stay fp32
   int fuse_x = -1;    // -1 auto (small NumStream), 0 batched x-projection GEMM, 1 fused into the step kernel
@@ -919,8 +920,9 @@ static klstm_status seq_forward(klstm_engine *e, const float *in, int in_stride,
 
 // May klstm_backpropagate leave the gradient products to the following klstm_update?
 static bool grads_fusable(const klstm_engine *e, int T, int flags, bool bf16_path) {
+  (void)T; (void)bf16_path;                           // (round 5: the bf16 tiles carry the fused epilogue too)
   return (flags & KLSTM_BPTT_FUSE_UPDATE) && !(flags & KLSTM_BPTT_DEFER_MOMENTUM) && e->R % 4 == 0 && e->C % 4 == 0 && e->I % 4 == 0 &&
-         !grads_bf16_tiles(Dims{e->I, e->C, e->R, e->S, T}, bf16_path);
+         e->fuse_update_ok;
 }
 static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride, const float *out_diff,
                                  int od_stride, float *in_diff, int id_stride, int T, float mmt, int flags) {
@@ -1286,10 +1288,13 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
     e->grads_pending = false;
     const Dims dg{e->I, e->C, e->R, e->S, e->gp_T};
     GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
-    e->planes_fresh = e->fold_scratch && e->fwd_folded && fold_bf16x3_supported(d, e->fold_eff);
-    if (e->planes_fresh) { fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane); u.split_mode = e->fold_eff == 2 ? 2 : 1; }
+    e->planes_fresh = e->fold_scratch && (e->fwd_ms || (e->fwd_folded && fold_bf16x3_supported(d, e->fold_eff)));
+    if (e->planes_fresh) {
+      fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
+      u.split_mode = e->fwd_ms ? 3 : e->fold_eff == 2 ? 2 : 1;        // (the many-stream bf16 launch: the operands themselves as bf16)
+    }
     HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
-                        probe(e, "k_grads_update"), false, &u, e->pctrl));
+                        probe(e, "k_grads_update"), e->gp_bf16, &u, e->pctrl));
   } else {
     const float *fold_grad = e->mmt_pending ? e->grads : nullptr;
     e->mmt_pending = false;
@@ -1423,6 +1428,11 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
     set_small_nt2(value);
+    return KLSTM_OK;
+  }
+  if (!strcmp(key, "fuse_update")) {     // 0: KLSTM_BPTT_FUSE_UPDATE is ignored (A-B runs)
+    { klstm_status gs = flush_grads(e); if (gs != KLSTM_OK) return gs; }
+    e->fuse_update_ok = value != 0;
     return KLSTM_OK;
   }
   if (!strcmp(key, "gemm_nt2")) {        // 0: the batched bf16 products around the many-stream chains on round 4's kernel + reduction launches

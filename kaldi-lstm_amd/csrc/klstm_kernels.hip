@@ -2117,6 +2117,78 @@ __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int 
     }
     __syncthreads();
   }
+  if (g.P) {
+    // Gradient product with momentum and Update folded in (launch_grads + GradsUpdate on the bf16 tiles; N, ldc, ldct multiples of 4,
+    // 16-byte aligned blobs) -- the epilogue of gemm_tile_impl on this tile shape: the 128-row tile leaves in FOUR chunks of 32 rows
+    // (rows 64 wr + 16 i + 0..15 of both wave rows: what fits the A staging area), each chunk through LDS as 16-byte row pieces:
+    // corr = beta*corr + grad (:468-487), clip, theta -= lr*corr (:504-512), the bf16 / fp16 planes of the updated tile, then its
+    // transposed copy.  The K loop ended with a barrier: As is free.
+    constexpr int BTN = 32 * NJ, CLD = BTN + 4, Q = BTN / 4, NPU = 32 * Q / 256, NPT = BTN * 8 / 256;
+    static_assert(32 * CLD <= 4 * PLANE, "the chunk does not fit the A staging area");
+    float *Cs = reinterpret_cast<float *>(As);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const float e[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) Cs[(wr * 16 + 4 * kg + r) * CLD + wc * 16 * NJ + j * 16 + i16] = e[r];
+      }
+      // this thread's pieces of the old corr and parameter rows, all requested before the first store
+      float4 oc4[NPU], op4[NPU];
+#pragma unroll
+      for (int u = 0; u < NPU; u++) {
+        const int p = tid + 256 * u, lr = p / Q, m = m0 + (lr >> 4) * 64 + i * 16 + (lr & 15), n = n0 + (p % Q) * 4;
+        const size_t off = m < g.M && n + 4 <= g.N ? (size_t)m * g.ldc + n : 0;
+        oc4[u] = g.beta != 0.f ? *reinterpret_cast<const float4 *>(g.Cm + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        op4[u] = *reinterpret_cast<const float4 *>(g.P + off);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NPU; u++) {
+        const int p = tid + 256 * u, lr = p / Q, nq = (p % Q) * 4;
+        const int m = m0 + (lr >> 4) * 64 + i * 16 + (lr & 15), n = n0 + nq;
+        if (m < g.M && n + 4 <= g.N) {
+          float *cs = Cs + lr * CLD + nq;
+          const float4 a4 = *reinterpret_cast<const float4 *>(cs);
+          float c[4] = {a4.x, a4.y, a4.z, a4.w};
+          if (g.beta != 0.f) {
+            const float4 o = oc4[u];
+            c[0] = g.beta * o.x + c[0]; c[1] = g.beta * o.y + c[1]; c[2] = g.beta * o.z + c[2]; c[3] = g.beta * o.w + c[3];
+          }
+          if (g.clip > 0.f) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { c[q] = c[q] < -g.clip ? -g.clip : c[q]; c[q] = c[q] > g.clip ? g.clip : c[q]; }
+          }
+          *reinterpret_cast<float4 *>(g.Cm + (size_t)m * g.ldc + n) = make_float4(c[0], c[1], c[2], c[3]);
+          float4 pv = op4[u];
+          pv.x = pv.x + (-g.lr) * c[0]; pv.y = pv.y + (-g.lr) * c[1]; pv.z = pv.z + (-g.lr) * c[2]; pv.w = pv.w + (-g.lr) * c[3];
+          *reinterpret_cast<float4 *>(g.P + (size_t)m * g.ldc + n) = pv;
+          *reinterpret_cast<float4 *>(cs) = pv;
+          if (g.s3 && !g.s3t) {
+            const float v4[4] = {pv.x, pv.y, pv.z, pv.w};
+            split_store4(g.s3mode, v4, g.s3 + (size_t)m * g.ldc + n, g.s3pl);
+          }
+        }
+      }
+      __syncthreads();
+      if (g.Ct) {
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+          const int p = tid + 256 * u, nl = p >> 3, lr = (p & 7) * 4;
+          const int n = n0 + nl, m = m0 + (lr >> 4) * 64 + i * 16 + (lr & 15);
+          if (n < g.N && m + 4 <= g.M) {
+            const float *cs = Cs + lr * CLD + nl;
+            const float v4[4] = {cs[0], cs[CLD], cs[2 * CLD], cs[3 * CLD]};
+            *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            if (g.s3 && g.s3t) split_store4(g.s3mode, v4, g.s3 + (size_t)n * g.ldct + m, g.s3pl);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -3366,7 +3438,7 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
   a.C = C; a.S = S; a.T = d.T; a.dgifo = dgifo; a.cc = cc; a.beta = beta;
   a.g_bias = dst + o_b; a.g_pi = dst + o_pi; a.g_pf = dst + o_pf; a.g_po = dst + o_po;
   a.p_bias = a.p_pi = a.p_pf = a.p_po = nullptr; a.lr = 0.f; a.clip = 0.f;
-  if (upd) {                                          // Update folded into the same pass (fp32 tiles only)
+  if (upd) {                                          // Update folded into the same pass (fp32 tiles and bf16 tiles alike)
     float *pb = upd->params;
     a.wx.P = pb + o_wx; a.wr.P = pb + o_wr; a.wm.P = pb + o_wm;
     a.wx.lr = a.wr.lr = a.wm.lr = a.lr = upd->lr;
@@ -3384,7 +3456,8 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
   // 16.5 us); from there on the bf16 tiles win (640 frames at 512/1024/512: 99 -> 55 us)
   const bool bf_ok = bf16 && TS >= GRADS_BF16_MIN_ROWS && aligned16(dgifo) && aligned16(dr) && aligned16(in) && aligned16(rr) && aligned16(mm) &&
                      in_stride % 4 == 0 && C % 4 == 0 && R % 4 == 0 && I % 4 == 0;
-  if (bf_ok && upd) return hipErrorInvalidValue;
+  if (bf_ok && upd && !(aligned16(dst) && aligned16(upd->params) && aligned16(upd->wrT) && aligned16(upd->wmT) && aligned16(upd->wxT)))
+    return hipErrorInvalidValue;                      // (the fused epilogue moves 16-byte pieces; the engine's blobs are aligned)
   if (bf_ok) {                                        // 128x128 tiles on the bf16 pipe
     // 128 x 64 tiles while 128 x 128 ones would not even give every CU a workgroup (measured at 1024/512, 640 frames: 192 tiles
     // (40 inputs) 24.8 -> 21.3 us; 288 tiles (512 inputs) 30 -> 33.5 us: stays wide)

@@ -223,9 +223,8 @@ class LstmDP:
         products run inside the following update() as ONE pass with momentum and the step (KLSTM_BPTT_FUSE_UPDATE)."""
         if want_in_diff and (self._ind is None or self._ind.shape[0] != x.shape[0]):
             self._ind = torch.empty(x.shape[0], self.e.I, device=x.device)
-        # (bf16 operand mode: the gradient products run on the bf16 tiles, which have no fused-Update epilogue; with the flag they
-        #  would fold the momentum in with scattered read-modify-writes: 53 + 14 us instead of 30 + 21 at 1024/512, 32 streams)
-        self._fused = fused_momentum is not None and not getattr(self.e, "options", {}).get("bf16", 0)
+        # (round 5: the bf16 gradient tiles carry the fused momentum + Update epilogue too, klstm_kernels.hip gemm_tile_bf16_tn)
+        self._fused = fused_momentum is not None
         if self._fused:
             self.e.backpropagate(x, out_diff, self._ind if want_in_diff else None, fused_momentum, DataParallelLstm.FUSE_UPDATE)
         else:

@@ -39,6 +39,11 @@ def test_launched_by_the_driver_with_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    # the keys that make an N > 1 line self-explaining (N = 1 runs 4 streams, N > 1 runs 8 per GPU): bench.multi_gpu_summary
+    d = json.loads(lines[0])
+    for key in ("single_gpu_same_load", "efficiency_vs_same_load", "allreduce_exposed_us"):
+        assert key in d, key
+    assert set(d["single_gpu_same_load"]) >= {"value", "ms_per_step", "streams", "steps"}
 
 
 def test_mismatched_world_size_is_an_error_not_a_silent_single_rank_run():

@@ -1378,6 +1378,40 @@ def test_backpropagate_fuse_update_flag(I, C, R, S, T, persist, clip):
         assert np.array_equal(res[2][4][-1], res[0][2])
 
 
+@pytest.mark.parametrize("I,C,R,S,T,clip", [(64, 256, 128, 24, 12, 0.0),        # 128 x 64 gradient tiles, weights-resident forward launch, launch-per-step BPTT
+                                            (512, 1024, 512, 32, 20, 0.0),      # a configs[4] layer: 128 x 128 tiles, one chain per XCD in both directions
+                                            (72, 160, 96, 13, 21, 0.02)])       # ragged tiles, clipping inside the fused pass
+def test_fuse_update_flag_on_the_bf16_gradient_tiles(I, C, R, S, T, clip):
+    """KLSTM_BPTT_FUSE_UPDATE in bf16 operand mode (round 5: the 128-row bf16 gradient tiles carry the momentum + Update + transposed
+    copy + bf16-plane epilogue too): bit-identical to gradient products and Update as separate passes over three chained minibatches --
+    parameters, momentum buffers, in_diff and the outputs of the following forward passes (which read the refreshed transposed
+    copies, the bf16 planes and the fold product made from them)."""
+    import kaldi_lstm_amd as k
+    p = make_params(I, C, R, scale=0.02, seed=13)
+    rng = np.random.RandomState(14)
+    xs = [dev(rng.randn(T * S, I)) for _ in range(3)]
+    ods = [dev(0.1 * rng.randn(T * S, R)) for _ in range(3)]
+    res = []
+    for flags in (0, 2):
+        e = k.Engine(I, C, R, S); e.set_params(p); e.set_option("bf16", 1)
+        out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+        outs = []
+        e.set_option("profile", 1)
+        for x, od in zip(xs, ods):
+            e.propagate(x, out)
+            outs.append(out.cpu().numpy().copy())
+            e.backpropagate(x, od, idf, momentum=0.9, flags=flags)
+            e.update(1e-3, clip)
+        e.synchronize()
+        assert e.profile_query("k_grads_update")[1] == (3 if flags else 0) and e.profile_query("k_update_repack")[1] == (0 if flags else 3)
+        res.append((outs, idf.cpu().numpy(), e.get_corr(), e.get_params()))
+        e.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("I,C,R,S,T", [(512, 1024, 512, 16, 20), (512, 1024, 512, 32, 20), (40, 1024, 512, 32, 20), (64, 256, 128, 24, 12),
                                        (72, 160, 96, 13, 21), (512, 1024, 256, 13, 21), (96, 1024, 128, 9, 29)])
 def test_many_stream_persistent_forward_bf16(I, C, R, S, T):
