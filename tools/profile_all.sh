@@ -1,4 +1,8 @@
 #!/bin/bash
+# The round's whole evidence in ONE GPU-box call (gpurun --timeout 2400 -- 'bash tools/profile_all.sh'): the four rocprofv3 passes of
+# tools/profile.sh for the default line, 8 streams per GPU and --config c5, a kernel-trace pass of --config c4, then tools/round_check.sh
+# (the -m gpu suite + every bench line).  Summaries land in gpurun_out/profiles_new/ (copy them to profiles/), bench lines and parity
+# margins in gpurun_out/check_r05/.
 bash tools/profile.sh r05 2>&1 | tail -2
 bash tools/profile.sh r05s8 --streams-per-gpu 8 2>&1 | tail -2
 bash tools/profile.sh r05c5 --config c5 2>&1 | tail -2
