@@ -408,6 +408,8 @@ hipError_t launch_gemm_bf16_nt2(const Nt2Job *jobs, int njobs, const Nt2Plan &pl
   const size_t need = pl.ks > 1 ? (size_t)pl.ks * a.nt_all * G16_BT * 32 * pl.nj : 0;
   if (pl.ks > 1 && (!ws || !tickets || ws_floats < need || ntickets < a.nt_all || need * 4 >= (1ull << 31))) return hipErrorInvalidValue;
   if (pl.ks != 1 && pl.ks != 2 && pl.ks != 4 && pl.ks != 8) return hipErrorInvalidValue;
+  for (int q = 0; q < njobs; q++)                     // every K slice of every product has at least one stage (the kernel's loaders load unconditionally)
+    if ((long)a.kslice * (pl.ks - 1) >= jobs[q].K) return hipErrorInvalidValue;
   a.ws_bytes = (unsigned)(need * 4);
   a.dbg = g16_dbg;
   const dim3 grid(8 * a.cpg), block(512);
