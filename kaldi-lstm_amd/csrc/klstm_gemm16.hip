@@ -315,7 +315,7 @@ __global__ __launch_bounds__(512, NJ >= 4 ? 2 : 4) void k_gemm_bf16_nt2(Nt2Args 
   __syncthreads();
   if (TIMING && wave == 0 && lane == 0) a.dbg[(size_t)blockIdx.x * 16 + 6] = clock64() - te0;       // (slab stores + drain + ticket)
   if (!last_s) return;
-  constexpr int ZC = NJ >= 4 ? 2 : 4;                               // slabs whose loads are in flight together (2 NJ ZC x 16 bytes per thread)
+  constexpr int ZC = 4;                                             // slabs whose loads are in flight together (2 NJ ZC x 16 bytes per thread)
   const int ibase = loader ? 2 : 0;
   f32x4 sum[2][NJ];
 #pragma unroll

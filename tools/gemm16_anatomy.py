@@ -35,6 +35,12 @@ def main():
         A = torch.randn(M, K, generator=gen).cuda(); B = torch.randn(N, K, generator=gen).cuda(); C = torch.empty(M, N, device="cuda")
         for nj, ks in cfgs:
             run(name, [(A, B, C, None, None)], nj, ks)
+    # d_r + in_diff of a configs[4] layer in one launch
+    S, T = 32, 20
+    dg = torch.randn((T + 2) * S, 4096, generator=gen).cuda(); wrT = torch.randn(512, 4096, generator=gen).cuda(); wxT = torch.randn(512, 4096, generator=gen).cuda()
+    od = torch.randn(M, 512, generator=gen).cuda(); dr = torch.empty(M, 512, device="cuda"); ind = torch.empty(M, 512, device="cuda")
+    for nj, ks in ((4, 4), (4, 2), (2, 4), (4, 8)):
+        run("d_r + in_diff", [(dg[2 * S:], wrT, dr, None, od), (dg[S:(T + 1) * S], wxT, ind, None, None)], nj, ks)
 
 
 if __name__ == "__main__":
