@@ -384,7 +384,8 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
    "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.
- *   "fuse_x"  -1/0/1  x(t) W_gifo_x^T inside the step kernel (auto: NumStream <= 16) or as one batched product (:246)
+ *   "fuse_update"  0/1  0 = KLSTM_BPTT_FUSE_UPDATE is ignored: gradient products and Update as separate passes (A-B runs; this engine)
+   "fuse_x"  -1/0/1  x(t) W_gifo_x^T inside the step kernel (auto: NumStream <= 16) or as one batched product (:246)
  *   "vector", "fat", "small_max", "small_nt2"  kernel-family selection for A-B experiments and tests
  *   "profile" 0/1  run every kernel eagerly between its own start/stop HIP events on the
  *                  engine's stream (hipExtLaunchKernelGGL); setting the key clears the
