@@ -79,6 +79,29 @@ def test_committed_bench_lines_agree_with_their_rocprof_tables():
         assert 0.97 <= max(rp) / ev <= 1.12, (probe, ev, rp)
 
 
+def test_pmc_summaries_name_the_kernels_of_the_same_rounds_rocprof_table():
+    """Counter passes and the kernel trace of a round come from the same command on the same library (tools/profile.sh): every kernel
+    the newest PMC summary of a bench line lists as recurring per minibatch must be in the rocprofv3 table committed under the same
+    tag, and the summary says which library it saw (`library_source_hash`; tools/round_check.sh refuses one that is older than csrc/)."""
+    import csv, glob, json, re
+    prof = os.path.join(ROOT, "profiles")
+    newest = {}
+    for f in sorted(glob.glob(os.path.join(prof, "r[0-9][0-9]*_pmc_traffic.json"))):
+        m = re.match(r"(r\d\d)(.*)_pmc_traffic.json", os.path.basename(f))
+        newest[m.group(2)] = (m.group(1), f)                       # suffix ("", "s8", "c5") -> newest round
+    assert "" in newest and "s8" in newest and "c5" in newest, newest
+    for suffix, (rnd, f) in newest.items():
+        d = json.load(open(f))
+        if rnd >= "r05":
+            assert d.get("library_source_hash"), f
+        table = os.path.join(prof, "%s%s_rocprofv3_kernel_stats.csv" % (rnd, suffix))
+        assert os.path.exists(table), table
+        names = [re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", r["Name"]).replace("klstm::", "")) for r in csv.DictReader(open(table))]
+        for kname, v in d["kernels"].items():
+            if d.get("minibatches") and v["launches"] >= d["minibatches"] and kname.startswith("k_"):
+                assert kname in names, (f, kname)
+
+
 def test_roofline_accounting_is_surveys_8d():
     """`roofline.achieved` divides ALGORITHMIC work by measured time: the per-frame figures are SURVEY.md 8(d)'s, not what the folded
     kernels execute.  Pinned here as numbers: FLOPs per frame 6 (4C I + 4C R + R C) = 13 056 000 at 40/800/512 (forward 4 352 000 -- what
