@@ -329,8 +329,13 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  give-up is answered INSIDE the call, before the caller (or a neighbouring component) has read `out` /
  *                  `in_diff`: fully transparent, at the price of one host wait per call (~6 us of launch gap each; Kaldi
  *                  synchronises per minibatch anyway: the C++ mirror turns it on).  0 (default of the C-ABI): asynchronous, as above.
-                  The wait is a spin on a host-mapped word the last workgroup of the launch writes (launch count + give-up bit),
-                  not a stream synchronisation ("persist_verify_spin" 0: hipStreamSynchronize instead; A-B runs).
+ *                  The wait is a spin on a host-mapped word the last workgroup of the launch writes (launch count + give-up bit),
+ *                  not a stream synchronisation ("persist_verify_spin" 0: hipStreamSynchronize instead; A-B runs).
+ *                  With KLSTM_BPTT_FUSE_UPDATE ("klstm_update follows immediately") the wait of klstm_backpropagate happens at the
+ *                  END OF THAT klstm_update instead: gradient products + Update (guarded: they do nothing behind a give-up) are
+ *                  enqueued while the BPTT launch runs, `in_diff` is valid when klstm_update has returned -- Kaldi's
+ *                  Component::Backpropagate returns only then.  (A promised klstm_update that never comes: the next
+ *                  klstm_propagate / synchronising call waits and answers.)
  *                  Not supported: a hipGraph captured by the CALLER around engine calls that take the persistent chain (the
  *                  engine cannot count launches inside a foreign graph): use "persist" = 0 there.
  *                  Per-engine knobs (A-B experiments and tests): "persist_waves" (forward and backward geometry: 8, 12, 16),

@@ -112,11 +112,14 @@ def test_forced_give_up_is_answered_by_running_the_minibatch_again(I, C, R, S, T
     e.close(); t.close()
 
 
+@pytest.mark.parametrize("flags", [0, 2])
 @pytest.mark.parametrize("direction", ["bwd", "fwd"])
-def test_persist_verify_answers_the_give_up_inside_the_call(direction):
+def test_persist_verify_answers_the_give_up_inside_the_call(direction, flags):
     """Option "persist_verify" = 1 (what the Kaldi adapter of INTEGRATION.md sets): the call waits for its persistent launch, so
     `out` is right when klstm_propagate returns and `in_diff` when klstm_backpropagate returns -- before any neighbour of the
-    component has read them -- whatever the launch did."""
+    component has read them -- whatever the launch did.  With KLSTM_BPTT_FUSE_UPDATE (flags = 2: "klstm_update follows
+    immediately", Kaldi's Component::Backpropagate) the second wait sits at the end of that klstm_update: `in_diff`, parameters
+    and momentum are right when IT returns, the give-up of the BPTT launch answered there (both calls run again)."""
     import kaldi_lstm_amd as k
     I, C, R, S, T = 40, 800, 512, 4, 20
     p = make_params(I, C, R, scale=0.01, seed=75)
@@ -132,12 +135,34 @@ def test_persist_verify_answers_the_give_up_inside_the_call(direction):
     torch.cuda.synchronize()                          # (no klstm call: what a neighbour reading `out` would see)
     assert relerr(out.cpu().numpy(), o.propagate(x)) <= 3e-5
     assert e.profile_query("persist_giveups")[1] == (1 if direction == "fwd" else 0)
-    e.backpropagate(xd, odd, idf, momentum=0.9, flags=2)
-    torch.cuda.synchronize()
+    e.backpropagate(xd, odd, idf, momentum=0.9, flags=flags)
+    if flags == 2:
+        e.update(1e-5)
+    torch.cuda.synchronize()                          # (no klstm call: what the neighbour reading `in_diff` would see)
     assert relerr(idf.cpu().numpy(), o.backpropagate(x, od, momentum=0.9)) <= 3e-4
     assert e.profile_query("persist_giveups")[1] == 1 and e.profile_query("persist_replayed")[1] == 1
-    e.update(1e-5); o.update(1e-5)
+    assert e.profile_query("persist_dropped")[1] == 0
+    if flags != 2:
+        e.update(1e-5)
+    o.update(1e-5)
     check_blob(e.get_params(), o.get_params(), 3e-5, C, R, "params")
+    check_blob(e.get_corr(), o.get_corr(), 3e-4, C, R, "corr")
+    # the promise broken: backpropagate(FUSE_UPDATE) and no klstm_update -- the next propagate waits, answers, and the record it
+    # answers with is still the old minibatch's (nothing dropped)
+    if flags == 2 and direction == "bwd":
+        e.set_option("persist_cooldown", 0)
+        e.set_option("persist_test_stall_bwd", 7)
+        x2, od2 = _minibatch(rng, I, R, S, T, 0.1)
+        x2d, od2d = dev(x2), dev(od2)
+        e.propagate(x2d, out); e.backpropagate(x2d, od2d, idf, momentum=0.9, flags=2)
+        e.set_option("persist_test_stall_bwd", 0)
+        out3 = torch.empty_like(out)
+        e.propagate(x2d, out3)                        # (flushes the gradient products of minibatch 2 the ordinary way, after the answer)
+        torch.cuda.synchronize()
+        o.propagate(x2)
+        assert relerr(idf.cpu().numpy(), o.backpropagate(x2, od2, momentum=0.9)) <= 3e-4
+        assert e.profile_query("persist_giveups")[1] == 2 and e.profile_query("persist_dropped")[1] == 0
+        check_blob(e.get_corr(), o.get_corr(), 3e-4, C, R, "corr after the broken promise")
     e.close()
 
 
