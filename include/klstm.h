@@ -416,6 +416,11 @@ klstm_status klstm_debug_occupy(int device, int workgroups, int microseconds, vo
  * K slices), 0 = the launcher's own plan; plan_out (or NULL) receives nj, ks and the number of output tiles. */
 klstm_status klstm_debug_gemm_bf16_nt2(int njobs, const int *mnk, const float *const *ptrs, const int *lds, int force_nj, int force_ks,
                                        void *hip_stream, int *plan_out);
+/* The same with bf16 copies of the operands in memory: copies = Ah [M x K], Bh [N x K] per job (unsigned short = bf16 bits, the RNE
+ * roundings of A and B, same leading dimensions in elements, % 8 == 0, 16-byte aligned).  When every job has both, the kernel reads
+ * THEM by LDS-DMA (half the bytes, no conversion pass) -- bit-identical results; NULL entries: as klstm_debug_gemm_bf16_nt2. */
+klstm_status klstm_debug_gemm_bf16_nt2h(int njobs, const int *mnk, const float *const *ptrs, const int *lds,
+                                        const unsigned short *const *copies, int force_nj, int force_ks, void *hip_stream, int *plan_out);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,7 @@ def load_library():
     lib.klstm_set_option.argtypes = [P, ctypes.c_char_p, I]
     lib.klstm_debug_occupy.argtypes = [I, I, I, P, P]
     lib.klstm_debug_gemm_bf16_nt2.argtypes = [I, P, P, P, I, I, P, P]
+    lib.klstm_debug_gemm_bf16_nt2h.argtypes = [I, P, P, P, P, I, I, P, P]
     lib.klstm_profile_query.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_long)]
     lib.klstm_time_shift.argtypes = [P, I, I, I, P, I, I, P]
@@ -541,10 +542,11 @@ def xent_eval_masked_post(net_out, post, mask, diff, stream=None):
     return float(rx.double().sum().item()), float(re_.double().sum().item()), int(rc.sum().item()), int((mask == 1).sum().item())
 
 
-def debug_gemm_bf16_nt2(jobs, force_nj=0, force_ks=0, stream=None):
-    """klstm_debug_gemm_bf16_nt2 (klstm.h): jobs = [(A [M x K], B [N x K], C [M x N], bias or None, add or None), ...] (one or two torch
-    CUDA fp32 tensors each, row strides honoured): C = A B^T (+ bias) (+ add), operands rounded to bf16, fp32 accumulate, one launch.
-    Returns the plan that ran (nj, ks, output tiles)."""
+def debug_gemm_bf16_nt2(jobs, force_nj=0, force_ks=0, stream=None, copies=None):
+    """klstm_debug_gemm_bf16_nt2 / _nt2h (klstm.h): jobs = [(A [M x K], B [N x K], C [M x N], bias or None, add or None), ...] (one or
+    two torch CUDA fp32 tensors each, row strides honoured): C = A B^T (+ bias) (+ add), operands rounded to bf16, fp32 accumulate, one
+    launch.  copies = [(Ah, Bh), ...]: torch.bfloat16 tensors of A's and B's shapes and row strides -- the kernel reads them instead
+    (LDS-DMA).  Returns the plan that ran (nj, ks, output tiles)."""
     lib = load_library()
     n = len(jobs)
     mnk = (ctypes.c_int * (3 * n))()
@@ -557,7 +559,16 @@ def debug_gemm_bf16_nt2(jobs, force_nj=0, force_ks=0, stream=None):
                                  add.data_ptr() if add is not None else None]
         lds[4 * q:4 * q + 4] = [A.stride(0), B.stride(0), C.stride(0), add.stride(0) if add is not None else 0]
     plan = (ctypes.c_int * 3)()
-    st = lib.klstm_debug_gemm_bf16_nt2(n, mnk, ptrs, lds, force_nj, force_ks, ctypes.c_void_p(stream) if stream else None, plan)
+    if copies is not None:
+        cp = (ctypes.c_void_p * (2 * n))()
+        for q, (Ah, Bh) in enumerate(copies):
+            A, B = jobs[q][0], jobs[q][1]
+            assert Ah.element_size() == 2 and Bh.element_size() == 2 and Ah.shape == A.shape and Bh.shape == B.shape
+            assert Ah.stride() == A.stride() and Bh.stride() == B.stride()
+            cp[2 * q:2 * q + 2] = [Ah.data_ptr(), Bh.data_ptr()]
+        st = lib.klstm_debug_gemm_bf16_nt2h(n, mnk, ptrs, lds, cp, force_nj, force_ks, ctypes.c_void_p(stream) if stream else None, plan)
+    else:
+        st = lib.klstm_debug_gemm_bf16_nt2(n, mnk, ptrs, lds, force_nj, force_ks, ctypes.c_void_p(stream) if stream else None, plan)
     if st != 0:
         raise KlstmError(st, lib.klstm_last_error().decode())
     return tuple(plan)

@@ -86,6 +86,12 @@ struct klstm_engine {
   float *params = nullptr, *grads = nullptr, *corr = nullptr;
   float *grads_own = nullptr;   // the engine's own gradient blob (grads points elsewhere after klstm_bind_grad_blob)
   float *wrT = nullptr, *wmT = nullptr, *wxT = nullptr;   // transposed copies for the BPTT kernels
+  unsigned short *wrTh = nullptr, *wxTh = nullptr;        // bf16 copies (RNE) of wrT / wxT, written by the Update kernels of the many-stream bf16 mode
+  bool wth_fresh = false;                                 // ... and whether they are the roundings of the CURRENT wrT / wxT
+  unsigned short *dgifo_h = nullptr;                      // bf16 copy of the dgifo rows, written by the per-XCD BPTT chain ((T_alloc + 2) S x 4C)
+  long n_copies = 0;                                      // launches of the batched products that read the bf16 copies (klstm_profile_query "gemm_copies_launches")
+  int copies_plan = 0;                                    // option "gemm_copies_plan" (A-B runs): 16 nj + ks forced on the launches that read the copies (0: the planner)
+  int use_copies = 1;                                     // option "gemm_copies": d_r + in_diff read the bf16 copies (klstm_gemm16.hip, LDS-DMA form)
   float *pk[4] = {nullptr, nullptr, nullptr, nullptr};    // packed MFMA-operand-ordered copies (vector kernels)
   // carried state, double-buffered: a forward pass reads [sp] and writes [sp ^ 1], then the engine flips sp -- a persistent
   // launch that gives up leaves the state it started from intact, and so does everything queued behind it (device-side guard)
@@ -202,6 +208,7 @@ static LaunchProbe probe(klstm_engine *e, const char *name) {
 static void free_planes(klstm_engine *e) {
   float **ps[] = {&e->gifo, &e->cc, &e->hh, &e->mm, &e->rr, &e->dgifo, &e->dc, &e->dr, &e->dr_part, &e->dx_part, &e->Pm, &e->ws};
   for (float **p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
+  if (e->dgifo_h) { (void)hipFree(e->dgifo_h); e->dgifo_h = nullptr; }
 }
 static void drop_graphs(klstm_engine *e) {
   for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -241,6 +248,8 @@ static klstm_status ensure_planes(klstm_engine *e, int T) {
   HIPCHK(hipMalloc(&e->mm, nb * e->C * sizeof(float)));
   HIPCHK(hipMalloc(&e->rr, nb * e->R * sizeof(float)));
   HIPCHK(hipMalloc(&e->dgifo, nb * 4 * e->C * sizeof(float)));
+  HIPCHK(hipMalloc(&e->dgifo_h, nb * 4 * e->C * sizeof(unsigned short)));
+  HIPCHK(hipMemsetAsync(e->dgifo_h, 0, nb * 4 * e->C * sizeof(unsigned short), e->stream));
   HIPCHK(hipMalloc(&e->dc, nb * e->C * sizeof(float)));
   HIPCHK(hipMalloc(&e->dr, nb * e->R * sizeof(float)));
   HIPCHK(hipMalloc(&e->dr_part, (size_t)e->ks * e->S * e->R * sizeof(float)));
@@ -296,9 +305,11 @@ static klstm_status ensure_tickets(klstm_engine *e) {
 static bool nt2_products(klstm_engine *e, const Nt2Job *jobs, int njobs, LaunchProbe pr, hipError_t *err) {
   if (!e->use_nt2 || !e->tickets) return false;
   for (int q = 0; q < njobs; q++) if (!gemm_bf16_nt2_supported(jobs[q])) return false;
-  const Nt2Plan pl = gemm_bf16_nt2_plan(jobs, njobs);
+  const bool copies = jobs[0].Ah != nullptr;
+  const Nt2Plan pl = gemm_bf16_nt2_plan(jobs, njobs, copies ? e->copies_plan >> 4 : 0, copies ? e->copies_plan & 15 : 0);
   if (pl.ks > 1 && (pl.ws_floats > e->ws_floats || !e->ws || pl.nt > NT2_TICKETS)) return false;
   *err = launch_gemm_bf16_nt2(jobs, njobs, pl, e->ws, e->ws_floats, e->tickets, NT2_TICKETS, e->stream, pr);
+  if (copies && *err == hipSuccess) e->n_copies++;
   return true;
 }
 static klstm_status ensure_ws(klstm_engine *e, int T) {
@@ -342,6 +353,11 @@ static klstm_status flush_momentum(klstm_engine *e) {
 
 static klstm_status repack(klstm_engine *e) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
+  if (e->wth_fresh && !e->graphs.empty()) {           // (the bf16 copies of wrT / wxT come out of the Update kernels only; a cached graph may read them)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+  }
+  e->wth_fresh = false;
   HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream,
                               probe(e, "k_update_repack")));
   if (e->pk[0]) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream, probe(e, "k_pack")));
@@ -672,6 +688,8 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
   alloc0(&e->wrT, (size_t)4 * e->C * e->R * sizeof(float));
   alloc0(&e->wmT, (size_t)e->R * e->C * sizeof(float));
   alloc0(&e->wxT, (size_t)4 * e->C * e->I * sizeof(float));
+  alloc0(reinterpret_cast<float **>(&e->wrTh), (size_t)4 * e->C * e->R * sizeof(unsigned short));
+  alloc0(reinterpret_cast<float **>(&e->wxTh), (size_t)4 * e->C * e->I * sizeof(unsigned short));
   for (int b = 0; b < 2; b++) {
     alloc0(&e->prev_c[b], (size_t)e->S * e->C * sizeof(float));
     alloc0(&e->prev_r[b], (size_t)e->S * e->R * sizeof(float));
@@ -713,6 +731,8 @@ void klstm_destroy(klstm_engine *e) {
   if (e->wrmT_l) (void)hipFree(e->wrmT_l);
   if (e->gran_xb) (void)hipFree(e->gran_xb);
   if (e->tickets) (void)hipFree(e->tickets);
+  if (e->wrTh) (void)hipFree(e->wrTh);
+  if (e->wxTh) (void)hipFree(e->wxTh);
   range_guard_destroy(e->rg);
   if (e->pstat_host) (void)hipHostFree(e->pstat_host);
   for (float *p : e->stage) if (p) (void)hipFree(p);
@@ -857,6 +877,7 @@ static BwdPtrs bwd_ptrs(klstm_engine *e) {
   p.pi = e->params + e->o_pi(); p.pf = e->params + e->o_pf(); p.po = e->params + e->o_po();
   p.gifo = e->gifo; p.cc = e->cc; p.hh = e->hh;
   p.dgifo = e->dgifo; p.dc = e->dc; p.dr = e->dr; p.dr_part = e->dr_part; p.dx_part = e->dx_part; p.ks = e->ks;
+  p.dgifo_h = e->use_copies ? e->dgifo_h : nullptr;
   p.pk_dr = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[2]) : nullptr;
   p.pk_dm = e->use_vector ? reinterpret_cast<const float4 *>(e->pk[3]) : nullptr;
   p.pk_fold = reinterpret_cast<const float4 *>(e->pk_fold[1]);
@@ -952,7 +973,12 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
                                  out_diff, od_stride},
                           Nt2Job{M, d.I, 4 * d.C, e->dgifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.wxT, 4 * d.C, in_diff, id_stride, nullptr, nullptr, 0}};
     hipError_t terr = hipSuccess;
-    if (nt2_products(e, jt, in_diff ? 2 : 1, probe(e, "k_gemm_dr"), &terr)) HIPCHK(terr);
+    Nt2Job jh[2] = {jt[0], jt[1]};
+    if (e->use_copies && e->wth_fresh && p.dgifo_h && !e->use_graph) {   // (a cached graph would bake the choice in) both operands exist as bf16 copies (the chain above wrote dgifo's, the last Update the weights'): LDS-DMA form, same bits
+      jh[0].Ah = p.dgifo_h + (size_t)2 * d.S * 4 * d.C; jh[0].Bh = e->wrTh;
+      jh[1].Ah = p.dgifo_h + (size_t)d.S * 4 * d.C;     jh[1].Bh = e->wxTh;
+    }
+    if (nt2_products(e, jh, in_diff ? 2 : 1, probe(e, "k_gemm_dr"), &terr)) HIPCHK(terr);
     else {
       HIPCHK(launch_gemm_bf16_nt_splitk(M, d.R, 4 * d.C, e->dgifo + (size_t)2 * d.S * 4 * d.C, 4 * d.C, p.wrT, 4 * d.C, 0.f,
                                         e->dr + (size_t)d.S * d.R, d.R, out_diff, od_stride, e->ws, KS, KL, st, probe(e, "k_gemm_dr"),
@@ -1312,6 +1338,8 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
       fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
       u.split_mode = e->fwd_ms ? 3 : e->fold_eff == 2 ? 2 : 1;        // (the many-stream bf16 launch: the operands themselves as bf16)
     }
+    e->wth_fresh = e->fwd_ms && e->use_copies;                        // (both tile forms of the fused epilogue write them next to wrT / wxT)
+    if (e->wth_fresh) { u.wrTh = e->wrTh; u.wxTh = e->wxTh; }
     HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
                         probe(e, "k_grads_update"), e->gp_bf16, &u, e->pctrl));
   } else {
@@ -1325,6 +1353,8 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
       fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
       u.split_mode = e->fwd_ms ? 3 : e->fold_eff == 2 ? 2 : 1;        // (the many-stream bf16 launch: the operands themselves as bf16)
     }
+    e->wth_fresh = e->planes_fresh && e->fwd_ms && e->use_copies;     // (planes_fresh: the vector kernel runs, and it is handed `u`)
+    if (e->wth_fresh) { u.wrTh = e->wrTh; u.wxTh = e->wxTh; }
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
                                 e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr,
                                 ar_mark_if_reduced(e), e->pctrl ? e->pctrl + 10 : nullptr));   // (also when the momentum pass ran on its own: a getter in between)
@@ -1454,6 +1484,14 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     e->fuse_update_ok = value != 0;
     return KLSTM_OK;
   }
+  if (!strcmp(key, "gemm_copies_plan")) { e->copies_plan = value < 0 ? 0 : value; return KLSTM_OK; }
+  if (!strcmp(key, "gemm_copies")) {     // 0: d_r + in_diff of the many-stream bf16 mode round their fp32 operands while staging them (no bf16 copies are written or read)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    e->use_copies = value != 0;
+    if (!e->use_copies) e->wth_fresh = false;
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "gemm_nt2")) {        // 0: the batched bf16 products around the many-stream chains on round 4's kernel + reduction launches
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
@@ -1577,7 +1615,7 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
     auto ev = [&](int which) { return range_guard_events(e->rg, which) + range_guard_events(nullptr, which); };
     const struct { const char *name; long v; } ctr[] = {
         {"persist_giveups", e->n_giveups}, {"persist_replayed", e->n_replayed}, {"persist_dropped", e->n_dropped},
-        {"persist_launches", (long)e->pseq}, {"persist_cooldown", (long)e->cooldown},
+        {"persist_launches", (long)e->pseq}, {"persist_cooldown", (long)e->cooldown}, {"gemm_copies_launches", e->n_copies},
         // range-guard events: this engine's own products + the stateless klstm_affine_* calls made on this device (its default guard)
         {"fp16_redo", ev(REDO_FOLD) + ev(REDO_NT) + ev(REDO_OUTER) + ev(REDO_SKINNY)},
         {"fp16_redo_fold", ev(REDO_FOLD)}, {"fp16_redo_nt", ev(REDO_NT)},
@@ -2008,6 +2046,10 @@ extern "C" klstm_status klstm_debug_occupy(int device, int workgroups, int micro
 //   force_nj / force_ks: 0 = the launcher's plan; plan_out (or null): nj, ks, output tiles of the plan that ran
 extern "C" klstm_status klstm_debug_gemm_bf16_nt2(int njobs, const int *mnk, const float *const *ptrs, const int *lds, int force_nj, int force_ks,
                                                   void *hip_stream, int *plan_out) {
+  return klstm_debug_gemm_bf16_nt2h(njobs, mnk, ptrs, lds, nullptr, force_nj, force_ks, hip_stream, plan_out);
+}
+extern "C" klstm_status klstm_debug_gemm_bf16_nt2h(int njobs, const int *mnk, const float *const *ptrs, const int *lds,
+                                                   const unsigned short *const *copies, int force_nj, int force_ks, void *hip_stream, int *plan_out) {
   if (njobs == 0) { gemm_bf16_nt2_debug_buffer(reinterpret_cast<long long *>(const_cast<int *>(mnk))); return KLSTM_OK; }   // (probe: timing buffer on / off)
   if (njobs < 1 || njobs > 2 || !mnk || !ptrs || !lds) return fail(KLSTM_ERR_ARG, "klstm_debug_gemm_bf16_nt2: bad arguments");
   Nt2Job jobs[2];
@@ -2015,6 +2057,11 @@ extern "C" klstm_status klstm_debug_gemm_bf16_nt2(int njobs, const int *mnk, con
     jobs[q] = Nt2Job{mnk[3 * q], mnk[3 * q + 1], mnk[3 * q + 2], ptrs[5 * q], lds[4 * q], ptrs[5 * q + 1], lds[4 * q + 1],
                      const_cast<float *>(ptrs[5 * q + 2]), lds[4 * q + 2], ptrs[5 * q + 3], ptrs[5 * q + 4], lds[4 * q + 3]};
     if (!gemm_bf16_nt2_supported(jobs[q])) return fail(KLSTM_ERR_SHAPE, "klstm_debug_gemm_bf16_nt2: job %d not supported by the kernel", q);
+    if (copies) {
+      jobs[q].Ah = copies[2 * q]; jobs[q].Bh = copies[2 * q + 1];
+      if ((jobs[q].Ah || jobs[q].Bh) && !gemm_bf16_nt2_copies_usable(jobs[q]))
+        return fail(KLSTM_ERR_SHAPE, "klstm_debug_gemm_bf16_nt2h: job %d: both bf16 copies, 16-byte aligned, leading dimensions %% 8 == 0", q);
+    }
   }
   const Nt2Plan pl = gemm_bf16_nt2_plan(jobs, njobs, force_nj, force_ks);
   static std::mutex mu;

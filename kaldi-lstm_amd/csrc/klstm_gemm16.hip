@@ -69,6 +69,7 @@ template <int NJ, int NF> struct G16Geo {
   static constexpr int NCV = NJL;                                           // (row, k-group) conversion units per loader lane and stage: 8 rows x 8 k-groups per 64 lanes
   static constexpr int EPI = G16_BT * (BTN + 4) * 4;                        // the epilogue's row-major tile
   static constexpr int LDS = 2 * STGH > EPI ? 2 * STGH : EPI;               // two bf16 stage buffers; the epilogue's tile afterwards
+  static constexpr int LDSH = NF * STGH > EPI ? NF * STGH : EPI;            // operands that ARE bf16 in memory: NF stage buffers filled by LDS-DMA
   static_assert(ROWS % 32 == 0, "loader geometry");
 };
 
@@ -99,11 +100,31 @@ struct Nt2Args {
 };
 
 // 512 threads: waves 0..3 contract (2 x 2 waves of 64 x 16 NJ), waves 4..7 bring the operands in and round them to bf16.
-template <int NJ, int NF, bool TIMING = false>
+template <int N> __device__ __forceinline__ void g16_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most `rem` stages of PER instructions each are outstanding (rem is wave-uniform, 0 .. MAXR)
+template <int PER, int MAXR> __device__ __forceinline__ void g16_wait_stages(int rem) {
+  if constexpr (MAXR > 0) {
+    if (rem >= MAXR) { g16_wait_vm<MAXR * PER>(); return; }
+    g16_wait_stages<PER, MAXR - 1>(rem);
+  } else {
+    g16_wait_vm<0>();
+  }
+}
+
+// H: both operands exist as bf16 copies in memory (Nt2Job::Ah / Bh, written by their producers: the BPTT chain's dgifo rows, the
+// Update's transposed weight copies) -- the loaders then move them straight into the bf16 stage by LDS-DMA (global_load_lds_dwordx4:
+// 64 lanes x 16 bytes = 8 rows x 128 bytes per instruction; the stage's swizzle goes on the SOURCE address: lane l fills slot l & 7 of
+// row l >> 3, so it fetches k-group (l & 7) ^ swizzle(row)), NF stage buffers, NF - 1 stages in flight with hand-counted vmcnt (the
+// loader waves issue nothing else on the VM counter and touch no LDS themselves: cdna_hip_programming.md "pipelining across
+// barriers").  Half the bytes per element through the vector-memory path, no conversion pass, no staging registers.  Same stages, same
+// slices, same MFMA order as the fp32-operand form: BIT-IDENTICAL results when the copies are the RNE roundings of A and B.
+template <int NJ, int NF, bool TIMING = false, bool H = false>
 __global__ __launch_bounds__(512, NJ >= 4 ? 2 : 4) void k_gemm_bf16_nt2(Nt2Args a) {   // (waves per SIMD: two workgroups per compute unit up to 128 x 64 tiles)
   typedef G16Geo<NJ, NF> Geo;
   constexpr int BTN = Geo::BTN, STGH = Geo::STGH, NCV = Geo::NCV;
-  static_assert(NF >= 2 && NF <= 3 && (NF - 1) * 2 * NCV <= 63, "vmcnt is a 6-bit counter");
+  constexpr int NSB = H ? NF : 2;                      // bf16 stage buffers in LDS
+  static_assert(H || (NF >= 2 && NF <= 3 && (NF - 1) * 2 * NCV <= 63), "vmcnt is a 6-bit counter");
+  static_assert(!H || (NF >= 3 && NF <= 6 && (NF - 2) * Geo::NJL <= 63 && NF * STGH <= 152 * 1024), "LDS-DMA form: three to six stage buffers");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned last_s;
   char *const hbuf = smem;                             // the two bf16 stage buffers
@@ -130,7 +151,43 @@ __global__ __launch_bounds__(512, NJ >= 4 ? 2 : 4) void k_gemm_bf16_nt2(Nt2Args 
 #pragma unroll
     for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0, 0, 0, 0};
 
-  if (loader) {
+  if (loader && H) {
+    // ---- LDS-DMA: instruction t of loader wave tw fills tile rows 8 (tw + 4 t) .. + 7 of the stage buffer (1 KB, lane-linear)
+    constexpr int NJL = Geo::NJL, D = NF - 1;
+    const unsigned short *srch[NJL];
+#pragma unroll
+    for (int t = 0; t < NJL; t++) {
+      const int rt = (tw + 4 * t) * 8 + (lane >> 3), q = (lane & 7) ^ g16_swh(rt & 15);
+      if (rt < G16_BT) srch[t] = g.Ah + (size_t)min(m0 + rt, g.M - 1) * g.lda + kbeg + 8 * q;
+      else srch[t] = g.Bh + (size_t)min(n0 + rt - G16_BT, g.N - 1) * g.ldb + kbeg + 8 * q;
+    }
+    auto issue = [&](int st, int buf) {
+      char *lb = hbuf + buf * STGH + tw * 1024;
+#pragma unroll
+      for (int t = 0; t < NJL; t++)
+        __builtin_amdgcn_global_load_lds((g16_gptr)(srch[t] + (size_t)st * G16_BK), (g16_lptr)(lb + t * 4096), 16, 0, 0);
+    };
+#pragma unroll
+    for (int st = 0; st < D; st++) if (st < nstage) issue(st, st);
+    int nb = D;                                        // buffer of the next stage to issue: (k + D) % NF
+    long long th_wait = 0, th_bar = 0, th_issue = 0, th_t0 = TIMING ? clock64() : 0;
+    for (int k = 0; k < nstage; k++) {
+      // stages issued beyond k: min(D - 1, nstage - 1 - k); everything older has landed once the count is down to theirs
+      const int rem = min(D - 1, nstage - 1 - k);
+      const long long c0 = TIMING ? clock64() : 0;
+      g16_wait_stages<NJL, D - 1>(rem);
+      const long long c1 = TIMING ? clock64() : 0;
+      asm volatile("s_barrier" ::: "memory");          // barrier k: stage k is in LDS (every loader waited); the MFMA waves are done with stage k - 1
+      const long long c2 = TIMING ? clock64() : 0;
+      if (k + D < nstage) issue(k + D, nb);            // ... whose buffer takes stage k + D
+      nb = nb + 1 == NF ? 0 : nb + 1;
+      if (TIMING) { th_wait += c1 - c0; th_bar += c2 - c1; th_issue += clock64() - c2; }
+    }
+    if (TIMING && wave == 4 && lane == 0) {
+      long long *d = a.dbg + (size_t)blockIdx.x * 16;
+      d[4] = th_wait; d[5] = clock64() - th_t0; d[8] = th_wait; d[9] = th_issue; d[10] = th_bar;
+    }
+  } else if (loader) {
     // ---- unit t of a lane = (row group t of this wave, row lane >> 3 of the group, k-group lane & 7): 32 contiguous bytes of an operand
     // row (two 16-byte loads; eight lanes cover 256 contiguous bytes) -> eight bf16 -> one 16-byte write into the bf16 stage.  Rows
     // beyond the operand read its last row (their results are never stored).  Loader wave tw owns tile rows 8 (tw + 4 t) .. + 7.
@@ -196,11 +253,13 @@ __global__ __launch_bounds__(512, NJ >= 4 ? 2 : 4) void k_gemm_bf16_nt2(Nt2Args 
     const int sh0 = (kg ^ sw) * 16, sh1 = ((4 + kg) ^ sw) * 16;      // the two MFMA k-steps of a stage
     const int arow = (wr * 64 + i16) * 128, brow = (G16_BT + wc * 16 * NJ + i16) * 128;
     long long tm_bar = 0, tm_rd = 0, tm_t0 = TIMING ? clock64() : 0;
+    int rb = 0;                                        // stage k lives in buffer k % NSB
     for (int k = 0; k < nstage; k++) {
       const long long tb0 = TIMING ? clock64() : 0;
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // barrier k (own reads of stage k - 1 are complete)
       if (TIMING) tm_bar += clock64() - tb0;
-      const char *sb = hbuf + (k & 1) * STGH;
+      const char *sb = hbuf + rb * STGH;
+      rb = rb + 1 == NSB ? 0 : rb + 1;
       bf16x8 af[2][4], bfr[2][NJ];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -220,7 +279,7 @@ __global__ __launch_bounds__(512, NJ >= 4 ? 2 : 4) void k_gemm_bf16_nt2(Nt2Args 
 #pragma unroll
           for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][i], bfr[h][j], acc[i][j], 0, 0, 0);
     }
-    for (int k = nstage; k < nround; k++) asm volatile("s_barrier" ::: "memory");   // (the loaders' padding steps)
+    if (!H) for (int k = nstage; k < nround; k++) asm volatile("s_barrier" ::: "memory");   // (the loaders' padding steps)
     if (TIMING && wave == 0 && lane == 0) {
       a.dbg[(size_t)blockIdx.x * 16 + 0] = tm_bar; a.dbg[(size_t)blockIdx.x * 16 + 1] = tm_rd; a.dbg[(size_t)blockIdx.x * 16 + 2] = clock64() - tm_t0;
       a.dbg[(size_t)blockIdx.x * 16 + 3] = nstage;
@@ -300,6 +359,12 @@ __global__ __launch_bounds__(512, NJ >= 4 ? 2 : 4) void k_gemm_bf16_nt2(Nt2Args 
 #pragma unroll
       for (int j = 0; j < NJ; j++)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, (int)(mine + (unsigned)(((i * NJ + j) * 256 + etid) * 16)), 0, 16);   // sc1
+    // ... and into LDS in the same order (the staging area is free): should this workgroup be the last to arrive, it adds its OWN partial
+    // tile from here instead of reading it back from memory -- one slab of ks less through the one compute unit that does the sum
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) *reinterpret_cast<f32x4 *>(smem + ((i * NJ + j) * 256 + etid) * 16) = acc[i][j];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every wave: its slab stores have been performed at device scope
   __syncthreads();
@@ -322,11 +387,20 @@ __global__ __launch_bounds__(512, NJ >= 4 ? 2 : 4) void k_gemm_bf16_nt2(Nt2Args 
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < NJ; j++) sum[i][j] = (f32x4){0, 0, 0, 0};
-  for (int z0 = 0; z0 < a.ks; z0 += ZC) {                           // slice order, whoever came last
+  // slice order, whoever came last: the other ks - 1 slabs from memory (up to ZC of them in flight together), the own one from LDS
+  auto add_own = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) sum[i][j] += *reinterpret_cast<const f32x4 *>(smem + (((ibase + i) * NJ + j) * 256 + etid) * 16);
+  };
+  bool own_done = false;
+  for (int x0 = 0; x0 < a.ks - 1; x0 += ZC) {                       // x: index among the OTHER slices; slice = x < z ? x : x + 1
     u32x4 q[ZC][2][NJ];
 #pragma unroll
     for (int zc = 0; zc < ZC; zc++) {
-      const unsigned zz = (unsigned)min(z0 + zc, a.ks - 1);
+      if (x0 + zc >= a.ks - 1) continue;
+      const unsigned zz = (unsigned)(x0 + zc < z ? x0 + zc : x0 + zc + 1);
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -336,13 +410,16 @@ __global__ __launch_bounds__(512, NJ >= 4 ? 2 : 4) void k_gemm_bf16_nt2(Nt2Args 
     }
 #pragma unroll
     for (int zc = 0; zc < ZC; zc++)
-      if (z0 + zc < a.ks) {
+      if (x0 + zc < a.ks - 1) {
+        if (!own_done && x0 + zc >= z) { add_own(); own_done = true; }   // (the next one from memory is slice x + 1 > z)
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < NJ; j++) sum[i][j] += __builtin_bit_cast(f32x4, q[zc][i][j]);
       }
   }
+  if (!own_done) add_own();
+  __syncthreads();                                                  // (every read of the own partial tile is done: the area becomes the result tile)
 #pragma unroll
   for (int j = 0; j < NJ; j++)
 #pragma unroll
@@ -363,6 +440,11 @@ bool gemm_bf16_nt2_supported(const Nt2Job &g) {
   auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   return g.M >= 256 && g.N >= 32 && g.K >= 64 && g.K % 64 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && al16(g.A) && al16(g.B) && g.C;
 }
+// ... and may it read the bf16 copies (both given, rows 16-byte aligned)?
+bool gemm_bf16_nt2_copies_usable(const Nt2Job &g) {
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return g.Ah && g.Bh && al16(g.Ah) && al16(g.Bh) && g.lda % 8 == 0 && g.ldb % 8 == 0;
+}
 
 // Tile width (16-column blocks per wave) and K slices for `njobs` products launched together.  Empirical (tools/gemm16_probe.py on the
 // shapes of BASELINE.json configs[4], 640 rows; profiles/r05_gemm16_probe.txt): the kernel is bound by the compute unit's vector-memory
@@ -372,12 +454,18 @@ bool gemm_bf16_nt2_supported(const Nt2Job &g) {
 //   long K, one product with fewer tiles:                       128 x 64 tiles, 4 slices    (d_r alone: 19.3-20.1 us; 24.5)
 //   short K, wide output (N >= 2048):                            128 x 128 tiles, no split   (x-projection: 12.7-13.4 us; 16.2)
 //   short K, narrow output:                                      128 x 32 tiles, no split    (P: 7.3-7.5 us; 11.0)
+// From bf16 copies (LDS-DMA form; tools/gemm16_probe.py --copies, profiles/r05_gemm16_copies.txt): the stage is half the bytes and the
+// loaders issue 1 KB per instruction, so narrower tiles with fewer slices win -- the in-launch reduction (slab round trips through
+// memory, summed by ONE compute unit per tile) is then the larger part: d_r + in_diff 128 x 64 tiles in 2 slices.
 Nt2Plan gemm_bf16_nt2_plan(const Nt2Job *jobs, int njobs, int force_nj, int force_ks) {
   int kmin = jobs[0].K, nmax = jobs[0].N;
   for (int q = 1; q < njobs; q++) { kmin = jobs[q].K < kmin ? jobs[q].K : kmin; nmax = jobs[q].N > nmax ? jobs[q].N : nmax; }
   auto tiles = [&](int nj) { int nt = 0; for (int q = 0; q < njobs; q++) nt += g16_cdiv(jobs[q].M, G16_BT) * g16_cdiv(jobs[q].N, 32 * nj); return nt; };
+  bool h = true;                                       // the LDS-DMA form (bf16 copies in memory) will run
+  for (int q = 0; q < njobs; q++) h = h && gemm_bf16_nt2_copies_usable(jobs[q]);
   int nj, ks;
-  if (kmin >= 2048) { nj = (njobs == 2 || tiles(4) >= 32) ? 4 : 2; ks = 4; }
+  if (kmin >= 2048 && h && njobs == 2) { nj = 2; ks = 2; }            // (copies: d_r + in_diff 18.5-20 us in two slices of 128 x 64 tiles, 21-22 as below; 27-30 from fp32 operands)
+  else if (kmin >= 2048) { nj = (njobs == 2 || tiles(4) >= 32) ? 4 : 2; ks = 4; }
   else if (nmax >= 2048) { nj = 4; ks = 1; }
   else { nj = tiles(1) > 512 ? 2 : 1; ks = 1; }
   if (force_nj) nj = force_nj;
@@ -413,9 +501,9 @@ hipError_t launch_gemm_bf16_nt2(const Nt2Job *jobs, int njobs, const Nt2Plan &pl
   a.ws_bytes = (unsigned)(need * 4);
   a.dbg = g16_dbg;
   const dim3 grid(8 * a.cpg), block(512);
-  auto go = [&](auto kern, int lds) -> hipError_t {
-    static bool raised[6] = {false, false, false, false, false, false};   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
-    const int slot = (pl.nj == 4 ? 2 : pl.nj == 2 ? 1 : 0) + (g16_dbg ? 3 : 0);
+  auto go = [&](auto kern, int lds, int hslot = -1) -> hipError_t {
+    static bool raised[12] = {false, false, false, false, false, false, false, false, false, false, false, false};   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
+    const int slot = hslot >= 0 ? hslot : (pl.nj == 4 ? 2 : pl.nj == 2 ? 1 : 0) + (g16_dbg ? 3 : 0);
     if (!raised[slot]) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return e;
@@ -425,6 +513,19 @@ hipError_t launch_gemm_bf16_nt2(const Nt2Job *jobs, int njobs, const Nt2Plan &pl
     else hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     return hipGetLastError();
   };
+  bool h = true;                                       // every product of the launch has both bf16 copies: the LDS-DMA form
+  for (int q = 0; q < njobs; q++) h = h && gemm_bf16_nt2_copies_usable(jobs[q]);
+  if (h && g16_dbg) {
+    if (pl.nj == 4) return go(k_gemm_bf16_nt2<4, 4, true, true>, G16Geo<4, 4>::LDSH, 11);
+    if (pl.nj == 2) return go(k_gemm_bf16_nt2<2, 6, true, true>, G16Geo<2, 6>::LDSH, 10);
+    return go(k_gemm_bf16_nt2<1, 6, true, true>, G16Geo<1, 6>::LDSH, 9);
+  }
+  if (h) {
+    // stage buffers: what fits the LDS -- the DMA's issue-to-landed time (~1 us) is hidden by the stages in flight, nothing else
+    if (pl.nj == 4) return go(k_gemm_bf16_nt2<4, 4, false, true>, G16Geo<4, 4>::LDSH, 8);
+    if (pl.nj == 2) return go(k_gemm_bf16_nt2<2, 6, false, true>, G16Geo<2, 6>::LDSH, 7);
+    return go(k_gemm_bf16_nt2<1, 6, false, true>, G16Geo<1, 6>::LDSH, 6);
+  }
   if (g16_dbg) {
     if (pl.nj == 4) return go(k_gemm_bf16_nt2<4, 2, true>, G16Geo<4, 2>::LDS);
     if (pl.nj == 2) return go(k_gemm_bf16_nt2<2, 2, true>, G16Geo<2, 2>::LDS);

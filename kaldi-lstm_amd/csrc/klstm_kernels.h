@@ -31,6 +31,7 @@ struct BwdPtrs {
   const float *pi, *pf, *po;
   const float *gifo, *cc, *hh;
   float *dgifo, *dc, *dr;
+  unsigned short *dgifo_h = nullptr;                 // (or null) bf16 copy (RNE) of the dgifo rows, written by the per-XCD BPTT chain next to them (Nt2Job::Ah)
   float *dr_part;                                    // split-K slabs [KS][S][R]
   float *dx_part;                                    // split-K slabs [KS][S][I] (in_diff of one frame)
   int ks;                                            // number of slabs
@@ -183,6 +184,7 @@ struct GradsUpdate {
   // optional: the bf16 planes of the fold operands (fold_bf16x3_planes) are written from the updated W_gifo_r / W_r_m too
   unsigned short *a3 = nullptr, *b3 = nullptr; long a_plane = 0, b_plane = 0;
   int split_mode = 1;      // the engine's fold mode: 1 = three bf16 planes, 2 = two fp16 planes
+  unsigned short *wrTh = nullptr, *wxTh = nullptr;   // (or null) bf16 copies (RNE) of the refreshed wrT / wxT, same layouts (Nt2Job::Bh)
 };
 // C = A B for few rows, a narrow result and a long contraction (klstm_fold.hip: the output layer's in_diff); ws holds one partial per K slice
 bool skinny_nn_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *Cm, int ldc);
@@ -208,9 +210,12 @@ struct Nt2Job {
   float *C; int ldc;
   const float *bias;                  // [N] or null
   const float *add; int add_ld;       // [M x N] or null
+  const unsigned short *Ah = nullptr, *Bh = nullptr;   // (or null) bf16 copies of A and B, RNE, same shapes and leading dimensions (in elements; % 8 == 0):
+                                                       // given for every product of a launch, the kernel reads THEM (LDS-DMA, half the bytes) -- same bits out
 };
 struct Nt2Plan { int nj, ks, nt; size_t ws_floats; };       // 16-column blocks per wave (tile = 128 x 32 nj), K slices, output tiles, workspace
 bool gemm_bf16_nt2_supported(const Nt2Job &g);
+bool gemm_bf16_nt2_copies_usable(const Nt2Job &g);
 Nt2Plan gemm_bf16_nt2_plan(const Nt2Job *jobs, int njobs, int force_nj = 0, int force_ks = 0);
 hipError_t launch_gemm_bf16_nt2(const Nt2Job *jobs, int njobs, const Nt2Plan &pl, float *ws, size_t ws_floats, unsigned *tickets, int ntickets,
                                 hipStream_t st, LaunchProbe pr = {});   // tickets: >= pl.nt words, zero between launches (the kernel leaves them zero)

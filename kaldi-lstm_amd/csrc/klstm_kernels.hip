@@ -1508,6 +1508,7 @@ struct GemmJob {
   float *P; float lr, clip;
   int s3mode;                                // plane format (klstm_math.h split_store4)
   unsigned short *s3; long s3pl; int s3t;   // the bf16 / fp16 planes of the UPDATED P (s3t = 0: P's layout, ld = ldc; 1: Ct's layout, ld = ldct)
+  unsigned short *cth = nullptr;            // (or null) bf16 copy (RNE) of Ct, same layout: the B operand of klstm_gemm16.hip's LDS-DMA form
   int coal;               // 1: Cm = beta*Cm + A*B through the same coalesced 16-byte epilogue without P (N, ldc % 4 == 0, aligned, no bias)
   const unsigned *guard = nullptr;   // k_gemm only: the engine's control words; a persistent launch in front gave up ([2] | [6]) -> write nothing
 };
@@ -1742,6 +1743,7 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
         const float v4[4] = {cs[0], cs[GLX], cs[2 * GLX], cs[3 * GLX]};
         *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(v4[0], v4[1], v4[2], v4[3]);
         if (g.s3 && g.s3t) split_store4(g.s3mode, v4, g.s3 + (size_t)n * g.ldct + m, g.s3pl);
+        if (g.cth) split_store4(3, v4, g.cth + (size_t)n * g.ldct + m, 0);
       }
     }
     return;
@@ -2119,26 +2121,32 @@ __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int 
   }
   if (g.P) {
     // Gradient product with momentum and Update folded in (launch_grads + GradsUpdate on the bf16 tiles; N, ldc, ldct multiples of 4,
-    // 16-byte aligned blobs) -- the epilogue of gemm_tile_impl on this tile shape: the 128-row tile leaves in FOUR chunks of 32 rows
-    // (rows 64 wr + 16 i + 0..15 of both wave rows: what fits the A staging area), each chunk through LDS as 16-byte row pieces:
-    // corr = beta*corr + grad (:468-487), clip, theta -= lr*corr (:504-512), the bf16 / fp16 planes of the updated tile, then its
-    // transposed copy.  The K loop ended with a barrier: As is free.
+    // 16-byte aligned blobs) -- the epilogue of gemm_tile_impl on this tile shape: the 128-row tile leaves in FOUR chunks of 32
+    // CONSECUTIVE rows (chunk c = blocks i = 2 (c & 1), + 1 of the two waves with wr = c >> 1: what fits the A staging area; the
+    // transposed copy then leaves in whole 128-byte lines per column, its bf16 copy in 64-byte runs), each chunk through LDS as 16-byte
+    // row pieces: corr = beta*corr + grad (:468-487), clip, theta -= lr*corr (:504-512), the bf16 / fp16 planes of the updated tile,
+    // then its transposed copy.  The K loop ended with a barrier: As is free.
     constexpr int BTN = 32 * NJ, CLD = BTN + 4, Q = BTN / 4, NPU = 32 * Q / 256, NPT = BTN * 8 / 256;
     static_assert(32 * CLD <= 4 * PLANE, "the chunk does not fit the A staging area");
     float *Cs = reinterpret_cast<float *>(As);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 4; i++) {                      // (chunk index: rows m0 + 32 i .. + 31)
+      if (wr == (i >> 1)) {
 #pragma unroll
-      for (int j = 0; j < NJ; j++) {
-        const float e[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+        for (int b = 0; b < 2; b++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) Cs[(wr * 16 + 4 * kg + r) * CLD + wc * 16 * NJ + j * 16 + i16] = e[r];
+          for (int j = 0; j < NJ; j++) {
+            const f32x4 &av = acc[2 * (i & 1) + b][j];
+            const float e[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) Cs[(b * 16 + 4 * kg + r) * CLD + wc * 16 * NJ + j * 16 + i16] = e[r];
+          }
       }
       // this thread's pieces of the old corr and parameter rows, all requested before the first store
       float4 oc4[NPU], op4[NPU];
 #pragma unroll
       for (int u = 0; u < NPU; u++) {
-        const int p = tid + 256 * u, lr = p / Q, m = m0 + (lr >> 4) * 64 + i * 16 + (lr & 15), n = n0 + (p % Q) * 4;
+        const int p = tid + 256 * u, lr = p / Q, m = m0 + 32 * i + lr, n = n0 + (p % Q) * 4;
         const size_t off = m < g.M && n + 4 <= g.N ? (size_t)m * g.ldc + n : 0;
         oc4[u] = g.beta != 0.f ? *reinterpret_cast<const float4 *>(g.Cm + off) : make_float4(0.f, 0.f, 0.f, 0.f);
         op4[u] = *reinterpret_cast<const float4 *>(g.P + off);
@@ -2147,7 +2155,7 @@ __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int 
 #pragma unroll
       for (int u = 0; u < NPU; u++) {
         const int p = tid + 256 * u, lr = p / Q, nq = (p % Q) * 4;
-        const int m = m0 + (lr >> 4) * 64 + i * 16 + (lr & 15), n = n0 + nq;
+        const int m = m0 + 32 * i + lr, n = n0 + nq;
         if (m < g.M && n + 4 <= g.N) {
           float *cs = Cs + lr * CLD + nq;
           const float4 a4 = *reinterpret_cast<const float4 *>(cs);
@@ -2176,12 +2184,13 @@ __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int 
 #pragma unroll
         for (int u = 0; u < NPT; u++) {
           const int p = tid + 256 * u, nl = p >> 3, lr = (p & 7) * 4;
-          const int n = n0 + nl, m = m0 + (lr >> 4) * 64 + i * 16 + (lr & 15);
+          const int n = n0 + nl, m = m0 + 32 * i + lr;
           if (n < g.N && m + 4 <= g.M) {
             const float *cs = Cs + lr * CLD + nl;
             const float v4[4] = {cs[0], cs[CLD], cs[2 * CLD], cs[3 * CLD]};
             *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(v4[0], v4[1], v4[2], v4[3]);
             if (g.s3 && g.s3t) split_store4(g.s3mode, v4, g.s3 + (size_t)n * g.ldct + m, g.s3pl);
+            if (g.cth) split_store4(3, v4, g.cth + (size_t)n * g.ldct + m, 0);
           }
         }
         __syncthreads();
@@ -2356,6 +2365,7 @@ struct UpdArgs {
   // optional (vector kernel): the three bf16 planes of the fold operands, written from the same tiles (klstm_fold3.hip):
   // a3 in W_gifo_r's own layout (matrix 1), b3 in W_r_m^T's (matrix 2, the transposed destination's)
   unsigned short *a3, *b3; long a_plane, b_plane; int split_mode;
+  unsigned short *dstTh[3];  // (or null; vector kernel) bf16 copies (RNE) of the transposed destinations, same layout
 };
 
 __device__ __forceinline__ float upd_elem(const UpdArgs &a, long idx) {
@@ -2489,6 +2499,7 @@ __global__ __launch_bounds__(256) void k_update_repack_v(UpdArgs a) {
       const float v4[4] = {tp[0], tp[68], tp[2 * 68], tp[3 * 68]};
       *reinterpret_cast<float4 *>(dst + (size_t)c * rows + r) = make_float4(v4[0], v4[1], v4[2], v4[3]);
       if (mi == 2 && a.b3) split_store4(a.split_mode, v4, a.b3 + (size_t)c * rows + r, a.b_plane);
+      if (a.dstTh[mi]) split_store4(3, v4, a.dstTh[mi] + (size_t)c * rows + r, 0);
     }
   }
 }
@@ -3448,6 +3459,7 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
     a.wm.Ct = upd->wmT; a.wm.ldct = R;               // [C x R]
     if (upd->a3) { a.wr.s3 = upd->a3; a.wr.s3pl = upd->a_plane; a.wr.s3t = 0; a.wr.s3mode = upd->split_mode; }
     if (upd->b3) { a.wm.s3 = upd->b3; a.wm.s3pl = upd->b_plane; a.wm.s3t = 1; a.wm.s3mode = upd->split_mode; }
+    a.wx.cth = upd->wxTh; a.wr.cth = upd->wrTh;      // (null: none)
     a.p_bias = pb + o_b; a.p_pi = pb + o_pi; a.p_pf = pb + o_pf; a.p_po = pb + o_po;
   }
   if (!upd && aligned16(dst) && C % 4 == 0 && R % 4 == 0 && I % 4 == 0) a.wx.coal = a.wr.coal = a.wm.coal = 1;
@@ -3485,6 +3497,7 @@ hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_bl
   a.guard = guard;
   a.mark = mark; a.peer_skip = peer_skip;
   a.a3 = a.b3 = nullptr; a.a_plane = a.b_plane = 0; a.split_mode = 1;
+  a.dstTh[0] = a.dstTh[1] = a.dstTh[2] = nullptr;
   a.param = param_blob; a.corr = corr_blob; a.grad = grad_blob; a.mmt = mmt; a.lr = lr; a.clip = clip;
   a.touch = (lr != 0.f || grad_blob != nullptr || clip > 0.f) ? 1 : 0;
   const long o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_wm = o_b + 7 * C;
@@ -3499,7 +3512,10 @@ hipError_t launch_update_repack(const Dims &d, float *param_blob, float *corr_bl
   for (int i = 0; i < 3; i++) { a.tb[i] = nb; nb += cdiv(a.rows[i], tsz) * cdiv(a.cols[i], tsz); }
   a.tb_vec = nb;
   nb += cdiv(7 * C, 1024);
-  if (vec && planes) { a.a3 = planes->a3; a.b3 = planes->b3; a.a_plane = planes->a_plane; a.b_plane = planes->b_plane; a.split_mode = planes->split_mode; }
+  if (vec && planes) {
+    a.a3 = planes->a3; a.b3 = planes->b3; a.a_plane = planes->a_plane; a.b_plane = planes->b_plane; a.split_mode = planes->split_mode;
+    a.dstTh[0] = planes->wxTh; a.dstTh[1] = planes->wrTh;
+  }
   if (vec) KLAUNCH(k_update_repack_v, dim3(nb), dim3(256), st, pr, a);
   KLAUNCH(k_update_repack, dim3(nb), dim3(256), st, pr, a);
 }

@@ -309,6 +309,7 @@ struct PersistXlBwdArgs {
   const float *pi, *pf, *po;
   const float *gifo, *cc, *hh;    // forward planes
   float *dgifo, *dc;
+  unsigned short *dgifo_h;        // (or null) the same rows rounded to bf16 (the values that travel in the granules): operand copy of the batched d_r / in_diff products
   uint4 *gran;                    // [8 groups][2 parities][4 streams][C] granules
   unsigned *xcnt;
   unsigned *ctrl;                 // the backward direction's control words
@@ -371,6 +372,10 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
     if (on) {                                                           // dgifo(T+1) = 0 (:351): operand rows of the batched d_r product
       float *zp = a.dgifo + ((size_t)(T + 1) * S + strm) * K + cell;
       zp[0] = 0.f; zp[C] = 0.f; zp[2 * C] = 0.f; zp[3 * C] = 0.f;
+      if (a.dgifo_h) {
+        unsigned short *zh = a.dgifo_h + ((size_t)(T + 1) * S + strm) * K + cell;
+        zh[0] = 0; zh[C] = 0; zh[2 * C] = 0; zh[3 * C] = 0;
+      }
     }
     // ---- the resident operand: 2 x 16 rows of W_rm^T (output cells 32 slot + 16 tile + i16) x this wave's sixteenth of K ----
     xl_bf16x8 af[16];
@@ -470,11 +475,15 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
         const float df = k_diff_sigmoid(d_c * cpv, yf);                 // :431-432
         dcn = d_c; fn = yf; din = di; dfn = df;                         // what frame t - 1 needs of frame t
         if (on) {
+          const unsigned short hg = bf16_rne(dg), hi = bf16_rne(di), hf = bf16_rne(df), ho = bf16_rne(d_o);
           if (t > 1 && !(a.test_stall == t && slot == 0 && grp == 0))   // publish dgifo(t): one plain 16-byte store -- the line stays in this XCC's L2
-            gr[((size_t)(t & 1) * 4 + n2) * C + cell] =
-                make_uint4(epoch + (unsigned)t, bf16_rne(dg) | ((unsigned)bf16_rne(di) << 16), bf16_rne(df) | ((unsigned)bf16_rne(d_o) << 16), 0u);
+            gr[((size_t)(t & 1) * 4 + n2) * C + cell] = make_uint4(epoch + (unsigned)t, hg | ((unsigned)hi << 16), hf | ((unsigned)ho << 16), 0u);
           float *dp = a.dgifo + ((size_t)t * S + strm) * K + cell;
           dp[0] = dg; dp[C] = di; dp[2 * C] = df; dp[3 * C] = d_o;
+          if (a.dgifo_h) {                                              // (2-byte stores in 32-byte runs: sixteen cells of a tile are sixteen lanes)
+            unsigned short *dh = a.dgifo_h + ((size_t)t * S + strm) * K + cell;
+            dh[0] = hg; dh[C] = hi; dh[2 * C] = hf; dh[3 * C] = ho;
+          }
           a.dc[((size_t)t * S + strm) * C + cell] = d_c;
         }
         if (lane == 0) __hip_atomic_fetch_add(pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -535,7 +544,7 @@ hipError_t launch_bwd_persist_xl(const Dims &d, const BwdPtrs &p, const unsigned
   PersistXlBwdArgs a;
   a.S = d.S; a.T = d.T; a.sx = (d.S + 7) / 8;
   a.wrmT = wrmT; a.P = P; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
-  a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc;
+  a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc; a.dgifo_h = p.dgifo_h;
   a.gran = static_cast<uint4 *>(gran);
   a.xcnt = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(gran) + (size_t)8 * 2 * 4 * XL_C * 16);
   a.ctrl = ctrl; a.guard = o.guard; a.hstat = o.hstat;

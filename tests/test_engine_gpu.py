@@ -1412,6 +1412,54 @@ def test_fuse_update_flag_on_the_bf16_gradient_tiles(I, C, R, S, T, clip):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("flags", [2, 0, 1])
+@pytest.mark.parametrize("I,C,R,S,T", [(512, 1024, 512, 32, 20), (40, 1024, 512, 32, 20), (512, 1024, 256, 13, 21)])
+def test_bf16_operand_copies_of_the_batched_bptt_products(I, C, R, S, T, flags):
+    """Many streams in bf16, one BPTT chain per XCD: d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r (...streams.h:391) and
+    in_diff = dgifo W_gifo_x (:457) read bf16 COPIES of their operands -- dgifo's written by the chain next to the fp32 rows (the values
+    its granules carry), W_gifo_r^T's / W_gifo_x^T's by whichever Update kernel ran (fused gradient + Update tiles: flags = 2;
+    k_update_repack_v behind the gradient products: 0; behind klstm_apply_momentum, the data-parallel order: 1) -- through LDS-DMA
+    (klstm_gemm16.hip, option "gemm_copies").  Same stages, slices and MFMA order as the form that rounds the fp32 operands while staging
+    them: with the tile width and K split of that form forced ("gemm_copies_plan" = 16 x 4 + 4) four chained minibatches are
+    BIT-IDENTICAL to "gemm_copies" = 0 in every output; with its own plan (narrower tiles, two slices: another summation order of the
+    same products: 1e-7 in d_r / in_diff, which the bf16 re-rounding of everything downstream turns into <= 2.5e-5 of a tensor's
+    maximum over the four chained minibatches; bar 2e-4).  The counter says the copies were read in the minibatches that follow an
+    Update (the first follows klstm_set_params: nothing has written the weights' copies yet; the third does again)."""
+    import kaldi_lstm_amd as k
+    p = make_params(I, C, R, scale=0.02, seed=21)
+    rng = np.random.RandomState(22)
+    xs = [dev(rng.randn(T * S, I)) for _ in range(4)]
+    ods = [dev(0.1 * rng.randn(T * S, R)) for _ in range(4)]
+    res = []
+    for copies in (1, 0, 2):
+        e = k.Engine(I, C, R, S); e.set_params(p); e.set_option("bf16", 1); e.set_option("gemm_copies", 1 if copies else 0)
+        if copies == 1:
+            e.set_option("gemm_copies_plan", 16 * 4 + 4)
+        out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+        outs, idfs = [], []
+        for i, (x, od) in enumerate(zip(xs, ods)):
+            e.propagate(x, out)
+            outs.append(out.cpu().numpy().copy())
+            e.backpropagate(x, od, idf, momentum=0.9, flags=flags)
+            if flags == 1:
+                e.apply_momentum(0.9)
+            e.update(1e-3)
+            idfs.append(idf.cpu().numpy().copy())
+            if i == 1:                                # parameters set from outside: the copies are stale until the next Update
+                e.synchronize(); e.set_params(e.get_params())
+        e.synchronize()
+        n = e.profile_query("gemm_copies_launches")[1]
+        assert n == (2 if copies else 0), n          # minibatches 2 and 4 (1 and 3 follow a set_params)
+        res.append((outs, idfs, e.get_corr(), e.get_params(), e.activations(1)))
+        e.close()
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert np.array_equal(a, b)
+    for a, b in zip(res[0][2:], res[1][2:]):
+        assert np.array_equal(a, b)
+    for a, b in zip(res[2][0] + res[2][1] + list(res[2][2:]), res[1][0] + res[1][1] + list(res[1][2:])):
+        bound(float(np.abs(a - b).max() / np.abs(b).max()), 2e-4, "own plan of the copies form vs the fp32-operand form")
+
+
 @pytest.mark.parametrize("I,C,R,S,T", [(512, 1024, 512, 16, 20), (512, 1024, 512, 32, 20), (40, 1024, 512, 32, 20), (64, 256, 128, 24, 12),
                                        (72, 160, 96, 13, 21), (512, 1024, 256, 13, 21), (96, 1024, 128, 9, 29)])
 def test_many_stream_persistent_forward_bf16(I, C, R, S, T):

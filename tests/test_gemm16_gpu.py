@@ -96,3 +96,64 @@ def test_engine_takes_the_pipelined_products_and_matches_the_old_kernels():
         e.close()
     for name, a, b in zip(("out", "in_diff", "corr"), res[0], res[1]):
         bound(float(np.abs(a - b).max() / np.abs(b).max()), 2e-5, name)
+
+
+@pytest.mark.parametrize("M,N,K,nj,ks", [
+    (640, 512, 4096, 0, 0), (640, 512, 4096, 4, 8), (640, 512, 4096, 2, 4), (640, 512, 4096, 1, 2), (640, 4096, 512, 0, 0), (640, 1024, 512, 0, 0),
+    (300, 72, 192, 1, 1), (257, 100, 320, 4, 1), (520, 40, 3200, 1, 4), (260, 96, 1024, 2, 4), (256, 32, 64, 1, 1), (256, 32, 128, 2, 1), (256, 64, 192, 4, 1),
+])
+def test_bf16_copies_in_memory_give_the_same_bits(M, N, K, nj, ks):
+    """klstm_debug_gemm_bf16_nt2h: the operands' bf16 copies (what the BPTT chain and the Update write next to their fp32 results) read
+    by LDS-DMA -- same stages, same slices, same MFMA order as the form that rounds fp32 operands while staging them: the SAME BITS,
+    also with fewer stages than stage buffers (K = 64, 128), ragged tails and uneven slices."""
+    import kaldi_lstm_amd as k
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + 1)
+    A = torch.randn(M, K, generator=g).cuda(); B = (0.05 * torch.randn(N, K, generator=g)).cuda()
+    add = torch.randn(M, N, generator=g).cuda()
+    Ah, Bh = A.to(torch.bfloat16), B.to(torch.bfloat16)
+    C0 = torch.full((M, N), float("nan"), device="cuda"); C1 = torch.full((M, N), float("nan"), device="cuda")
+    p0 = k.debug_gemm_bf16_nt2([(A, B, C0, None, add)], nj, ks)
+    p1 = k.debug_gemm_bf16_nt2([(A, B, C1, None, add)], nj, ks, copies=[(Ah, Bh)])
+    torch.cuda.synchronize()
+    assert p0 == p1
+    assert torch.equal(C0, C1)
+    bound(_rel(C1, _ref(A, B, None, add)), 2e-6, "C (bf16 copies)")
+    # the kernel reads the COPIES: with a copy that is not the rounding of A the result follows the copy
+    C2 = torch.empty(M, N, device="cuda")
+    k.debug_gemm_bf16_nt2([(A, B, C2, None, None)], nj, ks, copies=[((2 * A).to(torch.bfloat16), Bh)])
+    torch.cuda.synchronize()
+    bound(_rel(C2, 2 * _ref(A, B, None, None)), 2e-6, "C (copy of 2A)")
+
+
+def test_two_products_from_bf16_copies_pitched():
+    """d_r + in_diff of a configs[4] layer in one launch from the bf16 copies: the dgifo plane one time block apart (the SAME copy
+    buffer at two row offsets), pitched weight copies; bits equal to the fp32-operand launch, 10 launches the same bits."""
+    import kaldi_lstm_amd as k
+    S, T, C4, R, I = 32, 20, 4096, 512, 512
+    g = torch.Generator(device="cpu").manual_seed(6)
+    dg = (0.1 * torch.randn((T + 2) * S, C4, generator=g)).cuda()
+    wrT = (0.05 * torch.randn(R, C4 + 8, generator=g)).cuda()[:, :C4]; wxT = (0.05 * torch.randn(I, C4 + 8, generator=g)).cuda()[:, :C4]
+    dgh = dg.to(torch.bfloat16)
+    wrTh = torch.empty(R, C4 + 8, device="cuda", dtype=torch.bfloat16)[:, :C4]; wrTh.copy_(wrT)
+    wxTh = torch.empty(I, C4 + 8, device="cuda", dtype=torch.bfloat16)[:, :C4]; wxTh.copy_(wxT)
+    od = torch.randn(T * S, R, generator=g).cuda()
+    out = []
+    for copies in (None, [(dgh[2 * S:(T + 2) * S], wrTh), (dgh[S:(T + 1) * S], wxTh)]):
+        dr = torch.full((T * S, R), float("nan"), device="cuda"); ind = torch.full((T * S, I), float("nan"), device="cuda")
+        jobs = [(dg[2 * S:(T + 2) * S], wrT, dr, None, od), (dg[S:(T + 1) * S], wxT, ind, None, None)]
+        k.debug_gemm_bf16_nt2(jobs, 4, 4, copies=copies)          # (the same tile width and split for both forms: the planner's differ)
+        torch.cuda.synchronize()
+        out.append((dr.clone(), ind.clone()))
+        if copies is not None:
+            for _ in range(10):
+                k.debug_gemm_bf16_nt2(jobs, 4, 4, copies=copies)
+            torch.cuda.synchronize()
+            assert torch.equal(dr, out[-1][0]) and torch.equal(ind, out[-1][1])
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    # the planner's own choice for the copies (128 x 64 tiles, two slices): another summation order of the same products
+    dr = torch.full((T * S, R), float("nan"), device="cuda"); ind = torch.full((T * S, I), float("nan"), device="cuda")
+    jobs = [(dg[2 * S:(T + 2) * S], wrT, dr, None, od), (dg[S:(T + 1) * S], wxT, ind, None, None)]
+    plan = k.debug_gemm_bf16_nt2(jobs, copies=[(dgh[2 * S:(T + 2) * S], wrTh), (dgh[S:(T + 1) * S], wxTh)])
+    torch.cuda.synchronize()
+    assert plan[:2] == (2, 2), plan
+    bound(_rel(dr, out[0][0].double()), 2e-6, "d_r (copies, own plan)"); bound(_rel(ind, out[0][1].double()), 2e-6, "in_diff (copies, own plan)")

@@ -8,15 +8,15 @@ sys.path.insert(0, ".")
 import kaldi_lstm_amd as k
 
 
-def run(name, jobs, nj, ks):
+def run(name, jobs, nj, ks, copies=None):
     lib = k.load_library()
     dbg = torch.zeros(16 * 8192, dtype=torch.int64, device="cuda")
     lib.klstm_debug_gemm_bf16_nt2(0, ctypes.c_void_p(dbg.data_ptr()), None, None, 0, 0, None, None)
     for _ in range(3):
-        k.debug_gemm_bf16_nt2(jobs, nj, ks)
+        k.debug_gemm_bf16_nt2(jobs, nj, ks, copies=copies)
     torch.cuda.synchronize()
     dbg.zero_(); torch.cuda.synchronize()
-    plan = k.debug_gemm_bf16_nt2(jobs, nj, ks)
+    plan = k.debug_gemm_bf16_nt2(jobs, nj, ks, copies=copies)
     torch.cuda.synchronize()
     lib.klstm_debug_gemm_bf16_nt2(0, None, None, None, 0, 0, None, None)
     d = dbg.view(-1, 16).cpu().double()
@@ -41,6 +41,11 @@ def main():
     od = torch.randn(M, 512, generator=gen).cuda(); dr = torch.empty(M, 512, device="cuda"); ind = torch.empty(M, 512, device="cuda")
     for nj, ks in ((4, 4), (4, 2), (2, 4), (4, 8)):
         run("d_r + in_diff", [(dg[2 * S:], wrT, dr, None, od), (dg[S:(T + 1) * S], wxT, ind, None, None)], nj, ks)
+    # ... from the bf16 copies in memory (LDS-DMA form; loader columns: wait = own requests, issue = the DMA instructions)
+    dgh, wrTh, wxTh = dg.to(torch.bfloat16), wrT.to(torch.bfloat16), wxT.to(torch.bfloat16)
+    for nj, ks in ((4, 4), (2, 2), (1, 1), (2, 4), (4, 2)):
+        run("pair, copies", [(dg[2 * S:], wrT, dr, None, od), (dg[S:(T + 1) * S], wxT, ind, None, None)], nj, ks,
+            copies=[(dgh[2 * S:], wrTh), (dgh[S:(T + 1) * S], wxTh)])
 
 
 if __name__ == "__main__":

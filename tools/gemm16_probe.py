@@ -24,7 +24,40 @@ def timed(fn, reps=20, rounds=5):
     return best
 
 
+def main_copies():
+    """--copies: the K = 4C products from bf16 copies in memory (LDS-DMA form) next to the fp32-operand form, per tile width and split"""
+    M, S, T = 640, 32, 20
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    dg = torch.randn((T + 2) * S, 4096, generator=gen).cuda(); wrT = torch.randn(512, 4096, generator=gen).cuda(); wxT = torch.randn(512, 4096, generator=gen).cuda()
+    od = torch.randn(M, 512, generator=gen).cuda(); dr = torch.empty(M, 512, device="cuda"); ind = torch.empty(M, 512, device="cuda")
+    dgh, wrTh, wxTh = dg.to(torch.bfloat16), wrT.to(torch.bfloat16), wxT.to(torch.bfloat16)
+    jobs2 = [(dg[2 * S:], wrT, dr, None, od), (dg[S:(T + 1) * S], wxT, ind, None, None)]
+    cp2 = [(dgh[2 * S:], wrTh), (dgh[S:(T + 1) * S], wxTh)]
+    for label, jobs, cps in (("pair d_r + in_diff", jobs2, cp2), ("d_r alone", jobs2[:1], cp2[:1])):
+        for nj in (0, 1, 2, 4):
+            for ks in ((0,) if nj == 0 else (1, 2, 4, 8)):
+                row = []
+                for copies in (None, cps):
+                    try:
+                        us = timed(lambda s: k.debug_gemm_bf16_nt2(jobs, nj, ks, s, copies=copies))
+                    except Exception as ex:
+                        us = float("nan")
+                    row.append(us)
+                plan = k.debug_gemm_bf16_nt2(jobs, nj, ks, copies=cps)
+                print("%-19s nj %d ks %d : fp32 operands %6.1f us   bf16 copies %6.1f us" % (label, plan[0], plan[1], row[0], row[1]), flush=True)
+    # the short-K products, for completeness (their A operand is the caller's: no copy exists in the engine)
+    for name, N, K in (("xproj", 4096, 512), ("P", 1024, 512)):
+        A = torch.randn(M, K, generator=gen).cuda(); B = torch.randn(N, K, generator=gen).cuda(); C = torch.empty(M, N, device="cuda")
+        for nj in (1, 2, 4):
+            r0 = timed(lambda s: k.debug_gemm_bf16_nt2([(A, B, C, None, None)], nj, 1, s))
+            Ah, Bh = A.to(torch.bfloat16), B.to(torch.bfloat16)
+            r1 = timed(lambda s: k.debug_gemm_bf16_nt2([(A, B, C, None, None)], nj, 1, s, copies=[(Ah, Bh)]))
+            print("%-19s nj %d ks 1 : fp32 operands %6.1f us   bf16 copies %6.1f us" % (name, nj, r0, r1), flush=True)
+
+
 def main():
+    if "--copies" in sys.argv:
+        return main_copies()
     M = 640
     gen = torch.Generator(device="cpu").manual_seed(0)
     shapes = [("xproj", 4096, 512), ("P", 1024, 512), ("d_r", 512, 4096)]
