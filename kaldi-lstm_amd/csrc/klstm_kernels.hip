@@ -26,6 +26,7 @@
 //   fixed order through LDS (deterministic), and the fused LSTM cell math runs on the summed tile
 //   in registers.  D lane l holds stream l&15, rows 4*(l>>4)+{0..3}.
 #include "klstm_kernels.h"
+#include <type_traits>
 #include "klstm_math.h"
 
 #include <hip/hip_ext.h>
@@ -2129,73 +2130,94 @@ __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int 
     constexpr int BTN = 32 * NJ, CLD = BTN + 4, Q = BTN / 4, NPU = 32 * Q / 256, NPT = BTN * 8 / 256;
     static_assert(32 * CLD <= 4 * PLANE, "the chunk does not fit the A staging area");
     float *Cs = reinterpret_cast<float *>(As);
+    // V = 0: any tile.  V = 1, 2, 3: the three jobs of the many-stream bf16 mode on a FULL tile with momentum (W_gifo_r: bf16 plane in
+    // its own layout + transposed copy + that copy's bf16 copy; W_gifo_x: transposed copy + its bf16 copy; W_r_m: transposed copy + bf16
+    // plane in the copy's layout) with every load and store UNCONDITIONAL -- the compiler then counts what is outstanding and waits for
+    // exactly the loads it needs; behind a conditional store it waits for everything, i.e. for the previous chunk's stores to drain
+    // (twice per chunk).
+    auto epilogue = [&](auto vtag) {
+      constexpr int V = decltype(vtag)::value;
+      constexpr bool F = V != 0;
+      // this thread's pieces of the old corr and parameter rows of a chunk: requested ONE CHUNK AHEAD (chunk 0's before the loop,
+      // chunk i + 1's in front of chunk i's arithmetic and stores), so that only the first memory round trip is exposed -- a tile is
+      // usually the only one its compute unit has (256-288 tiles on 256 units), nothing else would hide the other three
+      float4 oc4[2][NPU], op4[2][NPU];
+      auto fetch_old = [&](int i, float4 (&oc)[NPU], float4 (&op)[NPU]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {                      // (chunk index: rows m0 + 32 i .. + 31)
-      if (wr == (i >> 1)) {
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-          for (int j = 0; j < NJ; j++) {
-            const f32x4 &av = acc[2 * (i & 1) + b][j];
-            const float e[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-            for (int r = 0; r < 4; r++) Cs[(b * 16 + 4 * kg + r) * CLD + wc * 16 * NJ + j * 16 + i16] = e[r];
-          }
-      }
-      // this thread's pieces of the old corr and parameter rows, all requested before the first store
-      float4 oc4[NPU], op4[NPU];
-#pragma unroll
-      for (int u = 0; u < NPU; u++) {
-        const int p = tid + 256 * u, lr = p / Q, m = m0 + 32 * i + lr, n = n0 + (p % Q) * 4;
-        const size_t off = m < g.M && n + 4 <= g.N ? (size_t)m * g.ldc + n : 0;
-        oc4[u] = g.beta != 0.f ? *reinterpret_cast<const float4 *>(g.Cm + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        op4[u] = *reinterpret_cast<const float4 *>(g.P + off);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < NPU; u++) {
-        const int p = tid + 256 * u, lr = p / Q, nq = (p % Q) * 4;
-        const int m = m0 + 32 * i + lr, n = n0 + nq;
-        if (m < g.M && n + 4 <= g.N) {
-          float *cs = Cs + lr * CLD + nq;
-          const float4 a4 = *reinterpret_cast<const float4 *>(cs);
-          float c[4] = {a4.x, a4.y, a4.z, a4.w};
-          if (g.beta != 0.f) {
-            const float4 o = oc4[u];
-            c[0] = g.beta * o.x + c[0]; c[1] = g.beta * o.y + c[1]; c[2] = g.beta * o.z + c[2]; c[3] = g.beta * o.w + c[3];
-          }
-          if (g.clip > 0.f) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) { c[q] = c[q] < -g.clip ? -g.clip : c[q]; c[q] = c[q] > g.clip ? g.clip : c[q]; }
-          }
-          *reinterpret_cast<float4 *>(g.Cm + (size_t)m * g.ldc + n) = make_float4(c[0], c[1], c[2], c[3]);
-          float4 pv = op4[u];
-          pv.x = pv.x + (-g.lr) * c[0]; pv.y = pv.y + (-g.lr) * c[1]; pv.z = pv.z + (-g.lr) * c[2]; pv.w = pv.w + (-g.lr) * c[3];
-          *reinterpret_cast<float4 *>(g.P + (size_t)m * g.ldc + n) = pv;
-          *reinterpret_cast<float4 *>(cs) = pv;
-          if (g.s3 && !g.s3t) {
-            const float v4[4] = {pv.x, pv.y, pv.z, pv.w};
-            split_store4(g.s3mode, v4, g.s3 + (size_t)m * g.ldc + n, g.s3pl);
-          }
+        for (int u = 0; u < NPU; u++) {
+          const int p = tid + 256 * u, lr = p / Q, m = m0 + 32 * i + lr, n = n0 + (p % Q) * 4;
+          const size_t off = F || (m < g.M && n + 4 <= g.N) ? (size_t)m * g.ldc + n : 0;
+          if (F) oc[u] = *reinterpret_cast<const float4 *>(g.Cm + off);
+          else oc[u] = g.beta != 0.f ? *reinterpret_cast<const float4 *>(g.Cm + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          op[u] = *reinterpret_cast<const float4 *>(g.P + off);
         }
-      }
-      __syncthreads();
-      if (g.Ct) {
+      };
+      fetch_old(0, oc4[0], op4[0]);
 #pragma unroll
-        for (int u = 0; u < NPT; u++) {
-          const int p = tid + 256 * u, nl = p >> 3, lr = (p & 7) * 4;
-          const int n = n0 + nl, m = m0 + 32 * i + lr;
-          if (n < g.N && m + 4 <= g.M) {
-            const float *cs = Cs + lr * CLD + nl;
-            const float v4[4] = {cs[0], cs[CLD], cs[2 * CLD], cs[3 * CLD]};
-            *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(v4[0], v4[1], v4[2], v4[3]);
-            if (g.s3 && g.s3t) split_store4(g.s3mode, v4, g.s3 + (size_t)n * g.ldct + m, g.s3pl);
-            if (g.cth) split_store4(3, v4, g.cth + (size_t)n * g.ldct + m, 0);
+      for (int i = 0; i < 4; i++) {                    // (chunk index: rows m0 + 32 i .. + 31)
+        if (wr == (i >> 1)) {
+#pragma unroll
+          for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+              const f32x4 &av = acc[2 * (i & 1) + b][j];
+              const float e[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+              for (int r = 0; r < 4; r++) Cs[(b * 16 + 4 * kg + r) * CLD + wc * 16 * NJ + j * 16 + i16] = e[r];
+            }
+        }
+        if (i < 3) fetch_old(i + 1, oc4[(i + 1) & 1], op4[(i + 1) & 1]);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NPU; u++) {
+          const int p = tid + 256 * u, lr = p / Q, nq = (p % Q) * 4;
+          const int m = m0 + 32 * i + lr, n = n0 + nq;
+          if (F || (m < g.M && n + 4 <= g.N)) {
+            float *cs = Cs + lr * CLD + nq;
+            const float4 a4 = *reinterpret_cast<const float4 *>(cs);
+            float c[4] = {a4.x, a4.y, a4.z, a4.w};
+            if (F || g.beta != 0.f) {
+              const float4 o = oc4[i & 1][u];
+              c[0] = g.beta * o.x + c[0]; c[1] = g.beta * o.y + c[1]; c[2] = g.beta * o.z + c[2]; c[3] = g.beta * o.w + c[3];
+            }
+            if (g.clip > 0.f) {
+#pragma unroll
+              for (int q = 0; q < 4; q++) { c[q] = c[q] < -g.clip ? -g.clip : c[q]; c[q] = c[q] > g.clip ? g.clip : c[q]; }
+            }
+            *reinterpret_cast<float4 *>(g.Cm + (size_t)m * g.ldc + n) = make_float4(c[0], c[1], c[2], c[3]);
+            float4 pv = op4[i & 1][u];
+            pv.x = pv.x + (-g.lr) * c[0]; pv.y = pv.y + (-g.lr) * c[1]; pv.z = pv.z + (-g.lr) * c[2]; pv.w = pv.w + (-g.lr) * c[3];
+            *reinterpret_cast<float4 *>(g.P + (size_t)m * g.ldc + n) = pv;
+            *reinterpret_cast<float4 *>(cs) = pv;
+            if (V == 1 || (V == 0 && g.s3 && !g.s3t)) {
+              const float v4[4] = {pv.x, pv.y, pv.z, pv.w};
+              split_store4(F ? 3 : g.s3mode, v4, g.s3 + (size_t)m * g.ldc + n, g.s3pl);
+            }
           }
         }
         __syncthreads();
+        if (F || g.Ct) {
+#pragma unroll
+          for (int u = 0; u < NPT; u++) {
+            const int p = tid + 256 * u, nl = p >> 3, lr = (p & 7) * 4;
+            const int n = n0 + nl, m = m0 + 32 * i + lr;
+            if (F || (n < g.N && m + 4 <= g.M)) {
+              const float *cs = Cs + lr * CLD + nl;
+              const float v4[4] = {cs[0], cs[CLD], cs[2 * CLD], cs[3 * CLD]};
+              *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+              if (V == 3 || (V == 0 && g.s3 && g.s3t)) split_store4(F ? 3 : g.s3mode, v4, g.s3 + (size_t)n * g.ldct + m, g.s3pl);
+              if (V == 1 || V == 2 || (V == 0 && g.cth)) split_store4(3, v4, g.cth + (size_t)n * g.ldct + m, 0);
+            }
+          }
+          __syncthreads();
+        }
       }
-    }
+    };
+    const bool fast = m0 + BT <= g.M && n0 + BTN <= g.N && g.beta != 0.f && g.Ct && (!g.s3 || g.s3mode == 3);
+    if (fast && g.s3 && !g.s3t && g.cth) epilogue(std::integral_constant<int, 1>());
+    else if (fast && !g.s3 && g.cth) epilogue(std::integral_constant<int, 2>());
+    else if (fast && g.s3 && g.s3t && !g.cth) epilogue(std::integral_constant<int, 3>());
+    else epilogue(std::integral_constant<int, 0>());
     return;
   }
 #pragma unroll
