@@ -390,9 +390,12 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.
  *   "fuse_update"  0/1  0 = KLSTM_BPTT_FUSE_UPDATE is ignored: gradient products and Update as separate passes (A-B runs; this engine)
- *   "gemm_copies"  0/1  bf16 mode, 9..32 streams with the per-XCD BPTT chain: that chain writes a bf16 copy of its dgifo rows, the Update
+ *   "gemm_copies"  0/1/2  bf16 mode, 9..32 streams with the per-XCD BPTT chain: that chain writes a bf16 copy of its dgifo rows, the Update
  *                  kernels bf16 copies of W_gifo_r^T / W_gifo_x^T, and the batched d_r + in_diff product reads THE COPIES by LDS-DMA
- *                  (1, default; 0: it rounds the fp32 operands while staging them -- the same roundings, twice the bytes).  The copies
+ *                  (1, default; 0: it rounds the fp32 operands while staging them -- the same roundings, twice the bytes).  With 1 the
+ *                  Update also leaves the fp32 W_gifo_r^T / W_gifo_x^T out while those chains run (nothing reads them then; whoever
+ *                  does -- a launch-per-step chain after a give-up or "persist" = 0, k_pack, the fp32-operand product -- gets them
+ *                  transposed from the parameters first); 2 = copies AND fp32 matrices on every Update (A-B runs, tests).  The copies
  *                  are used from the first minibatch after an Update on (klstm_set_params refreshes only the fp32 matrices);
  *                  klstm_profile_query(e, "gemm_copies_launches") counts the launches that read them.  "gemm_copies_plan" = 16 nj + ks
  *                  forces tile width (32 nj columns) and K slices of those launches (0: the planner; A-B runs and tests).

@@ -87,9 +87,13 @@ struct klstm_engine {
   float *grads_own = nullptr;   // the engine's own gradient blob (grads points elsewhere after klstm_bind_grad_blob)
   float *wrT = nullptr, *wmT = nullptr, *wxT = nullptr;   // transposed copies for the BPTT kernels
   unsigned short *wrTh = nullptr, *wxTh = nullptr;        // bf16 copies (RNE) of wrT / wxT, written by the Update kernels of the many-stream bf16 mode
-  bool wth_fresh = false;                                 // ... and whether they are the roundings of the CURRENT wrT / wxT
+  bool wth_fresh = false;                                 // ... and whether they are the roundings of the CURRENT W_gifo_r^T / W_gifo_x^T
+  bool wT32_stale = false;                                // the fp32 wrT / wxT were left out by the last Update (only their bf16 copies have a reader while the
+                                                          // per-XCD chains run): whoever needs them -- a launch-per-step chain, k_pack, the fp32-operand product --
+                                                          // refreshes them first (ensure_wT32)
   unsigned short *dgifo_h = nullptr;                      // bf16 copy of the dgifo rows, written by the per-XCD BPTT chain ((T_alloc + 2) S x 4C)
   long n_copies = 0;                                      // launches of the batched products that read the bf16 copies (klstm_profile_query "gemm_copies_launches")
+  int skip_wT32 = 1;                                      // (part of "gemm_copies": 2 = copies without leaving the fp32 ones out; A-B runs)
   int copies_plan = 0;                                    // option "gemm_copies_plan" (A-B runs): 16 nj + ks forced on the launches that read the copies (0: the planner)
   int use_copies = 1;                                     // option "gemm_copies": d_r + in_diff read the bf16 copies (klstm_gemm16.hip, LDS-DMA form)
   float *pk[4] = {nullptr, nullptr, nullptr, nullptr};    // packed MFMA-operand-ordered copies (vector kernels)
@@ -351,8 +355,17 @@ static klstm_status flush_momentum(klstm_engine *e) {
   return KLSTM_OK;
 }
 
+// the fp32 transposed copies of W_gifo_r / W_gifo_x, if the last Update left them out (a pure transposition of the current parameters)
+static klstm_status ensure_wT32(klstm_engine *e) {
+  if (!e->wT32_stale) return KLSTM_OK;
+  const Dims d{e->I, e->C, e->R, e->S, 0};
+  HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream, probe(e, "k_update_repack")));
+  e->wT32_stale = false;
+  return KLSTM_OK;
+}
 static klstm_status repack(klstm_engine *e) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
+  e->wT32_stale = false;
   if (e->wth_fresh && !e->graphs.empty()) {           // (the bf16 copies of wrT / wxT come out of the Update kernels only; a cached graph may read them)
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
@@ -554,6 +567,7 @@ static klstm_status ensure_packs(klstm_engine *e, int want = 15) {       // want
   const int todo = e->pk_stale & want;
   if (!todo) return KLSTM_OK;
   const Dims d{e->I, e->C, e->R, e->S, 0};
+  { klstm_status ws = ensure_wT32(e); if (ws != KLSTM_OK) return ws; }
   HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, todo, e->use_bf16, e->stream, probe(e, "k_pack")));
   e->pk_stale &= ~todo;
   return KLSTM_OK;
@@ -953,6 +967,8 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
   const Dims d{e->I, e->C, e->R, e->S, T};
   const BwdPtrs p = bwd_ptrs(e);
   hipStream_t st = e->stream;
+  const bool copies_form = e->bwd_xl && e->use_copies && e->wth_fresh && p.dgifo_h && !e->use_graph;   // d_r + in_diff from the bf16 copies
+  if (!copies_form) { klstm_status ws = ensure_wT32(e); if (ws != KLSTM_OK) return ws; }             // (everybody else reads the fp32 wrT / wxT)
   if (e->bwd_xl) {
     // many streams, bf16, one BPTT chain per XCD: P = out_diff W_r_m for all frames, the chain d_m(t) = P(t) + dgifo(t+1) W_rm with the
     // elementwise pass of the own cells, then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r (:391) and in_diff = dgifo W_gifo_x (:457)
@@ -974,12 +990,13 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
                           Nt2Job{M, d.I, 4 * d.C, e->dgifo + (size_t)d.S * 4 * d.C, 4 * d.C, p.wxT, 4 * d.C, in_diff, id_stride, nullptr, nullptr, 0}};
     hipError_t terr = hipSuccess;
     Nt2Job jh[2] = {jt[0], jt[1]};
-    if (e->use_copies && e->wth_fresh && p.dgifo_h && !e->use_graph) {   // (a cached graph would bake the choice in) both operands exist as bf16 copies (the chain above wrote dgifo's, the last Update the weights'): LDS-DMA form, same bits
+    if (copies_form) {   // (not under a cached graph: it would bake the choice in) both operands exist as bf16 copies (the chain above wrote dgifo's, the last Update the weights'): LDS-DMA form, same bits
       jh[0].Ah = p.dgifo_h + (size_t)2 * d.S * 4 * d.C; jh[0].Bh = e->wrTh;
       jh[1].Ah = p.dgifo_h + (size_t)d.S * 4 * d.C;     jh[1].Bh = e->wxTh;
     }
     if (nt2_products(e, jh, in_diff ? 2 : 1, probe(e, "k_gemm_dr"), &terr)) HIPCHK(terr);
     else {
+      { klstm_status ws = ensure_wT32(e); if (ws != KLSTM_OK) return ws; }
       HIPCHK(launch_gemm_bf16_nt_splitk(M, d.R, 4 * d.C, e->dgifo + (size_t)2 * d.S * 4 * d.C, 4 * d.C, p.wrT, 4 * d.C, 0.f,
                                         e->dr + (size_t)d.S * d.R, d.R, out_diff, od_stride, e->ws, KS, KL, st, probe(e, "k_gemm_dr"),
                                         probe(e, "k_reduce_dr")));
@@ -1093,6 +1110,7 @@ static klstm_status do_propagate(klstm_engine *e, const float *in, int rows, int
   if (!e->fwd_folded && (st = ensure_packs(e, e->fwd_ms ? (e->bwd_xl ? 0 : 12) : 15)) != KLSTM_OK) return st;     // (the many-stream launch reads the natural matrices; BPTT its packed operands)
   if (e->fwd_folded && !e->fwd_persist && (e->pk_stale & 1) && e->pk[0]) {   // step 1 of the launch-per-step folded chain
     const Dims d0{e->I, e->C, e->R, e->S, 0};
+    if ((st = ensure_wT32(e)) != KLSTM_OK) return st;
     HIPCHK(launch_pack(d0, e->params, e->wrT, e->wmT, e->wxT, e->pk, 1, e->use_bf16, e->stream, probe(e, "k_pack")));
     e->pk_stale &= ~1;
   }
@@ -1340,6 +1358,8 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
     }
     e->wth_fresh = e->fwd_ms && e->use_copies;                        // (both tile forms of the fused epilogue write them next to wrT / wxT)
     if (e->wth_fresh) { u.wrTh = e->wrTh; u.wxTh = e->wxTh; }
+    // ... and INSTEAD of them while the per-XCD chains run this engine: nothing reads the fp32 wrT / wxT then (ensure_wT32 for whoever does)
+    if (e->wth_fresh && e->bwd_xl && e->skip_wT32 && !e->replaying && !e->use_graph && e->gp_bf16) { u.no_wT32 = true; e->wT32_stale = true; }
     HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
                         probe(e, "k_grads_update"), e->gp_bf16, &u, e->pctrl));
   } else {
@@ -1355,8 +1375,10 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
     }
     e->wth_fresh = e->planes_fresh && e->fwd_ms && e->use_copies;     // (planes_fresh: the vector kernel runs, and it is handed `u`)
     if (e->wth_fresh) { u.wrTh = e->wrTh; u.wxTh = e->wxTh; }
-    HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, e->wrT, e->wmT,
-                                e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr,
+    const bool no32 = e->wth_fresh && e->bwd_xl && e->skip_wT32 && !e->replaying && !e->use_graph;   // (as above)
+    if (no32) e->wT32_stale = true;
+    HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, no32 ? nullptr : e->wrT, e->wmT,
+                                no32 ? nullptr : e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr,
                                 ar_mark_if_reduced(e), e->pctrl ? e->pctrl + 10 : nullptr));   // (also when the momentum pass ran on its own: a getter in between)
   }
   // (Packing the BPTT operands on a second stream, overlapped with the next forward pass, was measured to cost
@@ -1365,6 +1387,7 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
   // (and with the persistent forward kernel none at all: it reads the natural matrices)
   const int mask = e->fwd_persist ? 0 : e->fwd_ms ? (e->bwd_xl ? 0 : 12) : e->fwd_folded ? 1 : 15;   // (one chain per XCD in both directions: no packed operand is read)
   float *foldx = (e->fwd_folded && !e->fwd_persist && !e->use_bf16) ? e->pk_fold[0] : nullptr;
+  if (e->pk[0] && (mask || foldx)) { klstm_status ws = ensure_wT32(e); if (ws != KLSTM_OK) return ws; }
   if (e->pk[0] && (mask || foldx)) HIPCHK(launch_pack(d, e->params, e->wrT, e->wmT, e->wxT, e->pk, mask, e->use_bf16, e->stream, probe(e, "k_pack"), foldx));
   e->pk_stale = 15 & ~mask;
   e->fold_dirty = true;
@@ -1458,6 +1481,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     drop_graphs(e);
     if (value != 0 && !e->pk[0]) return fail(KLSTM_ERR_SHAPE, "bf16 mode needs I, C, R multiples of 8");
     e->use_bf16 = value != 0;
+    { klstm_status ws = ensure_wT32(e); if (ws != KLSTM_OK) return ws; }
     HIPCHK(launch_pack(Dims{e->I, e->C, e->R, e->S, 0}, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream));
     // Up to 8 streams the fp32 engine runs the weights-resident chain (one launch per direction); bf16 operand mode has no such chain
     // below 9 streams and steps one launch per frame: SLOWER than fp32 there (measured at 40/800/512, T = 20: 4 streams 291 us per
@@ -1489,7 +1513,9 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
     e->use_copies = value != 0;
+    e->skip_wT32 = value == 1;
     if (!e->use_copies) e->wth_fresh = false;
+    { klstm_status ws = ensure_wT32(e); if (ws != KLSTM_OK) return ws; }
     return KLSTM_OK;
   }
   if (!strcmp(key, "gemm_nt2")) {        // 0: the batched bf16 products around the many-stream chains on round 4's kernel + reduction launches

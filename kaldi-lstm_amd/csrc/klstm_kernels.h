@@ -185,6 +185,7 @@ struct GradsUpdate {
   unsigned short *a3 = nullptr, *b3 = nullptr; long a_plane = 0, b_plane = 0;
   int split_mode = 1;      // the engine's fold mode: 1 = three bf16 planes, 2 = two fp16 planes
   unsigned short *wrTh = nullptr, *wxTh = nullptr;   // (or null) bf16 copies (RNE) of the refreshed wrT / wxT, same layouts (Nt2Job::Bh)
+  bool no_wT32 = false;    // bf16 tiles only: full tiles leave the fp32 wrT / wxT out (only the bf16 copies have a reader); the caller treats them as stale
 };
 // C = A B for few rows, a narrow result and a long contraction (klstm_fold.hip: the output layer's in_diff); ws holds one partial per K slice
 bool skinny_nn_supported(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *Cm, int ldc);

@@ -2070,7 +2070,7 @@ __device__ __forceinline__ void stash_pair(unsigned *Ls, int u, const float4 (&r
 
 // NJ = 16-column blocks per wave: 4 = 128 x 128 tiles, 2 = 128 x 64 (twice the workgroups: the K loop exposes a memory latency per
 // tile, and 288 tiles of 128 x 128 leave the 256 CUs with one workgroup each)
-template <int NJ>
+template <int NJ, bool NO32 = false>                 // NO32: the kernel's fast epilogues are the ones WITHOUT the fp32 transposed copy (4, 5 instead of 1, 2)
 __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int n0, unsigned *As, unsigned *Bs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kg = lane >> 4;
@@ -2132,7 +2132,8 @@ __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int 
     float *Cs = reinterpret_cast<float *>(As);
     // V = 0: any tile.  V = 1, 2, 3: the three jobs of the many-stream bf16 mode on a FULL tile with momentum (W_gifo_r: bf16 plane in
     // its own layout + transposed copy + that copy's bf16 copy; W_gifo_x: transposed copy + its bf16 copy; W_r_m: transposed copy + bf16
-    // plane in the copy's layout) with every load and store UNCONDITIONAL -- the compiler then counts what is outstanding and waits for
+    // plane in the copy's layout; V = 4, 5: as 1, 2 WITHOUT the fp32 transposed copy -- only its bf16 copy has a reader while the
+    // per-XCD chains run: 17 MB of writes less per layer) with every load and store UNCONDITIONAL -- the compiler then counts what is outstanding and waits for
     // exactly the loads it needs; behind a conditional store it waits for everything, i.e. for the previous chunk's stores to drain
     // (twice per chunk).
     auto epilogue = [&](auto vtag) {
@@ -2189,7 +2190,7 @@ __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int 
             pv.x = pv.x + (-g.lr) * c[0]; pv.y = pv.y + (-g.lr) * c[1]; pv.z = pv.z + (-g.lr) * c[2]; pv.w = pv.w + (-g.lr) * c[3];
             *reinterpret_cast<float4 *>(g.P + (size_t)m * g.ldc + n) = pv;
             *reinterpret_cast<float4 *>(cs) = pv;
-            if (V == 1 || (V == 0 && g.s3 && !g.s3t)) {
+            if (V == 1 || V == 4 || (V == 0 && g.s3 && !g.s3t)) {
               const float v4[4] = {pv.x, pv.y, pv.z, pv.w};
               split_store4(F ? 3 : g.s3mode, v4, g.s3 + (size_t)m * g.ldc + n, g.s3pl);
             }
@@ -2204,18 +2205,21 @@ __device__ __forceinline__ void gemm_tile_bf16_tn(const GemmJob &g, int m0, int 
             if (F || (n < g.N && m + 4 <= g.M)) {
               const float *cs = Cs + lr * CLD + nl;
               const float v4[4] = {cs[0], cs[CLD], cs[2 * CLD], cs[3 * CLD]};
-              *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+              if (V <= 3) *reinterpret_cast<float4 *>(g.Ct + (size_t)n * g.ldct + m) = make_float4(v4[0], v4[1], v4[2], v4[3]);
               if (V == 3 || (V == 0 && g.s3 && g.s3t)) split_store4(F ? 3 : g.s3mode, v4, g.s3 + (size_t)n * g.ldct + m, g.s3pl);
-              if (V == 1 || V == 2 || (V == 0 && g.cth)) split_store4(3, v4, g.cth + (size_t)n * g.ldct + m, 0);
+              if (V == 1 || V == 2 || V == 4 || V == 5 || (V == 0 && g.cth)) split_store4(3, v4, g.cth + (size_t)n * g.ldct + m, 0);
             }
           }
           __syncthreads();
         }
       }
     };
+    // (NO32 is the KERNEL's: full tiles of W_gifo_r / W_gifo_x leave the fp32 transposed copy out, partial tiles -- the generic epilogue --
+    //  still write it, which is harmless: the engine treats the whole copy as stale.  A kernel with six epilogues, or a generic one with
+    //  a pointer test around that store, sent the register allocator into scratch: 872 bytes, 45 -> 73 us per launch.)
     const bool fast = m0 + BT <= g.M && n0 + BTN <= g.N && g.beta != 0.f && g.Ct && (!g.s3 || g.s3mode == 3);
-    if (fast && g.s3 && !g.s3t && g.cth) epilogue(std::integral_constant<int, 1>());
-    else if (fast && !g.s3 && g.cth) epilogue(std::integral_constant<int, 2>());
+    if (fast && g.s3 && !g.s3t && g.cth) epilogue(std::integral_constant<int, NO32 ? 4 : 1>());
+    else if (fast && !g.s3 && g.cth) epilogue(std::integral_constant<int, NO32 ? 5 : 2>());
     else if (fast && g.s3 && g.s3t && !g.cth) epilogue(std::integral_constant<int, 3>());
     else epilogue(std::integral_constant<int, 0>());
     return;
@@ -2342,6 +2346,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_nt(GemmJob g) {
   }
 }
 
+template <bool NO32>
 __global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
   const bool invalid = a.guard && (a.guard[2] | a.guard[6] | a.guard[9]);
   if (a.mark && blockIdx.x == 0 && threadIdx.x == 0) *a.mark = invalid ? 1.f : 0.f;
@@ -2357,10 +2362,10 @@ __global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
     const int lb = b < a.nb0 ? b : b < a.nb1 ? b - a.nb0 : b - a.nb1;
     if (a.bf16_narrow) {
       const int ntn = (g.N + BT / 2 - 1) / (BT / 2);
-      gemm_tile_bf16_tn<2>(g, (lb / ntn) * BT, (lb % ntn) * (BT / 2), As, Bs);
+      gemm_tile_bf16_tn<2, NO32>(g, (lb / ntn) * BT, (lb % ntn) * (BT / 2), As, Bs);
     } else {
       const int ntn = (g.N + BT - 1) / BT;
-      gemm_tile_bf16_tn<4>(g, (lb / ntn) * BT, (lb % ntn) * BT, As, Bs);
+      gemm_tile_bf16_tn<4, NO32>(g, (lb / ntn) * BT, (lb % ntn) * BT, As, Bs);
     }
     return;
   }
@@ -2432,7 +2437,7 @@ __global__ __launch_bounds__(256) void k_update_repack(UpdArgs a) {
   float *dst = a.dstT[mi];
   for (int j = ty; j < 32; j += 8) {
     const int c = bx + j, r = by + tx;     // dst[c][r]
-    if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[tx][j];
+    if (dst && c < cols && r < rows) dst[(size_t)c * rows + r] = tile[tx][j];
   }
 }
 
@@ -2519,7 +2524,7 @@ __global__ __launch_bounds__(256) void k_update_repack_v(UpdArgs a) {
     if (c < cols && r + 4 <= rows) {
       const float *tp = tile + rq * 68 + cl;
       const float v4[4] = {tp[0], tp[68], tp[2 * 68], tp[3 * 68]};
-      *reinterpret_cast<float4 *>(dst + (size_t)c * rows + r) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+      if (dst) *reinterpret_cast<float4 *>(dst + (size_t)c * rows + r) = make_float4(v4[0], v4[1], v4[2], v4[3]);   // (null: only the bf16 copy has a reader)
       if (mi == 2 && a.b3) split_store4(a.split_mode, v4, a.b3 + (size_t)c * rows + r, a.b_plane);
       if (a.dstTh[mi]) split_store4(3, v4, a.dstTh[mi] + (size_t)c * rows + r, 0);
     }
@@ -3500,7 +3505,8 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
     a.nb0 = cdiv(4 * C, BT) * cdiv(I, btn);
     a.nb1 = a.nb0 + cdiv(4 * C, BT) * cdiv(R, btn);
     a.nb2 = a.nb1 + cdiv(R, BT) * cdiv(C, btn);
-    KLAUNCH(k_grads_bf16, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
+    if (upd && upd->no_wT32) KLAUNCH(k_grads_bf16<true>, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
+    KLAUNCH(k_grads_bf16<false>, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
   }
   KLAUNCH(k_grads, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
 }

@@ -1460,6 +1460,49 @@ def test_bf16_operand_copies_of_the_batched_bptt_products(I, C, R, S, T, flags):
         bound(float(np.abs(a - b).max() / np.abs(b).max()), 2e-4, "own plan of the copies form vs the fp32-operand form")
 
 
+@pytest.mark.parametrize("direction", ["bwd", "fwd"])
+def test_fp32_transposed_copies_left_out_by_the_update_are_back_for_whoever_needs_them(direction):
+    """While the per-XCD chains run, the Update writes only the bf16 copies of W_gifo_r^T / W_gifo_x^T ("gemm_copies" = 1: nothing reads
+    the fp32 ones then; 17 MB of writes less per layer and minibatch).  Everybody else who reads them -- the launch-per-step chain that
+    runs a minibatch again after a give-up and the cool-down minibatch behind it (k_pack, the step kernels), the chain after
+    "persist" = 0, the fp32-operand product after "gemm_copies" = 0 -- must find them refreshed first.  Twin: the same engine with
+    "gemm_copies" = 2 (bf16 copies AND fp32 copies on every Update): the same kernels on the same operands otherwise, so every output of
+    seven chained minibatches is BIT-IDENTICAL -- two on the chains, a forced give-up (run again one launch per step), its cool-down
+    minibatch, one back on the chains, one after "persist" = 0, one after "gemm_copies" = 0."""
+    import kaldi_lstm_amd as k
+    I, C, R, S, T = 512, 1024, 512, 32, 20
+    p = make_params(I, C, R, scale=0.02, seed=31)
+    rng = np.random.RandomState(32)
+    xs = [dev(rng.randn(T * S, I)) for _ in range(7)]
+    ods = [dev(0.2 * rng.randn(T * S, R)) for _ in range(7)]
+    res = []
+    for mode in (1, 2):
+        e = k.Engine(I, C, R, S); e.set_params(p); e.set_option("bf16", 1); e.set_option("gemm_copies", mode)
+        e.set_option("persist_spin_us", 3000); e.set_option("persist_cooldown", 1); e.set_option("profile", 1)
+        out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+        got = []
+        for i, (x, od) in enumerate(zip(xs, ods)):
+            if i == 2:
+                e.set_option("persist_test_stall_" + direction, 4)
+            if i == 5:
+                e.set_option("persist", 0)
+            if i == 6:
+                e.set_option("persist", -1); e.set_option("gemm_copies", 0)
+            e.propagate(x, out); e.backpropagate(x, od, idf, momentum=0.9, flags=2); e.update(1e-3); e.synchronize()
+            if i == 2:
+                e.set_option("persist_test_stall_" + direction, 0)
+            got.append((out.cpu().numpy().copy(), idf.cpu().numpy().copy(), e.get_corr(), e.get_params()))
+        assert e.profile_query("persist_giveups")[1] == 1 and e.profile_query("persist_replayed")[1] == 1
+        assert e.profile_query("persist_dropped")[1] == 0
+        if mode == 1:
+            assert e.profile_query("gemm_copies_launches")[1] == 2      # minibatches 2 (index 1) and 5 (index 4); 3 gave up before / ran again without
+        res.append(got)
+        e.close()
+    for i, (a_, b_) in enumerate(zip(res[0], res[1])):
+        for name, u, v in zip(("out", "in_diff", "corr", "params"), a_, b_):
+            assert np.array_equal(u, v), f"minibatch {i}: {name} (max abs diff {np.abs(u - v).max():.3g})"
+
+
 @pytest.mark.parametrize("I,C,R,S,T", [(512, 1024, 512, 16, 20), (512, 1024, 512, 32, 20), (40, 1024, 512, 32, 20), (64, 256, 128, 24, 12),
                                        (72, 160, 96, 13, 21), (512, 1024, 256, 13, 21), (96, 1024, 128, 9, 29)])
 def test_many_stream_persistent_forward_bf16(I, C, R, S, T):

@@ -59,7 +59,8 @@ for name, c in agg.items():
 # one gradient launch per LSTM layer and minibatch: k_grads (fp32; bench.py default / --config c4: 2 layers) or k_grads_bf16 (--config c5: 3 layers)
 mcfg = re.search(r"--config[ =](c\d)", cmd)
 layers = {"c4": 2, "c5": 3}.get(mcfg.group(1) if mcfg else "", 1)
-nmb = max(kern.get("k_grads", {}).get("launches", 0), kern.get("k_grads_bf16", {}).get("launches", 0)) // layers
+nmb = max(kern.get("k_grads", {}).get("launches", 0),
+          sum(v.get("launches", 0) for n, v in kern.items() if n.startswith("k_grads_bf16"))) // layers   # (k_grads_bf16<false | true>)
 # steady state = the kernels that run once (or more) per minibatch; what runs once per PROCESS (set_params: k_update_repack_v, k_pack,
 # k_split3, the zero-fills of the planes) is listed as setup and not charged to a minibatch
 steady = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kern.values() if nmb and v["launches"] >= nmb) / nmb if nmb else None
