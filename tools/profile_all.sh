@@ -14,6 +14,7 @@ ROUND_CHECK_ALLOW_STALE_PMC=1 bash tools/round_check.sh r05
 # the probes whose tables the docs quote
 P=gpurun_out/profiles_new
 timeout 300 python tools/scale_probe.py 2>/dev/null | grep -v amdgpu.ids > $P/r05_scale_probe.txt
+timeout 300 python tools/scale_probe.py bf16 2>/dev/null | grep -v amdgpu.ids >> $P/r05_scale_probe.txt
 timeout 120 python tools/tail_timing.py 80 2>/dev/null | grep -v amdgpu.ids > $P/r05_tail_ops.txt
 timeout 200 python tools/gemm16_probe.py --copies 2>/dev/null | grep -v amdgpu.ids > $P/r05_gemm16_copies.txt
 timeout 200 python tools/gemm16_anatomy.py 2>/dev/null | grep -v amdgpu.ids > $P/r05_gemm16_anatomy.txt
