@@ -386,7 +386,11 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
                   resets it; klstm_last_error() carries a remark when a family latches and when it comes back.
                   klstm_profile_query(e, "fp16_redo*") = this engine's events + its device's stateless events; "fp16_redo_own" =
                   this engine's only; "fold_mode" = the fold product's format as it runs (1 while latched)
-   "persist_tail"  0/1  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it
+ *   "persist_tail"  0/1/2  d_r / in_diff inside the persistent backward launch (1, default) or as batched products after it (0).
+ *                  Inside: on TAIL WORKGROUPS of the same launch where the device has compute units to spare next to the chain's
+ *                  C / 4 (they read the chain's exchange without being waited for: the chain runs at its bare pace), else --
+ *                  or with 2 -- on the chain's own workgroups (rounds 3-5).  Same contraction order either way: bit-identical results.
+ *                  klstm_profile_query(e, "persist_tail_wgs") = tail workgroups of the last backward launch (0: none).
  *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.
  *   "fuse_update"  0/1  0 = KLSTM_BPTT_FUSE_UPDATE is ignored: gradient products and Update as separate passes (A-B runs; this engine)

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -92,6 +93,7 @@ struct klstm_engine {
                                                           // per-XCD chains run): whoever needs them -- a launch-per-step chain, k_pack, the fp32-operand product --
                                                           // refreshes them first (ensure_wT32)
   unsigned short *dgifo_h = nullptr;                      // bf16 copy of the dgifo rows, written by the per-XCD BPTT chain ((T_alloc + 2) S x 4C)
+  long tail_wgs = 0;                                      // tail workgroups of the last persistent backward launch (klstm_profile_query "persist_tail_wgs")
   long n_copies = 0;                                      // launches of the batched products that read the bf16 copies (klstm_profile_query "gemm_copies_launches")
   int skip_wT32 = 1;                                      // (part of "gemm_copies": 2 = copies without leaving the fp32 ones out; A-B runs)
   int copies_plan = 0;                                    // option "gemm_copies_plan" (A-B runs): 16 nj + ks forced on the launches that read the copies (0: the planner)
@@ -287,6 +289,8 @@ static size_t ws_need(const klstm_engine *e, int T) {
   if (np > need) need = np;
   const size_t nx = (size_t)8 * M * (e->R > e->I ? e->R : e->I);                                     // the per-XCD BPTT chain's d_r / in_diff in 8 K slices
   if (nx > need) need = nx;
+  const size_t ntl = persist_bwd_tail_ws_floats(d, true);                                             // the persistent BPTT launch's tail workgroups: partial d_r / in_diff rows per 32-cell slot
+  if (ntl > need) need = ntl;
   if (e->use_bf16 && M >= 256) {                                                                      // ... and on the pipelined kernel (klstm_gemm16.hip): padded tiles
     const Nt2Job j[2] = {Nt2Job{(int)M, e->R, 4 * e->C, nullptr, 4 * e->C, nullptr, 4 * e->C, nullptr, e->R, nullptr, nullptr, 0},
                          Nt2Job{(int)M, e->I, 4 * e->C, nullptr, 4 * e->C, nullptr, 4 * e->C, nullptr, e->I, nullptr, nullptr, 0}};
@@ -313,6 +317,11 @@ static bool nt2_products(klstm_engine *e, const Nt2Job *jobs, int njobs, LaunchP
   const Nt2Plan pl = gemm_bf16_nt2_plan(jobs, njobs, copies ? e->copies_plan >> 4 : 0, copies ? e->copies_plan & 15 : 0);
   if (pl.ks > 1 && (pl.ws_floats > e->ws_floats || !e->ws || pl.nt > NT2_TICKETS)) return false;
   *err = launch_gemm_bf16_nt2(jobs, njobs, pl, e->ws, e->ws_floats, e->tickets, NT2_TICKETS, e->stream, pr);
+  if (*err == hipErrorInvalidValue) {               // the launcher refused the plan before anything was enqueued (a forced split the shape
+    (void)hipGetLastError();                        // cannot take, an empty slice): not taken, the caller's round-4 kernels run
+    *err = hipSuccess;
+    return false;
+  }
   if (copies && *err == hipSuccess) e->n_copies++;
   return true;
 }
@@ -361,6 +370,22 @@ static klstm_status ensure_wT32(klstm_engine *e) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
   HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream, probe(e, "k_update_repack")));
   e->wT32_stale = false;
+  return KLSTM_OK;
+}
+// The bf16 copies of W_gifo_r^T / W_gifo_x^T (the LDS-DMA operands of the per-XCD BPTT chain's d_r + in_diff) as roundings of the
+// CURRENT parameters, by an UNGUARDED pure transposition.  The Update kernels write them too -- but an Update can decide ON THE
+// DEVICE to do nothing (a give-up in front of it, a data-parallel peer's validity word), and the host cannot know: an Update that
+// is the first to be asked for the copies (after klstm_create, set_params / sync_params, a "gemm_copies" toggle, a cool-down) is
+// therefore preceded by this pass, so that the copies are valid whether or not it runs.  One extra launch, only then.
+static klstm_status refresh_wth(klstm_engine *e) {
+  const Dims d{e->I, e->C, e->R, e->S, 0};
+  if (!e->wrTh || !e->wxTh || !update_repack_vectorised(d, e->params, e->corr, nullptr, e->wrT, e->wmT, e->wxT)) { e->wth_fresh = false; return KLSTM_OK; }
+  GradsUpdate u{e->params, 0.f, 0.f, e->wrT, e->wmT, e->wxT};
+  u.wrTh = e->wrTh; u.wxTh = e->wxTh;
+  HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream, probe(e, "k_update_repack"),
+                              nullptr, &u, nullptr, nullptr));
+  e->wT32_stale = false;
+  e->wth_fresh = true;
   return KLSTM_OK;
 }
 static klstm_status repack(klstm_engine *e) {
@@ -469,6 +494,7 @@ static klstm_status recover(klstm_engine *e, const unsigned (&w)[16]) {
   // host-side bookkeeping of work the device skipped
   e->grads_pending = false; e->mmt_pending = false; e->verify_later = false;
   e->planes_fresh = false; e->fold_dirty = true; e->foldx_fresh = false;
+  e->wth_fresh = false;                               // (an Update behind the give-up did nothing: the next one that wants the bf16 copies makes them first)
   if (e->pk[0]) e->pk_stale = 15;
   e->bwd_persist = false; e->bwd_xl = false;
   drop_graphs(e);
@@ -664,6 +690,7 @@ klstm_status klstm_create(int input_dim, int cell_dim, int recur_dim, int num_st
   HIPCHK(hipSetDevice(device));
   klstm_engine *e = new klstm_engine();
   e->ncu = prop.multiProcessorCount;
+  e->popt.ncu = e->ncu;
   e->fold_mode = e->fold_eff = fold_default_mode();
   e->rg = range_guard_create();
   range_guard_set_note([](const char *m) { note("%s", m); });
@@ -1024,9 +1051,16 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
                                           st, nullptr, 0, probe(e, "k_gemm_P"), probe(e, "k_reduce_P")));
     else HIPCHK(launch_gemm(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
     if (e->bwd_persist) {
-      tail_inside = e->persist_tail != 0 && persist_tail_in_kernel(d, in_diff != nullptr, e->popt);
+      {   // d_r / in_diff inside the launch: on tail workgroups (the launcher's own conditions: 16-byte rows at the boundary, the
+          // workspace, compute units next to the chain's) or on the chain's workgroups
+        const bool al = (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0 &&
+                        (!in_diff || ((reinterpret_cast<uintptr_t>(in_diff) & 15) == 0 && id_stride % 4 == 0));
+        e->tail_wgs = e->persist_tail != 0 && al && e->ws && e->ws_floats >= persist_bwd_tail_ws_floats(d, in_diff != nullptr)
+                          ? persist_bwd_tail_wgs(d, in_diff != nullptr, e->popt) : 0;
+        tail_inside = e->persist_tail != 0 && (e->tail_wgs > 0 || persist_tail_in_chain(d, in_diff != nullptr, e->popt));
+      }
       HIPCHK(launch_bwd_persist(d, p, e->Pm, out_diff, od_stride, in_diff, id_stride, tail_inside, e->gran[1], e->pctrl + 4, e->popt, st,
-                                probe(e, "k_bwd_persist")));
+                                probe(e, "k_bwd_persist"), e->ws, e->ws_floats, probe(e, "k_tail_reduce")));
       e->persist_dirty = true;
     } else {
       for (int t = T; t >= 1; t--) HIPCHK(launch_dmf_step(d, p, t, e->Pm, st, probe(e, "k_dmf_step")));
@@ -1180,7 +1214,11 @@ static klstm_status verify_now(klstm_engine *e, bool reports) {
         e->persist_dirty = false;
         return KLSTM_OK;
       }
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#else
+      std::this_thread::yield();
+#endif
       if ((spins & 4095) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) break;
     }
   }
@@ -1200,6 +1238,7 @@ klstm_status klstm_propagate(klstm_engine *e, const float *in, int rows, int in_
   if (rows < 0 || rows % e->S != 0)
     return fail(KLSTM_ERR_SHAPE, "klstm_propagate: rows (%d) %% num_stream (%d) != 0", rows, e->S);
   if (rows == 0) {          // T = 0: the reference's loops simply do not run (:261, :328 with zero rows); state is unchanged
+    { klstm_status vs = verify_deferred(e); if (vs != KLSTM_OK) return vs; }   // (a pending wait of the previous minibatch needs its record: as for rows > 0)
     e->rec = MbRec();       // (a new minibatch all the same)
     e->T_fwd = 0;
     e->T_bwd = -1;
@@ -1356,7 +1395,9 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
       fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
       u.split_mode = e->fwd_ms ? 3 : e->fold_eff == 2 ? 2 : 1;        // (the many-stream bf16 launch: the operands themselves as bf16)
     }
-    e->wth_fresh = e->fwd_ms && e->use_copies;                        // (both tile forms of the fused epilogue write them next to wrT / wxT)
+    const bool want_wth = e->fwd_ms && e->use_copies;                 // (both tile forms of the fused epilogue write them next to wrT / wxT)
+    if (want_wth && !e->wth_fresh) { klstm_status ws = refresh_wth(e); if (ws != KLSTM_OK) return ws; }   // (the guarded launch below may do nothing)
+    e->wth_fresh = want_wth && e->wth_fresh;
     if (e->wth_fresh) { u.wrTh = e->wrTh; u.wxTh = e->wxTh; }
     // ... and INSTEAD of them while the per-XCD chains run this engine: nothing reads the fp32 wrT / wxT then (ensure_wT32 for whoever does)
     if (e->wth_fresh && e->bwd_xl && e->skip_wT32 && !e->replaying && !e->use_graph && e->gp_bf16) { u.no_wT32 = true; e->wT32_stale = true; }
@@ -1373,7 +1414,9 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
       fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
       u.split_mode = e->fwd_ms ? 3 : e->fold_eff == 2 ? 2 : 1;        // (the many-stream bf16 launch: the operands themselves as bf16)
     }
-    e->wth_fresh = e->planes_fresh && e->fwd_ms && e->use_copies;     // (planes_fresh: the vector kernel runs, and it is handed `u`)
+    const bool want_wth = e->planes_fresh && e->fwd_ms && e->use_copies;   // (planes_fresh: the vector kernel runs, and it is handed `u`)
+    if (want_wth && !e->wth_fresh) { klstm_status ws = refresh_wth(e); if (ws != KLSTM_OK) return ws; }   // (as above: guard or peer-skip mark)
+    e->wth_fresh = want_wth && e->wth_fresh;
     if (e->wth_fresh) { u.wrTh = e->wrTh; u.wxTh = e->wxTh; }
     const bool no32 = e->wth_fresh && e->bwd_xl && e->skip_wT32 && !e->replaying && !e->use_graph;   // (as above)
     if (no32) e->wT32_stale = true;
@@ -1508,7 +1551,13 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     e->fuse_update_ok = value != 0;
     return KLSTM_OK;
   }
-  if (!strcmp(key, "gemm_copies_plan")) { e->copies_plan = value < 0 ? 0 : value; return KLSTM_OK; }
+  if (!strcmp(key, "gemm_copies_plan")) {
+    const int nj = value >> 4, ks = value & 15;       // 16 nj + ks; 0 = the planner
+    if (value != 0 && (value < 0 || (nj != 1 && nj != 2 && nj != 4) || (ks != 1 && ks != 2 && ks != 4 && ks != 8)))
+      return fail(KLSTM_ERR_ARG, "gemm_copies_plan: 16 nj + ks with nj in {1, 2, 4} and ks in {1, 2, 4, 8} (or 0)");
+    e->copies_plan = value;
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "gemm_copies")) {     // 0: d_r + in_diff of the many-stream bf16 mode round their fp32 operands while staging them (no bf16 copies are written or read)
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
@@ -1549,7 +1598,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else if (!strcmp(key, "persist_spin_us")) e->popt.spin_limit = (long long)value * 100;      // wall clock: 100 MHz
     else if (!strcmp(key, "persist_test_stall_fwd")) e->popt.test_stall_fwd = value;            // test hooks: force the timeout path
     else if (!strcmp(key, "persist_test_stall_bwd")) e->popt.test_stall_bwd = value;
-    else if (!strcmp(key, "persist_ncu")) e->ncu = value;                                       // test hook: pretend the device has this many CUs
+    else if (!strcmp(key, "persist_ncu")) { e->ncu = value; e->popt.ncu = value; }                                      // test hook: pretend the device has this many CUs
     else if (!strcmp(key, "persist_verify")) e->persist_verify = value != 0;
     else if (!strcmp(key, "persist_verify_spin")) e->verify_spin = value != 0;
     else if (!strcmp(key, "persist_cooldown")) { e->cooldown_len = value < 0 ? 0 : value; e->cooldown_cur = 0; if (e->cooldown > e->cooldown_len) e->cooldown = e->cooldown_len; }
@@ -1560,6 +1609,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
     e->persist_tail = value;
+    e->popt.tail_mode = value;                       // (1: inside, on tail workgroups where they fit; 2: inside, on the chain's workgroups; 0: after the launch)
     return KLSTM_OK;
   }
   // Process-wide knobs (which kernel a product runs on; A-B experiments and tests): the cached graphs of EVERY live engine hold
@@ -1642,6 +1692,7 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
     const struct { const char *name; long v; } ctr[] = {
         {"persist_giveups", e->n_giveups}, {"persist_replayed", e->n_replayed}, {"persist_dropped", e->n_dropped},
         {"persist_launches", (long)e->pseq}, {"persist_cooldown", (long)e->cooldown}, {"gemm_copies_launches", e->n_copies},
+        {"persist_tail_wgs", e->tail_wgs},
         // range-guard events: this engine's own products + the stateless klstm_affine_* calls made on this device (its default guard)
         {"fp16_redo", ev(REDO_FOLD) + ev(REDO_NT) + ev(REDO_OUTER) + ev(REDO_SKINNY)},
         {"fp16_redo_fold", ev(REDO_FOLD)}, {"fp16_redo_nt", ev(REDO_NT)},

@@ -502,12 +502,12 @@ hipError_t launch_gemm_bf16_nt2(const Nt2Job *jobs, int njobs, const Nt2Plan &pl
   a.dbg = g16_dbg;
   const dim3 grid(8 * a.cpg), block(512);
   auto go = [&](auto kern, int lds, int hslot = -1) -> hipError_t {
-    static bool raised[12] = {false, false, false, false, false, false, false, false, false, false, false, false};   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
-    const int slot = hslot >= 0 ? hslot : (pl.nj == 4 ? 2 : pl.nj == 2 ? 1 : 0) + (g16_dbg ? 3 : 0);
-    if (!raised[slot]) {
+    // (per launch, like every other kernel here: the attribute belongs to the current DEVICE -- engines may sit on several -- and a
+    //  process-wide "already raised" cache would also be a data race between host threads)
+    (void)hslot;
+    {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return e;
-      raised[slot] = true;
     }
     if (pr.start) hipExtLaunchKernelGGL(kern, grid, block, lds, st, pr.start, pr.stop, 0, a);
     else hipLaunchKernelGGL(kern, grid, block, lds, st, a);

@@ -288,6 +288,10 @@ struct PersistOpts {
   int nap0 = -1, nap = -1;        // sweepers sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
   int nap0_bwd = -1;              // the same for the backward launch
   int bwd_waves = 0;              // backward: 12 or 16 waves per workgroup
+  int ncu = 0;                    // compute units of the device (0: unknown): the backward launch puts d_r / in_diff on workgroups of their own when
+                                  // there are enough of them next to the chain's C / 4
+  int tail_mode = -1;             // option "persist_tail": -1 / 1 d_r / in_diff inside the backward launch, on tail workgroups where they fit, else on
+                                  // the chain's; 2 always on the chain's workgroups (rounds 3-5); 0 batched products after the launch
   int bwd_interleave = -1;        // backward, 5..8 streams: the two groups of 4 as interleaved chains (-1 / 1) or one after the other (0)
   int xl = -1;                    // many streams, bf16, C = 1024: one chain per XCD (klstm_persist_xl.hip; -1 / 1) or klstm_persist_ms.hip (0)
   int xl_bwd = -1;                // ... and the BPTT chain the same way (-1 / 1) or one launch per step (0)
@@ -311,9 +315,15 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
                               unsigned long long *gran, unsigned *ctrl, const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});
 bool persist_p_in_kernel(const Dims &d, const PersistOpts &o);   // P = out_diff W_r_m computed inside the backward launch (then P may be null)
 bool persist_tail_in_kernel(const Dims &d, bool want_in_diff, const PersistOpts &o);   // d_r / in_diff contracted inside the backward launch
+bool persist_tail_in_chain(const Dims &d, bool want_in_diff, const PersistOpts &o);    // ... on the chain's own workgroups
+int persist_bwd_tail_wgs(const Dims &d, bool want_in_diff, const PersistOpts &o);      // ... on this many workgroups of their own (0: on the chain's)
+// tws / tws_floats: workspace for the tail workgroups' partial rows (persist_bwd_tail_ws_floats; null: the chain's workgroups carry d_r / in_diff);
+// pr_reduce: the k_tail_reduce launch behind the chain launch when tail workgroups ran
+size_t persist_bwd_tail_ws_floats(const Dims &d, bool want_in_diff);
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, const float *out_diff, int od_stride,
                               float *in_diff, int id_stride, bool tail_inside, unsigned long long *gran, unsigned *ctrl,
-                              const PersistOpts &o, hipStream_t st, LaunchProbe pr = {});
+                              const PersistOpts &o, hipStream_t st, LaunchProbe pr = {}, float *tws = nullptr, size_t tws_floats = 0,
+                              LaunchProbe pr_reduce = {});
 
 // Many-stream (9..32) weights-resident forward chain of the bf16 operand mode (klstm_persist_ms.hip): one launch runs all T steps of
 // the folded recurrence; wrm = W_gifo_r W_r_m as bf16, logical rows (4 cell + gate) x C (launch_fold_ms, once per Update); the x term must be in

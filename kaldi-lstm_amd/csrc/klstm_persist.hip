@@ -479,8 +479,8 @@ int persist_fwd_grid(const Dims &d, const PersistOpts &o) {
   const PGeo g = pick_geo_fwd(o, d.C, pcdiv(d.C, KCH) + pcdiv(Ik, KCH), pcdiv(d.R, KCH) * KCH + Ik);
   return g.tpw ? d.C / 4 / g.tpw : 0;
 }
-// forward: [2 parities][C][8 stream slots]; backward: [2 stream groups][2 parities][C][4 stream slots] -- the same size
-size_t persist_gran_bytes(const Dims &d) { return (size_t)2 * d.C * 8 * sizeof(unsigned long long); }
+// forward: [2 parities][C][8 stream slots]; backward: [2 stream groups][BWD_RING = 32 ring slots][C][4 stream slots] (klstm_persist_bwd.hip)
+size_t persist_gran_bytes(const Dims &d) { return (size_t)32 * d.C * 8 * sizeof(unsigned long long); }
 
 template <class K, class A>
 static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t st, LaunchProbe pr, const A &a) {

@@ -40,9 +40,18 @@
 
 #include <hip/hip_ext.h>
 
+#include <algorithm>
+#include <type_traits>
+
 namespace klstm {
 
 #pragma clang fp contract(off)
+
+// Granule ring of the backward chains: frame t of a group lives in slot t % BWD_RING.  The chain itself needs 2 (a workgroup publishes
+// frame t - 1 only after it has seen all of frame t); the tail workgroups read the same granules WITHOUT being waited for -- they start
+// late (their resident rows are 256 KB per workgroup) and catch up -- so a slot has to outlive that: 32 slots = they may be 30 frames
+// behind before a frame is lost (which they notice: bwd_tail_role).  1.6 MB per engine at C = 800.
+constexpr int BWD_RING = 32;
 
 struct PersistBwd2Args {
   int C, R, S, T, I;
@@ -60,7 +69,11 @@ struct PersistBwd2Args {
   const float *gifo, *cc, *hh;
   float *dgifo, *dc;
   const float *P;                 // out_diff * W_r_m [T*S x C] (pin == 0)
-  unsigned long long *gran;       // [stream groups][2][C*4] granules, cell-major (4 stream slots per cell)
+  unsigned long long *gran;       // [stream groups][BWD_RING][C*4] granules, cell-major (4 stream slots per cell); frame t lives in ring slot t % BWD_RING
+  int tqpp;                       // ... column quads per part (a multiple of 4)
+  int tq, tparts;                 // tail workgroups (blockIdx >= C/4; d_r / in_diff off the chain, see bwd_tail_role): column quads in total
+                                  // (R/4 of d_r, then I/4 of in_diff; 0: no tail workgroups) and workgroups per 32-cell slot (column parts)
+  float *tws;                     // their partial rows [C/32 slots][T*S][4 tq]
   unsigned *ctrl;                 // [0] epoch, [1] finished workgroups, [2] status (0 = ok)
   int nap0, nap;                  // SC waves sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
   long long spin_limit;           // wall-clock ticks (100 MHz) a single wait may take
@@ -106,6 +119,239 @@ __device__ __forceinline__ float dpp_quad(unsigned v, bool odd_pair) {
                   : __int_as_float(__builtin_amdgcn_update_dpp(0, (int)v, 0xA0, 0xf, 0xf, true));
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------
+// TAIL WORKGROUPS (round 6): d_r(t-1) = out_diff(t-1) + dgifo(t) W_gifo_r (:391) and in_diff(t) = dgifo(t) W_gifo_x (:457) OFF the chain.
+// Until round 5 the first (R + I) / 4 chain workgroups carried 4 of these output columns each: a second contraction of the same
+// dgifo(t) per step, in the loop that sets the pace of the whole chain (69.0 vs 61.0 us per launch at 4 streams, 101.5 vs 83.5 at 8;
+// tools/ab_step.py, "persist_tail" = 0 vs 2).  A chain of C / 4 = 200 workgroups leaves 56 of the 256 compute units idle: workgroups
+// C / 4 .. of the SAME launch land there.
+//   * First form (measured, dropped: profiles/r06_tail_wg_anatomy.txt): every tail workgroup sweeps ALL of d_m(t) like a chain
+//     workgroup, recomputes dgifo(t) of all cells and owns a few output columns.  46 more compute units pulling the 77 KB of planes per
+//     step slowed the CHAIN's plane loads (1.53 -> 1.91 us) and a tail step took 3.96 us against the chain's 2.84: slower than rounds 3-5.
+//   * This form splits K instead: tail workgroup j owns the 32-cell slot j -- the rows (gate, cell) of W_gifo_r^T / W_gifo_x^T of ITS
+//     cells for ALL output columns, resident in registers (72 per lane at 552 columns) -- sweeps the 1 KB of d_m granules of its cells,
+//     pulls the planes of its cells (1.5 KB instead of 77 KB per step), applies the elementwise BPTT exactly as the chain does and
+//     writes its PARTIAL d_r / in_diff rows of frame t to a workspace; k_tail_reduce adds the C / 32 partials in slot order behind the
+//     launch (fixed order: deterministic).  Planes and granules are read once in total, the chain is not disturbed.
+//   * Nobody waits for a tail workgroup, so it may fall behind (a slow start, a co-tenant on its compute unit).  The granule ring has
+//     BWD_RING = 32 slots; a sweep that finds a NEWER frame of this launch in its slot (tag in [tag0 + 1, expected)) has lost its frame:
+//     the workgroup gives up like any expired wait (status word; the engine runs the minibatch again on the launch-per-step chain).
+// Wave 0 sweeps and applies (lane = (cell, stream pair), the SC waves' natural layout) and leaves dgifo(t) of the slot in LDS in MFMA
+// B-operand order; after ONE workgroup barrier every wave contracts it against its TQW column quads (4x4x1 geometry: 16 k per MFMA, 8
+// MFMAs per quad) and lanes 12..15 store 16 bytes per quad and stream.  Two LDS buffers: wave 0 prepares frame t - 1 while the others
+// still contract frame t.
+// IL: the (frame, group) order of the interleaved kernel (t, 0), (t, 1), (t - 1, 0), ...; otherwise group after group.
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int TAIL_TG = 2;       // groups of 4 column quads per wave (32 weight registers each)
+
+template <int NW, bool IL>
+__device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *lds, unsigned epoch, unsigned behind_giveup) {
+  unsigned *abortf = reinterpret_cast<unsigned *>(lds);
+  float *xt2 = lds + 16;                             // [2][4 gates][32 cells][4 streams]
+  const int C = a.C, S = a.S, T = a.T, K = 4 * a.C, R = a.R;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ngrp = (S + 3) >> 2;
+  const int tb = (int)blockIdx.x - C / 4;
+  const int slot = tb / a.tparts, part = tb % a.tparts;      // the 32-cell slot; which a.tqpp column quads of it
+  const int nq = a.tq, ngr = R / 4, ncols = 4 * nq;          // quads 0 .. ngr - 1: d_r columns; then in_diff columns
+  const int q_lo = part * a.tqpp, q_hi = q_lo + a.tqpp < nq ? q_lo + a.tqpp : nq;
+  const int tlo = nq > ngr ? 1 : 2;                  // frame 1 is swept only where in_diff(1) is contracted
+  const int nfr = T - tlo + 1, nsteps = nfr * ngrp;
+  if (__builtin_amdgcn_readfirstlane(behind_giveup) != 0u) return;
+  auto frame_of = [&](int n) { return IL ? T - (n >> 1) : T - n % nfr; };
+  auto group_of = [&](int n) { return IL ? (n & 1) : n / nfr; };
+
+  // ---- resident rows.  Geometry of v_mfma_f32_4x4x1_16b here: block bb = lane >> 2 = (column quad qq = bb >> 2 of the group, k-group kk = bb & 3),
+  // MFMA m contracts k = 4 m + kk (k = 32 e + cell of the slot: 32 MFMAs for the 128 rows), A lane 4 bb + i = W^T[column 4 cq + i][k],
+  // B lane 4 bb + j = dgifo[k][stream j].  Only FOUR k-groups share an output, and they sit in one row of 16 lanes: two DPP row shifts
+  // finish the sum (16 k-groups per output -- the chain's layout -- needs two more cross-row stages per value: 36 values x 4 stages per
+  // wave and step made the contraction VALU-bound, 2.8 us per step; profiles/r06_tail_wg_anatomy.txt) ----
+  const int bb = lane >> 2, i4 = lane & 3, qq = bb >> 2, kk = bb & 3;
+  float wq[TAIL_TG][32];
+  int cqg[TAIL_TG];
+#pragma unroll
+  for (int gq = 0; gq < TAIL_TG; gq++) {
+    const int cq = q_lo + 4 * (wave + NW * gq) + qq; // this lane's column quad of the wave's group gq
+    cqg[gq] = cq;
+    const bool qv = cq < q_hi;
+    const float *src = !qv ? a.wrT : cq < ngr ? a.wrT + (size_t)(4 * cq + i4) * K : a.wxT + (size_t)(4 * (cq - ngr) + i4) * K;
+#pragma unroll
+    for (int m = 0; m < 32; m++) {
+      const int cell = 32 * slot + 4 * (m & 7) + kk;
+      const float v = src[(m >> 3) * C + (cell < C ? cell : 0)];
+      wq[gq][m] = qv && cell < C ? v : 0.f;
+    }
+  }
+  const bool two_groups = q_lo + 4 * (wave + NW) < q_hi;     // (wave-uniform: the second group of this wave exists)
+  float *pslot = a.tws + (size_t)slot * T * S * ncols;       // this slot's partial rows [T * S][ncols]
+
+  // ---- wave 0: the elementwise side (natural layout: cell c32 = lane & 31, stream pair h = lane >> 5) ----
+  const int c32 = lane & 31, h = lane >> 5;
+  const int cl = 32 * slot + c32;
+  const bool live = cl < C;
+  const int clc = live ? cl : 0;
+  const int svoff = clc * 32 + h * 16;
+  const int voffG = (2 * h * K + clc) * 4, voffC = (2 * h * C + clc) * 4;
+  float wpi = 0.f, wpf = 0.f, wpo = 0.f;
+  if (wave == 0) { wpi = a.pi[clc]; wpf = a.pf[clc]; wpo = a.po[clc]; }
+  const __amdgpu_buffer_rsrc_t rs_g = buf_rsrc(a.gifo, (T + 2) * S * K * 4), rs_h = buf_rsrc(a.hh, (T + 2) * S * C * 4);
+  const __amdgpu_buffer_rsrc_t rs_c = buf_rsrc(a.cc, (T + 2) * S * C * 4);
+  const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(a.gran, ngrp * BWD_RING * C * 32);
+  float carry[IL ? 2 : 1][2];
+#pragma unroll
+  for (int gc = 0; gc < (IL ? 2 : 1); gc++) { carry[gc][0] = 0.f; carry[gc][1] = 0.f; }
+  PT_DECL();
+
+  // the elementwise side of one step: planes of the slot's cells, sweep of their granules, dgifo(t) into xt (operand order)
+  auto prepare = [&](auto GC, int t, int g, float *xt) -> bool {
+    constexpr int gc = decltype(GC)::value;
+    const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
+    const bool need0 = 2 * h < Sg, need1 = 2 * h + 1 < Sg;
+    const int sG = (t * S + 4 * g) * K * 4, sC = (t * S + 4 * g) * C * 4;
+    Bptt2Coef cf[2];
+#pragma unroll
+    for (int x = 0; x < 2; x++) {                  // stream 2h + x of the group (absent streams read a later row or zeros: never used)
+      const int oG = sG + x * K * 4, oC = sC + x * C * 4;
+      const float yg = buf_f32(rs_g, voffG, oG), yi = buf_f32(rs_g, voffG, oG + C * 4);
+      const float yf = buf_f32(rs_g, voffG, oG + 2 * C * 4), yo = buf_f32(rs_g, voffG, oG + 3 * C * 4);
+      const float yh = buf_f32(rs_h, voffC, oC), cpv = buf_f32(rs_c, voffC, oC - S * C * 4);
+      cf[x] = bptt2_coef(yg, yi, yf, yo, yh, cpv, wpi, wpf, wpo);
+    }
+    const unsigned tag0 = epoch + (unsigned)(g * (T + 2));
+    const int soff = (g * BWD_RING + t % BWD_RING) * C * 32;
+    u32x4 q;
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 0;; spins++) {
+      q = __builtin_amdgcn_raw_buffer_load_b128(rs_gr, svoff, soff, 16);   // aux 16 = sc1
+      const unsigned d0 = q.y - tag0, d1 = q.w - tag0;                      // frame the granule carries (this launch's: 1 .. T)
+#ifdef KLSTM_PERSIST_TIMING
+      const bool ok = !live | (((!need0) | (d0 - 1u < (unsigned)t)) & ((!need1) | (d1 - 1u < (unsigned)t)));   // (tools/persist_anatomy: a lost frame counts as seen -- timing only)
+      const bool lost = false;
+#else
+      const bool ok = !live | (((!need0) | (d0 == (unsigned)t)) & ((!need1) | (d1 == (unsigned)t)));
+      const bool lost = live & ((need0 & (d0 - 1u < (unsigned)t - 1u)) | (need1 & (d1 - 1u < (unsigned)t - 1u)));   // a NEWER frame sits in the slot
+#endif
+      if (__all(ok)) break;
+      if (__any(lost) || ((spins & 15) == 15 && wall_clock64() - t0 > a.spin_limit)) {
+        __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) { atomicCAS(&a.ctrl[3], 0u, launch_ordinal(a.guard)); atomicMax(&a.ctrl[2], 0x80000000u | 0x4000u | (unsigned)t); }
+        return false;
+      }
+      for (int i = 0; i < a.nap; i++) __builtin_amdgcn_s_sleep(1);
+    }
+    PT_MARK(0);                                      // planes + sweep
+    float dcv;
+    const float4 d0 = bptt2_apply(live ? __uint_as_float(q.x) : 0.f, cf[0], carry[gc][0], dcv);
+    const float4 d1 = bptt2_apply(live ? __uint_as_float(q.z) : 0.f, cf[1], carry[gc][1], dcv);
+    float2 *xw = reinterpret_cast<float2 *>(xt + c32 * 4 + 2 * h);
+    xw[0] = make_float2(d0.x, d1.x); xw[64] = make_float2(d0.y, d1.y);             // gate e at + e*128 floats
+    xw[128] = make_float2(d0.z, d1.z); xw[192] = make_float2(d0.w, d1.w);
+    PT_MARK(1);                                      // apply + tile
+    return true;
+  };
+  // the contraction side: every wave, its groups of 4 column quads against the slot's dgifo(t)
+  auto contract = [&](int t, int g, const float *xt) {
+    const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
+    f32x4 acc[TAIL_TG][2];
+#pragma unroll
+    for (int gq = 0; gq < TAIL_TG; gq++) { acc[gq][0] = (f32x4){0, 0, 0, 0}; acc[gq][1] = (f32x4){0, 0, 0, 0}; }
+    const float *xb = xt + kk * 4 + i4;              // B lane 4 bb + j: dgifo[k = 4 m + kk][j]: [e = m >> 3][cell 4 (m & 7) + kk][j]
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {                 // (the B operand in two halves of 16 registers)
+      float Bv[16];
+#pragma unroll
+      for (int mm = 0; mm < 16; mm++) { const int m = 16 * hh + mm; Bv[mm] = xb[(m >> 3) * 128 + (m & 7) * 16]; }
+#pragma unroll
+      for (int mm = 0; mm < 16; mm++)
+        acc[0][mm & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[0][16 * hh + mm], Bv[mm], acc[0][mm & 1], 0, 0, 0);
+      if (two_groups) {
+#pragma unroll
+        for (int mm = 0; mm < 16; mm++)
+          acc[1][mm & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[1][16 * hh + mm], Bv[mm], acc[1][mm & 1], 0, 0, 0);
+      }
+    }
+    float *orow = pslot + ((size_t)(t - 1) * S + 4 * g + i4) * ncols;
+    const bool st_lane = kk == 3 && i4 < Sg;         // lanes 12..15 of every row of 16: (stream i4) of the row's quad
+#pragma unroll
+    for (int gq = 0; gq < TAIL_TG; gq++) {
+      if (gq == 1 && !two_groups) break;
+      const f32x4 v = acc[gq][0] + acc[gq][1];
+      float c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {                  // the row's four k-groups (klstm_persist_dev.h kgroup_sum, first half)
+        c[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[e]), 0x114, 0xf, 0xf, true));   // row_shr:4
+        c[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c[e]), 0x118, 0xf, 0xf, true));   // row_shr:8
+      }
+      if (st_lane && cqg[gq] < q_hi) *reinterpret_cast<float4 *>(orow + 4 * cqg[gq]) = make_float4(c[0], c[1], c[2], c[3]);
+    }
+  };
+
+  for (int n = 0; n < nsteps; n++) {
+    const int t = frame_of(n), g = group_of(n);
+    float *xt = xt2 + (n & 1) * 512;
+    PT_MARK(5);
+    if (wave == 0) {
+      bool ok;
+      if (IL) ok = (n & 1) ? prepare(std::integral_constant<int, IL ? 1 : 0>(), t, g, xt) : prepare(std::integral_constant<int, 0>(), t, g, xt);
+      else {
+        if (t == T) { carry[0][0] = 0.f; carry[0][1] = 0.f; }     // a new group's chain
+        ok = prepare(std::integral_constant<int, 0>(), t, g, xt);
+      }
+      (void)ok;
+    }
+    lds_barrier();                                   // dgifo(t) of the slot is in xt (the other buffer: frame t + 1, read by now)
+    PT_MARK(2);
+    if (*abortf) break;
+    contract(t, g, xt);
+    PT_MARK(3);                                      // contraction + partial rows
+  }
+  PT_FLUSH(0);
+}
+
+// d_r / in_diff from the tail workgroups' partial rows: the nslots partials of an output added in slot order (fixed order), out_diff
+// added to the d_r columns (:391), d_r(T) = out_diff(T) (:351).  One thread per (frame row, column quad).
+struct TailReduceArgs {
+  const float *tws; int nslots, T, S, R, ncols;
+  const float *od; int od_stride;
+  float *dr; float *in_diff; int id_stride;
+  const unsigned *guard;          // a launch in front gave up: the partial rows are not there -- write nothing (everything is run again)
+};
+__global__ __launch_bounds__(256) void k_tail_reduce(TailReduceArgs a) {
+  if (a.guard && (a.guard[2] | a.guard[6])) return;
+  // 8 lanes per (frame row, column quad): lane l adds slots l, l + 8, l + 16, ... in that order, then three butterfly stages -- one fixed
+  // tree for every output, whatever the launch geometry: deterministic.  (One thread per output walked its 25 slots alone: 173 waves on
+  // the whole chip, 25 dependent round trips.)
+  const int nqc = a.ncols >> 2;
+  const int gidx = blockIdx.x * 256 + threadIdx.x, idx = gidx >> 3, l = gidx & 7;
+  const bool on = idx < a.T * a.S * nqc;
+  const int r = on ? idx / nqc : 0, cq = on ? idx - r * nqc : 0;       // r = (t - 1) S + s
+  const int t = r / a.S + 1, s = r - (t - 1) * a.S;
+  const bool isr = 4 * cq < a.R;
+  const size_t stride = (size_t)a.T * a.S * a.ncols;
+  const float *p = a.tws + (size_t)r * a.ncols + 4 * cq;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = l; j < a.nslots; j += 8) {
+    const float4 v = *reinterpret_cast<const float4 *>(p + j * stride);
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {
+    sum.x += __shfl_xor(sum.x, m); sum.y += __shfl_xor(sum.y, m); sum.z += __shfl_xor(sum.z, m); sum.w += __shfl_xor(sum.w, m);
+  }
+  if (!on || l != 0) return;
+  if (isr) {
+    if (t < 2) return;                               // (frame 1 feeds no d_r row; d_r(T) = out_diff(T) goes out with the row of frame T; T >= 3 here)
+    const float4 o = *reinterpret_cast<const float4 *>(a.od + (size_t)((t - 2) * a.S + s) * a.od_stride + 4 * cq);
+    *reinterpret_cast<float4 *>(a.dr + ((size_t)(t - 1) * a.S + s) * a.R + 4 * cq) = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + sum.w);   // :391
+    if (t == a.T)
+      *reinterpret_cast<float4 *>(a.dr + ((size_t)a.T * a.S + s) * a.R + 4 * cq) = *reinterpret_cast<const float4 *>(a.od + (size_t)((a.T - 1) * a.S + s) * a.od_stride + 4 * cq);
+  } else if (a.in_diff) {
+    *reinterpret_cast<float4 *>(a.in_diff + (size_t)((t - 1) * a.S + s) * a.id_stride + 4 * cq - a.R) = sum;   // :457
+  }
+}
+
 template <int NW, int NU>
 __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
   constexpr int NSC = NW - 2, NSLOT = NSC * NU;
@@ -145,7 +391,9 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
   __syncthreads();
   PT_DECL();
 
-  if (wave == 0) {
+  if (a.tq && (int)blockIdx.x >= C / 4) {
+    bwd_tail_role<NW, false>(a, lds, epoch, behind_giveup);          // a tail workgroup: d_r / in_diff partials of its 32 cells, off the chain
+  } else if (wave == 0) {
     // =========================== owner: combine, publish, own plane rows ===========================
     // lanes 0..15 = (own cell oi = lane >> 2, stream oj = lane & 3)
     const int oi = (lane >> 2) & 3, oj = lane & 3;
@@ -158,7 +406,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
       const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
       const bool on = lane < 16 && oj < Sg;
       const int srow = 4 * g + (oj < Sg ? oj : 0);
-      unsigned long long *gr = a.gran + (size_t)g * 2 * C * 4;
+      unsigned long long *gr = a.gran + (size_t)g * BWD_RING * C * 4;
       const unsigned tag0 = epoch + (unsigned)(g * (T + 2));
       if (on) {                                      // the batched d_r product (tail outside) reads dgifo(T+1) as operand rows: zero (:351)
         float *zp = a.dgifo + ((size_t)(T + 1) * S + srow) * K + ocell;
@@ -172,7 +420,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
       } else {
         dmv = a.P[((size_t)(T - 1) * S + srow) * C + ocell];
       }
-      if (on && !(a.test_stall == T && blockIdx.x == 0)) publish(gr + (size_t)(T & 1) * C * 4, ocell * 4 + oj, tag0 + (unsigned)T, dmv);
+      if (on && !(a.test_stall == T && blockIdx.x == 0)) publish(gr + (size_t)(T % BWD_RING) * C * 4, ocell * 4 + oj, tag0 + (unsigned)T, dmv);
       __hip_atomic_store(pubn, g * T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       float carry = 0.f;
       float yg, yi, yf, yo, yh, cpv;
@@ -212,7 +460,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
         for (int w = 1; w < NSC; w++) sum += part[w];  // fixed order
         const float dmn = sum + pnext;               // :408 with :391 substituted: d_m(t-1) = contraction + P(t-1)
         if (on && !(a.test_stall == t - 1 && blockIdx.x == 0))
-          publish(gr + (size_t)((t - 1) & 1) * C * 4, ocell * 4 + oj, tag0 + (unsigned)(t - 1), dmn);
+          publish(gr + (size_t)((t - 1) % BWD_RING) * C * 4, ocell * 4 + oj, tag0 + (unsigned)(t - 1), dmn);
         __hip_atomic_store(pubn, g * T + (T - t + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         PT_MARK(1);                                  // combine + publish
         own_rows(t, dmv);
@@ -355,7 +603,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
     for (int g = 0; g < ngrp && !dead; g++) {
       const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
       const bool need0 = 2 * h < Sg, need1 = 2 * h + 1 < Sg;
-      const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(a.gran + (size_t)g * 2 * C * 4, 2 * C * 32);
+      const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(a.gran + (size_t)g * BWD_RING * C * 4, BWD_RING * C * 32);
       const unsigned tag0 = epoch + (unsigned)(g * (T + 2));
       float carry[NU][2];
 #pragma unroll
@@ -382,7 +630,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
         // ---- sweep d_m(t): until every live tag equals tag0 + t ----
         for (int i = 0; i < a.nap0; i++) __builtin_amdgcn_s_sleep(4);
         const unsigned tag = tag0 + (unsigned)t;
-        const int soff = (t & 1) * C * 32;
+        const int soff = (t % BWD_RING) * C * 32;
         u32x4 q[NU];
         {
           const long long t0 = wall_clock64();
@@ -538,7 +786,9 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
   __syncthreads();
   const int Sg1 = S - 4;                             // streams of group 1 (group 0 has 4)
 
-  if (wave == 0) {
+  if (a.tq && (int)blockIdx.x >= C / 4) {
+    bwd_tail_role<NW, true>(a, lds, epoch, behind_giveup);           // a tail workgroup: d_r / in_diff partials of its 32 cells, off the chains
+  } else if (wave == 0) {
     // =========================== owner: combine, publish, own plane rows ===========================
     const int oi = (lane >> 2) & 3, oj = lane & 3;
     const int ocell = (int)blockIdx.x * 4 + oi;
@@ -554,7 +804,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
       const int Sg = g ? Sg1 : 4;
       on[g] = lane < 16 && oj < Sg;
       srow[g] = 4 * g + (oj < Sg ? oj : 0);
-      gr[g] = a.gran + (size_t)g * 2 * C * 4;
+      gr[g] = a.gran + (size_t)g * BWD_RING * C * 4;
       tag0[g] = epoch + (unsigned)(g * (T + 2));
     }
     auto load_planes = [&](int t, int g) {
@@ -586,7 +836,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
       } else {
         dmv[g] = a.P[((size_t)(T - 1) * S + srow[g]) * C + ocell];
       }
-      if (on[g] && !(a.test_stall == T && blockIdx.x == 0)) publish(gr[g] + (size_t)(T & 1) * C * 4, ocell * 4 + oj, tag0[g] + (unsigned)T, dmv[g]);
+      if (on[g] && !(a.test_stall == T && blockIdx.x == 0)) publish(gr[g] + (size_t)(T % BWD_RING) * C * 4, ocell * 4 + oj, tag0[g] + (unsigned)T, dmv[g]);
       __hip_atomic_store(pubn + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       load_planes(T, g);
     }
@@ -609,7 +859,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
         for (int w = 1; w < NSC; w++) sum += part[w];  // fixed order
         const float dmn = sum + pnext;               // :408 with :391 substituted
         if (on[g] && !(a.test_stall == t - 1 && blockIdx.x == 0))
-          publish(gr[g] + (size_t)((t - 1) & 1) * C * 4, ocell * 4 + oj, tag0[g] + (unsigned)(t - 1), dmn);
+          publish(gr[g] + (size_t)((t - 1) % BWD_RING) * C * 4, ocell * 4 + oj, tag0[g] + (unsigned)(t - 1), dmn);
         __hip_atomic_store(pubn + g, T - t + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         own_rows(t, g);
         dmv[g] = dmn;
@@ -735,7 +985,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
     const int voffG = (2 * h * K + 32 * w + c32) * 4, voffC = (2 * h * C + 32 * w + c32) * 4;
     const __amdgpu_buffer_rsrc_t rs_g = buf_rsrc(a.gifo, (T + 2) * S * K * 4), rs_h = buf_rsrc(a.hh, (T + 2) * S * C * 4);
     const __amdgpu_buffer_rsrc_t rs_c = buf_rsrc(a.cc, (T + 2) * S * C * 4);
-    const __amdgpu_buffer_rsrc_t rs_gr0 = buf_rsrc(a.gran, 2 * C * 32), rs_gr1 = buf_rsrc(a.gran + (size_t)2 * C * 4, 2 * C * 32);
+    const __amdgpu_buffer_rsrc_t rs_gr0 = buf_rsrc(a.gran, BWD_RING * C * 32), rs_gr1 = buf_rsrc(a.gran + (size_t)BWD_RING * C * 4, BWD_RING * C * 32);
     int nd = 0;
     bool dead = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
     float carry[2][NU][2];
@@ -767,7 +1017,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
         // ---- sweep d_m(t) of group g ----
         for (int i = 0; i < a.nap0; i++) __builtin_amdgcn_s_sleep(4);
         const unsigned tag = epoch + (unsigned)(g * (T + 2)) + (unsigned)t;
-        const int soff = (t & 1) * C * 32;
+        const int soff = (t % BWD_RING) * C * 32;
         u32x4 q[NU];
         {
           const long long t0 = wall_clock64();
@@ -887,7 +1137,28 @@ static PGeo2 pick_geo_bwd2(const Dims &d, const PersistOpts &o) {
 }
 static size_t bwd2_lds_bytes(const PGeo2 &g, int T, bool pin, bool interleaved = false) {
   const int nsc = g.nw - 2, nslot = nsc * g.nu, ng = interleaved ? 2 : 1;       // (interleaved: `red` and the P rows per group)
-  return (size_t)(16 + ng * nsc * 16 + 2 * nsc * 16 + nsc * 512 + nslot * 512 + (pin ? ng * T * 16 : 0)) * sizeof(float);
+  return (size_t)(16 + ng * nsc * 16 + 2 * nsc * 16 + nsc * 512 + nslot * 512 + (pin ? ng * T * 16 : 0)) * sizeof(float);   // (a tail workgroup needs 4 KB of it)
+}
+// Tail workgroups (bwd_tail_role): one per 32-cell slot and column part.  Returns the column parts per slot (0: no tail workgroups --
+// the chain's workgroups carry the columns, or the batched products run after the launch).  They need compute units of their own next
+// to the chain's C / 4.
+static int bwd2_tail_parts(const Dims &d, bool want_in_diff, const PersistOpts &o, int *ntw = nullptr, int *qpp = nullptr) {
+  const PGeo2 g = pick_geo_bwd2(d, o);
+  if (ntw) *ntw = 0;
+  if (!g.nw || o.tail_mode == 2 || o.tail_mode == 0 || o.ncu <= d.C / 4 || d.R % 4 != 0 || d.I % 4 != 0) return 0;
+  const int nq = d.R / 4 + (want_in_diff ? d.I / 4 : 0), nslots = pcdiv2(d.C, 32);
+  // the fewest column parts whose quads fit the waves (TAIL_TG groups of 4 quads per wave) -- every part is one more workgroup per slot
+  for (int parts = 1; d.C / 4 + nslots * parts <= o.ncu; parts++) {
+    const int per = 4 * pcdiv2(pcdiv2(nq, parts), 4);
+    if (per > 4 * TAIL_TG * g.nw) continue;
+    if (ntw) *ntw = nslots * parts;
+    if (qpp) *qpp = per;
+    return parts;
+  }
+  return 0;
+}
+size_t persist_bwd_tail_ws_floats(const Dims &d, bool want_in_diff) {
+  return (size_t)pcdiv2(d.C, 32) * d.T * d.S * (d.R + (want_in_diff ? d.I : 0));
 }
 // 5..8 streams: the two groups as interleaved chains (k_bwd_persist2i) unless the option says otherwise
 static bool bwd_interleaved(const Dims &d, const PersistOpts &o) { return d.S > 4 && o.bwd_interleave != 0; }
@@ -903,10 +1174,19 @@ bool persist_p_in_kernel(const Dims &d, const PersistOpts &o) {
   return g.nw != 0 && d.R <= 512 && d.R % 4 == 0 && bwd2_lds_bytes(g, d.T, true, bwd_interleaved(d, o)) <= 152 * 1024;
 }
 // d_r and in_diff inside the backward launch: 4 columns per workgroup
-bool persist_tail_in_kernel(const Dims &d, bool want_in_diff, const PersistOpts &o) {
+bool persist_tail_in_chain(const Dims &d, bool want_in_diff, const PersistOpts &o) {       // ... on the chain's own workgroups (rounds 3-5)
   const PGeo2 g = pick_geo_bwd2(d, o);
   if (!g.nw || d.R % 4 != 0 || d.I % 4 != 0 || d.C % 4 != 0) return false;
   return d.R / 4 + (want_in_diff ? d.I / 4 : 0) <= d.C / 4;
+}
+bool persist_tail_in_kernel(const Dims &d, bool want_in_diff, const PersistOpts &o) {      // ... there, or on tail workgroups (given 16-byte rows at the boundary)
+  return persist_tail_in_chain(d, want_in_diff, o) || bwd2_tail_parts(d, want_in_diff, o) > 0;
+}
+
+int persist_bwd_tail_wgs(const Dims &d, bool want_in_diff, const PersistOpts &o) {
+  int ntw = 0;
+  (void)bwd2_tail_parts(d, want_in_diff, o, &ntw);
+  return ntw;
 }
 
 template <class Kn>
@@ -920,14 +1200,23 @@ static hipError_t plaunch2(Kn kern, int grid, int threads, size_t shm, hipStream
 
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, const float *out_diff, int od_stride,
                               float *in_diff, int id_stride, bool tail_inside, unsigned long long *gran, unsigned *ctrl,
-                              const PersistOpts &o, hipStream_t st, LaunchProbe pr) {
+                              const PersistOpts &o, hipStream_t st, LaunchProbe pr, float *tws, size_t tws_floats, LaunchProbe pr_reduce) {
   PersistBwd2Args a;
   a.C = d.C; a.R = d.R; a.S = d.S; a.T = d.T; a.I = d.I;
   a.pin = persist_p_in_kernel(d, o) && out_diff && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
   if (!a.pin && !P) return hipErrorInvalidValue;
   a.od = out_diff; a.od_stride = od_stride; a.wmT = p.wmT;
   a.din = tail_inside ? (in_diff ? 3 : 1) : 0; a.wrT = p.wrT; a.wxT = p.wxT; a.dr = p.dr; a.in_diff = in_diff; a.id_stride = id_stride;
-  if (a.din && (!persist_tail_in_kernel(d, in_diff != nullptr, o) || !out_diff)) return hipErrorInvalidValue;
+  if (a.din && !out_diff) return hipErrorInvalidValue;
+  // d_r / in_diff on workgroups of their own next to the chain (compute units the chain leaves idle) instead of on the chain's
+  int ntw = 0;
+  a.tq = 0; a.tparts = 0; a.tqpp = 0; a.tws = tws;
+  if (tail_inside && tws && out_diff && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0 &&
+      (!in_diff || ((reinterpret_cast<uintptr_t>(in_diff) & 15) == 0 && id_stride % 4 == 0)) &&
+      tws_floats >= persist_bwd_tail_ws_floats(d, in_diff != nullptr))
+    a.tparts = bwd2_tail_parts(d, in_diff != nullptr, o, &ntw, &a.tqpp);
+  if (a.tparts) { a.tq = d.R / 4 + (in_diff ? d.I / 4 : 0); a.din = 0; }
+  else if (a.din && !persist_tail_in_chain(d, in_diff != nullptr, o)) return hipErrorInvalidValue;   // (neither form takes this call: the caller asks first)
   a.nch1 = p.nch_gates;
   a.wpk = reinterpret_cast<const float *>(p.pk_fold_gates); a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc; a.P = P; a.gran = gran; a.ctrl = ctrl;
@@ -942,19 +1231,28 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
 #endif
   const PGeo2 g = pick_geo_bwd2(d, o);
   if (!g.nw || !p.pk_fold_gates || d.S > 8) return hipErrorInvalidValue;
-  const int grid = persist_bwd_grid(d);
+  const int grid = persist_bwd_grid(d) + ntw;
+  hipError_t err = hipErrorInvalidValue;
   if (bwd_interleaved(d, o)) {
     const size_t shmi = bwd2_lds_bytes(g, d.T, a.pin != 0, true);
-    if (g.nw == 16 && g.nu == 2) return plaunch2(k_bwd_persist2i<16, 2>, grid, 1024, shmi, st, pr, a);
-    if (g.nw == 16 && g.nu == 3) return plaunch2(k_bwd_persist2i<16, 3>, grid, 1024, shmi, st, pr, a);
-    if (g.nw == 12 && g.nu == 3) return plaunch2(k_bwd_persist2i<12, 3>, grid, 768, shmi, st, pr, a);
-    return hipErrorInvalidValue;
+    if (g.nw == 16 && g.nu == 2) err = plaunch2(k_bwd_persist2i<16, 2>, grid, 1024, shmi, st, pr, a);
+    else if (g.nw == 16 && g.nu == 3) err = plaunch2(k_bwd_persist2i<16, 3>, grid, 1024, shmi, st, pr, a);
+    else if (g.nw == 12 && g.nu == 3) err = plaunch2(k_bwd_persist2i<12, 3>, grid, 768, shmi, st, pr, a);
+  } else {
+    const size_t shm = bwd2_lds_bytes(g, d.T, a.pin != 0);
+    if (g.nw == 16 && g.nu == 2) err = plaunch2(k_bwd_persist2<16, 2>, grid, 1024, shm, st, pr, a);
+    else if (g.nw == 16 && g.nu == 3) err = plaunch2(k_bwd_persist2<16, 3>, grid, 1024, shm, st, pr, a);
+    else if (g.nw == 12 && g.nu == 3) err = plaunch2(k_bwd_persist2<12, 3>, grid, 768, shm, st, pr, a);
   }
-  const size_t shm = bwd2_lds_bytes(g, d.T, a.pin != 0);
-  if (g.nw == 16 && g.nu == 2) return plaunch2(k_bwd_persist2<16, 2>, grid, 1024, shm, st, pr, a);
-  if (g.nw == 16 && g.nu == 3) return plaunch2(k_bwd_persist2<16, 3>, grid, 1024, shm, st, pr, a);
-  if (g.nw == 12 && g.nu == 3) return plaunch2(k_bwd_persist2<12, 3>, grid, 768, shm, st, pr, a);
-  return hipErrorInvalidValue;
+  if (err != hipSuccess || !a.tq) return err;
+  // the tail workgroups' partial rows -> d_r, in_diff
+  TailReduceArgs ra;
+  ra.tws = tws; ra.nslots = pcdiv2(d.C, 32); ra.T = d.T; ra.S = d.S; ra.R = d.R; ra.ncols = 4 * a.tq;
+  ra.od = out_diff; ra.od_stride = od_stride; ra.dr = p.dr; ra.in_diff = in_diff; ra.id_stride = id_stride; ra.guard = o.guard;
+  const int nthr = d.T * d.S * a.tq * 8;
+  if (pr_reduce.start) hipExtLaunchKernelGGL(k_tail_reduce, dim3(pcdiv2(nthr, 256)), dim3(256), 0, st, pr_reduce.start, pr_reduce.stop, 0, ra);
+  else hipLaunchKernelGGL(k_tail_reduce, dim3(pcdiv2(nthr, 256)), dim3(256), 0, st, ra);
+  return hipGetLastError();
 }
 
 }  // namespace klstm

@@ -34,7 +34,7 @@ with torch.cuda.stream(stream):
     e.profile_query("k_fold"); e.set_option("profile", 1)
     for i in range(20): step(i)
     kern = {}
-    for name in ("k_fwd_persist", "k_bwd_persist", "k_grads_update", "k_fold", "k_gates_step", "k_gates_fold", "k_dmf_step", "k_grads", "k_update_repack"):
+    for name in ("k_fwd_persist", "k_bwd_persist", "k_tail_reduce", "k_grads_update", "k_fold", "k_gates_step", "k_gates_fold", "k_dmf_step", "k_grads", "k_update_repack"):
         tot, n = e.profile_query(name)
         if n: kern[name] = round(tot / n, 2)
 print(json.dumps({"lib": os.environ.get("KLSTM_LIB_PATH", "default"), "S": S, "opts": opts, "us_per_minibatch": res, "kernels_us": kern}))

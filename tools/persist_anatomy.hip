@@ -23,16 +23,16 @@ int main(int argc, char **argv) {
   float *vecs = dalloc(7 * C), *gifo = dalloc((size_t)(T + 2) * S * 4 * C), *cc = dalloc((size_t)(T + 2) * S * C),
         *hh = dalloc((size_t)(T + 2) * S * C), *mm = dalloc((size_t)(T + 2) * S * C), *x = dalloc((size_t)T * S * I), *cs = dalloc(S * C),
         *wr = dalloc((size_t)4 * C * R), *wx = dalloc((size_t)4 * C * I), *pr0 = dalloc(S * R), *rr = dalloc((size_t)(T + 2) * S * R);
-  unsigned long long *gran; CK(hipMalloc(&gran, 2 * C * 8 * 8)); CK(hipMemset(gran, 0, 2 * C * 8 * 8));
+  unsigned long long *gran; CK(hipMalloc(&gran, 32 * C * 8 * 8)); CK(hipMemset(gran, 0, 32 * C * 8 * 8));
   unsigned *ctrl; CK(hipMalloc(&ctrl, 32)); CK(hipMemset(ctrl, 0, 32));
   long long *dbg; CK(hipMalloc(&dbg, 256 * 16 * 10 * 8)); CK(hipMemset(dbg, 0, 256 * 16 * 10 * 8));
   for (int waves : {12}) for (int tpw : {1}) for (int nap0 : {0, 1, 2, 3, 4, 5, 6, 8}) for (int nap : {0}) {
     if (4 * tpw >= waves) continue;
     PersistOpts o; o.waves = waves; o.tpw = tpw;
-    PersistFwdArgs a;
+    PersistFwdArgs a{};
     a.C = C; a.I = I; a.R = R; a.S = S; a.T = T; a.nchm = nchm; a.nch = nch; a.wpk = wpk; a.wr = wr; a.wx = wx; a.prev_r = pr0; a.rr = rr; a.wm = nullptr; a.rin = 0; a.out = nullptr; a.out_stride = 0;
     a.bias = vecs; a.pi = vecs + 4 * C; a.pf = vecs + 5 * C; a.po = vecs + 6 * C;
-    a.gifo = gifo; a.cc = cc; a.hh = hh; a.mm = mm; a.x = x; a.x_stride = I; a.prev_c = cs; a.gran = gran; a.ctrl = ctrl; a.dbg = dbg; a.nap0 = nap0; a.nap = nap; a.spin_limit = SPIN_LIMIT_DEFAULT; a.test_stall = 0;
+    a.gifo = gifo; a.cc = cc; a.hh = hh; a.mm = mm; a.x = x; a.x_stride = I; a.prev_c = cs; a.next_c = cs; a.next_r = pr0; a.guard = nullptr; a.gran = gran; a.ctrl = ctrl; a.dbg = dbg; a.nap0 = nap0; a.nap = nap; a.spin_limit = SPIN_LIMIT_DEFAULT; a.test_stall = 0;
     const PGeo g = pick_geo_fwd(o, C, nch, (R + 31) / 32 * 32 + I);
     const size_t shm = (size_t)((S > 4 ? 8 : 4) * (g.maxc * 128 + 16) + (S > 4 ? 8 : 4) * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);
     const int grid = C / 4 / g.tpw;
@@ -86,18 +86,24 @@ int main(int argc, char **argv) {
           *wrT = dalloc((size_t)R * 4 * C), *wxT = dalloc((size_t)I * 4 * C), *wmT = dalloc((size_t)C * R);
     rfill(od, (size_t)T * S * R, -0.1f, 0.1f); rfill(wrT, (size_t)R * 4 * C, -0.01f, 0.01f); rfill(wxT, (size_t)I * 4 * C, -0.01f, 0.01f);
     rfill(wmT, (size_t)C * R, -0.01f, 0.01f); rfill(P, (size_t)T * S * C, -0.01f, 0.01f);
-    CK(hipMemset(gran, 0, 2 * C * 8 * 8)); CK(hipMemset(ctrl, 0, 32));
+    CK(hipMemset(gran, 0, 32 * C * 8 * 8)); CK(hipMemset(ctrl, 0, 32));
     BwdPtrs bp{};
     bp.wrT = wrT; bp.wmT = wmT; bp.wxT = wxT; bp.pi = vecs + 4 * C; bp.pf = vecs + 5 * C; bp.po = vecs + 6 * C;
     bp.gifo = gifo; bp.cc = cc; bp.hh = hh; bp.dgifo = dgifo; bp.dc = dc; bp.dr = dr; bp.pk_fold = wpb;
+    bp.pk_fold_gates = wpk; bp.nch_gates = nch;      // (the backward launch takes its columns of W_rm from the gates-order operand)
     const Dims d{I, C, R, S, T};
-    for (int full : {0, 1}) for (int waves : {16, 12}) for (int nap0 : {0}) {
+    const size_t tws_n = persist_bwd_tail_ws_floats(d, true);
+    float *tws = dalloc(tws_n);
+    // full: 0 bare chain; 1 P + d_r + in_diff on the chain's workgroups ("persist_tail" = 2); 2 P inside, d_r + in_diff on tail workgroups (round 6)
+    for (int full : {0, 1, 2}) for (int waves : {16, 12}) for (int nap0 : {0}) {
+      if (full == 2 && waves != 16) continue;
       PersistOpts o; o.bwd_waves = waves; o.nap0_bwd = nap0; o.dbg = dbg;
+      o.ncu = 256; o.tail_mode = full == 2 ? 1 : 2;
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       float best = 1e9;
       for (int rep = 0; rep < 4; rep++) {
         CK(hipEventRecord(e0, st));
-        CK(launch_bwd_persist(d, bp, P, full ? od : nullptr, R, full ? idf : nullptr, I, full != 0, gran, ctrl, o, st));
+        CK(launch_bwd_persist(d, bp, P, full ? od : nullptr, R, full ? idf : nullptr, I, full != 0, gran, ctrl, o, st, {}, tws, tws_n, {}));
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
       }
@@ -109,7 +115,7 @@ int main(int argc, char **argv) {
       const int ngrp = (S + 3) / 4, nsteps = ngrp * (T - 1);
       const PGeo2 g = pick_geo_bwd2(d, o);
       printf("BWD2 S=%d waves=%d nu=%d %s nap0=%d: %.3f us/step over %d steps (%.1f us per launch, status %x)\n", S, g.nw, g.nu,
-             full ? "P+d_r+in_diff inside" : "bare chain", nap0, best * 1e3 / nsteps, nsteps, best * 1e3, stw[2]);
+             full == 2 ? "P inside, d_r+in_diff on TAIL WORKGROUPS" : full ? "P+d_r+in_diff inside" : "bare chain", nap0, best * 1e3 / nsteps, nsteps, best * 1e3, stw[2]);
       const char *no[6] = {"wait-partials", "combine+publish", "own-rows", "-", "-", "loophead"};
       const char *ns[10] = {"planes+coef", "sweep", "apply+contract", "d-slice", "-", "loophead", "-", "-", "-", "-"};
       printf("   owner wg0 :");
@@ -127,6 +133,21 @@ int main(int argc, char **argv) {
         printf("     wave %2d:", w);
         for (int i : {5, 0, 1, 2, 3}) printf(" %.2f", row(0, w)[i] / cyc_per_us / nsteps);
         printf("\n");
+      }
+      const int ntw = full == 2 ? persist_bwd_tail_wgs(d, true, o) : 0;
+      if (ntw) {
+        // the tail workgroups keep their own clocks.  wave 0 (elementwise side): planes + sweep / apply + tile / barrier / contraction + partial rows / loop head
+        const char *nt[6] = {"planes+sweep", "apply+tile", "barrier", "contract+store", "-", "loophead"};
+        for (int w : {0, 3}) {
+          printf("   %d tail workgroups, wave %d (mean | max over them; a step of theirs has to fit the chain's):", ntw, w);
+          double tm[6] = {0, 0, 0, 0, 0, 0}, tx[6] = {0, 0, 0, 0, 0, 0}, sum = 0;
+          for (int wg = grid; wg < grid + ntw; wg++) for (int i = 0; i < 6; i++) {
+            const double v = row(wg, w)[i] / cyc_per_us / nsteps;
+            tm[i] += v / ntw; if (v > tx[i]) tx[i] = v;
+          }
+          for (int i : {5, 0, 1, 2, 3}) { printf(" %s %.2f|%.2f", nt[i], tm[i], tx[i]); sum += tm[i]; }
+          printf("  = %.2f us per step\n", sum);
+        }
       }
     }
   }
