@@ -232,7 +232,7 @@ def cpu_baseline(S, budget_s):
 
 
 
-def multi_gpu_summary(value, world, same_load, allreduce_us):
+def multi_gpu_summary(value, world, same_load, allreduce_us, ranks_seen=None):
     """The keys that make an N > 1 line self-explaining (N = 1 runs 4 streams, N > 1 runs 8 per GPU: value(N) / (N * value(1)) is
     NOT an efficiency).  `single_gpu_same_load` = this job's per-GPU load (8 streams) on one GPU with no collective, measured by
     every rank on its own GPU in the same process before the library's communicator exists (slowest rank); `efficiency_vs_same_load`
@@ -240,7 +240,7 @@ def multi_gpu_summary(value, world, same_load, allreduce_us):
     events around the collective: nothing overlaps it, the Update waits for it)."""
     return {"single_gpu_same_load": same_load,
             "efficiency_vs_same_load": (value / (world * same_load["value"])) if same_load and same_load.get("value") else None,
-            "allreduce_exposed_us": allreduce_us}
+            "allreduce_exposed_us": allreduce_us, "ranks_seen": ranks_seen}
 
 
 def kaldi_adapter_leg(S, steps=400, warmup=50):
@@ -603,7 +603,7 @@ def main():
         kern = {}
         for name in ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj",
                      "k_gates_fold", "k_gemm_rbatch", "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step",
-                     "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx", "k_fwd_persist", "k_bwd_persist",
+                     "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx", "k_fwd_persist", "k_bwd_persist", "k_tail_reduce",
                      "k_grads", "k_grads_update", "k_update_repack", "k_pack", "k_pack_fwd", "k_pack_bwd", "k_apply_momentum",
                      "rccl_allreduce", "oneshot_allreduce"):
             tot, n = eng.profile_query(name)
@@ -640,6 +640,7 @@ def main():
                       "fold": fold_names.get(eng.profile_query("fold_mode")[1], "?") if folded_chain(eng) else "none (no fold product on this chain)",
                       "fp16_range_guard_events": eng.profile_query("fp16_redo")[1]}
         # every minibatch of the run was applied: no persistent launch gave up, no Update was left out (the counters of klstm.h "persist")
+        tail_wgs = eng.profile_query("persist_tail_wgs")[1]
         ev_names = ("persist_giveups", "persist_replayed", "persist_dropped", "dp_updates_left_out")
         ev = torch.tensor([eng.profile_query(name)[1] for name in ev_names], dtype=torch.int64, device="cuda")
         if world > 1:
@@ -754,7 +755,9 @@ def main():
         chain_us = sum(v["us_per_step"] for n, v in kern.items() if n in step_kernels)
         res = {
             "metric": "frames/sec fwd+BPTT, 40in/800cell/512proj LSTM at 1/2/4/8 MI355X",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # `steps` = the steps of the timed region (the K asked for, then whole K-blocks until --min-seconds): steps x ms_per_step = timed_region_s
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": nsteps_total, "steps_requested": args.steps, "warmup": args.warmup,
+            "timed_region_s": dt_total,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "google/ LstmProjectedStreams 40->cell800/proj512, NumStream=%d per GPU (%d in total), "
@@ -768,6 +771,8 @@ def main():
                        "recurrence": ("persistent weights-resident chain" if "k_bwd_persist" in kern or "k_fwd_persist" in kern else
                                       "folded (W_rm = W_gifo_r W_r_m, one kernel per step and direction)" if folded
                                       else "reference-shaped (gates + projection, d_r + d_m kernels per step)"),
+                       "bptt_tail": ("d_r / in_diff from %d tail workgroups of the BPTT launch (one per 32-cell slot and column part, off the chain) + k_tail_reduce"
+                                     % tail_wgs if tail_wgs else "d_r / in_diff on the chain's workgroups or as batched products"),
                        "update": ("gradient products + momentum + Update as one pass (klstm_backpropagate with KLSTM_BPTT_FUSE_UPDATE: the "
                                   "Update follows immediately, as in Kaldi's Component::Backpropagate)" if "k_grads_update" in kern else
                                   "gradient products, all-reduce, momentum + Update" if (world > 1 or args.force_collective) else "gradient products, then Update"),
@@ -793,7 +798,7 @@ def main():
         if adapter:
             res["kaldi_adapter"] = adapter
         if world > 1 or args.force_collective:
-            res.update(multi_gpu_summary(value, world, same_load, res.get("allreduce_us")))
+            res.update(multi_gpu_summary(value, world, same_load, res.get("allreduce_us"), dp.ranks_seen))   # (first measurement of SURVEY 8(e): top-level keys)
         if strict:
             # the headline workload with the fold product on fp32 operands (every product of the path then is an fp32 MFMA) and on
             # three bf16 planes (fp32 range, matrix cores): `value` itself runs what config.arithmetic.fold says

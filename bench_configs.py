@@ -108,7 +108,7 @@ def _apply_options(engines, args):
 def _engine_kernels(engines, step, base, nprof=10):
     names = ("k_gates_step", "k_proj_step", "k_dr_step", "k_dm_step", "k_dr_step0", "k_gemm_xproj", "k_gates_fold", "k_gemm_rbatch",
              "k_reduce_rbatch", "k_gemm_P", "k_reduce_P", "k_dmf_step", "k_gemm_tail", "k_reduce_tail", "k_fold", "k_pack_foldx",
-             "k_fwd_persist", "k_bwd_persist", "k_fwd_persist_ms", "k_fwd_persist_xl", "k_fold_ms", "k_bwd_persist_xl", "k_gemm_dr", "k_reduce_dr", "k_gemm_indiff",
+             "k_fwd_persist", "k_bwd_persist", "k_tail_reduce", "k_fwd_persist_ms", "k_fwd_persist_xl", "k_fold_ms", "k_bwd_persist_xl", "k_gemm_dr", "k_reduce_dr", "k_gemm_indiff",
              "k_reduce_indiff", "k_grads", "k_grads_update", "k_update_repack", "k_pack",
              "k_apply_momentum")
     for e in engines:

@@ -382,7 +382,7 @@ static klstm_status refresh_wth(klstm_engine *e) {
   if (!e->wrTh || !e->wxTh || !update_repack_vectorised(d, e->params, e->corr, nullptr, e->wrT, e->wmT, e->wxT)) { e->wth_fresh = false; return KLSTM_OK; }
   GradsUpdate u{e->params, 0.f, 0.f, e->wrT, e->wmT, e->wxT};
   u.wrTh = e->wrTh; u.wxTh = e->wxTh;
-  HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream, probe(e, "k_update_repack"),
+  HIPCHK(launch_update_repack(d, e->params, e->corr, nullptr, 0.f, 0.f, 0.f, e->wrT, e->wmT, e->wxT, e->stream, probe(e, "k_refresh_wth"),
                               nullptr, &u, nullptr, nullptr));
   e->wT32_stale = false;
   e->wth_fresh = true;
@@ -915,6 +915,7 @@ static FwdPtrs fwd_ptrs(klstm_engine *e) {
 static BwdPtrs bwd_ptrs(klstm_engine *e) {
   BwdPtrs p;
   p.wrT = e->wrT; p.wmT = e->wmT; p.wxT = e->wxT;
+  p.wr_nat = e->params + e->o_wr(); p.wx_nat = e->params + e->o_wx();
   p.pi = e->params + e->o_pi(); p.pf = e->params + e->o_pf(); p.po = e->params + e->o_po();
   p.gifo = e->gifo; p.cc = e->cc; p.hh = e->hh;
   p.dgifo = e->dgifo; p.dc = e->dc; p.dr = e->dr; p.dr_part = e->dr_part; p.dx_part = e->dx_part; p.ks = e->ks;
@@ -995,7 +996,18 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
   const BwdPtrs p = bwd_ptrs(e);
   hipStream_t st = e->stream;
   const bool copies_form = e->bwd_xl && e->use_copies && e->wth_fresh && p.dgifo_h && !e->use_graph;   // d_r + in_diff from the bf16 copies
-  if (!copies_form) { klstm_status ws = ensure_wT32(e); if (ws != KLSTM_OK) return ws; }             // (everybody else reads the fp32 wrT / wxT)
+  // The persistent fp32 launch: d_r / in_diff inside it -- on tail workgroups (the launcher's own conditions: 16-byte rows at the boundary,
+  // the workspace, compute units next to the chain's; they read the NATURAL W_gifo_r / W_gifo_x) or on the chain's workgroups
+  bool tail_inside = false;
+  if (e->fwd_folded && e->bwd_persist && !e->bwd_xl) {
+    const bool al = (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0 &&
+                    (!in_diff || ((reinterpret_cast<uintptr_t>(in_diff) & 15) == 0 && id_stride % 4 == 0));
+    e->tail_wgs = e->persist_tail != 0 && al && e->ws && e->ws_floats >= persist_bwd_tail_ws_floats(d, in_diff != nullptr)
+                      ? persist_bwd_tail_wgs(d, in_diff != nullptr, e->popt) : 0;
+    tail_inside = e->persist_tail != 0 && (e->tail_wgs > 0 || persist_tail_in_chain(d, in_diff != nullptr, e->popt));
+  }
+  const bool natural_only = e->fwd_folded && e->bwd_persist && !e->bwd_xl && (e->tail_wgs > 0 || !tail_inside);   // (nobody in this call reads wrT / wxT)
+  if (!copies_form && !natural_only) { klstm_status ws = ensure_wT32(e); if (ws != KLSTM_OK) return ws; }   // (everybody else reads the fp32 wrT / wxT)
   if (e->bwd_xl) {
     // many streams, bf16, one BPTT chain per XCD: P = out_diff W_r_m for all frames, the chain d_m(t) = P(t) + dgifo(t+1) W_rm with the
     // elementwise pass of the own cells, then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r (:391) and in_diff = dgifo W_gifo_x (:457)
@@ -1042,7 +1054,6 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     const int M = T * d.S;
     // P = out_diff W_r_m for all frames; chain of T folded steps; then d_r(1..T) = out_diff + dgifo(2..T+1) W_gifo_r
     // (:391, feeds the W_r_m gradient :486) and in_diff = dgifo W_gifo_x (:457) as split-K products
-    bool tail_inside = false;
     const bool p_inside = e->bwd_persist && persist_p_in_kernel(d, e->popt) && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
     int kl = 0;
     int ks = gemm_splitk_plan(M, d.C, d.R, &kl);
@@ -1051,14 +1062,6 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
                                           st, nullptr, 0, probe(e, "k_gemm_P"), probe(e, "k_reduce_P")));
     else HIPCHK(launch_gemm(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
     if (e->bwd_persist) {
-      {   // d_r / in_diff inside the launch: on tail workgroups (the launcher's own conditions: 16-byte rows at the boundary, the
-          // workspace, compute units next to the chain's) or on the chain's workgroups
-        const bool al = (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0 &&
-                        (!in_diff || ((reinterpret_cast<uintptr_t>(in_diff) & 15) == 0 && id_stride % 4 == 0));
-        e->tail_wgs = e->persist_tail != 0 && al && e->ws && e->ws_floats >= persist_bwd_tail_ws_floats(d, in_diff != nullptr)
-                          ? persist_bwd_tail_wgs(d, in_diff != nullptr, e->popt) : 0;
-        tail_inside = e->persist_tail != 0 && (e->tail_wgs > 0 || persist_tail_in_chain(d, in_diff != nullptr, e->popt));
-      }
       HIPCHK(launch_bwd_persist(d, p, e->Pm, out_diff, od_stride, in_diff, id_stride, tail_inside, e->gran[1], e->pctrl + 4, e->popt, st,
                                 probe(e, "k_bwd_persist"), e->ws, e->ws_floats, probe(e, "k_tail_reduce")));
       e->persist_dirty = true;
@@ -1381,6 +1384,12 @@ klstm_status klstm_apply_momentum(klstm_engine *e, float momentum) {
 }
 
 }  // extern "C"
+// the fp32 wrT / wxT have no reader while this holds: the last backward pass ran the persistent fp32 launch with tail workgroups (or with the
+// batched tail behind it: natural matrices too) and nothing suggests the next one will not
+static bool natural_readers_only(const klstm_engine *e) {
+  return e->skip_wT32 && e->fwd_folded && e->fwd_persist && e->bwd_persist && !e->bwd_xl && !e->use_bf16 && e->tail_wgs > 0 && e->persist_tail == 1 &&
+         !e->replaying && !e->use_graph && e->cooldown == 0;
+}
 static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad) {
   const Dims d{e->I, e->C, e->R, e->S, 0};
   const RangeGuardScope rgs(e->rg);
@@ -1390,6 +1399,9 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
     e->grads_pending = false;
     const Dims dg{e->I, e->C, e->R, e->S, e->gp_T};
     GradsUpdate u{e->params, learn_rate, clip_grad, e->wrT, e->wmT, e->wxT};
+    // The persistent fp32 chain with tail workgroups reads the NATURAL W_gifo_r / W_gifo_x: the transposed copies have no reader and are
+    // left out (7 MB of the pass's 57 at 40/800/512); ensure_wT32() is there for whoever needs them (in-chain tail, launch-per-step chain, k_pack)
+    if (natural_readers_only(e) && !e->gp_bf16) { u.wrT = nullptr; u.wxT = nullptr; e->wT32_stale = true; }
     e->planes_fresh = e->fold_scratch && (e->fwd_ms || (e->fwd_folded && fold_bf16x3_supported(d, e->fold_eff)));
     if (e->planes_fresh) {
       fold_bf16x3_planes(d, e->fold_scratch, &u.a3, &u.a_plane, &u.b3, &u.b_plane);
@@ -1418,7 +1430,7 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
     if (want_wth && !e->wth_fresh) { klstm_status ws = refresh_wth(e); if (ws != KLSTM_OK) return ws; }   // (as above: guard or peer-skip mark)
     e->wth_fresh = want_wth && e->wth_fresh;
     if (e->wth_fresh) { u.wrTh = e->wrTh; u.wxTh = e->wxTh; }
-    const bool no32 = e->wth_fresh && e->bwd_xl && e->skip_wT32 && !e->replaying && !e->use_graph;   // (as above)
+    const bool no32 = (e->wth_fresh && e->bwd_xl && e->skip_wT32 && !e->replaying && !e->use_graph) || natural_readers_only(e);   // (as above)
     if (no32) e->wT32_stale = true;
     HIPCHK(launch_update_repack(d, e->params, e->corr, fold_grad, e->mmt_value, learn_rate, clip_grad, no32 ? nullptr : e->wrT, e->wmT,
                                 no32 ? nullptr : e->wxT, e->stream, probe(e, "k_update_repack"), e->pctrl, e->planes_fresh ? &u : nullptr,

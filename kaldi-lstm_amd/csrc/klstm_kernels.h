@@ -28,6 +28,7 @@ struct FwdPtrs {
 
 struct BwdPtrs {
   const float *wrT, *wmT, *wxT;                      // transposed copies [R x 4C], [C x R], [I x 4C]
+  const float *wr_nat = nullptr, *wx_nat = nullptr;  // the natural W_gifo_r [4C x R], W_gifo_x [4C x I] (the persistent BPTT launch's tail workgroups read these)
   const float *pi, *pf, *po;
   const float *gifo, *cc, *hh;
   float *dgifo, *dc, *dr;

@@ -59,7 +59,8 @@ struct PersistBwd2Args {
   int din;                        // bit 0: d_r(1..T) contracted here, bit 1: in_diff too (4 columns per workgroup)
   const float *od; int od_stride; // out_diff rows [T*S x R]
   const float *wmT;               // W_r_m^T [C x R]
-  const float *wrT, *wxT;         // W_gifo_r^T [R x 4C], W_gifo_x^T [I x 4C]
+  const float *wrT, *wxT;         // W_gifo_r^T [R x 4C], W_gifo_x^T [I x 4C] (d_r / in_diff on the chain's workgroups)
+  const float *wrN, *wxN;         // W_gifo_r [4C x R], W_gifo_x [4C x I] as the parameter blob holds them (the tail workgroups)
   float *dr;                      // d_r plane [(T+2)*S x R], time-major row blocks
   float *in_diff; int id_stride;  // [T*S x I]
   int nch1;                       // 32-wide chunks per row tile of wpk (the m part and the x part of the folded gates operand)
@@ -71,9 +72,10 @@ struct PersistBwd2Args {
   const float *P;                 // out_diff * W_r_m [T*S x C] (pin == 0)
   unsigned long long *gran;       // [stream groups][BWD_RING][C*4] granules, cell-major (4 stream slots per cell); frame t lives in ring slot t % BWD_RING
   int tqpp;                       // ... column quads per part (a multiple of 4)
+  int tw0;                        // ... 1: wave 0 prepares only (the others contract: NW - 1 waves x TAIL_TG groups of 4 quads hold a part); 0: it contracts too
   int tq, tparts;                 // tail workgroups (blockIdx >= C/4; d_r / in_diff off the chain, see bwd_tail_role): column quads in total
                                   // (R/4 of d_r, then I/4 of in_diff; 0: no tail workgroups) and workgroups per 32-cell slot (column parts)
-  float *tws;                     // their partial rows [C/32 slots][T*S][4 tq]
+  float *tws;                     // their partial rows [C/32 slots][T*S][4 tq]: k_tail_reduce adds them behind the launch
   unsigned *ctrl;                 // [0] epoch, [1] finished workgroups, [2] status (0 = ok)
   int nap0, nap;                  // SC waves sleep nap0 x 256 clocks before the first pass of a step, nap x 64 between passes
   long long spin_limit;           // wall-clock ticks (100 MHz) a single wait may take
@@ -143,6 +145,41 @@ __device__ __forceinline__ float dpp_quad(unsigned v, bool odd_pair) {
 // still contract frame t.
 // IL: the (frame, group) order of the interleaved kernel (t, 0), (t, 1), (t - 1, 0), ...; otherwise group after group.
 // -------------------------------------------------------------------------------------------------------------------
+// d_r / in_diff from the tail workgroups' partial rows: output idx = (frame row r = (t - 1) S + s, column quad cq), 8 lanes per output --
+// lane l adds slots l, l + 8, l + 16, ... in that order, then three butterfly stages: ONE fixed tree per output whoever runs it
+// (deterministic).  out_diff is added to the d_r columns (:391), d_r(T) = out_diff(T) (:351).
+__device__ __forceinline__ void tail_reduce_outputs(const float *tws, int nslots, int T, int S, int R, int ncols, const float *od, int od_stride,
+                                                    float *dr, float *in_diff, int id_stride, int first, int step, int l) {
+  const int nqc = ncols >> 2, nout = T * S * nqc;
+  const size_t stride = (size_t)T * S * ncols;
+  for (int idx = first;; idx += step) {              // (idx grows with the lane: a wave leaves when its first output is past the end -- the butterflies need every lane)
+    const bool on = idx < nout;
+    if (!__any(on)) break;
+    const int r = on ? idx / nqc : 0, cq = on ? idx - r * nqc : 0;
+    const int t = r / S + 1, s = r - (t - 1) * S;
+    const float *p = tws + (size_t)r * ncols + 4 * cq;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = l; j < nslots; j += 8) {
+      const float4 v = *reinterpret_cast<const float4 *>(p + j * stride);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      sum.x += __shfl_xor(sum.x, m); sum.y += __shfl_xor(sum.y, m); sum.z += __shfl_xor(sum.z, m); sum.w += __shfl_xor(sum.w, m);
+    }
+    if (!on || l != 0) continue;
+    if (4 * cq < R) {
+      if (t < 2) continue;                           // (frame 1 feeds no d_r row; d_r(T) = out_diff(T) goes out with the row of frame T; T >= 3 here)
+      const float4 o = *reinterpret_cast<const float4 *>(od + (size_t)((t - 2) * S + s) * od_stride + 4 * cq);
+      *reinterpret_cast<float4 *>(dr + ((size_t)(t - 1) * S + s) * R + 4 * cq) = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + sum.w);   // :391
+      if (t == T)
+        *reinterpret_cast<float4 *>(dr + ((size_t)T * S + s) * R + 4 * cq) = *reinterpret_cast<const float4 *>(od + (size_t)((T - 1) * S + s) * od_stride + 4 * cq);
+    } else if (in_diff) {
+      *reinterpret_cast<float4 *>(in_diff + (size_t)((t - 1) * S + s) * id_stride + 4 * cq - R) = sum;   // :457
+    }
+  }
+}
+
 constexpr int TAIL_TG = 2;       // groups of 4 column quads per wave (32 weight registers each)
 
 template <int NW, bool IL>
@@ -168,23 +205,31 @@ __device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *l
   // B lane 4 bb + j = dgifo[k][stream j].  Only FOUR k-groups share an output, and they sit in one row of 16 lanes: two DPP row shifts
   // finish the sum (16 k-groups per output -- the chain's layout -- needs two more cross-row stages per value: 36 values x 4 stages per
   // wave and step made the contraction VALU-bound, 2.8 us per step; profiles/r06_tail_wg_anatomy.txt) ----
+  // Read from the NATURAL matrices (W[k][column]: the four columns of a quad are 16 contiguous bytes, the quads of a group 64): the
+  // transposed copies have no reader then and the Update leaves them out (klstm_engine.hip "wT32_stale").
+  // Where the part's groups fit NW - 1 waves, wave 0 only prepares (a.tw0: the elementwise side of frame t - 1 runs under the others'
+  // contraction of frame t); group G of a part goes to contracting wave G % ncw.
   const int bb = lane >> 2, i4 = lane & 3, qq = bb >> 2, kk = bb & 3;
+  const int ncw = NW - a.tw0, cwave = wave - a.tw0;  // contracting waves; this wave's rank among them
+  const bool contracts = cwave >= 0;
   float wq[TAIL_TG][32];
   int cqg[TAIL_TG];
 #pragma unroll
   for (int gq = 0; gq < TAIL_TG; gq++) {
-    const int cq = q_lo + 4 * (wave + NW * gq) + qq; // this lane's column quad of the wave's group gq
+    const int cq = q_lo + 4 * (cwave + ncw * gq) + qq;   // this lane's column quad of the wave's group gq
     cqg[gq] = cq;
-    const bool qv = cq < q_hi;
-    const float *src = !qv ? a.wrT : cq < ngr ? a.wrT + (size_t)(4 * cq + i4) * K : a.wxT + (size_t)(4 * (cq - ngr) + i4) * K;
+    const bool qv = contracts && cq < q_hi;
+    const bool isr = cq < ngr;
+    const int ld = isr ? R : a.I;
+    const float *src = !qv ? a.wrN : isr ? a.wrN + 4 * cq + i4 : a.wxN + 4 * (cq - ngr) + i4;
 #pragma unroll
     for (int m = 0; m < 32; m++) {
       const int cell = 32 * slot + 4 * (m & 7) + kk;
-      const float v = src[(m >> 3) * C + (cell < C ? cell : 0)];
+      const float v = src[(size_t)((m >> 3) * C + (cell < C ? cell : 0)) * (qv ? ld : 0)];
       wq[gq][m] = qv && cell < C ? v : 0.f;
     }
   }
-  const bool two_groups = q_lo + 4 * (wave + NW) < q_hi;     // (wave-uniform: the second group of this wave exists)
+  const bool two_groups = contracts && q_lo + 4 * (cwave + ncw) < q_hi;     // (wave-uniform: the second group of this wave exists)
   float *pslot = a.tws + (size_t)slot * T * S * ncols;       // this slot's partial rows [T * S][ncols]
 
   // ---- wave 0: the elementwise side (natural layout: cell c32 = lane & 31, stream pair h = lane >> 5) ----
@@ -288,26 +333,35 @@ __device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *l
     }
   };
 
-  for (int n = 0; n < nsteps; n++) {
-    const int t = frame_of(n), g = group_of(n);
-    float *xt = xt2 + (n & 1) * 512;
+  // Iteration n: wave 0 prepares step n into buffer n & 1 while the other waves contract step n - 1 out of the other buffer; ONE barrier per
+  // iteration hands buffer n & 1 over and gives buffer (n - 1) & 1 back.
+  for (int n = 0; n <= nsteps; n++) {
     PT_MARK(5);
     if (wave == 0) {
-      bool ok;
-      if (IL) ok = (n & 1) ? prepare(std::integral_constant<int, IL ? 1 : 0>(), t, g, xt) : prepare(std::integral_constant<int, 0>(), t, g, xt);
-      else {
-        if (t == T) { carry[0][0] = 0.f; carry[0][1] = 0.f; }     // a new group's chain
-        ok = prepare(std::integral_constant<int, 0>(), t, g, xt);
+      if (n < nsteps) {
+        const int t = frame_of(n), g = group_of(n);
+        float *xt = xt2 + (n & 1) * 512;
+        bool ok;
+        if (IL) ok = (n & 1) ? prepare(std::integral_constant<int, IL ? 1 : 0>(), t, g, xt) : prepare(std::integral_constant<int, 0>(), t, g, xt);
+        else {
+          if (t == T) { carry[0][0] = 0.f; carry[0][1] = 0.f; }     // a new group's chain
+          ok = prepare(std::integral_constant<int, 0>(), t, g, xt);
+        }
+        (void)ok;
       }
-      (void)ok;
     }
-    lds_barrier();                                   // dgifo(t) of the slot is in xt (the other buffer: frame t + 1, read by now)
+    if (contracts && n > 0) {
+      contract(frame_of(n - 1), group_of(n - 1), xt2 + ((n - 1) & 1) * 512);
+      PT_MARK(3);                                    // contraction + partial rows
+    }
+    lds_barrier();
     PT_MARK(2);
     if (*abortf) break;
-    contract(t, g, xt);
-    PT_MARK(3);                                      // contraction + partial rows
   }
   PT_FLUSH(0);
+  // (Measured and dropped, round 6: the tail workgroups adding the partial rows THEMSELVES behind an arrival counter -- agent-scope release
+  //  of their rows, acquire before reading the others' -- instead of k_tail_reduce behind the launch: 75.1 us per launch against 61.5 + 4.2
+  //  at 4 streams; the release / acquire pair writes back and invalidates L2 far beyond the 4.4 MB in question.)
 }
 
 // d_r / in_diff from the tail workgroups' partial rows: the nslots partials of an output added in slot order (fixed order), out_diff
@@ -320,36 +374,8 @@ struct TailReduceArgs {
 };
 __global__ __launch_bounds__(256) void k_tail_reduce(TailReduceArgs a) {
   if (a.guard && (a.guard[2] | a.guard[6])) return;
-  // 8 lanes per (frame row, column quad): lane l adds slots l, l + 8, l + 16, ... in that order, then three butterfly stages -- one fixed
-  // tree for every output, whatever the launch geometry: deterministic.  (One thread per output walked its 25 slots alone: 173 waves on
-  // the whole chip, 25 dependent round trips.)
-  const int nqc = a.ncols >> 2;
-  const int gidx = blockIdx.x * 256 + threadIdx.x, idx = gidx >> 3, l = gidx & 7;
-  const bool on = idx < a.T * a.S * nqc;
-  const int r = on ? idx / nqc : 0, cq = on ? idx - r * nqc : 0;       // r = (t - 1) S + s
-  const int t = r / a.S + 1, s = r - (t - 1) * a.S;
-  const bool isr = 4 * cq < a.R;
-  const size_t stride = (size_t)a.T * a.S * a.ncols;
-  const float *p = a.tws + (size_t)r * a.ncols + 4 * cq;
-  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = l; j < a.nslots; j += 8) {
-    const float4 v = *reinterpret_cast<const float4 *>(p + j * stride);
-    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-  }
-#pragma unroll
-  for (int m = 1; m < 8; m <<= 1) {
-    sum.x += __shfl_xor(sum.x, m); sum.y += __shfl_xor(sum.y, m); sum.z += __shfl_xor(sum.z, m); sum.w += __shfl_xor(sum.w, m);
-  }
-  if (!on || l != 0) return;
-  if (isr) {
-    if (t < 2) return;                               // (frame 1 feeds no d_r row; d_r(T) = out_diff(T) goes out with the row of frame T; T >= 3 here)
-    const float4 o = *reinterpret_cast<const float4 *>(a.od + (size_t)((t - 2) * a.S + s) * a.od_stride + 4 * cq);
-    *reinterpret_cast<float4 *>(a.dr + ((size_t)(t - 1) * a.S + s) * a.R + 4 * cq) = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + sum.w);   // :391
-    if (t == a.T)
-      *reinterpret_cast<float4 *>(a.dr + ((size_t)a.T * a.S + s) * a.R + 4 * cq) = *reinterpret_cast<const float4 *>(a.od + (size_t)((a.T - 1) * a.S + s) * a.od_stride + 4 * cq);
-  } else if (a.in_diff) {
-    *reinterpret_cast<float4 *>(a.in_diff + (size_t)((t - 1) * a.S + s) * a.id_stride + 4 * cq - a.R) = sum;   // :457
-  }
+  const int gidx = blockIdx.x * 256 + threadIdx.x;
+  tail_reduce_outputs(a.tws, a.nslots, a.T, a.S, a.R, a.ncols, a.od, a.od_stride, a.dr, a.in_diff, a.id_stride, gidx >> 3, (int)gridDim.x * 32, gidx & 7);
 }
 
 template <int NW, int NU>
@@ -1142,17 +1168,19 @@ static size_t bwd2_lds_bytes(const PGeo2 &g, int T, bool pin, bool interleaved =
 // Tail workgroups (bwd_tail_role): one per 32-cell slot and column part.  Returns the column parts per slot (0: no tail workgroups --
 // the chain's workgroups carry the columns, or the batched products run after the launch).  They need compute units of their own next
 // to the chain's C / 4.
-static int bwd2_tail_parts(const Dims &d, bool want_in_diff, const PersistOpts &o, int *ntw = nullptr, int *qpp = nullptr) {
+static int bwd2_tail_parts(const Dims &d, bool want_in_diff, const PersistOpts &o, int *ntw = nullptr, int *qpp = nullptr, int *tw0 = nullptr) {
   const PGeo2 g = pick_geo_bwd2(d, o);
   if (ntw) *ntw = 0;
   if (!g.nw || o.tail_mode == 2 || o.tail_mode == 0 || o.ncu <= d.C / 4 || d.R % 4 != 0 || d.I % 4 != 0) return 0;
   const int nq = d.R / 4 + (want_in_diff ? d.I / 4 : 0), nslots = pcdiv2(d.C, 32);
-  // the fewest column parts whose quads fit the waves (TAIL_TG groups of 4 quads per wave) -- every part is one more workgroup per slot
+  // the fewest column parts whose quads fit the waves (TAIL_TG groups of 4 quads per contracting wave) -- every part is one more workgroup
+  // per slot; wave 0 is left out of the contraction where the part fits without it
   for (int parts = 1; d.C / 4 + nslots * parts <= o.ncu; parts++) {
     const int per = 4 * pcdiv2(pcdiv2(nq, parts), 4);
     if (per > 4 * TAIL_TG * g.nw) continue;
     if (ntw) *ntw = nslots * parts;
     if (qpp) *qpp = per;
+    if (tw0) *tw0 = per <= 4 * TAIL_TG * (g.nw - 1) ? 1 : 0;
     return parts;
   }
   return 0;
@@ -1205,16 +1233,16 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
   a.C = d.C; a.R = d.R; a.S = d.S; a.T = d.T; a.I = d.I;
   a.pin = persist_p_in_kernel(d, o) && out_diff && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
   if (!a.pin && !P) return hipErrorInvalidValue;
-  a.od = out_diff; a.od_stride = od_stride; a.wmT = p.wmT;
+  a.od = out_diff; a.od_stride = od_stride; a.wmT = p.wmT; a.wrN = p.wr_nat; a.wxN = p.wx_nat;
   a.din = tail_inside ? (in_diff ? 3 : 1) : 0; a.wrT = p.wrT; a.wxT = p.wxT; a.dr = p.dr; a.in_diff = in_diff; a.id_stride = id_stride;
   if (a.din && !out_diff) return hipErrorInvalidValue;
   // d_r / in_diff on workgroups of their own next to the chain (compute units the chain leaves idle) instead of on the chain's
   int ntw = 0;
-  a.tq = 0; a.tparts = 0; a.tqpp = 0; a.tws = tws;
-  if (tail_inside && tws && out_diff && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0 &&
+  a.tq = 0; a.tparts = 0; a.tqpp = 0; a.tw0 = 0; a.tws = tws;
+  if (tail_inside && tws && out_diff && p.wr_nat && p.wx_nat && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0 &&
       (!in_diff || ((reinterpret_cast<uintptr_t>(in_diff) & 15) == 0 && id_stride % 4 == 0)) &&
       tws_floats >= persist_bwd_tail_ws_floats(d, in_diff != nullptr))
-    a.tparts = bwd2_tail_parts(d, in_diff != nullptr, o, &ntw, &a.tqpp);
+    a.tparts = bwd2_tail_parts(d, in_diff != nullptr, o, &ntw, &a.tqpp, &a.tw0);
   if (a.tparts) { a.tq = d.R / 4 + (in_diff ? d.I / 4 : 0); a.din = 0; }
   else if (a.din && !persist_tail_in_chain(d, in_diff != nullptr, o)) return hipErrorInvalidValue;   // (neither form takes this call: the caller asks first)
   a.nch1 = p.nch_gates;

@@ -1564,6 +1564,48 @@ def test_fp32_transposed_copies_left_out_by_the_update_are_back_for_whoever_need
             assert np.array_equal(u, v), f"minibatch {i}: {name} (max abs diff {np.abs(u - v).max():.3g})"
 
 
+@pytest.mark.parametrize("fused", [2, 0])
+def test_transposed_copies_left_out_in_tail_workgroup_mode_are_back_for_whoever_needs_them(fused):
+    """Round 6, fp32 persistent chain: with d_r / in_diff on tail workgroups (they read the NATURAL W_gifo_r / W_gifo_x) the Update leaves
+    the fp32 W_gifo_r^T / W_gifo_x^T out (7 of the pass's 57 MB).  Whoever reads them afterwards must find them refreshed first: the chain's
+    own workgroups after "persist_tail" = 2, the launch-per-step chain after a forced give-up (run again) and its cool-down minibatch,
+    the chain after "persist" = 0.  Twin: "gemm_copies" = 2 (the transposed copies on every Update), the same kernels on the same
+    operands otherwise: every output of seven chained minibatches is BIT-IDENTICAL.  fused: the Update inside the gradient pass
+    (KLSTM_BPTT_FUSE_UPDATE) or as k_update_repack behind it."""
+    import kaldi_lstm_amd as k
+    I, C, R, S, T = 40, 800, 512, 4, 20
+    p = make_params(I, C, R, scale=0.02, seed=41)
+    rng = np.random.RandomState(42)
+    xs = [dev(rng.randn(T * S, I)) for _ in range(7)]
+    ods = [dev(0.2 * rng.randn(T * S, R)) for _ in range(7)]
+    res = []
+    for mode in (1, 2):
+        e = k.Engine(I, C, R, S); e.set_params(p); e.set_option("gemm_copies", mode)
+        e.set_option("persist_spin_us", 3000); e.set_option("persist_cooldown", 1)
+        out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
+        got = []
+        for i, (x, od) in enumerate(zip(xs, ods)):
+            if i == 2:
+                e.set_option("persist_test_stall_bwd", 4)
+            if i == 5:
+                e.set_option("persist_tail", 2)
+            if i == 6:
+                e.set_option("persist_tail", 1); e.set_option("persist", 0)
+            e.propagate(x, out); e.backpropagate(x, od, idf, momentum=0.9, flags=fused); e.update(1e-3); e.synchronize()
+            if i in (0, 1, 4):
+                assert e.profile_query("persist_tail_wgs")[1] > 0
+            if i == 2:
+                e.set_option("persist_test_stall_bwd", 0)
+            got.append((out.cpu().numpy().copy(), idf.cpu().numpy().copy(), e.get_corr(), e.get_params()))
+        assert e.profile_query("persist_giveups")[1] == 1 and e.profile_query("persist_replayed")[1] == 1
+        assert e.profile_query("persist_dropped")[1] == 0
+        res.append(got)
+        e.close()
+    for i, (a_, b_) in enumerate(zip(res[0], res[1])):
+        for name, u, v in zip(("out", "in_diff", "corr", "params"), a_, b_):
+            assert np.array_equal(u, v), f"minibatch {i}: {name} (max abs diff {np.abs(u - v).max():.3g})"
+
+
 @pytest.mark.parametrize("I,C,R,S,T", [(512, 1024, 512, 16, 20), (512, 1024, 512, 32, 20), (40, 1024, 512, 32, 20), (64, 256, 128, 24, 12),
                                        (72, 160, 96, 13, 21), (512, 1024, 256, 13, 21), (96, 1024, 128, 9, 29)])
 def test_many_stream_persistent_forward_bf16(I, C, R, S, T):

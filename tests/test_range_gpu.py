@@ -204,18 +204,19 @@ def test_fold_product_with_parameters_beyond_the_fp16_range(_fresh_guard_state):
     e.close()
 
 
-@pytest.mark.parametrize("I,od_scale", [(40, 1e-7), (512, 1e-7), (512, 1e-9), (512, 2000.0)])
-def test_lstm_layer_with_tiny_and_large_out_diff(_fresh_guard_state, I, od_scale):
+@pytest.mark.parametrize("I,od_scale,tail", [(40, 1e-7, 1), (512, 1e-7, 1), (512, 1e-7, 0), (512, 1e-9, 0), (512, 2000.0, 0), (512, 2000.0, 1)])
+def test_lstm_layer_with_tiny_and_large_out_diff(_fresh_guard_state, I, od_scale, tail):
     """Whole layer, out_diff entries around 1e-7 / 1e-9 (BPTT is linear in out_diff: every derivative scales along) and around 2000
-    (dgifo x 2^12 passes the planes' range: the guard of the two-job product).  I = 512: d_r / in_diff run as the two-job f16 product
-    on dgifo (the input is too wide for the persistent backward launch); I = 40: inside the persistent launch, fp32 throughout."""
+    (dgifo x 2^12 passes the planes' range: the guard of the two-job product).  I = 512 with "persist_tail" = 0 (and until round 5 by
+    default: the input is too wide for the chain's own workgroups): d_r / in_diff run as the two-job f16 product on dgifo behind the
+    persistent launch; "persist_tail" = 1 (round 6, the default): on the launch's tail workgroups, fp32 throughout, like I = 40."""
     import kaldi_lstm_amd as k
     g = _fresh_guard_state
     C, R, S, T = 800, 512, 4, 20
     p = make_params(I, C, R, scale=0.02, seed=51)
     rng = np.random.RandomState(52)
     o = Oracle(I, C, R, S, np.float32); o.set_params(p)
-    e = k.Engine(I, C, R, S); e.set_params(p)
+    e = k.Engine(I, C, R, S); e.set_params(p); e.set_option("persist_tail", tail)
     out = torch.empty(T * S, R, device="cuda"); idf = torch.empty(T * S, I, device="cuda")
     for step in range(2):
         x = rng.randn(T * S, I).astype(np.float32); od = (od_scale * rng.randn(T * S, R)).astype(np.float32)
@@ -225,7 +226,8 @@ def test_lstm_layer_with_tiny_and_large_out_diff(_fresh_guard_state, I, od_scale
         got = idf.cpu().numpy()
         assert np.isfinite(got).all() and relerr(got, id_o) <= 3e-4, (step, relerr(got, id_o))
         check_blob(e.get_corr(), o.get_corr(), 5e-4, C, R, "corr")
-    if I == 512 and od_scale >= 1000:
+    assert (e.profile_query("persist_tail_wgs")[1] > 0) == (tail == 1)
+    if I == 512 and od_scale >= 1000 and tail == 0:
         assert _redo(e, "_skinny") > 0 and _redo(g, "_skinny") == 0      # (the engine that ran the product, nobody else)
     else:
         assert _redo(e) == 0
