@@ -359,9 +359,12 @@ __device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *l
     if (*abortf) break;
   }
   PT_FLUSH(0);
-  // (Measured and dropped, round 6: the tail workgroups adding the partial rows THEMSELVES behind an arrival counter -- agent-scope release
-  //  of their rows, acquire before reading the others' -- instead of k_tail_reduce behind the launch: 75.1 us per launch against 61.5 + 4.2
-  //  at 4 streams; the release / acquire pair writes back and invalidates L2 far beyond the 4.4 MB in question.)
+  // (Measured and dropped, round 6, both to save k_tail_reduce's 4.2 us behind the launch: (a) the tail workgroups adding the partial rows
+  //  THEMSELVES behind an arrival counter -- agent-scope release of their rows, acquire before reading the others': 75.1 us per launch
+  //  against 61.5 + 4.2 at 4 streams; the release / acquire pair writes back and invalidates L2 far beyond the 4.4 MB in question.
+  //  (b) partial rows as {tag, value} granules (write-through) and REDUCER workgroups on the 6 compute units left, sweeping a frame's
+  //  granules of all 25 slots and adding them in slot order inside the launch: correct, but 74 KB of sc1 loads per frame and reducer, polled
+  //  until complete, take 5.5 us per frame -- 113.7 us per launch at 4 streams, 207 at 8.)
 }
 
 // d_r / in_diff from the tail workgroups' partial rows: the nslots partials of an output added in slot order (fixed order), out_diff
