@@ -1602,6 +1602,7 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else if (!strcmp(key, "persist_waves")) { e->popt.waves = value; e->popt.bwd_waves = value; }
     else if (!strcmp(key, "persist_bwd_waves")) e->popt.bwd_waves = value;
     else if (!strcmp(key, "persist_bwd_interleave")) e->popt.bwd_interleave = value;
+    else if (!strcmp(key, "persist_fwd_interleave")) e->popt.fwd_interleave = value;
     else if (!strcmp(key, "persist_xl")) e->popt.xl = value;
     else if (!strcmp(key, "persist_xl_bwd")) e->popt.xl_bwd = value;
     else if (!strcmp(key, "persist_nap0")) e->popt.nap0 = value;

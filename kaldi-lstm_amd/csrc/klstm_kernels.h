@@ -293,6 +293,7 @@ struct PersistOpts {
                                   // there are enough of them next to the chain's C / 4
   int tail_mode = -1;             // option "persist_tail": -1 / 1 d_r / in_diff inside the backward launch, on tail workgroups where they fit, else on
                                   // the chain's; 2 always on the chain's workgroups (rounds 3-5); 0 batched products after the launch
+  int fwd_interleave = -1;        // forward, 5..8 streams: the two groups of 4 as interleaved chains (-1 / 1) or in lock-step (0: rounds 2-5)
   int bwd_interleave = -1;        // backward, 5..8 streams: the two groups of 4 as interleaved chains (-1 / 1) or one after the other (0)
   int xl = -1;                    // many streams, bf16, C = 1024: one chain per XCD (klstm_persist_xl.hip; -1 / 1) or klstm_persist_ms.hip (0)
   int xl_bwd = -1;                // ... and the BPTT chain the same way (-1 / 1) or one launch per step (0)

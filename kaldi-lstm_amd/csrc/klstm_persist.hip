@@ -150,8 +150,16 @@ constexpr int persist_maxu(int maxc) { return maxc == 7 ? 5 : maxc; }
 
 // NG: groups of 4 streams (NumStream <= 4*NG); the weights stay where they are, every step contracts them NG times
 // XB: the x-projection is the caller's batched product (a.xg); compiled apart so that the default kernels carry nothing of it
-template <int TPW, int MAXC, int PNW, int PCELL, int NG, bool XB = false>
+// IL (NG = 2, round 6): the two groups of 4 streams as two INTERLEAVED chains -- a group's step needs that group's m(t-1) from every
+// workgroup and nothing of the other group.  Until round 5 both groups moved in lock-step (one sweep over all 8 streams' granules, one
+// barrier, two contractions, two cell updates, then everybody waits for the 8-stream exchange: 4.1 us per step against 2.2 at 4 streams).
+// Here every role walks (t, group 0), (t, group 1), (t + 1, group 0), ...: one barrier per (t, group); while group 0's m(t) crosses the
+// fabric the workgroup sweeps, contracts and updates group 1, whose granules were published half a step earlier and are mostly there.
+// Granules lie group-major ([parity][group][C][4 streams]) so that a group's sweep reads whole lines.  Same arithmetic per (cell,
+// stream): bit-identical to the lock-step form (tests/test_persist_robustness_gpu.py).
+template <int TPW, int MAXC, int PNW, int PCELL, int NG, bool XB = false, bool IL = false>
 __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
+  static_assert(!IL || NG == 2, "interleaved chains: two stream groups");
   constexpr int PNT = PNW * 64, NCW = 4 * TPW, NSW = (PNW - NCW - 1) * 64, MAXU = persist_maxu(MAXC);   // cell waves, one projection wave, sweepers
   constexpr int SS = 4 * NG;                         // stream slots per cell (slab rows, granules)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       const float go = k_sigmoid(ao);              // :306
       const float m = h * go;                      // :309
       if ((t < T || a.rin) && !(a.test_stall == t && blockIdx.x == 0))                                           // (m(T): for r(T) only)
-        publish(a.gran + (size_t)(t & 1) * C * SS, e_cell * SS + es_g, epoch + (unsigned)t, m);
+        publish(a.gran + (size_t)(t & 1) * C * SS, IL ? (g * C + e_cell) * 4 + es : e_cell * SS + es_g, epoch + (unsigned)t, m);
       const int vg = (es_g * 4 * C + e_cell) * 4, vc = (es_g * C + e_cell) * 4, sg = t * S * 4 * C * 4, sc = t * S * C * 4;
       buf_store_f32(rs_g, vg, sg, gg); buf_store_f32(rs_g, vg, sg + C * 4, gi);
       buf_store_f32(rs_g, vg, sg + 2 * C * 4, gf); buf_store_f32(rs_g, vg, sg + 3 * C * 4, go);
@@ -313,6 +321,29 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       if (lane == 0) __hip_atomic_fetch_add(pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // publishes of this step issued
       PT_MARK(4);
     bool dead = false;
+    if constexpr (IL) {
+      for (int t = 2; t <= T && !dead; t++) {
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          if (dead) break;
+          float4 xpg = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (xb && e_ong[g]) {
+            const float *gp = a.xg + ((size_t)t * S + 4 * g + es) * 4 * C + e_cell;
+            xpg = make_float4(gp[0], gp[C], gp[2 * C], gp[3 * C]);
+          }
+          PT_MARK(5);
+          lds_barrier();                             // slab rows of group g for step t ready
+          PT_MARK(1);
+          if (*abortf) { dead = true; break; }
+          const f32x4 v = cell_contract<MAXC>(a0, a1, ldsB + (4 * g + bj) * LDB, kg);
+          PT_MARK(2);
+          cell_math(t, g, v, xpg);
+          if (lane == 0) __hip_atomic_fetch_add(pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // publishes of (t, g) issued
+          PT_MARK(4);
+        }
+      }
+      if (a.rin && !dead) { lds_barrier(); if (!*abortf) lds_barrier(); }   // (slabs of m(T) of the two groups for the projection wave)
+    } else {
     for (int t = 2; t <= T; t++) {
       float4 xpt[NG];
       load_xp(t, xpt);
@@ -335,6 +366,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
     }
     if (a.rin && !dead) lds_barrier();               // (slab of m(T) for the projection wave)
     }
+    }
   } else if (wave == NCW) {
     // =========================== projection wave: r(t-1) = W_r_m m(t-1) (:312) from the slab of step t ===========================
     // Rows 4*blockIdx .. +3 of W_r_m resident (same 4-row geometry, K = C), the first R/4 workgroups; everything it does
@@ -351,6 +383,28 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       a1[i] = proj_on && k + 64 < C ? *reinterpret_cast<const float4 *>(a.wm + (size_t)prow * C + k + 64) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     lds_barrier();                                   // step 1
+    if constexpr (IL) {
+      int itn = 0;
+      bool out_ = false;
+      for (int t = 2; !skip && !out_ && t <= T + (a.rin ? 1 : 0); t++) {
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          lds_barrier();
+          if (*abortf) { out_ = true; break; }
+          ++itn;
+          if (!proj_on) continue;
+          const f32x4 v = cell_contract<MAXC>(a0, a1, ldsB + (4 * g + bj) * LDB, kg, projf, itn);
+          const int ps = 4 * g + bj;
+          if (kg == 3 && ps < S) {                   // lanes 12..15: stream ps, components = rows 4*blockIdx .. +3
+            const int f = t - 1, g4 = (int)blockIdx.x * 4;
+            *reinterpret_cast<float4 *>(a.rr + ((size_t)f * S + ps) * R + g4) = make_float4(v.x, v.y, v.z, v.w);
+            float *op = a.out + ((size_t)(f - 1) * S + ps) * a.out_stride + g4;
+            op[0] = v.x; op[1] = v.y; op[2] = v.z; op[3] = v.w;
+            if (f == T) *reinterpret_cast<float4 *>(a.next_r + (size_t)ps * R + g4) = make_float4(v.x, v.y, v.z, v.w);
+          }
+        }
+      }
+    } else
     for (int t = 2; !skip && t <= T + (a.rin ? 1 : 0); t++) {
       lds_barrier();
       if (*abortf) break;
@@ -376,6 +430,66 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
     const int nx4 = I / 4;                           // float4 per x row; the first sweeper wave also stages x(t)
     const bool x_on = sidx < S * nx4;
     const int xs = x_on ? sidx / nx4 : 0, xk = x_on ? (sidx % nx4) * 4 : 0;
+    if constexpr (IL) {
+      // step 1 (both groups at once, as in the lock-step form), then one iteration per (t, group)
+      {
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x_on) xv = *reinterpret_cast<const float4 *>(a.x + (size_t)xs * a.x_stride + xk);
+        for (int i = sidx; i < S * (R / 4); i += NSW) {
+          const int s_ = i / (R / 4), k = (i % (R / 4)) * 4;
+          const float4 rv = *reinterpret_cast<const float4 *>(a.prev_r + (size_t)s_ * R + k);
+          *reinterpret_cast<float4 *>(ldsU + s_ * LDU + k) = rv;
+          if (blockIdx.x == 0) *reinterpret_cast<float4 *>(a.rr + (size_t)s_ * R + k) = rv;
+        }
+        if (x_on) *reinterpret_cast<float4 *>(ldsU + xs * LDU + RP + xk) = xv;
+        lds_barrier();
+      }
+      bool out_ = *abortf || __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
+      for (int t = 2; !out_ && t <= T + (a.rin ? 1 : 0); t++) {
+        for (int g = 0; g < 2; g++) {
+          const int it = 2 * (t - 2) + g;            // iteration index; the cell waves have issued NCW * (it + 2) publishes after it
+          const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
+          PT_MARK(5);
+          const bool x_mine = x_on && (xs >> 2) == g && t <= T;
+          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (x_mine) xv = *reinterpret_cast<const float4 *>(a.x + ((size_t)(t - 1) * S + xs) * a.x_stride + xk);
+          float mv[2 * PCELL][2];                    // m(t-1) of group g: 16-byte units (cell, stream pair)
+          {
+            const int target = t == 2 ? NCW : NCW * it;          // publishes of (t - 1, g) issued by this workgroup's own cell waves
+            const long long w0 = wall_clock64();
+            for (unsigned spins = 0; __hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; spins++) {
+              __builtin_amdgcn_s_sleep(1);
+              if ((spins & 1023) == 1023 && wall_clock64() - w0 > a.spin_limit) break;
+            }
+          }
+          if (!sweep_units<2 * PCELL>(a.gran + (size_t)((t - 1) & 1) * C * SS + (size_t)g * C * 4, 2 * C, Sg, 2, epoch + (unsigned)(t - 1), sidx, NSW, mv,
+                                      a.spin_limit, a.nap0, a.nap)) {
+            *abortf = 1u;
+            if (lane == 0) {
+              atomicCAS(&a.ctrl[3], 0u, launch_ordinal(a.guard));
+              atomicMax(&a.ctrl[2], 0x80000000u | (unsigned)t);
+              if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+          }
+          // (group g's slab rows were read by the cell waves two barriers ago; the projection wave says when it has)
+          if (proj_on && it >= 2)
+            while (__hip_atomic_load(projf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it - 1) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+          for (int k = 0; k < 2 * PCELL; k++) {
+            const int u = sidx + k * NSW, cl = u >> 1, s2 = 2 * (u & 1);
+            if (cl < C) {
+              if (s2 < Sg) ldsB[(4 * g + s2) * LDB + cl] = mv[k][0];
+              if (s2 + 1 < Sg) ldsB[(4 * g + s2 + 1) * LDB + cl] = mv[k][1];
+            }
+          }
+          if (x_mine) *reinterpret_cast<float4 *>(ldsB + xs * LDB + XP + xk) = xv;
+          PT_MARK(0);
+          lds_barrier();
+          PT_MARK(1);
+          if (*abortf) { out_ = true; break; }
+        }
+      }
+    } else
     for (int t = 1; t <= T + (a.rin ? 1 : 0); t++) {  // (rin: one more slab, m(T), for r(T))
       PT_MARK(5);
       float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -505,8 +619,23 @@ static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t
     if (g.pcell == 3) return plaunch(KERN<TP, MC, 12, 3, NG_, true>, grid, 768, shm, st, pr, a);                \
     return plaunch(KERN<TP, MC, 12, 4, NG_, true>, grid, 768, shm, st, pr, a);                                  \
   }
+#define PF5I(KERN, TP, MC)                                                                                      \
+  if (il && !xbat && g.waves == 12 && g.tpw == TP && g.maxc == MC && ng == 2) {                                 \
+    if (g.pcell == 1) return plaunch(KERN<TP, MC, 12, 1, 2, false, true>, grid, 768, shm, st, pr, a);           \
+    if (g.pcell == 2) return plaunch(KERN<TP, MC, 12, 2, 2, false, true>, grid, 768, shm, st, pr, a);           \
+    if (g.pcell == 3) return plaunch(KERN<TP, MC, 12, 3, 2, false, true>, grid, 768, shm, st, pr, a);           \
+    return plaunch(KERN<TP, MC, 12, 4, 2, false, true>, grid, 768, shm, st, pr, a);                             \
+  }
+#define PFXI(KERN, TP, MC)                                                                                      \
+  if (il && xbat && g.waves == 12 && g.tpw == TP && g.maxc == MC && ng == 2) {                                  \
+    if (g.pcell == 1) return plaunch(KERN<TP, MC, 12, 1, 2, true, true>, grid, 768, shm, st, pr, a);            \
+    if (g.pcell == 2) return plaunch(KERN<TP, MC, 12, 2, 2, true, true>, grid, 768, shm, st, pr, a);            \
+    if (g.pcell == 3) return plaunch(KERN<TP, MC, 12, 3, 2, true, true>, grid, 768, shm, st, pr, a);            \
+    return plaunch(KERN<TP, MC, 12, 4, 2, true, true>, grid, 768, shm, st, pr, a);                              \
+  }
 #define PDISPATCH_FWD(KERN)                                                                                     \
   do {                                                                                                          \
+    PFXI(KERN, 1, 7) PFXI(KERN, 1, 9) PF5I(KERN, 1, 7) PF5I(KERN, 1, 9) PF5I(KERN, 1, 12)                        \
     PFX(KERN, 1, 7, 1) PFX(KERN, 1, 9, 1) PFX(KERN, 2, 7, 1) PFX(KERN, 2, 9, 1)                                  \
     PFX(KERN, 1, 7, 2) PFX(KERN, 1, 9, 2) PFX(KERN, 2, 7, 2) PFX(KERN, 2, 9, 2)                                  \
     if (xbat) return hipErrorInvalidValue;                                                                       \
@@ -537,7 +666,8 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
   a.x = in; a.x_stride = in_stride; a.prev_c = p.prev_c; a.prev_r = p.prev_r; a.next_c = p.next_c; a.next_r = p.next_r; a.gran = gran; a.ctrl = ctrl;
   a.guard = o.guard;
   a.rin = out && persist_r_in_kernel(d, o); a.out = out; a.out_stride = out_stride;
-  a.nap0 = o.nap0 >= 0 ? o.nap0 : d.S > 4 ? 4 : 2; a.nap = o.nap >= 0 ? o.nap : 0;     // (behind the publish flag; measured: tools/persist_anatomy, tools/nap_sweep.py)
+  const bool il = d.S > 4 && o.fwd_interleave != 0;  // 5..8 streams: the two groups as interleaved chains (tpw = 1 geometries)
+  a.nap0 = o.nap0 >= 0 ? o.nap0 : il ? 0 : d.S > 4 ? 4 : 2; a.nap = o.nap >= 0 ? o.nap : 0;     // (behind the publish flag; measured: tools/persist_anatomy, tools/nap_sweep.py)
   a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;
   a.test_stall = o.test_stall_fwd;
   a.hstat = o.hstat;

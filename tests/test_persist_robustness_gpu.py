@@ -404,6 +404,35 @@ def test_interleaved_stream_groups_of_the_backward_launch_are_bit_identical_to_g
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("I,S", [(40, 5), (40, 6), (40, 8), (512, 8)])
+def test_interleaved_stream_groups_of_the_forward_launch_are_bit_identical_to_groups_in_lock_step(I, S):
+    """Round 6, 5..8 streams: the forward launch walks its two groups of 4 streams as two interleaved chains (one barrier per (frame,
+    group): while one group's m(t) crosses the fabric the workgroup sweeps, contracts and updates the other) instead of both groups in
+    lock-step ("persist_fwd_interleave" = 0, rounds 2-5).  Same instruction sequence per (cell, stream): every output, every plane, the
+    parameters, the momentum and the carried state agree to the bit over chained minibatches (I = 512: the wide-input form, the x term
+    from the batched product), and a Reset in between."""
+    import kaldi_lstm_amd as k
+    C, R, T = 800, 512, 20
+    p = make_params(I, C, R, scale=0.01, seed=93)
+    rng = np.random.RandomState(94)
+    a = k.Engine(I, C, R, S); a.set_params(p); a.set_option("persist", 2)
+    b = k.Engine(I, C, R, S); b.set_params(p); b.set_option("persist", 2); b.set_option("persist_fwd_interleave", 0)
+    out_a = torch.empty(T * S, R, device="cuda"); idf_a = torch.empty(T * S, I, device="cuda")
+    out_b = torch.empty(T * S, R, device="cuda"); idf_b = torch.empty(T * S, I, device="cuda")
+    for i in range(3):
+        x, od = _minibatch(rng, I, R, S, T, 0.1)
+        xd, odd = dev(x), dev(od)
+        if i == 2:
+            fl = [1 if s % 3 == 0 else 0 for s in range(S)]
+            a.reset(fl); b.reset(fl)
+        _step(a, xd, odd, out_a, idf_a, 1e-5)
+        _step(b, xd, odd, out_b, idf_b, 1e-5)
+        _same(_snapshot(a, out_a, idf_a), _snapshot(b, out_b, idf_b), "minibatch %d" % i)
+        assert np.array_equal(a.activations(0), b.activations(0)), "forward planes, minibatch %d" % i
+    assert a.profile_query("persist_giveups")[1] == 0 and b.profile_query("persist_giveups")[1] == 0
+    a.close(); b.close()
+
+
 def test_cool_down_backs_off_while_the_give_ups_keep_coming():
     """A co-tenant that stays: every attempt to go back to the persistent chain gives up again (here: the test hook stays on).  The
     cool-down doubles with every give-up that follows a re-arm closely -- 2, 4, 8 minibatches with "persist_cooldown" = 2 -- instead of
