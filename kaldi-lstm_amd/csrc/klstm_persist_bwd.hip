@@ -364,7 +364,10 @@ __device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *l
   //  against 61.5 + 4.2 at 4 streams; the release / acquire pair writes back and invalidates L2 far beyond the 4.4 MB in question.
   //  (b) partial rows as {tag, value} granules (write-through) and REDUCER workgroups on the 6 compute units left, sweeping a frame's
   //  granules of all 25 slots and adding them in slot order inside the launch: correct, but 74 KB of sc1 loads per frame and reducer, polled
-  //  until complete, take 5.5 us per frame -- 113.7 us per launch at 4 streams, 207 at 8.)
+  //  until complete, take 5.5 us per frame -- 113.7 us per launch at 4 streams, 207 at 8.  (c) the same granules, but every tail workgroup's
+  //  LAST wave adding a 1 / 50 share of the outputs of the step two back (9.6 KB of sc1 loads per step): a coherent load of another XCD's
+  //  fresh write-through data takes ~2 us, two passes per step, and the wave sits in the workgroup's per-step barrier: 88.5 us per launch
+  //  at 4 streams, 157.6 at 8.  All three are bit-correct; k_tail_reduce behind the launch stays.)
 }
 
 // d_r / in_diff from the tail workgroups' partial rows: the nslots partials of an output added in slot order (fixed order), out_diff
