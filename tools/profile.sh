@@ -6,7 +6,7 @@
 #   2. --pmc FETCH_SIZE                                         -> HBM/MALL read traffic per launch
 #   3. --pmc WRITE_SIZE                                         -> write traffic per launch
 #   4. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE  -> MFMA pipe utilisation per kernel
-TAG=${1:-r04}
+TAG=${1:-r06}
 shift
 EXTRA="$@"
 OUT=gpurun_out/prof_$TAG

@@ -3,7 +3,7 @@
 # Usage (through gpurun): bash tools/round_check.sh TAG   -> gpurun_out/check_TAG/{pytest.log, bench_*.json, parity_margins.json}
 # Refuses when the committed PMC summary of the round (profiles/TAG_pmc_traffic.json) is older than the kernels it describes
 # (the source hash recorded next to it): re-run tools/profile.sh TAG [--streams-per-gpu 8 | --config c5] first.
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/check_$TAG
 mkdir -p $OUT
 python - <<PY || exit 3
