@@ -39,6 +39,7 @@ int main(int argc, char **argv) {
     LaunchProbe pr;
     const int ng = S > 4 ? 2 : 1;
     const bool xbat = false;
+    const bool il = S > 4;                           // (5..8 streams: the two groups as interleaved chains, like the engine)
     a.xg = nullptr; a.hstat = nullptr;
     auto go = [&]() -> hipError_t { PDISPATCH_FWD(k_fwd_persist); };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
