@@ -91,6 +91,7 @@ int main(int argc, char **argv) {
     BwdPtrs bp{};
     bp.wrT = wrT; bp.wmT = wmT; bp.wxT = wxT; bp.pi = vecs + 4 * C; bp.pf = vecs + 5 * C; bp.po = vecs + 6 * C;
     bp.gifo = gifo; bp.cc = cc; bp.hh = hh; bp.dgifo = dgifo; bp.dc = dc; bp.dr = dr; bp.pk_fold = wpb;
+    bp.wr_nat = wr; bp.wx_nat = wx;                  // (the tail workgroups read the natural matrices)
     bp.pk_fold_gates = wpk; bp.nch_gates = nch;      // (the backward launch takes its columns of W_rm from the gates-order operand)
     const Dims d{I, C, R, S, T};
     const size_t tws_n = persist_bwd_tail_ws_floats(d, true);
