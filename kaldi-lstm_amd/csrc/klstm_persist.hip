@@ -150,7 +150,7 @@ constexpr int persist_maxu(int maxc) { return maxc == 7 ? 5 : maxc; }
 
 // NG: groups of 4 streams (NumStream <= 4*NG); the weights stay where they are, every step contracts them NG times
 // XB: the x-projection is the caller's batched product (a.xg); compiled apart so that the default kernels carry nothing of it
-// IL (NG = 2, round 6): the two groups of 4 streams as two INTERLEAVED chains -- a group's step needs that group's m(t-1) from every
+// IL (NG = 2 .. 4, round 6): the groups of 4 streams as INTERLEAVED chains -- a group's step needs that group's m(t-1) from every
 // workgroup and nothing of the other group.  Until round 5 both groups moved in lock-step (one sweep over all 8 streams' granules, one
 // barrier, two contractions, two cell updates, then everybody waits for the 8-stream exchange: 4.1 us per step against 2.2 at 4 streams).
 // Here every role walks (t, group 0), (t, group 1), (t + 1, group 0), ...: one barrier per (t, group); while group 0's m(t) crosses the
@@ -159,7 +159,7 @@ constexpr int persist_maxu(int maxc) { return maxc == 7 ? 5 : maxc; }
 // stream): bit-identical to the lock-step form (tests/test_persist_robustness_gpu.py).
 template <int TPW, int MAXC, int PNW, int PCELL, int NG, bool XB = false, bool IL = false>
 __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
-  static_assert(!IL || NG == 2, "interleaved chains: two stream groups");
+  static_assert(!IL || (NG >= 2 && NG <= 4), "interleaved chains: two to four stream groups");
   constexpr int PNT = PNW * 64, NCW = 4 * TPW, NSW = (PNW - NCW - 1) * 64, MAXU = persist_maxu(MAXC);   // cell waves, one projection wave, sweepers
   constexpr int SS = 4 * NG;                         // stream slots per cell (slab rows, granules)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
     if constexpr (IL) {
       for (int t = 2; t <= T && !dead; t++) {
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
+        for (int g = 0; g < NG; g++) {
           if (dead) break;
           float4 xpg = make_float4(0.f, 0.f, 0.f, 0.f);
           if (xb && e_ong[g]) {
@@ -342,7 +342,8 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
           PT_MARK(4);
         }
       }
-      if (a.rin && !dead) { lds_barrier(); if (!*abortf) lds_barrier(); }   // (slabs of m(T) of the two groups for the projection wave)
+      if (a.rin && !dead)                            // (slabs of m(T) of the groups for the projection wave)
+        for (int g = 0; g < NG; g++) { lds_barrier(); if (*abortf) break; }
     } else {
     for (int t = 2; t <= T; t++) {
       float4 xpt[NG];
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       bool out_ = false;
       for (int t = 2; !skip && !out_ && t <= T + (a.rin ? 1 : 0); t++) {
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
+        for (int g = 0; g < NG; g++) {
           lds_barrier();
           if (*abortf) { out_ = true; break; }
           ++itn;
@@ -446,8 +447,8 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
       }
       bool out_ = *abortf || __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
       for (int t = 2; !out_ && t <= T + (a.rin ? 1 : 0); t++) {
-        for (int g = 0; g < 2; g++) {
-          const int it = 2 * (t - 2) + g;            // iteration index; the cell waves have issued NCW * (it + 2) publishes after it
+        for (int g = 0; g < NG; g++) {
+          const int it = NG * (t - 2) + g;           // iteration index; the cell waves have issued NCW * (it + 2) publishes after it
           const int Sg = S - 4 * g < 4 ? S - 4 * g : 4;
           PT_MARK(5);
           const bool x_mine = x_on && (xs >> 2) == g && t <= T;
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
           if (x_mine) xv = *reinterpret_cast<const float4 *>(a.x + ((size_t)(t - 1) * S + xs) * a.x_stride + xk);
           float mv[2 * PCELL][2];                    // m(t-1) of group g: 16-byte units (cell, stream pair)
           {
-            const int target = t == 2 ? NCW : NCW * it;          // publishes of (t - 1, g) issued by this workgroup's own cell waves
+            const int target = t == 2 ? NCW : NCW * (it - NG + 2);   // publishes of (t - 1, g) issued by this workgroup's own cell waves (iteration it - NG)
             const long long w0 = wall_clock64();
             for (unsigned spins = 0; __hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; spins++) {
               __builtin_amdgcn_s_sleep(1);
@@ -472,8 +473,8 @@ __global__ __launch_bounds__(PNW * 64) void k_fwd_persist(PersistFwdArgs a) {
             }
           }
           // (group g's slab rows were read by the cell waves two barriers ago; the projection wave says when it has)
-          if (proj_on && it >= 2)
-            while (__hip_atomic_load(projf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it - 1) __builtin_amdgcn_s_sleep(1);
+          if (proj_on && it >= NG)
+            while (__hip_atomic_load(projf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it - NG + 1) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
           for (int k = 0; k < 2 * PCELL; k++) {
             const int u = sidx + k * NSW, cl = u >> 1, s2 = 2 * (u & 1);
@@ -581,11 +582,13 @@ bool persist_x_batched(const Dims &d) {
   return pcdiv((pcdiv(d.C, KCH) + pcdiv(d.I, KCH)) * KCH, 128) > 9 || d.S * (d.I / 4) > 192;
 }
 bool persist_supported(const Dims &d, const PersistOpts &o) {
-  if (d.S > 8 || d.C % 8 != 0 || d.I % 8 != 0 || d.R % 4 != 0) return false;
+  if (d.S > 16 || d.C % 8 != 0 || d.I % 8 != 0 || d.R % 4 != 0) return false;
   const int Ik = persist_x_batched(d) ? 0 : d.I;
   const int nf = pcdiv(d.C, KCH) + pcdiv(Ik, KCH);
   const PGeo gf = pick_geo_fwd(o, d.C, nf, pcdiv(d.R, KCH) * KCH + Ik);
   if ((d.S > 4 || persist_x_batched(d)) && (gf.waves != 12 || (persist_x_batched(d) && gf.maxc > 9))) return false;
+  // 9..16 streams: three / four interleaved chains only (x inside the step, one tile per workgroup, <= 7 operand chunks of 128: C + I <= 896)
+  if (d.S > 8 && (o.fwd_interleave == 0 || persist_x_batched(d) || gf.tpw != 1 || gf.maxc > 7)) return false;
   return gf.tpw > 0;
 }
 int persist_fwd_grid(const Dims &d, const PersistOpts &o) {
@@ -594,7 +597,7 @@ int persist_fwd_grid(const Dims &d, const PersistOpts &o) {
   return g.tpw ? d.C / 4 / g.tpw : 0;
 }
 // forward: [2 parities][C][8 stream slots]; backward: [2 stream groups][BWD_RING = 32 ring slots][C][4 stream slots] (klstm_persist_bwd.hip)
-size_t persist_gran_bytes(const Dims &d) { return (size_t)32 * d.C * 8 * sizeof(unsigned long long); }
+size_t persist_gran_bytes(const Dims &d) { return (size_t)64 * d.C * 8 * sizeof(unsigned long long); }   // (backward: up to 4 groups x 32 ring slots)
 
 template <class K, class A>
 static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t st, LaunchProbe pr, const A &a) {
@@ -633,8 +636,17 @@ static hipError_t plaunch(K kern, int grid, int threads, size_t shm, hipStream_t
     if (g.pcell == 3) return plaunch(KERN<TP, MC, 12, 3, 2, true, true>, grid, 768, shm, st, pr, a);            \
     return plaunch(KERN<TP, MC, 12, 4, 2, true, true>, grid, 768, shm, st, pr, a);                              \
   }
+#define PF5IN(KERN, MC, NG_)        /* 9..16 streams: three / four interleaved chains (12 waves, one tile per workgroup) */ \
+  if (il && !xbat && g.waves == 12 && g.tpw == 1 && g.maxc == MC && ng == NG_) {                                \
+    if (g.pcell == 1) return plaunch(KERN<1, MC, 12, 1, NG_, false, true>, grid, 768, shm, st, pr, a);          \
+    if (g.pcell == 2) return plaunch(KERN<1, MC, 12, 2, NG_, false, true>, grid, 768, shm, st, pr, a);          \
+    if (g.pcell == 3) return plaunch(KERN<1, MC, 12, 3, NG_, false, true>, grid, 768, shm, st, pr, a);          \
+    return plaunch(KERN<1, MC, 12, 4, NG_, false, true>, grid, 768, shm, st, pr, a);                            \
+  }
 #define PDISPATCH_FWD(KERN)                                                                                     \
   do {                                                                                                          \
+    PF5IN(KERN, 7, 3) PF5IN(KERN, 7, 4)                                                                          \
+    if (ng > 2) return hipErrorInvalidValue;                                                                     \
     PFXI(KERN, 1, 7) PFXI(KERN, 1, 9) PF5I(KERN, 1, 7) PF5I(KERN, 1, 9) PF5I(KERN, 1, 12)                        \
     PFX(KERN, 1, 7, 1) PFX(KERN, 1, 9, 1) PFX(KERN, 2, 7, 1) PFX(KERN, 2, 9, 1)                                  \
     PFX(KERN, 1, 7, 2) PFX(KERN, 1, 9, 2) PFX(KERN, 2, 7, 2) PFX(KERN, 2, 9, 2)                                  \
@@ -676,7 +688,7 @@ hipError_t launch_fwd_persist(const Dims &d, const FwdPtrs &p, const float *in, 
 #endif
   const PGeo g = pick_geo_fwd(o, d.C, nch_k, pcdiv(d.R, KCH) * KCH + a.I);
   if (!g.tpw || !p.pk_fold || (!xbat && ((reinterpret_cast<uintptr_t>(in) & 15) || in_stride % 4 != 0))) return hipErrorInvalidValue;
-  const int ng = d.S > 4 ? 2 : 1;
+  const int ng = (d.S + 3) / 4;
   const size_t shm = (size_t)(4 * ng * (g.maxc * 128 + 16) + 4 * ng * (persist_maxu(g.maxc) * 128 + 16) + 4) * sizeof(float);   // (+ abort flag, projection flag)
   const int grid = d.C / 4 / g.tpw;
   PDISPATCH_FWD(k_fwd_persist);

@@ -182,7 +182,7 @@ __device__ __forceinline__ void tail_reduce_outputs(const float *tws, int nslots
 
 constexpr int TAIL_TG = 2;       // groups of 4 column quads per wave (32 weight registers each)
 
-template <int NW, bool IL>
+template <int NW, bool IL, int NGI = 2>
 __device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *lds, unsigned epoch, unsigned behind_giveup) {
   unsigned *abortf = reinterpret_cast<unsigned *>(lds);
   float *xt2 = lds + 16;                             // [2][4 gates][32 cells][4 streams]
@@ -197,8 +197,8 @@ __device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *l
   const int tlo = nq > ngr ? 1 : 2;                  // frame 1 is swept only where in_diff(1) is contracted
   const int nfr = T - tlo + 1, nsteps = nfr * ngrp;
   if (__builtin_amdgcn_readfirstlane(behind_giveup) != 0u) return;
-  auto frame_of = [&](int n) { return IL ? T - (n >> 1) : T - n % nfr; };
-  auto group_of = [&](int n) { return IL ? (n & 1) : n / nfr; };
+  auto frame_of = [&](int n) { return IL ? T - n / NGI : T - n % nfr; };
+  auto group_of = [&](int n) { return IL ? n % NGI : n / nfr; };
 
   // ---- resident rows.  Geometry of v_mfma_f32_4x4x1_16b here: block bb = lane >> 2 = (column quad qq = bb >> 2 of the group, k-group kk = bb & 3),
   // MFMA m contracts k = 4 m + kk (k = 32 e + cell of the slot: 32 MFMAs for the 128 rows), A lane 4 bb + i = W^T[column 4 cq + i][k],
@@ -244,9 +244,9 @@ __device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *l
   const __amdgpu_buffer_rsrc_t rs_g = buf_rsrc(a.gifo, (T + 2) * S * K * 4), rs_h = buf_rsrc(a.hh, (T + 2) * S * C * 4);
   const __amdgpu_buffer_rsrc_t rs_c = buf_rsrc(a.cc, (T + 2) * S * C * 4);
   const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(a.gran, ngrp * BWD_RING * C * 32);
-  float carry[IL ? 2 : 1][2];
+  float carry[IL ? NGI : 1][2];
 #pragma unroll
-  for (int gc = 0; gc < (IL ? 2 : 1); gc++) { carry[gc][0] = 0.f; carry[gc][1] = 0.f; }
+  for (int gc = 0; gc < (IL ? NGI : 1); gc++) { carry[gc][0] = 0.f; carry[gc][1] = 0.f; }
   PT_DECL();
 
   // the elementwise side of one step: planes of the slot's cells, sweep of their granules, dgifo(t) into xt (operand order)
@@ -342,8 +342,12 @@ __device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *l
         const int t = frame_of(n), g = group_of(n);
         float *xt = xt2 + (n & 1) * 512;
         bool ok;
-        if (IL) ok = (n & 1) ? prepare(std::integral_constant<int, IL ? 1 : 0>(), t, g, xt) : prepare(std::integral_constant<int, 0>(), t, g, xt);
-        else {
+        if (IL) {                                    // (the carry set is a compile-time index: one call site per group)
+          ok = g == 0 ? prepare(std::integral_constant<int, 0>(), t, g, xt)
+             : g == 1 ? prepare(std::integral_constant<int, ((IL && (NGI > 1)) ? 1 : 0)>(), t, g, xt)
+             : g == 2 ? prepare(std::integral_constant<int, ((IL && (NGI > 2)) ? 2 : 0)>(), t, g, xt)
+                      : prepare(std::integral_constant<int, ((IL && (NGI > 3)) ? 3 : 0)>(), t, g, xt);
+        } else {
           if (t == T) { carry[0][0] = 0.f; carry[0][1] = 0.f; }     // a new group's chain
           ok = prepare(std::integral_constant<int, 0>(), t, g, xt);
         }
@@ -786,21 +790,22 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2(PersistBwd2Args a) {
 // by a mix of two steps.  The d_r / in_diff partials keep their one counter with the hand-shake of k_bwd_persist2 (nobody adds
 // for set n before the P wave has consumed set n - 1).
 // -------------------------------------------------------------------------------------------------------------------
-template <int NW, int NU>
+// NGI: interleaved stream groups (2: 5..8 streams; round 6: 3 / 4 for 9..16 streams -- the same walk (t, 0), (t, 1), ..., (t, NGI - 1), (t - 1, 0), ...)
+template <int NW, int NU, int NGI = 2>
 __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
   constexpr int NSC = NW - 2, NSLOT = NSC * NU;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned *abortf = reinterpret_cast<unsigned *>(lds);
   int *dcnt = reinterpret_cast<int *>(lds) + 2;      // d_r / in_diff partials written
   int *dcons = reinterpret_cast<int *>(lds) + 3;     // d sets the P wave has consumed
-  int *pcnt = reinterpret_cast<int *>(lds) + 4;      // [2] d_m partials written, per group (one count per SC wave and step)
-  int *pdone = reinterpret_cast<int *>(lds) + 6;     // [2] frames of P in LDS, per group (descending frames)
-  int *pubn = reinterpret_cast<int *>(lds) + 8;      // [2] publishes the owner has issued, per group
-  f32x4 *red = reinterpret_cast<f32x4 *>(lds + 16);  // [2 groups][NSC][4 streams]: components = the 4 own cells
-  f32x4 *red2 = red + 2 * NSC * 4;                   // [2][NSC][4 streams]: components = the 4 d_r / in_diff columns
+  int *pcnt = reinterpret_cast<int *>(lds) + 4;      // [NGI] d_m partials written, per group (one count per SC wave and step)
+  int *pdone = reinterpret_cast<int *>(lds) + 8;     // [NGI] frames of P in LDS, per group (descending frames)
+  int *pubn = reinterpret_cast<int *>(lds) + 12;     // [NGI] publishes the owner has issued, per group
+  f32x4 *red = reinterpret_cast<f32x4 *>(lds + 16);  // [NGI groups][NSC][4 streams]: components = the 4 own cells
+  f32x4 *red2 = red + NGI * NSC * 4;                 // [2][NSC][4 streams]: components = the 4 d_r / in_diff columns
   float *xtile = reinterpret_cast<float *>(red2 + 2 * NSC * 4);   // [NSC][4 gates][32 cells][4 streams]: natural -> operand order
   float *wD = xtile + NSC * 512;                         // [NSLOT][2 sets][4 gates][64 lanes]: A operands of the d_r / in_diff columns
-  f32x4 *ldsP = reinterpret_cast<f32x4 *>(wD + NSLOT * 512);     // [2 groups][T][4 streams] (pin): components = the 4 own cells
+  f32x4 *ldsP = reinterpret_cast<f32x4 *>(wD + NSLOT * 512);     // [NGI groups][T][4 streams] (pin): components = the 4 own cells
   const int C = a.C, S = a.S, T = a.T, K = 4 * a.C;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -816,10 +821,10 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
   const int dcol = d_isr ? (int)blockIdx.x * 4 : ((int)blockIdx.x - ngr) * 4;
   if (tid < 16) reinterpret_cast<int *>(lds)[tid] = 0;
   __syncthreads();
-  const int Sg1 = S - 4;                             // streams of group 1 (group 0 has 4)
+  auto sg_of = [&](int g) { return S - 4 * g < 4 ? S - 4 * g : 4; };   // streams of group g (the last one may be partial)
 
   if (a.tq && (int)blockIdx.x >= C / 4) {
-    bwd_tail_role<NW, true>(a, lds, epoch, behind_giveup);           // a tail workgroup: d_r / in_diff partials of its 32 cells, off the chains
+    bwd_tail_role<NW, true, NGI>(a, lds, epoch, behind_giveup);           // a tail workgroup: d_r / in_diff partials of its 32 cells, off the chains
   } else if (wave == 0) {
     // =========================== owner: combine, publish, own plane rows ===========================
     const int oi = (lane >> 2) & 3, oj = lane & 3;
@@ -827,13 +832,14 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
     const float wpi = a.pi[ocell], wpf = a.pf[ocell], wpo = a.po[ocell];
     const float *redf = reinterpret_cast<const float *>(red);
     bool dead = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
-    bool on[2]; int srow[2]; unsigned long long *gr[2]; unsigned tag0[2];
-    float carry[2] = {0.f, 0.f}, dmv[2] = {0.f, 0.f};
-    float yg[2], yi[2], yf[2], yo[2], yh[2], cpv[2];
-    int np[2] = {0, 0};
+    bool on[NGI]; int srow[NGI]; unsigned long long *gr[NGI]; unsigned tag0[NGI];
+    float carry[NGI], dmv[NGI];
+    float yg[NGI], yi[NGI], yf[NGI], yo[NGI], yh[NGI], cpv[NGI];
+    int np[NGI];
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-      const int Sg = g ? Sg1 : 4;
+    for (int g = 0; g < NGI; g++) {
+      const int Sg = sg_of(g);
+      carry[g] = 0.f; dmv[g] = 0.f; np[g] = 0;
       on[g] = lane < 16 && oj < Sg;
       srow[g] = 4 * g + (oj < Sg ? oj : 0);
       gr[g] = a.gran + (size_t)g * BWD_RING * C * 4;
@@ -856,7 +862,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
       }
     };
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
+    for (int g = 0; g < NGI; g++) {
       if (dead) break;
       if (on[g]) {                                   // dgifo(T+1) = 0 (:351): operand rows of the batched d_r product (tail outside)
         float *zp = a.dgifo + ((size_t)(T + 1) * S + srow[g]) * K + ocell;
@@ -874,7 +880,8 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
     }
     for (int t = T; t >= 2 && !dead; t--) {
 #pragma unroll
-      for (int g = 0; g < 2; g++) {
+      for (int g = 0; g < NGI; g++) {
+        if (dead) break;
         float pnext = 0.f;
         if (!a.pin) pnext = a.P[((size_t)(t - 2) * S + srow[g]) * C + ocell];
         ++np[g];
@@ -898,7 +905,10 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
         load_planes(t - 1, g);
       }
     }
-    if (!dead) { own_rows(1, 0); own_rows(1, 1); }
+    if (!dead) {
+#pragma unroll
+      for (int g = 0; g < NGI; g++) own_rows(1, g);
+    }
   } else if (wave == 1) {
     // =========================== P wave: own columns of P = out_diff W_r_m; finishes d_r / in_diff ===========================
     const int kg = lane >> 2, bj = lane & 3, R = a.R;
@@ -918,8 +928,8 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
       while (nextf >= flo && nextf >= 0) {
         const int f = nextf;
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
-          const bool rv = bj < (g ? Sg1 : 4);
+        for (int g = 0; g < NGI; g++) {
+          const bool rv = bj < sg_of(g);
           const float *op = a.od + ((size_t)f * S + 4 * g + (rv ? bj : 0)) * a.od_stride + 4 * kg;
           float4 b0[4], b1[4];
 #pragma unroll
@@ -947,16 +957,17 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
     if (!dead) {
       // d_r(T) = out_diff(T): dgifo(T+1) = 0 (:351, :391)
 #pragma unroll
-      for (int g = 0; g < 2; g++)
-        if (d_on && d_isr && lane < 16 && fj < (g ? Sg1 : 4))
+      for (int g = 0; g < NGI; g++)
+        if (d_on && d_isr && lane < 16 && fj < sg_of(g))
           a.dr[((size_t)T * S + 4 * g + fj) * R + dcol + fi] = a.od[((size_t)(T - 1) * S + 4 * g + fj) * a.od_stride + dcol + fi];
       if (a.pin) p_until(T - 2);
       if (d_on) {
         for (int t = T; t >= (d_isr ? 2 : 1) && !dead; t--) {
           if (a.pin) p_until(t - 3);                 // one frame ahead of the owner
 #pragma unroll
-          for (int g = 0; g < 2; g++) {
-            const int Sg = g ? Sg1 : 4;
+          for (int g = 0; g < NGI; g++) {
+            if (dead) break;
+            const int Sg = sg_of(g);
             float odv = 0.f;
             if (d_isr && lane < 16 && fj < Sg) odv = a.od[((size_t)(t - 2) * S + 4 * g + fj) * a.od_stride + dcol + fi];
             ++nd;
@@ -1017,21 +1028,21 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
     const int voffG = (2 * h * K + 32 * w + c32) * 4, voffC = (2 * h * C + 32 * w + c32) * 4;
     const __amdgpu_buffer_rsrc_t rs_g = buf_rsrc(a.gifo, (T + 2) * S * K * 4), rs_h = buf_rsrc(a.hh, (T + 2) * S * C * 4);
     const __amdgpu_buffer_rsrc_t rs_c = buf_rsrc(a.cc, (T + 2) * S * C * 4);
-    const __amdgpu_buffer_rsrc_t rs_gr0 = buf_rsrc(a.gran, BWD_RING * C * 32), rs_gr1 = buf_rsrc(a.gran + (size_t)BWD_RING * C * 4, BWD_RING * C * 32);
+    const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(a.gran, NGI * BWD_RING * C * 32);   // [NGI groups][BWD_RING][C][4 streams] granules
     int nd = 0;
     bool dead = __builtin_amdgcn_readfirstlane(behind_giveup) != 0u;
-    float carry[2][NU][2];
+    float carry[NGI][NU][2];
 #pragma unroll
-    for (int g = 0; g < 2; g++)
+    for (int g = 0; g < NGI; g++)
 #pragma unroll
       for (int u = 0; u < NU; u++) { carry[g][u][0] = 0.f; carry[g][u][1] = 0.f; }
     const int tlo = (d_on && !d_isr) ? 1 : 2;        // frame 1 is swept only where in_diff(1) is contracted
     for (int t = T; t >= tlo && !dead; t--) {
 #pragma unroll
-      for (int g = 0; g < 2; g++) {
-        const int Sg = g ? Sg1 : 4;
+      for (int g = 0; g < NGI; g++) {
+        if (dead) break;
+        const int Sg = sg_of(g);
         const bool need0 = 2 * h < Sg, need1 = 2 * h + 1 < Sg;
-        const __amdgpu_buffer_rsrc_t rs_gr = g ? rs_gr1 : rs_gr0;
         // plane loads go out once the owner's publish of d_m(t) of THIS group has been issued (k_bwd_persist2)
         if (!lds_wait_ge(pubn + g, T - t + 1, abortf, limit)) { dead = true; break; }
         const int sG = (t * S + 4 * g) * K * 4, sC = (t * S + 4 * g) * C * 4;
@@ -1049,7 +1060,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
         // ---- sweep d_m(t) of group g ----
         for (int i = 0; i < a.nap0; i++) __builtin_amdgcn_s_sleep(4);
         const unsigned tag = epoch + (unsigned)(g * (T + 2)) + (unsigned)t;
-        const int soff = (t % BWD_RING) * C * 32;
+        const int soff = (g * BWD_RING + t % BWD_RING) * C * 32;
         u32x4 q[NU];
         {
           const long long t0 = wall_clock64();
@@ -1146,7 +1157,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_persist2i(PersistBwd2Args a) {
     atomicMax(&a.ctrl[2], 0x80000000u | 0x7fffu);
     if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  finish(a.ctrl, epoch, 2 * (T + 2), a.guard ? a.guard + 8 : nullptr, a.guard, a.hstat ? a.hstat + 1 : nullptr);
+  finish(a.ctrl, epoch, NGI * (T + 2), a.guard ? a.guard + 8 : nullptr, a.guard, a.hstat ? a.hstat + 1 : nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -1167,8 +1178,8 @@ static PGeo2 pick_geo_bwd2(const Dims &d, const PersistOpts &o) {
   }
   return PGeo2{0, 0};
 }
-static size_t bwd2_lds_bytes(const PGeo2 &g, int T, bool pin, bool interleaved = false) {
-  const int nsc = g.nw - 2, nslot = nsc * g.nu, ng = interleaved ? 2 : 1;       // (interleaved: `red` and the P rows per group)
+static size_t bwd2_lds_bytes(const PGeo2 &g, int T, bool pin, int ngi = 1) {
+  const int nsc = g.nw - 2, nslot = nsc * g.nu, ng = ngi;                       // (interleaved: `red` and the P rows per group)
   return (size_t)(16 + ng * nsc * 16 + 2 * nsc * 16 + nsc * 512 + nslot * 512 + (pin ? ng * T * 16 : 0)) * sizeof(float);   // (a tail workgroup needs 4 KB of it)
 }
 // Tail workgroups (bwd_tail_role): one per 32-cell slot and column part.  Returns the column parts per slot (0: no tail workgroups --
@@ -1196,16 +1207,19 @@ size_t persist_bwd_tail_ws_floats(const Dims &d, bool want_in_diff) {
 }
 // 5..8 streams: the two groups as interleaved chains (k_bwd_persist2i) unless the option says otherwise
 static bool bwd_interleaved(const Dims &d, const PersistOpts &o) { return d.S > 4 && o.bwd_interleave != 0; }
+static int bwd_groups(const Dims &d) { return (d.S + 3) / 4; }
 
 bool persist_bwd_supported(const Dims &d, const PersistOpts &o) {
-  if (d.S > 8 || d.C % 8 != 0 || d.R % 4 != 0 || d.C / 4 > 256) return false;
-  return pick_geo_bwd2(d, o).nw != 0;
+  if (d.S > 16 || d.C % 8 != 0 || d.R % 4 != 0 || d.C / 4 > 256) return false;
+  const PGeo2 g = pick_geo_bwd2(d, o);
+  if (d.S > 8 && (o.bwd_interleave == 0 || g.nw != 16 || g.nu != 2)) return false;   // 9..16 streams: three / four interleaved chains, 16 waves x 2 slots only
+  return g.nw != 0;
 }
 int persist_bwd_grid(const Dims &d) { return d.C / 4; }
 // P = out_diff W_r_m inside the backward launch: own columns in LDS (T frames x 4 streams x 4 cells), rows of W_r_m^T in registers
 bool persist_p_in_kernel(const Dims &d, const PersistOpts &o) {
   const PGeo2 g = pick_geo_bwd2(d, o);
-  return g.nw != 0 && d.R <= 512 && d.R % 4 == 0 && bwd2_lds_bytes(g, d.T, true, bwd_interleaved(d, o)) <= 152 * 1024;
+  return g.nw != 0 && d.R <= 512 && d.R % 4 == 0 && bwd2_lds_bytes(g, d.T, true, bwd_interleaved(d, o) ? bwd_groups(d) : 1) <= 152 * 1024;
 }
 // d_r and in_diff inside the backward launch: 4 columns per workgroup
 bool persist_tail_in_chain(const Dims &d, bool want_in_diff, const PersistOpts &o) {       // ... on the chain's own workgroups (rounds 3-5)
@@ -1264,12 +1278,16 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
   a.dbg = o.dbg;
 #endif
   const PGeo2 g = pick_geo_bwd2(d, o);
-  if (!g.nw || !p.pk_fold_gates || d.S > 8) return hipErrorInvalidValue;
+  if (!g.nw || !p.pk_fold_gates || d.S > 16) return hipErrorInvalidValue;
   const int grid = persist_bwd_grid(d) + ntw;
   hipError_t err = hipErrorInvalidValue;
   if (bwd_interleaved(d, o)) {
-    const size_t shmi = bwd2_lds_bytes(g, d.T, a.pin != 0, true);
-    if (g.nw == 16 && g.nu == 2) err = plaunch2(k_bwd_persist2i<16, 2>, grid, 1024, shmi, st, pr, a);
+    const int ngi = bwd_groups(d);
+    const size_t shmi = bwd2_lds_bytes(g, d.T, a.pin != 0, ngi);
+    if (ngi == 3 && g.nw == 16 && g.nu == 2) err = plaunch2(k_bwd_persist2i<16, 2, 3>, grid, 1024, shmi, st, pr, a);
+    else if (ngi == 4 && g.nw == 16 && g.nu == 2) err = plaunch2(k_bwd_persist2i<16, 2, 4>, grid, 1024, shmi, st, pr, a);
+    else if (ngi > 2) err = hipErrorInvalidValue;
+    else if (g.nw == 16 && g.nu == 2) err = plaunch2(k_bwd_persist2i<16, 2>, grid, 1024, shmi, st, pr, a);
     else if (g.nw == 16 && g.nu == 3) err = plaunch2(k_bwd_persist2i<16, 3>, grid, 1024, shmi, st, pr, a);
     else if (g.nw == 12 && g.nu == 3) err = plaunch2(k_bwd_persist2i<12, 3>, grid, 768, shmi, st, pr, a);
   } else {

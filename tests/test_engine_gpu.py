@@ -1218,6 +1218,10 @@ def test_full_size_decreasing_T_split_k_workspace(S, Ts):
     (40, 64, 32, 4, 600, True),      # T*S = 2400 rows: P does not fit the LDS budget -> batched P product, the rest in-kernel
     (40, 256, 192, 2, 9, True),      # R/4 + I/4 = 58 column groups on 64 workgroups
     (40, 800, 640, 4, 5, False),     # step-1 operand wider than the forward geometry takes -> launch-per-step chain, same answers
+    (40, 800, 512, 12, 20, True),    # round 6: 9..16 streams = three / four groups of 4 as interleaved chains
+    (40, 800, 512, 16, 20, True),
+    (40, 64, 32, 10, 7, True),       # ... ragged third group
+    (24, 136, 72, 13, 9, False),     # ... four groups, the last one a single stream
 ])
 def test_persistent_chain(I, C, R, S, T, want_in_diff, waves, tpw):
     """Option "persist": steps 2..T of the forward recurrence and T..1 of BPTT run inside ONE launch per direction with the
