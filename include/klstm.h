@@ -391,8 +391,10 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  C / 4 (they read the chain's exchange without being waited for: the chain runs at its bare pace), else --
  *                  or with 2 -- on the chain's own workgroups (rounds 3-5).  Same contraction order either way: bit-identical results.
  *                  klstm_profile_query(e, "persist_tail_wgs") = tail workgroups of the last backward launch (0: none).
- *   "bf16"    0/1  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
+ *   "bf16"    0/1/2  bf16 operands (weights, staged activations, gradient products from 256 frames on) with fp32
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.
+ *                  1 = where it pays: from 9 streams on; an engine of up to 8 streams keeps its fp32 weights-resident chain (faster
+ *                  there, and exact; remark in klstm_last_error()).  2 = bf16 operands at any stream count.
  *   "fuse_update"  0/1  0 = KLSTM_BPTT_FUSE_UPDATE is ignored: gradient products and Update as separate passes (A-B runs; this engine)
  *   "gemm_copies"  0/1/2  bf16 mode, 9..32 streams with the per-XCD BPTT chain: that chain writes a bf16 copy of its dgifo rows, the Update
  *                  kernels bf16 copies of W_gifo_r^T / W_gifo_x^T, and the batched d_r + in_diff product reads THE COPIES by LDS-DMA

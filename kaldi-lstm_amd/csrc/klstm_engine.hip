@@ -1535,15 +1535,17 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
     if (value != 0 && !e->pk[0]) return fail(KLSTM_ERR_SHAPE, "bf16 mode needs I, C, R multiples of 8");
-    e->use_bf16 = value != 0;
+    // 1 = where it pays: from 9 streams on.  Up to 8 streams the fp32 engine runs the weights-resident chain (one launch per direction);
+    // bf16 operand mode has no such chain below 9 streams and would step one launch per frame (measured at 40/800/512, T = 20: 4 streams
+    // 291 us per minibatch against 147 in fp32, 8 streams 313 against 191; profiles/r06_scale_probe.txt) -- so a request for bf16 at
+    // <= 8 streams is served by the fp32 chain: faster AND at fp32 accuracy (the option allows bf16 rounding, it does not demand it).
+    // 2 = bf16 operands at any stream count (tests of the launch-per-step bf16 kernels, A-B runs).
+    e->use_bf16 = value == 2 || (value != 0 && e->S > 8);
     { klstm_status ws = ensure_wT32(e); if (ws != KLSTM_OK) return ws; }
     HIPCHK(launch_pack(Dims{e->I, e->C, e->R, e->S, 0}, e->params, e->wrT, e->wmT, e->wxT, e->pk, 15, e->use_bf16, e->stream));
-    // Up to 8 streams the fp32 engine runs the weights-resident chain (one launch per direction); bf16 operand mode has no such chain
-    // below 9 streams and steps one launch per frame: SLOWER than fp32 there (measured at 40/800/512, T = 20: 4 streams 291 us per
-    // minibatch against 156 in fp32, 8 streams 312 against 238; profiles/r04_scale_probe.txt).  bf16 pays from 9 streams on.
-    if (e->use_bf16 && e->S <= 8)
-      note("bf16 operand mode at %d streams: slower than fp32 here (no weights-resident bf16 chain below 9 streams; fp32 runs one launch "
-           "per direction up to 8 streams) -- about 1.9x the time per minibatch at 4 streams, 1.3x at 8; it pays from 9 streams on", e->S);
+    if (value == 1 && !e->use_bf16)
+      note("bf16 operand mode at %d streams: served by the fp32 weights-resident chain (one launch per direction up to 8 streams; the bf16 "
+           "step kernels take about 1.9x the time per minibatch at 4 streams, 1.6x at 8); \"bf16\" = 2 forces bf16 operands", e->S);
     return KLSTM_OK;
   }
   if (!strcmp(key, "fat_fine")) {

@@ -1126,6 +1126,12 @@ __global__ __launch_bounds__(256, 2) void k_nt_shared_a16(DirectNtArgs a) {
   kpass(slot < xunits ? nb_main + slot / MI : -1, slot < xunits ? slot % MI : 0, std::integral_constant<int, 1>());
 }
 
+// Round 6, measured and dropped: the same f16 x 2 product WITHOUT the shared staging of A (k_direct_nt16: every wave on its own -- its 16 rows
+// of B and all MI row blocks of A straight from memory into a register ring, B 8 chunks ahead, A 2, loads pinned between the MFMA groups,
+// no LDS, no barrier; bit-identical to k_nt_shared_a16).  80 x 16624 over K = 512: 47.8 us against 20.0 (9000 columns: 25.5 against 14.8)
+// -- every wave re-reads the 160 KB of A out of L2, 164 MB per launch in 16-line gathers (16 rows x 64 bytes per instruction), and that,
+// not the weight stream, sets the time; a row stride of 528 floats instead of 512 gives 31.5 us, other paddings nothing.  Two column
+// blocks per wave (half the A traffic) do not fit two waves per SIMD next to a B ring deep enough for HBM.  The LDS-shared form stays.
 static int g_nt_shared = 1;
 static int g_nt_ni = 2, g_nt_waves = 1;   //    // measured at 80 x 16624 x 512 (tools/nt_sweep.py): 29.5 us; 1x1 36.7, 2x2 34.0, 4x1 49.4; tiled kernel 37.9
 void set_direct_nt_shape(int ni, int waves) {       // option value 0: wide results on k_direct_nt again (A-B); 99: on the fp32 k_nt_shared_a;

@@ -2831,15 +2831,19 @@ __global__ __launch_bounds__(1024) void k_softmax_xent_rows_v(const float *__res
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; w++) if (smv[w] > best || (smv[w] == best && smi[w] < bi)) { best = smv[w]; bi = smi[w]; }
-    row_xent[row] = (tgt >= 0 && tgt < cols) ? -m * logf(s_yt) : 0.f;
-    row_correct[row] = (m == 1.f && bi == tgt) ? 1.f : 0.f;
+    // (write-through, agent scope: the workgroup that takes the last ticket reads them with agent-scope loads)
+    __hip_atomic_store(row_xent + row, (tgt >= 0 && tgt < cols) ? -m * logf(s_yt) : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(row_correct + row, (m == 1.f && bi == tgt) ? 1.f : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!totals) return;
   // statistics onto the device totals without a launch of their own: the workgroup that takes the last ticket sees every row's two
-  // numbers (release fence before the ticket, device-scope loads after it) and adds them up in a fixed order
+  // numbers and adds them up in a fixed order.  Round 6: the two numbers leave as write-through (sc1) stores and the ticket is taken
+  // once they are acknowledged (s_waitcnt vmcnt(0)) -- no __threadfence(): an agent-scope release writes back EVERY dirty line of the
+  // L2 (here: the 5.3 MB of derivatives the launch has just stored; ~3.5 us and more per workgroup, MI355X_MICROARCH.md) for 8 bytes
+  // that matter.  The same store-then-flag idiom as the granules of the persistent chains (klstm_persist_dev.h publish()).
   if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
   }
   __syncthreads();
   if (!s_last) return;

@@ -806,6 +806,32 @@ def test_nonfinite_inputs_propagate_like_the_oracle():
     e.close()
 
 
+@pytest.mark.parametrize("S", [4, 8])
+def test_bf16_request_at_up_to_8_streams_is_served_by_the_fp32_chain(S):
+    """Option "bf16" = 1 asks for bf16 operands where they pay.  Up to 8 streams they do not (no weights-resident bf16 chain there: the
+    bf16 step kernels take 1.6-1.9x the fp32 chain's time), so the request is served by the fp32 persistent launches: the same bits as an
+    engine that never heard of the option, the same kernels in its profile, a remark in last_error(); "bf16" = 2 forces bf16 operands."""
+    import kaldi_lstm_amd as k
+    I, C, R, T = 40, 800, 512, 20
+    p = make_params(I, C, R, scale=0.02, seed=31)
+    rng = np.random.RandomState(32)
+    x = dev(rng.randn(T * S, I).astype(np.float32)); od = dev((0.1 * rng.randn(T * S, R)).astype(np.float32))
+    res = []
+    for b in (0, 1, 2):
+        e = make_engine(I, C, R, S, p); e.set_option("bf16", b); e.set_option("profile", 1)
+        out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
+        for _ in range(2):
+            e.propagate(x, out); e.backpropagate(x, od, ind, momentum=0.9, flags=2); e.update(1e-3)
+        e.synchronize()
+        res.append((out.cpu().numpy(), ind.cpu().numpy(), e.get_params(), e.profile_query("k_fwd_persist")[1], e.profile_query("k_bwd_persist")[1]))
+        e.close()
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert np.array_equal(a, b)
+    assert res[1][3] == 2 and res[1][4] == 2                   # one persistent launch per direction and minibatch
+    assert res[2][3] == 0 and res[2][4] == 0                   # forced: the launch-per-step bf16 kernels
+    assert 1e-5 < relerr(res[2][0], res[0][0]) <= 3e-2
+
+
 @pytest.mark.parametrize("I,C,R,S,T,fuse_x,fat", [
     (40, 64, 32, 4, 6, 1, 1),       # 4x4x4_16b geometry (S <= 12), x term fused
     (40, 64, 32, 12, 4, 1, 1),      # 4x4x4_16b geometry, three stream groups
@@ -832,7 +858,7 @@ def test_bf16_operand_mode(I, C, R, S, T, fuse_x, fat):
     e = make_engine(I, C, R, S, p)
     e.set_option("fuse_x", fuse_x)
     e.set_option("fat", fat)
-    e.set_option("bf16", 1)
+    e.set_option("bf16", 2)                       # (2: bf16 operands at any stream count; 1 serves <= 8 streams from the fp32 chain)
     c0, r0 = np.zeros((S, C)), np.zeros((S, R))
     pe = p.astype(np.float32).copy()
     corr = np.zeros_like(pe, dtype=np.float64)

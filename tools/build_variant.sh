@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../kaldi-lstm_amd"
 name=$1; shift
 mkdir -p build_$name
-for f in klstm_kernels klstm_persist klstm_persist_bwd klstm_persist_ms klstm_persist_xl klstm_fold klstm_fold3 klstm_oneshot klstm_outer klstm_engine; do
+for f in klstm_kernels klstm_persist klstm_persist_bwd klstm_persist_ms klstm_persist_xl klstm_fold klstm_fold3 klstm_oneshot klstm_outer klstm_gemm16 klstm_engine; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -I/opt/rocm/include "$@" -c csrc/$f.hip -o build_$name/$f.o &
 done
 wait

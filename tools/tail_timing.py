@@ -22,6 +22,9 @@ print("N=%d frames, affine %d -> %d" % (N, K, M))
 print("affine_propagate    : %7.1f us" % t(lambda: k.affine_propagate(x, W, b, out)))
 print("softmax             : %7.1f us" % t(lambda: k.softmax(out, post)))
 print("xent (kernel only)  : %7.1f us" % t(lambda: lib.klstm_xent_eval_masked(post.data_ptr(), N, M, M, tg.data_ptr(), mk.data_ptr(), diff.data_ptr(), M, rx.data_ptr(), rc.data_ptr(), None)))
+tot = torch.zeros(3, device="cuda", dtype=torch.float64)
+print("softmax + xent, one pass (rows only)       : %7.1f us" % t(lambda: k.softmax_xent_masked(out, tg, mk, diff, lazy=True, rows_out=(rx, rc))))
+print("softmax + xent, one pass (+ device totals) : %7.1f us" % t(lambda: k.softmax_xent_masked(out, tg, mk, diff, rows_out=(rx, rc), totals=tot)))
 print("affine_backpropagate: %7.1f us" % t(lambda: k.affine_backpropagate(diff, W, ind)))
 print("affine_gradient     : %7.1f us" % t(lambda: k.affine_gradient(x, diff, gW, gb)))
 print("sgd_momentum_update : %7.1f us" % t(lambda: k.sgd_momentum_update(W.view(-1), Wc.view(-1), gW.view(-1), 0.9, 1e-5)))
