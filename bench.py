@@ -256,10 +256,11 @@ def kaldi_adapter_leg(S, steps=400, warmup=50):
             mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
             mod.build_adapter_bench()
         out = {}
-        for tag, verify, d2h, spin in (("", 1, 0, 1), ("with_d2h_per_minibatch", 1, 1, 1), ("verify_by_stream_sync", 1, 0, 0),
-                                       ("persist_verify_0", 0, 0, 1)):
-            r = subprocess.run([exe, str(S), str(steps), str(warmup), str(verify), str(d2h), str(spin)], capture_output=True, text=True,
-                               timeout=120)
+        for tag, verify, d2h, spin, dsmall in (("", 1, 0, 1, 1), ("with_d2h_per_minibatch", 1, 1, 1, 1),
+                                               ("with_d2h_per_minibatch_hipmemcpy", 1, 1, 1, 0), ("verify_by_stream_sync", 1, 0, 0, 1),
+                                               ("persist_verify_0", 0, 0, 1, 1)):
+            r = subprocess.run([exe, str(S), str(steps), str(warmup), str(verify), str(d2h), str(spin), str(dsmall)], capture_output=True,
+                               text=True, timeout=120)
             if r.returncode != 0:
                 raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
             d = json.loads(r.stdout.strip().splitlines()[-1])

@@ -406,6 +406,8 @@ static klstm_status repack(klstm_engine *e) {
   return KLSTM_OK;
 }
 
+static int g_d2h_small = 1;           // process-wide A-B knob ("d2h_small"): klstm_memcpy_d2h's small-copy kernel (below)
+
 // ---- folded recurrence: policy, buffers, refresh of W_rm and its packed copies ----
 static bool fold_wanted(const klstm_engine *e, int T) {
   if (e->use_fold == 0 || !e->use_vector || e->use_bf16 || !e->pk[0] || e->S > get_small_max()) return false;
@@ -1548,6 +1550,10 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
            "step kernels take about 1.9x the time per minibatch at 4 streams, 1.6x at 8); \"bf16\" = 2 forces bf16 operands", e->S);
     return KLSTM_OK;
   }
+  if (!strcmp(key, "d2h_small")) {       // process-wide: 0 = klstm_memcpy_d2h always through hipMemcpyAsync (A-B runs)
+    g_d2h_small = value != 0;
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "fat_fine")) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
@@ -1761,7 +1767,76 @@ klstm_status klstm_memcpy_h2d(void *dst, const void *src, size_t bytes, void *hi
   HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
   return KLSTM_OK;
 }
+// Small device-to-host copies -- the three scalars Xent::EvalMasked reads back EVERY minibatch (google/nnet/nnet-loss.cc:110-141: what an
+// unmodified bd-nnet-train-lstm-streams does), a CuVector::CopyToVec of a few numbers.  hipMemcpy of pageable memory costs ~45 us of idle
+// GPU per call on this stack (staging + completion signal + wake-up: profiles/r05 kaldi_adapter with_d2h_per_minibatch), a third of a
+// 150 us minibatch.  Up to D2H_SMALL_BYTES the copy is a ONE-WAVE KERNEL on the caller's stream that writes {sequence tag, word} granules
+// into a host-mapped staging buffer (8-byte system-scope stores: tag and word cannot tear, the data is the flag -- no fence, no completion
+// signal; the idiom of the persistent chains' granules and of "persist_verify"'s done word), and the host spins on the tags: it has the
+// numbers one PCIe write after the kernel ran.  Same semantics as before: stream-ordered behind everything queued on hip_stream, returns
+// when dst is filled.  Anything else (larger, unaligned, no mapped memory) takes hipMemcpyAsync + hipStreamSynchronize.
+constexpr size_t D2H_SMALL_BYTES = 256;
+__global__ __launch_bounds__(64) void k_d2h_small(const unsigned *__restrict__ src, unsigned long long *dst, int nwords, unsigned seq) {
+  const int i = threadIdx.x;
+  if (i < nwords)
+    __hip_atomic_store(dst + i, ((unsigned long long)seq << 32) | src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct D2hStage {
+  unsigned long long *host = nullptr, *dev = nullptr;
+  int device = -1;
+  unsigned seq = 0;
+  bool broken = false;
+  ~D2hStage() { if (host) (void)hipHostFree(host); }
+};
+static bool d2h_small(void *dst, const void *src, size_t bytes, hipStream_t st) {
+  static thread_local D2hStage sg;    // (the call is synchronous: one staging buffer per calling thread)
+  if (!g_d2h_small || sg.broken || bytes == 0 || bytes > D2H_SMALL_BYTES || (bytes & 3) || (reinterpret_cast<uintptr_t>(src) & 3)) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (!sg.host) {
+    void *hp = nullptr;
+    if (hipHostMalloc(&hp, (D2H_SMALL_BYTES / 4) * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError(); sg.broken = true; return false;
+    }
+    memset(hp, 0, (D2H_SMALL_BYTES / 4) * sizeof(unsigned long long));
+    sg.host = static_cast<unsigned long long *>(hp);
+  }
+  if (sg.device != dev) {
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, sg.host, 0) != hipSuccess) { (void)hipGetLastError(); sg.broken = true; return false; }
+    sg.dev = static_cast<unsigned long long *>(dp); sg.device = dev;
+  }
+  if (++sg.seq == 0) sg.seq = 1;      // (0 = what the buffer holds before its first use)
+  const int nw = (int)(bytes / 4);
+  hipLaunchKernelGGL(k_d2h_small, dim3(1), dim3(64), 0, st, static_cast<const unsigned *>(src), sg.dev, nw, sg.seq);
+  if (hipGetLastError() != hipSuccess) return false;
+  const volatile unsigned long long *q = sg.host;
+  const auto t0 = std::chrono::steady_clock::now();
+  int have = 0;
+  bool synced = false;
+  for (unsigned spins = 1; have < nw; spins++) {
+    while (have < nw && (unsigned)(q[have] >> 32) == sg.seq) have++;
+    if (have == nw) break;
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+    if ((spins & 1023) == 0 && !synced && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+      // a long queue in front of the copy: sleep in the runtime instead of burning a core; the granules are there when it returns
+      if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return false; }
+      synced = true;
+    } else if (synced && (spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+      return false;                   // (never seen: the ordinary copy answers)
+    }
+  }
+  unsigned *out = static_cast<unsigned *>(dst);
+  if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) for (int i = 0; i < nw; i++) out[i] = (unsigned)q[i];
+  else for (int i = 0; i < nw; i++) { const unsigned w = (unsigned)q[i]; memcpy(static_cast<char *>(dst) + 4 * i, &w, 4); }
+  return true;
+}
 klstm_status klstm_memcpy_d2h(void *dst, const void *src, size_t bytes, void *hip_stream) {
+  if (d2h_small(dst, src, bytes, (hipStream_t)hip_stream)) return KLSTM_OK;
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
   return KLSTM_OK;

@@ -1788,3 +1788,37 @@ def test_many_stream_persistent_forward_gives_up_and_is_run_again(direction):
             assert relerr(out.cpu().numpy(), out_t.cpu().numpy()) <= 2e-2
     assert e.profile_query("k_fwd_persist_ms")[1] + e.profile_query("k_fwd_persist_xl")[1] == 2 and e.profile_query("persist_giveups")[1] == 1
     e.close(); t.close()
+
+
+@pytest.mark.parametrize("use_stream", [False, True])
+def test_small_device_to_host_copies(use_stream):
+    """klstm_memcpy_d2h of a few words (the three scalars Xent::EvalMasked reads back every minibatch, nnet-loss.cc:110-141) goes through
+    a one-wave kernel into a host-mapped staging buffer and a spin on the sequence tags instead of a pageable hipMemcpy: same semantics
+    (ordered behind the stream's work, dst filled on return), every size up to 256 bytes, unaligned destinations, repeated calls (a stale
+    buffer never matches: fresh tag per call), larger / odd sizes through the ordinary copy; "d2h_small" = 0 switches it off."""
+    import ctypes
+    import kaldi_lstm_amd as k
+    lib = k.load_library()
+    lib.klstm_memcpy_d2h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.klstm_memcpy_d2h.restype = ctypes.c_int
+    stream = torch.cuda.Stream() if use_stream else None
+    sp = stream.cuda_stream if use_stream else None
+    e = k.Engine(40, 64, 32, 4)
+    rng = np.random.RandomState(5)
+    for small in (1, 0, 1):
+        e.set_option("d2h_small", small)
+        for nbytes in (4, 12, 64, 252, 256, 260, 4096, 10, 7):
+            for rep in range(3):
+                host = rng.randint(0, 2 ** 31 - 1, size=2048).astype(np.int32)
+                with torch.cuda.stream(stream) if use_stream else torch.cuda.stream(torch.cuda.current_stream()):
+                    src = torch.from_numpy(host).cuda(non_blocking=False)
+                    src += 1                                              # (a kernel in front of the copy, on the same stream)
+                if not use_stream:
+                    torch.cuda.current_stream().synchronize()             # (the copy goes to the NULL stream: order it by hand)
+                buf = np.zeros(4096 + 16, np.uint8)
+                off = 1 if rep == 2 else 0                                # an unaligned destination too
+                assert lib.klstm_memcpy_d2h(buf.ctypes.data + off, src.data_ptr(), nbytes, sp) == 0
+                want = (host + 1).view(np.uint8)[:nbytes]
+                assert np.array_equal(buf[off:off + nbytes], want), (small, nbytes, rep)
+                assert not buf[off + nbytes:].any()
+    e.close()

@@ -13,11 +13,12 @@
 // Needs no HIP headers (g++ -std=c++17 -O2 -Iinclude tools/kaldi_adapter_bench.cpp -Lkaldi-lstm_amd -lklstm): device memory through
 // the klstm_malloc / klstm_memcpy_* helpers of the C-ABI.  Prints ONE JSON line; bench.py puts it into its line as `kaldi_adapter`.
 //
-//   kaldi_adapter_bench [streams=4] [steps=400] [warmup=50] [persist_verify=1] [d2h_per_minibatch=0] [verify_spin=1]
+//   kaldi_adapter_bench [streams=4] [steps=400] [warmup=50] [persist_verify=1] [d2h_per_minibatch=0] [verify_spin=1] [d2h_small=1]
 //     verify_spin = 0: the engine's wait for a persistent launch is a hipStreamSynchronize (round 4's) instead of a spin on the
 //     host-mapped done word
 //     d2h_per_minibatch = 1: a 12-byte pageable device-to-host copy after Update, what Xent::EvalMasked does per minibatch
 //     (google/nnet/nnet-loss.cc:110-141)
+//     d2h_small = 0: that copy through hipMemcpyAsync + hipStreamSynchronize (rounds 1-5) instead of klstm_memcpy_d2h's small-copy kernel
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +39,7 @@ int main(int argc, char **argv) {
   const int verify = argc > 4 ? std::atoi(argv[4]) : 1;
   const int d2h = argc > 5 ? std::atoi(argv[5]) : 0;
   const int vspin = argc > 6 ? std::atoi(argv[6]) : 1;
+  const int dsmall = argc > 7 ? std::atoi(argv[7]) : 1;
   const int I = 40, C = 800, R = 512, T = 20, NCHUNK = 50;
   try {
     LstmProjectedStreams c(I, R);
@@ -50,6 +52,7 @@ int main(int argc, char **argv) {
     c.SetUpdateFollows(true);                                       // the shim's constructor
     if (!verify) c.SetPersistVerify(false);
     if (!vspin) c.SetEngineOption("persist_verify_spin", 0);
+    if (!dsmall) c.SetEngineOption("d2h_small", 0);
 
     const int rows = T * S, xs = I + 4, os = R + 8, ds = R + 4, is = I + 12;
     std::mt19937 gen(1234);
@@ -91,11 +94,11 @@ int main(int argc, char **argv) {
     OKC(klstm_profile_query(c.Engine(), "persist_replayed", &us, &replayed));
     OKC(klstm_profile_query(c.Engine(), "persist_dropped", &us, &dropped));
     std::printf("{\"value\": %.1f, \"unit\": \"frames/s\", \"ms_per_step\": %.5f, \"steps\": %d, \"warmup\": %d, \"streams\": %d, "
-                "\"persist_verify\": %d, \"verify_spin\": %d, \"d2h_per_minibatch\": %d, \"update\": \"fused (SetUpdateFollows(true))\", "
+                "\"persist_verify\": %d, \"verify_spin\": %d, \"d2h_per_minibatch\": %d, \"d2h_small\": %d, \"update\": \"fused (SetUpdateFollows(true))\", "
                 "\"persist_launches\": %ld, \"persist_launches_expected\": %ld, \"persist_giveups\": %ld, \"persist_replayed\": %ld, "
                 "\"persist_dropped\": %ld, \"driver\": \"tools/kaldi_adapter_bench.cpp: klstm_kaldi::LstmProjectedStreams as in INTEGRATION.md 2, "
                 "Reset + PropagateFnc + BackpropagateFnc + Update per minibatch on pitched device matrices\"}\n",
-                (double)steps * rows / sec, sec / steps * 1e3, steps, warmup, S, verify, vspin, d2h, launches, 2L * (steps + warmup), giveups,
+                (double)steps * rows / sec, sec / steps * 1e3, steps, warmup, S, verify, vspin, d2h, dsmall, launches, 2L * (steps + warmup), giveups,
                 replayed, dropped);
     klstm_free(dx); klstm_free(dod); klstm_free(dout); klstm_free(did); klstm_free(dscal);
     return 0;
