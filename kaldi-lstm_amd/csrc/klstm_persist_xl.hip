@@ -38,7 +38,7 @@ namespace klstm {
 typedef __bf16 xl_bf16x8 __attribute__((ext_vector_type(8)));
 
 struct PersistXlArgs {
-  int R, S, T, sx;                // (C = 1024); sx = streams per XCC group
+  int C, R, S, T, sx;             // C % 32 == 0, C <= XL_C (round 6; until then C = 1024 only); sx = streams per XCC group
   const unsigned short *wrm;      // folded W_rm as bf16, LOGICAL rows (4 cell + gate) x C
   const float *wr;                // natural W_gifo_r [4C x R] (step 1)
   const unsigned short *wrb;      // (or null) the same rounded to bf16, same layout (the fold product's operand plane): half the bytes of the prologue
@@ -58,6 +58,10 @@ struct PersistXlArgs {
   int test_stall;
 };
 
+// XL_C: the LARGEST cell count (LDS slabs, granule arrays and thread maps are laid out for it); a layer with fewer cells (C % 32 == 0)
+// uses the first C / 32 slots of every XCC group as cell owners -- the other workgroups of the group still project (16 rows of W_r_m
+// each: R <= 512 needs all 32) and therefore sweep; K = C is cut into two halves of ceil(C / 64) chunks of 32, chunks past the operand
+// carry zero weights against zero slab columns (the slab is cleared once, cells >= C are never written).
 constexpr int XL_C = 1024, XL_LD = 2 * XL_C + 16;    // slab row bytes: [cell] bf16 + 16 (conflict-free ds_read_b128)
 
 __device__ __forceinline__ xl_bf16x8 xl_load8(const float *p, bool on) {
@@ -66,8 +70,11 @@ __device__ __forceinline__ xl_bf16x8 xl_load8(const float *p, bool on) {
   return (xl_bf16x8){(__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w, (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w};
 }
 
+// FULL: C = XL_C as a compile-time constant (the configs[4] layers: every chunk live, every slot an owner -- the round-5 kernel to the
+// instruction; the run-time cell count costs the BPTT launch 5 % there)
+template <bool FULL>
 __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
-  constexpr int C = XL_C;
+  const int C = FULL ? XL_C : a.C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *slab = smem;                                           // [5][XL_LD]: rows 0..3 = the group's streams, row 4 = zeros
   f32x4 *part = reinterpret_cast<f32x4 *>(smem + 5 * XL_LD);            // [2 K halves][8 row tiles][64]
@@ -99,24 +106,26 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
     atomicMax(&a.ctrl[2], 0x80000000u | 0x7ffeu);
     if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  const bool idle = misplaced || skip || sxl == 0;                      // (a group without streams has nothing to exchange)
+  const bool owner = !misplaced && 32 * slot < C;                       // this workgroup owns 32 cells (C < XL_C: the first C / 32 slots of a group)
+  const bool idle = misplaced || skip || sxl == 0 || (!owner && 16 * slot >= R);   // (a group without streams has nothing to exchange; a slot without cells or rows of W_r_m nothing to do)
 
   if (!idle) {
     const int i16 = lane & 15, kg = lane >> 4;                          // MFMA operand lane: row / column i16, k-group kg
     const int ti = wave >> 1, kp = wave & 1;                            // row tile, K half
-    unsigned long long *gr = a.gran + (size_t)grp * 2 * 4 * (C / 2);    // the group's granules: [2 parities][4 streams][C / 2 cell pairs]
-    const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(gr, 2 * 4 * (C / 2) * 8);
+    const int nchC = C / 32, kh = (nchC + 1) / 2;                       // chunks of 32 over K = C, per K half
+    unsigned long long *gr = a.gran + (size_t)grp * 2 * 4 * (XL_C / 2); // the group's granules: [2 parities][4 streams][XL_C / 2 cell pairs]
+    const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(gr, 2 * 4 * (XL_C / 2) * 8);
     // ---- cell-update lanes: waves 0 and 1, lane = (cell cl = lane & 15 of the wave's 16, stream n2 = lane >> 4): one (cell, stream) pair
     //      per lane, taken out of the partial tiles in LDS (with the MFMA result layout as the cell layout -- 8 waves, 16 live lanes each --
     //      every plane store wrote sixteen 16-byte runs and the workgroup issued 64 of them per step in front of the next sweep) ----
-    const bool cellw = wave < 2;
+    const bool cellw = wave < 2 && owner;
     const int cl = lane & 15, n2 = lane >> 4, c32 = 16 * (wave & 1) + cl;
     const bool on = cellw && n2 < sxl;
-    const int cell = 32 * slot + c32, strm = s0 + (n2 < sxl ? n2 : 0);
+    const int cell = owner ? 32 * slot + c32 : 0, strm = s0 + (n2 < sxl ? n2 : 0);
     const int psrc = (c32 >> 2) * 64 + 16 * (c32 & 3) + n2;            // tile c32 / 4, result lane (k-group c32 % 4, column n2): g, i, f, o of the pair
     float cp = on ? a.prev_c[(size_t)strm * C + cell] : 0.f;            // carried c(0) (:231)
     if (on) a.cc[(size_t)strm * C + cell] = cp;                         // time block 0 of the c plane: BPTT reads it
-    const float wpi = a.pi[cell], wpf = a.pf[cell], wpo = a.po[cell];
+    const float wpi = a.pi[cell], wpf = a.pf[cell], wpo = a.po[cell];   // (no cells here: cell = 0, never used)
     // ---- time block 0 of the r plane + the slab of step 1: the carried r(0) of the group's streams, rounded like every staged activation
     for (int i = tid; i < sxl * (R / 4); i += 1024) {
       const int n = i / (R / 4), k = (i % (R / 4)) * 4;
@@ -127,13 +136,13 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
     }
     // ---- operands: step-1 rows (natural W_gifo_r, this wave's half of K = R), then the resident rows of W_rm ----
     // operand row of this lane: tile row i16 = 4 cell' + gate  ->  natural row gate C + (32 slot + 4 ti + cell')
-    const size_t arow = (size_t)(i16 & 3) * C + 32 * slot + 4 * ti + (i16 >> 2);
+    const size_t arow = (size_t)(i16 & 3) * C + (owner ? 32 * slot + 4 * ti + (i16 >> 2) : 0);
     const int nchU = R / 32, cwU = (nchU + 1) / 2;                      // chunks of 32 over R, per K half
     xl_bf16x8 uf[8], af[16];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int cu = kp * cwU + j;
-      const bool in = j < cwU && cu < nchU;
+      const bool in = owner && j < cwU && cu < nchU;
       if (a.wrb) uf[j] = in ? *reinterpret_cast<const xl_bf16x8 *>(a.wrb + arow * R + 32 * cu + 8 * kg) : (xl_bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
       else uf[j] = xl_load8(a.wr + arow * R + 32 * cu + 8 * kg, in);
     }
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
       if (!first) {
         // ---- sweep m(t-1) of the group: thread = (stream n = tid >> 8, cells 4 (tid & 255) .. + 3): ONE 16-byte sc1 load = two granules ----
         // (polling starts once this workgroup's own cell waves have issued their publishes of step t-1: klstm_persist.hip)
-        {
+        if (owner) {
           const long long w0 = wall_clock64();
           for (unsigned spins = 0; __hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * (t - 1); spins++) {
             __builtin_amdgcn_s_sleep(1);
@@ -159,9 +168,9 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
           }
         }
         const int n = tid >> 8, c4 = tid & 255;
-        const bool live = n < sxl;
+        const bool live = n < sxl && 4 * c4 < C;
         const unsigned tag = epoch + (unsigned)(t - 1);
-        const int off = ((((t - 1) & 1) * 4 + (live ? n : 0)) * (C / 2) + 2 * c4) * 8;
+        const int off = ((((t - 1) & 1) * 4 + (live ? n : 0)) * (XL_C / 2) + 2 * (live ? c4 : 0)) * 8;
         u32x4 q0;
         bool ok = false;
         const long long t0 = wall_clock64();
@@ -196,12 +205,12 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[j], bv, acc, 0, 0, 0);
         }
       } else {
-        if (t <= T) {
+        if (t <= T && owner) {
 #pragma unroll
           for (int hf = 0; hf < 8; hf++) {                              // (two chunks' operands in flight at a time: the resident rows leave few registers)
             xl_bf16x8 bv[2];
 #pragma unroll
-            for (int j = 0; j < 2; j++) bv[j] = *reinterpret_cast<const xl_bf16x8 *>(brow + 64 * (16 * kp + 2 * hf + j));
+            for (int j = 0; j < 2; j++) bv[j] = *reinterpret_cast<const xl_bf16x8 *>(brow + 64 * (kh * kp + 2 * hf + j));
 #pragma unroll
             for (int j = 0; j < 2; j++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2 * hf + j], bv[j], acc, 0, 0, 0);
           }
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
         // the even cell takes its neighbour's value (the next lane) and issues ONE plain 8-byte store -- the line stays in this XCC's L2
         const unsigned mb = bf16_rne(m), mb_up = (unsigned)__shfl_down((int)mb, 1);
         if (on && (cl & 1) == 0 && !(a.test_stall == t && slot == 0 && grp == 0))
-          gr[((size_t)(t & 1) * 4 + n2) * (C / 2) + (cell >> 1)] = ((unsigned long long)(epoch + (unsigned)t) << 32) | (mb | (mb_up << 16));
+          gr[((size_t)(t & 1) * 4 + n2) * (XL_C / 2) + (cell >> 1)] = ((unsigned long long)(epoch + (unsigned)t) << 32) | (mb | (mb_up << 16));
         if (on) {
           float *gp = a.gifo + ((size_t)t * S + strm) * 4 * C + cell;
           gp[0] = gg; gp[C] = gi; gp[2 * C] = gf; gp[3 * C] = go;
@@ -266,10 +275,17 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
     };
     if (run_step(1, true)) {
 #pragma unroll
-      for (int j = 0; j < 16; j++)
-        af[j] = *reinterpret_cast<const xl_bf16x8 *>(a.wrm + (size_t)(128 * slot + 16 * ti + i16) * C + 512 * kp + 32 * j + 8 * kg);
+      for (int j = 0; j < 16; j++) {                                    // (C = 1024: kh = 16, every chunk live)
+        const int ch = kh * kp + j;
+        const bool in = owner && j < kh && ch < nchC;
+        af[j] = *reinterpret_cast<const xl_bf16x8 *>(a.wrm + (size_t)(in ? 128 * slot + 16 * ti + i16 : 0) * C + 32 * (in ? ch : 0) + 8 * kg);
+        if (!in) af[j] = (xl_bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
 #pragma unroll
-      for (int j = 0; j < 2; j++) rf[j] = xl_load8(a.wm + (size_t)(prow < R ? prow : 0) * C + 64 * wave + 32 * j + 8 * kg, projw && prow < R);
+      for (int j = 0; j < 2; j++) {
+        const int k0 = 64 * wave + 32 * j;
+        rf[j] = xl_load8(a.wm + (size_t)(prow < R ? prow : 0) * C + (k0 < C ? k0 : 0) + 8 * kg, projw && prow < R && k0 < C);
+      }
       for (int t = 2; t <= T + 1; t++)                                   // (t = T + 1: r(T) only)
         if (!run_step(t, false)) break;
     }
@@ -303,7 +319,7 @@ __global__ __launch_bounds__(1024) void k_fwd_persist_xl(PersistXlArgs a) {
 // [k = 4 cell + gate].
 // -------------------------------------------------------------------------------------------------------------------
 struct PersistXlBwdArgs {
-  int S, T, sx;
+  int C, S, T, sx;                // C % 32 == 0, C <= XL_C (round 6): the first C / 32 slots of every XCC group own cells, the others idle
   const unsigned short *wrmT;     // [C][4C] bf16: row c = column c of W_rm over the logical rows k = 4 cell + gate
   const float *P;                 // out_diff W_r_m [T*S x C]
   const float *pi, *pf, *po;
@@ -321,8 +337,9 @@ struct PersistXlBwdArgs {
 
 constexpr int XL_LDB = 2 * 4 * XL_C + 16;            // backward slab row bytes: [4 cell + gate] bf16 + 16
 
+template <bool FULL>
 __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
-  constexpr int C = XL_C, K = 4 * XL_C;
+  const int C = FULL ? XL_C : a.C, K = 4 * C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *slab = smem;                                           // [5][XL_LDB]: rows 0..3 = dgifo(t+1) of the group's streams, row 4 = zeros
   f32x4 *part = reinterpret_cast<f32x4 *>(smem + 5 * XL_LDB);           // [16 K parts][2 row tiles][64]
@@ -353,14 +370,15 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
     atomicMax(&a.ctrl[2], 0x80000000u | 0x7ffeu);
     if (a.hstat) __hip_atomic_store(a.hstat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  const bool idle = misplaced || skip || sxl == 0;
+  const bool idle = misplaced || skip || sxl == 0 || 32 * slot >= C;   // (C < XL_C: slots without cells have nothing to do here)
 
   if (!idle) {
     const int i16 = lane & 15, kg = lane >> 4;
-    const int kp = wave;                                                // K sixteenth (256 k) of BOTH row tiles: the slab is read once per k
+    const int kp = wave;                                                // K sixteenth of BOTH row tiles: the slab is read once per k
+    const int nchK = K / 32, cw = (nchK + 15) / 16;                     // chunks of 32 over K = 4C, per wave (C = 1024: 8 = 256 k)
     const int ti = wave & 1;                                            // (elementwise waves 0 and 1: the row tile whose cells they update)
-    uint4 *gr = a.gran + (size_t)grp * 2 * 4 * C;                        // the group's granules: [2 parities][4 streams][C cells]
-    const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(gr, 2 * 4 * C * 16);
+    uint4 *gr = a.gran + (size_t)grp * 2 * 4 * XL_C;                     // the group's granules: [2 parities][4 streams][XL_C cells]
+    const __amdgpu_buffer_rsrc_t rs_gr = buf_rsrc(gr, 2 * 4 * XL_C * 16);
     // ---- elementwise lanes: the two waves with kp = 0, lane = (cell cl = lane & 15 of the wave's row tile, stream n2 = lane >> 4):
     //      one (cell, stream) pair per lane (four pairs per lane in the MFMA result layout cost 56 registers of state and operands)
     const bool cellw = wave < 2;
@@ -380,8 +398,12 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
     // ---- the resident operand: 2 x 16 rows of W_rm^T (output cells 32 slot + 16 tile + i16) x this wave's sixteenth of K ----
     xl_bf16x8 af[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++)
-      af[j] = *reinterpret_cast<const xl_bf16x8 *>(a.wrmT + (size_t)(32 * slot + 16 * (j >> 3) + i16) * K + 256 * kp + 32 * (j & 7) + 8 * kg);
+    for (int j = 0; j < 16; j++) {
+      const int ch = cw * kp + (j & 7);
+      const bool in = (j & 7) < cw && ch < nchK;
+      af[j] = *reinterpret_cast<const xl_bf16x8 *>(a.wrmT + (size_t)(32 * slot + 16 * (j >> 3) + i16) * K + 32 * (in ? ch : 0) + 8 * kg);
+      if (!in) af[j] = (xl_bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
     const unsigned char *brow = slab + (i16 < 4 ? i16 : 4) * XL_LDB + 16 * kg;
     bool dead = false;
     for (int t = T; t >= 1 && !dead; t--) {
@@ -398,14 +420,15 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
         const int n = tid >> 8, c4 = tid & 255;
         const bool live = n < sxl;
         const unsigned tag = epoch + (unsigned)(t + 1);
-        const int off = ((((t + 1) & 1) * 4 + (live ? n : 0)) * C + c4) * 16;
+        const int off = ((((t + 1) & 1) * 4 + (live ? n : 0)) * XL_C + c4) * 16;
+        const bool le[4] = {c4 < C, c4 + 256 < C, c4 + 512 < C, c4 + 768 < C};     // (cells past C: no granule, nothing to wait for)
         u32x4 q[4];
         bool ok = false;
         const long long t0 = wall_clock64();
         for (unsigned spins = 0;; spins++) {
 #pragma unroll
           for (int e = 0; e < 4; e++) q[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_gr, off + 4096 * e, 0, 16);   // aux 16 = sc1
-          ok = !live | ((q[0].x == tag) & (q[1].x == tag) & (q[2].x == tag) & (q[3].x == tag));
+          ok = !live | ((!le[0] | (q[0].x == tag)) & (!le[1] | (q[1].x == tag)) & (!le[2] | (q[2].x == tag)) & (!le[3] | (q[3].x == tag)));
           if (__all(ok)) break;
           if ((spins & 31) == 31) {
             if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
@@ -423,7 +446,7 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
         if (live) {
           uint2 *sp = reinterpret_cast<uint2 *>(slab + n * XL_LDB + 8 * c4);     // slab row [k = 4 cell + gate] bf16: 8 bytes per cell
 #pragma unroll
-          for (int e = 0; e < 4; e++) sp[256 * e] = make_uint2(q[e].y, q[e].z);
+          for (int e = 0; e < 4; e++) if (le[e]) sp[256 * e] = make_uint2(q[e].y, q[e].z);
         }
       }
       // the own pair's operands of frame t: requested here, consumed behind the two barriers
@@ -443,7 +466,7 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
         for (int hf = 0; hf < 4; hf++) {
           xl_bf16x8 bv[2];
 #pragma unroll
-          for (int j = 0; j < 2; j++) bv[j] = *reinterpret_cast<const xl_bf16x8 *>(brow + 64 * (8 * kp + 2 * hf + j));
+          for (int j = 0; j < 2; j++) bv[j] = *reinterpret_cast<const xl_bf16x8 *>(brow + 64 * (cw * kp + 2 * hf + j));
 #pragma unroll
           for (int j = 0; j < 2; j++) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2 * hf + j], bv[j], acc0, 0, 0, 0);
@@ -477,7 +500,7 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
         if (on) {
           const unsigned short hg = bf16_rne(dg), hi = bf16_rne(di), hf = bf16_rne(df), ho = bf16_rne(d_o);
           if (t > 1 && !(a.test_stall == t && slot == 0 && grp == 0))   // publish dgifo(t): one plain 16-byte store -- the line stays in this XCC's L2
-            gr[((size_t)(t & 1) * 4 + n2) * C + cell] = make_uint4(epoch + (unsigned)t, hg | ((unsigned)hi << 16), hf | ((unsigned)ho << 16), 0u);
+            gr[((size_t)(t & 1) * 4 + n2) * XL_C + cell] = make_uint4(epoch + (unsigned)t, hg | ((unsigned)hi << 16), hf | ((unsigned)ho << 16), 0u);
           float *dp = a.dgifo + ((size_t)t * S + strm) * K + cell;
           dp[0] = dg; dp[C] = di; dp[2 * C] = df; dp[3 * C] = d_o;
           if (a.dgifo_h) {                                              // (2-byte stores in 32-byte runs: sixteen cells of a tile are sixteen lanes)
@@ -511,7 +534,10 @@ __global__ __launch_bounds__(1024) void k_bwd_persist_xl(PersistXlBwdArgs a) {
 // launcher
 // -------------------------------------------------------------------------------------------------------------------
 bool persist_xl_supported(const Dims &d, const PersistOpts &o) {
-  return o.xl != 0 && d.C == XL_C && d.S >= 9 && d.S <= 32 && d.R % 32 == 0 && d.R >= 32 && d.R <= 512 && d.T >= 3 && d.T * d.S >= 256;
+  // C: any multiple of 32 from 512 up to XL_C (round 6; smaller layers keep the one-copy-over-all-CUs launch: half of an XCC's workgroups
+  // would idle, and the tests of that kernel live there)
+  return o.xl != 0 && d.C % 32 == 0 && d.C >= 512 && d.C <= XL_C && d.S >= 9 && d.S <= 32 && d.R % 32 == 0 && d.R >= 32 && d.R <= 512 && d.T >= 3 &&
+         d.T * d.S >= 256;
 }
 size_t persist_xl_gran_bytes() { return (size_t)8 * 2 * 4 * (XL_C / 2) * 8 + 64; }   // granules + the eight per-XCC counters
 
@@ -519,7 +545,7 @@ hipError_t launch_fwd_persist_xl(const Dims &d, const FwdPtrs &p, const unsigned
                                  const PersistOpts &o, hipStream_t st, LaunchProbe pr) {
   if (!persist_xl_supported(d, o) || !wrm || !gran || !out) return hipErrorInvalidValue;
   PersistXlArgs a;
-  a.R = d.R; a.S = d.S; a.T = d.T; a.sx = (d.S + 7) / 8;
+  a.C = d.C; a.R = d.R; a.S = d.S; a.T = d.T; a.sx = (d.S + 7) / 8;
   a.wrm = wrm; a.wr = p.wr; a.wrb = p.wr_bf16; a.wm = p.wm; a.out = out; a.out_stride = out_stride; a.next_r = p.next_r;
   a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.mm = p.mm; a.rr = p.rr;
@@ -530,9 +556,10 @@ hipError_t launch_fwd_persist_xl(const Dims &d, const FwdPtrs &p, const unsigned
   a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;
   a.test_stall = o.test_stall_fwd;
   const size_t shm = (size_t)5 * XL_LD + (size_t)2 * 16 * 64 * 16 + 32;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd_persist_xl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (pr.start) hipExtLaunchKernelGGL(k_fwd_persist_xl, dim3(256), dim3(1024), shm, st, pr.start, pr.stop, 0, a);
-  else hipLaunchKernelGGL(k_fwd_persist_xl, dim3(256), dim3(1024), shm, st, a);
+  auto kern = d.C == XL_C ? k_fwd_persist_xl<true> : k_fwd_persist_xl<false>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (pr.start) hipExtLaunchKernelGGL(kern, dim3(256), dim3(1024), shm, st, pr.start, pr.stop, 0, a);
+  else hipLaunchKernelGGL(kern, dim3(256), dim3(1024), shm, st, a);
   return hipGetLastError();
 }
 
@@ -542,7 +569,7 @@ hipError_t launch_bwd_persist_xl(const Dims &d, const BwdPtrs &p, const unsigned
                                  const PersistOpts &o, hipStream_t st, LaunchProbe pr) {
   if (!persist_xl_supported(d, o) || !wrmT || !P || !gran) return hipErrorInvalidValue;
   PersistXlBwdArgs a;
-  a.S = d.S; a.T = d.T; a.sx = (d.S + 7) / 8;
+  a.C = d.C; a.S = d.S; a.T = d.T; a.sx = (d.S + 7) / 8;
   a.wrmT = wrmT; a.P = P; a.pi = p.pi; a.pf = p.pf; a.po = p.po;
   a.gifo = p.gifo; a.cc = p.cc; a.hh = p.hh; a.dgifo = p.dgifo; a.dc = p.dc; a.dgifo_h = p.dgifo_h;
   a.gran = static_cast<uint4 *>(gran);
@@ -551,9 +578,10 @@ hipError_t launch_bwd_persist_xl(const Dims &d, const BwdPtrs &p, const unsigned
   a.spin_limit = o.spin_limit > 0 ? o.spin_limit : SPIN_LIMIT_DEFAULT;
   a.test_stall = o.test_stall_bwd;
   const size_t shm = (size_t)5 * XL_LDB + (size_t)32 * 64 * 16 + 32;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persist_xl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (pr.start) hipExtLaunchKernelGGL(k_bwd_persist_xl, dim3(256), dim3(1024), shm, st, pr.start, pr.stop, 0, a);
-  else hipLaunchKernelGGL(k_bwd_persist_xl, dim3(256), dim3(1024), shm, st, a);
+  auto kern = d.C == XL_C ? k_bwd_persist_xl<true> : k_bwd_persist_xl<false>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (pr.start) hipExtLaunchKernelGGL(kern, dim3(256), dim3(1024), shm, st, pr.start, pr.stop, 0, a);
+  else hipLaunchKernelGGL(kern, dim3(256), dim3(1024), shm, st, a);
   return hipGetLastError();
 }
 

@@ -1682,8 +1682,17 @@ def test_transposed_copies_left_out_in_tail_workgroup_mode_are_back_for_whoever_
             assert np.array_equal(u, v), f"minibatch {i}: {name} (max abs diff {np.abs(u - v).max():.3g})"
 
 
+def _per_xcd_chains(C, R, S, T):
+    """klstm_persist_xl.hip takes the layer (round 6: any C % 32 == 0 from 512 to 1024; until then C = 1024 only)"""
+    return C % 32 == 0 and 512 <= C <= 1024 and 9 <= S <= 32 and R % 32 == 0 and 32 <= R <= 512 and T >= 3 and T * S >= 256
+
+
 @pytest.mark.parametrize("I,C,R,S,T", [(512, 1024, 512, 16, 20), (512, 1024, 512, 32, 20), (40, 1024, 512, 32, 20), (64, 256, 128, 24, 12),
-                                       (72, 160, 96, 13, 21), (512, 1024, 256, 13, 21), (96, 1024, 128, 9, 29)])
+                                       (72, 160, 96, 13, 21), (512, 1024, 256, 13, 21), (96, 1024, 128, 9, 29),
+                                       (40, 800, 512, 16, 20),      # round 6: the per-XCD chains at C != 1024 -- BASELINE configs[1]'s layer in bf16: 25 of 32 slots own cells,
+                                       (512, 800, 512, 32, 20),     # ... configs[3]'s inner layer: 7 cell-less workgroups per XCC still project (R = 512)
+                                       (64, 544, 96, 13, 21),       # ... 17 chunks of K (9 + 8 per half; BPTT: 68 chunks, 5 per wave, two waves short), ragged groups
+                                       (96, 512, 512, 9, 29)])      # ... half the slots own cells, all of them project
 def test_many_stream_persistent_forward_bf16(I, C, R, S, T):
     """The weights-resident forward launch for 9..32 streams in bf16 operand mode (klstm_persist_ms.hip): one
     launch runs all T steps of the folded recurrence, the x term and r(1..T) are batched products around it.  Three chained
@@ -1707,7 +1716,7 @@ def test_many_stream_persistent_forward_bf16(I, C, R, S, T):
         e.propagate(xd, out); e.backpropagate(xd, odd, idf, momentum=mmt); e.synchronize()
         parts = [split_blob(pe, I, C, R)[n] for n, _ in param_sizes(I, C, R)]
         # (C = 1024: one chain per XCD in both directions, klstm_persist_xl.hip -- the BPTT chain closes over dgifo through W_rm too)
-        out_m, id_m, grads, cT, rT = bf16_emul.minibatch(parts, x, od, c0, r0, S, fuse_x=0, fold=True, fold_bwd=C == 1024)
+        out_m, id_m, grads, cT, rT = bf16_emul.minibatch(parts, x, od, c0, r0, S, fuse_x=0, fold=True, fold_bwd=_per_xcd_chains(C, R, S, T))
         corr = mmt * corr + np.concatenate([a.ravel() for a in grads])
         assert relerr(out.cpu().numpy(), out_m) <= 6e-3, ck
         assert relerr(idf.cpu().numpy(), id_m) <= 6e-3, ck
@@ -1717,7 +1726,9 @@ def test_many_stream_persistent_forward_bf16(I, C, R, S, T):
         c0, r0 = cs.astype(np.float64), rs.astype(np.float64)
         e.update(lr)
         pe = (pe.astype(np.float64) - lr * corr).astype(np.float32)
-    assert e.profile_query("k_fwd_persist_xl" if C == 1024 else "k_fwd_persist_ms")[1] == 3 and e.profile_query("k_gates_step")[1] == 0
+    xl = _per_xcd_chains(C, R, S, T)
+    assert e.profile_query("k_fwd_persist_xl" if xl else "k_fwd_persist_ms")[1] == 3 and e.profile_query("k_gates_step")[1] == 0
+    assert e.profile_query("k_bwd_persist_xl")[1] == (3 if xl else 0)
     assert e.profile_query("persist_giveups")[1] == 0
     e.close()
 
