@@ -395,6 +395,11 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  accumulate, fp32 masters (the reference is fp32 only).  Needs I, C, R multiples of 8.
  *                  1 = where it pays: from 9 streams on; an engine of up to 8 streams keeps its fp32 weights-resident chain (faster
  *                  there, and exact; remark in klstm_last_error()).  2 = bf16 operands at any stream count.
+ *   "tail_merge"  0/1  1 = the reduction of the tail workgroups' partial d_r / in_diff rows runs on the first workgroups of the gradient
+ *                  launch behind the BPTT launch instead of in a launch of its own (k_tail_reduce).  With KLSTM_BPTT_FUSE_UPDATE that launch is
+ *                  klstm_update's: `in_diff` is then complete when klstm_update's launches are (klstm_synchronize in between runs it
+ *                  at once).  Bit-identical; measured SLOWER (146.0 -> 148.1 us per minibatch at 40/800/512 x 4): default 0, kept for A-B runs.
+ *                  klstm_profile_query "tail_merge_launches", "tail_merge_timeouts" (must stay 0).
  *   "fuse_update"  0/1  0 = KLSTM_BPTT_FUSE_UPDATE is ignored: gradient products and Update as separate passes (A-B runs; this engine)
  *   "gemm_copies"  0/1/2  bf16 mode, 9..32 streams with the per-XCD BPTT chain: that chain writes a bf16 copy of its dgifo rows, the Update
  *                  kernels bf16 copies of W_gifo_r^T / W_gifo_x^T, and the batched d_r + in_diff product reads THE COPIES by LDS-DMA

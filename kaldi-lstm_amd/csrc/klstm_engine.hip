@@ -139,6 +139,18 @@ struct klstm_engine {
   PersistOpts popt;         // per-engine knobs of the persistent kernels (options persist_waves, persist_tpw, persist_nap*, ...)
   int ncu = 0;              // compute units of the device: every workgroup of a persistent launch needs one of its own
   int persist_tail = 1;     // option "persist_tail": d_r / in_diff inside the persistent backward launch (0: batched products after it)
+  // option "tail_merge" (default 0: measured slower): the reduction of the tail workgroups' partial rows runs on the first workgroups of the
+  // gradient launch that follows the BPTT launch (k_grads<true>) instead of in a launch of its own.  With KLSTM_BPTT_FUSE_UPDATE that launch
+  // is klstm_update's: the job waits with the gradient products (tail_pending; whoever flushes them, or synchronises, runs it).
+  // tools/ab_step.py, 40/800/512: 4 streams k_tail_reduce 4.3 + k_grads 14.4 = 18.7 us apart, 20.0 us merged (146.0 -> 148.1 us per
+  // minibatch); 8 streams 4.4 + 18.2 -> 27.3 (189.9 -> 195.0).  Every gradient tile is resident from the start and latency-bound (operands,
+  // old corr / parameters, stores: three dependent memory round trips); the W_r_m tiles start one cross-XCD hand-over later (partial rows ->
+  // write-through d_r -> acknowledgement -> counter -> poll -> sc1 loads, ~6 us) and the launch ends that much later.  Bit-identical (test).
+  int tail_merge = 0;
+  unsigned *tr_ctr = nullptr;   // device: [0] arrivals of reduce workgroups over the engine's life, [1] expired waits
+  unsigned tr_seq = 0;          // merged launches enqueued so far
+  bool tail_pending = false;
+  TailReduceJob tr_job;
   bool bwd_persist = false; // ... and its backpropagate runs steps T..1 inside one persistent launch
   bool persist_dirty = false;   // a persistent launch ran since the status words were last read back
   unsigned long long *gran[2] = {nullptr, nullptr};   // granule slots of the forward / backward chain
@@ -344,14 +356,30 @@ static float *ar_mark(const klstm_engine *e) {
 }
 static const float *ar_mark_if_reduced(const klstm_engine *e) { return e->ar_marked ? ar_mark(e) : nullptr; }
 
+// "tail_merge": the waiting reduction as an argument of the gradient launch that is about to be enqueued (null: none waits).  The launch
+// ordinal is taken here: call it once per launch_grads, right in front of it.
+static const TailReduceJob *take_tail_job(klstm_engine *e) {
+  if (!e->tail_pending) return nullptr;
+  e->tail_pending = false;
+  e->tr_job.ctr = e->tr_ctr; e->tr_job.seq = ++e->tr_seq;
+  return &e->tr_job;
+}
+// ... or in a launch of its own (somebody wants in_diff / d_r before any gradient launch: klstm_synchronize, a getter, set_corr)
+static klstm_status flush_tail(klstm_engine *e) {
+  if (!e->tail_pending) return KLSTM_OK;
+  e->tail_pending = false;
+  HIPCHK(launch_tail_reduce(e->tr_job, e->pctrl, e->stream, probe(e, "k_tail_reduce")));
+  return KLSTM_OK;
+}
+
 // gradient products deferred by KLSTM_BPTT_FUSE_UPDATE, the ordinary way (somebody looks before the Update arrives)
 static klstm_status flush_grads(klstm_engine *e) {
-  if (!e->grads_pending) return KLSTM_OK;
+  if (!e->grads_pending) return flush_tail(e);
   e->grads_pending = false;
   const RangeGuardScope rgs(e->rg);
   const Dims d{e->I, e->C, e->R, e->S, e->gp_T};
   HIPCHK(launch_grads(d, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
-                      probe(e, "k_grads"), e->gp_bf16, nullptr, e->pctrl));
+                      probe(e, "k_grads"), e->gp_bf16, nullptr, e->pctrl, nullptr, take_tail_job(e)));
   if (e->verify_later) e->persist_dirty = true;      // (the promised klstm_update did not come: whoever synchronises next looks, as for any unverified launch)
   return KLSTM_OK;
 }
@@ -450,6 +478,9 @@ static klstm_status ensure_persist(klstm_engine *e) {
   }
   HIPCHK(hipMalloc(&e->pctrl, 16 * sizeof(unsigned)));   // (+ 8 diagnostic words: which cells' granules never arrived)
   HIPCHK(hipMemsetAsync(e->pctrl, 0, 16 * sizeof(unsigned), e->stream));
+  HIPCHK(hipMalloc(&e->tr_ctr, 4 * sizeof(unsigned)));   // "tail_merge": arrivals / expired waits (words of their own: recover() rewrites pctrl)
+  HIPCHK(hipMemsetAsync(e->tr_ctr, 0, 4 * sizeof(unsigned), e->stream));
+  e->tr_seq = 0;
   if (hipHostMalloc(reinterpret_cast<void **>(&e->pstat_host), 64, hipHostMallocMapped) == hipSuccess) {
     *e->pstat_host = 0u;
     e->pstat_host[1] = 0u;                         // (the done word of finish(): launch count | give-up bit)
@@ -494,7 +525,7 @@ static klstm_status recover(klstm_engine *e, const unsigned (&w)[16]) {
   e->cooldown = e->cooldown_cur;
   e->clean_run = 0;
   // host-side bookkeeping of work the device skipped
-  e->grads_pending = false; e->mmt_pending = false; e->verify_later = false;
+  e->grads_pending = false; e->mmt_pending = false; e->verify_later = false; e->tail_pending = false;
   e->planes_fresh = false; e->fold_dirty = true; e->foldx_fresh = false;
   e->wth_fresh = false;                               // (an Update behind the give-up did nothing: the next one that wants the bf16 copies makes them first)
   if (e->pk[0]) e->pk_stale = 15;
@@ -568,6 +599,7 @@ static klstm_status check_persist(klstm_engine *e) {
     const unsigned z9 = 0u;
     HIPCHK(hipMemcpy(e->pctrl + 9, &z9, sizeof(z9), hipMemcpyHostToDevice));
     e->grads_pending = false; e->mmt_pending = false;
+    { klstm_status ts = flush_tail(e); if (ts != KLSTM_OK) return ts; }
     return fail(KLSTM_ERR_HIP, "one-shot all-reduce timed out (phase %x): a peer did not arrive; the gradient blob was NOT reduced and this "
                 "rank's Update was NOT applied -- replicas may have diverged, stop the run (or use klstm_allreduce_grads)", w[9]);
   }
@@ -768,6 +800,7 @@ void klstm_destroy(klstm_engine *e) {
   if (e->flags_dev) (void)hipFree(e->flags_dev);
   for (auto *g : e->gran) if (g) (void)hipFree(g);
   if (e->pctrl) (void)hipFree(e->pctrl);
+  if (e->tr_ctr) (void)hipFree(e->tr_ctr);
   if (e->fold_scratch) (void)hipFree(e->fold_scratch);
   if (e->wrm_l) (void)hipFree(e->wrm_l);
   if (e->gran_ms) (void)hipFree(e->gran_ms);
@@ -840,6 +873,7 @@ klstm_status klstm_get_corr_host(klstm_engine *e, float *flat) {
 }
 klstm_status klstm_set_corr_host(klstm_engine *e, const float *flat) {
   if (e) { e->mmt_pending = false; e->grads_pending = false; }    // (whatever was on its way into corr is replaced)
+  if (e) { klstm_status ts = flush_tail(e); if (ts != KLSTM_OK) return ts; }   // (in_diff of that minibatch still wants its reduction)
   return blob_h2d(e, e ? e->corr : nullptr, flat);
 }
 klstm_status klstm_get_grads_host(klstm_engine *e, float *flat) { return blob_d2h(e, flat, e ? e->grads : nullptr); }
@@ -1063,10 +1097,14 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     else if (ks > 1) HIPCHK(launch_gemm_splitk(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, e->ws, ks, kl,
                                           st, nullptr, 0, probe(e, "k_gemm_P"), probe(e, "k_reduce_P")));
     else HIPCHK(launch_gemm(false, false, M, d.C, d.R, out_diff, od_stride, wm, d.C, 0.f, e->Pm, d.C, nullptr, st, probe(e, "k_gemm_P")));
+    // "tail_merge": the reduction of the tail workgroups' partial rows rides on the gradient launch that follows (here, or in klstm_update)
+    TailReduceJob tj;
+    const bool merge = e->bwd_persist && e->tail_merge && e->tail_wgs > 0 && e->tr_ctr && !e->use_graph && d.R % 8 == 0 && d.C % 8 == 0;
     if (e->bwd_persist) {
       HIPCHK(launch_bwd_persist(d, p, e->Pm, out_diff, od_stride, in_diff, id_stride, tail_inside, e->gran[1], e->pctrl + 4, e->popt, st,
-                                probe(e, "k_bwd_persist"), e->ws, e->ws_floats, probe(e, "k_tail_reduce")));
+                                probe(e, "k_bwd_persist"), e->ws, e->ws_floats, probe(e, "k_tail_reduce"), merge ? &tj : nullptr));
       e->persist_dirty = true;
+      if (merge && tj.tws) { e->tr_job = tj; e->tail_pending = true; }
     } else {
       for (int t = T; t >= 1; t--) HIPCHK(launch_dmf_step(d, p, t, e->Pm, st, probe(e, "k_dmf_step")));
     }
@@ -1076,7 +1114,7 @@ static klstm_status seq_backward(klstm_engine *e, const float *in, int in_stride
     const bool defer = (flags & KLSTM_BPTT_DEFER_MOMENTUM) != 0;
     if (grads_fusable(e, T, flags, false)) return KLSTM_OK;      // (klstm_update runs them together with the Update)
     HIPCHK(launch_grads(d, e->dgifo, e->dr, in, in_stride, e->rr, e->mm, e->cc, defer ? 0.f : mmt, defer ? e->grads : e->corr, st,
-                        probe(e, "k_grads"), false, nullptr, e->pctrl, defer ? ar_mark(e) : nullptr));
+                        probe(e, "k_grads"), false, nullptr, e->pctrl, defer ? ar_mark(e) : nullptr, take_tail_job(e)));
     return KLSTM_OK;
   }
   for (int t = T; t >= 1; t--) {
@@ -1181,6 +1219,7 @@ static klstm_status do_backpropagate(klstm_engine *e, const float *in, int in_st
   //  up they compute on invalid planes, but what they write -- derivative planes, in_diff -- is rewritten when the minibatch is run
   //  again, and the gradient / Update kernels behind them are guarded.)
   if (e->fwd_folded) { klstm_status fs = ensure_fold(e, !e->fwd_persist, !e->bwd_persist); if (fs != KLSTM_OK) return fs; }   // no-op unless parameters changed in between
+  { klstm_status ts = flush_tail(e); if (ts != KLSTM_OK) return ts; }   // (a reduction still waiting here has lost its gradient launch)
   klstm_engine::Key key(-T, in, in_stride, out_diff, out_diff_stride, in_diff, in_diff_stride, momentum,
                         flags | (e->fwd_folded ? 256 : 0) | (e->bwd_persist ? 512 : 0) | (e->bwd_xl ? 1024 : 0));
   // (one or two launches: the persistent kernel with P and the tail inside, plus at most the gradient products)
@@ -1416,8 +1455,9 @@ static klstm_status do_update(klstm_engine *e, float learn_rate, float clip_grad
     // ... and INSTEAD of them while the per-XCD chains run this engine: nothing reads the fp32 wrT / wxT then (ensure_wT32 for whoever does)
     if (e->wth_fresh && e->bwd_xl && e->skip_wT32 && !e->replaying && !e->use_graph && e->gp_bf16) { u.no_wT32 = true; e->wT32_stale = true; }
     HIPCHK(launch_grads(dg, e->dgifo, e->dr, e->gp_in, e->gp_in_stride, e->rr, e->mm, e->cc, e->gp_mmt, e->corr, e->stream,
-                        probe(e, "k_grads_update"), e->gp_bf16, &u, e->pctrl));
+                        probe(e, "k_grads_update"), e->gp_bf16, &u, e->pctrl, nullptr, take_tail_job(e)));
   } else {
+    { klstm_status ts = flush_tail(e); if (ts != KLSTM_OK) return ts; }
     const float *fold_grad = e->mmt_pending ? e->grads : nullptr;
     e->mmt_pending = false;
     // (data-parallel order: gradient -> all-reduce -> this) the planes of the fold operands come out of the same pass
@@ -1466,6 +1506,7 @@ klstm_status klstm_update(klstm_engine *e, float learn_rate, float clip_grad) {
 klstm_status klstm_synchronize(klstm_engine *e) {
   if (!e) return fail(KLSTM_ERR_ARG, "null engine");
   HIPCHK(hipSetDevice(e->device));
+  { klstm_status ts = flush_tail(e); if (ts != KLSTM_OK) return ts; }   // ("tail_merge": in_diff / d_r of a BPTT pass whose gradient launch has not come)
   for (;;) {
     HIPCHK(hipStreamSynchronize(e->stream));
     const klstm_status st = check_persist(e);
@@ -1626,6 +1667,11 @@ klstm_status klstm_set_option(klstm_engine *e, const char *key, int value) {
     else return fail(KLSTM_ERR_ARG, "klstm_set_option: unknown key '%s'", key);
     return KLSTM_OK;
   }
+  if (!strcmp(key, "tail_merge")) {
+    { klstm_status ts = flush_tail(e); if (ts != KLSTM_OK) return ts; }
+    e->tail_merge = value != 0;
+    return KLSTM_OK;
+  }
   if (!strcmp(key, "persist_tail")) {
     HIPCHK(hipStreamSynchronize(e->stream));
     drop_graphs(e);
@@ -1713,7 +1759,7 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
     const struct { const char *name; long v; } ctr[] = {
         {"persist_giveups", e->n_giveups}, {"persist_replayed", e->n_replayed}, {"persist_dropped", e->n_dropped},
         {"persist_launches", (long)e->pseq}, {"persist_cooldown", (long)e->cooldown}, {"gemm_copies_launches", e->n_copies},
-        {"persist_tail_wgs", e->tail_wgs},
+        {"persist_tail_wgs", e->tail_wgs}, {"tail_merge_launches", (long)e->tr_seq},
         // range-guard events: this engine's own products + the stateless klstm_affine_* calls made on this device (its default guard)
         {"fp16_redo", ev(REDO_FOLD) + ev(REDO_NT) + ev(REDO_OUTER) + ev(REDO_SKINNY)},
         {"fp16_redo_fold", ev(REDO_FOLD)}, {"fp16_redo_nt", ev(REDO_NT)},
@@ -1722,6 +1768,12 @@ klstm_status klstm_profile_query(klstm_engine *e, const char *kernel, double *to
         {"fold_mode", (long)e->fold_eff}};
     for (const auto &c : ctr)
       if (!strcmp(kernel, c.name)) { *total_us = 0.0; *launches = c.v; return KLSTM_OK; }
+    if (!strcmp(kernel, "tail_merge_timeouts")) {      // W_r_m tiles whose wait for the reduce workgroups of their launch expired (must stay 0)
+      unsigned v = 0;
+      if (e->tr_ctr) HIPCHK(hipMemcpy(&v, e->tr_ctr + 1, sizeof(v), hipMemcpyDeviceToHost));
+      *total_us = 0.0; *launches = (long)v;
+      return KLSTM_OK;
+    }
     if (!strcmp(kernel, "dp_updates_left_out")) {      // Updates every rank left out because SOME rank's gradient of that minibatch was not real
       unsigned v = 0;
       if (e->pctrl) HIPCHK(hipMemcpy(&v, e->pctrl + 10, sizeof(v), hipMemcpyDeviceToHost));

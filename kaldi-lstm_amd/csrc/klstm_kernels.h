@@ -223,10 +223,24 @@ hipError_t launch_gemm_bf16_nt2(const Nt2Job *jobs, int njobs, const Nt2Plan &pl
                                 hipStream_t st, LaunchProbe pr = {});   // tickets: >= pl.nt words, zero between launches (the kernel leaves them zero)
 void gemm_bf16_nt2_debug_buffer(long long *dev);      // probe support: 8 shader-clock sums per workgroup (null: off)
 bool grads_bf16_tiles(const Dims &d, bool bf16);      // would launch_grads take the bf16 tile path?
+// The reduction of the tail workgroups' partial d_r / in_diff rows (klstm_persist_bwd.hip: one partial row set per 32-cell slot, added in
+// slot order) as a job: run by k_tail_reduce behind the BPTT launch, or -- "tail_merge" -- by the FIRST workgroups of the gradient launch
+// that follows on the same stream (launch_grads `tr`): the launch of its own (4.3 us of dispatch + one round trip at 40/800/512) is gone,
+// the W_r_m gradient tiles (the only readers of d_r) wait for an arrival counter, everybody else starts at once.
+struct TailReduceJob {
+  const float *tws = nullptr; int nslots = 0, T = 0, S = 0, R = 0, ncols = 0;   // partial rows [nslots][T*S][ncols]; ncols = R (+ I)
+  const float *od = nullptr; int od_stride = 0;                                // out_diff: added to the d_r columns (:391), d_r(T) = out_diff(T) (:351)
+  float *dr = nullptr; float *in_diff = nullptr; int id_stride = 0;
+  unsigned *ctr = nullptr;        // merged form: [0] arrivals of the reduce workgroups (never reset: launch n waits for n * nred), [1] waits that expired
+  unsigned seq = 0;               // merged form: ordinal of this launch among the engine's merged launches (1, 2, ...)
+};
+int tail_reduce_blocks(const TailReduceJob &j);   // reduce workgroups of the merged form (a multiple of 8)
+hipError_t launch_tail_reduce(const TailReduceJob &j, const unsigned *guard, hipStream_t st, LaunchProbe pr = {});   // the launch of its own
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst_blob,
                         hipStream_t st, LaunchProbe pr = {}, bool bf16 = false, const GradsUpdate *upd = nullptr,
-                        const unsigned *guard = nullptr, float *mark = nullptr);   // bf16: operands rounded to bf16, 16x16x32 MFMA, fp32 accumulate
+                        const unsigned *guard = nullptr, float *mark = nullptr,
+                        const TailReduceJob *tr = nullptr);   // bf16: operands rounded to bf16, 16x16x32 MFMA, fp32 accumulate; tr: fp32 tiles only
 // mark (data-parallel runs): one float behind the gradient blob that travels through the all-reduce with it -- launch_grads writes 0
 // (this rank's gradient is real) or 1 (the guard stopped it); launch_update_repack / launch_apply_momentum given the same address AFTER
 // the all-reduce leave everything alone when the sum is non-zero (and count it in *peer_skip): a minibatch that was invalid on ANY rank
@@ -325,7 +339,9 @@ size_t persist_bwd_tail_ws_floats(const Dims &d, bool want_in_diff);
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, const float *out_diff, int od_stride,
                               float *in_diff, int id_stride, bool tail_inside, unsigned long long *gran, unsigned *ctrl,
                               const PersistOpts &o, hipStream_t st, LaunchProbe pr = {}, float *tws = nullptr, size_t tws_floats = 0,
-                              LaunchProbe pr_reduce = {});
+                              LaunchProbe pr_reduce = {}, TailReduceJob *defer = nullptr);
+// defer (or null): when tail workgroups ran, the reduction is NOT launched but described in *defer (tws != null says so): the caller hands
+// it to the gradient launch that follows (launch_grads `tr`) or to launch_tail_reduce
 
 // Many-stream (9..32) weights-resident forward chain of the bf16 operand mode (klstm_persist_ms.hip): one launch runs all T steps of
 // the folded recurrence; wrm = W_gifo_r W_r_m as bf16, logical rows (4 cell + gate) x C (launch_fold_ms, once per Update); the x term must be in

@@ -28,6 +28,7 @@
 #include "klstm_kernels.h"
 #include <type_traits>
 #include "klstm_math.h"
+#include "klstm_persist_dev.h"
 
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -1560,6 +1561,21 @@ __device__ __forceinline__ void fetch_tile_vec(const float *__restrict__ P, int 
     t.v[h][0] = ldg4(p); t.v[h][1] = ldg4(p + 4);
   }
 }
+// The [K x X] tile of an operand that OTHER workgroups of the same launch have just written with write-through stores (k_grads<true>: the
+// d_r rows from the reduce workgroups): 16-byte sc1 loads -- served from beyond this XCD's L2, which may hold a line of it that another
+// XCD completed later.  Same addresses, same padding rule.
+__device__ __forceinline__ void fetch_tile_vec_coh(const float *__restrict__ P, int ld, int X, int K, int x0, int k0, int tid, RawTile &t) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, K * ld * 4, 0x00020000);
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int k = k0 + h * 32 + (tid >> 3), x = x0 + (tid & 7) * 8;
+    t.ok[h] = k < K && x < X;
+    const int off = (min(k, K - 1) * ld + min(x, X - 8)) * 4;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16), q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 16);   // aux 16 = sc1
+    t.v[h][0] = __builtin_bit_cast(float4, q0); t.v[h][1] = __builtin_bit_cast(float4, q1);
+  }
+}
 // the padding mask is applied HERE, one K tile later: touching the fetched registers any earlier makes the wave wait for
 // the loads before it multiplies the current tile
 __device__ __forceinline__ void unpack_tile(const RawTile &t, float (&r)[2][8]) {
@@ -1589,7 +1605,7 @@ __device__ __forceinline__ float lds_operand(const float *Ls, int k, int x) { re
 
 // 64x64 output tile, 4 waves (2x2) of 32x32, K tile 64.  The next K tile is fetched into registers while the
 // current one is multiplied out of LDS (global latency hides under 16 k-steps x 4 MFMAs per wave).
-template <bool TA, bool TB, bool VEC>
+template <bool TA, bool TB, bool VEC, bool COHA = false>   // COHA: A through fetch_tile_vec_coh (TA, VEC)
 __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0, float *As, float *Bs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kg = lane >> 4;
@@ -1604,7 +1620,8 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
   RawTile ta, tb;
   auto fetch = [&](int k0) {
     if constexpr (VEC) {
-      fetch_tile_vec<TA>(g.A, g.lda, g.M, g.K, m0, k0, tid, ta, g.gperm);
+      if constexpr (COHA) fetch_tile_vec_coh(g.A, g.lda, g.M, g.K, m0, k0, tid, ta);
+      else fetch_tile_vec<TA>(g.A, g.lda, g.M, g.K, m0, k0, tid, ta, g.gperm);
       fetch_tile_vec<!TB>(g.B, g.ldb, g.N, g.K, n0, k0, tid, tb);   // B [N x K] when TB, else [K x N]
     } else {
       fetch_tile<TA>(g.A, g.lda, g.vecA, g.M, g.K, m0, k0, tid, ra, g.gperm);
@@ -1721,6 +1738,8 @@ __device__ __forceinline__ void gemm_tile_impl(const GemmJob &g, int m0, int n0,
 #pragma unroll
           for (int q = 0; q < 4; q++) { c[q] = c[q] < -g.clip ? -g.clip : c[q]; c[q] = c[q] > g.clip ? g.clip : c[q]; }
         }
+        // (plain stores.  Measured and dropped, round 6: corr / parameters / planes as nontemporal stores -- the launch 14.4 -> 15.6 us and
+        //  the fold behind it 13.9 -> 14.4 us at 40/800/512: it finds the planes this pass has just written closer than HBM.)
         *cp = make_float4(c[0], c[1], c[2], c[3]);
         if (g.P) {
           pv.x = pv.x + (-g.lr) * c[0]; pv.y = pv.y + (-g.lr) * c[1]; pv.z = pv.z + (-g.lr) * c[2]; pv.w = pv.w + (-g.lr) * c[3];
@@ -1947,6 +1966,9 @@ struct GradsArgs {
   float *g_bias, *g_pi, *g_pf, *g_po;
   float *p_bias, *p_pi, *p_pf, *p_po;   // parameters to update in the same pass (null: gradient only)
   float lr, clip;
+  // k_grads<true> ("tail_merge"): the first nred workgroups add the tail workgroups' partial d_r / in_diff rows (TailReduceJob), the
+  // W_r_m tiles wait until tr.ctr[0] has reached tr_target
+  TailReduceJob tr; int nred; unsigned tr_target;
 };
 
 // bias / peephole column sums of k_grads: block vb covers 64 columns of the 4C gate axis with 4 row groups
@@ -2004,23 +2026,67 @@ __device__ __forceinline__ void grads_column_sums(const GradsArgs &a, int vb, fl
   }
 }
 
+// TM ("tail_merge"): the launch also runs the reduction of the tail workgroups' partial rows that used to be k_tail_reduce behind the BPTT
+// launch.  Workgroups [0, nred) (dispatched first) add the partial rows -- d_r as write-through stores --, wait for their stores'
+// acknowledgements and arrive at tr.ctr[0]; the W_r_m tiles (the only readers of d_r) sit at the END of every XCD's range, wait for
+// ctr[0] to reach tr_target (a launch ordinal times nred: nothing to reset, a launch that does nothing still arrives) and read d_r with sc1
+// loads; the W_gifo_x / W_gifo_r tiles and the column sums start at once.  The wait is bounded (200 ms; an expiry is counted in ctr[1] and
+// the tile goes on -- the reduce workgroups have the lowest indices, so they are resident or done before any tile that waits for them).
+template <bool TM>
 __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
   const bool invalid = a.guard && (a.guard[2] | a.guard[6] | a.guard[9]);
   if (a.mark && blockIdx.x == 0 && threadIdx.x == 0) *a.mark = invalid ? 1.f : 0.f;
+  int bi = (int)blockIdx.x;
+  if constexpr (TM) {
+    if (bi < a.nred) {
+      if (!invalid) {
+        const int gidx = bi * 256 + (int)threadIdx.x;
+        tail_reduce_outputs<true>(a.tr.tws, a.tr.nslots, a.tr.T, a.tr.S, a.tr.R, a.tr.ncols, a.tr.od, a.tr.od_stride, a.tr.dr, a.tr.in_diff,
+                                  a.tr.id_stride, gidx >> 3, a.nred * 32, gidx & 7, nullptr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(a.tr.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    bi -= a.nred;
+  }
   if (invalid) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
   __shared__ __attribute__((aligned(16))) float As[GLDS];
   __shared__ __attribute__((aligned(16))) float Bs[GLDS];
   // XCD-aware order: workgroup w lands on XCD w % 8 (observed dispatch rule, speed only); XCD x gets the contiguous
   // m-major tile range [x*cpx, (x+1)*cpx), so its private L2 holds a few A row panels and the B column panels
-  // instead of streaming every A panel once per XCD.
+  // instead of streaming every A panel once per XCD.  (TM: two such ranges per XCD -- its share of the tiles that wait for nobody,
+  // then its share of the W_r_m tiles and column sums.)
   const int nbt = a.nb2 + a.nvec;
-  const int cpx = (nbt + 7) >> 3;
-  const int b = (int)(blockIdx.x & 7) * cpx + (int)(blockIdx.x >> 3);
-  if (b >= nbt) return;
+  int b;
+  if constexpr (TM) {
+    const int cpx1 = (a.nb1 + 7) >> 3, cpx2 = (nbt - a.nb1 + 7) >> 3, x = bi & 7, pos = bi >> 3;
+    if (pos < cpx1) { b = x * cpx1 + pos; if (b >= a.nb1) return; }
+    else { b = a.nb1 + x * cpx2 + (pos - cpx1); if (b >= nbt) return; }
+  } else {
+    const int cpx = (nbt + 7) >> 3;
+    b = (bi & 7) * cpx + (bi >> 3);
+    if (b >= nbt) return;
+  }
   if (b < a.nb2) {
     const GemmJob &g = b < a.nb0 ? a.wx : b < a.nb1 ? a.wr : a.wm;
     const int lb = b < a.nb0 ? b : b < a.nb1 ? b - a.nb0 : b - a.nb1;
     const int ntn = (g.N + GT - 1) / GT;
+    if constexpr (TM) {
+      if (b >= a.nb1) {
+        if (threadIdx.x == 0) {
+          const long long t0 = wall_clock64();
+          while ((int)(__hip_atomic_load(a.tr.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.tr_target) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 20000000LL) { __hip_atomic_fetch_add(a.tr.ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          }
+        }
+        __syncthreads();
+        gemm_tile_impl<true, false, true, true>(g, (lb / ntn) * GT, (lb % ntn) * GT, As, Bs);   // (the merged form is only launched with 16-byte rows)
+        return;
+      }
+    }
     gemm_tile<true, false>(g, (lb / ntn) * GT, (lb % ntn) * GT, As, Bs);
     return;
   }
@@ -3462,7 +3528,8 @@ bool grads_bf16_tiles(const Dims &d, bool bf16) { return bf16 && d.T * d.S >= GR
 
 hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, const float *in, int in_stride,
                         const float *rr, const float *mm, const float *cc, float beta, float *dst,
-                        hipStream_t st, LaunchProbe pr, bool bf16, const GradsUpdate *upd, const unsigned *guard, float *mark) {
+                        hipStream_t st, LaunchProbe pr, bool bf16, const GradsUpdate *upd, const unsigned *guard, float *mark,
+                        const TailReduceJob *tr) {
   const int S = d.S, C = d.C, R = d.R, I = d.I, TS = d.T * d.S;
   const long o_wx = 0, o_wr = (long)4 * C * I, o_b = o_wr + (long)4 * C * R, o_pi = o_b + 4 * C,
              o_pf = o_pi + C, o_po = o_pf + C, o_wm = o_po + C;
@@ -3501,6 +3568,7 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
                      in_stride % 4 == 0 && C % 4 == 0 && R % 4 == 0 && I % 4 == 0;
   if (bf_ok && upd && !(aligned16(dst) && aligned16(upd->params) && aligned16(upd->wrT) && aligned16(upd->wmT) && aligned16(upd->wxT)))
     return hipErrorInvalidValue;                      // (the fused epilogue moves 16-byte pieces; the engine's blobs are aligned)
+  if (bf_ok && tr) return hipErrorInvalidValue;       // (the merged reduction rides on the fp32 tiles only)
   if (bf_ok) {                                        // 128x128 tiles on the bf16 pipe
     // 128 x 64 tiles while 128 x 128 ones would not even give every CU a workgroup (measured at 1024/512, 640 frames: 192 tiles
     // (40 inputs) 24.8 -> 21.3 us; 288 tiles (512 inputs) 30 -> 33.5 us: stays wide)
@@ -3512,7 +3580,12 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
     if (upd && upd->no_wT32) KLAUNCH(k_grads_bf16<true>, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
     KLAUNCH(k_grads_bf16<false>, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
   }
-  KLAUNCH(k_grads, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
+  if (tr) {   // the reduction of the tail workgroups' partial rows on the first workgroups of this launch
+    if (!(a.wm.vecA && a.wm.vecB) || !tr->ctr || !tr->tws) return hipErrorInvalidValue;   // (16-byte rows: the engine's own buffers)
+    a.tr = *tr; a.nred = tail_reduce_blocks(*tr); a.tr_target = tr->seq * (unsigned)a.nred;
+    KLAUNCH(k_grads<true>, dim3(a.nred + 8 * (cdiv(a.nb1, 8) + cdiv(a.nb2 + a.nvec - a.nb1, 8))), dim3(256), st, pr, a);
+  }
+  KLAUNCH(k_grads<false>, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
 }
 
 bool update_repack_vectorised(const Dims &d, const float *param_blob, const float *corr_blob, const float *grad_blob, const float *wrT,

@@ -145,61 +145,7 @@ __device__ __forceinline__ float dpp_quad(unsigned v, bool odd_pair) {
 // still contract frame t.
 // IL: the (frame, group) order of the interleaved kernel (t, 0), (t, 1), (t - 1, 0), ...; otherwise group after group.
 // -------------------------------------------------------------------------------------------------------------------
-// d_r / in_diff from the tail workgroups' partial rows: output idx = (frame row r = (t - 1) S + s, column quad cq), 8 lanes per output --
-// lane l adds slots l, l + 8, l + 16, ... in that order, then three butterfly stages: ONE fixed tree per output whoever runs it
-// (deterministic).  out_diff is added to the d_r columns (:391), d_r(T) = out_diff(T) (:351).
-// Every load of an output -- the guard words, up to four partial rows per lane, the out_diff piece -- is requested before the first
-// use (one memory round trip per output instead of three in a row: the launch is nothing but latency, 4.3 -> ... us); a raised guard only
-// withholds the stores (the partial rows of a launch that gave up are garbage, reading them is harmless).
-__device__ __forceinline__ void tail_reduce_outputs(const float *tws, int nslots, int T, int S, int R, int ncols, const float *od, int od_stride,
-                                                    float *dr, float *in_diff, int id_stride, int first, int step, int l,
-                                                    const unsigned *guard = nullptr) {
-  const int nqc = ncols >> 2, nout = T * S * nqc;
-  const size_t stride = (size_t)T * S * ncols;
-  unsigned bad = 0u;
-  if (guard) bad = __hip_atomic_load(guard + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | __hip_atomic_load(guard + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int idx = first;; idx += step) {              // (idx grows with the lane: a wave leaves when its first output is past the end -- the butterflies need every lane)
-    const bool on = idx < nout;
-    if (!__any(on)) break;
-    const int r = on ? idx / nqc : 0, cq = on ? idx - r * nqc : 0;
-    const int t = r / S + 1, s = r - (t - 1) * S;
-    const float *p = tws + (size_t)r * ncols + 4 * cq;
-    const bool is_r = 4 * cq < R, want_od = on && l == 0 && is_r && t >= 2;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f), oT = o;
-    if (want_od) o = *reinterpret_cast<const float4 *>(od + (size_t)((t - 2) * S + s) * od_stride + 4 * cq);
-    if (want_od && t == T) oT = *reinterpret_cast<const float4 *>(od + (size_t)((T - 1) * S + s) * od_stride + 4 * cq);
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nslots <= 32) {                              // (C <= 1024: at most four slots per lane, all in flight at once; same order of additions)
-      float4 v[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int j = l + 8 * q;
-        v[q] = *reinterpret_cast<const float4 *>(p + (size_t)(j < nslots ? j : 0) * stride);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (l + 8 * q < nslots) { sum.x += v[q].x; sum.y += v[q].y; sum.z += v[q].z; sum.w += v[q].w; }
-    } else {
-      for (int j = l; j < nslots; j += 8) {
-        const float4 v = *reinterpret_cast<const float4 *>(p + j * stride);
-        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-      }
-    }
-#pragma unroll
-    for (int m = 1; m < 8; m <<= 1) {
-      sum.x += __shfl_xor(sum.x, m); sum.y += __shfl_xor(sum.y, m); sum.z += __shfl_xor(sum.z, m); sum.w += __shfl_xor(sum.w, m);
-    }
-    if (!on || l != 0 || bad) continue;
-    if (is_r) {
-      if (t < 2) continue;                           // (frame 1 feeds no d_r row; d_r(T) = out_diff(T) goes out with the row of frame T; T >= 3 here)
-      *reinterpret_cast<float4 *>(dr + ((size_t)(t - 1) * S + s) * R + 4 * cq) = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + sum.w);   // :391
-      if (t == T) *reinterpret_cast<float4 *>(dr + ((size_t)T * S + s) * R + 4 * cq) = oT;
-    } else if (in_diff) {
-      *reinterpret_cast<float4 *>(in_diff + (size_t)((t - 1) * S + s) * id_stride + 4 * cq - R) = sum;   // :457
-    }
-  }
-}
-
+// (tail_reduce_outputs: klstm_persist_dev.h -- the gradient launch runs it too, "tail_merge")
 constexpr int TAIL_TG = 2;       // groups of 4 column quads per wave (32 weight registers each)
 
 template <int NW, bool IL, int NGI = 2>
@@ -391,20 +337,22 @@ __device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *l
   //  until complete, take 5.5 us per frame -- 113.7 us per launch at 4 streams, 207 at 8.  (c) the same granules, but every tail workgroup's
   //  LAST wave adding a 1 / 50 share of the outputs of the step two back (9.6 KB of sc1 loads per step): a coherent load of another XCD's
   //  fresh write-through data takes ~2 us, two passes per step, and the wave sits in the workgroup's per-step barrier: 88.5 us per launch
-  //  at 4 streams, 157.6 at 8.  All three are bit-correct; k_tail_reduce behind the launch stays.)
+  //  at 4 streams, 157.6 at 8.  (d) the reduction on the FIRST workgroups of the gradient launch that follows (option "tail_merge",
+  //  k_grads<true>: write-through d_r, arrival counter, the W_r_m tiles wait and read with sc1 loads): 20.0 us against 4.3 + 14.4 at 4
+  //  streams, 27.3 against 4.4 + 18.2 at 8 -- every gradient tile is resident from the start and latency-bound, the tiles that wait end
+  //  one cross-XCD hand-over (~6 us) late.  All four are bit-correct; k_tail_reduce behind the launch stays.)
 }
 
 // d_r / in_diff from the tail workgroups' partial rows: the nslots partials of an output added in slot order (fixed order), out_diff
 // added to the d_r columns (:391), d_r(T) = out_diff(T) (:351).  One thread per (frame row, column quad).
 struct TailReduceArgs {
-  const float *tws; int nslots, T, S, R, ncols;
-  const float *od; int od_stride;
-  float *dr; float *in_diff; int id_stride;
+  TailReduceJob j;
   const unsigned *guard;          // a launch in front gave up: the partial rows are not there -- write nothing (everything is run again)
 };
 __global__ __launch_bounds__(256) void k_tail_reduce(TailReduceArgs a) {
   const int gidx = blockIdx.x * 256 + threadIdx.x;
-  tail_reduce_outputs(a.tws, a.nslots, a.T, a.S, a.R, a.ncols, a.od, a.od_stride, a.dr, a.in_diff, a.id_stride, gidx >> 3, (int)gridDim.x * 32, gidx & 7, a.guard);
+  tail_reduce_outputs<false>(a.j.tws, a.j.nslots, a.j.T, a.j.S, a.j.R, a.j.ncols, a.j.od, a.j.od_stride, a.j.dr, a.j.in_diff, a.j.id_stride, gidx >> 3,
+                             (int)gridDim.x * 32, gidx & 7, a.guard);
 }
 
 template <int NW, int NU>
@@ -1267,8 +1215,10 @@ static hipError_t plaunch2(Kn kern, int grid, int threads, size_t shm, hipStream
 
 hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, const float *out_diff, int od_stride,
                               float *in_diff, int id_stride, bool tail_inside, unsigned long long *gran, unsigned *ctrl,
-                              const PersistOpts &o, hipStream_t st, LaunchProbe pr, float *tws, size_t tws_floats, LaunchProbe pr_reduce) {
+                              const PersistOpts &o, hipStream_t st, LaunchProbe pr, float *tws, size_t tws_floats, LaunchProbe pr_reduce,
+                              TailReduceJob *defer) {
   PersistBwd2Args a;
+  if (defer) *defer = TailReduceJob{};
   a.C = d.C; a.R = d.R; a.S = d.S; a.T = d.T; a.I = d.I;
   a.pin = persist_p_in_kernel(d, o) && out_diff && (reinterpret_cast<uintptr_t>(out_diff) & 15) == 0 && od_stride % 4 == 0;
   if (!a.pin && !P) return hipErrorInvalidValue;
@@ -1317,13 +1267,21 @@ hipError_t launch_bwd_persist(const Dims &d, const BwdPtrs &p, const float *P, c
   }
   if (err != hipSuccess || !a.tq) return err;
   // the tail workgroups' partial rows -> d_r, in_diff
+  TailReduceJob j;
+  j.tws = tws; j.nslots = pcdiv2(d.C, 32); j.T = d.T; j.S = d.S; j.R = d.R; j.ncols = 4 * a.tq;
+  j.od = out_diff; j.od_stride = od_stride; j.dr = p.dr; j.in_diff = in_diff; j.id_stride = id_stride;
+  if (defer) { *defer = j; return hipSuccess; }      // (the gradient launch that follows runs it on its first workgroups)
+  return launch_tail_reduce(j, o.guard, st, pr_reduce);
+}
+
+hipError_t launch_tail_reduce(const TailReduceJob &j, const unsigned *guard, hipStream_t st, LaunchProbe pr) {
   TailReduceArgs ra;
-  ra.tws = tws; ra.nslots = pcdiv2(d.C, 32); ra.T = d.T; ra.S = d.S; ra.R = d.R; ra.ncols = 4 * a.tq;
-  ra.od = out_diff; ra.od_stride = od_stride; ra.dr = p.dr; ra.in_diff = in_diff; ra.id_stride = id_stride; ra.guard = o.guard;
-  const int nthr = d.T * d.S * a.tq * 8;
-  if (pr_reduce.start) hipExtLaunchKernelGGL(k_tail_reduce, dim3(pcdiv2(nthr, 256)), dim3(256), 0, st, pr_reduce.start, pr_reduce.stop, 0, ra);
+  ra.j = j; ra.guard = guard;
+  const int nthr = j.T * j.S * (j.ncols / 4) * 8;
+  if (pr.start) hipExtLaunchKernelGGL(k_tail_reduce, dim3(pcdiv2(nthr, 256)), dim3(256), 0, st, pr.start, pr.stop, 0, ra);
   else hipLaunchKernelGGL(k_tail_reduce, dim3(pcdiv2(nthr, 256)), dim3(256), 0, st, ra);
   return hipGetLastError();
 }
+int tail_reduce_blocks(const TailReduceJob &j) { return pcdiv2(pcdiv2(j.T * j.S * (j.ncols / 4) * 8, 256), 8) * 8; }
 
 }  // namespace klstm

@@ -1,6 +1,7 @@
 // kaldi-lstm_amd/csrc/klstm_persist_dev.h -- device helpers shared by the two persistent (weights-resident) chain kernels,
 // klstm_persist.hip (forward) and klstm_persist_bwd.hip (backward): the granule transport, buffer-descriptor plane I/O,
-// the k-group sums of the 4-row MFMA geometry, bounded waits and the end-of-launch epoch hand-over.
+// the k-group sums of the 4-row MFMA geometry, bounded waits and the end-of-launch epoch hand-over; the reduction of the tail
+// workgroups' partial rows (k_tail_reduce, and the first workgroups of k_grads).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "klstm_math.h"
@@ -77,6 +78,72 @@ __device__ __forceinline__ f32x4 kgroup_sum_pl(f32x4 v) {
   }
   return f32x4{c[0], c[1], c[2], c[3]};
 }
+
+// d_r / in_diff from the tail workgroups' partial rows: output idx = (frame row r = (t - 1) S + s, column quad cq), 8 lanes per output --
+// lane l adds slots l, l + 8, l + 16, ... in that order, then three butterfly stages: ONE fixed tree per output whoever runs it
+// (deterministic).  out_diff is added to the d_r columns (:391), d_r(T) = out_diff(T) (:351).
+// Every load of an output -- the guard words, up to four partial rows per lane, the out_diff piece -- is requested before the first
+// use (one memory round trip per output instead of three in a row: the launch is nothing but latency, 4.3 -> ... us); a raised guard only
+// withholds the stores (the partial rows of a launch that gave up are garbage, reading them is harmless).
+// WT: the d_r rows leave as 16-byte write-through (sc1) stores -- a consumer in the SAME launch (the W_r_m gradient tiles of k_grads, which
+// read them with sc1 loads behind an arrival counter) finds them beyond its own XCD's L2; in_diff has no reader inside the launch.
+template <bool WT>
+__device__ __forceinline__ void tail_reduce_outputs(const float *tws, int nslots, int T, int S, int R, int ncols, const float *od, int od_stride,
+                                                    float *dr, float *in_diff, int id_stride, int first, int step, int l,
+                                                    const unsigned *guard = nullptr) {
+  const int nqc = ncols >> 2, nout = T * S * nqc;
+  const size_t stride = (size_t)T * S * ncols;
+  unsigned bad = 0u;
+  if (guard) bad = __hip_atomic_load(guard + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | __hip_atomic_load(guard + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int idx = first;; idx += step) {              // (idx grows with the lane: a wave leaves when its first output is past the end -- the butterflies need every lane)
+    const bool on = idx < nout;
+    if (!__any(on)) break;
+    const int r = on ? idx / nqc : 0, cq = on ? idx - r * nqc : 0;
+    const int t = r / S + 1, s = r - (t - 1) * S;
+    const float *p = tws + (size_t)r * ncols + 4 * cq;
+    const bool is_r = 4 * cq < R, want_od = on && l == 0 && is_r && t >= 2;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f), oT = o;
+    if (want_od) o = *reinterpret_cast<const float4 *>(od + (size_t)((t - 2) * S + s) * od_stride + 4 * cq);
+    if (want_od && t == T) oT = *reinterpret_cast<const float4 *>(od + (size_t)((T - 1) * S + s) * od_stride + 4 * cq);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nslots <= 32) {                              // (C <= 1024: at most four slots per lane, all in flight at once; same order of additions)
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int j = l + 8 * q;
+        v[q] = *reinterpret_cast<const float4 *>(p + (size_t)(j < nslots ? j : 0) * stride);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (l + 8 * q < nslots) { sum.x += v[q].x; sum.y += v[q].y; sum.z += v[q].z; sum.w += v[q].w; }
+    } else {
+      for (int j = l; j < nslots; j += 8) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + j * stride);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      sum.x += __shfl_xor(sum.x, m); sum.y += __shfl_xor(sum.y, m); sum.z += __shfl_xor(sum.z, m); sum.w += __shfl_xor(sum.w, m);
+    }
+    if (!on || l != 0 || bad) continue;
+    if (is_r) {
+      if (t < 2) continue;                           // (frame 1 feeds no d_r row; d_r(T) = out_diff(T) goes out with the row of frame T; T >= 3 here)
+      const float4 v = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + sum.w);   // :391
+      if constexpr (WT) {
+        const __amdgpu_buffer_rsrc_t rs = buf_rsrc(dr, (T + 1) * S * R * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (((t - 1) * S + s) * R + 4 * cq) * 4, 0, 16);   // aux 16 = sc1
+        if (t == T) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oT), rs, ((T * S + s) * R + 4 * cq) * 4, 0, 16);
+      } else {
+        *reinterpret_cast<float4 *>(dr + ((size_t)(t - 1) * S + s) * R + 4 * cq) = v;
+        if (t == T) *reinterpret_cast<float4 *>(dr + ((size_t)T * S + s) * R + 4 * cq) = oT;
+      }
+    } else if (in_diff) {
+      *reinterpret_cast<float4 *>(in_diff + (size_t)((t - 1) * S + s) * id_stride + 4 * cq - R) = sum;   // :457
+    }
+  }
+}
+
 
 // workgroup barrier that orders LDS traffic only
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -263,6 +263,65 @@ def test_tail_workgroups_against_the_in_chain_tail(I, C, R, S, T, want_in_diff):
         e.close()
 
 
+@pytest.mark.parametrize("I,C,R,S,T,want_in_diff", [
+    (40, 800, 512, 4, 20, True),     # configs[1]
+    (40, 800, 512, 8, 20, True),     # configs[2] shard
+    (40, 800, 512, 12, 20, True),    # three interleaved chains
+    (40, 800, 512, 3, 9, False),     # no in_diff: d_r columns only
+    (512, 800, 512, 4, 20, True),    # configs[3]'s inner layer: two column parts per slot
+    (24, 136, 72, 7, 10, True),      # ragged slots
+])
+@pytest.mark.parametrize("how", ["plain", "fused", "fused_sync", "defer"])
+def test_tail_merge_bit_identical(I, C, R, S, T, want_in_diff, how):
+    """Round 6 ("tail_merge" = 1, the default): the reduction of the tail workgroups' partial d_r / in_diff rows runs on the FIRST
+    workgroups of the gradient launch behind the BPTT launch (k_grads<true>: write-through stores of d_r, an arrival counter, the W_r_m
+    gradient tiles wait and read with sc1 loads) instead of in k_tail_reduce.  Same summation tree per output, so everything -- in_diff,
+    d_r, the seven gradient tensors, the updated parameters -- must be BIT-identical to an engine with "tail_merge" = 0, however the
+    gradient launch comes about: in klstm_backpropagate (plain), in klstm_update (KLSTM_BPTT_FUSE_UPDATE: in_diff is complete when
+    klstm_update's launches are), after a klstm_synchronize in between (the reduction is flushed as a launch of its own, the gradient
+    products still wait), or with KLSTM_BPTT_DEFER_MOMENTUM (data-parallel order).  Four chained minibatches; no wait may expire."""
+    import kaldi_lstm_amd as k
+    rng = np.random.RandomState(11)
+    p = make_params(I, C, R, scale=0.05, seed=12)
+    flags = {"plain": 0, "fused": 2, "fused_sync": 2, "defer": 1}[how]
+    eng = []
+    for merge in (1, 0):
+        e = k.Engine(I, C, R, S)
+        e.set_option("persist", 2); e.set_option("tail_merge", merge); e.set_params(p)
+        eng.append(e)
+    for ck in range(4):
+        x = rng.randn(T * S, I).astype(np.float32); od = (0.3 * rng.randn(T * S, R)).astype(np.float32)
+        xd, odd = dev(x), dev(od)
+        res = []
+        for e in eng:
+            outd = torch.empty(T * S, R, device="cuda"); idd = torch.zeros(T * S, I, device="cuda") if want_in_diff else None
+            e.propagate(xd, outd); e.backpropagate(xd, odd, idd, momentum=0.9, flags=flags)
+            mid = None
+            if how == "fused_sync":
+                e.synchronize()
+                mid = idd.cpu().numpy() if want_in_diff else None
+            if how == "defer":
+                e.apply_momentum(0.9)
+            e.update(1e-3); e.synchronize()
+            res.append(dict(out=outd.cpu().numpy(), ind=idd.cpu().numpy() if want_in_diff else None, mid=mid, corr=e.get_corr(),
+                            par=e.get_params(), D=e.activations(1)))
+        a, b = res
+        assert np.array_equal(a["out"], b["out"])
+        assert np.array_equal(a["D"], b["D"]), "derivative planes / d_r differ"
+        if want_in_diff:
+            assert np.array_equal(a["ind"], b["ind"]), "in_diff differs"
+            if a["mid"] is not None:
+                assert np.array_equal(a["mid"], a["ind"]) and np.array_equal(b["mid"], a["mid"]), "in_diff was not complete at klstm_synchronize"
+        assert np.array_equal(a["corr"], b["corr"]) and np.array_equal(a["par"], b["par"])
+    assert eng[0].profile_query("persist_tail_wgs")[1] > 0 and eng[0].profile_query("persist_giveups")[1] == 0
+    nm = eng[0].profile_query("tail_merge_launches")[1]
+    assert nm == (0 if how == "fused_sync" else 4), nm
+    assert eng[1].profile_query("tail_merge_launches")[1] == 0
+    assert eng[0].profile_query("tail_merge_timeouts")[1] == 0
+    for e in eng:
+        e.close()
+
+
 @pytest.mark.parametrize("fold", [0, 1])
 def test_config_c2_50_chunk_drift(fold):
     """SURVEY 8(d) parity gate "after 1 and after 50 chunks": one whole 1000-frame utterance per stream = 50 chained
