@@ -140,7 +140,7 @@ struct klstm_engine {
   int ncu = 0;              // compute units of the device: every workgroup of a persistent launch needs one of its own
   int persist_tail = 1;     // option "persist_tail": d_r / in_diff inside the persistent backward launch (0: batched products after it)
   // option "tail_merge" (default 0: measured slower): the reduction of the tail workgroups' partial rows runs on the first workgroups of the
-  // gradient launch that follows the BPTT launch (k_grads<true>) instead of in a launch of its own.  With KLSTM_BPTT_FUSE_UPDATE that launch
+  // gradient launch that follows the BPTT launch (k_grads_tm) instead of in a launch of its own.  With KLSTM_BPTT_FUSE_UPDATE that launch
   // is klstm_update's: the job waits with the gradient products (tail_pending; whoever flushes them, or synchronises, runs it).
   // tools/ab_step.py, 40/800/512: 4 streams k_tail_reduce 4.3 + k_grads 14.4 = 18.7 us apart, 20.0 us merged (146.0 -> 148.1 us per
   // minibatch); 8 streams 4.4 + 18.2 -> 27.3 (189.9 -> 195.0).  Every gradient tile is resident from the start and latency-bound (operands,

@@ -1009,6 +1009,9 @@ __global__ __launch_bounds__(256, 2) void k_nt_shared_a16(DirectNtArgs a) {
     gsrc[h] = a.A + (size_t)(gon[h] ? row : 0) * a.lda + 4 * pc;
     ldst[h] = u < UNITS ? row * 64 + (((pc >> 1) ^ ((-(row >> 2)) & 3)) * 16) + (pc & 1) * 8 : -1;
   }
+  // (Measured and dropped, round 6: every workgroup starting at another chunk of K and wrapping around -- all workgroups read the same rows
+  //  of A, whose 2 KB stride puts a chunk's row pieces into lines that differ in address bits 11 and up only; the suspicion was one L2
+  //  channel per chunk.  80 x 16624 over 512: 20.3 us with and without; 8 chunks 14.3, 16 chunks 20.3: 0.75 us per chunk + 8 us per launch.)
   auto kpass = [&](int nbk, int m_lo, auto NMC) {
     constexpr int NM = decltype(NMC)::value;
     const int nb = 16 * (nbk < 0 ? 0 : nbk) + i16;

@@ -1561,7 +1561,7 @@ __device__ __forceinline__ void fetch_tile_vec(const float *__restrict__ P, int 
     t.v[h][0] = ldg4(p); t.v[h][1] = ldg4(p + 4);
   }
 }
-// The [K x X] tile of an operand that OTHER workgroups of the same launch have just written with write-through stores (k_grads<true>: the
+// The [K x X] tile of an operand that OTHER workgroups of the same launch have just written with write-through stores (k_grads_tm: the
 // d_r rows from the reduce workgroups): 16-byte sc1 loads -- served from beyond this XCD's L2, which may hold a line of it that another
 // XCD completed later.  Same addresses, same padding rule.
 __device__ __forceinline__ void fetch_tile_vec_coh(const float *__restrict__ P, int ld, int X, int K, int x0, int k0, int tid, RawTile &t) {
@@ -1966,7 +1966,7 @@ struct GradsArgs {
   float *g_bias, *g_pi, *g_pf, *g_po;
   float *p_bias, *p_pi, *p_pf, *p_po;   // parameters to update in the same pass (null: gradient only)
   float lr, clip;
-  // k_grads<true> ("tail_merge"): the first nred workgroups add the tail workgroups' partial d_r / in_diff rows (TailReduceJob), the
+  // k_grads_tm ("tail_merge"): the first nred workgroups add the tail workgroups' partial d_r / in_diff rows (TailReduceJob), the
   // W_r_m tiles wait until tr.ctr[0] has reached tr_target
   TailReduceJob tr; int nred; unsigned tr_target;
 };
@@ -2026,14 +2026,14 @@ __device__ __forceinline__ void grads_column_sums(const GradsArgs &a, int vb, fl
   }
 }
 
-// TM ("tail_merge"): the launch also runs the reduction of the tail workgroups' partial rows that used to be k_tail_reduce behind the BPTT
+// TM (k_grads_tm, "tail_merge"): the launch also runs the reduction of the tail workgroups' partial rows that used to be k_tail_reduce behind the BPTT
 // launch.  Workgroups [0, nred) (dispatched first) add the partial rows -- d_r as write-through stores --, wait for their stores'
 // acknowledgements and arrive at tr.ctr[0]; the W_r_m tiles (the only readers of d_r) sit at the END of every XCD's range, wait for
 // ctr[0] to reach tr_target (a launch ordinal times nred: nothing to reset, a launch that does nothing still arrives) and read d_r with sc1
 // loads; the W_gifo_x / W_gifo_r tiles and the column sums start at once.  The wait is bounded (200 ms; an expiry is counted in ctr[1] and
 // the tile goes on -- the reduce workgroups have the lowest indices, so they are resident or done before any tile that waits for them).
 template <bool TM>
-__global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
+__device__ __forceinline__ void grads_body(const GradsArgs &a) {
   const bool invalid = a.guard && (a.guard[2] | a.guard[6] | a.guard[9]);
   if (a.mark && blockIdx.x == 0 && threadIdx.x == 0) *a.mark = invalid ? 1.f : 0.f;
   int bi = (int)blockIdx.x;
@@ -2092,6 +2092,8 @@ __global__ __launch_bounds__(256) void k_grads(GradsArgs a) {
   }
   grads_column_sums(a, b - a.nb2, As, Bs);
 }
+__global__ __launch_bounds__(256) void k_grads(GradsArgs a) { grads_body<false>(a); }
+__global__ __launch_bounds__(256) void k_grads_tm(GradsArgs a) { grads_body<true>(a); }   // "tail_merge"
 
 // ---------------------------------------------------------------------------------------------
 // bf16 operand mode: the three gradient products on v_mfma_f32_16x16x32_bf16.  128x128 output tiles (the 64x64 fp32
@@ -3583,9 +3585,9 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
   if (tr) {   // the reduction of the tail workgroups' partial rows on the first workgroups of this launch
     if (!(a.wm.vecA && a.wm.vecB) || !tr->ctr || !tr->tws) return hipErrorInvalidValue;   // (16-byte rows: the engine's own buffers)
     a.tr = *tr; a.nred = tail_reduce_blocks(*tr); a.tr_target = tr->seq * (unsigned)a.nred;
-    KLAUNCH(k_grads<true>, dim3(a.nred + 8 * (cdiv(a.nb1, 8) + cdiv(a.nb2 + a.nvec - a.nb1, 8))), dim3(256), st, pr, a);
+    KLAUNCH(k_grads_tm, dim3(a.nred + 8 * (cdiv(a.nb1, 8) + cdiv(a.nb2 + a.nvec - a.nb1, 8))), dim3(256), st, pr, a);
   }
-  KLAUNCH(k_grads<false>, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
+  KLAUNCH(k_grads, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
 }
 
 bool update_repack_vectorised(const Dims &d, const float *param_blob, const float *corr_blob, const float *grad_blob, const float *wrT,

@@ -338,7 +338,7 @@ __device__ __forceinline__ void bwd_tail_role(const PersistBwd2Args &a, float *l
   //  LAST wave adding a 1 / 50 share of the outputs of the step two back (9.6 KB of sc1 loads per step): a coherent load of another XCD's
   //  fresh write-through data takes ~2 us, two passes per step, and the wave sits in the workgroup's per-step barrier: 88.5 us per launch
   //  at 4 streams, 157.6 at 8.  (d) the reduction on the FIRST workgroups of the gradient launch that follows (option "tail_merge",
-  //  k_grads<true>: write-through d_r, arrival counter, the W_r_m tiles wait and read with sc1 loads): 20.0 us against 4.3 + 14.4 at 4
+  //  k_grads_tm: write-through d_r, arrival counter, the W_r_m tiles wait and read with sc1 loads): 20.0 us against 4.3 + 14.4 at 4
   //  streams, 27.3 against 4.4 + 18.2 at 8 -- every gradient tile is resident from the start and latency-bound, the tiles that wait end
   //  one cross-XCD hand-over (~6 us) late.  All four are bit-correct; k_tail_reduce behind the launch stays.)
 }

@@ -274,7 +274,7 @@ def test_tail_workgroups_against_the_in_chain_tail(I, C, R, S, T, want_in_diff):
 @pytest.mark.parametrize("how", ["plain", "fused", "fused_sync", "defer"])
 def test_tail_merge_bit_identical(I, C, R, S, T, want_in_diff, how):
     """Round 6 (option "tail_merge" = 1; default 0, measured slower): the reduction of the tail workgroups' partial d_r / in_diff rows runs on the FIRST
-    workgroups of the gradient launch behind the BPTT launch (k_grads<true>: write-through stores of d_r, an arrival counter, the W_r_m
+    workgroups of the gradient launch behind the BPTT launch (k_grads_tm: write-through stores of d_r, an arrival counter, the W_r_m
     gradient tiles wait and read with sc1 loads) instead of in k_tail_reduce.  Same summation tree per output, so everything -- in_diff,
     d_r, the seven gradient tensors, the updated parameters -- must be BIT-identical to an engine with "tail_merge" = 0, however the
     gradient launch comes about: in klstm_backpropagate (plain), in klstm_update (KLSTM_BPTT_FUSE_UPDATE: in_diff is complete when
