@@ -1,6 +1,6 @@
 """Random shapes through the persistent chain (option persist = 2) against the oracle: the checks of
 tests/test_engine_gpu.py::test_persistent_chain on shapes the parametrised test does not list (geometry switches of the backward
-kernel at C > 896, partial 32-cell slots, ragged fold tiles, wide inputs through the batched x-projection, 1..8 streams, short and
+kernel at C > 896, partial 32-cell slots, ragged fold tiles, wide inputs through the batched x-projection, 1..16 streams, short and
 long T).  Diagnostic: prints one line per shape, exits non-zero on the first failure."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,7 @@ for it in range(n):
     R = int(rng.choice([32, 64, 128, 256, 512]))
     R = min(R, C)
     I = int(rng.choice([40, 8, 64, 128, 512]))
-    S = int(rng.randint(1, 9))
+    S = int(rng.randint(1, 17))                            # (round 6: 9..16 streams as three / four interleaved chains where the shape allows)
     T = int(rng.choice([8, 9, 13, 20, 33]))
     big = C > 96                                         # (the 0.3-scale parameters of the small test shapes saturate wider layers)
     try:
