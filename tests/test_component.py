@@ -228,7 +228,9 @@ def test_component_train_steps_gpu(tmp_path, marker, S, mode, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("marker,S,T,nmb", [("<LstmProjectedStreams>", 4, 20, 5), ("<LstmProjected>", 1, 1000, 2)])
+@pytest.mark.parametrize("marker,S,T,nmb", [("<LstmProjectedStreams>", 4, 20, 5), ("<LstmProjected>", 1, 1000, 2),
+                                             ("<LstmProjectedStreams>", 8, 20, 3),      # configs[2]'s per-GPU shard: interleaved chains + tail workgroups
+                                             ("<LstmProjectedStreams>", 12, 20, 3)])    # round 6: three interleaved chains per launch
 def test_component_at_the_benchmarked_shape_gpu(tmp_path, marker, S, T, nmb):
     """The Kaldi-side component at the shape bench.py measures (BASELINE.json configs[1]: 40 -> 800 / 512, NumStream 4, T = 20;
     and configs[0]: <LstmProjected> over 1000-frame utterances), constructed and driven exactly as the shim of INTEGRATION.md 2
