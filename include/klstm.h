@@ -370,7 +370,8 @@ klstm_status klstm_xent_eval_masked_post(const float *net_out, int rows, int col
  *                  klstm_affine_backpropagate and the BPTT tail -- entries of 1e-7 (late training) keep fp32 accuracy (22 bits
  *                  down to 2^-26, an absolute error below 2^-47 under that; derivatives of 16 and more take the guard's path).
  *                  klstm_affine_propagate of <= 80 rows into > 8192 columns: "direct_nt_shape" 99 = the same layout on the fp32
- *                  MFMA, 0 = the register-direct fp32 kernel, 10*NI + waves = geometry of that kernel;
+ *                  MFMA, 0 = the register-direct fp32 kernel, 10*NI + waves = geometry of that kernel, 97 = the f16 x 2 product with the
+ *                  input rows resident in registers and K cut into four quarters (round 6: measured, not faster at 80 rows);
  *                  klstm_affine_gradient / klstm_affine_update of <= 96 rows and >= 2048 outputs: "outer_f16" 0 = fp32 tiles;
  *                  klstm_affine_backpropagate of <= 80 rows over >= 4096 outputs: "skinny_f16" 0 = fp32 MFMA;
  *                  d_r / in_diff of an engine whose input is too wide for the persistent backward launch: "skinny_f16_pair" 0 =

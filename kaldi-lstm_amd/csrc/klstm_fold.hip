@@ -31,6 +31,8 @@
 #include "klstm_math.h"
 
 #include <hip/hip_ext.h>
+#include <mutex>
+#include <set>
 #include <type_traits>
 
 namespace klstm {
@@ -1129,6 +1131,139 @@ __global__ __launch_bounds__(256, 2) void k_nt_shared_a16(DirectNtArgs a) {
   kpass(slot < xunits ? nb_main + slot / MI : -1, slot < xunits ? slot % MI : 0, std::integral_constant<int, 1>());
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the same f16 x 2 product with the input rows RESIDENT for the whole pass and no workgroup barrier inside it (VERDICT r03-r05:
+// the variant that had never been built).  k_nt_shared_a16 walks K in 16 barrier-bounded chunk steps (0.75 us each, paced by the rows of A
+// requested one step earlier: 20.3 us at 80 x 16624 x 512 whatever the weight stream does).  Here K is cut into four quarters, one per
+// wave: wave w keeps ITS quarter of all MI row blocks of A as fp16 planes in registers (MI x KS x 2 operands of 4 registers: 160 at 80 x
+// 512; one wave per SIMD), loaded and split once, and streams the same quarter of the workgroup's 64 rows of B (4 column blocks x KS
+// k-steps, register ring NB_RING deep, no LDS, no barrier): 15 MFMAs per fetch.  The four waves' partial tiles meet in LDS (80 KB) behind
+// ONE barrier and are added in wave order (deterministic), + bias, 256-byte row pieces out.  Sum over K = quarter by quarter: last-bit
+// differences to k_nt_shared_a16, same parity bars.  Range guard as there (non-finite output -> that output again in plain fp32).
+// MEASURED (tools/t_affprop.py, profiles/r06_affprop_resident.txt) and NOT the default: 80 x 16624 x 512 21.0 us against 19.8 (37 rows: 14.7
+// against 16.5; K = 256: 14.5 / 13.9; 9000 columns, 141 of the 256 CUs busy: 17.4 / 14.8) -- with a ring of 6 fetches 32 us (two rounds of
+// 260 one-per-CU workgroups), with every request of the pass in flight from the first instruction and the blocks dealt 4 / 5 per workgroup
+// 21.0, with 64 contiguous bytes per row and load instruction 20.9.  Barriers, chunk steps and request depth are not what bounds this
+// product: both forms bring the same 288 KB into every CU (its 64 rows of W and ALL of A), and a CU ingests 30-55 GB/s whatever is in
+// flight (docs/DESIGN_rounds_1-4.md 3d).  Option "direct_nt_shape" = 97 runs it.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MI, int KS>
+__global__ __launch_bounds__(256) void k_nt_resident_a16(DirectNtArgs a) {
+  constexpr int NB = 5, NF = NB * KS;                  // column blocks per workgroup (at most), B fetches per wave: ALL in flight from the start
+  extern __shared__ __attribute__((aligned(16))) float part_ra[];   // [4 waves][NB][16 MI rows][16]
+  float *part = part_ra;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int KQ = 32 * KS, k0 = wave * KQ + 4 * kg;     // this wave's quarter of K (K = 4 KQ); of every 32-k step this lane holds k = 4 kg .. + 3 and 16 + 4 kg .. + 3
+                                                      // (the same bijection for A and B: every k once; a load instruction then reads 64 CONTIGUOUS bytes of each of
+                                                      //  its 16 rows -- 16 line requests instead of 32)
+  // the 16-column blocks are dealt evenly: the first `rem` workgroups take one more (16624 columns = 1039 blocks on 256 CUs: 15 x 5 + 241 x 4
+  // -- one round of the chip; a 257th workgroup would run alone behind the others)
+  const int nblk = (a.N + 15) >> 4, G = (int)gridDim.x, q = nblk / G, rem = nblk - q * G, wg = (int)blockIdx.x;
+  const int blk0 = wg * q + (wg < rem ? wg : rem), nbw = q + (wg < rem ? 1 : 0);
+  // ---- B: fetch f = (column block j = f / KS, k-step ks = f % KS): rows 16 (blk0 + j) + i16 of B, 8 consecutive k ----
+  float4 rb[NF][2];
+#pragma unroll
+  for (int f = 0; f < NF; f++) {
+    const int j = f / KS, ks = f % KS, n = 16 * (blk0 + (j < nbw ? j : 0)) + i16;
+    const float *bp = a.B + (size_t)(n < a.N ? n : a.N - 1) * a.ldb + k0 + 32 * ks;
+    rb[f][0] = *reinterpret_cast<const float4 *>(bp); rb[f][1] = *reinterpret_cast<const float4 *>(bp + 16);
+  }
+  __builtin_amdgcn_sched_barrier(0);                   // (every request of the pass is out before anything waits: the scheduler would sink them next to their uses)
+  // ---- A: the wave's quarter of every row block, split once ----
+  nt_f16x8 af[MI][KS][2];
+  {
+    float4 ra[MI][KS][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        const int m = 16 * mi + i16;
+        const float *ap = a.A + (size_t)(m < a.M ? m : a.M - 1) * a.lda + k0 + 32 * ks;
+        ra[mi][ks][0] = *reinterpret_cast<const float4 *>(ap); ra[mi][ks][1] = *reinterpret_cast<const float4 *>(ap + 16);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        const bool on = 16 * mi + i16 < a.M;
+        const float4 v0 = keep4(ra[mi][ks][0], on), v1 = keep4(ra[mi][ks][1], on);
+        uint4 u1, u2;
+        f16_split2_pair(v0.x, v0.y, u1.x, u2.x);
+        f16_split2_pair(v0.z, v0.w, u1.y, u2.y);
+        f16_split2_pair(v1.x, v1.y, u1.z, u2.z);
+        f16_split2_pair(v1.z, v1.w, u1.w, u2.w);
+        af[mi][ks][0] = __builtin_bit_cast(nt_f16x8, u1); af[mi][ks][1] = __builtin_bit_cast(nt_f16x8, u2);
+      }
+  }
+  // ---- the pass: up to NB column blocks x KS k-steps, fully unrolled ----
+  f32x4 acc[MI], accx[MI];
+#pragma unroll
+  for (int f = 0; f < NF; f++) {
+    const int j = f / KS, ks = f % KS;
+    if (j >= nbw) break;                               // (workgroup-uniform; the loads of the absent fifth block went to block 0's rows)
+    if (ks == 0) {
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) { acc[mi] = (f32x4){0, 0, 0, 0}; accx[mi] = (f32x4){0, 0, 0, 0}; }
+    }
+    const float4 b0 = rb[f][0], b1v = rb[f][1];
+    uint4 u1, u2;
+    f16_split2_pair(b0.x, b0.y, u1.x, u2.x);
+    f16_split2_pair(b0.z, b0.w, u1.y, u2.y);
+    f16_split2_pair(b1v.x, b1v.y, u1.z, u2.z);
+    f16_split2_pair(b1v.z, b1v.w, u1.w, u2.w);
+    const nt_f16x8 b1 = __builtin_bit_cast(nt_f16x8, u1), b2 = __builtin_bit_cast(nt_f16x8, u2);
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+      accx[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][ks][0], b2, accx[mi], 0, 0, 0);
+      accx[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][ks][1], b1, accx[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][ks][0], b1, acc[mi], 0, 0, 0);
+    }
+    if (ks == KS - 1) {                                // the wave's partial tile of column block j: rows 16 mi + 4 kg + r, column i16
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) {
+        const f32x4 v = acc[mi] + accx[mi] * (1.f / 2048.f);
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[(((wave * NB + j) * MI + mi) * 16 + 4 * kg + r) * 16 + i16] = v[r];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the four K quarters in wave order, + bias, out: thread = (row, 4 consecutive columns) ----
+  bool redo = false;
+#pragma unroll 1
+  for (int u = tid; u < 16 * MI * 4 * nbw; u += 256) { // units of 4 columns: 4 nbw per row
+    const int m = u / (4 * nbw), cq = u - m * 4 * nbw, j = cq >> 2, c4 = (cq & 3) * 4;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const float4 v = *reinterpret_cast<const float4 *>(&part[(((w * NB + j) * MI + (m >> 4)) * 16 + (m & 15)) * 16 + c4]);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const int n = 16 * (blk0 + j) + c4;
+    if (m >= a.M || n >= a.N) continue;
+    float o[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (n + e >= a.N) continue;
+      const float bias = a.bias ? a.bias[n + e] : 0.f;
+      float v = o[e];
+      if (nonfinite_probe(0.f, v) != 0.f || v != v) {  // range guard: an operand beyond the fp16 range -> this output again in plain fp32
+        v = redo_dot(a.A + (size_t)m * a.lda, 1, a.B + (size_t)(n + e) * a.ldb, 1, a.K);
+        redo = true;
+      }
+      o[e] = v + bias;
+    }
+    float *cp = a.Cm + (size_t)m * a.ldc + n;
+    if (n + 4 <= a.N && (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Cm) & 15) == 0) *reinterpret_cast<float4 *>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+      for (int e = 0; e < 4 && n + e < a.N; e++) cp[e] = o[e];
+  }
+  if (wave_any(redo)) redo_note(a.redo);
+}
+bool nt_resident_supported(int M, int N, int K) { return M >= 1 && M <= 80 && N > 8192 && K % 128 == 0 && K >= 128 && K <= 512; }
+
 // Round 6, measured and dropped: the same f16 x 2 product WITHOUT the shared staging of A (k_direct_nt16: every wave on its own -- its 16 rows
 // of B and all MI row blocks of A straight from memory into a register ring, B 8 chunks ahead, A 2, loads pinned between the MFMA groups,
 // no LDS, no barrier; bit-identical to k_nt_shared_a16).  80 x 16624 over K = 512: 47.8 us against 20.0 (9000 columns: 25.5 against 14.8)
@@ -1138,7 +1273,7 @@ __global__ __launch_bounds__(256, 2) void k_nt_shared_a16(DirectNtArgs a) {
 static int g_nt_shared = 1;
 static int g_nt_ni = 2, g_nt_waves = 1;   //    // measured at 80 x 16624 x 512 (tools/nt_sweep.py): 29.5 us; 1x1 36.7, 2x2 34.0, 4x1 49.4; tiled kernel 37.9
 void set_direct_nt_shape(int ni, int waves) {       // option value 0: wide results on k_direct_nt again (A-B); 99: on the fp32 k_nt_shared_a;
-  g_nt_shared = (ni == 0 && waves == 0) ? 0 : (ni == 9 && waves == 9) ? 2 : (ni == 9 && waves == 8) ? 3 : 1;     // 98 (and every other value): on k_nt_shared_a16
+  g_nt_shared = (ni == 0 && waves == 0) ? 0 : (ni == 9 && waves == 9) ? 2 : (ni == 9 && waves == 8) ? 3 : (ni == 9 && waves == 7) ? 4 : 1;   // 97: k_nt_resident_a16 (A-B)     // 98 (and every other value): on k_nt_shared_a16
   if (g_nt_shared != 1) return;
   g_nt_ni = ni == 1 || ni == 2 ? ni : 4; g_nt_waves = waves >= 1 && waves <= 4 ? waves : 2;
 }
@@ -1174,6 +1309,31 @@ hipError_t launch_direct_nt(int M, int N, int K, const float *A, int lda, const 
   // k_nt_shared_a (fp32 MFMA, one wave per SIMD, the blocks past 1024 as a second pass) 29.1 / 18.9 us, k_nt_shared_a16 (f16 x 2
   // operands split on the fly, two waves per SIMD so that all 260 workgroups are resident at once) 20.6 / 14.5 us: the default.
   // direct_nt_shape = 99 asks for the fp32 form, 0 for k_direct_nt
+  if (g_nt_shared == 4 && f16_ok && nt_resident_supported(M, N, K)) {   // round 6, option value 97 (A-B runs): A resident in registers, K in four quarters (one per wave)
+    const int nblk = (N + 15) / 16, g4 = (nblk + 3) / 4, g5 = (nblk + 4) / 5;
+    const dim3 grid(g4 <= 256 ? g4 : (g5 > 256 ? g5 : 256)), block(256);   // 4 column blocks per workgroup; 5 for some when that keeps the launch in one round
+    const int mi_ = (M + 15) / 16, ks_ = K / 128;
+    const size_t shm = (size_t)4 * 5 * mi_ * 16 * 16 * sizeof(float);
+    // (the dynamic-LDS opt-in is per device and costs the host ~10 us per call: once per (device, instance))
+    static std::mutex ra_mu;
+    static std::set<int> ra_done;
+    int ra_dev = 0;
+    (void)hipGetDevice(&ra_dev);
+#define RA_GO(MI_, KS_) do { if (shm > 64 * 1024) { std::lock_guard<std::mutex> lk(ra_mu); if (ra_done.insert(ra_dev * 64 + MI_ * 8 + KS_).second) \
+                               (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nt_resident_a16<MI_, KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
+                             if (pr.start) hipExtLaunchKernelGGL((k_nt_resident_a16<MI_, KS_>), grid, block, shm, st, pr.start, pr.stop, 0, a); \
+                             else hipLaunchKernelGGL((k_nt_resident_a16<MI_, KS_>), grid, block, shm, st, a); return hipGetLastError(); } while (0)
+#define RA_MI(MI_) do { switch (ks_) { case 1: RA_GO(MI_, 1); case 2: RA_GO(MI_, 2); case 3: RA_GO(MI_, 3); default: RA_GO(MI_, 4); } } while (0)
+    switch (mi_) {
+      case 1: RA_MI(1);
+      case 2: RA_MI(2);
+      case 3: RA_MI(3);
+      case 4: RA_MI(4);
+      default: RA_MI(5);
+    }
+#undef RA_MI
+#undef RA_GO
+  }
   if (N > 8192 && K % 256 == 0 && g_nt_shared) {
     const int nbt = (N + 15) / 16, mi_ = (M + 15) / 16;
     int wgs = (nbt + 3) / 4;

@@ -232,3 +232,35 @@ def test_lstm_layer_with_tiny_and_large_out_diff(_fresh_guard_state, I, od_scale
     else:
         assert _redo(e) == 0
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K,M", [(80, 512, 16624), (37, 512, 16624), (80, 256, 9000), (5, 128, 33000), (80, 384, 8200)])
+def test_affine_propagate_resident_rows_form(N, K, M, _fresh_guard_state):
+    """Round 6, option "direct_nt_shape" = 97: the f16 x 2 propagate with the input rows resident in registers (k_nt_resident_a16: K in four
+    quarters, one per wave, no barrier inside the pass; measured and not the default) against float64 at the bar of the default kernel,
+    including an input beyond the fp16 range (range guard: those outputs again in fp32)."""
+    import kaldi_lstm_amd as k
+    rng = np.random.RandomState(2)
+    x = torch.from_numpy(rng.randn(N, K).astype(np.float32)).cuda()
+    W = torch.from_numpy((0.05 * rng.randn(M, K)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rng.randn(M).astype(np.float32)).cuda()
+    out = torch.empty(N, M, device="cuda")
+    e = k.Engine(40, 64, 32, 4)
+    try:
+        e.set_option("direct_nt_shape", 97)
+        k.affine_propagate(x, W, b, out); torch.cuda.synchronize()
+        ref = (x.double() @ W.double().t() + b.double()).cpu().numpy()
+        err = np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert err <= 2e-5, err
+        assert e.profile_query("fp16_redo_nt")[1] == 0
+        x2 = x.clone(); x2[N // 2, 3] = 1e6                     # beyond fp16: row N // 2 overflows its first plane
+        k.affine_propagate(x2, W, b, out); torch.cuda.synchronize()
+        ref2 = (x2.double() @ W.double().t() + b.double()).cpu().numpy()
+        assert np.isfinite(out.cpu().numpy()).all()
+        assert np.abs(out.cpu().numpy() - ref2).max() / np.abs(ref2).max() <= 2e-5
+        assert e.profile_query("fp16_redo_nt")[1] > 0
+    finally:
+        e.set_option("direct_nt_shape", 21)
+        e.set_option("fp16_products", 1)
+        e.close()
