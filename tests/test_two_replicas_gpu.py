@@ -60,7 +60,7 @@ def _worker(rank, world, port, q):
             dist.all_gather_object(hs, one.export())
             one.connect(rank, world, hs)
         out = torch.empty(T * S, R, device="cuda"); ind = torch.empty(T * S, I, device="cuda")
-        snaps = []
+        snaps, gus = [], []
         for it, (x, od) in enumerate(_minibatches(I, R, 2 * S, T, 60 + ci)):
             xs = shard_time_major(torch.from_numpy(x), 2 * S, rank, world).contiguous().cuda()
             ods = shard_time_major(torch.from_numpy(od), 2 * S, rank, world).contiguous().cuda()
@@ -87,7 +87,8 @@ def _worker(rank, world, port, q):
                 e.update(LR)
             e.synchronize()
             snaps.append(e.get_params())
-        results.append(dict(params=snaps, corr=e.get_corr(), status=(one.status() if one is not None else 0),
+            gus.append(e.profile_query("persist_giveups")[1])          # (this replica's give-ups so far: which minibatch each one belongs to)
+        results.append(dict(params=snaps, corr=e.get_corr(), status=(one.status() if one is not None else 0), gus=gus,
                             giveups=e.profile_query("persist_giveups")[1], left_out=e.profile_query("dp_updates_left_out")[1],
                             dropped=e.profile_query("persist_dropped")[1]))
         dist.barrier()
@@ -136,7 +137,11 @@ def test_two_hip_replicas_stay_bit_identical_and_match_one_engine_with_all_strea
                 unchanged.append(bool(np.array_equal(a["params"][it], prev)))
                 prev = a["params"][it]
             assert sum(unchanged) == a["left_out"], f"{tag}: {a['left_out']} Updates left out, parameters unchanged across {unchanged}"
-            if b["giveups"] == 1:                     # (only the forced one: it was minibatch 1)
+            # ... and they are exactly the minibatches in which replica 1 gave up: the forced one (minibatch 1) -- unless a give-up of its
+            # own in minibatch 0 put minibatch 1 on the launch-per-step chain (cool-down), where the forced stall has nothing to stall
+            gave_up = [b["gus"][it] > (b["gus"][it - 1] if it else 0) for it in range(NMB)]
+            assert unchanged == gave_up, f"{tag}: give-ups of replica 1 in minibatches {gave_up}, parameters unchanged across {unchanged}"
+            if b["giveups"] == 1 and not gave_up[0]:  # (only the forced one: it was minibatch 1)
                 assert unchanged == [False, True, False], f"{tag}: the Update of the failed minibatch was applied ({unchanged})"
         if a["left_out"]:
             continue                                  # (a left-out Update: the one-engine twin below sees every minibatch)
