@@ -2092,7 +2092,10 @@ __device__ __forceinline__ void grads_body(const GradsArgs &a) {
   }
   grads_column_sums(a, b - a.nb2, As, Bs);
 }
-__global__ __launch_bounds__(256) void k_grads(GradsArgs a) { grads_body<false>(a); }
+// Four waves per SIMD (128 registers; two values spill): a 512-input layer has 954 tiles and column-sum blocks -- at three per SIMD 768 are
+// resident and the rest wait a whole tile time (every tile is latency-bound: operands, old corr / parameters, stores).  tools/ab_step.py,
+// bench.py --config c4 (A-B of builds, twice each): 40-input layer 14.4 -> 13.7 us, 512-input layer 21.3 -> 18.3 us, configs[3] 0.4110 -> 0.4077 ms.
+__global__ __launch_bounds__(256, 4) void k_grads(GradsArgs a) { grads_body<false>(a); }
 __global__ __launch_bounds__(256) void k_grads_tm(GradsArgs a) { grads_body<true>(a); }   // "tail_merge"
 
 // ---------------------------------------------------------------------------------------------
