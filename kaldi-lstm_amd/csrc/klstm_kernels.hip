@@ -2417,8 +2417,10 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_nt(GemmJob g) {
   }
 }
 
-template <bool NO32>
-__global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
+// NARROW: 128 x 64 tiles as an instance of their own -- half the accumulators and B staging registers: three waves per SIMD instead of two,
+// so that twice the tiles are still all resident (a tile is a chain of dependent memory round trips: residency is what counts)
+template <bool NO32, bool NARROW = false>
+__global__ __launch_bounds__(256, NARROW ? 3 : 2) void k_grads_bf16(GradsArgs a) {
   const bool invalid = a.guard && (a.guard[2] | a.guard[6] | a.guard[9]);
   if (a.mark && blockIdx.x == 0 && threadIdx.x == 0) *a.mark = invalid ? 1.f : 0.f;
   if (invalid) return;   // a persistent launch of this minibatch gave up: leave momentum and parameters alone
@@ -2431,7 +2433,7 @@ __global__ __launch_bounds__(256) void k_grads_bf16(GradsArgs a) {
   if (b < a.nb2) {
     const GemmJob &g = b < a.nb0 ? a.wx : b < a.nb1 ? a.wr : a.wm;
     const int lb = b < a.nb0 ? b : b < a.nb1 ? b - a.nb0 : b - a.nb1;
-    if (a.bf16_narrow) {
+    if constexpr (NARROW) {
       const int ntn = (g.N + BT / 2 - 1) / (BT / 2);
       gemm_tile_bf16_tn<2, NO32>(g, (lb / ntn) * BT, (lb % ntn) * (BT / 2), As, Bs);
     } else {
@@ -3577,11 +3579,20 @@ hipError_t launch_grads(const Dims &d, const float *dgifo, const float *dr, cons
   if (bf_ok) {                                        // 128x128 tiles on the bf16 pipe
     // 128 x 64 tiles while 128 x 128 ones would not even give every CU a workgroup (measured at 1024/512, 640 frames: 192 tiles
     // (40 inputs) 24.8 -> 21.3 us; 288 tiles (512 inputs) 30 -> 33.5 us: stays wide)
-    a.bf16_narrow = cdiv(4 * C, BT) * (cdiv(I, BT) + cdiv(R, BT)) + cdiv(R, BT) * cdiv(C, BT) < 256 ? 1 : 0;
+    // ... and, round 6, whenever the 128 x 64 tiles are ALL resident at the three waves per SIMD their own kernel instance runs at (768
+    // workgroups): every tile is a chain of dependent memory round trips, so half the epilogue per tile with every tile in flight wins --
+    // 576 tiles at 512 inputs: 41.9 -> 38-39 us per layer, configs[4] 0.659 -> 0.649 ms (A-B of builds, profiles/r06_grads_bf16_narrow_ab.txt;
+    // the measurement above was taken when both widths shared one kernel at two waves per SIMD: 576 tiles in 512 slots)
+    const int narrow_tiles = cdiv(4 * C, BT) * (cdiv(I, BT / 2) + cdiv(R, BT / 2)) + cdiv(R, BT) * cdiv(C, BT / 2);
+    a.bf16_narrow = (cdiv(4 * C, BT) * (cdiv(I, BT) + cdiv(R, BT)) + cdiv(R, BT) * cdiv(C, BT) < 256 || narrow_tiles + a.nvec <= 768) ? 1 : 0;
     const int btn = a.bf16_narrow ? BT / 2 : BT;
     a.nb0 = cdiv(4 * C, BT) * cdiv(I, btn);
     a.nb1 = a.nb0 + cdiv(4 * C, BT) * cdiv(R, btn);
     a.nb2 = a.nb1 + cdiv(R, BT) * cdiv(C, btn);
+    if (a.bf16_narrow) {
+      if (upd && upd->no_wT32) KLAUNCH((k_grads_bf16<true, true>), dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
+      KLAUNCH((k_grads_bf16<false, true>), dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
+    }
     if (upd && upd->no_wT32) KLAUNCH(k_grads_bf16<true>, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
     KLAUNCH(k_grads_bf16<false>, dim3(cdiv(a.nb2 + a.nvec, 8) * 8), dim3(256), st, pr, a);
   }
